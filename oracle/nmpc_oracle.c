@@ -1,0 +1,659 @@
+/*
+ * oracle/nmpc_oracle.c -- TEST INFRASTRUCTURE ONLY (never linked by the product).
+ *
+ * Plain-C FP64 restatement of ONE acados SQP-RTI step of the TUM-CONTROL nominal
+ * NMPC (single-track + Pacejka), i.e. of what `acados_solver.solve()` computes at
+ *   Model_Predictive_Controller/Nominal_NMPC/NMPC_class.py:183
+ * for the OCP defined in
+ *   Model_Predictive_Controller/Nominal_NMPC/NMPC_STM_acados_settings.py:16-245
+ * with the dynamics of
+ *   Prediction_Models/pred_model_dynamic_stm_pacejka.py:118-177.
+ *
+ * The arithmetic itself lives in un-vendored third-party code (acados + BLASFEO +
+ * HPIPM, version unpinned by the reference; casadi==3.5.5 for AD/codegen), so this
+ * file restates the PUBLISHED algorithm of that stack:
+ *   ERK4 x num_steps with forward sensitivities  -> (Phi, A, B)
+ *   NONLINEAR_LS cost + GAUSS_NEWTON Hessian      -> diagonal stage Hessians
+ *   BGH constraints, two-sided soft               -> linearised rows + slack penalties
+ *   FULL_CONDENSING                               -> dense QP in dU (x0 eliminated)
+ *   dense primal-dual interior point (Mehrotra)   -> dU, slacks
+ *   full step (FIXED_STEP, step length 1)
+ * Parity is pinned against the reference's logged acados outputs
+ * (Learning_To_Adapt/SafeRL_WMPC/_baseline/F/...npz, see tests/golden/).
+ *
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this.
+ *
+ * Everything here is deliberately the dumbest dense formulation (no tiles, no
+ * structure exploitation): it is the checker, the HIP solver is the product.
+ */
+#define _GNU_SOURCE
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+#include <stdio.h>
+
+#define NX 8
+#define NU 2
+#define NMAXH 64                 /* max horizon */
+#define NVMAX (NU * NMAXH)       /* condensed variables */
+#define MMAX  (3 * NMAXH)        /* constraint rows: N box + N delta + N h */
+
+/* ------------------------------------------------------------------ model */
+typedef struct {
+    /* Config/EDGAR/veh_params_pred.yaml:3-10, pacejka_params.yaml:3-12 */
+    double lf, lr, m, Iz, ro, S, Cd;
+    double Bf, Cf, Df, Ef, Br, Cr, Dr, Er;
+    double g, fr0, fr1, fr4;          /* pred_model_dynamic_stm_pacejka.py:38-46 */
+    double acc_min;                   /* veh_params: acc_min (negative) */
+    int    n_ggv;                     /* Config/EDGAR/ggv.csv */
+    double ggv_v[16], ggv_ax[16], ggv_ay[16];
+} stm_model;
+
+/* forward-mode dual numbers over the 5 "active" states (vl, vt, r, delta, a) */
+#define ND 5
+typedef struct { double v; double d[ND]; } dual;
+
+static dual dc(double c) { dual r; r.v = c; for (int i = 0; i < ND; i++) r.d[i] = 0.0; return r; }
+static dual dvar(double v, int i) { dual r = dc(v); r.d[i] = 1.0; return r; }
+static dual dadd(dual a, dual b) { dual r; r.v = a.v + b.v; for (int i = 0; i < ND; i++) r.d[i] = a.d[i] + b.d[i]; return r; }
+static dual dsub(dual a, dual b) { dual r; r.v = a.v - b.v; for (int i = 0; i < ND; i++) r.d[i] = a.d[i] - b.d[i]; return r; }
+static dual dmul(dual a, dual b) { dual r; r.v = a.v * b.v; for (int i = 0; i < ND; i++) r.d[i] = a.d[i] * b.v + a.v * b.d[i]; return r; }
+static dual ddiv(dual a, dual b) { dual r; r.v = a.v / b.v; for (int i = 0; i < ND; i++) r.d[i] = (a.d[i] - r.v * b.d[i]) / b.v; return r; }
+static dual dscale(dual a, double s) { dual r; r.v = a.v * s; for (int i = 0; i < ND; i++) r.d[i] = a.d[i] * s; return r; }
+static dual dchain(dual a, double fv, double fp) { dual r; r.v = fv; for (int i = 0; i < ND; i++) r.d[i] = fp * a.d[i]; return r; }
+static dual dsin(dual a) { return dchain(a, sin(a.v), cos(a.v)); }
+static dual dcos(dual a) { return dchain(a, cos(a.v), -sin(a.v)); }
+static dual datan(dual a) { return dchain(a, atan(a.v), 1.0 / (1.0 + a.v * a.v)); }
+static dual dsqrt(dual a) { double s = sqrt(a.v); return dchain(a, s, 0.5 / s); }
+static dual dasin(dual a) { return dchain(a, asin(a.v), 1.0 / sqrt(1.0 - a.v * a.v)); }
+/* fmax(fmin(a, hi), lo) with CasADi's convention: derivative of the taken branch */
+static dual dclip(dual a, double lo, double hi) { if (a.v > hi) return dc(hi); if (a.v < lo) return dc(lo); return a; }
+
+/* xdot = f(x,u) and its Jacobians. Jx is 8x8 row-major, Ju 8x2 row-major.
+ * pred_model_dynamic_stm_pacejka.py:118-177 */
+static void stm_f_jac(const stm_model *p, const double *x, const double *u,
+                      double *xdot, double *Jx, double *Ju)
+{
+    const double psi = x[2];
+    dual vl = dvar(x[3], 0), vt = dvar(x[4], 1), r = dvar(x[5], 2), de = dvar(x[6], 3), a = dvar(x[7], 4);
+
+    /* rolling resistance :118-124 */
+    dual vkmh = dscale(dsqrt(dadd(dmul(vl, vl), dmul(vt, vt))), 3.6);
+    dual w = dscale(vkmh, 0.01);
+    dual w2 = dmul(w, w);
+    dual fr = dadd(dadd(dc(p->fr0), dscale(w, p->fr1)), dscale(dmul(w2, w2), p->fr4));
+    const double Fz_f = p->m * p->lr * p->g / (p->lf + p->lr);
+    const double Fz_r = p->m * p->lf * p->g / (p->lf + p->lr);
+    /* longitudinal forces :133-142 (banking = 0, F_braking = 0) */
+    dual Fx_f = dscale(fr, -Fz_f);
+    dual Fx_r = dsub(dscale(a, p->m), dscale(fr, Fz_r));
+    dual Faero = dscale(dmul(vl, vl), 0.5 * p->ro * p->S * p->Cd);
+    /* slip angles :148-149 */
+    dual al_f, al_r;
+    if (x[3] > 0.001) {
+        al_f = dsub(de, datan(ddiv(dadd(vt, dscale(r, p->lf)), vl)));
+        al_r = datan(ddiv(dsub(dscale(r, p->lr), vt), vl));
+    } else {
+        al_f = dc(0.0); al_r = dc(0.0);
+    }
+    /* Pacejka :154-155 */
+    dual bf = dscale(al_f, p->Bf), br = dscale(al_r, p->Br);
+    dual Fy_f_lat = dscale(dsin(dscale(datan(dsub(bf, dscale(dsub(bf, datan(bf)), p->Ef))), p->Cf)), p->Df);
+    dual Fy_r_lat = dscale(dsin(dscale(datan(dsub(br, dscale(dsub(br, datan(br)), p->Er))), p->Cr)), p->Dr);
+    /* combined slip :158-163 */
+    const double Fmax_f = sqrt(Fz_f * Fz_f + (p->Cf * Fz_f) * (p->Cf * Fz_f));
+    const double Fmax_r = sqrt(Fz_r * Fz_r + (p->Cr * Fz_r) * (p->Cr * Fz_r));
+    dual Gy_f = dclip(dscale(Fx_f, 1.0 / Fmax_f), -0.98, 0.98);
+    dual Gy_r = dclip(dscale(Fx_r, 1.0 / Fmax_r), -0.98, 0.98);
+    dual Fy_f = dmul(Fy_f_lat, dcos(dasin(Gy_f)));
+    dual Fy_r = dmul(Fy_r_lat, dcos(dasin(Gy_r)));
+    /* state derivatives :167-177 */
+    dual sd = dsin(de), cd = dcos(de);
+    dual vld = dadd(dscale(dadd(dsub(dsub(Fx_r, Faero), dmul(Fy_f, sd)), dmul(Fx_f, cd)), 1.0 / p->m), dmul(vt, r));
+    dual front = dadd(dmul(Fy_f, cd), dmul(Fx_f, sd));
+    dual vtd = dsub(dscale(dadd(Fy_r, front), 1.0 / p->m), dmul(vl, r));
+    dual rd = dscale(dsub(dscale(front, p->lf), dscale(Fy_r, p->lr)), 1.0 / p->Iz);
+
+    const double c = cos(psi), s = sin(psi);
+    xdot[0] = x[3] * c - x[4] * s;
+    xdot[1] = x[3] * s + x[4] * c;
+    xdot[2] = x[5];
+    xdot[3] = vld.v; xdot[4] = vtd.v; xdot[5] = rd.v;
+    xdot[6] = u[1];
+    xdot[7] = u[0];
+    if (Jx) {
+        memset(Jx, 0, sizeof(double) * NX * NX);
+        Jx[0 * NX + 2] = -x[3] * s - x[4] * c; Jx[0 * NX + 3] = c; Jx[0 * NX + 4] = -s;
+        Jx[1 * NX + 2] = x[3] * c - x[4] * s;  Jx[1 * NX + 3] = s; Jx[1 * NX + 4] = c;
+        Jx[2 * NX + 5] = 1.0;
+        for (int j = 0; j < ND; j++) {
+            Jx[3 * NX + 3 + j] = vld.d[j];
+            Jx[4 * NX + 3 + j] = vtd.d[j];
+            Jx[5 * NX + 3 + j] = rd.d[j];
+        }
+    }
+    if (Ju) {
+        memset(Ju, 0, sizeof(double) * NX * NU);
+        Ju[6 * NU + 1] = 1.0;   /* delta_f_dot = steering_rate */
+        Ju[7 * NU + 0] = 1.0;   /* a_dot = jerk */
+    }
+}
+
+/* exported for tests: plain f and Jacobians */
+void oracle_stm_f(const stm_model *p, const double *x, const double *u, double *xdot, double *Jx, double *Ju)
+{
+    stm_f_jac(p, x, u, xdot, Jx, Ju);
+}
+
+/* One shooting interval: ERK4, nsub steps of h = dt/nsub, with forward sensitivities
+ * propagated through the same scheme (acados sim_erk with sens_forw; options at
+ * NMPC_STM_acados_settings.py:238-240). A = dPhi/dx (8x8), B = dPhi/du (8x2). */
+void oracle_rk4_sens(const stm_model *p, const double *x0, const double *u, double dt, int nsub,
+                     double *xn, double *A, double *B)
+{
+    double x[NX], S[NX * (NX + NU)];         /* S = [dx/dx0 | dx/du], row-major 8x10 */
+    const int NS = NX + NU;
+    memcpy(x, x0, sizeof(x));
+    memset(S, 0, sizeof(S));
+    for (int i = 0; i < NX; i++) S[i * NS + i] = 1.0;
+    const double h = dt / nsub;
+    const double cc[4] = {0.0, 0.5, 0.5, 1.0};
+    const double bb[4] = {1.0 / 6, 2.0 / 6, 2.0 / 6, 1.0 / 6};
+    for (int step = 0; step < nsub; step++) {
+        double k[4][NX], K[4][NX * (NX + NU)];
+        for (int st = 0; st < 4; st++) {
+            double xs[NX], Ss[NX * (NX + NU)], Jx[NX * NX], Ju[NX * NU];
+            for (int i = 0; i < NX; i++) xs[i] = x[i] + (st ? cc[st] * h * k[st - 1][i] : 0.0);
+            for (int i = 0; i < NX * NS; i++) Ss[i] = S[i] + (st ? cc[st] * h * K[st - 1][i] : 0.0);
+            stm_f_jac(p, xs, u, k[st], Jx, Ju);
+            for (int i = 0; i < NX; i++)
+                for (int j = 0; j < NS; j++) {
+                    double acc = (j >= NX) ? Ju[i * NU + (j - NX)] : 0.0;
+                    for (int l = 0; l < NX; l++) acc += Jx[i * NX + l] * Ss[l * NS + j];
+                    K[st][i * NS + j] = acc;
+                }
+        }
+        for (int i = 0; i < NX; i++)
+            for (int st = 0; st < 4; st++) x[i] += h * bb[st] * k[st][i];
+        for (int i = 0; i < NX * NS; i++)
+            for (int st = 0; st < 4; st++) S[i] += h * bb[st] * K[st][i];
+    }
+    memcpy(xn, x, sizeof(x));
+    for (int i = 0; i < NX; i++) {
+        for (int j = 0; j < NX; j++) A[i * NX + j] = S[i * NS + j];
+        for (int j = 0; j < NU; j++) B[i * NU + j] = S[i * NS + NX + j];
+    }
+}
+
+/* piecewise-linear table (casadi.interpolant 'linear'; NMPC_class.py:322-335),
+ * linear extrapolation from the end segments (flat for the shipped ggv.csv). */
+static void interp_lin(int n, const double *xs, const double *ys, double x, double *y, double *dy)
+{
+    int i = 0;
+    while (i < n - 2 && x >= xs[i + 1]) i++;
+    double sl = (ys[i + 1] - ys[i]) / (xs[i + 1] - xs[i]);
+    *y = ys[i] + sl * (x - xs[i]);
+    *dy = sl;
+}
+
+/* combined_acc_limits == 2 (circle): h = (a/ax)^2 + (vl*r/ay)^2
+ * NMPC_STM_acados_settings.py:70-74,108-119 */
+void oracle_h(const stm_model *p, const double *x, double *h, double *gh)
+{
+    double ax, dax, ay, day;
+    interp_lin(p->n_ggv, p->ggv_v, p->ggv_ax, x[3], &ax, &dax);
+    interp_lin(p->n_ggv, p->ggv_v, p->ggv_ay, x[3], &ay, &day);
+    if (x[7] < 0.0) { ax = -p->acc_min; dax = 0.0; }
+    const double alat = x[3] * x[5];
+    const double nlon = x[7] / ax, nlat = alat / ay;
+    *h = nlon * nlon + nlat * nlat;
+    if (gh) {
+        for (int i = 0; i < NX; i++) gh[i] = 0.0;
+        gh[3] = 2.0 * nlat * (x[5] / ay - alat / (ay * ay) * day) - 2.0 * nlon * x[7] / (ax * ax) * dax;
+        gh[5] = 2.0 * nlat * x[3] / ay;
+        gh[7] = 2.0 * nlon / ax;
+    }
+}
+
+/* yaw wrapped to [0, 2pi): NMPC_STM_acados_settings.py:41-42 */
+static double wrap_yaw(double yaw)
+{
+    double y = fmod(yaw, 2.0 * M_PI);
+    if (y < 0.0) y += 2.0 * M_PI;
+    return y;
+}
+
+/* ------------------------------------------------------------------ dense QP IPM */
+typedef struct {
+    int iter_max;
+    double tol_stat, tol_ineq, tol_comp;
+    double mu0;           /* initial complementarity target */
+    double reg;           /* primal regularisation added to diag(M) */
+} ipm_opts;
+
+typedef struct {
+    int iter; int status; /* 0 ok, 1 max iter, 2 min step, 3 nan */
+    double res_stat, res_ineq, res_comp;
+} ipm_info;
+
+/* Cholesky M = L L^T in place (lower), returns 0 ok */
+static int chol_lower(int n, double *M, int ld)
+{
+    for (int j = 0; j < n; j++) {
+        double d = M[j * ld + j];
+        for (int k = 0; k < j; k++) d -= M[j * ld + k] * M[j * ld + k];
+        if (!(d > 0.0)) return 1;
+        d = sqrt(d);
+        M[j * ld + j] = d;
+        for (int i = j + 1; i < n; i++) {
+            double s = M[i * ld + j];
+            for (int k = 0; k < j; k++) s -= M[i * ld + k] * M[j * ld + k];
+            M[i * ld + j] = s / d;
+        }
+    }
+    return 0;
+}
+static void chol_solve(int n, const double *L, int ld, double *b)
+{
+    for (int i = 0; i < n; i++) {
+        double s = b[i];
+        for (int k = 0; k < i; k++) s -= L[i * ld + k] * b[k];
+        b[i] = s / L[i * ld + i];
+    }
+    for (int i = n - 1; i >= 0; i--) {
+        double s = b[i];
+        for (int k = i + 1; k < n; k++) s -= L[k * ld + i] * b[k];
+        b[i] = s / L[i * ld + i];
+    }
+}
+
+/*
+ * min 1/2 v'Hv + q'v + sum_i [ zl_i sl_i + 1/2 Zl_i sl_i^2 + zu_i su_i + 1/2 Zu_i su_i^2 ]
+ * s.t. l_i - sl_i <= c_i'v + d_i <= u_i + su_i,  sl, su >= 0        (i = 0..m-1)
+ *
+ * Per row and side (eps = +1 lower, -1 upper):
+ *   t = eps*(c'v + d - bound) + s >= 0  (multiplier lam),   s >= 0 (multiplier mu)
+ * Infeasible-start Mehrotra predictor-corrector; the slack/multiplier blocks are
+ * eliminated so that each iteration factorises the nv x nv matrix H + C' Gamma C
+ * (what HPIPM's dense IPM does after removing the soft-constraint slacks).
+ * Side index: 0 = lower, 1 = upper; arrays are [2*m] with side-major layout.
+ */
+static void qp_ipm(int nv, int m, const double *H, const double *q, const double *C, const double *d,
+                   const double *lb, const double *ub,
+                   const double *zl, const double *zu, const double *Zl, const double *Zu,
+                   const ipm_opts *opt, double *v, double *s_out, double *lam_out, ipm_info *info)
+{
+    const int M2 = 2 * m;
+    double *s = calloc(8 * M2 + 8, sizeof(double));
+    double *t = s + M2, *lam = t + M2, *mu = lam + M2;
+    double *ds = mu + M2, *dt = ds + M2, *dlam = dt + M2, *dmu = dlam + M2;
+    double *z = malloc(sizeof(double) * 10 * M2), *Z = z + M2, *bnd = Z + M2, *eps = bnd + M2;
+    double *rs = eps + M2, *rt = rs + M2, *rc1 = rt + M2, *rc2 = rc1 + M2, *gam = rc2 + M2, *rho = gam + M2;
+    double *Mx = malloc(sizeof(double) * nv * nv);
+    double *rv = malloc(sizeof(double) * 4 * nv), *dv = rv + nv, *rhs = dv + nv, *e = malloc(sizeof(double) * 2 * m);
+    double *cdv = e + m;
+
+    for (int i = 0; i < m; i++) {
+        z[i] = zl[i]; Z[i] = Zl[i]; bnd[i] = lb[i]; eps[i] = 1.0;
+        z[m + i] = zu[i]; Z[m + i] = Zu[i]; bnd[m + i] = ub[i]; eps[m + i] = -1.0;
+    }
+    /* --- initial point: v = 0, t consistent with the slack, multipliers mu0 / (.) */
+    for (int j = 0; j < nv; j++) v[j] = 0.0;
+    for (int k = 0; k < M2; k++) {
+        int i = k % m;
+        double r0 = eps[k] * (d[i] - bnd[k]);       /* >= 0 : satisfied at v = 0 */
+        double thr = sqrt(opt->mu0);
+        s[k] = thr;
+        t[k] = r0 + s[k];
+        if (t[k] < thr) { t[k] = thr; }
+        lam[k] = opt->mu0 / t[k];
+        mu[k] = opt->mu0 / s[k];
+    }
+    int it = 0, status = 1;
+    double res_stat = 0, res_ineq = 0, res_comp = 0;
+    double qn = 1.0;
+    for (int j = 0; j < nv; j++) if (fabs(q[j]) > qn) qn = fabs(q[j]);
+    for (it = 0; ; it++) {
+        /* residuals */
+        for (int i = 0; i < m; i++) {
+            double acc = d[i];
+            for (int j = 0; j < nv; j++) acc += C[i * nv + j] * v[j];
+            e[i] = acc;
+        }
+        for (int j = 0; j < nv; j++) {
+            double acc = q[j];
+            for (int l = 0; l < nv; l++) acc += H[j * nv + l] * v[l];
+            for (int i = 0; i < m; i++) acc -= C[i * nv + j] * (lam[i] - lam[m + i]);
+            rv[j] = acc;
+        }
+        res_stat = 0; res_ineq = 0; res_comp = 0;
+        double gap = 0.0;
+        for (int j = 0; j < nv; j++) if (fabs(rv[j]) > res_stat) res_stat = fabs(rv[j]);
+        for (int k = 0; k < M2; k++) {
+            int i = k % m;
+            rs[k] = z[k] + Z[k] * s[k] - lam[k] - mu[k];
+            rt[k] = t[k] - eps[k] * (e[i] - bnd[k]) - s[k];
+            if (fabs(rs[k]) > res_stat) res_stat = fabs(rs[k]);
+            if (fabs(rt[k]) > res_ineq) res_ineq = fabs(rt[k]);
+            gap += t[k] * lam[k] + s[k] * mu[k];
+            if (t[k] * lam[k] > res_comp) res_comp = t[k] * lam[k];
+            if (s[k] * mu[k] > res_comp) res_comp = s[k] * mu[k];
+        }
+        gap /= (2.0 * M2);
+        if (!(res_stat == res_stat) || !(gap == gap)) { status = 3; break; }
+        if (res_stat <= opt->tol_stat * qn && res_ineq <= opt->tol_ineq && res_comp <= opt->tol_comp) { status = 0; break; }
+        if (it >= opt->iter_max) { status = 1; break; }
+
+        /* --- factorise M = H + sum gamma c c' */
+        for (int k = 0; k < M2; k++) {
+            double Ds = Z[k] + mu[k] / s[k];
+            gam[k] = 1.0 / (t[k] / lam[k] + 1.0 / Ds);
+        }
+        memcpy(Mx, H, sizeof(double) * nv * nv);
+        for (int j = 0; j < nv; j++) Mx[j * nv + j] += opt->reg;
+        for (int i = 0; i < m; i++) {
+            double g = gam[i] + gam[m + i];
+            const double *ci = C + i * nv;
+            for (int j = 0; j < nv; j++) {
+                if (ci[j] == 0.0) continue;
+                double gc = g * ci[j];
+                for (int l = 0; l <= j; l++) Mx[j * nv + l] += gc * ci[l];
+            }
+        }
+        if (chol_lower(nv, Mx, nv)) { status = 3; break; }
+
+        double sigma = 0.0, mu_aff = 0.0, alpha = 1.0;
+        for (int pass = 0; pass < 2; pass++) {
+            /* complementarity residuals: predictor (tau = 0) then corrector */
+            for (int k = 0; k < M2; k++) {
+                if (pass == 0) { rc1[k] = t[k] * lam[k]; rc2[k] = s[k] * mu[k]; }
+                else {
+                    rc1[k] = t[k] * lam[k] + dt[k] * dlam[k] - sigma * gap;
+                    rc2[k] = s[k] * mu[k] + ds[k] * dmu[k] - sigma * gap;
+                }
+                double Ds = Z[k] + mu[k] / s[k];
+                rho[k] = -rt[k] + rc1[k] / lam[k] - (rs[k] + rc2[k] / s[k]) / Ds;
+            }
+            for (int j = 0; j < nv; j++) rhs[j] = -rv[j];
+            for (int i = 0; i < m; i++) {
+                double w = gam[i] * rho[i] - gam[m + i] * rho[m + i];
+                const double *ci = C + i * nv;
+                for (int j = 0; j < nv; j++) rhs[j] -= ci[j] * w;
+            }
+            memcpy(dv, rhs, sizeof(double) * nv);
+            chol_solve(nv, Mx, nv, dv);
+            for (int i = 0; i < m; i++) {
+                double acc = 0.0;
+                for (int j = 0; j < nv; j++) acc += C[i * nv + j] * dv[j];
+                cdv[i] = acc;
+            }
+            double amax = 1.0;
+            for (int k = 0; k < M2; k++) {
+                int i = k % m;
+                double Ds = Z[k] + mu[k] / s[k];
+                dlam[k] = -gam[k] * (eps[k] * cdv[i] + rho[k]);
+                ds[k] = (dlam[k] - rs[k] - rc2[k] / s[k]) / Ds;
+                dmu[k] = (-rc2[k] - mu[k] * ds[k]) / s[k];
+                dt[k] = (-rc1[k] - t[k] * dlam[k]) / lam[k];
+                if (dt[k] < 0.0 && -t[k] / dt[k] < amax) amax = -t[k] / dt[k];
+                if (ds[k] < 0.0 && -s[k] / ds[k] < amax) amax = -s[k] / ds[k];
+                if (dlam[k] < 0.0 && -lam[k] / dlam[k] < amax) amax = -lam[k] / dlam[k];
+                if (dmu[k] < 0.0 && -mu[k] / dmu[k] < amax) amax = -mu[k] / dmu[k];
+            }
+            if (pass == 0) {
+                mu_aff = 0.0;
+                for (int k = 0; k < M2; k++)
+                    mu_aff += (t[k] + amax * dt[k]) * (lam[k] + amax * dlam[k]) + (s[k] + amax * ds[k]) * (mu[k] + amax * dmu[k]);
+                mu_aff /= (2.0 * M2);
+                double ratio = mu_aff / gap;
+                sigma = ratio * ratio * ratio;
+            } else {
+                alpha = 0.995 * amax; if (amax >= 1.0) alpha = 1.0; if (alpha > 1.0) alpha = 1.0;
+            }
+        }
+        if (alpha < 1e-12) { status = 2; break; }
+        for (int j = 0; j < nv; j++) v[j] += alpha * dv[j];
+        for (int k = 0; k < M2; k++) {
+            t[k] += alpha * dt[k]; s[k] += alpha * ds[k];
+            lam[k] += alpha * dlam[k]; mu[k] += alpha * dmu[k];
+        }
+    }
+    if (s_out) memcpy(s_out, s, sizeof(double) * M2);
+    if (lam_out) memcpy(lam_out, lam, sizeof(double) * M2);
+    info->iter = it; info->status = status;
+    info->res_stat = res_stat; info->res_ineq = res_ineq; info->res_comp = res_comp;
+    free(s); free(z); free(Mx); free(rv); free(e);
+}
+
+/* ------------------------------------------------------------------ the OCP */
+typedef struct {
+    int N, nsub;
+    double dt;
+    stm_model model;
+    ipm_opts ipm;
+    /* iterate */
+    double X[(NMAXH + 1) * NX], U[NMAXH * NU];
+    /* problem data */
+    double x0[NX];                       /* lbx_0 = ubx_0 */
+    double yref[(NMAXH + 1) * 6];        /* stage N uses the first 4 */
+    double W[(NMAXH + 1) * 6];           /* diagonal of W per stage (stage N: first 4) */
+    double lbu[NMAXH], ubu[NMAXH];       /* steering-rate box, stages 0..N-1 */
+    double lbx[NMAXH + 1], ubx[NMAXH + 1]; /* delta box, stages 1..N */
+    double lh[NMAXH + 1], uh[NMAXH + 1];   /* stages 1..N */
+    /* slack penalties, canonical slot order (bu, bx, h) per stage */
+    double zl[(NMAXH + 1) * 3], zu[(NMAXH + 1) * 3], Zl[(NMAXH + 1) * 3], Zu[(NMAXH + 1) * 3];
+    /* outputs of the last solve */
+    double A[NMAXH * NX * NX], B[NMAXH * NX * NU], b[NMAXH * NX];
+    double sl[MMAX], su[MMAX];           /* slack values of the last QP, row order below */
+    double lam[2 * MMAX];
+    double cost;
+    int qp_iter, status;
+    double res[3];
+} oracle_ocp;
+
+oracle_ocp *oracle_create(int N, double dt, int nsub)
+{
+    if (N < 1 || N > NMAXH) return NULL;
+    oracle_ocp *o = calloc(1, sizeof(oracle_ocp));
+    o->N = N; o->dt = dt; o->nsub = nsub;
+    o->ipm.iter_max = 50; o->ipm.tol_stat = 1e-8; o->ipm.tol_ineq = 1e-8; o->ipm.tol_comp = 1e-8;
+    o->ipm.mu0 = 1.0; o->ipm.reg = 0.0;
+    return o;
+}
+void oracle_free(oracle_ocp *o) { free(o); }
+size_t oracle_sizeof(void) { return sizeof(oracle_ocp); }
+
+/* field access by name for the ctypes wrapper (pointer into the struct + length) */
+double *oracle_field(oracle_ocp *o, const char *name, int *len)
+{
+    const int N = o->N;
+#define F(nm, ptr, n) if (!strcmp(name, nm)) { *len = (n); return (ptr); }
+    F("X", o->X, (N + 1) * NX) F("U", o->U, N * NU) F("x0", o->x0, NX)
+    F("yref", o->yref, (N + 1) * 6) F("W", o->W, (N + 1) * 6)
+    F("lbu", o->lbu, N) F("ubu", o->ubu, N)
+    F("lbx", o->lbx, N + 1) F("ubx", o->ubx, N + 1) F("lh", o->lh, N + 1) F("uh", o->uh, N + 1)
+    F("zl", o->zl, (N + 1) * 3) F("zu", o->zu, (N + 1) * 3) F("Zl", o->Zl, (N + 1) * 3) F("Zu", o->Zu, (N + 1) * 3)
+    F("A", o->A, N * NX * NX) F("B", o->B, N * NX * NU) F("b", o->b, N * NX)
+    F("sl", o->sl, 3 * N) F("su", o->su, 3 * N) F("lam", o->lam, 6 * N)
+    F("cost", &o->cost, 1) F("res", o->res, 3)
+    F("ipm_tol", &o->ipm.tol_stat, 3) F("ipm_mu0", &o->ipm.mu0, 1) F("ipm_reg", &o->ipm.reg, 1)
+#undef F
+    *len = 0; return NULL;
+}
+void oracle_set_model(oracle_ocp *o, const stm_model *m) { o->model = *m; }
+void oracle_set_iter_max(oracle_ocp *o, int it) { o->ipm.iter_max = it; }
+int oracle_qp_iter(const oracle_ocp *o) { return o->qp_iter; }
+int oracle_status(const oracle_ocp *o) { return o->status; }
+
+/* total cost at the current iterate with the given slack values
+ * (acados ocp_nlp_eval_cost: stage terms scaled by dt, terminal unscaled) */
+static double eval_cost(const oracle_ocp *o)
+{
+    const int N = o->N;
+    double c = 0.0;
+    for (int k = 0; k <= N; k++) {
+        const double sc = (k < N) ? o->dt : 1.0;
+        const double *x = o->X + k * NX, *yr = o->yref + k * 6, *W = o->W + k * 6;
+        double y[6] = {x[0], x[1], wrap_yaw(x[2]), x[3], 0, 0};
+        int ny = 4;
+        if (k < N) { y[4] = o->U[k * NU]; y[5] = o->U[k * NU + 1]; ny = 6; }
+        double acc = 0.0;
+        for (int i = 0; i < ny; i++) { double r = y[i] - yr[i]; acc += 0.5 * W[i] * r * r; }
+        c += sc * acc;
+    }
+    /* slack terms: rows [bu_0..bu_{N-1} | (bx_k, h_k) k=1..N] */
+    for (int i = 0; i < 3 * N; i++) {
+        int k, slot;
+        if (i < N) { k = i; slot = 0; } else { k = 1 + (i - N) / 2; slot = 1 + (i - N) % 2; }
+        const double sc = (k < N) ? o->dt : 1.0;
+        c += sc * (o->zl[k * 3 + slot] * o->sl[i] + 0.5 * o->Zl[k * 3 + slot] * o->sl[i] * o->sl[i]);
+        c += sc * (o->zu[k * 3 + slot] * o->su[i] + 0.5 * o->Zu[k * 3 + slot] * o->su[i] * o->su[i]);
+    }
+    return c;
+}
+
+/* One SQP real-time iteration. Returns acados-like status. */
+int oracle_solve(oracle_ocp *o)
+{
+    const int N = o->N, nv = NU * N, m = 3 * N;
+    const double dt = o->dt;
+    double *G = calloc((size_t)(N + 1) * NX * nv, sizeof(double));   /* G_k: 8 x nv each */
+    double *g = calloc((size_t)(N + 1) * NX, sizeof(double));
+    double *H = calloc((size_t)nv * nv, sizeof(double)), *q = calloc(nv, sizeof(double));
+    double *C = calloc((size_t)m * nv, sizeof(double)), *d = calloc(m, sizeof(double));
+    double *lb = calloc(6 * m, sizeof(double)), *ub = lb + m, *zl = ub + m, *zu = zl + m, *Zl = zu + m, *Zu = Zl + m;
+    double *v = calloc(nv, sizeof(double));
+
+    /* 1. linearise dynamics */
+    for (int k = 0; k < N; k++) {
+        double xn[NX];
+        oracle_rk4_sens(&o->model, o->X + k * NX, o->U + k * NU, dt, o->nsub, xn, o->A + k * 64, o->B + k * 16);
+        for (int i = 0; i < NX; i++) o->b[k * NX + i] = xn[i] - o->X[(k + 1) * NX + i];
+    }
+    /* 4./5. initial-value embedding and condensing: dx_k = G_k v + g_k */
+    for (int i = 0; i < NX; i++) g[i] = o->x0[i] - o->X[i];
+    for (int k = 0; k < N; k++) {
+        const double *A = o->A + k * 64, *B = o->B + k * 16;
+        double *Gn = G + (size_t)(k + 1) * NX * nv, *Gk = G + (size_t)k * NX * nv;
+        for (int i = 0; i < NX; i++) {
+            for (int j = 0; j < NU * k; j++) {
+                double acc = 0.0;
+                for (int l = 0; l < NX; l++) acc += A[i * NX + l] * Gk[l * nv + j];
+                Gn[i * nv + j] = acc;
+            }
+            for (int j = 0; j < NU; j++) Gn[i * nv + NU * k + j] = B[i * NU + j];
+            double acc = o->b[k * NX + i];
+            for (int l = 0; l < NX; l++) acc += A[i * NX + l] * g[k * NX + l];
+            g[(k + 1) * NX + i] = acc;
+        }
+    }
+    /* 2. Gauss-Newton cost: y = [x0,x1,wrap(x2),x3,u0,u1], J = selection */
+    for (int k = 0; k <= N; k++) {
+        const double sc = (k < N) ? dt : 1.0;
+        const double *x = o->X + k * NX, *yr = o->yref + k * 6, *W = o->W + k * 6;
+        const double *Gk = G + (size_t)k * NX * nv;
+        double y[4] = {x[0], x[1], wrap_yaw(x[2]), x[3]};
+        for (int r = 0; r < 4; r++) {
+            const double w = sc * W[r];
+            const double res = y[r] - yr[r] + g[k * NX + r];     /* residual incl. the constant part of dx */
+            const double *Gr = Gk + r * nv;
+            for (int j = 0; j < NU * k; j++) {
+                if (Gr[j] == 0.0) continue;
+                q[j] += w * res * Gr[j];
+                for (int l = 0; l <= j; l++) H[j * nv + l] += w * Gr[j] * Gr[l];
+            }
+        }
+        if (k < N)
+            for (int r = 0; r < NU; r++) {
+                const double w = sc * W[4 + r];
+                H[(NU * k + r) * nv + NU * k + r] += w;
+                q[NU * k + r] += w * (o->U[k * NU + r] - yr[4 + r]);
+            }
+    }
+    for (int j = 0; j < nv; j++) for (int l = 0; l < j; l++) H[l * nv + j] = H[j * nv + l];
+    /* 3. constraints. Row order: [bu_k k=0..N-1 | (bx_k, h_k) k=1..N] */
+    for (int k = 0; k < N; k++) {
+        const double sc = dt;
+        C[k * nv + NU * k + 1] = 1.0;
+        d[k] = o->U[k * NU + 1];
+        lb[k] = o->lbu[k]; ub[k] = o->ubu[k];
+        zl[k] = sc * o->zl[k * 3]; zu[k] = sc * o->zu[k * 3]; Zl[k] = sc * o->Zl[k * 3]; Zu[k] = sc * o->Zu[k * 3];
+    }
+    for (int k = 1; k <= N; k++) {
+        const double sc = (k < N) ? dt : 1.0;
+        const double *x = o->X + k * NX;
+        const double *Gk = G + (size_t)k * NX * nv;
+        int ib = N + 2 * (k - 1), ih = ib + 1;
+        for (int j = 0; j < NU * k; j++) C[ib * nv + j] = Gk[6 * nv + j];
+        d[ib] = x[6] + g[k * NX + 6];
+        lb[ib] = o->lbx[k]; ub[ib] = o->ubx[k];
+        double h, gh[NX];
+        oracle_h(&o->model, x, &h, gh);
+        double acc = h;
+        for (int l = 0; l < NX; l++) acc += gh[l] * g[k * NX + l];
+        d[ih] = acc;
+        for (int j = 0; j < NU * k; j++) {
+            double a2 = 0.0;
+            for (int l = 0; l < NX; l++) a2 += gh[l] * Gk[l * nv + j];
+            C[ih * nv + j] = a2;
+        }
+        lb[ih] = o->lh[k]; ub[ih] = o->uh[k];
+        for (int s = 1; s <= 2; s++) {
+            int i = (s == 1) ? ib : ih;
+            zl[i] = sc * o->zl[k * 3 + s]; zu[i] = sc * o->zu[k * 3 + s];
+            Zl[i] = sc * o->Zl[k * 3 + s]; Zu[i] = sc * o->Zu[k * 3 + s];
+        }
+    }
+    /* 6. QP */
+    double *sall = calloc(2 * m, sizeof(double));
+    ipm_info info;
+    qp_ipm(nv, m, H, q, C, d, lb, ub, zl, zu, Zl, Zu, &o->ipm, v, sall, o->lam, &info);
+    memcpy(o->sl, sall, sizeof(double) * m);
+    memcpy(o->su, sall + m, sizeof(double) * m);
+    o->qp_iter = info.iter;
+    o->res[0] = info.res_stat; o->res[1] = info.res_ineq; o->res[2] = info.res_comp;
+    /* acados: QP max-iter is not a failure; NaN / min-step -> 4 */
+    o->status = (info.status == 0 || info.status == 1) ? 0 : 4;
+    /* 7. full step */
+    if (o->status == 0) {
+        for (int k = 0; k <= N; k++) {
+            const double *Gk = G + (size_t)k * NX * nv;
+            for (int i = 0; i < NX; i++) {
+                double acc = g[k * NX + i];
+                for (int j = 0; j < NU * k; j++) acc += Gk[i * nv + j] * v[j];
+                o->X[k * NX + i] += acc;
+            }
+        }
+        for (int j = 0; j < nv; j++) o->U[j] += v[j];
+    }
+    o->cost = eval_cost(o);
+    free(G); free(g); free(H); free(q); free(C); free(d); free(lb); free(v); free(sall);
+    return o->status;
+}
+
+/* batch helper for the cpu_baseline leg: solve `nb` independent OCPs that share the
+ * model / weights / bounds of `tmpl`, each from a cold start (X_k = x0, U = 0).
+ * x0: nb x 8, yref: nb x (N+1) x 6. Outputs u0 (nb x 2), X1 (nb x 8), stats (nb x 3: cost, qp_iter, status).
+ * OpenMP over instances when compiled with -fopenmp. */
+void oracle_solve_batch_cold(const oracle_ocp *tmpl, int nb, const double *x0, const double *yref,
+                             double *u0, double *X1, double *stats, int nthreads)
+{
+    (void)nthreads;
+#ifdef _OPENMP
+#pragma omp parallel for schedule(dynamic, 4) num_threads(nthreads)
+#endif
+    for (int b = 0; b < nb; b++) {
+        oracle_ocp *o = malloc(sizeof(oracle_ocp));
+        memcpy(o, tmpl, sizeof(oracle_ocp));
+        const int N = o->N;
+        memcpy(o->x0, x0 + (size_t)b * NX, sizeof(double) * NX);
+        memcpy(o->yref, yref + (size_t)b * (N + 1) * 6, sizeof(double) * (N + 1) * 6);
+        for (int k = 0; k <= N; k++) memcpy(o->X + k * NX, o->x0, sizeof(double) * NX);
+        memset(o->U, 0, sizeof(double) * N * NU);
+        oracle_solve(o);
+        u0[b * 2] = o->U[0]; u0[b * 2 + 1] = o->U[1];
+        memcpy(X1 + (size_t)b * NX, o->X + NX, sizeof(double) * NX);
+        stats[b * 3] = o->cost; stats[b * 3 + 1] = o->qp_iter; stats[b * 3 + 2] = o->status;
+        free(o);
+    }
+}

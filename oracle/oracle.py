@@ -1,0 +1,231 @@
+"""
+oracle/oracle.py -- ctypes wrapper around oracle/liboracle.so.
+
+TEST INFRASTRUCTURE ONLY. Only tests/, __graft_entry__.smoke() and bench.py's
+``cpu_baseline`` leg may import this module; the product (tum-control_amd/) never does.
+
+The C file restates the acados SQP-RTI step the reference calls at
+Model_Predictive_Controller/Nominal_NMPC/NMPC_class.py:183; see its header for the
+full list of reference lines followed. Parity pin: tests/test_oracle_golden.py checks it
+against the reference's logged acados outputs committed under tests/golden/.
+"""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "liboracle.so")
+
+
+class StmModel(ctypes.Structure):
+    _fields_ = (
+        [(n, ctypes.c_double) for n in
+         ("lf", "lr", "m", "Iz", "ro", "S", "Cd",
+          "Bf", "Cf", "Df", "Ef", "Br", "Cr", "Dr", "Er",
+          "g", "fr0", "fr1", "fr4", "acc_min")]
+        + [("n_ggv", ctypes.c_int),
+           ("ggv_v", ctypes.c_double * 16), ("ggv_ax", ctypes.c_double * 16), ("ggv_ay", ctypes.c_double * 16)]
+    )
+
+
+# EDGAR constants, restated from the reference's config data:
+#   Config/EDGAR/veh_params_pred.yaml:3-10,16-25, Config/EDGAR/pacejka_params.yaml:3-12,
+#   Config/EDGAR/ggv.csv, Prediction_Models/pred_model_dynamic_stm_pacejka.py:38-46
+EDGAR = dict(
+    lf=1.484, lr=1.644, m=2520.0, Iz=13600.0, ro=1.225, S=2.9, Cd=0.35,
+    Bf=10.0, Cf=1.3, Df=15591.427, Ef=0.97, Br=10.0, Cr=1.6, Dr=24629.523, Er=0.97,
+    g=9.81, fr0=0.009, fr1=0.002, fr4=0.0003, acc_min=-3.5,
+    ggv_v=[0, 4, 8, 11.11, 12, 20, 24, 28, 32, 37.5],
+    ggv_ax=[3, 3, 3, 3, 2.5, 2.5, 2.5, 2.5, 2.5, 2.5],
+    ggv_ay=[5.886] * 10,
+    delta_f_min=-0.610865, delta_f_max=0.610865,
+    delta_f_dot_min=-0.322, delta_f_dot_max=0.322,
+)
+
+
+def edgar_model():
+    m = StmModel()
+    for k in ("lf", "lr", "m", "Iz", "ro", "S", "Cd", "Bf", "Cf", "Df", "Ef", "Br", "Cr", "Dr", "Er",
+              "g", "fr0", "fr1", "fr4", "acc_min"):
+        setattr(m, k, EDGAR[k])
+    n = len(EDGAR["ggv_v"])
+    m.n_ggv = n
+    for i in range(n):
+        m.ggv_v[i] = EDGAR["ggv_v"][i]
+        m.ggv_ax[i] = EDGAR["ggv_ax"][i]
+        m.ggv_ay[i] = EDGAR["ggv_ay"][i]
+    return m
+
+
+def build(force=False):
+    """Compile liboracle.so with gcc (oracle/Makefile)."""
+    if force or not os.path.exists(_LIB_PATH) or \
+            os.path.getmtime(_LIB_PATH) < os.path.getmtime(os.path.join(_HERE, "nmpc_oracle.c")):
+        subprocess.check_call(["make", "-C", _HERE, "-B", "liboracle.so"], stdout=subprocess.DEVNULL)
+    return _LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_LIB_PATH):
+            build()
+        L = ctypes.CDLL(_LIB_PATH)
+        dp = ctypes.POINTER(ctypes.c_double)
+        L.oracle_create.restype = ctypes.c_void_p
+        L.oracle_create.argtypes = [ctypes.c_int, ctypes.c_double, ctypes.c_int]
+        L.oracle_free.argtypes = [ctypes.c_void_p]
+        L.oracle_field.restype = dp
+        L.oracle_field.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.POINTER(ctypes.c_int)]
+        L.oracle_set_model.argtypes = [ctypes.c_void_p, ctypes.POINTER(StmModel)]
+        L.oracle_set_iter_max.argtypes = [ctypes.c_void_p, ctypes.c_int]
+        L.oracle_solve.argtypes = [ctypes.c_void_p]
+        L.oracle_solve.restype = ctypes.c_int
+        L.oracle_qp_iter.argtypes = [ctypes.c_void_p]
+        L.oracle_status.argtypes = [ctypes.c_void_p]
+        L.oracle_stm_f.argtypes = [ctypes.POINTER(StmModel), dp, dp, dp, dp, dp]
+        L.oracle_rk4_sens.argtypes = [ctypes.POINTER(StmModel), dp, dp, ctypes.c_double, ctypes.c_int, dp, dp, dp]
+        L.oracle_h.argtypes = [ctypes.POINTER(StmModel), dp, dp, dp]
+        L.oracle_solve_batch_cold.argtypes = [ctypes.c_void_p, ctypes.c_int, dp, dp, dp, dp, dp, ctypes.c_int]
+        _lib = L
+    return _lib
+
+
+def _dp(a):
+    return a.ctypes.data_as(ctypes.POINTER(ctypes.c_double))
+
+
+def stm_f(x, u, model=None):
+    """xdot, Jx (8x8), Ju (8x2) of the single-track model."""
+    model = model or edgar_model()
+    x = np.ascontiguousarray(x, dtype=np.float64)
+    u = np.ascontiguousarray(u, dtype=np.float64)
+    xd = np.zeros(8); Jx = np.zeros((8, 8)); Ju = np.zeros((8, 2))
+    lib().oracle_stm_f(ctypes.byref(model), _dp(x), _dp(u), _dp(xd), _dp(Jx), _dp(Ju))
+    return xd, Jx, Ju
+
+
+def rk4_sens(x, u, dt, nsub, model=None):
+    model = model or edgar_model()
+    x = np.ascontiguousarray(x, dtype=np.float64)
+    u = np.ascontiguousarray(u, dtype=np.float64)
+    xn = np.zeros(8); A = np.zeros((8, 8)); B = np.zeros((8, 2))
+    lib().oracle_rk4_sens(ctypes.byref(model), _dp(x), _dp(u), float(dt), int(nsub), _dp(xn), _dp(A), _dp(B))
+    return xn, A, B
+
+
+def h_con(x, model=None):
+    model = model or edgar_model()
+    x = np.ascontiguousarray(x, dtype=np.float64)
+    h = np.zeros(1); gh = np.zeros(8)
+    lib().oracle_h(ctypes.byref(model), _dp(x), _dp(h), _dp(gh))
+    return float(h[0]), gh
+
+
+class OracleOcp:
+    """One nominal-NMPC OCP instance (N stages), CPU FP64.
+
+    Array attributes are numpy views straight into the C struct:
+      X (N+1,8)  U (N,2)  x0 (8)  yref (N+1,6)  W (N+1,6: diagonal of W per stage)
+      lbu/ubu (N)  lbx/ubx (N+1)  lh/uh (N+1)  zl/zu/Zl/Zu (N+1,3: slots bu,bx,h)
+    """
+
+    def __init__(self, N=38, dt=0.08, nsub=3, model=None):
+        L = lib()
+        self._h = L.oracle_create(int(N), float(dt), int(nsub))
+        if not self._h:
+            raise ValueError("bad horizon")
+        self.N, self.dt, self.nsub = N, dt, nsub
+        self._model = model or edgar_model()
+        L.oracle_set_model(self._h, ctypes.byref(self._model))
+        self.X = self._view("X").reshape(N + 1, 8)
+        self.U = self._view("U").reshape(N, 2)
+        self.x0 = self._view("x0")
+        self.yref = self._view("yref").reshape(N + 1, 6)
+        self.W = self._view("W").reshape(N + 1, 6)
+        self.lbu, self.ubu = self._view("lbu"), self._view("ubu")
+        self.lbx, self.ubx = self._view("lbx"), self._view("ubx")
+        self.lh, self.uh = self._view("lh"), self._view("uh")
+        self.zl, self.zu = self._view("zl").reshape(N + 1, 3), self._view("zu").reshape(N + 1, 3)
+        self.Zl, self.Zu = self._view("Zl").reshape(N + 1, 3), self._view("Zu").reshape(N + 1, 3)
+        self.A = self._view("A").reshape(N, 8, 8)
+        self.B = self._view("B").reshape(N, 8, 2)
+        self.b = self._view("b").reshape(N, 8)
+        self.sl, self.su = self._view("sl"), self._view("su")
+        self.ipm_tol = self._view("ipm_tol")
+        self.ipm_mu0 = self._view("ipm_mu0")
+        self.ipm_reg = self._view("ipm_reg")
+        self.res = self._view("res")
+        # bounds of the shipped OCP (NMPC_STM_acados_settings.py:108-139)
+        self.lbu[:] = EDGAR["delta_f_dot_min"]; self.ubu[:] = EDGAR["delta_f_dot_max"]
+        self.lbx[:] = EDGAR["delta_f_min"]; self.ubx[:] = EDGAR["delta_f_max"]
+        self.lh[:] = 0.0; self.uh[:] = 1.0
+
+    def _view(self, name):
+        n = ctypes.c_int(0)
+        p = lib().oracle_field(self._h, name.encode(), ctypes.byref(n))
+        if not p:
+            raise KeyError(name)
+        return np.ctypeslib.as_array(p, shape=(n.value,))
+
+    def __del__(self):
+        try:
+            if self._h:
+                lib().oracle_free(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+    def set_weights(self, q_xy, q_yaw, q_vel, r_jerk, r_steer, L1, L2, scale=1.0):
+        """update_cost_function_weights (NMPC_class.py:269-317): W = blockdiag(Q,R) raw."""
+        self.W[:] = scale * np.array([q_xy, q_xy, q_yaw, q_vel, r_jerk, r_steer])
+        for a in (self.zl, self.zu):
+            a[:] = L1
+        for a in (self.Zl, self.Zu):
+            a[:] = L2
+
+    def cold_start(self, x0):
+        """acados create / reset(): x_k = x0 for all k, u = 0 (NMPC_class.py:250-254)."""
+        self.x0[:] = x0
+        self.X[:] = np.asarray(x0)[None, :]
+        self.U[:] = 0.0
+
+    def set_yref(self, pos_x, pos_y, ref_yaw, ref_v):
+        """NMPC_class.py:169-180"""
+        n = self.N + 1
+        self.yref[:] = 0.0
+        self.yref[:, 0] = pos_x[:n]; self.yref[:, 1] = pos_y[:n]
+        self.yref[:, 2] = ref_yaw[:n]; self.yref[:, 3] = ref_v[:n]
+
+    def set_iter_max(self, it):
+        lib().oracle_set_iter_max(self._h, int(it))
+
+    def solve(self):
+        return lib().oracle_solve(self._h)
+
+    @property
+    def cost(self):
+        return float(self._view("cost")[0])
+
+    @property
+    def qp_iter(self):
+        return lib().oracle_qp_iter(self._h)
+
+    @property
+    def status(self):
+        return lib().oracle_status(self._h)
+
+    def solve_batch_cold(self, x0, yref, nthreads=1):
+        """cpu_baseline helper: nb independent cold-start solves sharing this OCP's data."""
+        x0 = np.ascontiguousarray(x0, dtype=np.float64)
+        yref = np.ascontiguousarray(yref, dtype=np.float64)
+        nb = x0.shape[0]
+        assert yref.shape == (nb, self.N + 1, 6)
+        u0 = np.zeros((nb, 2)); X1 = np.zeros((nb, 8)); stats = np.zeros((nb, 3))
+        lib().oracle_solve_batch_cold(self._h, nb, _dp(x0), _dp(yref), _dp(u0), _dp(X1), _dp(stats), int(nthreads))
+        return u0, X1, stats

@@ -1,0 +1,173 @@
+#!/usr/bin/env python3
+"""
+tests/golden/make_golden.py -- regenerates the golden fixtures in this directory.
+
+Runs ONLY in the build container (needs /root/reference, which never travels to the
+GPU box). It imports the pure-numpy pieces of the reference with stub `casadi` /
+`chaospy` modules and reads the reference's logged acados outputs; what it writes is
+DATA (inputs + expected outputs), never reference source:
+
+  kat0.npz            step 0 (cold start) of all 52 _baseline/F/{monteblanco,lvms}/{k}.npz
+  replay_<t>_<k>_<a>_<b>.npz   sequential closed-loop windows (x0_i, yref_i, expected u0/x1/cost/qp_iter)
+  planner.npz         PlannerEmulator input/output pairs
+  pce.npz             alphaGeneration / polyChaosExpansion / compute_x0dist / sigma points of acados_ocp_SNMPC.json
+  r2.npz              P_propagation input/output pairs
+
+Reference call sites reproduced by the replay protocol:
+  get_baseline_performances.py:101-131 (loop), Utils/SimulationMode_main_class.py:106-156
+  (sim_step / StateEstimation), Utils/MPC_sim_utils.py:137-194 (PlannerEmulator),
+  Utils/Logging_Plotting.py:124-146,341-343 (what the logs hold; yaw is stored wrapped).
+"""
+import json
+import os
+import sys
+import types
+from collections import deque
+
+import numpy as np
+
+REF = "/root/reference"
+OUT = os.path.dirname(os.path.abspath(__file__))
+
+# --- stub the absent third-party modules so the reference's numpy code imports
+for name in ("casadi", "chaospy", "matplotlib", "matplotlib.pyplot", "matplotlib.cm", "matplotlib.colors", "pylab"):
+    if name not in sys.modules:
+        try:
+            __import__(name)
+        except Exception:
+            sys.modules[name] = types.ModuleType(name)
+sys.modules["casadi"].__dict__.setdefault("__all__", [])
+sys.path.insert(0, REF)
+
+from Utils.MPC_sim_utils import PlannerEmulator, postprocess_yaw  # noqa: E402
+from Utils.SimulationMode_main_class import moving_average_filter  # noqa: E402
+
+BASE = os.path.join(REF, "Learning_To_Adapt/SafeRL_WMPC/_baseline/F")
+F = np.loadtxt(os.path.join(REF, "Learning_To_Adapt/SafeRL_WMPC/_parameters/F.csv"), delimiter=",")
+N, TP = 38, 3.04
+WINDOWS = np.array([1, 1, 4, 2, 2, 3, 4, 2])
+
+
+def load_traj(track):
+    with open(os.path.join(REF, "Trajectories", f"reftraj_{track}_edgar.json")) as f:
+        return json.load(f)
+
+
+def yref_of(traj, pose):
+    _, t = PlannerEmulator(traj, pose, N + 1, TP, True)
+    return np.stack([np.asarray(t["pos_x"], float), np.asarray(t["pos_y"], float),
+                     np.asarray(t["ref_yaw"], float), np.asarray(t["ref_v"], float)], axis=1)
+
+
+def replay_inputs(track, k, nsteps):
+    """(x0_i, yref_i, expected) for steps 0..nsteps-1 of one logged closed loop."""
+    d = np.load(os.path.join(BASE, track, f"{k}.npz"))
+    traj = load_traj(track)
+    CiLX = d["CiLX"].copy()
+    CiLX[:, 2] = np.unwrap(CiLX[:, 2])        # logs hold yaw mod 2pi, the live state is continuous
+    SimX = d["MPC_SimX"]
+    buf = [deque(maxlen=15) for _ in range(8)]
+    x0s, yrefs = [], []
+    X0 = np.array([traj["pos_x"][0], traj["pos_y"][0], postprocess_yaw(traj["ref_yaw"][0]), traj["ref_v"][0], 0, 0, 0, 0.0])
+    for i in range(nsteps):
+        if i == 0:
+            x0 = X0.copy()
+            pose = X0[:4].copy()
+        else:
+            xn = np.append(CiLX[i], SimX[i][7])
+            for j in range(8):
+                buf[j].append(xn[j])
+                xn[j] = moving_average_filter(np.array(buf[j]), WINDOWS[j])
+            x0 = xn
+            pose = CiLX[i][:4]
+        x0s.append(x0)
+        yrefs.append(yref_of(traj, pose))
+    exp = dict(u0=d["simU"][:nsteps], x1=SimX[1:nsteps + 1], cost=d["simSolverDebug"][:nsteps, 0],
+               qp_iter=d["simSolverDebug"][:nsteps, 3], status=d["simSolverDebug"][:nsteps, 4])
+    return np.array(x0s), np.array(yrefs), exp
+
+
+def make_kat0():
+    rows = []
+    for track in ("monteblanco", "lvms"):
+        for k in range(26):
+            x0s, yrefs, exp = replay_inputs(track, k, 1)
+            rows.append((track, k, x0s[0], yrefs[0], exp))
+    np.savez_compressed(
+        os.path.join(OUT, "kat0.npz"),
+        track=np.array([r[0] for r in rows]), k=np.array([r[1] for r in rows]),
+        params=np.array([F[r[1]] for r in rows]),
+        x0=np.array([r[2] for r in rows]), yref=np.array([r[3] for r in rows]),
+        u0=np.array([r[4]["u0"][0] for r in rows]), x1=np.array([r[4]["x1"][0] for r in rows]),
+        cost=np.array([r[4]["cost"][0] for r in rows]), qp_iter=np.array([r[4]["qp_iter"][0] for r in rows]))
+
+
+def make_replay(track, k, nsteps):
+    x0s, yrefs, exp = replay_inputs(track, k, nsteps)
+    np.savez_compressed(os.path.join(OUT, f"replay_{track}_{k}_0_{nsteps}.npz"),
+                        params=F[k], x0=x0s, yref=yrefs, **exp)
+
+
+def make_planner():
+    rng = np.random.default_rng(7)
+    out = {}
+    for track in ("monteblanco", "lvms", "modena"):
+        traj = load_traj(track)
+        n = len(traj["pos_x"])
+        idx = np.concatenate([np.arange(0, n, 53), [n - 1, n - 2, n - 5, n - 12, n - 25]])
+        poses = np.stack([np.asarray(traj["pos_x"])[idx], np.asarray(traj["pos_y"])[idx]], 1) + rng.normal(0, 0.7, (len(idx), 2))
+        res39, res41, cidx = [], [], []
+        for p in poses:
+            c, t = PlannerEmulator(traj, p, 39, 3.04, True)
+            res39.append(np.stack([t["pos_x"], t["pos_y"], t["ref_yaw"], t["ref_v"]], 1))
+            c2, t2 = PlannerEmulator(traj, p, 41, 3.2, True)
+            res41.append(np.stack([t2["pos_x"], t2["pos_y"], t2["ref_yaw"], t2["ref_v"]], 1))
+            cidx.append(c)
+        out[f"{track}_pose"] = poses
+        out[f"{track}_idx"] = np.array(cidx)
+        out[f"{track}_n39"] = np.array(res39)
+        out[f"{track}_n41"] = np.array(res41)
+    np.savez_compressed(os.path.join(OUT, "planner.npz"), **out)
+
+
+def make_pce():
+    from Model_Predictive_Controller.Stochastic_NMPC.stochastic_mpc_utils import (
+        alphaGeneration, polyChaosExpansion, compute_x0dist, hermiteGeneration)
+    alphas = alphaGeneration(3, 2)
+    rng = np.random.default_rng(3)
+    w = rng.normal(size=(3, 15))
+    phi = np.array([polyChaosExpansion(w[:, i], alphas, "gaussian") for i in range(15)])
+    herm = np.array([[hermiteGeneration(x, n) for n in range(4)] for x in (-1.3, 0.0, 0.4, 2.2)])
+    x0 = np.array([1.0, 2.0, 0.3, 20.0, 0.1, 0.02, 0.01, 0.5])
+    stds = np.array([0, 0, 0, 0.8, 0.35, 0.035, 0, 0])
+    x0d = compute_x0dist(x0.copy(), w, 15, stds)
+    with open(os.path.join(REF, "acados_ocp_SNMPC.json")) as f:
+        js = json.load(f)
+    lbx0 = np.array(js["constraints"]["lbx_0"], float).reshape(11, 8)
+    np.savez_compressed(os.path.join(OUT, "pce.npz"), alphas=alphas, w=w, phi=phi, herm=herm,
+                        x0=x0, stds=stds, x0dist=x0d, json_lbx0=lbx0)
+
+
+def make_r2():
+    from Model_Predictive_Controller.Reduced_Robustified_NMPC.Robust_NMPC_pred_model_utils import P_propagation
+    rng = np.random.default_rng(11)
+    P = rng.normal(size=(6, 8, 8)); P = P @ P.transpose(0, 2, 1)
+    A = rng.normal(size=(6, 8, 8)); B = rng.normal(size=(6, 8, 4)); W = np.diag([0.1, 0.2, 0.3, 0.4])
+    Pn = np.array([P_propagation(P[i], A[i], B[i], W) for i in range(6)])
+    np.savez_compressed(os.path.join(OUT, "r2.npz"), P=P, A=A, B=B, W=W, Pn=Pn)
+
+
+if __name__ == "__main__":
+    what = sys.argv[1:] or ["kat0", "replay", "planner", "pce", "r2"]
+    if "kat0" in what:
+        make_kat0()
+    if "replay" in what:
+        make_replay("lvms", 0, 450)
+        make_replay("monteblanco", 0, 400)
+    if "planner" in what:
+        make_planner()
+    if "pce" in what:
+        make_pce()
+    if "r2" in what:
+        make_r2()
+    print("golden fixtures written to", OUT)

@@ -1,0 +1,97 @@
+"""
+Pins the CPU oracle (oracle/nmpc_oracle.c) against the reference's logged acados outputs
+(tests/golden/*.npz, made by tests/golden/make_golden.py from
+Learning_To_Adapt/SafeRL_WMPC/_baseline/F/*/*.npz). The reference has no tests of its
+own; these logs are the only known answers for the hot path.
+"""
+import os
+
+import numpy as np
+import pytest
+
+from oracle.oracle import OracleOcp, stm_f, rk4_sens, h_con
+
+
+def _solve_kat(d, i):
+    o = OracleOcp(38, 0.08, 3)
+    o.set_weights(*d["params"][i])
+    o.cold_start(d["x0"][i])
+    y = d["yref"][i]
+    o.set_yref(y[:, 0], y[:, 1], y[:, 2], y[:, 3])
+    st = o.solve()
+    return o, st
+
+
+def test_kat0_all_52_logs(golden_dir):
+    """Cold-start step 0 of every logged closed loop: u0, x1, cost."""
+    d = np.load(os.path.join(golden_dir, "kat0.npz"))
+    assert len(d["k"]) == 52
+    for i in range(52):
+        o, st = _solve_kat(d, i)
+        assert st == 0
+        # tolerance: 1e-6 relative (logs are reproduced to ~3e-8; north_star asks 1e-4)
+        np.testing.assert_allclose(o.U[0], d["u0"][i], rtol=1e-6, atol=1e-8)
+        np.testing.assert_allclose(o.X[1], d["x1"][i], rtol=1e-6, atol=1e-8)
+        assert abs(o.cost - d["cost"][i]) <= 1e-6 * abs(d["cost"][i])
+        assert o.qp_iter <= 50
+
+
+@pytest.mark.parametrize("name,tol", [("replay_lvms_0_0_450.npz", 2e-6), ("replay_monteblanco_0_0_400.npz", 2e-5)])
+def test_sequential_replay(golden_dir, name, tol):
+    """Warm-started RTI sequence (iterate carried over un-shifted): exercises the
+    linearised lower bound of h, active soft slacks (lvms step 55) and the hard-active
+    h<=1 rows (lvms 300-326). Tolerance absolute on (u0, x1); north_star asks 1e-4 rel."""
+    d = np.load(os.path.join(golden_dir, name))
+    o = OracleOcp(38, 0.08, 3)
+    o.set_weights(*d["params"])
+    worst = 0.0
+    for i in range(len(d["x0"])):
+        if i == 0:
+            o.cold_start(d["x0"][0])
+        else:
+            o.x0[:] = d["x0"][i]
+        y = d["yref"][i]
+        o.set_yref(y[:, 0], y[:, 1], y[:, 2], y[:, 3])
+        assert o.solve() == 0
+        worst = max(worst, np.abs(o.U[0] - d["u0"][i]).max(), np.abs(o.X[1] - d["x1"][i]).max())
+        assert abs(o.cost - d["cost"][i]) <= 1e-4 * max(1.0, abs(d["cost"][i]))
+    assert worst < tol
+
+
+def test_jacobians_finite_difference():
+    rng = np.random.default_rng(0)
+    for _ in range(20):
+        x = np.array([rng.normal(0, 50), rng.normal(0, 50), rng.uniform(-7, 7), rng.uniform(3, 38),
+                      rng.normal(0, 0.3), rng.normal(0, 0.1), rng.normal(0, 0.05), rng.uniform(-3, 2.5)])
+        u = rng.normal(0, 1, 2)
+        f0, Jx, Ju = stm_f(x, u)
+        for j in range(8):
+            e = np.zeros(8); e[j] = 1e-6 * max(1.0, abs(x[j]))
+            fd = (stm_f(x + e, u)[0] - stm_f(x - e, u)[0]) / (2 * e[j])
+            np.testing.assert_allclose(Jx[:, j], fd, rtol=2e-6, atol=2e-7)
+        xn, A, B = rk4_sens(x, u, 0.08, 3)
+        for j in range(8):
+            e = np.zeros(8); e[j] = 1e-6 * max(1.0, abs(x[j]))
+            fd = (rk4_sens(x + e, u, 0.08, 3)[0] - rk4_sens(x - e, u, 0.08, 3)[0]) / (2 * e[j])
+            np.testing.assert_allclose(A[:, j], fd, rtol=2e-6, atol=2e-7)
+        for j in range(2):
+            e = np.zeros(2); e[j] = 1e-6
+            fd = (rk4_sens(x, u + e, 0.08, 3)[0] - rk4_sens(x, u - e, 0.08, 3)[0]) / 2e-6
+            np.testing.assert_allclose(B[:, j], fd, rtol=2e-6, atol=2e-7)
+        h0, gh = h_con(x)
+        for j in range(8):
+            e = np.zeros(8); e[j] = 1e-6 * max(1.0, abs(x[j]))
+            fd = (h_con(x + e)[0] - h_con(x - e)[0]) / (2 * e[j])
+            assert abs(gh[j] - fd) <= 2e-6 * max(1.0, abs(fd))
+
+
+def test_model_structure():
+    """delta and a are pure integrators of the inputs (rows 6,7 of A,B)."""
+    x = np.array([1.0, 2.0, 0.5, 20.0, 0.1, 0.05, 0.02, 0.7]); u = np.array([0.3, -0.1])
+    xn, A, B = rk4_sens(x, u, 0.08, 3)
+    np.testing.assert_allclose(xn[6], x[6] + 0.08 * u[1], rtol=0, atol=1e-15)
+    np.testing.assert_allclose(xn[7], x[7] + 0.08 * u[0], rtol=0, atol=1e-15)
+    np.testing.assert_allclose(A[6], np.eye(8)[6], atol=1e-15)
+    np.testing.assert_allclose(A[7], np.eye(8)[7], atol=1e-15)
+    np.testing.assert_allclose(B[6], [0, 0.08], atol=1e-15)
+    np.testing.assert_allclose(B[7], [0.08, 0], atol=1e-15)
