@@ -1,0 +1,128 @@
+/*
+ * include/tum_nmpc.h -- C-ABI of libtumnmpc.so, the MI355X-native batched SQP-RTI solver.
+ *
+ * Drop-in boundary: the reference drives its solver through acados_template.AcadosOcpSolver
+ * (a ctypes wrapper around the generated libacados_ocp_solver_<name>.so). Every entry point
+ * below replaces one AcadosOcpSolver method the reference calls; the reference call sites are
+ * cited per function (paths relative to bzarr/TUM-CONTROL). All functions take plain pointers
+ * and sizes; no torch / C++ types cross the boundary.
+ *
+ * New relative to acados: a leading BATCH dimension. A capsule owns `batch` independent OCP
+ * instances (perturbed-x0 / sigma-point / Monte-Carlo / weight-sweep fan-outs); one wavefront
+ * solves one instance. Host buffers passed to set/get hold `nb` consecutive instances
+ * [b0, b0+nb), `stride` doubles apart (stride 0 on a set = broadcast one record to all nb).
+ *
+ * Conventions: doubles everywhere; matrices column-major like acados; every set/get COPIES
+ * (caller owns host buffers, capsule owns device memory); return 0 on success, non-zero on
+ * error with the message available from tum_ocp_last_error(). One host thread per capsule.
+ */
+#ifndef TUM_NMPC_H
+#define TUM_NMPC_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TUM_NX 8          /* [posx,posy,yaw,vlong,vlat,yawrate,delta_f,a]  pred_model_dynamic_stm_pacejka.py:80-93 */
+#define TUM_NU 2          /* [jerk, steering_rate]                                                        :96-98   */
+#define TUM_NY 6          /* cost_y_expr = [x0,x1,wrap(yaw),vlong,u]        NMPC_STM_acados_settings.py:51 */
+#define TUM_NYE 4
+#define TUM_N_MAX 40      /* horizon limit of this build (2N <= 80 condensed variables, 5 MFMA tiles)     */
+#define TUM_ALL_STAGES (-1)
+
+/* acados return codes the callers test (NMPC_class.py:183-206, main.py:59-61) */
+#define TUM_SUCCESS 0
+#define TUM_QP_FAILURE 4
+
+typedef struct tum_ocp tum_ocp;           /* opaque capsule (acados: nlp_solver_capsule) */
+
+/* Problem description = what NMPC_STM_acados_settings.py:16-245 bakes into the generated solver. */
+typedef struct tum_ocp_desc {
+    int N;                 /* shooting intervals, ocp.dims.N                     :34  */
+    int nsub;              /* sim_method_num_steps (ERK4 sub-steps)              :240 */
+    double dt;             /* Tf / N                                             :230 */
+    int batch;             /* number of independent OCP instances                     */
+    int device;            /* HIP device ordinal                                      */
+    /* single-track / Pacejka constants, Config/EDGAR/veh_params_pred.yaml, pacejka_params.yaml,
+       pred_model_dynamic_stm_pacejka.py:33-46 */
+    double lf, lr, m, Iz, ro, S, Cd;
+    double Bf, Cf, Df, Ef, Br, Cr, Dr, Er;
+    double g, fr0, fr1, fr4;
+    double acc_min;        /* braking limit used as ax_max when a < 0            NMPC_STM_acados_settings.py:74 */
+    /* velocity-dependent gg limits, Config/EDGAR/ggv.csv via NMPC_class.py:322-335 */
+    int n_ggv;
+    double ggv_v[16], ggv_ax[16], ggv_ay[16];
+    /* QP solver options (acados: qp_solver_iter_max :232, HPIPM tolerances json:904-950) */
+    int qp_iter_max;
+    double qp_tol_stat, qp_tol_ineq, qp_tol_comp, qp_mu0;
+    int store_qp_in;       /* keep A_k,B_k,b_k of the last linearisation for tum_ocp_get_from_qp_in */
+} tum_ocp_desc;
+
+/* AcadosOcpSolver(ocp, json_file=..., generate=..., build=...)   NMPC_STM_acados_settings.py:243 */
+tum_ocp *tum_ocp_create(const tum_ocp_desc *desc);
+void tum_ocp_free(tum_ocp *c);
+const char *tum_ocp_last_error(void);
+int tum_ocp_batch(const tum_ocp *c);
+int tum_ocp_horizon(const tum_ocp *c);
+
+/* acados_solver.set(stage, field, value)   NMPC_class.py:172,178,254; SNMPC_class.py:124,130
+ * field: "x" (8), "u" (2), "yref" (6 for stage<N, 4 for stage N).
+ * stage == TUM_ALL_STAGES: v holds all stages back to back ("x": (N+1)*8, "u": N*2, "yref": (N+1)*6
+ * with the terminal record padded to 6). */
+int tum_ocp_set(tum_ocp *c, int stage, const char *field, const double *v, int len, int b0, int nb, int stride);
+/* acados_solver.get(stage, field)          NMPC_class.py:193,198; Reduced_Robustified_NMPC_class.py:280,298
+ * field: "x", "u" (and the soft-constraint slacks of the last QP: "sl", "su", 3 per stage in acados order). */
+int tum_ocp_get(tum_ocp *c, int stage, const char *field, double *v, int len, int b0, int nb, int stride);
+
+/* acados_solver.constraints_set(stage, field, value)   NMPC_class.py:111-112,245-246;
+ * Reduced_Robustified_NMPC_class.py:335-336,359,362-365
+ * stage 0 "lbx"/"ubx" (8 values) = initial state x0 (initial-value embedding);
+ * stage>=1 "lbx"/"ubx" (1 value) = steering-angle bound; "lbu"/"ubu" (1) = steering-rate bound;
+ * "lh"/"uh" (1) = bounds of the gg-circle constraint. */
+int tum_ocp_constraints_set(tum_ocp *c, int stage, const char *field, const double *v, int len, int b0, int nb, int stride);
+
+/* acados_solver.cost_set(stage, field, value)   NMPC_class.py:295-317
+ * "W": ny*ny (stage<N: 36, stage N: 16) column-major, must be diagonal (the reference only installs
+ * blockdiag(Q,R)); all stages < N share one W per instance (the reference sets them identically).
+ * "zl","zu","Zl","Zu": 1 value at stage 0 [sbu], 3 at stages 1..N-1 [sbu,sbx,sh], 2 at stage N [sbx,sh]. */
+int tum_ocp_cost_set(tum_ocp *c, int stage, const char *field, const double *v, int len, int b0, int nb, int stride);
+
+/* status = acados_solver.solve()   NMPC_class.py:183, SNMPC_class.py:198, Reduced_Robustified_NMPC_class.py:264
+ * One SQP real-time iteration for every instance. Returns the max status over the batch
+ * (0 ok, 4 QP failure); per-instance values via tum_ocp_get_stats("status"). Synchronous. */
+int tum_ocp_solve(tum_ocp *c);
+/* Asynchronous flavour for benchmarking / pipelining: enqueue on the capsule's stream, no host sync. */
+int tum_ocp_solve_async(tum_ocp *c);
+int tum_ocp_synchronize(tum_ocp *c);
+
+/* acados_solver.get_cost()   NMPC_class.py:202 */
+int tum_ocp_get_cost(tum_ocp *c, double *out, int b0, int nb);
+/* acados_solver.get_stats(field)   NMPC_class.py:203-205
+ * "time_tot" -> 1 double, device seconds of the last solve (HIP events on the capsule's stream)
+ * "sqp_iter" -> nb ints (always 1), "qp_iter" -> nb ints, "status" -> nb ints, "qp_status" -> nb ints
+ * "res" -> nb x 3 doubles (stat, ineq, comp residuals of the last QP). */
+int tum_ocp_get_stats(tum_ocp *c, const char *field, void *out, int b0, int nb);
+/* acados_solver.reset()   NMPC_class.py:251 -- zero the iterate of every instance */
+int tum_ocp_reset(tum_ocp *c);
+/* acados_solver.get_from_qp_in(stage, "A")   Reduced_Robustified_NMPC_class.py:295
+ * "A" (64, column-major 8x8), "B" (16, column-major 8x2), "b" (8) of the LAST linearisation. */
+int tum_ocp_get_from_qp_in(tum_ocp *c, int stage, const char *field, double *out, int len, int b0, int nb, int stride);
+
+/* Device-side plumbing (no reference counterpart): use an external HIP stream (e.g. torch's current
+ * stream) and copy results device-to-device into caller-owned HBM (for the RCCL gather). */
+int tum_ocp_set_stream(tum_ocp *c, void *hip_stream);
+/* field: "u0" (nb x 2), "x1" (nb x 8), "cost" (nb), "X" (nb x (N+1)*8), "U" (nb x N*2),
+ * "status" / "qp_iter" (nb int32) */
+int tum_ocp_get_device(tum_ocp *c, const char *field, void *dev_dst, int b0, int nb);
+/* cold start every instance on the device: X_k = x0 for all k, U = 0 (acados create / reset + set x;
+ * NMPC_class.py:250-254) using the x0 already uploaded with constraints_set(0,"lbx"). */
+int tum_ocp_cold_start(tum_ocp *c);
+/* last kernel launch time in milliseconds (HIP events on the launch stream) */
+double tum_ocp_last_kernel_ms(tum_ocp *c);
+/* debug: dump of condensed-QP intermediates of instance b (see csrc/nmpc_kernel.hip) */
+int tum_ocp_debug_dump(tum_ocp *c, int b, double *out, int len);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TUM_NMPC_H */

@@ -512,6 +512,11 @@ static double eval_cost(const oracle_ocp *o)
     return c;
 }
 
+/* optional dump of the condensed QP of the next oracle_solve calls (tests only):
+ * layout [H nv*nv | q nv | C m*nv | d m | g (N+1)*8] */
+static double *g_dbg = NULL;
+void oracle_set_debug(double *buf) { g_dbg = buf; }
+
 /* One SQP real-time iteration. Returns acados-like status. */
 int oracle_solve(oracle_ocp *o)
 {
@@ -603,6 +608,14 @@ int oracle_solve(oracle_ocp *o)
             zl[i] = sc * o->zl[k * 3 + s]; zu[i] = sc * o->zu[k * 3 + s];
             Zl[i] = sc * o->Zl[k * 3 + s]; Zu[i] = sc * o->Zu[k * 3 + s];
         }
+    }
+    if (g_dbg) {
+        double *p = g_dbg;
+        memcpy(p, H, sizeof(double) * nv * nv); p += nv * nv;
+        memcpy(p, q, sizeof(double) * nv); p += nv;
+        memcpy(p, C, sizeof(double) * m * nv); p += m * nv;
+        memcpy(p, d, sizeof(double) * m); p += m;
+        memcpy(p, g, sizeof(double) * (N + 1) * NX);
     }
     /* 6. QP */
     double *sall = calloc(2 * m, sizeof(double));

@@ -91,6 +91,7 @@ def lib():
         L.oracle_stm_f.argtypes = [ctypes.POINTER(StmModel), dp, dp, dp, dp, dp]
         L.oracle_rk4_sens.argtypes = [ctypes.POINTER(StmModel), dp, dp, ctypes.c_double, ctypes.c_int, dp, dp, dp]
         L.oracle_h.argtypes = [ctypes.POINTER(StmModel), dp, dp, dp]
+        L.oracle_set_debug.argtypes = [dp]
         L.oracle_solve_batch_cold.argtypes = [ctypes.c_void_p, ctypes.c_int, dp, dp, dp, dp, dp, ctypes.c_int]
         _lib = L
     return _lib
@@ -207,6 +208,23 @@ class OracleOcp:
 
     def solve(self):
         return lib().oracle_solve(self._h)
+
+    def solve_debug(self):
+        """solve() that also returns the condensed QP (H, q, C, d, g) it built."""
+        N = self.N; nv, m = 2 * N, 3 * N
+        buf = np.zeros(nv * nv + nv + m * nv + m + (N + 1) * 8)
+        lib().oracle_set_debug(_dp(buf))
+        try:
+            st = lib().oracle_solve(self._h)
+        finally:
+            lib().oracle_set_debug(None)
+        o = 0
+        H = buf[o:o + nv * nv].reshape(nv, nv); o += nv * nv
+        q = buf[o:o + nv]; o += nv
+        C = buf[o:o + m * nv].reshape(m, nv); o += m * nv
+        d = buf[o:o + m]; o += m
+        g = buf[o:].reshape(N + 1, 8)
+        return st, dict(H=H, q=q, C=C, d=d, g=g)
 
     @property
     def cost(self):

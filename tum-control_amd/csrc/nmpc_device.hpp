@@ -1,0 +1,327 @@
+// nmpc_device.hpp -- CDNA4 (gfx950) device code of the batched SQP-RTI solver.
+//
+// One wavefront (64 lanes, one 64-thread workgroup) solves one OCP instance:
+//   phase 1  linearise   lane = shooting stage: ERK4 x nsub with hand-derived forward sensitivities
+//                        of the single-track/Pacejka ODE (pred_model_dynamic_stm_pacejka.py:118-177)
+//   phase 2  condense    lane = column of G (dx_k = G_k dU + g_k); the Gauss-Newton Hessian is a SYRK
+//                        over the 4 cost rows of every stage, accumulated with v_mfma_f64_16x16x4_f64
+//                        into 15 register-resident 16x16 tiles (upper triangle of the 80x80 H)
+//   phase 3  dense IPM   Mehrotra predictor-corrector on the condensed soft-constrained QP; per
+//                        iteration  M = H + C' Gamma C  (MFMA SYRK), blocked Cholesky (MFMA trailing
+//                        updates, register panel factorisation with readlane broadcasts), two solves
+//   phase 4  expand      dx trajectory, full step, cost at the new iterate
+// Everything between the initial loads and the final stores lives in LDS / registers.
+//
+// Reference semantics: NMPC_STM_acados_settings.py:16-245 (OCP), SURVEY.md Appendix B (one RTI call).
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace tum {
+
+typedef double d4 __attribute__((ext_vector_type(4)));
+
+constexpr int NX = 8, NU = 2;
+constexpr int NMAX = 40;                    // max horizon of this build
+constexpr int NT = 5;                       // 16-wide MFMA tiles per dimension
+constexpr int NVP = 16 * NT;                // 80 (padded) condensed variables
+constexpr int NTT = NT * (NT + 1) / 2;      // 15 upper-triangular tiles
+constexpr int ABS = 53;                     // LDS stride (doubles) of one stage's linearisation record
+constexpr int LPK = NVP * (NVP + 1) / 2;    // 3240 packed lower-triangular entries
+
+__host__ __device__ constexpr int tidx(int K, int I) { return K * NT - K * (K - 1) / 2 + (I - K); }   // K <= I
+__host__ __device__ constexpr int lpk(int i, int j) { return i * (i + 1) / 2 + j; }                    // i >= j
+// packed constraint matrix: stage s (1..N) owns two rows (delta, h) of 2s entries each
+__host__ __device__ constexpr int coff(int s, int which) { return 2 * s * (s - 1) + which * 2 * s; }
+
+// LDS carve (offsets in doubles)
+constexpr int O_AB = 0;                               // NMAX*ABS              compact (Sp,S,b) per stage
+constexpr int O_M = O_AB + NMAX * ABS;                // LPK                   KKT matrix / Cholesky factor
+constexpr int O_STAGE = O_M;                          //   aliased: 4 x NVP staging rows for the H SYRK
+constexpr int O_C = O_M + LPK;                        // 2*NMAX*(NMAX+1)       packed general-constraint rows
+constexpr int O_X = O_C + 2 * NMAX * (NMAX + 1);      // (NMAX+1)*8            iterate X
+constexpr int O_G = O_X + (NMAX + 1) * NX;            // (NMAX+1)*8            g_k (constant part of dx_k)
+constexpr int O_RES = O_G + (NMAX + 1) * NX;          // (NMAX+1)*4            y - yref of the 4 state cost rows
+constexpr int O_GH = O_RES + (NMAX + 1) * 4;          // (NMAX+1)*4            (gh3, gh5, gh7, h) per stage
+constexpr int O_D = O_GH + (NMAX + 1) * 4;            // 2*NMAX                constant term of the general rows
+constexpr int O_GAM = O_D + 2 * NMAX;                 // 2*NMAX                gamma of the general rows
+constexpr int O_WR = O_GAM + 2 * NMAX;                // 2*NMAX                rhs weights of the general rows
+constexpr int O_WB = O_WR + 2 * NMAX;                 // NMAX                  box-row scalars (gamma / weights)
+constexpr int O_DV = O_WB + NMAX;                     // NVP                   broadcast copy of a v-space vector
+constexpr int O_INVD = O_DV + NVP;                    // NVP                   1 / diag(L)
+constexpr int O_U = O_INVD + NVP;                     // NVP                   iterate U
+constexpr int LDS_DOUBLES = O_U + NVP;
+constexpr int LDS_BYTES = LDS_DOUBLES * 8;
+
+struct Model {
+    double lf, lr, inv_m, inv_Iz, m, ka;            // ka = 0.5*ro*S*Cd
+    double Bf, Cf, Df, Ef, Br, Cr, Dr, Er;
+    double Fz_f, Fz_r, invFmax_f, invFmax_r;
+    double fr0, fr1, fr4;
+    double ax_brake;                                  // -acc_min
+    int n_ggv;
+    double ggv_v[16], ggv_ax[16], ggv_ay[16];
+};
+
+struct KArgs {
+    int N, nsub, batch, flags;                        // flags: 1 store_qp_in, 2 debug dump
+    double dt;
+    int iter_max;
+    double tol_stat, tol_ineq, tol_comp, mu0, reg;
+    Model mp;
+    double *X, *U;                                    // iterate, [b][(N+1)*8], [b][N*2]
+    const double *x0, *yref, *W, *pen, *bnd;          // [b][8], [b][(N+1)*6], [b][10], [b][36], [b][6][N+1]
+    double *cost, *res, *slack;                       // [b], [b][3], [b][6N]
+    int *status, *qp_iter, *qp_status;                // [b]
+    double *qpin;                                     // [b][N][88]  (A 64 | B 16 | b 8), row-major
+    double *dbg;                                      // debug dump, instance 0.. (flags&2)
+    int dbg_stride;
+};
+
+// ---------------------------------------------------------------- wave helpers
+__device__ __forceinline__ double rl(double v, int lane)   // broadcast lane `lane` (wave-uniform index)
+{
+    int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
+    int hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double wave_sum(double v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ double wave_max(double v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o, 64));
+    return v;
+}
+__device__ __forceinline__ double wave_min(double v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmin(v, __shfl_xor(v, o, 64));
+    return v;
+}
+__device__ __forceinline__ d4 mfma(double a, double b, d4 c) { return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0); }
+__device__ __forceinline__ void wsync() { __syncthreads(); }   // 1 wave per workgroup: LDS ordering point
+
+// ---------------------------------------------------------------- model
+// Core of the single-track ODE: derivatives of (vlong, vlat, yawrate) and their partials w.r.t.
+// (vl, vt, r, delta, a). pred_model_dynamic_stm_pacejka.py:118-175; derivative conventions follow
+// CasADi (if_else / fmin / fmax: derivative of the taken branch).
+__device__ __forceinline__ void pacejka(double B, double C, double D, double E, double al, double &Fy, double &dFy)
+{
+    const double x1 = B * al;
+    const double at1 = atan(x1);
+    const double inner = x1 - E * (x1 - at1);
+    const double th = atan(inner);
+    double sn, cs;
+    sincos(C * th, &sn, &cs);
+    Fy = D * sn;
+    dFy = D * cs * C / (1.0 + inner * inner) * (1.0 - E + E / (1.0 + x1 * x1)) * B;
+}
+
+__device__ __forceinline__ void stm_core(const Model &p, double vl, double vt, double r, double de, double a,
+                                         double f[3], double J[3][5])
+{
+    const double vv = vl * vl + vt * vt;
+    const double sp = sqrt(vv);
+    const double w = 0.036 * sp;                       // v[km/h] / 100
+    const double w2 = w * w;
+    const double fr = p.fr0 + p.fr1 * w + p.fr4 * w2 * w2;
+    const double dfr_dw = p.fr1 + 4.0 * p.fr4 * w2 * w;
+    const double isp = 0.036 / sp;
+    const double fr_vl = dfr_dw * isp * vl, fr_vt = dfr_dw * isp * vt;
+    const double Fxf = -fr * p.Fz_f;
+    const double Fxr = p.m * a - fr * p.Fz_r;
+    double alf = 0, alf_vl = 0, alf_vt = 0, alf_r = 0, alf_de = 0, alr = 0, alr_vl = 0, alr_vt = 0, alr_r = 0;
+    if (vl > 0.001) {
+        const double ivl = 1.0 / vl;
+        const double qf = (vt + p.lf * r) * ivl, cf2 = 1.0 / (1.0 + qf * qf);
+        alf = de - atan(qf);
+        alf_vl = qf * ivl * cf2; alf_vt = -ivl * cf2; alf_r = -p.lf * ivl * cf2; alf_de = 1.0;
+        const double qr = (p.lr * r - vt) * ivl, cr2 = 1.0 / (1.0 + qr * qr);
+        alr = atan(qr);
+        alr_vl = -qr * ivl * cr2; alr_vt = -ivl * cr2; alr_r = p.lr * ivl * cr2;
+    }
+    double Fyf_lat, dFyf, Fyr_lat, dFyr;
+    pacejka(p.Bf, p.Cf, p.Df, p.Ef, alf, Fyf_lat, dFyf);
+    pacejka(p.Br, p.Cr, p.Dr, p.Er, alr, Fyr_lat, dFyr);
+    // combined slip weighting, clipped at +-0.98
+    double Gf = Fxf * p.invFmax_f, gf_on = 1.0;
+    if (Gf > 0.98) { Gf = 0.98; gf_on = 0.0; } else if (Gf < -0.98) { Gf = -0.98; gf_on = 0.0; }
+    double Gr = Fxr * p.invFmax_r, gr_on = 1.0;
+    if (Gr > 0.98) { Gr = 0.98; gr_on = 0.0; } else if (Gr < -0.98) { Gr = -0.98; gr_on = 0.0; }
+    const double cgf = sqrt(1.0 - Gf * Gf), cgr = sqrt(1.0 - Gr * Gr);       // cos(asin(G))
+    const double dcgf = -Gf / cgf * gf_on * p.invFmax_f;                      // d cgf / d Fxf
+    const double dcgr = -Gr / cgr * gr_on * p.invFmax_r;                      // d cgr / d Fxr
+    const double Fxf_vl = -p.Fz_f * fr_vl, Fxf_vt = -p.Fz_f * fr_vt;
+    const double Fxr_vl = -p.Fz_r * fr_vl, Fxr_vt = -p.Fz_r * fr_vt;
+    const double Fyf = Fyf_lat * cgf, Fyr = Fyr_lat * cgr;
+    const double Fyf_vl = dFyf * alf_vl * cgf + Fyf_lat * dcgf * Fxf_vl;
+    const double Fyf_vt = dFyf * alf_vt * cgf + Fyf_lat * dcgf * Fxf_vt;
+    const double Fyf_r = dFyf * alf_r * cgf;
+    const double Fyf_de = dFyf * alf_de * cgf;
+    const double Fyr_vl = dFyr * alr_vl * cgr + Fyr_lat * dcgr * Fxr_vl;
+    const double Fyr_vt = dFyr * alr_vt * cgr + Fyr_lat * dcgr * Fxr_vt;
+    const double Fyr_r = dFyr * alr_r * cgr;
+    const double Fyr_a = Fyr_lat * dcgr * p.m;
+    double sd, cd;
+    sincos(de, &sd, &cd);
+    const double im = p.inv_m;
+    f[0] = (Fxr - p.ka * vl * vl - Fyf * sd + Fxf * cd) * im + vt * r;
+    J[0][0] = (Fxr_vl - 2.0 * p.ka * vl - Fyf_vl * sd + Fxf_vl * cd) * im;
+    J[0][1] = (Fxr_vt - Fyf_vt * sd + Fxf_vt * cd) * im + r;
+    J[0][2] = -Fyf_r * sd * im + vt;
+    J[0][3] = (-Fyf_de * sd - Fyf * cd - Fxf * sd) * im;
+    J[0][4] = 1.0;
+    const double front = Fyf * cd + Fxf * sd;
+    const double fr_vl_ = Fyf_vl * cd + Fxf_vl * sd, fr_vt_ = Fyf_vt * cd + Fxf_vt * sd;
+    const double fr_r_ = Fyf_r * cd, fr_de_ = Fyf_de * cd - Fyf * sd + Fxf * cd;
+    f[1] = (Fyr + front) * im - vl * r;
+    J[1][0] = (Fyr_vl + fr_vl_) * im - r;
+    J[1][1] = (Fyr_vt + fr_vt_) * im;
+    J[1][2] = (Fyr_r + fr_r_) * im - vl;
+    J[1][3] = fr_de_ * im;
+    J[1][4] = Fyr_a * im;
+    const double iz = p.inv_Iz;
+    f[2] = (p.lf * front - p.lr * Fyr) * iz;
+    J[2][0] = (p.lf * fr_vl_ - p.lr * Fyr_vl) * iz;
+    J[2][1] = (p.lf * fr_vt_ - p.lr * Fyr_vt) * iz;
+    J[2][2] = (p.lf * fr_r_ - p.lr * Fyr_r) * iz;
+    J[2][3] = p.lf * fr_de_ * iz;
+    J[2][4] = -p.lr * Fyr_a * iz;
+}
+
+// piecewise-linear gg table (casadi interpolant 'linear', NMPC_class.py:322-335)
+__device__ __forceinline__ void interp_lin(int n, const double *xs, const double *ys, double x, double &y, double &dy)
+{
+    int i = 0;
+    while (i < n - 2 && x >= xs[i + 1]) i++;
+    const double sl = (ys[i + 1] - ys[i]) / (xs[i + 1] - xs[i]);
+    y = ys[i] + sl * (x - xs[i]);
+    dy = sl;
+}
+
+// h = (a/ax)^2 + (vl*r/ay)^2 and its gradient entries (d/dvl, d/dr, d/da)
+// NMPC_STM_acados_settings.py:70-74,108-119 (combined_acc_limits == 2)
+__device__ __forceinline__ void h_con(const Model &p, double vl, double r, double a, double &h, double &g3, double &g5, double &g7)
+{
+    double ax, dax, ay, day;
+    interp_lin(p.n_ggv, p.ggv_v, p.ggv_ax, vl, ax, dax);
+    interp_lin(p.n_ggv, p.ggv_v, p.ggv_ay, vl, ay, day);
+    if (a < 0.0) { ax = p.ax_brake; dax = 0.0; }
+    const double alat = vl * r, nlon = a / ax, nlat = alat / ay;
+    h = nlon * nlon + nlat * nlat;
+    g3 = 2.0 * nlat * (r / ay - alat / (ay * ay) * day) - 2.0 * nlon * a / (ax * ax) * dax;
+    g5 = 2.0 * nlat * vl / ay;
+    g7 = 2.0 * nlon / ax;
+}
+
+__device__ __forceinline__ double wrap_yaw(double yaw)     // NMPC_STM_acados_settings.py:41-42
+{
+    double y = fmod(yaw, 2.0 * M_PI);
+    if (y < 0.0) y += 2.0 * M_PI;
+    return y;
+}
+
+// One shooting interval with structured forward sensitivities (lane-local).
+// Tracked: Sp[2] = d(px,py)/dpsi0 ; S[6][7] = d(px,py,psi,vl,vt,r)/d(vl0,vt0,r0,delta0,a0,jerk,steer_rate).
+// delta and a are exact integrators of the inputs; d psi / d psi0 = 1; (px,py) columns are identity.
+__device__ __forceinline__ void rk4_sens(const Model &p, const double x0[8], const double u[2], double dt, int nsub,
+                                         double xn[8], double Sp[2], double S[6][7])
+{
+    double x[8];
+#pragma unroll
+    for (int i = 0; i < 8; i++) x[i] = x0[i];
+    Sp[0] = 0.0; Sp[1] = 0.0;
+#pragma unroll
+    for (int i = 0; i < 6; i++)
+#pragma unroll
+        for (int c = 0; c < 7; c++) S[i][c] = 0.0;
+    S[3][0] = 1.0; S[4][1] = 1.0; S[5][2] = 1.0;
+    const double h = dt / nsub;
+    for (int sub = 0; sub < nsub; sub++) {
+        double xacc[6], kp[6], Spacc[2], Kpp[2], Sacc[6][7], Kp[6][7];
+#pragma unroll
+        for (int i = 0; i < 6; i++) { xacc[i] = 0.0; kp[i] = 0.0; }
+        Spacc[0] = Spacc[1] = 0.0; Kpp[0] = Kpp[1] = 0.0;
+#pragma unroll
+        for (int i = 0; i < 6; i++)
+#pragma unroll
+            for (int c = 0; c < 7; c++) { Sacc[i][c] = 0.0; Kp[i][c] = 0.0; }
+#pragma unroll
+        for (int st = 0; st < 4; st++) {
+            const double ci = (st == 0) ? 0.0 : (st == 3 ? 1.0 : 0.5);
+            const double bi = (st == 0 || st == 3) ? (1.0 / 6.0) : (2.0 / 6.0);
+            const double ch = ci * h;
+            const double tau = sub * h + ch;                 // time since the start of the interval
+            const double psi = x[2] + ch * kp[2];
+            const double vl = x[3] + ch * kp[3], vt = x[4] + ch * kp[4], r = x[5] + ch * kp[5];
+            const double de = x[6] + ch * u[1], a = x[7] + ch * u[0];
+            double f[3], J[3][5];
+            stm_core(p, vl, vt, r, de, a, f, J);
+            double sn, cs;
+            sincos(psi, &sn, &cs);
+            double k[6];
+            k[0] = vl * cs - vt * sn; k[1] = vl * sn + vt * cs; k[2] = r;
+            k[3] = f[0]; k[4] = f[1]; k[5] = f[2];
+            const double J02 = -k[1], J12 = k[0];            // d(px_dot,py_dot)/dpsi
+            // psi0 column: only rows px,py (S[psi][psi0] = 1, core rows 0)
+            {
+                const double K0 = J02, K1 = J12;
+                Spacc[0] += bi * K0; Spacc[1] += bi * K1;
+                Kpp[0] = K0; Kpp[1] = K1;
+            }
+#pragma unroll
+            for (int c = 0; c < 7; c++) {
+                double s[6];
+#pragma unroll
+                for (int i = 0; i < 6; i++) s[i] = S[i][c] + ch * Kp[i][c];
+                const double sde = (c == 3 ? 1.0 : 0.0) + (c == 6 ? tau : 0.0);
+                const double sa = (c == 4 ? 1.0 : 0.0) + (c == 5 ? tau : 0.0);
+                double K[6];
+                K[0] = J02 * s[2] + cs * s[3] - sn * s[4];
+                K[1] = J12 * s[2] + sn * s[3] + cs * s[4];
+                K[2] = s[5];
+#pragma unroll
+                for (int i = 0; i < 3; i++)
+                    K[3 + i] = J[i][0] * s[3] + J[i][1] * s[4] + J[i][2] * s[5] + J[i][3] * sde + J[i][4] * sa;
+#pragma unroll
+                for (int i = 0; i < 6; i++) { Sacc[i][c] += bi * K[i]; Kp[i][c] = K[i]; }
+            }
+#pragma unroll
+            for (int i = 0; i < 6; i++) { xacc[i] += bi * k[i]; kp[i] = k[i]; }
+        }
+#pragma unroll
+        for (int i = 0; i < 6; i++) x[i] += h * xacc[i];
+        x[6] += h * u[1]; x[7] += h * u[0];
+        Sp[0] += h * Spacc[0]; Sp[1] += h * Spacc[1];
+#pragma unroll
+        for (int i = 0; i < 6; i++)
+#pragma unroll
+            for (int c = 0; c < 7; c++) S[i][c] += h * Sacc[i][c];
+    }
+#pragma unroll
+    for (int i = 0; i < 8; i++) xn[i] = x[i];
+}
+
+// w <- A_k w using the compact record (Sp[2] | S[6][7] | b[8]); rows 6,7 of A are identity rows.
+__device__ __forceinline__ void apply_A(const double *rec, double w[8])
+{
+    double n[6];
+    n[0] = w[0] + rec[0] * w[2];
+    n[1] = w[1] + rec[1] * w[2];
+    n[2] = w[2];
+    n[3] = 0.0; n[4] = 0.0; n[5] = 0.0;
+#pragma unroll
+    for (int i = 0; i < 6; i++) {
+        const double *Si = rec + 2 + i * 7;
+#pragma unroll
+        for (int c = 0; c < 5; c++) n[i] += Si[c] * w[3 + c];
+    }
+#pragma unroll
+    for (int i = 0; i < 6; i++) w[i] = n[i];
+}
+
+}  // namespace tum

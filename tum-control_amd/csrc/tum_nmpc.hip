@@ -1,0 +1,426 @@
+// tum_nmpc.hip -- host side of libtumnmpc.so: the C-ABI declared in include/tum_nmpc.h.
+// Owns device memory for `batch` OCP instances and launches the fused SQP-RTI kernel.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/tum_nmpc.h"
+#include "nmpc_kernel.hpp"
+
+using namespace tum;
+
+static thread_local std::string g_err;
+static int fail(const std::string &m) { g_err = m; return 1; }
+#define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return fail(std::string(#x) + ": " + hipGetErrorString(e_)); } while (0)
+
+struct tum_ocp {
+    tum_ocp_desc d;
+    int N, batch;
+    hipStream_t stream; bool own_stream;
+    hipEvent_t ev0, ev1;
+    KArgs ka;
+    double *dX, *dU, *dx0, *dyref, *dW, *dpen, *dbnd, *dcost, *dres, *dslack, *dqpin, *ddbg;
+    int *dstatus, *dqpiter, *dqpstatus;
+    float last_ms;
+    bool solved;
+    std::vector<double> stage;     // host staging
+};
+
+static const int DBG_STRIDE = 20480;
+static const int DBG_INST = 4;
+
+extern "C" const char *tum_ocp_last_error(void) { return g_err.c_str(); }
+extern "C" int tum_ocp_batch(const tum_ocp *c) { return c->batch; }
+extern "C" int tum_ocp_horizon(const tum_ocp *c) { return c->N; }
+
+template <typename T>
+static hipError_t dalloc(T **p, size_t n) { hipError_t e = hipMalloc((void **)p, n * sizeof(T)); if (e == hipSuccess) e = hipMemset(*p, 0, n * sizeof(T)); return e; }
+
+extern "C" tum_ocp *tum_ocp_create(const tum_ocp_desc *desc)
+{
+    if (!desc) { fail("null desc"); return nullptr; }
+    if (desc->N < 1 || desc->N > TUM_N_MAX) { fail("N out of range (1..40)"); return nullptr; }
+    if (desc->batch < 1) { fail("batch < 1"); return nullptr; }
+    if (desc->nsub < 1 || !(desc->dt > 0)) { fail("bad nsub/dt"); return nullptr; }
+    if (desc->n_ggv < 2 || desc->n_ggv > 16) { fail("n_ggv out of range (2..16)"); return nullptr; }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) { fail("no HIP device: libtumnmpc has no CPU fallback"); return nullptr; }
+    if (hipSetDevice(desc->device) != hipSuccess) { fail("hipSetDevice failed"); return nullptr; }
+    tum_ocp *c = new tum_ocp();
+    c->d = *desc; c->N = desc->N; c->batch = desc->batch; c->last_ms = 0; c->solved = false;
+    const int N = c->N; const size_t B = c->batch;
+    bool ok = true;
+    ok &= hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) == hipSuccess; c->own_stream = true;
+    ok &= hipEventCreate(&c->ev0) == hipSuccess && hipEventCreate(&c->ev1) == hipSuccess;
+    ok &= dalloc(&c->dX, B * (N + 1) * NX) == hipSuccess;
+    ok &= dalloc(&c->dU, B * N * NU) == hipSuccess;
+    ok &= dalloc(&c->dx0, B * NX) == hipSuccess;
+    ok &= dalloc(&c->dyref, B * (N + 1) * 6) == hipSuccess;
+    ok &= dalloc(&c->dW, B * 10) == hipSuccess;
+    ok &= dalloc(&c->dpen, B * 36) == hipSuccess;
+    ok &= dalloc(&c->dbnd, B * 6 * (N + 1)) == hipSuccess;
+    ok &= dalloc(&c->dcost, B) == hipSuccess;
+    ok &= dalloc(&c->dres, B * 3) == hipSuccess;
+    ok &= dalloc(&c->dslack, B * 6 * N) == hipSuccess;
+    ok &= dalloc(&c->dstatus, B) == hipSuccess;
+    ok &= dalloc(&c->dqpiter, B) == hipSuccess;
+    ok &= dalloc(&c->dqpstatus, B) == hipSuccess;
+    c->dqpin = nullptr;
+    if (desc->store_qp_in) ok &= dalloc(&c->dqpin, B * N * 88) == hipSuccess;
+    ok &= dalloc(&c->ddbg, (size_t)DBG_STRIDE * DBG_INST) == hipSuccess;
+    if (!ok) { fail("device allocation failed"); tum_ocp_free(c); return nullptr; }
+
+    KArgs &ka = c->ka;
+    memset(&ka, 0, sizeof(ka));
+    ka.N = N; ka.nsub = desc->nsub; ka.batch = c->batch; ka.flags = desc->store_qp_in ? 1 : 0; ka.dt = desc->dt;
+    ka.iter_max = desc->qp_iter_max > 0 ? desc->qp_iter_max : 50;
+    ka.tol_stat = desc->qp_tol_stat > 0 ? desc->qp_tol_stat : 1e-8;
+    ka.tol_ineq = desc->qp_tol_ineq > 0 ? desc->qp_tol_ineq : 1e-8;
+    ka.tol_comp = desc->qp_tol_comp > 0 ? desc->qp_tol_comp : 1e-8;
+    ka.mu0 = desc->qp_mu0 > 0 ? desc->qp_mu0 : 1.0;
+    ka.reg = 0.0;
+    Model &m = ka.mp;
+    m.lf = desc->lf; m.lr = desc->lr; m.m = desc->m; m.inv_m = 1.0 / desc->m; m.inv_Iz = 1.0 / desc->Iz;
+    m.ka = 0.5 * desc->ro * desc->S * desc->Cd;
+    m.Bf = desc->Bf; m.Cf = desc->Cf; m.Df = desc->Df; m.Ef = desc->Ef;
+    m.Br = desc->Br; m.Cr = desc->Cr; m.Dr = desc->Dr; m.Er = desc->Er;
+    m.Fz_f = desc->m * desc->lr * desc->g / (desc->lf + desc->lr);
+    m.Fz_r = desc->m * desc->lf * desc->g / (desc->lf + desc->lr);
+    m.invFmax_f = 1.0 / std::sqrt(m.Fz_f * m.Fz_f + (desc->Cf * m.Fz_f) * (desc->Cf * m.Fz_f));
+    m.invFmax_r = 1.0 / std::sqrt(m.Fz_r * m.Fz_r + (desc->Cr * m.Fz_r) * (desc->Cr * m.Fz_r));
+    m.fr0 = desc->fr0; m.fr1 = desc->fr1; m.fr4 = desc->fr4;
+    m.ax_brake = -desc->acc_min;
+    m.n_ggv = desc->n_ggv;
+    for (int i = 0; i < 16; i++) { m.ggv_v[i] = desc->ggv_v[i]; m.ggv_ax[i] = desc->ggv_ax[i]; m.ggv_ay[i] = desc->ggv_ay[i]; }
+    ka.X = c->dX; ka.U = c->dU; ka.x0 = c->dx0; ka.yref = c->dyref; ka.W = c->dW; ka.pen = c->dpen; ka.bnd = c->dbnd;
+    ka.cost = c->dcost; ka.res = c->dres; ka.slack = c->dslack;
+    ka.status = c->dstatus; ka.qp_iter = c->dqpiter; ka.qp_status = c->dqpstatus;
+    ka.qpin = c->dqpin; ka.dbg = c->ddbg; ka.dbg_stride = DBG_STRIDE;
+
+    if (hipFuncSetAttribute((const void *)nmpc_rti_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) != hipSuccess) {
+        fail("hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed"); tum_ocp_free(c); return nullptr;
+    }
+    return c;
+}
+
+extern "C" void tum_ocp_free(tum_ocp *c)
+{
+    if (!c) return;
+    hipFree(c->dX); hipFree(c->dU); hipFree(c->dx0); hipFree(c->dyref); hipFree(c->dW); hipFree(c->dpen); hipFree(c->dbnd);
+    hipFree(c->dcost); hipFree(c->dres); hipFree(c->dslack); hipFree(c->dstatus); hipFree(c->dqpiter); hipFree(c->dqpstatus);
+    if (c->dqpin) hipFree(c->dqpin);
+    hipFree(c->ddbg);
+    if (c->ev0) hipEventDestroy(c->ev0);
+    if (c->ev1) hipEventDestroy(c->ev1);
+    if (c->own_stream && c->stream) hipStreamDestroy(c->stream);
+    delete c;
+}
+
+static int chk_range(tum_ocp *c, int b0, int nb)
+{
+    if (!c) return fail("null capsule");
+    if (b0 < 0 || nb < 1 || b0 + nb > c->batch) return fail("instance range out of bounds");
+    return 0;
+}
+
+// strided scatter: host records (nb x len, `stride` apart; stride 0 = broadcast) -> device rows
+static int put(tum_ocp *c, double *dbase, size_t rec, size_t off, const double *v, int len, int b0, int nb, int stride)
+{
+    if (stride != 0 && stride < len) return fail("stride < len");
+    const double *src = v;
+    size_t spitch = (size_t)stride * sizeof(double);
+    if (stride == 0) {
+        c->stage.assign((size_t)nb * len, 0.0);
+        for (int i = 0; i < nb; i++) memcpy(&c->stage[(size_t)i * len], v, sizeof(double) * len);
+        src = c->stage.data(); spitch = (size_t)len * sizeof(double);
+    }
+    HIPCHK(hipMemcpy2DAsync(dbase + (size_t)b0 * rec + off, rec * sizeof(double), src, spitch,
+                            (size_t)len * sizeof(double), nb, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return 0;
+}
+static int fetch(tum_ocp *c, const double *dbase, size_t rec, size_t off, double *v, int len, int b0, int nb, int stride)
+{
+    if (stride < len) return fail("stride < len");
+    HIPCHK(hipMemcpy2DAsync(v, (size_t)stride * sizeof(double), dbase + (size_t)b0 * rec + off, rec * sizeof(double),
+                            (size_t)len * sizeof(double), nb, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+extern "C" int tum_ocp_set(tum_ocp *c, int stage, const char *field, const double *v, int len, int b0, int nb, int stride)
+{
+    if (chk_range(c, b0, nb)) return 1;
+    if (!field || !v) return fail("null argument");
+    const int N = c->N;
+    const std::string f(field);
+    if (f == "x") {
+        if (stage == TUM_ALL_STAGES) { if (len != (N + 1) * NX) return fail("set x: len != (N+1)*8"); return put(c, c->dX, (N + 1) * NX, 0, v, len, b0, nb, stride); }
+        if (stage < 0 || stage > N) return fail("set x: stage out of range");
+        if (len != NX) return fail("set x: mismatching dimension, expected 8");
+        return put(c, c->dX, (N + 1) * NX, (size_t)stage * NX, v, len, b0, nb, stride);
+    }
+    if (f == "u") {
+        if (stage == TUM_ALL_STAGES) { if (len != N * NU) return fail("set u: len != N*2"); return put(c, c->dU, N * NU, 0, v, len, b0, nb, stride); }
+        if (stage < 0 || stage >= N) return fail("set u: stage out of range");
+        if (len != NU) return fail("set u: mismatching dimension, expected 2");
+        return put(c, c->dU, N * NU, (size_t)stage * NU, v, len, b0, nb, stride);
+    }
+    if (f == "yref") {
+        if (stage == TUM_ALL_STAGES) { if (len != (N + 1) * 6) return fail("set yref: len != (N+1)*6"); return put(c, c->dyref, (N + 1) * 6, 0, v, len, b0, nb, stride); }
+        if (stage < 0 || stage > N) return fail("set yref: stage out of range");
+        const int want = (stage < N) ? TUM_NY : TUM_NYE;
+        if (len != want) return fail("set yref: mismatching dimension for this stage");
+        return put(c, c->dyref, (N + 1) * 6, (size_t)stage * 6, v, len, b0, nb, stride);
+    }
+    return fail("set: unknown field '" + f + "'");
+}
+
+extern "C" int tum_ocp_get(tum_ocp *c, int stage, const char *field, double *v, int len, int b0, int nb, int stride)
+{
+    if (chk_range(c, b0, nb)) return 1;
+    if (!field || !v) return fail("null argument");
+    const int N = c->N;
+    const std::string f(field);
+    if (f == "x") {
+        if (stage == TUM_ALL_STAGES) { if (len != (N + 1) * NX) return fail("get x: len"); return fetch(c, c->dX, (N + 1) * NX, 0, v, len, b0, nb, stride); }
+        if (stage < 0 || stage > N || len != NX) return fail("get x: bad stage/len");
+        return fetch(c, c->dX, (N + 1) * NX, (size_t)stage * NX, v, len, b0, nb, stride);
+    }
+    if (f == "u") {
+        if (stage == TUM_ALL_STAGES) { if (len != N * NU) return fail("get u: len"); return fetch(c, c->dU, N * NU, 0, v, len, b0, nb, stride); }
+        if (stage < 0 || stage >= N || len != NU) return fail("get u: bad stage/len");
+        return fetch(c, c->dU, N * NU, (size_t)stage * NU, v, len, b0, nb, stride);
+    }
+    if (f == "sl" || f == "su") {
+        // acados order per stage: stage 0 [sbu], stages 1..N-1 [sbu,sbx,sh], stage N [sbx,sh]
+        const int want = (stage == 0) ? 1 : (stage == N ? 2 : 3);
+        if (stage < 0 || stage > N || len != want) return fail("get sl/su: bad stage/len");
+        std::vector<double> all((size_t)nb * 6 * N);
+        if (fetch(c, c->dslack, 6 * N, 0, all.data(), 6 * N, b0, nb, 6 * N)) return 1;
+        const int side = (f == "su") ? 3 * N : 0;
+        for (int i = 0; i < nb; i++) {
+            const double *s = &all[(size_t)i * 6 * N + side];
+            double *o = v + (size_t)i * stride; int n = 0;
+            if (stage < N) o[n++] = s[stage];
+            if (stage >= 1) { o[n++] = s[N + 2 * (stage - 1)]; o[n++] = s[N + 2 * (stage - 1) + 1]; }
+        }
+        return 0;
+    }
+    return fail("get: unknown field '" + f + "'");
+}
+
+extern "C" int tum_ocp_constraints_set(tum_ocp *c, int stage, const char *field, const double *v, int len, int b0, int nb, int stride)
+{
+    if (chk_range(c, b0, nb)) return 1;
+    if (!field || !v) return fail("null argument");
+    const int N = c->N, NB = N + 1;
+    const std::string f(field);
+    if (stage < 0 || stage > N) return fail("constraints_set: stage out of range");
+    if (f == "lbx" || f == "ubx") {
+        if (stage == 0) {   // x0 equality: lbx_0 = ubx_0 = x0 (NMPC_class.py:243-246)
+            if (len != NX) return fail("constraints_set lbx/ubx at stage 0: expected 8 values (x0)");
+            return put(c, c->dx0, NX, 0, v, len, b0, nb, stride);
+        }
+        if (len != 1) return fail("constraints_set lbx/ubx: expected 1 value (steering angle)");
+        return put(c, c->dbnd, 6 * NB, (size_t)(f == "lbx" ? 2 : 3) * NB + stage, v, 1, b0, nb, stride);
+    }
+    if (f == "lbu" || f == "ubu") {
+        if (stage >= N) return fail("constraints_set lbu/ubu: stage out of range");
+        if (len != 1) return fail("constraints_set lbu/ubu: expected 1 value (steering rate)");
+        return put(c, c->dbnd, 6 * NB, (size_t)(f == "lbu" ? 0 : 1) * NB + stage, v, 1, b0, nb, stride);
+    }
+    if (f == "lh" || f == "uh") {
+        if (stage == 0) return fail("constraints_set lh/uh: no nonlinear constraint at stage 0 (nh_0 = 0)");
+        if (len != 1) return fail("constraints_set lh/uh: expected 1 value");
+        return put(c, c->dbnd, 6 * NB, (size_t)(f == "lh" ? 4 : 5) * NB + stage, v, 1, b0, nb, stride);
+    }
+    return fail("constraints_set: unknown field '" + f + "'");
+}
+
+extern "C" int tum_ocp_cost_set(tum_ocp *c, int stage, const char *field, const double *v, int len, int b0, int nb, int stride)
+{
+    if (chk_range(c, b0, nb)) return 1;
+    if (!field || !v) return fail("null argument");
+    const int N = c->N;
+    const std::string f(field);
+    if (stage < 0 || stage > N) return fail("cost_set: stage out of range");
+    if (f == "W") {
+        const int ny = (stage < N) ? TUM_NY : TUM_NYE;
+        if (len != ny * ny) return fail("cost_set W: mismatching dimension");
+        const int cnt = stride == 0 ? 1 : nb;
+        std::vector<double> diag((size_t)cnt * ny);
+        for (int i = 0; i < cnt; i++) {
+            const double *Wm = v + (size_t)i * stride;
+            for (int r = 0; r < ny; r++)
+                for (int q = 0; q < ny; q++) {
+                    if (r == q) diag[(size_t)i * ny + r] = Wm[r * ny + r];
+                    else if (Wm[q * ny + r] != 0.0) return fail("cost_set W: only diagonal W supported");
+                }
+        }
+        return put(c, c->dW, 10, stage < N ? 0 : 6, diag.data(), ny, b0, nb, stride == 0 ? 0 : ny);
+    }
+    int which = -1;
+    if (f == "zl") which = 0; else if (f == "zu") which = 1; else if (f == "Zl") which = 2; else if (f == "Zu") which = 3;
+    if (which < 0) return fail("cost_set: unknown field '" + f + "'");
+    // penalty classes: 0 = stage 0 [sbu], 1 = stages 1..N-1 [sbu,sbx,sh], 2 = stage N [sbx,sh]
+    const int cls = (stage == 0) ? 0 : (stage < N ? 1 : 2);
+    const int want = (cls == 0) ? 1 : (cls == 1 ? 3 : 2);
+    if (len != want) return fail("cost_set " + f + ": mismatching dimension for this stage");
+    const int slot0 = (cls == 2) ? 1 : 0;
+    for (int j = 0; j < want; j++) {
+        const int slot = slot0 + j;
+        // element (cls, slot, which) of pen[b][3][3][4]; one strided put per slot
+        const int cnt = stride == 0 ? 1 : nb;
+        std::vector<double> col(cnt);
+        for (int i = 0; i < cnt; i++) col[i] = v[(size_t)i * stride + j];
+        if (put(c, c->dpen, 36, (size_t)(cls * 3 + slot) * 4 + which, col.data(), 1, b0, nb, stride == 0 ? 0 : 1)) return 1;
+    }
+    return 0;
+}
+
+static int launch(tum_ocp *c)
+{
+    HIPCHK(hipSetDevice(c->d.device));
+    HIPCHK(hipEventRecord(c->ev0, c->stream));
+    hipLaunchKernelGGL(nmpc_rti_kernel, dim3(c->batch), dim3(64), LDS_BYTES, c->stream, c->ka);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipEventRecord(c->ev1, c->stream));
+    c->solved = true;
+    return 0;
+}
+
+extern "C" int tum_ocp_solve_async(tum_ocp *c)
+{
+    if (!c) return fail("null capsule");
+    return launch(c);
+}
+extern "C" int tum_ocp_synchronize(tum_ocp *c)
+{
+    if (!c) return fail("null capsule");
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+extern "C" int tum_ocp_solve(tum_ocp *c)
+{
+    if (!c) { fail("null capsule"); return -1; }
+    if (launch(c)) return -1;
+    if (hipStreamSynchronize(c->stream) != hipSuccess) { fail("kernel execution failed"); return -1; }
+    std::vector<int> st(c->batch);
+    if (hipMemcpy(st.data(), c->dstatus, sizeof(int) * c->batch, hipMemcpyDeviceToHost) != hipSuccess) { fail("status copy failed"); return -1; }
+    int mx = 0;
+    for (int s : st) if (s > mx) mx = s;
+    return mx;
+}
+
+extern "C" double tum_ocp_last_kernel_ms(tum_ocp *c)
+{
+    if (!c || !c->solved) return 0.0;
+    if (hipEventSynchronize(c->ev1) != hipSuccess) return 0.0;
+    float ms = 0;
+    if (hipEventElapsedTime(&ms, c->ev0, c->ev1) != hipSuccess) return 0.0;
+    c->last_ms = ms;
+    return ms;
+}
+
+extern "C" int tum_ocp_get_cost(tum_ocp *c, double *out, int b0, int nb)
+{
+    if (chk_range(c, b0, nb)) return 1;
+    HIPCHK(hipMemcpy(out, c->dcost + b0, sizeof(double) * nb, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+extern "C" int tum_ocp_get_stats(tum_ocp *c, const char *field, void *out, int b0, int nb)
+{
+    if (!c || !field || !out) return fail("null argument");
+    const std::string f(field);
+    if (f == "time_tot") { *(double *)out = tum_ocp_last_kernel_ms(c) * 1e-3; return 0; }
+    if (chk_range(c, b0, nb)) return 1;
+    if (f == "sqp_iter") { int *o = (int *)out; for (int i = 0; i < nb; i++) o[i] = 1; return 0; }
+    if (f == "qp_iter") { HIPCHK(hipMemcpy(out, c->dqpiter + b0, sizeof(int) * nb, hipMemcpyDeviceToHost)); return 0; }
+    if (f == "status") { HIPCHK(hipMemcpy(out, c->dstatus + b0, sizeof(int) * nb, hipMemcpyDeviceToHost)); return 0; }
+    if (f == "qp_status") { HIPCHK(hipMemcpy(out, c->dqpstatus + b0, sizeof(int) * nb, hipMemcpyDeviceToHost)); return 0; }
+    if (f == "res") { HIPCHK(hipMemcpy(out, c->dres + (size_t)b0 * 3, sizeof(double) * 3 * nb, hipMemcpyDeviceToHost)); return 0; }
+    return fail("get_stats: unknown field '" + f + "'");
+}
+
+extern "C" int tum_ocp_reset(tum_ocp *c)
+{
+    if (!c) return fail("null capsule");
+    HIPCHK(hipMemsetAsync(c->dX, 0, sizeof(double) * (size_t)c->batch * (c->N + 1) * NX, c->stream));
+    HIPCHK(hipMemsetAsync(c->dU, 0, sizeof(double) * (size_t)c->batch * c->N * NU, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+extern "C" int tum_ocp_cold_start(tum_ocp *c)
+{
+    if (!c) return fail("null capsule");
+    hipLaunchKernelGGL(cold_start_kernel, dim3(c->batch), dim3(64), 0, c->stream, c->dX, c->dU, c->dx0, c->N, c->batch);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+extern "C" int tum_ocp_get_from_qp_in(tum_ocp *c, int stage, const char *field, double *out, int len, int b0, int nb, int stride)
+{
+    if (chk_range(c, b0, nb)) return 1;
+    if (!c->dqpin) return fail("get_from_qp_in: capsule created without store_qp_in");
+    if (!c->solved) return fail("get_from_qp_in: no solve yet");
+    if (stage < 0 || stage >= c->N) return fail("get_from_qp_in: stage out of range");
+    const std::string f(field ? field : "");
+    int off, n, rows, cols;
+    if (f == "A") { off = 0; n = 64; rows = 8; cols = 8; }
+    else if (f == "B") { off = 64; n = 16; rows = 8; cols = 2; }
+    else if (f == "b") { off = 80; n = 8; rows = 8; cols = 1; }
+    else return fail("get_from_qp_in: unknown field '" + f + "'");
+    if (len != n || stride < n) return fail("get_from_qp_in: bad len/stride");
+    std::vector<double> tmp((size_t)nb * n);
+    if (fetch(c, c->dqpin, (size_t)c->N * 88, (size_t)stage * 88 + off, tmp.data(), n, b0, nb, n)) return 1;
+    for (int i = 0; i < nb; i++)          // device keeps row-major, acados hands out column-major
+        for (int r = 0; r < rows; r++)
+            for (int q = 0; q < cols; q++) out[(size_t)i * stride + q * rows + r] = tmp[(size_t)i * n + r * cols + q];
+    return 0;
+}
+
+extern "C" int tum_ocp_set_stream(tum_ocp *c, void *hip_stream)
+{
+    if (!c) return fail("null capsule");
+    if (c->own_stream && c->stream) hipStreamDestroy(c->stream);
+    c->stream = (hipStream_t)hip_stream; c->own_stream = false;
+    return 0;
+}
+
+extern "C" int tum_ocp_get_device(tum_ocp *c, const char *field, void *dst, int b0, int nb)
+{
+    if (chk_range(c, b0, nb)) return 1;
+    if (!field || !dst) return fail("null argument");
+    const int N = c->N;
+    const std::string f(field);
+    hipStream_t s = c->stream;
+    if (f == "u0") { HIPCHK(hipMemcpy2DAsync(dst, 2 * 8, c->dU + (size_t)b0 * N * NU, (size_t)N * NU * 8, 2 * 8, nb, hipMemcpyDeviceToDevice, s)); return 0; }
+    if (f == "x1") { HIPCHK(hipMemcpy2DAsync(dst, 8 * 8, c->dX + (size_t)b0 * (N + 1) * NX + NX, (size_t)(N + 1) * NX * 8, 8 * 8, nb, hipMemcpyDeviceToDevice, s)); return 0; }
+    if (f == "cost") { HIPCHK(hipMemcpyAsync(dst, c->dcost + b0, 8 * (size_t)nb, hipMemcpyDeviceToDevice, s)); return 0; }
+    if (f == "X") { HIPCHK(hipMemcpyAsync(dst, c->dX + (size_t)b0 * (N + 1) * NX, 8 * (size_t)nb * (N + 1) * NX, hipMemcpyDeviceToDevice, s)); return 0; }
+    if (f == "U") { HIPCHK(hipMemcpyAsync(dst, c->dU + (size_t)b0 * N * NU, 8 * (size_t)nb * N * NU, hipMemcpyDeviceToDevice, s)); return 0; }
+    if (f == "status") { HIPCHK(hipMemcpyAsync(dst, c->dstatus + b0, 4 * (size_t)nb, hipMemcpyDeviceToDevice, s)); return 0; }
+    if (f == "qp_iter") { HIPCHK(hipMemcpyAsync(dst, c->dqpiter + b0, 4 * (size_t)nb, hipMemcpyDeviceToDevice, s)); return 0; }
+    return fail("get_device: unknown field '" + f + "'");
+}
+
+extern "C" int tum_ocp_debug_dump(tum_ocp *c, int b, double *out, int len)
+{
+    if (!c) return fail("null capsule");
+    if (b < 0 || b >= DBG_INST || b >= c->batch) return fail("debug_dump: instance out of range");
+    if (len > DBG_STRIDE) len = DBG_STRIDE;
+    c->ka.flags |= 2;
+    if (launch(c)) return 1;
+    HIPCHK(hipStreamSynchronize(c->stream));
+    c->ka.flags &= ~2;
+    HIPCHK(hipMemcpy(out, c->ddbg + (size_t)b * DBG_STRIDE, sizeof(double) * len, hipMemcpyDeviceToHost));
+    return 0;
+}

@@ -1,0 +1,320 @@
+"""
+solver.py -- ctypes binding of libtumnmpc.so with the AcadosOcpSolver method surface.
+
+`BatchedOcpSolver` mirrors the methods of acados_template.AcadosOcpSolver that the reference's
+controller classes call (complete list):
+    solve, set, get, cost_set, constraints_set, get_cost, get_stats, reset, get_from_qp_in
+  call sites: Model_Predictive_Controller/Nominal_NMPC/NMPC_class.py:111-112,172,178,183,193,198,202-205,
+  245-246,251,254,295-317; Stochastic_NMPC/SNMPC_class.py:124,130,198;
+  Reduced_Robustified_NMPC/Reduced_Robustified_NMPC_class.py:264,280,295,298,335-336,359.
+With batch == 1 every method takes / returns exactly the shapes acados does, so the reference's
+controller code runs unchanged on it. With batch > 1 values gain a leading batch axis; a value
+without it is broadcast to all instances.
+
+There is NO CPU fallback: if the HIP library or a GPU is missing, construction raises.
+"""
+import ctypes
+import os
+
+import numpy as np
+
+from . import config as _config
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libtumnmpc.so")
+ALL_STAGES = -1
+
+
+class TumOcpDesc(ctypes.Structure):
+    _fields_ = (
+        [("N", ctypes.c_int), ("nsub", ctypes.c_int), ("dt", ctypes.c_double),
+         ("batch", ctypes.c_int), ("device", ctypes.c_int)]
+        + [(n, ctypes.c_double) for n in
+           ("lf", "lr", "m", "Iz", "ro", "S", "Cd", "Bf", "Cf", "Df", "Ef", "Br", "Cr", "Dr", "Er",
+            "g", "fr0", "fr1", "fr4", "acc_min")]
+        + [("n_ggv", ctypes.c_int),
+           ("ggv_v", ctypes.c_double * 16), ("ggv_ax", ctypes.c_double * 16), ("ggv_ay", ctypes.c_double * 16),
+           ("qp_iter_max", ctypes.c_int),
+           ("qp_tol_stat", ctypes.c_double), ("qp_tol_ineq", ctypes.c_double), ("qp_tol_comp", ctypes.c_double),
+           ("qp_mu0", ctypes.c_double), ("store_qp_in", ctypes.c_int)]
+    )
+
+
+_lib = None
+# every symbol include/tum_nmpc.h declares (tests/test_cabi.py checks the .so exports them all)
+C_SYMBOLS = ["tum_ocp_create", "tum_ocp_free", "tum_ocp_last_error", "tum_ocp_batch", "tum_ocp_horizon",
+             "tum_ocp_set", "tum_ocp_get", "tum_ocp_constraints_set", "tum_ocp_cost_set",
+             "tum_ocp_solve", "tum_ocp_solve_async", "tum_ocp_synchronize",
+             "tum_ocp_get_cost", "tum_ocp_get_stats", "tum_ocp_reset", "tum_ocp_get_from_qp_in",
+             "tum_ocp_set_stream", "tum_ocp_get_device", "tum_ocp_cold_start", "tum_ocp_last_kernel_ms",
+             "tum_ocp_debug_dump"]
+
+
+def load_library(path=None):
+    """dlopen libtumnmpc.so (built by __graft_entry__.build()); raises if it is missing."""
+    global _lib
+    if _lib is not None and path is None:
+        return _lib
+    p = path or LIB_PATH
+    if not os.path.exists(p):
+        raise RuntimeError(f"{p} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                           "(the solver has no CPU fallback)")
+    L = ctypes.CDLL(p)
+    dp = ctypes.POINTER(ctypes.c_double)
+    vp, ci, cs = ctypes.c_void_p, ctypes.c_int, ctypes.c_char_p
+    L.tum_ocp_create.restype = vp; L.tum_ocp_create.argtypes = [ctypes.POINTER(TumOcpDesc)]
+    L.tum_ocp_free.restype = None; L.tum_ocp_free.argtypes = [vp]
+    L.tum_ocp_last_error.restype = cs; L.tum_ocp_last_error.argtypes = []
+    L.tum_ocp_batch.argtypes = [vp]; L.tum_ocp_horizon.argtypes = [vp]
+    for name in ("tum_ocp_set", "tum_ocp_constraints_set", "tum_ocp_cost_set"):
+        getattr(L, name).argtypes = [vp, ci, cs, dp, ci, ci, ci, ci]
+    L.tum_ocp_get.argtypes = [vp, ci, cs, dp, ci, ci, ci, ci]
+    L.tum_ocp_get_from_qp_in.argtypes = [vp, ci, cs, dp, ci, ci, ci, ci]
+    L.tum_ocp_solve.argtypes = [vp]; L.tum_ocp_solve_async.argtypes = [vp]; L.tum_ocp_synchronize.argtypes = [vp]
+    L.tum_ocp_get_cost.argtypes = [vp, dp, ci, ci]
+    L.tum_ocp_get_stats.argtypes = [vp, cs, vp, ci, ci]
+    L.tum_ocp_reset.argtypes = [vp]; L.tum_ocp_cold_start.argtypes = [vp]
+    L.tum_ocp_set_stream.argtypes = [vp, vp]
+    L.tum_ocp_get_device.argtypes = [vp, cs, vp, ci, ci]
+    L.tum_ocp_last_kernel_ms.restype = ctypes.c_double; L.tum_ocp_last_kernel_ms.argtypes = [vp]
+    L.tum_ocp_debug_dump.argtypes = [vp, ci, dp, ci]
+    if path is None:
+        _lib = L
+    return L
+
+
+def make_desc(N, dt, nsub, batch, device=0, cfg=None, store_qp_in=False, qp_iter_max=50,
+              qp_tol=(1e-8, 1e-8, 1e-8), qp_mu0=1.0):
+    cfg = cfg or _config.default_config()
+    d = TumOcpDesc()
+    d.N, d.nsub, d.dt, d.batch, d.device = int(N), int(nsub), float(dt), int(batch), int(device)
+    for k in ("lf", "lr", "m", "Iz", "ro", "S", "Cd", "acc_min"):
+        setattr(d, k, float(cfg["veh"][k]))
+    for k in ("Bf", "Cf", "Df", "Ef", "Br", "Cr", "Dr", "Er"):
+        setattr(d, k, float(cfg["tire"][k]))
+    for k in ("g", "fr0", "fr1", "fr4"):
+        setattr(d, k, float(cfg["phys"][k]))
+    n = len(cfg["ggv"]["v"])
+    if n > 16:
+        raise ValueError("ggv table longer than 16 rows")
+    d.n_ggv = n
+    for i in range(n):
+        d.ggv_v[i], d.ggv_ax[i], d.ggv_ay[i] = cfg["ggv"]["v"][i], cfg["ggv"]["ax"][i], cfg["ggv"]["ay"][i]
+    d.qp_iter_max = int(qp_iter_max)
+    d.qp_tol_stat, d.qp_tol_ineq, d.qp_tol_comp = (float(t) for t in qp_tol)
+    d.qp_mu0 = float(qp_mu0)
+    d.store_qp_in = 1 if store_qp_in else 0
+    return d
+
+
+def _dp(a):
+    return a.ctypes.data_as(ctypes.POINTER(ctypes.c_double))
+
+
+class BatchedOcpSolver:
+    """`batch` independent copies of the nominal NMPC OCP on one MI355X; acados method names."""
+
+    def __init__(self, N=38, dt=0.08, nsub=3, batch=1, device=0, cfg=None, store_qp_in=False,
+                 qp_iter_max=50, qp_tol=(1e-8, 1e-8, 1e-8), qp_mu0=1.0):
+        self._L = load_library()
+        self.N, self.dt, self.nsub, self.batch = int(N), float(dt), int(nsub), int(batch)
+        self.cfg = cfg or _config.default_config()
+        self._desc = make_desc(N, dt, nsub, batch, device, self.cfg, store_qp_in, qp_iter_max, qp_tol, qp_mu0)
+        self._h = self._L.tum_ocp_create(ctypes.byref(self._desc))
+        if not self._h:
+            raise RuntimeError("tum_ocp_create failed: " + self._err())
+        self.status = 0
+
+    # ------------------------------------------------------------------ plumbing
+    def _err(self):
+        e = self._L.tum_ocp_last_error()
+        return e.decode() if e else ""
+
+    def _chk(self, rc, what):
+        if rc != 0:
+            raise Exception(f"BatchedOcpSolver.{what}: {self._err()}")
+
+    def __del__(self):
+        try:
+            if getattr(self, "_h", None):
+                self._L.tum_ocp_free(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+    def _put(self, fn, stage, field, value, what):
+        v = np.ascontiguousarray(value, dtype=np.float64)
+        if v.ndim >= 2 and v.shape[0] == self.batch and self.batch > 1:
+            v = v.reshape(self.batch, -1)
+            ln = v.shape[1]
+            self._chk(fn(self._h, stage, field.encode(), _dp(v), ln, 0, self.batch, ln), what)
+        else:
+            if self.batch > 1 and v.ndim >= 1 and v.shape[0] == self.batch and field in ("uh", "lh", "lbu", "ubu"):
+                v = v.reshape(self.batch, 1)
+                self._chk(fn(self._h, stage, field.encode(), _dp(v), 1, 0, self.batch, 1), what)
+                return
+            v = v.reshape(-1)
+            self._chk(fn(self._h, stage, field.encode(), _dp(v), v.size, 0, self.batch, 0), what)
+
+    def _out(self, a):
+        return a[0] if self.batch == 1 else a
+
+    # ------------------------------------------------------------------ acados surface
+    def set(self, stage, field, value):
+        """acados_solver.set(stage, 'x'|'u'|'yref', value)"""
+        self._put(self._L.tum_ocp_set, stage, field, value, "set")
+
+    def get(self, stage, field):
+        """acados_solver.get(stage, 'x'|'u'|'sl'|'su')"""
+        N = self.N
+        if field == "x":
+            ln = 8
+        elif field == "u":
+            ln = 2
+        elif field in ("sl", "su"):
+            ln = 1 if stage == 0 else (2 if stage == N else 3)
+        else:
+            raise Exception(f"BatchedOcpSolver.get: unknown field '{field}'")
+        out = np.zeros((self.batch, ln))
+        self._chk(self._L.tum_ocp_get(self._h, stage, field.encode(), _dp(out), ln, 0, self.batch, ln), "get")
+        return self._out(out)
+
+    def constraints_set(self, stage, field, value):
+        self._put(self._L.tum_ocp_constraints_set, stage, field, value, "constraints_set")
+
+    def cost_set(self, stage, field, value):
+        v = np.asarray(value, dtype=np.float64)
+        if field == "W":
+            ny = 6 if stage < self.N else 4
+            if v.ndim == 3:     # (batch, ny, ny): column-major per instance (diagonal => same either way)
+                v = np.ascontiguousarray(v.transpose(0, 2, 1)).reshape(v.shape[0], ny * ny)
+            else:
+                v = np.ascontiguousarray(v.T).reshape(-1)
+        self._put(self._L.tum_ocp_cost_set, stage, field, v, "cost_set")
+
+    def solve(self):
+        st = self._L.tum_ocp_solve(self._h)
+        if st < 0:
+            raise Exception("BatchedOcpSolver.solve: " + self._err())
+        self.status = st
+        return st
+
+    def get_cost(self):
+        out = np.zeros(self.batch)
+        self._chk(self._L.tum_ocp_get_cost(self._h, _dp(out), 0, self.batch), "get_cost")
+        return float(out[0]) if self.batch == 1 else out
+
+    def get_stats(self, field):
+        if field == "time_tot":
+            o = ctypes.c_double(0.0)
+            self._chk(self._L.tum_ocp_get_stats(self._h, b"time_tot", ctypes.byref(o), 0, 1), "get_stats")
+            return o.value
+        if field in ("sqp_iter", "qp_iter", "status", "qp_status"):
+            out = np.zeros(self.batch, dtype=np.int32)
+            self._chk(self._L.tum_ocp_get_stats(self._h, field.encode(), out.ctypes.data_as(ctypes.c_void_p), 0, self.batch), "get_stats")
+            if field == "sqp_iter" and self.batch == 1:
+                return int(out[0])
+            return out            # acados returns an array for qp_iter; callers take np.max
+        if field == "res":
+            out = np.zeros((self.batch, 3))
+            self._chk(self._L.tum_ocp_get_stats(self._h, b"res", out.ctypes.data_as(ctypes.c_void_p), 0, self.batch), "get_stats")
+            return self._out(out)
+        raise Exception(f"BatchedOcpSolver.get_stats: unknown field '{field}'")
+
+    def reset(self):
+        self._chk(self._L.tum_ocp_reset(self._h), "reset")
+
+    def get_from_qp_in(self, stage, field):
+        shp = {"A": (8, 8), "B": (8, 2), "b": (8,)}.get(field)
+        if shp is None:
+            raise Exception(f"BatchedOcpSolver.get_from_qp_in: unknown field '{field}'")
+        n = int(np.prod(shp))
+        out = np.zeros((self.batch, n))
+        self._chk(self._L.tum_ocp_get_from_qp_in(self._h, stage, field.encode(), _dp(out), n, 0, self.batch, n), "get_from_qp_in")
+        if len(shp) == 2:     # the C-ABI hands matrices out column-major (acados convention)
+            out = np.ascontiguousarray(out.reshape(self.batch, shp[1], shp[0]).transpose(0, 2, 1))
+        return self._out(out)
+
+    # ------------------------------------------------------------------ batch conveniences (no acados counterpart)
+    def set_x0(self, x0):
+        """lbx_0 = ubx_0 = x0 for every instance; x0: (8,) or (batch, 8)."""
+        self.constraints_set(0, "lbx", x0)
+
+    def set_yref_all(self, yref):
+        """yref: (N+1, 6) or (batch, N+1, 6); the terminal record uses its first 4 entries."""
+        y = np.ascontiguousarray(yref, dtype=np.float64)
+        if y.ndim == 3:
+            y = y.reshape(y.shape[0], -1)
+        else:
+            y = y.reshape(-1)
+        self._put(self._L.tum_ocp_set, ALL_STAGES, "yref", y, "set_yref_all")
+
+    def set_iterate(self, X=None, U=None):
+        if X is not None:
+            X = np.ascontiguousarray(X, dtype=np.float64)
+            self._put(self._L.tum_ocp_set, ALL_STAGES, "x", X.reshape(X.shape[0], -1) if X.ndim == 3 else X.reshape(-1), "set_iterate")
+        if U is not None:
+            U = np.ascontiguousarray(U, dtype=np.float64)
+            self._put(self._L.tum_ocp_set, ALL_STAGES, "u", U.reshape(U.shape[0], -1) if U.ndim == 3 else U.reshape(-1), "set_iterate")
+
+    def get_iterate(self):
+        N = self.N
+        X = np.zeros((self.batch, (N + 1) * 8)); U = np.zeros((self.batch, N * 2))
+        self._chk(self._L.tum_ocp_get(self._h, ALL_STAGES, b"x", _dp(X), X.shape[1], 0, self.batch, X.shape[1]), "get")
+        self._chk(self._L.tum_ocp_get(self._h, ALL_STAGES, b"u", _dp(U), U.shape[1], 0, self.batch, U.shape[1]), "get")
+        return X.reshape(self.batch, N + 1, 8), U.reshape(self.batch, N, 2)
+
+    def cold_start(self):
+        """X_k = x0 for all k, U = 0 on the device (acados create/reset semantics)."""
+        self._chk(self._L.tum_ocp_cold_start(self._h), "cold_start")
+
+    def solve_async(self):
+        self._chk(self._L.tum_ocp_solve_async(self._h), "solve_async")
+
+    def synchronize(self):
+        self._chk(self._L.tum_ocp_synchronize(self._h), "synchronize")
+
+    def set_stream(self, hip_stream_ptr):
+        self._chk(self._L.tum_ocp_set_stream(self._h, ctypes.c_void_p(hip_stream_ptr)), "set_stream")
+
+    def get_device(self, field, dev_ptr, b0=0, nb=None):
+        nb = self.batch - b0 if nb is None else nb
+        self._chk(self._L.tum_ocp_get_device(self._h, field.encode(), ctypes.c_void_p(dev_ptr), b0, nb), "get_device")
+
+    def last_kernel_ms(self):
+        return float(self._L.tum_ocp_last_kernel_ms(self._h))
+
+    def debug_dump(self, b=0, n=20480):
+        out = np.zeros(n)
+        self._chk(self._L.tum_ocp_debug_dump(self._h, b, _dp(out), n), "debug_dump")
+        return out
+
+    # ------------------------------------------------------------------ reference defaults
+    def install_reference_ocp(self, Q=None, R=None, Qe=None, L1=None, L2=None, w_scale=0.01):
+        """What NMPC_STM_acados_settings.py:48-60,126-139,161-224 bakes into the solver at creation:
+        W = 0.01*blockdiag(Q,R), W_e = 0.01*Qe, bounds on delta_f / steering rate, 0 <= h <= 1,
+        slack penalties L1/L2 on every soft bound."""
+        mpc, veh = self.cfg["mpc"], self.cfg["veh"]
+        if Q is None:
+            Q = np.diag([mpc["q_lon"] / mpc["s_lon"] ** 2, mpc["q_lat"] / mpc["s_lat"] ** 2,
+                         mpc["q_yaw"] / mpc["s_yaw"] ** 2, mpc["q_vel"] / mpc["s_vel"] ** 2])
+        if R is None:
+            R = np.diag([mpc["r_jerk"] / mpc["s_jerk"] ** 2, mpc["r_steering_rate"] / mpc["s_steering_rate"] ** 2])
+        Qe = Q if Qe is None else Qe
+        L1 = mpc["L1_pen"] if L1 is None else L1
+        L2 = mpc["L2_pen"] if L2 is None else L2
+        N = self.N
+        W = np.zeros((6, 6)); W[:4, :4] = Q; W[4:, 4:] = R
+        self.cost_set(0, "W", w_scale * W)          # shared by all stages < N
+        self.cost_set(N, "W", w_scale * np.asarray(Qe))
+        for st, n in ((0, 1), (1, 3), (N, 2)):       # one representative stage per penalty class
+            for f, val in (("zl", L1), ("zu", L1), ("Zl", L2), ("Zu", L2)):
+                self.cost_set(st, f, np.ones(n) * val)
+        for k in range(N):
+            self.constraints_set(k, "lbu", np.array([veh["delta_f_dot_min"]]))
+            self.constraints_set(k, "ubu", np.array([veh["delta_f_dot_max"]]))
+        for k in range(1, N + 1):
+            self.constraints_set(k, "lbx", np.array([veh["delta_f_min"]]))
+            self.constraints_set(k, "ubx", np.array([veh["delta_f_max"]]))
+            self.constraints_set(k, "lh", np.array([0.0]))
+            self.constraints_set(k, "uh", np.array([1.0]))
