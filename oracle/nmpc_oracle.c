@@ -31,6 +31,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <stdio.h>
+#include <malloc.h>
 
 #define NX 8
 #define NU 2
@@ -368,8 +369,12 @@ static void qp_ipm(int nv, int m, const double *H, const double *q, const double
             for (int k = 0; k < M2; k++) {
                 if (pass == 0) { rc1[k] = t[k] * lam[k]; rc2[k] = s[k] * mu[k]; }
                 else {
-                    rc1[k] = t[k] * lam[k] + dt[k] * dlam[k] - sigma * gap;
-                    rc2[k] = s[k] * mu[k] + ds[k] * dmu[k] - sigma * gap;
+                    /* centring target, floored so the products settle just below tol_comp instead of
+                     * collapsing to 0 (which would blow up gamma = lam/t and the conditioning of M) */
+                    double tau = sigma * gap;
+                    if (tau < 0.1 * opt->tol_comp) tau = 0.1 * opt->tol_comp;
+                    rc1[k] = t[k] * lam[k] + dt[k] * dlam[k] - tau;
+                    rc2[k] = s[k] * mu[k] + ds[k] * dmu[k] - tau;
                 }
                 double Ds = Z[k] + mu[k] / s[k];
                 rho[k] = -rt[k] + rc1[k] / lam[k] - (rs[k] + rc2[k] / s[k]) / Ds;
@@ -652,6 +657,10 @@ void oracle_solve_batch_cold(const oracle_ocp *tmpl, int nb, const double *x0, c
                              double *u0, double *X1, double *stats, int nthreads)
 {
     (void)nthreads;
+    /* keep the per-solve work arrays (a few 100 KB) in the thread arenas: without this every solve
+     * mmap()s/munmap()s them and the threads serialise on the process address-space lock */
+    mallopt(M_MMAP_THRESHOLD, 64 << 20);
+    mallopt(M_TRIM_THRESHOLD, 256 << 20);
 #ifdef _OPENMP
 #pragma omp parallel for schedule(dynamic, 4) num_threads(nthreads)
 #endif

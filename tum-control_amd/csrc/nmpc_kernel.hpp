@@ -482,8 +482,11 @@ __global__ void __launch_bounds__(64, 1) nmpc_rti_kernel(const KArgs ka)
                     rc1[rr][sd] = R.t[rr][sd] * R.lam[rr][sd];
                     rc2[rr][sd] = R.s[rr][sd] * R.mu[rr][sd];
                     if (pass == 1) {
-                        rc1[rr][sd] += dT[rr][sd] * dL[rr][sd] - sigma * gap;
-                        rc2[rr][sd] += dS[rr][sd] * dMu[rr][sd] - sigma * gap;
+                        // centring target floored just below tol_comp: keeps gamma = lam/t (and the
+                        // conditioning of M) bounded once complementarity has converged
+                        const double tau = fmax(sigma * gap, 0.1 * ka.tol_comp);
+                        rc1[rr][sd] += dT[rr][sd] * dL[rr][sd] - tau;
+                        rc2[rr][sd] += dS[rr][sd] * dMu[rr][sd] - tau;
                     }
                     rho[rr][sd] = -R.rt[rr][sd] + rc1[rr][sd] / R.lam[rr][sd]
                                   - (R.rs[rr][sd] + rc2[rr][sd] / R.s[rr][sd]) / Ds[rr][sd];

@@ -110,13 +110,13 @@ extern "C" tum_ocp *tum_ocp_create(const tum_ocp_desc *desc)
 extern "C" void tum_ocp_free(tum_ocp *c)
 {
     if (!c) return;
-    hipFree(c->dX); hipFree(c->dU); hipFree(c->dx0); hipFree(c->dyref); hipFree(c->dW); hipFree(c->dpen); hipFree(c->dbnd);
-    hipFree(c->dcost); hipFree(c->dres); hipFree(c->dslack); hipFree(c->dstatus); hipFree(c->dqpiter); hipFree(c->dqpstatus);
-    if (c->dqpin) hipFree(c->dqpin);
-    hipFree(c->ddbg);
-    if (c->ev0) hipEventDestroy(c->ev0);
-    if (c->ev1) hipEventDestroy(c->ev1);
-    if (c->own_stream && c->stream) hipStreamDestroy(c->stream);
+    (void)hipFree(c->dX); (void)hipFree(c->dU); (void)hipFree(c->dx0); (void)hipFree(c->dyref); (void)hipFree(c->dW); (void)hipFree(c->dpen); (void)hipFree(c->dbnd);
+    (void)hipFree(c->dcost); (void)hipFree(c->dres); (void)hipFree(c->dslack); (void)hipFree(c->dstatus); (void)hipFree(c->dqpiter); (void)hipFree(c->dqpstatus);
+    if (c->dqpin) (void)hipFree(c->dqpin);
+    (void)hipFree(c->ddbg);
+    if (c->ev0) (void)hipEventDestroy(c->ev0);
+    if (c->ev1) (void)hipEventDestroy(c->ev1);
+    if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
 
@@ -390,7 +390,7 @@ extern "C" int tum_ocp_get_from_qp_in(tum_ocp *c, int stage, const char *field, 
 extern "C" int tum_ocp_set_stream(tum_ocp *c, void *hip_stream)
 {
     if (!c) return fail("null capsule");
-    if (c->own_stream && c->stream) hipStreamDestroy(c->stream);
+    if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
     c->stream = (hipStream_t)hip_stream; c->own_stream = false;
     return 0;
 }

@@ -1,0 +1,153 @@
+"""
+nmpc.py -- host-side mirror of the reference's nominal NMPC controller interface, on top of the
+HIP solver. Same names, argument meaning and return values as
+  Model_Predictive_Controller/Nominal_NMPC/NMPC_STM_acados_settings.py:16,245   acados_settings(...)
+  Model_Predictive_Controller/Nominal_NMPC/NMPC_class.py:34-317                 Nonlinear_Model_Predictive_Controller
+so that main.py / Utils/SimulationMode_main_class.py drive it unchanged. (The RL weight-switching
+branch, NMPC_class.py:120-160,208-239, is out of scope: it needs stable_baselines3 and is ML around
+the controller, not the solve.)
+"""
+import types
+
+import numpy as np
+
+from . import config as _config
+from .solver import BatchedOcpSolver
+
+
+def acados_settings(Tf, N, x0, Q, R, Qe, L1_pen, L2_pen, ax_max_interpolant=None, ay_max_interpolant=None,
+                    combined_acc_limits=2, veh_params_file=None, tire_params_file=None,
+                    solver_generate_C_code=True, solver_build=True, cfg=None, batch=1, device=0,
+                    store_qp_in=False):
+    """Builds the nominal OCP solver (NMPC_STM_acados_settings.py:16-245) and returns
+    (constraints, model, acados_solver, ocp) like the reference. The interpolant / file / codegen
+    arguments are accepted for signature compatibility; the gg table and vehicle constants come
+    from `cfg` (config.default_config() or config.load_reference_config())."""
+    if combined_acc_limits != 2:
+        raise NotImplementedError("only combined_acc_limits == 2 (circle), the shipped variant, is built")
+    cfg = cfg or _config.default_config()
+    veh = cfg["veh"]
+    solver = BatchedOcpSolver(N=N, dt=Tf / N, nsub=3, batch=batch, device=device, cfg=cfg, store_qp_in=store_qp_in)
+    solver.install_reference_ocp(Q=np.asarray(Q), R=np.asarray(R), Qe=np.asarray(Qe), L1=L1_pen, L2=L2_pen, w_scale=0.01)
+    solver.constraints_set(0, "lbx", np.asarray(x0, dtype=float))
+    solver.constraints_set(0, "ubx", np.asarray(x0, dtype=float))
+    solver.cold_start()          # acados create: x_k = x0, u = 0
+    constraints = types.SimpleNamespace(lat_acc_min=veh["lat_acc_min"], lat_acc_max=veh["lat_acc_max"],
+                                        alat=lambda x: x[3] * x[5], a_lat=lambda x: x[3] * x[5])
+    model = types.SimpleNamespace(
+        name="pred_dynamic_bicycle_model", nx=8, nu=2,
+        jerk_min=veh["jerk_min"], jerk_max=veh["jerk_max"], acc_min=veh["acc_min"], acc_max=veh["acc_max"],
+        delta_f_min=veh["delta_f_min"], delta_f_max=veh["delta_f_max"],
+        delta_f_dot_min=veh["delta_f_dot_min"], delta_f_dot_max=veh["delta_f_dot_max"],
+        params=types.SimpleNamespace(lf=veh["lf"], lr=veh["lr"], m=veh["m"], Iz=veh["Iz"],
+                                     veh_length=veh["veh_length"], veh_width=veh["veh_width"], **cfg["tire"]),
+        x0=np.zeros(8))
+    ocp = types.SimpleNamespace(cost=types.SimpleNamespace(cost_type="NONLINEAR_LS"), dims=types.SimpleNamespace(N=N),
+                                nh=1, nh_e=1)
+    return constraints, model, solver, ocp
+
+
+class Nonlinear_Model_Predictive_Controller:
+    """NMPC_class.py:34-317. `sim_main_params` needs Tp, Ts, Ts_MPC (dict); config_path / MPC_params_file
+    may point at a TUM-CONTROL Config directory, or be None to use the built-in EDGAR constants."""
+
+    def __init__(self, config_path=None, MPC_params_file=None, sim_main_params=None, X0_MPC=None, device=0,
+                 store_qp_in=False):
+        if config_path is not None and MPC_params_file is not None:
+            self.cfg = _config.load_reference_config(config_path, sim_main_params, MPC_params_file)
+        else:
+            self.cfg = _config.default_config()
+        sim = dict(self.cfg["sim"])
+        if sim_main_params:
+            sim.update({k: sim_main_params[k] for k in ("Tp", "Ts", "Ts_MPC") if k in sim_main_params})
+        self.MPC_params = self.cfg["mpc"]
+        self.Tp, self.Ts, self.Ts_MPC = sim["Tp"], sim["Ts"], sim["Ts_MPC"]
+        self.N = int(self.Tp / self.Ts_MPC)
+        m = self.MPC_params
+        self.L1_pen, self.L2_pen = m["L1_pen"], m["L2_pen"]
+        self.Q = np.diag([m["q_lon"] / m["s_lon"] ** 2, m["q_lat"] / m["s_lat"] ** 2,
+                          m["q_yaw"] / m["s_yaw"] ** 2, m["q_vel"] / m["s_vel"] ** 2])
+        self.R = np.diag([m["r_jerk"] / m["s_jerk"] ** 2, m["r_steering_rate"] / m["s_steering_rate"] ** 2])
+        self.Qe = self.Q
+        self.combined_acc_limits = m["combined_acc_limits"]
+        self._device, self._store_qp_in = device, store_qp_in
+        X0_MPC = np.zeros(8) if X0_MPC is None else np.asarray(X0_MPC, dtype=float)
+        self.constraint, self.model, self.acados_solver, self.ocp = acados_settings(
+            self.Tp, self.N, X0_MPC, self.Q, self.R, self.Qe, self.L1_pen, self.L2_pen,
+            combined_acc_limits=self.combined_acc_limits, cfg=self.cfg, device=device, store_qp_in=store_qp_in)
+        self.costfunction_type = self.ocp.cost.cost_type
+        self.nx = 8
+        self.x0 = X0_MPC
+        self.acados_solver.constraints_set(0, "lbx", self.x0)
+        self.acados_solver.constraints_set(0, "ubx", self.x0)
+        self.stats = np.zeros(5)
+        self.pred_X = np.empty((0, self.nx))
+        self.nh, self.nh_e = 1, 1
+        self.WMPC = False
+
+    def solve(self, current_ref_traj):
+        """NMPC_class.py:163-241: set yref on every stage, one SQP-RTI step, read u0 / predictions / stats."""
+        s, N = self.acados_solver, self.N
+        for j in range(N):
+            yref = np.array([current_ref_traj['pos_x'][j], current_ref_traj['pos_y'][j],
+                             current_ref_traj['ref_yaw'][j], current_ref_traj['ref_v'][j], 0, 0])
+            s.set(j, "yref", yref)
+        yref_N = np.array([current_ref_traj['pos_x'][N], current_ref_traj['pos_y'][N],
+                           current_ref_traj['ref_yaw'][N], current_ref_traj['ref_v'][N]])
+        s.set(N, "yref", yref_N)
+        status = s.solve()
+        u0 = s.get(0, "u")
+        if status == 0:
+            pred_X = np.empty((0, self.nx))
+            for j in range(N):
+                pred_X = np.concatenate((pred_X, np.array(s.get(j, "x")).reshape(1, -1)), axis=0)
+            self.pred_X = pred_X
+        self.stats[0] = s.get_cost()
+        self.stats[1] = s.get_stats('time_tot')
+        self.stats[2] = s.get_stats('sqp_iter')
+        self.stats[3] = np.max(s.get_stats('qp_iter'))
+        self.stats[4] = status
+        return u0, self.pred_X, self.stats
+
+    def set_initial_state(self, x0):
+        self.x0 = x0
+        self.acados_solver.constraints_set(0, "lbx", self.x0)
+        self.acados_solver.constraints_set(0, "ubx", self.x0)
+
+    def reset(self, x0):
+        self.acados_solver.reset()
+        self.set_initial_state(x0)
+        for i in range(self.N + 1):
+            self.acados_solver.set(i, 'x', self.x0)
+
+    def reintialize_solver(self, X0_MPC, solver_generate_C_code=False, solver_build=False):
+        self.constraint, self.model, self.acados_solver, self.ocp = acados_settings(
+            self.Tp, self.N, X0_MPC, self.Q, self.R, self.Qe, self.L1_pen, self.L2_pen,
+            combined_acc_limits=self.combined_acc_limits, cfg=self.cfg, device=self._device,
+            store_qp_in=self._store_qp_in)
+        self.set_initial_state(X0_MPC)
+
+    def update_cost_function_weights(self, params):
+        """NMPC_class.py:269-317: params = [q_xy, q_yaw, q_vel, r_jerk, r_steering_rate, L1, L2]; W is
+        installed RAW (no 0.01 factor), slack penalties on every stage."""
+        if hasattr(params, "numpy"):
+            params = params.numpy()
+        params = np.asarray(params, dtype=float)
+        Q = np.diag([params[0], params[0], params[1], params[2]])
+        R = np.diag([params[3], params[4]])
+        L1, L2 = params[5], params[6]
+        W = np.zeros((6, 6)); W[:4, :4] = Q; W[4:, 4:] = R
+        s, N = self.acados_solver, self.N
+        for i in range(N):
+            s.cost_set(i, 'W', W)
+        s.cost_set(N, 'W', Q)
+        z0, Z0 = np.ones(self.nh) * L1, np.ones(self.nh) * L2
+        for f, v in (('zl', z0), ('zu', z0), ('Zl', Z0), ('Zu', Z0)):
+            s.cost_set(0, f, v)
+        ze, Ze = np.ones(self.nh_e + 1) * L1, np.ones(self.nh_e + 1) * L2
+        for f, v in (('zl', ze), ('zu', ze), ('Zl', Ze), ('Zu', Ze)):
+            s.cost_set(N, f, v)
+        z, Z = np.ones(self.nh + 2) * L1, np.ones(self.nh + 2) * L2
+        for i in range(1, N):
+            for f, v in (('zl', z), ('zu', z), ('Zl', Z), ('Zu', Z)):
+                s.cost_set(i, f, v)

@@ -56,6 +56,12 @@ def load_library(path=None):
     if _lib is not None and path is None:
         return _lib
     p = path or LIB_PATH
+    try:
+        # torch ships its own HIP runtime: let it load first so that libtumnmpc.so binds to the same
+        # libamdhip64 (two runtimes in one process lose the device)
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     if not os.path.exists(p):
         raise RuntimeError(f"{p} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                            "(the solver has no CPU fallback)")
@@ -307,7 +313,8 @@ class BatchedOcpSolver:
         W = np.zeros((6, 6)); W[:4, :4] = Q; W[4:, 4:] = R
         self.cost_set(0, "W", w_scale * W)          # shared by all stages < N
         self.cost_set(N, "W", w_scale * np.asarray(Qe))
-        for st, n in ((0, 1), (1, 3), (N, 2)):       # one representative stage per penalty class
+        classes = ((0, 1), (1, 3), (N, 2)) if N > 1 else ((0, 1), (N, 2))
+        for st, n in classes:                        # one representative stage per penalty class
             for f, val in (("zl", L1), ("zu", L1), ("Zl", L2), ("Zu", L2)):
                 self.cost_set(st, f, np.ones(n) * val)
         for k in range(N):
