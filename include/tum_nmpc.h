@@ -122,6 +122,10 @@ double tum_ocp_last_kernel_ms(tum_ocp *c);
 /* debug: dump of condensed-QP intermediates of instance b (see csrc/nmpc_kernel.hip) */
 int tum_ocp_debug_dump(tum_ocp *c, int b, double *out, int len);
 
+/* development aid: one solve with in-kernel phase timers; out = batch x 12 shader-cycle counters
+ * [linearise, condense, ipm-residuals, M assembly, Cholesky, rhs, tri-solves, row updates, (iteration tail), expand+cost] */
+int tum_ocp_profile_phases(tum_ocp *c, long long *out);
+
 #ifdef __cplusplus
 }
 #endif

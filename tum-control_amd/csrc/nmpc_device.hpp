@@ -63,7 +63,7 @@ struct Model {
 };
 
 struct KArgs {
-    int N, nsub, batch, flags;                        // flags: 1 store_qp_in, 2 debug dump
+    int N, nsub, batch, flags;                        // flags: 1 store_qp_in, 2 debug dump, 4 phase timers
     double dt;
     int iter_max;
     double tol_stat, tol_ineq, tol_comp, mu0, reg;
@@ -75,6 +75,7 @@ struct KArgs {
     double *qpin;                                     // [b][N][88]  (A 64 | B 16 | b 8), row-major
     double *dbg;                                      // debug dump, instance 0.. (flags&2)
     int dbg_stride;
+    long long *prof;                                  // [b][12] phase cycle counters (flags&4)
 };
 
 // ---------------------------------------------------------------- wave helpers

@@ -15,6 +15,9 @@ struct RowState {
     double rs[3][2], rt[3][2];
 };
 
+// optional in-kernel phase timers (flags & 4): cycles per phase accumulated into ka.prof[b][16]
+#define TUM_TICK(slot) do { if (ka.flags & 4) { const long long t_ = __builtin_readcyclecounter(); pacc[slot] += t_ - tprev; tprev = t_; } } while (0)
+
 __device__ __forceinline__ int acados_status(int qp_status) { return (qp_status == 0 || qp_status == 1) ? 0 : 4; }
 
 __global__ void __launch_bounds__(64, 1) nmpc_rti_kernel(const KArgs ka)
@@ -39,6 +42,8 @@ __global__ void __launch_bounds__(64, 1) nmpc_rti_kernel(const KArgs ka)
     const double *gpen = ka.pen + (size_t)b * 36;
     const double *gbnd = ka.bnd + (size_t)b * 6 * (N + 1);
 
+    long long pacc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    long long tprev = __builtin_readcyclecounter();
     // ------------------------------------------------------------ phase 0: loads
     for (int i = lane; i < (N + 1) * NX; i += 64) sX[i] = gX[i];
     for (int i = lane; i < NVP; i += 64) sU[i] = (i < nv) ? gU[i] : 0.0;
@@ -98,6 +103,7 @@ __global__ void __launch_bounds__(64, 1) nmpc_rti_kernel(const KArgs ka)
     }
     wsync();
 
+    TUM_TICK(0);
     // ------------------------------------------------------------ phase 2: condense
     // bank 0: column `lane` (stage lane>>1, input lane&1); bank 1: column 64+lane for lane < 16,
     // lane 16 of bank 1 carries g_k (the response to dx_0 and the defects b_k).
@@ -231,6 +237,7 @@ __global__ void __launch_bounds__(64, 1) nmpc_rti_kernel(const KArgs ka)
         for (int i = lane; i < (N + 1) * NX; i += 64) dbg[12960 + i] = sG[i];
     }
 
+    TUM_TICK(1);
     // ------------------------------------------------------------ phase 3: interior point
     RowState R;
     double dval[3], lo[3], hi[3];
@@ -328,6 +335,7 @@ __global__ void __launch_bounds__(64, 1) nmpc_rti_kernel(const KArgs ka)
         if (res_stat <= ka.tol_stat * qn && res_ineq <= ka.tol_ineq && res_comp <= ka.tol_comp) { qp_status = 0; break; }
         if (it >= ka.iter_max) { qp_status = 1; break; }
 
+        TUM_TICK(2);
         // ---- gamma, M = H + C' Gamma C
         double gam[3][2], Ds[3][2];
 #pragma unroll
@@ -398,6 +406,7 @@ __global__ void __launch_bounds__(64, 1) nmpc_rti_kernel(const KArgs ka)
             for (int i = lane; i < LPK; i += 64) dbg[13300 + i] = sM[i];
         }
 
+        TUM_TICK(3);
         // ---- blocked Cholesky, left-looking: M = L L'
         bool chol_ok = true;
 #pragma unroll
@@ -469,6 +478,7 @@ __global__ void __launch_bounds__(64, 1) nmpc_rti_kernel(const KArgs ka)
             for (int i = lane; i < LPK; i += 64) dbg[16540 + i] = sM[i];
         }
 
+        TUM_TICK(4);
         // ---- predictor / corrector
         double dS[3][2], dT[3][2], dL[3][2], dMu[3][2];
         double dv0 = 0.0, dv1 = 0.0, alpha = 1.0, sigma = 0.0;
@@ -508,6 +518,7 @@ __global__ void __launch_bounds__(64, 1) nmpc_rti_kernel(const KArgs ka)
                 dbg[19780 + lane] = b0;
                 if (lane < 16) dbg[19780 + 64 + lane] = b1;
             }
+            TUM_TICK(5);
             // forward substitution L y = b (column oriented)
             for (int j = 0; j < 64; j++) {
                 const double yj = rl(b0, j) * sInvD[j];
@@ -533,6 +544,7 @@ __global__ void __launch_bounds__(64, 1) nmpc_rti_kernel(const KArgs ka)
                 if (lane < j) b0 -= sM[lpk(j, lane)] * xj;
             }
             dv0 = b0; dv1 = b1;
+            TUM_TICK(6);
             wsync();
             sDv[lane] = dv0;
             if (lane < 16) sDv[64 + lane] = dv1;
@@ -590,6 +602,7 @@ __global__ void __launch_bounds__(64, 1) nmpc_rti_kernel(const KArgs ka)
                 alpha = (amax >= 1.0) ? 1.0 : 0.995 * amax;
             }
         }
+        TUM_TICK(7);
         if (alpha < 1e-12) { qp_status = 2; break; }
         v0 += alpha * dv0; v1 += alpha * dv1;
         const double om = 1.0 - alpha;
@@ -605,6 +618,7 @@ __global__ void __launch_bounds__(64, 1) nmpc_rti_kernel(const KArgs ka)
     }
     const int status = acados_status(qp_status);
 
+    TUM_TICK(8);
     // ------------------------------------------------------------ phase 4: expand, full step, cost
     wsync();
     sDv[lane] = v0;
@@ -674,6 +688,9 @@ __global__ void __launch_bounds__(64, 1) nmpc_rti_kernel(const KArgs ka)
             sl[sd * 3 * N + N + 2 * lane + 1] = R.s[2][sd];
         }
     }
+    TUM_TICK(9);
+    if ((ka.flags & 4) && lane == 0)
+        for (int i = 0; i < 12; i++) ka.prof[(size_t)b * 12 + i] = pacc[i];
     if (lane == 0) {
         ka.cost[b] = cost;
         ka.status[b] = status;

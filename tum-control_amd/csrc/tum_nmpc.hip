@@ -25,6 +25,7 @@ struct tum_ocp {
     KArgs ka;
     double *dX, *dU, *dx0, *dyref, *dW, *dpen, *dbnd, *dcost, *dres, *dslack, *dqpin, *ddbg;
     int *dstatus, *dqpiter, *dqpstatus;
+    long long *dprof;
     float last_ms;
     bool solved;
     std::vector<double> stage;     // host staging
@@ -72,6 +73,7 @@ extern "C" tum_ocp *tum_ocp_create(const tum_ocp_desc *desc)
     c->dqpin = nullptr;
     if (desc->store_qp_in) ok &= dalloc(&c->dqpin, B * N * 88) == hipSuccess;
     ok &= dalloc(&c->ddbg, (size_t)DBG_STRIDE * DBG_INST) == hipSuccess;
+    ok &= dalloc(&c->dprof, B * 12) == hipSuccess;
     if (!ok) { fail("device allocation failed"); tum_ocp_free(c); return nullptr; }
 
     KArgs &ka = c->ka;
@@ -99,7 +101,7 @@ extern "C" tum_ocp *tum_ocp_create(const tum_ocp_desc *desc)
     ka.X = c->dX; ka.U = c->dU; ka.x0 = c->dx0; ka.yref = c->dyref; ka.W = c->dW; ka.pen = c->dpen; ka.bnd = c->dbnd;
     ka.cost = c->dcost; ka.res = c->dres; ka.slack = c->dslack;
     ka.status = c->dstatus; ka.qp_iter = c->dqpiter; ka.qp_status = c->dqpstatus;
-    ka.qpin = c->dqpin; ka.dbg = c->ddbg; ka.dbg_stride = DBG_STRIDE;
+    ka.qpin = c->dqpin; ka.dbg = c->ddbg; ka.dbg_stride = DBG_STRIDE; ka.prof = c->dprof;
 
     if (hipFuncSetAttribute((const void *)nmpc_rti_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) != hipSuccess) {
         fail("hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed"); tum_ocp_free(c); return nullptr;
@@ -113,7 +115,7 @@ extern "C" void tum_ocp_free(tum_ocp *c)
     (void)hipFree(c->dX); (void)hipFree(c->dU); (void)hipFree(c->dx0); (void)hipFree(c->dyref); (void)hipFree(c->dW); (void)hipFree(c->dpen); (void)hipFree(c->dbnd);
     (void)hipFree(c->dcost); (void)hipFree(c->dres); (void)hipFree(c->dslack); (void)hipFree(c->dstatus); (void)hipFree(c->dqpiter); (void)hipFree(c->dqpstatus);
     if (c->dqpin) (void)hipFree(c->dqpin);
-    (void)hipFree(c->ddbg);
+    (void)hipFree(c->ddbg); (void)hipFree(c->dprof);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
@@ -422,5 +424,18 @@ extern "C" int tum_ocp_debug_dump(tum_ocp *c, int b, double *out, int len)
     HIPCHK(hipStreamSynchronize(c->stream));
     c->ka.flags &= ~2;
     HIPCHK(hipMemcpy(out, c->ddbg + (size_t)b * DBG_STRIDE, sizeof(double) * len, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+// development aid: one solve with the in-kernel phase timers on; out = batch x 12 cycle counters
+extern "C" int tum_ocp_profile_phases(tum_ocp *c, long long *out)
+{
+    if (!c || !out) return fail("null argument");
+    c->ka.flags |= 4;
+    int rc = launch(c);
+    c->ka.flags &= ~4;
+    if (rc) return 1;
+    HIPCHK(hipStreamSynchronize(c->stream));
+    HIPCHK(hipMemcpy(out, c->dprof, sizeof(long long) * 12 * (size_t)c->batch, hipMemcpyDeviceToHost));
     return 0;
 }

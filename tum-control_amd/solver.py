@@ -47,7 +47,7 @@ C_SYMBOLS = ["tum_ocp_create", "tum_ocp_free", "tum_ocp_last_error", "tum_ocp_ba
              "tum_ocp_solve", "tum_ocp_solve_async", "tum_ocp_synchronize",
              "tum_ocp_get_cost", "tum_ocp_get_stats", "tum_ocp_reset", "tum_ocp_get_from_qp_in",
              "tum_ocp_set_stream", "tum_ocp_get_device", "tum_ocp_cold_start", "tum_ocp_last_kernel_ms",
-             "tum_ocp_debug_dump"]
+             "tum_ocp_debug_dump", "tum_ocp_profile_phases"]
 
 
 def load_library(path=None):
@@ -84,6 +84,7 @@ def load_library(path=None):
     L.tum_ocp_get_device.argtypes = [vp, cs, vp, ci, ci]
     L.tum_ocp_last_kernel_ms.restype = ctypes.c_double; L.tum_ocp_last_kernel_ms.argtypes = [vp]
     L.tum_ocp_debug_dump.argtypes = [vp, ci, dp, ci]
+    L.tum_ocp_profile_phases.argtypes = [vp, ctypes.POINTER(ctypes.c_longlong)]
     if path is None:
         _lib = L
     return L
@@ -289,6 +290,12 @@ class BatchedOcpSolver:
 
     def last_kernel_ms(self):
         return float(self._L.tum_ocp_last_kernel_ms(self._h))
+
+    def profile_phases(self):
+        """One solve with the in-kernel phase timers on: (batch, 12) shader-cycle counters."""
+        out = np.zeros((self.batch, 12), dtype=np.int64)
+        self._chk(self._L.tum_ocp_profile_phases(self._h, out.ctypes.data_as(ctypes.POINTER(ctypes.c_longlong))), "profile_phases")
+        return out
 
     def debug_dump(self, b=0, n=20480):
         out = np.zeros(n)
