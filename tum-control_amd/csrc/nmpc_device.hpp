@@ -30,27 +30,36 @@ constexpr int LPK = NVP * (NVP + 1) / 2;    // 3240 packed lower-triangular entr
 
 __host__ __device__ constexpr int tidx(int K, int I) { return K * NT - K * (K - 1) / 2 + (I - K); }   // K <= I
 __host__ __device__ constexpr int lpk(int i, int j) { return i * (i + 1) / 2 + j; }                    // i >= j
-// packed constraint matrix: stage s (1..N) owns two rows (delta, h) of 2s entries each
-__host__ __device__ constexpr int coff(int s, int which) { return 2 * s * (s - 1) + which * 2 * s; }
+// packed gg-constraint rows: stage s (1..N) owns one row (grad h' G_s) of 2s entries.
+// (The steering-angle rows need no storage: delta is a pure integrator of the steering rate, so
+//  row s of that block is dt on the odd (steering-rate) columns < 2s and 0 elsewhere.)
+__host__ __device__ constexpr int hoff(int s) { return s * (s - 1); }
 
 // LDS carve (offsets in doubles)
 constexpr int O_AB = 0;                               // NMAX*ABS              compact (Sp,S,b) per stage
-constexpr int O_M = O_AB + NMAX * ABS;                // LPK                   KKT matrix / Cholesky factor
-constexpr int O_STAGE = O_M;                          //   aliased: 4 x NVP staging rows for the H SYRK
-constexpr int O_C = O_M + LPK;                        // 2*NMAX*(NMAX+1)       packed general-constraint rows
-constexpr int O_X = O_C + 2 * NMAX * (NMAX + 1);      // (NMAX+1)*8            iterate X
+constexpr int O_M = O_AB + NMAX * ABS;                // LPK                   KKT matrix / L D L' factor
+//   aliased into the M region (dead before the first KKT assembly):
+constexpr int O_STAGE = O_M;                          //     4 x NVP staging rows for the H SYRK
+constexpr int O_RES = O_STAGE + 4 * NVP;              //     (NMAX+1)*4  y - yref of the 4 state cost rows
+constexpr int O_GH = O_RES + (NMAX + 1) * 4;          //     (NMAX+1)*4  (gh3, gh5, gh7, h) per stage
+constexpr int O_D = O_GH + (NMAX + 1) * 4;            //     2*NMAX      constant term of the general rows
+constexpr int O_CH = O_M + LPK;                       // NMAX*(NMAX+1)         packed h rows
+constexpr int O_X = O_CH + NMAX * (NMAX + 1);         // (NMAX+1)*8            iterate X
 constexpr int O_G = O_X + (NMAX + 1) * NX;            // (NMAX+1)*8            g_k (constant part of dx_k)
-constexpr int O_RES = O_G + (NMAX + 1) * NX;          // (NMAX+1)*4            y - yref of the 4 state cost rows
-constexpr int O_GH = O_RES + (NMAX + 1) * 4;          // (NMAX+1)*4            (gh3, gh5, gh7, h) per stage
-constexpr int O_D = O_GH + (NMAX + 1) * 4;            // 2*NMAX                constant term of the general rows
-constexpr int O_GAM = O_D + 2 * NMAX;                 // 2*NMAX                gamma of the general rows
-constexpr int O_WR = O_GAM + 2 * NMAX;                // 2*NMAX                rhs weights of the general rows
-constexpr int O_WB = O_WR + 2 * NMAX;                 // NMAX                  box-row scalars (gamma / weights)
-constexpr int O_DV = O_WB + NMAX;                     // NVP                   broadcast copy of a v-space vector
-constexpr int O_INVD = O_DV + NVP;                    // NVP                   1 / diag(L)
-constexpr int O_U = O_INVD + NVP;                     // NVP                   iterate U
-constexpr int LDS_DOUBLES = O_U + NVP;
+constexpr int O_ROW = O_G + (NMAX + 1) * NX;          // 36*NMAX               IPM row state [field][row*2+side][lane]
+constexpr int O_GAMH = O_ROW + 36 * NMAX;             // NMAX                  gamma of the h rows
+constexpr int O_WH = O_GAMH + NMAX;                   // NMAX                  rhs weights of the h rows
+constexpr int O_WB = O_WH + NMAX;                     // NMAX                  box-row scalars (gamma / weights)
+constexpr int O_SFX = O_WB + NMAX;                    // NMAX+8                suffix sums over the steering-angle rows
+constexpr int O_DV = O_SFX + NMAX + 8;                // NVP                   broadcast copy of a v-space vector
+constexpr int O_INVD = O_DV + NVP;                    // NVP                   1 / d_j
+constexpr int O_DD = O_INVD + NVP;                    // NVP                   d_j (pivots of L D L')
+constexpr int O_U = O_DD + NVP;                       // NVP                   iterate U
+constexpr int O_PEN = O_U + NVP;                      // 36 (+4)               slack penalties [class][slot][zl,zu,Zl,Zu]
+constexpr int LDS_DOUBLES = O_PEN + 40;
 constexpr int LDS_BYTES = LDS_DOUBLES * 8;
+static_assert(O_D + 2 * NMAX <= O_CH, "aliased condensing scratch must fit inside the KKT matrix region");
+static_assert(LDS_BYTES <= 80 * 1024, "two workgroups per CU need <= 80 KiB each");
 
 struct Model {
     double lf, lr, inv_m, inv_Iz, m, ka;            // ka = 0.5*ro*S*Cd
@@ -102,6 +111,27 @@ __device__ __forceinline__ double wave_min(double v)
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v = fmin(v, __shfl_xor(v, o, 64));
     return v;
+}
+// inclusive prefix / suffix sums over the 64 lanes
+__device__ __forceinline__ double wave_prefix(double v, int lane)
+{
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const double t = __shfl_up(v, o, 64); if (lane >= o) v += t; }
+    return v;
+}
+__device__ __forceinline__ double wave_suffix(double v, int lane)
+{
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const double t = __shfl_down(v, o, 64); if (lane + o < 64) v += t; }
+    return v;
+}
+// 1/x to ~1 ulp without the IEEE division sequence: v_rcp_f64 + two Newton steps (5 VALU instead of ~27)
+__device__ __forceinline__ double frcp(double x)
+{
+    double r = __builtin_amdgcn_rcp(x);
+    r = fma(fma(-x, r, 1.0), r, r);
+    r = fma(fma(-x, r, 1.0), r, r);
+    return r;
 }
 __device__ __forceinline__ d4 mfma(double a, double b, d4 c) { return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0); }
 __device__ __forceinline__ void wsync() { __syncthreads(); }   // 1 wave per workgroup: LDS ordering point

@@ -4,21 +4,66 @@
 
 namespace tum {
 
-// Row-side state of the interior point method held by lane l < N:
-//   row 0: steering-rate box of stage l      (variable 2l+1)
-//   row 1: steering-angle bound of stage l+1 (general row 2l)
-//   row 2: gg-circle constraint of stage l+1 (general row 2l+1)
-// side 0 = lower, 1 = upper.
-struct RowState {
-    double s[3][2], t[3][2], lam[3][2], mu[3][2];
-    double z[3][2], Z[3][2];
-    double rs[3][2], rt[3][2];
-};
-
-// optional in-kernel phase timers (flags & 4): cycles per phase accumulated into ka.prof[b][16]
-#define TUM_TICK(slot) do { if (ka.flags & 4) { const long long t_ = __builtin_readcyclecounter(); pacc[slot] += t_ - tprev; tprev = t_; } } while (0)
+// optional in-kernel phase timers (flags & 4): cycles per phase accumulated into ka.prof[b][12]
+#define TUM_TICK(slot) do { asm volatile("; TUM_MARK " #slot); if (ka.flags & 4) { const long long t_ = __builtin_readcyclecounter(); pacc[slot] += t_ - tprev; tprev = t_; } } while (0)
 
 __device__ __forceinline__ int acados_status(int qp_status) { return (qp_status == 0 || qp_status == 1) ? 0 : 4; }
+
+// Row-side state of the interior point method held by lane l < N:
+//   row 0: steering-rate box of stage l      (variable 2l+1)
+//   row 1: steering-angle bound of stage l+1 (structured row: dt on the odd columns < 2(l+1))
+//   row 2: gg-circle constraint of stage l+1 (packed row l+1 of sCh)
+// side 0 = lower, 1 = upper.
+
+// Everything derived from the lane id that the IPM uses. Instantiated from an OPAQUE copy of the lane id inside
+// the iteration loop: otherwise LICM hoists hundreds of lane predicates / LDS addresses out of the loop and the
+// register allocator spills them (SGPR masks to VGPR lanes, addresses to scratch).
+#define ROWF(f, k) sRowL[((f) * 6 + (k)) * NMAX]
+#define TUM_LANE_DEFS \
+    const bool rowlane = lane < N; \
+    const int rl_ = rowlane ? lane : 0; \
+    double *sRowL = sRow + rl_; \
+    const int cls0 = (rl_ == 0) ? 0 : 1, cls12 = (rl_ + 1 < N) ? 1 : 2; \
+    const double sc12 = (rl_ + 1 < N) ? dt : 1.0; \
+    auto pen = [&](int rr, int sd, int quad) -> double { \
+        const int cls = rr == 0 ? cls0 : cls12; \
+        return (rr == 0 ? dt : sc12) * sPen[(cls * 3 + rr) * 4 + 2 * quad + sd]; \
+    }; \
+    const bool v0on = lane < nv, v1on = (lane < 16) && (64 + lane < nv); \
+    const bool odd = lane & 1; \
+    const int lane1 = 64 + lc; \
+    auto ctw = [&](double &o0, double &o1) { \
+        double a0 = (odd && v0on) ? sWb[lane >> 1] + dt * sSfx[(lane >> 1) + 1] : 0.0; \
+        double a1 = (odd && v1on) ? sWb[32 + (lane >> 1)] + dt * sSfx[32 + (lane >> 1) + 1] : 0.0; \
+        const int s00 = (lane >> 1) + 1; \
+        double e0 = 0.0; \
+    _Pragma("unroll 8") \
+        for (int s = 1; s <= NMAX; s += 2) { \
+            const double c0 = sCh[hoff(s) + (s >= s00 ? lane : 0)]; \
+            const double c1 = sCh[hoff(s + 1) + (s + 1 >= s00 ? lane : 0)]; \
+            a0 += ((s >= s00 && s <= N) ? c0 : 0.0) * sWh[s - 1]; \
+            e0 += ((s + 1 >= s00 && s + 1 <= N) ? c1 : 0.0) * sWh[s]; \
+        } \
+        a0 += e0; \
+    _Pragma("unroll") \
+        for (int s = 33; s <= NMAX; s++) { \
+            const bool on = (lane < 16) && (lane1 < 2 * s) && (s <= N); \
+            const double c = sCh[hoff(s) + (lane1 < 2 * s ? lane1 : 0)]; \
+            a1 += (on ? c : 0.0) * sWh[s - 1]; \
+        } \
+        o0 = v0on ? a0 : 0.0; o1 = v1on ? a1 : 0.0; \
+    }; \
+    auto publish = [&](double wbox, double wdel, double wh, double *dstH) { \
+        const double sfx = wave_suffix(rowlane ? wdel : 0.0, lane); \
+        wsync(); \
+        if (lane < NMAX) { sWb[lane] = rowlane ? wbox : 0.0; dstH[lane] = rowlane ? wh : 0.0; } \
+        if (lane < NMAX + 7) sSfx[lane + 1] = (lane < N) ? sfx : 0.0; \
+        wsync(); \
+    }; \
+    int rb[NT]; \
+    _Pragma("unroll") \
+    for (int I = 0; I < NT; I++) rb[I] = lpk(16 * I + lc, 0); \
+    const int myrow0 = lpk(lane, 0), myrow1 = lpk(lane1, 0);
 
 __global__ void __launch_bounds__(64, 1) nmpc_rti_kernel(const KArgs ka)
 {
@@ -30,9 +75,10 @@ __global__ void __launch_bounds__(64, 1) nmpc_rti_kernel(const KArgs ka)
     const double dt = ka.dt;
     const Model &mp = ka.mp;
 
-    double *sAB = lds + O_AB, *sM = lds + O_M, *sStage = lds + O_STAGE, *sC = lds + O_C, *sX = lds + O_X;
-    double *sG = lds + O_G, *sRes = lds + O_RES, *sGh = lds + O_GH, *sD = lds + O_D, *sGam = lds + O_GAM;
-    double *sWr = lds + O_WR, *sWb = lds + O_WB, *sDv = lds + O_DV, *sInvD = lds + O_INVD, *sU = lds + O_U;
+    double *sAB = lds + O_AB, *sM = lds + O_M, *sStage = lds + O_STAGE, *sCh = lds + O_CH, *sX = lds + O_X;
+    double *sG = lds + O_G, *sRes = lds + O_RES, *sGh = lds + O_GH, *sD = lds + O_D, *sGamH = lds + O_GAMH;
+    double *sWh = lds + O_WH, *sWb = lds + O_WB, *sSfx = lds + O_SFX, *sDv = lds + O_DV, *sInvD = lds + O_INVD;
+    double *sDd = lds + O_DD, *sU = lds + O_U, *sPen = lds + O_PEN, *sRow = lds + O_ROW;
 
     double *gX = ka.X + (size_t)b * (N + 1) * NX;
     double *gU = ka.U + (size_t)b * N * NU;
@@ -47,6 +93,7 @@ __global__ void __launch_bounds__(64, 1) nmpc_rti_kernel(const KArgs ka)
     // ------------------------------------------------------------ phase 0: loads
     for (int i = lane; i < (N + 1) * NX; i += 64) sX[i] = gX[i];
     for (int i = lane; i < NVP; i += 64) sU[i] = (i < nv) ? gU[i] : 0.0;
+    if (lane < 36) sPen[lane] = gpen[lane];
     double Wd[6], We[4];
 #pragma unroll
     for (int i = 0; i < 6; i++) Wd[i] = gW[i];
@@ -107,96 +154,91 @@ __global__ void __launch_bounds__(64, 1) nmpc_rti_kernel(const KArgs ka)
     // ------------------------------------------------------------ phase 2: condense
     // bank 0: column `lane` (stage lane>>1, input lane&1); bank 1: column 64+lane for lane < 16,
     // lane 16 of bank 1 carries g_k (the response to dx_0 and the defects b_k).
-    double w0[8], w1[8];
-#pragma unroll
-    for (int i = 0; i < 8; i++) { w0[i] = 0.0; w1[i] = 0.0; }
     const int j0 = lane >> 1, r0 = lane & 1, j1 = 32 + (lane >> 1);
     const bool isg = (lane == 16);
-    if (isg) {
-#pragma unroll
-        for (int i = 0; i < 8; i++) { w1[i] = gx0[i] - sX[i]; sG[i] = w1[i]; }
-    }
+    const int lq = lane >> 4, lc = lane & 15;
     double q0 = 0.0, q1 = 0.0;
     d4 Ht[NTT];
 #pragma unroll
     for (int i = 0; i < NTT; i++) Ht[i] = d4{0.0, 0.0, 0.0, 0.0};
-    const int lq = lane >> 4, lc = lane & 15;
-
-    for (int k = 0; k < N; k++) {
-        const double *rec = sAB + k * ABS;
-        // bank 0
-        if (j0 < k) apply_A(rec, w0);
-        else if (j0 == k) {
+    {
+        double w0[8], w1[8];
 #pragma unroll
-            for (int i = 0; i < 6; i++) w0[i] = rec[2 + i * 7 + 5 + r0];
-            w0[6] = r0 ? dt : 0.0; w0[7] = r0 ? 0.0 : dt;
-        }
-        // bank 1
+        for (int i = 0; i < 8; i++) { w0[i] = 0.0; w1[i] = 0.0; }
         if (isg) {
-            apply_A(rec, w1);
 #pragma unroll
-            for (int i = 0; i < 8; i++) w1[i] += rec[44 + i];
-        } else if (lane < 16) {
-            if (j1 < k) apply_A(rec, w1);
-            else if (j1 == k) {
+            for (int i = 0; i < 8; i++) { w1[i] = gx0[i] - sX[i]; sG[i] = w1[i]; }
+        }
+        for (int k = 0; k < N; k++) {
+            const double *rec = sAB + k * ABS;
+            // bank 0
+            if (j0 < k) apply_A(rec, w0);
+            else if (j0 == k) {
 #pragma unroll
-                for (int i = 0; i < 6; i++) w1[i] = rec[2 + i * 7 + 5 + r0];
-                w1[6] = r0 ? dt : 0.0; w1[7] = r0 ? 0.0 : dt;
+                for (int i = 0; i < 6; i++) w0[i] = rec[2 + i * 7 + 5 + r0];
+                w0[6] = r0 ? dt : 0.0; w0[7] = r0 ? 0.0 : dt;
             }
-        }
-        const int s = k + 1;                         // stage whose G_s the lanes now hold
-        const double sc = (s < N) ? dt : 1.0;
-        const double g3 = sGh[s * 4 + 0], g5 = sGh[s * 4 + 1], g7 = sGh[s * 4 + 2];
-        if (isg) {
+            // bank 1 (columns 64.. only exist from stage 32 on; the g column runs from the start)
+            if (isg) {
+                apply_A(rec, w1);
 #pragma unroll
-            for (int i = 0; i < 8; i++) sG[s * NX + i] = w1[i];
-            sD[2 * (s - 1)] = sX[s * NX + 6] + w1[6];
-            sD[2 * (s - 1) + 1] = sGh[s * 4 + 3] + g3 * w1[3] + g5 * w1[5] + g7 * w1[7];
-        }
-        // constraint rows of stage s and staging of the 4 cost rows
-        if (lane < 2 * s) {
-            sC[coff(s, 0) + lane] = w0[6];
-            sC[coff(s, 1) + lane] = g3 * w0[3] + g5 * w0[5] + g7 * w0[7];
-        }
-        if (lane < 16 && 64 + lane < 2 * s) {
-            sC[coff(s, 0) + 64 + lane] = w1[6];
-            sC[coff(s, 1) + 64 + lane] = g3 * w1[3] + g5 * w1[5] + g7 * w1[7];
-        }
+                for (int i = 0; i < 8; i++) w1[i] += rec[44 + i];
+            } else if (lane < 16 && k >= 32) {
+                if (j1 < k) apply_A(rec, w1);
+                else if (j1 == k) {
 #pragma unroll
-        for (int r = 0; r < 4; r++) {
-            sStage[r * NVP + lane] = w0[r];
-            if (lane < 16) sStage[r * NVP + 64 + lane] = w1[r];
-        }
-        wsync();
-        // gradient: q += sum_r sc*W_r*(res_r + g_s[r]) * G_s[r,:]
-        double wr[4];
+                    for (int i = 0; i < 6; i++) w1[i] = rec[2 + i * 7 + 5 + r0];
+                    w1[6] = r0 ? dt : 0.0; w1[7] = r0 ? 0.0 : dt;
+                }
+            }
+            const int s = k + 1;                         // stage whose G_s the lanes now hold
+            const double sc = (s < N) ? dt : 1.0;
+            const double g3 = sGh[s * 4 + 0], g5 = sGh[s * 4 + 1], g7 = sGh[s * 4 + 2];
+            if (isg) {
 #pragma unroll
-        for (int r = 0; r < 4; r++) wr[r] = sc * ((s < N) ? Wd[r] : We[r]);
-        {
-            double a0 = 0.0, a1 = 0.0;
+                for (int i = 0; i < 8; i++) sG[s * NX + i] = w1[i];
+                sD[2 * (s - 1)] = sX[s * NX + 6] + w1[6];
+                sD[2 * (s - 1) + 1] = sGh[s * 4 + 3] + g3 * w1[3] + g5 * w1[5] + g7 * w1[7];
+            }
+            // gg-constraint row of stage s and staging of the 4 cost rows
+            if (lane < 2 * s) sCh[hoff(s) + lane] = g3 * w0[3] + g5 * w0[5] + g7 * w0[7];
+            if (lane < 16 && 64 + lane < 2 * s) sCh[hoff(s) + 64 + lane] = g3 * w1[3] + g5 * w1[5] + g7 * w1[7];
 #pragma unroll
             for (int r = 0; r < 4; r++) {
-                const double e = wr[r] * (sRes[s * 4 + r] + sG[s * NX + r]);
-                a0 += e * w0[r]; a1 += e * w1[r];
+                sStage[r * NVP + lane] = w0[r];
+                if (lane < 16) sStage[r * NVP + 64 + lane] = w1[r];
             }
-            q0 += a0;
-            if (lane < 16) q1 += a1;
+            wsync();
+            // gradient: q += sum_r sc*W_r*(res_r + g_s[r]) * G_s[r,:]
+            double wr[4];
+#pragma unroll
+            for (int r = 0; r < 4; r++) wr[r] = sc * ((s < N) ? Wd[r] : We[r]);
+            {
+                double a0 = 0.0, a1 = 0.0;
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    const double e = wr[r] * (sRes[s * 4 + r] + sG[s * NX + r]);
+                    a0 += e * w0[r]; a1 += e * w1[r];
+                }
+                q0 += a0;
+                if (lane < 16) q1 += a1;
+            }
+            // Gauss-Newton Hessian SYRK (rank-4 update per stage) on the matrix cores
+            const int Ts = (2 * s + 15) >> 4;
+            const double wl = (lq == 0) ? wr[0] : (lq == 1) ? wr[1] : (lq == 2) ? wr[2] : wr[3];
+            double aop[NT], bop[NT];
+#pragma unroll
+            for (int T = 0; T < NT; T++) {
+                bop[T] = (T < Ts) ? sStage[lq * NVP + 16 * T + lc] : 0.0;
+                aop[T] = bop[T] * wl;
+            }
+#pragma unroll
+            for (int K = 0; K < NT; K++)
+#pragma unroll
+                for (int I = K; I < NT; I++)
+                    if (I < Ts) Ht[tidx(K, I)] = mfma(aop[K], bop[I], Ht[tidx(K, I)]);
+            wsync();
         }
-        // Gauss-Newton Hessian SYRK (rank-4 update per stage) on the matrix cores
-        const int Ts = (2 * s + 15) >> 4;
-        const double wl = (lq == 0) ? wr[0] : (lq == 1) ? wr[1] : (lq == 2) ? wr[2] : wr[3];
-        double aop[NT], bop[NT];
-#pragma unroll
-        for (int T = 0; T < NT; T++) {
-            bop[T] = (T < Ts) ? sStage[lq * NVP + 16 * T + lc] : 0.0;
-            aop[T] = bop[T] * wl;
-        }
-#pragma unroll
-        for (int K = 0; K < NT; K++)
-#pragma unroll
-            for (int I = K; I < NT; I++)
-                if (I < Ts) Ht[tidx(K, I)] = mfma(aop[K], bop[I], Ht[tidx(K, I)]);
-        wsync();
     }
     // input cost (R) and padding on the diagonal, gradient of the input cost
 #pragma unroll
@@ -229,9 +271,9 @@ __global__ void __launch_bounds__(64, 1) nmpc_rti_kernel(const KArgs ka)
         dbg[6400 + lane] = q0;
         if (lane < 16) dbg[6400 + 64 + lane] = q1;
         for (int s = 1; s <= N; s++)
-            for (int wch = 0; wch < 2; wch++) {
-                const int row = 2 * (s - 1) + wch;
-                for (int c = lane; c < NVP; c += 64) dbg[6480 + row * NVP + c] = (c < 2 * s) ? sC[coff(s, wch) + c] : 0.0;
+            for (int c = lane; c < NVP; c += 64) {
+                dbg[6480 + (2 * (s - 1)) * NVP + c] = ((c & 1) && c < 2 * s) ? dt : 0.0;
+                dbg[6480 + (2 * (s - 1) + 1) * NVP + c] = (c < 2 * s) ? sCh[hoff(s) + c] : 0.0;
             }
         for (int i = lane; i < 2 * N; i += 64) dbg[12880 + i] = sD[i];
         for (int i = lane; i < (N + 1) * NX; i += 64) dbg[12960 + i] = sG[i];
@@ -239,166 +281,135 @@ __global__ void __launch_bounds__(64, 1) nmpc_rti_kernel(const KArgs ka)
 
     TUM_TICK(1);
     // ------------------------------------------------------------ phase 3: interior point
-    RowState R;
-    double dval[3], lo[3], hi[3];
-    const bool rowlane = lane < N;
-    {
-        const int l = rowlane ? lane : 0;
-        const int NB = N + 1;
-        // constant terms and bounds
-        dval[0] = sU[2 * l + 1]; lo[0] = gbnd[0 * NB + l]; hi[0] = gbnd[1 * NB + l];
-        dval[1] = sD[2 * l];     lo[1] = gbnd[2 * NB + l + 1]; hi[1] = gbnd[3 * NB + l + 1];
-        dval[2] = sD[2 * l + 1]; lo[2] = gbnd[4 * NB + l + 1]; hi[2] = gbnd[5 * NB + l + 1];
-        // penalties: class 0 = stage 0, 1 = stages 1..N-1, 2 = stage N; slot = row; [zl, zu, Zl, Zu]
-        const int cls0 = (l == 0) ? 0 : 1, cls12 = (l + 1 < N) ? 1 : 2;
-        const double sc0 = dt, sc12 = (l + 1 < N) ? dt : 1.0;
-#pragma unroll
-        for (int rr = 0; rr < 3; rr++) {
-            const int cls = rr == 0 ? cls0 : cls12;
-            const double sc = rr == 0 ? sc0 : sc12;
-            const double *pp = gpen + (cls * 3 + rr) * 4;
-            R.z[rr][0] = sc * pp[0]; R.z[rr][1] = sc * pp[1];
-            R.Z[rr][0] = sc * pp[2]; R.Z[rr][1] = sc * pp[3];
-        }
-    }
-    const double thr = sqrt(ka.mu0);
-#pragma unroll
-    for (int rr = 0; rr < 3; rr++)
-#pragma unroll
-        for (int sd = 0; sd < 2; sd++) {
-            const double eps = sd ? -1.0 : 1.0, bnd = sd ? hi[rr] : lo[rr];
-            const double r0v = eps * (dval[rr] - bnd);
-            R.s[rr][sd] = thr;
-            double t = r0v + thr;
-            if (t < thr) t = thr;
-            R.t[rr][sd] = t;
-            R.lam[rr][sd] = ka.mu0 / t;
-            R.mu[rr][sd] = ka.mu0 / thr;
-            R.rs[rr][sd] = R.z[rr][sd] + R.Z[rr][sd] * thr - R.lam[rr][sd] - R.mu[rr][sd];
-            R.rt[rr][sd] = t - r0v - thr;
-        }
-
-    // v-space vectors in "vector layout": element c in lane c (bank 0), element 64+c in lane c<16 (bank 1)
-    double v0 = 0.0, v1 = 0.0, rv0, rv1;
-
-    // y = C' * w  with w_box in sWb[k], w_gen in sWr[row]; result in vector layout
-    auto ctw = [&](double &o0, double &o1) {
-        double a0 = 0.0, a1 = 0.0;
-        if (lane & 1) a0 = ((lane >> 1) < N) ? sWb[lane >> 1] : 0.0;
-        if ((lane & 1) && lane < 16) a1 = ((32 + (lane >> 1)) < N) ? sWb[32 + (lane >> 1)] : 0.0;
-        for (int s = 1; s <= N; s++) {
-            const double wd = sWr[2 * (s - 1)], wh = sWr[2 * (s - 1) + 1];
-            if (lane < 2 * s) a0 += sC[coff(s, 0) + lane] * wd + sC[coff(s, 1) + lane] * wh;
-            if (lane < 16 && 64 + lane < 2 * s) a1 += sC[coff(s, 0) + 64 + lane] * wd + sC[coff(s, 1) + 64 + lane] * wh;
-        }
-        o0 = a0; o1 = a1;
-    };
-
-    // initial stationarity residual r_v = q - C'(lam_l - lam_u)   (v = 0)
-    if (rowlane) {
-        sWb[lane] = R.lam[0][0] - R.lam[0][1];
-        sWr[2 * lane] = R.lam[1][0] - R.lam[1][1];
-        sWr[2 * lane + 1] = R.lam[2][0] - R.lam[2][1];
-    }
-    wsync();
-    {
-        double c0, c1;
-        ctw(c0, c1);
-        rv0 = q0 - c0; rv1 = q1 - c1;
-        if (lane >= nv) rv0 = 0.0;
-        if (!(lane < 16 && 64 + lane < nv)) rv1 = 0.0;
-    }
-    double qn = wave_max(fmax(fabs(q0), (lane < 16) ? fabs(q1) : 0.0));
-    if (qn < 1.0) qn = 1.0;
+    // Row state lives in LDS between the (short) row phases so that the long factorisation / substitution
+    // phases only carry the 15 H tiles in registers. sRow[(field*6 + row*2 + side)*NMAX + lane],
+    // fields: 0 s, 1 t, 2 lam, 3 mu, 4 rs (slack stationarity residual), 5 rt (primal residual).
+    double v0 = 0.0, v1 = 0.0, rv0, rv1, qn;
     const double npairs = 12.0 * N;
+    const double inv_npairs = 1.0 / npairs;
+    const int nchunk = (N + 3) >> 2;                 // chunks of 4 gg rows
     int it = 0, qp_status = 1;
     double res_stat = 0.0, res_ineq = 0.0, res_comp = 0.0;
-
-    for (;; it++) {
-        // ---- residual norms
-        double ls = fmax(fabs(rv0), fabs(rv1)), li = 0.0, lcmp = 0.0, lg = 0.0;
-        if (rowlane) {
-#pragma unroll
-            for (int rr = 0; rr < 3; rr++)
-#pragma unroll
-                for (int sd = 0; sd < 2; sd++) {
-                    ls = fmax(ls, fabs(R.rs[rr][sd]));
-                    li = fmax(li, fabs(R.rt[rr][sd]));
-                    const double c1 = R.t[rr][sd] * R.lam[rr][sd], c2 = R.s[rr][sd] * R.mu[rr][sd];
-                    lcmp = fmax(lcmp, fmax(c1, c2));
-                    lg += c1 + c2;
-                }
-        }
-        res_stat = wave_max(ls); res_ineq = wave_max(li); res_comp = wave_max(lcmp);
-        const double gap = wave_sum(lg) / npairs;
-        if (!(res_stat == res_stat) || !(gap == gap)) { qp_status = 3; break; }
-        if (res_stat <= ka.tol_stat * qn && res_ineq <= ka.tol_ineq && res_comp <= ka.tol_comp) { qp_status = 0; break; }
-        if (it >= ka.iter_max) { qp_status = 1; break; }
-
-        TUM_TICK(2);
-        // ---- gamma, M = H + C' Gamma C
-        double gam[3][2], Ds[3][2];
+    {
+        TUM_LANE_DEFS
+    {
+        const int NB = N + 1;
+        double dval[3], lo[3], hi[3];
+        dval[0] = sU[2 * rl_ + 1]; lo[0] = gbnd[0 * NB + rl_]; hi[0] = gbnd[1 * NB + rl_];
+        dval[1] = sD[2 * rl_];     lo[1] = gbnd[2 * NB + rl_ + 1]; hi[1] = gbnd[3 * NB + rl_ + 1];
+        dval[2] = sD[2 * rl_ + 1]; lo[2] = gbnd[4 * NB + rl_ + 1]; hi[2] = gbnd[5 * NB + rl_ + 1];
+        const double thr = sqrt(ka.mu0);
+        double st[6][6];
 #pragma unroll
         for (int rr = 0; rr < 3; rr++)
 #pragma unroll
             for (int sd = 0; sd < 2; sd++) {
-                Ds[rr][sd] = R.Z[rr][sd] + R.mu[rr][sd] / R.s[rr][sd];
-                gam[rr][sd] = 1.0 / (R.t[rr][sd] / R.lam[rr][sd] + 1.0 / Ds[rr][sd]);
+                const int k = rr * 2 + sd;
+                const double eps = sd ? -1.0 : 1.0, bnd = sd ? hi[rr] : lo[rr];
+                const double r0v = eps * (dval[rr] - bnd);
+                double t = r0v + thr;
+                if (t < thr) t = thr;
+                st[0][k] = thr; st[1][k] = t; st[2][k] = ka.mu0 / t; st[3][k] = ka.mu0 / thr;
+                st[4][k] = pen(rr, sd, 0) + pen(rr, sd, 1) * thr - st[2][k] - st[3][k];
+                st[5][k] = t - r0v - thr;
             }
+        wsync();          // the aliased condensing scratch (sD) has been consumed
         if (rowlane) {
-            sWb[lane] = gam[0][0] + gam[0][1];
-            sGam[2 * lane] = gam[1][0] + gam[1][1];
-            sGam[2 * lane + 1] = gam[2][0] + gam[2][1];
-        } else if (lane < NMAX) {
-            sWb[lane] = 0.0; sGam[2 * lane] = 0.0; sGam[2 * lane + 1] = 0.0;
+#pragma unroll
+            for (int f = 0; f < 6; f++)
+#pragma unroll
+                for (int k = 0; k < 6; k++) ROWF(f, k) = st[f][k];
         }
-        wsync();
+    }
+
+    // initial stationarity residual r_v = q - C'(lam_l - lam_u)   (v = 0)
+    wsync();
+    publish(ROWF(2, 0) - ROWF(2, 1), ROWF(2, 2) - ROWF(2, 3), ROWF(2, 4) - ROWF(2, 5), sWh);
+    {
+        double c0, c1;
+        ctw(c0, c1);
+        rv0 = v0on ? q0 - c0 : 0.0; rv1 = v1on ? q1 - c1 : 0.0;
+    }
+    qn = wave_max(fmax(fabs(q0), (lane < 16) ? fabs(q1) : 0.0));
+    if (qn < 1.0) qn = 1.0;
+    }
+    const int lane_outer = lane;
+    for (;; it++) {
+        int lane_v = lane_outer;
+        asm volatile("" : "+v"(lane_v));          // opaque per iteration (see TUM_LANE_DEFS)
+        const int lane = lane_v;
+        const int lq = lane >> 4, lc = lane & 15;
+        TUM_LANE_DEFS
+        // ---- row phase A: residual norms, gamma
+        double gap;
         {
-            d4 Mt[NTT];
+            double ls = fmax(fabs(rv0), fabs(rv1)), li = 0.0, lcmp = 0.0, lg = 0.0;
+            double gsum[3];
 #pragma unroll
-            for (int i = 0; i < NTT; i++) Mt[i] = Ht[i];
+            for (int rr = 0; rr < 3; rr++) {
+                gsum[rr] = 0.0;
 #pragma unroll
-            for (int K = 0; K < NT; K++)
-#pragma unroll
-                for (int jj = 0; jj < 4; jj++) {
-                    const int row = lq + 4 * jj;
-                    if (row == lc) {
-                        const int idx = 16 * K + row;
-                        double add = ka.reg;
-                        if ((idx & 1) && idx < nv) add += sWb[idx >> 1];
-                        Mt[tidx(K, K)][jj] += add;
-                    }
+                for (int sd = 0; sd < 2; sd++) {
+                    const int k = rr * 2 + sd;
+                    const double s_ = ROWF(0, k), t_ = ROWF(1, k), l_ = ROWF(2, k), m_ = ROWF(3, k);
+                    ls = fmax(ls, rowlane ? fabs(ROWF(4, k)) : 0.0);
+                    li = fmax(li, rowlane ? fabs(ROWF(5, k)) : 0.0);
+                    const double c1 = t_ * l_, c2 = s_ * m_;
+                    lcmp = fmax(lcmp, rowlane ? fmax(c1, c2) : 0.0);
+                    lg += rowlane ? c1 + c2 : 0.0;
+                    const double Ds = pen(rr, sd, 1) + m_ * frcp(s_);
+                    gsum[rr] += frcp(t_ * frcp(l_) + frcp(Ds));
                 }
-            const int nchunk = (2 * N + 3) >> 2;
-            for (int c = 0; c < nchunk; c++) {
-                const int row = 4 * c + lq;                // general row handled by this lane group
-                const int s = (row >> 1) + 1, wch = row & 1;
-                const int smax = 2 * c + 2;                // last stage in the chunk
-                const int Tc = (2 * smax + 15) >> 4;
-                const double gr = (s <= N) ? sGam[row] : 0.0;
-                double aop[NT], bop[NT];
-#pragma unroll
-                for (int T = 0; T < NT; T++) {
-                    const int col = 16 * T + lc;
-                    bop[T] = (T < Tc && s <= N && col < 2 * s) ? sC[coff(s, wch) + col] : 0.0;
-                    aop[T] = bop[T] * gr;
-                }
-#pragma unroll
-                for (int K = 0; K < NT; K++)
-#pragma unroll
-                    for (int I = K; I < NT; I++)
-                        if (I < Tc) Mt[tidx(K, I)] = mfma(aop[K], bop[I], Mt[tidx(K, I)]);
             }
-            // store as packed lower triangle: M[col_g][row_g] for col_g >= row_g
+            res_stat = wave_max(ls); res_ineq = wave_max(li); res_comp = wave_max(lcmp);
+            gap = wave_sum(lg) * inv_npairs;
+            if (!(res_stat == res_stat) || !(gap == gap)) { qp_status = 3; break; }
+            if (res_stat <= ka.tol_stat * qn && res_ineq <= ka.tol_ineq && res_comp <= ka.tol_comp) { qp_status = 0; break; }
+            if (it >= ka.iter_max) { qp_status = 1; break; }
+            TUM_TICK(2);
+            publish(gsum[0], gsum[1], gsum[2], sGamH);
+        }
+        // ---- M = H + C' Gamma C, one 16x16 tile at a time (single accumulator live)
+        {
+            double gch[10];
+#pragma unroll
+            for (int c = 0; c < 10; c++) gch[c] = sGamH[(4 * c + lq < N) ? 4 * c + lq : 0] * ((4 * c + lq < N) ? 1.0 : 0.0);
+            const double dt2 = dt * dt;
 #pragma unroll
             for (int K = 0; K < NT; K++)
 #pragma unroll
-                for (int I = K; I < NT; I++)
+                for (int I = K; I < NT; I++) {
+                    d4 acc = Ht[tidx(K, I)];
+                    // steering-angle rows (structured), box rows and regularisation
+#pragma unroll
+                    for (int jj = 0; jj < 4; jj++) {
+                        const int row = 16 * K + lq + 4 * jj, col = 16 * I + lc;
+                        const int mx = (row > col) ? row : col;
+                        const double sf = sSfx[(mx >> 1) + 1];
+                        double add = ((row & 1) && (col & 1) && mx < nv) ? dt2 * sf : 0.0;
+                        if (K == I) {
+                            const double wb = sWb[(row >> 1) < NMAX ? (row >> 1) : 0];
+                            if (row == col) add += ka.reg + (((row & 1) && row < nv) ? wb : 0.0);
+                        }
+                        acc[jj] += add;
+                    }
+                    // gg rows: SYRK over chunks of 4 rows (stages 4c+1 .. 4c+4); tile column I needs c >= 2I
+#pragma unroll
+                    for (int c = 2 * I; c < 10; c++) {
+                        const int s = 4 * c + lq + 1;                 // <= 40 always
+                        const int base = hoff(s);
+                        const bool ka_ = (16 * K + lc < 2 * s), kb_ = (16 * I + lc < 2 * s);
+                        const double av = sCh[base + (ka_ ? 16 * K + lc : 0)];
+                        const double bv = sCh[base + (kb_ ? 16 * I + lc : 0)];
+                        acc = mfma(ka_ ? av * gch[c] : 0.0, (kb_ && s <= N) ? bv : 0.0, acc);
+                    }
+                    // store as packed lower triangle: M[col_g][row_g] for col_g >= row_g
 #pragma unroll
                     for (int jj = 0; jj < 4; jj++) {
                         const int rg = 16 * K + lq + 4 * jj, cg = 16 * I + lc;
-                        if (cg >= rg) sM[lpk(cg, rg)] = Mt[tidx(K, I)][jj];
+                        if (K < I || cg >= rg) sM[rb[I] + rg] = acc[jj];
                     }
+                }
         }
         wsync();
         if ((ka.flags & 2) && b < 4 && it == 0) {
@@ -407,70 +418,103 @@ __global__ void __launch_bounds__(64, 1) nmpc_rti_kernel(const KArgs ka)
         }
 
         TUM_TICK(3);
-        // ---- blocked Cholesky, left-looking: M = L L'
+        // ---- blocked L D L' factorisation. Unit-lower L overwrites the strict lower triangle of M, the
+        //      pivots go to sDd / sInvD. Block column J (16 wide): (1) left-looking update with the block
+        //      columns already factorised (MFMA, 4 per earlier block), result kept in registers as D-layout
+        //      tiles; (2) four 4-column micro-panels: the 4x4 diagonal block is factorised redundantly by
+        //      every lane from LDS broadcasts (all scalars stay in VGPRs: no readlane / SGPR traffic), every
+        //      row below solves its 4 entries against it, and the rest of the panel gets a rank-4 MFMA update.
         bool chol_ok = true;
 #pragma unroll
         for (int J = 0; J < NT; J++) {
-            // (1) update block column J with the block columns already factorised
-            if (J > 0) {
+            d4 T[NT];
 #pragma unroll
-                for (int I = J; I < NT; I++) {
-                    d4 T;
+            for (int I = J; I < NT; I++) {
 #pragma unroll
-                    for (int jj = 0; jj < 4; jj++) {
-                        const int rg = 16 * I + lq + 4 * jj, cg = 16 * J + lc;
-                        T[jj] = (rg >= cg) ? sM[lpk(rg, cg)] : 0.0;
+                for (int jj = 0; jj < 4; jj++) {
+                    const int rg = 16 * I + lq + 4 * jj, cg = 16 * J + lc;
+                    const bool valid = (I > J) || (rg >= cg);
+                    const double v = sM[lpk(rg, valid ? cg : rg)];
+                    T[I][jj] = valid ? v : 0.0;
+                }
+#pragma unroll
+                for (int K = 0; K < J; K++)
+#pragma unroll
+                    for (int kc = 0; kc < 4; kc++) {
+                        const int kk = 16 * K + 4 * kc + lq;
+                        T[I] = mfma(-sM[rb[I] + kk] * sDd[kk], sM[rb[J] + kk], T[I]);
                     }
+            }
 #pragma unroll
-                    for (int K = 0; K < J; K++)
+            for (int m = 0; m < 4; m++) {
+                const int c0 = 16 * J + 4 * m;
+                // (a) publish columns c0..c0+3 of the panel tiles (rows >= column) for the lane = row readers
+                if ((lc >> 2) == m) {
 #pragma unroll
-                        for (int kc = 0; kc < 4; kc++) {
-                            const double a = -sM[lpk(16 * I + lc, 16 * K + 4 * kc + lq)];
-                            const double bb = sM[lpk(16 * J + lc, 16 * K + 4 * kc + lq)];
-                            T = mfma(a, bb, T);
+                    for (int I = J; I < NT; I++)
+#pragma unroll
+                        for (int jj = 0; jj < 4; jj++) {
+                            const int rg = 16 * I + lq + 4 * jj, cg = 16 * J + lc;
+                            if ((I > J) || (rg >= cg)) sM[lpk(rg, cg)] = T[I][jj];
                         }
-#pragma unroll
-                    for (int jj = 0; jj < 4; jj++) {
-                        const int rg = 16 * I + lq + 4 * jj, cg = 16 * J + lc;
-                        if (rg >= cg) sM[lpk(rg, cg)] = T[jj];
-                    }
                 }
                 wsync();
-            }
-            // (2) factorise the 16-wide panel: lane = row (bank 0: rows 0..63, bank 1: rows 64..79)
-            double P0[16], P1[16];
-            const int i0 = lane, i1 = 64 + lane;
+                // (b) 4x4 diagonal block, L D L' on uniform values
+                const int r1 = lpk(c0 + 1, c0), r2 = lpk(c0 + 2, c0), r3 = lpk(c0 + 3, c0);
+                const double a00 = sM[lpk(c0, c0)];
+                const double a10 = sM[r1], a11 = sM[r1 + 1];
+                const double a20 = sM[r2], a21 = sM[r2 + 1], a22 = sM[r2 + 2];
+                const double a30 = sM[r3], a31 = sM[r3 + 1], a32 = sM[r3 + 2], a33 = sM[r3 + 3];
+                // (c) this lane's rows below the block (issued together with the broadcasts)
+                const int row = c0 + 4 + lane;
+                const bool rin = row < NVP;
+                const int rbase = lpk(rin ? row : NVP - 1, c0);
+                double e0 = sM[rbase], e1 = sM[rbase + 1], e2 = sM[rbase + 2], e3 = sM[rbase + 3];
+                const bool two = (J == 0) && (m < 3);             // rows c0+68.. exist only for c0 < 12
+                const int row1 = c0 + 68 + lane;
+                const bool rin1 = two && (row1 < NVP);
+                const int rbase1 = lpk(rin1 ? row1 : NVP - 1, c0);
+                double f0 = 0, f1 = 0, f2 = 0, f3 = 0;
+                if (two) { f0 = sM[rbase1]; f1 = sM[rbase1 + 1]; f2 = sM[rbase1 + 2]; f3 = sM[rbase1 + 3]; }
+                const double d0 = a00, i0 = frcp(d0);
+                const double l10 = a10 * i0, l20 = a20 * i0, l30 = a30 * i0;
+                const double d1 = a11 - l10 * a10, i1 = frcp(d1);
+                const double y21 = a21 - l20 * a10, y31 = a31 - l30 * a10;
+                const double l21 = y21 * i1, l31 = y31 * i1;
+                const double d2 = a22 - l20 * a20 - l21 * y21, i2 = frcp(d2);
+                const double y32 = a32 - l30 * a20 - l31 * y21;
+                const double l32 = y32 * i2;
+                const double d3 = a33 - l30 * a30 - l31 * y31 - l32 * y32, i3 = frcp(d3);
+                if (!(d0 > 1e-300) || !(d1 > 1e-300) || !(d2 > 1e-300) || !(d3 > 1e-300)) chol_ok = false;
+                // forward substitution of every row below against L4 (y = L * d), then L = y / d
+                e1 -= l10 * e0; e2 -= l20 * e0 + l21 * e1; e3 -= l30 * e0 + l31 * e1 + l32 * e2;
+                if (rin) { sM[rbase] = e0 * i0; sM[rbase + 1] = e1 * i1; sM[rbase + 2] = e2 * i2; sM[rbase + 3] = e3 * i3; }
+                if (two) {
+                    f1 -= l10 * f0; f2 -= l20 * f0 + l21 * f1; f3 -= l30 * f0 + l31 * f1 + l32 * f2;
+                    if (rin1) { sM[rbase1] = f0 * i0; sM[rbase1 + 1] = f1 * i1; sM[rbase1 + 2] = f2 * i2; sM[rbase1 + 3] = f3 * i3; }
+                }
+                if (lane == 0) {
+                    sM[r1] = l10; sM[r2] = l20; sM[r2 + 1] = l21; sM[r3] = l30; sM[r3 + 1] = l31; sM[r3 + 2] = l32;
+                    sDd[c0] = d0; sDd[c0 + 1] = d1; sDd[c0 + 2] = d2; sDd[c0 + 3] = d3;
+                    sInvD[c0] = i0; sInvD[c0 + 1] = i1; sInvD[c0 + 2] = i2; sInvD[c0 + 3] = i3;
+                }
+                wsync();
+                // (d) rank-4 update of the panel's remaining columns on the matrix cores
+                if (m < 3) {
+                    const double dsel = (lq == 0) ? d0 : (lq == 1) ? d1 : (lq == 2) ? d2 : d3;
+                    const int kcol = c0 + lq;
+                    const int rowJ = 16 * J + lc;
+                    const double bl = sM[lpk(rowJ, rowJ > kcol ? kcol : 0)];
+                    const double bval = (rowJ > kcol) ? bl : ((rowJ == kcol) ? 1.0 : 0.0);
 #pragma unroll
-            for (int jj = 0; jj < 16; jj++) {
-                const int jc = 16 * J + jj;
-                P0[jj] = (i0 >= jc) ? sM[lpk(i0, jc)] : 0.0;
-                P1[jj] = (lane < 16 && i1 >= jc) ? sM[lpk(i1, jc)] : 0.0;
-            }
-#pragma unroll
-            for (int jj = 0; jj < 16; jj++) {
-                const int jc = 16 * J + jj;
-                const int pl = jc & 63;
-                const double piv = (J < 4) ? rl(P0[jj], pl) : rl(P1[jj], pl);
-                if (!(piv > 1e-300)) chol_ok = false;
-                const double dg = sqrt(piv), inv = 1.0 / dg;
-                if (lane == 0) sInvD[jc] = inv;
-                if (i0 > jc) P0[jj] *= inv; else if (i0 == jc) P0[jj] = dg;
-                if (i1 > jc) P1[jj] *= inv; else if (i1 == jc) P1[jj] = dg;
-#pragma unroll
-                for (int cc = jj + 1; cc < 16; cc++) {
-                    const int pc = (16 * J + cc) & 63;
-                    const double lcj = (J < 4) ? rl(P0[jj], pc) : rl(P1[jj], pc);
-                    P0[cc] -= P0[jj] * lcj;
-                    P1[cc] -= P1[jj] * lcj;
+                    for (int I = J; I < NT; I++) {
+                        double aval;
+                        if (I == J) aval = bval;
+                        else aval = sM[rb[I] + kcol];                 // rows of later blocks are always below
+                        T[I] = mfma(-aval * dsel, bval, T[I]);
+                    }
                 }
             }
-#pragma unroll
-            for (int jj = 0; jj < 16; jj++) {
-                const int jc = 16 * J + jj;
-                if (i0 >= jc) sM[lpk(i0, jc)] = P0[jj];
-                if (lane < 16 && i1 >= jc) sM[lpk(i1, jc)] = P1[jj];
-            }
-            wsync();
         }
         if (!chol_ok) { qp_status = 3; break; }
         if ((ka.flags & 2) && b < 4 && it == 0) {
@@ -480,68 +524,121 @@ __global__ void __launch_bounds__(64, 1) nmpc_rti_kernel(const KArgs ka)
 
         TUM_TICK(4);
         // ---- predictor / corrector
-        double dS[3][2], dT[3][2], dL[3][2], dMu[3][2];
+        double cross1[6], cross2[6];                 // dT*dL and dS*dMu of the affine step
         double dv0 = 0.0, dv1 = 0.0, alpha = 1.0, sigma = 0.0;
+        double dSt[4][6];                            // corrector step of (s, t, lam, mu), kept until alpha is known
+        const double invd0 = sInvD[lane], invd1 = sInvD[lane1] * ((lane < 16) ? 1.0 : 0.0);
 #pragma unroll 1
         for (int pass = 0; pass < 2; pass++) {
-            double rc1[3][2], rc2[3][2], rho[3][2];
+            const double tau = (pass == 1) ? fmax(sigma * gap, 0.1 * ka.tol_comp) : 0.0;
+            // row phase B1: rhs weights  w = gam_l*rho_l - gam_u*rho_u
+            {
+                double w[3];
 #pragma unroll
-            for (int rr = 0; rr < 3; rr++)
+                for (int rr = 0; rr < 3; rr++) {
+                    w[rr] = 0.0;
 #pragma unroll
-                for (int sd = 0; sd < 2; sd++) {
-                    rc1[rr][sd] = R.t[rr][sd] * R.lam[rr][sd];
-                    rc2[rr][sd] = R.s[rr][sd] * R.mu[rr][sd];
-                    if (pass == 1) {
-                        // centring target floored just below tol_comp: keeps gamma = lam/t (and the
-                        // conditioning of M) bounded once complementarity has converged
-                        const double tau = fmax(sigma * gap, 0.1 * ka.tol_comp);
-                        rc1[rr][sd] += dT[rr][sd] * dL[rr][sd] - tau;
-                        rc2[rr][sd] += dS[rr][sd] * dMu[rr][sd] - tau;
+                    for (int sd = 0; sd < 2; sd++) {
+                        const int k = rr * 2 + sd;
+                        const double s_ = ROWF(0, k), t_ = ROWF(1, k), l_ = ROWF(2, k), m_ = ROWF(3, k);
+                        const double is_ = frcp(s_), il_ = frcp(l_);
+                        const double iDs = frcp(pen(rr, sd, 1) + m_ * is_);
+                        const double gam = frcp(t_ * il_ + iDs);
+                        double rc1 = t_ * l_, rc2 = s_ * m_;
+                        if (pass == 1) { rc1 += cross1[k] - tau; rc2 += cross2[k] - tau; }
+                        const double rho = -ROWF(5, k) + rc1 * il_ - (ROWF(4, k) + rc2 * is_) * iDs;
+                        w[rr] += (sd ? -1.0 : 1.0) * gam * rho;
                     }
-                    rho[rr][sd] = -R.rt[rr][sd] + rc1[rr][sd] / R.lam[rr][sd]
-                                  - (R.rs[rr][sd] + rc2[rr][sd] / R.s[rr][sd]) / Ds[rr][sd];
                 }
-            wsync();
-            if (rowlane) {
-                sWb[lane] = gam[0][0] * rho[0][0] - gam[0][1] * rho[0][1];
-                sWr[2 * lane] = gam[1][0] * rho[1][0] - gam[1][1] * rho[1][1];
-                sWr[2 * lane + 1] = gam[2][0] * rho[2][0] - gam[2][1] * rho[2][1];
+                publish(w[0], w[1], w[2], sWh);
             }
-            wsync();
             double b0, b1;
             ctw(b0, b1);
-            b0 = -rv0 - b0; b1 = -rv1 - b1;
-            if (lane >= nv) b0 = 0.0;
-            if (!(lane < 16 && 64 + lane < nv)) b1 = 0.0;
+            b0 = v0on ? -rv0 - b0 : 0.0; b1 = v1on ? -rv1 - b1 : 0.0;
             if ((ka.flags & 2) && b < 4 && it == 0 && pass == 0) {
                 double *dbg = ka.dbg + (size_t)b * ka.dbg_stride;
                 dbg[19780 + lane] = b0;
                 if (lane < 16) dbg[19780 + 64 + lane] = b1;
             }
             TUM_TICK(5);
-            // forward substitution L y = b (column oriented)
-            for (int j = 0; j < 64; j++) {
-                const double yj = rl(b0, j) * sInvD[j];
-                if (lane == j) b0 = yj;
-                if (lane > j) b0 -= sM[lpk(lane, j)] * yj;
-                if (lane < 16) b1 -= sM[lpk(64 + lane, j)] * yj;
+            // Triangular solves in 4-wide micro-blocks: the 4 unknowns of a micro-block are broadcast with
+            // readlane, solved against the 4x4 unit-lower diagonal block on uniform values, and every other
+            // row applies them with 4 FMAs against its (contiguous, prefetched) entries of L.
+            // forward: L y = b
+#pragma unroll 2
+            for (int c0 = 0; c0 < 64; c0 += 4) {
+                const int r1 = lpk(c0 + 1, c0), r2 = lpk(c0 + 2, c0), r3 = lpk(c0 + 3, c0);
+                const double l10 = sM[r1], l20 = sM[r2], l21 = sM[r2 + 1], l30 = sM[r3], l31 = sM[r3 + 1], l32 = sM[r3 + 2];
+                const bool below = lane > c0 + 3;
+                const int o0 = myrow0 + (below ? c0 : 0);
+                const double m0 = sM[o0], m1 = sM[o0 + 1], m2 = sM[o0 + 2], m3 = sM[o0 + 3];
+                const int o1 = myrow1 + c0;
+                const double n0 = sM[o1], n1 = sM[o1 + 1], n2 = sM[o1 + 2], n3 = sM[o1 + 3];
+                const double y0 = rl(b0, c0);
+                const double y1 = rl(b0, c0 + 1) - l10 * y0;
+                const double y2 = rl(b0, c0 + 2) - l20 * y0 - l21 * y1;
+                const double y3 = rl(b0, c0 + 3) - l30 * y0 - l31 * y1 - l32 * y2;
+                if (below) b0 -= m0 * y0 + m1 * y1 + m2 * y2 + m3 * y3;
+                if (lane == c0 + 1) b0 = y1;
+                if (lane == c0 + 2) b0 = y2;
+                if (lane == c0 + 3) b0 = y3;
+                if (lane < 16) b1 -= n0 * y0 + n1 * y1 + n2 * y2 + n3 * y3;
             }
-            for (int j = 64; j < NVP; j++) {
-                const double yj = rl(b1, j - 64) * sInvD[j];
-                if (lane == j - 64) b1 = yj;
-                if (lane < 16 && lane > j - 64) b1 -= sM[lpk(64 + lane, j)] * yj;
+#pragma unroll
+            for (int c0 = 64; c0 < NVP; c0 += 4) {
+                const int r1 = lpk(c0 + 1, c0), r2 = lpk(c0 + 2, c0), r3 = lpk(c0 + 3, c0);
+                const double l10 = sM[r1], l20 = sM[r2], l21 = sM[r2 + 1], l30 = sM[r3], l31 = sM[r3 + 1], l32 = sM[r3 + 2];
+                const bool below = (lane < 16) && (lane1 > c0 + 3);
+                const int o1 = myrow1 + (below ? c0 : 0);
+                const double n0 = sM[o1], n1 = sM[o1 + 1], n2 = sM[o1 + 2], n3 = sM[o1 + 3];
+                const double y0 = rl(b1, c0 - 64);
+                const double y1 = rl(b1, c0 - 63) - l10 * y0;
+                const double y2 = rl(b1, c0 - 62) - l20 * y0 - l21 * y1;
+                const double y3 = rl(b1, c0 - 61) - l30 * y0 - l31 * y1 - l32 * y2;
+                if (below) b1 -= n0 * y0 + n1 * y1 + n2 * y2 + n3 * y3;
+                if (lane == c0 - 63) b1 = y1;
+                if (lane == c0 - 62) b1 = y2;
+                if (lane == c0 - 61) b1 = y3;
             }
-            // backward substitution L' x = y
-            for (int j = NVP - 1; j >= 64; j--) {
-                const double xj = rl(b1, j - 64) * sInvD[j];
-                if (lane == j - 64) b1 = xj;
-                if (lane < 16 && lane < j - 64) b1 -= sM[lpk(j, 64 + lane)] * xj;
-                b0 -= sM[lpk(j, lane)] * xj;
+            // z = D^-1 y
+            b0 *= invd0; b1 *= invd1;
+            // backward: L' x = z. Micro-block rows c0..c0+3 of L are contiguous in the packed layout.
+#pragma unroll
+            for (int c0 = NVP - 4; c0 >= 64; c0 -= 4) {
+                const int r1 = lpk(c0 + 1, 0), r2 = lpk(c0 + 2, 0), r3 = lpk(c0 + 3, 0), r0b = lpk(c0, 0);
+                const double l10 = sM[r1 + c0], l20 = sM[r2 + c0], l21 = sM[r2 + c0 + 1];
+                const double l30 = sM[r3 + c0], l31 = sM[r3 + c0 + 1], l32 = sM[r3 + c0 + 2];
+                // entries L[c0+k][col] for this lane's columns (bank 0: col = lane, bank 1: col = 64+lane < c0)
+                const double m0 = sM[r0b + lane], m1 = sM[r1 + lane], m2 = sM[r2 + lane], m3 = sM[r3 + lane];
+                const bool left = (lane < 16) && (lane1 < c0);
+                const int oc = left ? lane1 : 0;
+                const double n0 = sM[r0b + oc], n1 = sM[r1 + oc], n2 = sM[r2 + oc], n3 = sM[r3 + oc];
+                const double x3 = rl(b1, c0 - 61);
+                const double x2 = rl(b1, c0 - 62) - l32 * x3;
+                const double x1 = rl(b1, c0 - 63) - l21 * x2 - l31 * x3;
+                const double x0 = rl(b1, c0 - 64) - l10 * x1 - l20 * x2 - l30 * x3;
+                b0 -= m0 * x0 + m1 * x1 + m2 * x2 + m3 * x3;
+                if (left) b1 -= n0 * x0 + n1 * x1 + n2 * x2 + n3 * x3;
+                if (lane == c0 - 64) b1 = x0;
+                if (lane == c0 - 63) b1 = x1;
+                if (lane == c0 - 62) b1 = x2;
             }
-            for (int j = 63; j >= 0; j--) {
-                const double xj = rl(b0, j) * sInvD[j];
-                if (lane == j) b0 = xj;
-                if (lane < j) b0 -= sM[lpk(j, lane)] * xj;
+#pragma unroll 2
+            for (int c0 = 60; c0 >= 0; c0 -= 4) {
+                const int r1 = lpk(c0 + 1, 0), r2 = lpk(c0 + 2, 0), r3 = lpk(c0 + 3, 0), r0b = lpk(c0, 0);
+                const double l10 = sM[r1 + c0], l20 = sM[r2 + c0], l21 = sM[r2 + c0 + 1];
+                const double l30 = sM[r3 + c0], l31 = sM[r3 + c0 + 1], l32 = sM[r3 + c0 + 2];
+                const bool left = lane < c0;
+                const int oc = left ? lane : 0;
+                const double m0 = sM[r0b + oc], m1 = sM[r1 + oc], m2 = sM[r2 + oc], m3 = sM[r3 + oc];
+                const double x3 = rl(b0, c0 + 3);
+                const double x2 = rl(b0, c0 + 2) - l32 * x3;
+                const double x1 = rl(b0, c0 + 1) - l21 * x2 - l31 * x3;
+                const double x0 = rl(b0, c0) - l10 * x1 - l20 * x2 - l30 * x3;
+                if (left) b0 -= m0 * x0 + m1 * x1 + m2 * x2 + m3 * x3;
+                if (lane == c0) b0 = x0;
+                if (lane == c0 + 1) b0 = x1;
+                if (lane == c0 + 2) b0 = x2;
             }
             dv0 = b0; dv1 = b1;
             TUM_TICK(6);
@@ -554,69 +651,85 @@ __global__ void __launch_bounds__(64, 1) nmpc_rti_kernel(const KArgs ka)
                 dbg[19860 + lane] = dv0;
                 if (lane < 16) dbg[19860 + 64 + lane] = dv1;
             }
-            // C * dv for this lane's rows
-            double cdv[3] = {0.0, 0.0, 0.0};
-            if (rowlane) {
-                cdv[0] = sDv[2 * lane + 1];
-                const int s = lane + 1;
-                const double *c0 = sC + coff(s, 0), *c1 = sC + coff(s, 1);
+            // row phase B2: C*dv for this lane's rows, step in (s,t,lam,mu), step length
+            double cdv[3];
+            {
+                const double xo = rowlane ? sDv[2 * rl_ + 1] : 0.0;
+                cdv[0] = xo;
+                cdv[1] = dt * wave_prefix(xo, lane);
+                const int s = rl_ + 1;
+                const double *ch = sCh + hoff(s);
                 double a0 = 0.0, a1 = 0.0;
-                for (int c = 0; c < 2 * s; c++) {
-                    const double x = sDv[c];
-                    a0 += c0[c] * x; a1 += c1[c] * x;
+#pragma unroll 8
+                for (int c = 0; c < NVP; c += 2) {
+                    const bool on = (c < 2 * s);
+                    const double x0_ = ch[on ? c : 0], x1_ = ch[on ? c + 1 : 0];
+                    a0 += (on ? x0_ : 0.0) * sDv[c];
+                    a1 += (on ? x1_ : 0.0) * sDv[c + 1];
                 }
-                cdv[1] = a0; cdv[2] = a1;
+                cdv[2] = a0 + a1;
             }
             double amax = 1.0, lmu = 0.0;
+            double dcur[4][6];
 #pragma unroll
             for (int rr = 0; rr < 3; rr++)
 #pragma unroll
                 for (int sd = 0; sd < 2; sd++) {
+                    const int k = rr * 2 + sd;
                     const double eps = sd ? -1.0 : 1.0;
-                    const double dl = -gam[rr][sd] * (eps * cdv[rr] + rho[rr][sd]);
-                    const double dsl = (dl - R.rs[rr][sd] - rc2[rr][sd] / R.s[rr][sd]) / Ds[rr][sd];
-                    const double dm = (-rc2[rr][sd] - R.mu[rr][sd] * dsl) / R.s[rr][sd];
-                    const double dtt = (-rc1[rr][sd] - R.t[rr][sd] * dl) / R.lam[rr][sd];
-                    dL[rr][sd] = dl; dS[rr][sd] = dsl; dMu[rr][sd] = dm; dT[rr][sd] = dtt;
-                    if (rowlane) {
-                        if (dtt < 0.0) amax = fmin(amax, -R.t[rr][sd] / dtt);
-                        if (dsl < 0.0) amax = fmin(amax, -R.s[rr][sd] / dsl);
-                        if (dl < 0.0) amax = fmin(amax, -R.lam[rr][sd] / dl);
-                        if (dm < 0.0) amax = fmin(amax, -R.mu[rr][sd] / dm);
-                    }
+                    const double s_ = ROWF(0, k), t_ = ROWF(1, k), l_ = ROWF(2, k), m_ = ROWF(3, k);
+                    const double is_ = frcp(s_), il_ = frcp(l_), it_ = frcp(t_), im_ = frcp(m_);
+                    const double iDs = frcp(pen(rr, sd, 1) + m_ * is_);
+                    const double gam = frcp(t_ * il_ + iDs);
+                    double rc1 = t_ * l_, rc2 = s_ * m_;
+                    if (pass == 1) { rc1 += cross1[k] - tau; rc2 += cross2[k] - tau; }
+                    const double rsk = ROWF(4, k);
+                    const double rho = -ROWF(5, k) + rc1 * il_ - (rsk + rc2 * is_) * iDs;
+                    const double dl = -gam * (eps * cdv[rr] + rho);
+                    const double dsl = (dl - rsk - rc2 * is_) * iDs;
+                    const double dm = (-rc2 - m_ * dsl) * is_;
+                    const double dtt = (-rc1 - t_ * dl) * il_;
+                    dcur[0][k] = dsl; dcur[1][k] = dtt; dcur[2][k] = dl; dcur[3][k] = dm;
+                    // largest alpha keeping x + alpha*dx >= 0:  alpha <= 1 / max(-dx/x)
+                    double q = fmax(fmax(-dsl * is_, -dtt * it_), fmax(-dl * il_, -dm * im_));
+                    q = rowlane ? q : 0.0;
+                    amax = fmax(amax, q);                 // amax temporarily holds max(1, max ratio)
+                    if (pass == 0) { cross1[k] = dtt * dl; cross2[k] = dsl * dm; }
                 }
-            amax = wave_min(amax);
+            amax = frcp(wave_max(amax));                  // = min(1, 1/max ratio)
             if (pass == 0) {
-                if (rowlane) {
 #pragma unroll
-                    for (int rr = 0; rr < 3; rr++)
-#pragma unroll
-                        for (int sd = 0; sd < 2; sd++)
-                            lmu += (R.t[rr][sd] + amax * dT[rr][sd]) * (R.lam[rr][sd] + amax * dL[rr][sd])
-                                 + (R.s[rr][sd] + amax * dS[rr][sd]) * (R.mu[rr][sd] + amax * dMu[rr][sd]);
-                }
-                const double mu_aff = wave_sum(lmu) / npairs;
-                const double ratio = mu_aff / gap;
+                for (int k = 0; k < 6; k++)
+                    lmu += (ROWF(1, k) + amax * dcur[1][k]) * (ROWF(2, k) + amax * dcur[2][k])
+                         + (ROWF(0, k) + amax * dcur[0][k]) * (ROWF(3, k) + amax * dcur[3][k]);
+                const double mu_aff = wave_sum(rowlane ? lmu : 0.0) * inv_npairs;
+                const double ratio = mu_aff * frcp(gap);
                 sigma = ratio * ratio * ratio;
             } else {
                 alpha = (amax >= 1.0) ? 1.0 : 0.995 * amax;
+#pragma unroll
+                for (int f = 0; f < 4; f++)
+#pragma unroll
+                    for (int k = 0; k < 6; k++) dSt[f][k] = dcur[f][k];
             }
+            TUM_TICK(7);
         }
-        TUM_TICK(7);
         if (alpha < 1e-12) { qp_status = 2; break; }
         v0 += alpha * dv0; v1 += alpha * dv1;
         const double om = 1.0 - alpha;
         rv0 *= om; rv1 *= om;
+        if (rowlane) {
 #pragma unroll
-        for (int rr = 0; rr < 3; rr++)
+            for (int k = 0; k < 6; k++) {
 #pragma unroll
-            for (int sd = 0; sd < 2; sd++) {
-                R.t[rr][sd] += alpha * dT[rr][sd]; R.s[rr][sd] += alpha * dS[rr][sd];
-                R.lam[rr][sd] += alpha * dL[rr][sd]; R.mu[rr][sd] += alpha * dMu[rr][sd];
-                R.rs[rr][sd] *= om; R.rt[rr][sd] *= om;
+                for (int f = 0; f < 4; f++) ROWF(f, k) += alpha * dSt[f][k];
+                ROWF(4, k) *= om; ROWF(5, k) *= om;
             }
+        }
+        wsync();
     }
     const int status = acados_status(qp_status);
+    TUM_LANE_DEFS
 
     TUM_TICK(8);
     // ------------------------------------------------------------ phase 4: expand, full step, cost
@@ -671,7 +784,10 @@ __global__ void __launch_bounds__(64, 1) nmpc_rti_kernel(const KArgs ka)
         for (int rr = 0; rr < 3; rr++)
 #pragma unroll
             for (int sd = 0; sd < 2; sd++)
-                cl += R.z[rr][sd] * R.s[rr][sd] + 0.5 * R.Z[rr][sd] * R.s[rr][sd] * R.s[rr][sd];
+            {
+                const double sv = ROWF(0, rr * 2 + sd);
+                cl += pen(rr, sd, 0) * sv + 0.5 * pen(rr, sd, 1) * sv * sv;
+            }
     }
     const double cost = wave_sum(cl);
 
@@ -683,9 +799,9 @@ __global__ void __launch_bounds__(64, 1) nmpc_rti_kernel(const KArgs ka)
         // order: [lower: box_k (N) | (bx_k, h_k) k=1..N] then the same for upper
 #pragma unroll
         for (int sd = 0; sd < 2; sd++) {
-            sl[sd * 3 * N + lane] = R.s[0][sd];
-            sl[sd * 3 * N + N + 2 * lane] = R.s[1][sd];
-            sl[sd * 3 * N + N + 2 * lane + 1] = R.s[2][sd];
+            sl[sd * 3 * N + lane] = ROWF(0, 0 + sd);
+            sl[sd * 3 * N + N + 2 * lane] = ROWF(0, 2 + sd);
+            sl[sd * 3 * N + N + 2 * lane + 1] = ROWF(0, 4 + sd);
         }
     }
     TUM_TICK(9);
