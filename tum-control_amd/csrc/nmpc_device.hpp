@@ -35,31 +35,36 @@ __host__ __device__ constexpr int lpk(int i, int j) { return i * (i + 1) / 2 + j
 //  row s of that block is dt on the odd (steering-rate) columns < 2s and 0 elsewhere.)
 __host__ __device__ constexpr int hoff(int s) { return s * (s - 1); }
 
-// LDS carve (offsets in doubles)
-constexpr int O_AB = 0;                               // NMAX*ABS              compact (Sp,S,b) per stage
-constexpr int O_M = O_AB + NMAX * ABS;                // LPK                   KKT matrix / L D L' factor
-//   aliased into the M region (dead before the first KKT assembly):
-constexpr int O_STAGE = O_M;                          //     4 x NVP staging rows for the H SYRK
+// LDS carve (offsets in doubles). Three workgroups per CU need <= 53.3 KiB each, so everything that is
+// only alive before the interior point loop (linearisation records, condensing scratch, the iterate) is
+// aliased into regions the IPM owns; the linearisation records are parked in HBM/L2 (KArgs::ws) while the
+// IPM runs and come back for the final expansion.
+constexpr int O_M = 0;                                // LPK                   KKT matrix / L D L' factor
+//   aliased into the M region (dead before the first KKT assembly, reloaded after the last):
+constexpr int O_AB = O_M;                             //     NMAX*ABS    compact (Sp,S,b) per stage
+constexpr int O_STAGE = O_AB + NMAX * ABS;            //     4 x NVP     staging rows for the H SYRK
 constexpr int O_RES = O_STAGE + 4 * NVP;              //     (NMAX+1)*4  y - yref of the 4 state cost rows
 constexpr int O_GH = O_RES + (NMAX + 1) * 4;          //     (NMAX+1)*4  (gh3, gh5, gh7, h) per stage
 constexpr int O_D = O_GH + (NMAX + 1) * 4;            //     2*NMAX      constant term of the general rows
+constexpr int O_G = O_D + 2 * NMAX;                   //     (NMAX+1)*8  g_k (constant part of dx_k)
 constexpr int O_CH = O_M + LPK;                       // NMAX*(NMAX+1)         packed h rows
-constexpr int O_X = O_CH + NMAX * (NMAX + 1);         // (NMAX+1)*8            iterate X
-constexpr int O_G = O_X + (NMAX + 1) * NX;            // (NMAX+1)*8            g_k (constant part of dx_k)
-constexpr int O_ROW = O_G + (NMAX + 1) * NX;          // 36*NMAX               IPM row state [field][row*2+side][lane]
+constexpr int O_ROW = O_CH + NMAX * (NMAX + 1);       // 36*NMAX               IPM row state [field][row*2+side][lane]
+//   aliased into the row-state region (alive before the IPM initialises it / after it has been consumed):
+constexpr int O_X = O_ROW;                            //     (NMAX+1)*8  iterate X
+constexpr int O_U = O_X + (NMAX + 1) * NX;            //     NVP         iterate U
 constexpr int O_GAMH = O_ROW + 36 * NMAX;             // NMAX                  gamma of the h rows
-constexpr int O_WH = O_GAMH + NMAX;                   // NMAX                  rhs weights of the h rows
+constexpr int O_WH = O_GAMH;                          //   (same buffer: gamma while assembling, weights while forming the rhs)
 constexpr int O_WB = O_WH + NMAX;                     // NMAX                  box-row scalars (gamma / weights)
 constexpr int O_SFX = O_WB + NMAX;                    // NMAX+8                suffix sums over the steering-angle rows
 constexpr int O_DV = O_SFX + NMAX + 8;                // NVP                   broadcast copy of a v-space vector
-constexpr int O_INVD = O_DV + NVP;                    // NVP                   1 / d_j
-constexpr int O_DD = O_INVD + NVP;                    // NVP                   d_j (pivots of L D L')
-constexpr int O_U = O_DD + NVP;                       // NVP                   iterate U
-constexpr int O_PEN = O_U + NVP;                      // 36 (+4)               slack penalties [class][slot][zl,zu,Zl,Zu]
+constexpr int O_DD = O_DV + NVP;                      // NVP                   d_j (pivots of L D L')
+constexpr int O_PEN = O_DD + NVP;                     // 36 (+4)               slack penalties [class][slot][zl,zu,Zl,Zu]
 constexpr int LDS_DOUBLES = O_PEN + 40;
 constexpr int LDS_BYTES = LDS_DOUBLES * 8;
-static_assert(O_D + 2 * NMAX <= O_CH, "aliased condensing scratch must fit inside the KKT matrix region");
-static_assert(LDS_BYTES <= 80 * 1024, "two workgroups per CU need <= 80 KiB each");
+constexpr int WS_DOUBLES = NMAX * ABS;                // per-instance HBM workspace (parked linearisation records)
+static_assert(O_G + (NMAX + 1) * NX <= O_CH, "aliased condensing scratch must fit inside the KKT matrix region");
+static_assert(O_U + NVP <= O_GAMH, "aliased iterate must fit inside the row-state region");
+static_assert(LDS_BYTES <= 52 * 1024, "three workgroups per CU (allocation granularity leaves < 53.3 KiB)");
 
 struct Model {
     double lf, lr, inv_m, inv_Iz, m, ka;            // ka = 0.5*ro*S*Cd
@@ -85,6 +90,7 @@ struct KArgs {
     double *dbg;                                      // debug dump, instance 0.. (flags&2)
     int dbg_stride;
     long long *prof;                                  // [b][12] phase cycle counters (flags&4)
+    double *ws;                                       // [b][WS_DOUBLES] linearisation records parked during the IPM
 };
 
 // ---------------------------------------------------------------- wave helpers
@@ -94,36 +100,47 @@ __device__ __forceinline__ double rl(double v, int lane)   // broadcast lane `la
     int hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
     return __hiloint2double(hi, lo);
 }
-__device__ __forceinline__ double wave_sum(double v)
+// ---- wavefront scans / reductions on DPP (row_shr 1,2,4,8 then row_bcast 15/31: the gfx9 wave64 scan
+//      sequence). No LDS round trips, unlike __shfl: a 64-lane scan costs ~12 DPP moves + 6 ops.
+template <int CTRL, int ROWMASK>
+__device__ __forceinline__ double dpp_f64(double ident, double v)
 {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    const int lo = __builtin_amdgcn_update_dpp(__double2loint(ident), __double2loint(v), CTRL, ROWMASK, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(__double2hiint(ident), __double2hiint(v), CTRL, ROWMASK, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+#define TUM_DPP_SCAN(OP, IDENT)                                   \
+    v = OP(v, dpp_f64<0x111, 0xf>(IDENT, v));                     \
+    v = OP(v, dpp_f64<0x112, 0xf>(IDENT, v));                     \
+    v = OP(v, dpp_f64<0x114, 0xf>(IDENT, v));                     \
+    v = OP(v, dpp_f64<0x118, 0xf>(IDENT, v));                     \
+    v = OP(v, dpp_f64<0x142, 0xa>(IDENT, v));                     \
+    v = OP(v, dpp_f64<0x143, 0xc>(IDENT, v));
+__device__ __forceinline__ double op_add(double a, double b) { return a + b; }
+__device__ __forceinline__ double op_max(double a, double b) { return fmax(a, b); }
+// inclusive prefix sum over the 64 lanes
+__device__ __forceinline__ double wave_prefix(double v, int /*lane*/)
+{
+    TUM_DPP_SCAN(op_add, 0.0)
     return v;
 }
-__device__ __forceinline__ double wave_max(double v)
-{
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o, 64));
-    return v;
-}
-__device__ __forceinline__ double wave_min(double v)
-{
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmin(v, __shfl_xor(v, o, 64));
-    return v;
-}
-// inclusive prefix / suffix sums over the 64 lanes
-__device__ __forceinline__ double wave_prefix(double v, int lane)
-{
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) { const double t = __shfl_up(v, o, 64); if (lane >= o) v += t; }
-    return v;
-}
+// inclusive suffix sum: reverse, prefix, reverse
 __device__ __forceinline__ double wave_suffix(double v, int lane)
 {
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) { const double t = __shfl_down(v, o, 64); if (lane + o < 64) v += t; }
-    return v;
+    v = __shfl(v, 63 - lane, 64);
+    TUM_DPP_SCAN(op_add, 0.0)
+    return __shfl(v, 63 - lane, 64);
+}
+__device__ __forceinline__ double wave_sum(double v)
+{
+    TUM_DPP_SCAN(op_add, 0.0)
+    return rl(v, 63);
+}
+// max of NON-NEGATIVE values (identity 0)
+__device__ __forceinline__ double wave_max(double v)
+{
+    TUM_DPP_SCAN(op_max, 0.0)
+    return rl(v, 63);
 }
 // 1/x to ~1 ulp without the IEEE division sequence: v_rcp_f64 + two Newton steps (5 VALU instead of ~27)
 __device__ __forceinline__ double frcp(double x)

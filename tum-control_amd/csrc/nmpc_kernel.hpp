@@ -77,7 +77,7 @@ __global__ void __launch_bounds__(64, 1) nmpc_rti_kernel(const KArgs ka)
 
     double *sAB = lds + O_AB, *sM = lds + O_M, *sStage = lds + O_STAGE, *sCh = lds + O_CH, *sX = lds + O_X;
     double *sG = lds + O_G, *sRes = lds + O_RES, *sGh = lds + O_GH, *sD = lds + O_D, *sGamH = lds + O_GAMH;
-    double *sWh = lds + O_WH, *sWb = lds + O_WB, *sSfx = lds + O_SFX, *sDv = lds + O_DV, *sInvD = lds + O_INVD;
+    double *sWh = lds + O_WH, *sWb = lds + O_WB, *sSfx = lds + O_SFX, *sDv = lds + O_DV;
     double *sDd = lds + O_DD, *sU = lds + O_U, *sPen = lds + O_PEN, *sRow = lds + O_ROW;
 
     double *gX = ka.X + (size_t)b * (N + 1) * NX;
@@ -279,6 +279,11 @@ __global__ void __launch_bounds__(64, 1) nmpc_rti_kernel(const KArgs ka)
         for (int i = lane; i < (N + 1) * NX; i += 64) dbg[12960 + i] = sG[i];
     }
 
+    // park the linearisation records in the HBM/L2 workspace: their LDS space becomes the KKT matrix
+    {
+        double *ws = ka.ws + (size_t)b * WS_DOUBLES;
+        for (int i = lane; i < N * ABS; i += 64) ws[i] = sAB[i];
+    }
     TUM_TICK(1);
     // ------------------------------------------------------------ phase 3: interior point
     // Row state lives in LDS between the (short) row phases so that the long factorisation / substitution
@@ -496,7 +501,6 @@ __global__ void __launch_bounds__(64, 1) nmpc_rti_kernel(const KArgs ka)
                 if (lane == 0) {
                     sM[r1] = l10; sM[r2] = l20; sM[r2 + 1] = l21; sM[r3] = l30; sM[r3 + 1] = l31; sM[r3 + 2] = l32;
                     sDd[c0] = d0; sDd[c0 + 1] = d1; sDd[c0 + 2] = d2; sDd[c0 + 3] = d3;
-                    sInvD[c0] = i0; sInvD[c0 + 1] = i1; sInvD[c0 + 2] = i2; sInvD[c0 + 3] = i3;
                 }
                 wsync();
                 // (d) rank-4 update of the panel's remaining columns on the matrix cores
@@ -527,7 +531,7 @@ __global__ void __launch_bounds__(64, 1) nmpc_rti_kernel(const KArgs ka)
         double cross1[6], cross2[6];                 // dT*dL and dS*dMu of the affine step
         double dv0 = 0.0, dv1 = 0.0, alpha = 1.0, sigma = 0.0;
         double dSt[4][6];                            // corrector step of (s, t, lam, mu), kept until alpha is known
-        const double invd0 = sInvD[lane], invd1 = sInvD[lane1] * ((lane < 16) ? 1.0 : 0.0);
+        const double invd0 = frcp(sDd[lane]), invd1 = frcp(sDd[lane1]) * ((lane < 16) ? 1.0 : 0.0);
 #pragma unroll 1
         for (int pass = 0; pass < 2; pass++) {
             const double tau = (pass == 1) ? fmax(sigma * gap, 0.1 * ka.tol_comp) : 0.0;
@@ -565,7 +569,7 @@ __global__ void __launch_bounds__(64, 1) nmpc_rti_kernel(const KArgs ka)
             // readlane, solved against the 4x4 unit-lower diagonal block on uniform values, and every other
             // row applies them with 4 FMAs against its (contiguous, prefetched) entries of L.
             // forward: L y = b
-#pragma unroll 2
+#pragma unroll
             for (int c0 = 0; c0 < 64; c0 += 4) {
                 const int r1 = lpk(c0 + 1, c0), r2 = lpk(c0 + 2, c0), r3 = lpk(c0 + 3, c0);
                 const double l10 = sM[r1], l20 = sM[r2], l21 = sM[r2 + 1], l30 = sM[r3], l31 = sM[r3 + 1], l32 = sM[r3 + 2];
@@ -623,7 +627,7 @@ __global__ void __launch_bounds__(64, 1) nmpc_rti_kernel(const KArgs ka)
                 if (lane == c0 - 63) b1 = x1;
                 if (lane == c0 - 62) b1 = x2;
             }
-#pragma unroll 2
+#pragma unroll
             for (int c0 = 60; c0 >= 0; c0 -= 4) {
                 const int r1 = lpk(c0 + 1, 0), r2 = lpk(c0 + 2, 0), r3 = lpk(c0 + 3, 0), r0b = lpk(c0, 0);
                 const double l10 = sM[r1 + c0], l20 = sM[r2 + c0], l21 = sM[r2 + c0 + 1];
@@ -733,21 +737,50 @@ __global__ void __launch_bounds__(64, 1) nmpc_rti_kernel(const KArgs ka)
 
     TUM_TICK(8);
     // ------------------------------------------------------------ phase 4: expand, full step, cost
+    // slack part of the cost and the slack outputs first: the row state is about to be overwritten by X, U
+    double cl = 0.0;
+    if (rowlane) {
+#pragma unroll
+        for (int rr = 0; rr < 3; rr++)
+#pragma unroll
+            for (int sd = 0; sd < 2; sd++) {
+                const double sv = ROWF(0, rr * 2 + sd);
+                cl += pen(rr, sd, 0) * sv + 0.5 * pen(rr, sd, 1) * sv * sv;
+            }
+        if (ka.slack) {
+            double *sl = ka.slack + (size_t)b * 6 * N;
+            // order: [lower: box_k (N) | (bx_k, h_k) k=1..N] then the same for upper
+#pragma unroll
+            for (int sd = 0; sd < 2; sd++) {
+                sl[sd * 3 * N + lane] = ROWF(0, 0 + sd);
+                sl[sd * 3 * N + N + 2 * lane] = ROWF(0, 2 + sd);
+                sl[sd * 3 * N + N + 2 * lane + 1] = ROWF(0, 4 + sd);
+            }
+        }
+    }
     wsync();
     sDv[lane] = v0;
     if (lane < 16) sDv[64 + lane] = v1;
+    // bring back the iterate and the linearisation records
+    for (int i = lane; i < (N + 1) * NX; i += 64) sX[i] = gX[i];
+    for (int i = lane; i < NVP; i += 64) sU[i] = (i < nv) ? gU[i] : 0.0;
+    {
+        const double *ws = ka.ws + (size_t)b * WS_DOUBLES;
+        for (int i = lane; i < N * ABS; i += 64) sAB[i] = ws[i];
+    }
     wsync();
     if (status == 0) {
-        // dx_0 = g_0 ; dx_{k+1} = A_k dx_k + B_k du_k + b_k   (every lane runs the same recurrence)
+        // dx_0 = x0 - X_0 ; dx_{k+1} = A_k dx_k + B_k du_k + b_k   (every lane runs the same recurrence)
         double dx[8];
 #pragma unroll
-        for (int i = 0; i < 8; i++) dx[i] = sG[i];
+        for (int i = 0; i < 8; i++) dx[i] = gx0[i] - sX[i];
         auto pick = [&](const double (&a)[8]) {
             double m = a[0];
 #pragma unroll
             for (int i = 1; i < 8; i++) if (lane == i) m = a[i];
             return m;
         };
+        wsync();
         if (lane < 8) sX[lane] += pick(dx);
         for (int k = 0; k < N; k++) {
             const double *rec = sAB + k * ABS;
@@ -764,7 +797,6 @@ __global__ void __launch_bounds__(64, 1) nmpc_rti_kernel(const KArgs ka)
     }
     wsync();
     // cost at the (new) iterate: stage terms scaled by dt, terminal unscaled, slack penalties pre-scaled
-    double cl = 0.0;
     if (lane <= N) {
         const int k = lane;
         const double sc = (k < N) ? dt : 1.0;
@@ -777,33 +809,13 @@ __global__ void __launch_bounds__(64, 1) nmpc_rti_kernel(const KArgs ka)
             e = sU[2 * k] - yr[4]; acc += Wd[4] * e * e;
             e = sU[2 * k + 1] - yr[5]; acc += Wd[5] * e * e;
         }
-        cl = 0.5 * sc * acc;
-    }
-    if (rowlane) {
-#pragma unroll
-        for (int rr = 0; rr < 3; rr++)
-#pragma unroll
-            for (int sd = 0; sd < 2; sd++)
-            {
-                const double sv = ROWF(0, rr * 2 + sd);
-                cl += pen(rr, sd, 0) * sv + 0.5 * pen(rr, sd, 1) * sv * sv;
-            }
+        cl += 0.5 * sc * acc;
     }
     const double cost = wave_sum(cl);
 
     // ------------------------------------------------------------ stores
     for (int i = lane; i < (N + 1) * NX; i += 64) gX[i] = sX[i];
     for (int i = lane; i < nv; i += 64) gU[i] = sU[i];
-    if (rowlane && ka.slack) {
-        double *sl = ka.slack + (size_t)b * 6 * N;
-        // order: [lower: box_k (N) | (bx_k, h_k) k=1..N] then the same for upper
-#pragma unroll
-        for (int sd = 0; sd < 2; sd++) {
-            sl[sd * 3 * N + lane] = ROWF(0, 0 + sd);
-            sl[sd * 3 * N + N + 2 * lane] = ROWF(0, 2 + sd);
-            sl[sd * 3 * N + N + 2 * lane + 1] = ROWF(0, 4 + sd);
-        }
-    }
     TUM_TICK(9);
     if ((ka.flags & 4) && lane == 0)
         for (int i = 0; i < 12; i++) ka.prof[(size_t)b * 12 + i] = pacc[i];

@@ -26,6 +26,7 @@ struct tum_ocp {
     double *dX, *dU, *dx0, *dyref, *dW, *dpen, *dbnd, *dcost, *dres, *dslack, *dqpin, *ddbg;
     int *dstatus, *dqpiter, *dqpstatus;
     long long *dprof;
+    double *dws;
     float last_ms;
     bool solved;
     std::vector<double> stage;     // host staging
@@ -74,6 +75,7 @@ extern "C" tum_ocp *tum_ocp_create(const tum_ocp_desc *desc)
     if (desc->store_qp_in) ok &= dalloc(&c->dqpin, B * N * 88) == hipSuccess;
     ok &= dalloc(&c->ddbg, (size_t)DBG_STRIDE * DBG_INST) == hipSuccess;
     ok &= dalloc(&c->dprof, B * 12) == hipSuccess;
+    ok &= dalloc(&c->dws, B * WS_DOUBLES) == hipSuccess;
     if (!ok) { fail("device allocation failed"); tum_ocp_free(c); return nullptr; }
 
     KArgs &ka = c->ka;
@@ -101,7 +103,7 @@ extern "C" tum_ocp *tum_ocp_create(const tum_ocp_desc *desc)
     ka.X = c->dX; ka.U = c->dU; ka.x0 = c->dx0; ka.yref = c->dyref; ka.W = c->dW; ka.pen = c->dpen; ka.bnd = c->dbnd;
     ka.cost = c->dcost; ka.res = c->dres; ka.slack = c->dslack;
     ka.status = c->dstatus; ka.qp_iter = c->dqpiter; ka.qp_status = c->dqpstatus;
-    ka.qpin = c->dqpin; ka.dbg = c->ddbg; ka.dbg_stride = DBG_STRIDE; ka.prof = c->dprof;
+    ka.qpin = c->dqpin; ka.dbg = c->ddbg; ka.dbg_stride = DBG_STRIDE; ka.prof = c->dprof; ka.ws = c->dws;
 
     if (hipFuncSetAttribute((const void *)nmpc_rti_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) != hipSuccess) {
         fail("hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed"); tum_ocp_free(c); return nullptr;
@@ -115,7 +117,7 @@ extern "C" void tum_ocp_free(tum_ocp *c)
     (void)hipFree(c->dX); (void)hipFree(c->dU); (void)hipFree(c->dx0); (void)hipFree(c->dyref); (void)hipFree(c->dW); (void)hipFree(c->dpen); (void)hipFree(c->dbnd);
     (void)hipFree(c->dcost); (void)hipFree(c->dres); (void)hipFree(c->dslack); (void)hipFree(c->dstatus); (void)hipFree(c->dqpiter); (void)hipFree(c->dqpstatus);
     if (c->dqpin) (void)hipFree(c->dqpin);
-    (void)hipFree(c->ddbg); (void)hipFree(c->dprof);
+    (void)hipFree(c->ddbg); (void)hipFree(c->dprof); (void)hipFree(c->dws);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
