@@ -122,6 +122,24 @@ double tum_ocp_last_kernel_ms(tum_ocp *c);
 /* debug: dump of condensed-QP intermediates of instance b (see csrc/nmpc_kernel.hip) */
 int tum_ocp_debug_dump(tum_ocp *c, int b, double *out, int len);
 
+/* ---- the small kernels either side of the solve ---------------------------------
+ * Scenario fan-out of the initial state (Stochastic_NMPC/stochastic_mpc_utils.py:78-91 compute_x0dist as a
+ * batch axis): batch must equal P*(S+1); instance p*(S+1) is pose p, instance p*(S+1)+s is pose p + offs[s-1].
+ * pose: P x 8, offs: S x 8 (host). Writes lbx_0 = ubx_0 of every instance. */
+int tum_ocp_set_x0_fanout(tum_ocp *c, const double *pose, const double *offs, int P, int S);
+/* PCE moments over each scenario group (Stochastic_NMPC/SNMPC_acados_settings.py:116-133): coefficients
+ * c = A v with the L x S least-squares PCE matrix A (row-major, host), mean = c_0, var = sum_{k>=1} c_k^2, for
+ * every component of field "x" (8) / "u" (2) at `stage` of the current iterate. mean, var: P x m (host). */
+int tum_pce_moments(tum_ocp *c, const char *field, int stage, const double *A, int L, int S, double *mean, double *var);
+/* R2NMPC constraint tightening after a solve (Reduced_Robustified_NMPC_class.py:286-366): propagates
+ * Sigma_{k+1} = A_k Sigma_k A_k' + B W B' with the A_k of the last linearisation (needs store_qp_in) and rewrites the
+ * capsule's lbx/ubx (steering angle) and uh (gg circle) of stages 1..N-1 for the NEXT solve.
+ * Sigma0, BWB: 8x8 row-major (host); backoff (optional, host): batch x N x 2 (steering, gg) back-offs. */
+int tum_ocp_r2_backoff(tum_ocp *c, const double *Sigma0, const double *BWB, int uph,
+                       double delta_min, double delta_max, double uh_nom, double *backoff);
+/* read back a bound installed with constraints_set / r2_backoff (one value per instance) */
+int tum_ocp_constraints_get(tum_ocp *c, int stage, const char *field, double *v, int b0, int nb);
+
 /* development aid: one solve with in-kernel phase timers; out = batch x 12 shader-cycle counters
  * [linearise, condense, ipm-residuals, M assembly, Cholesky, rhs, tri-solves, row updates, (iteration tail), expand+cost] */
 int tum_ocp_profile_phases(tum_ocp *c, long long *out);

@@ -228,3 +228,69 @@ def test_acados_error_behaviour():
     assert s.get(0, "x").shape == (8,) and s.get(0, "u").shape == (2,)
     with pytest.raises(RuntimeError):
         BatchedOcpSolver(N=41, batch=1)
+
+
+def test_scenario_fanout_and_pce_moments():
+    """BASELINE configs[2] shape (sigma-point fan-out; here 64 poses x 16): x0 fan-out kernel, per-scenario parity with the
+    oracle, and the PCE mean / variance reduction against numpy."""
+    from tum_control_amd.snmpc import ScenarioSNMPC
+    from tum_control_amd.workloads import scenario_batch
+    N, P = 40, 64
+    sn = ScenarioSNMPC(P, n_samples=15, N=N)
+    x0, yref, S1 = scenario_batch(P, sn.offsets, N=N)
+    assert S1 == 16
+    st, u0_nom, mean, var = sn.solve(x0[::S1], yref[::S1])
+    assert st == 0
+    X, U = sn.solver.get_iterate()
+    # fan-out
+    x0_dev = np.stack([sn.solver.get(0, "x")])[0]
+    # per-instance parity on a subset
+    o = _oracle_default(N)
+    for b in (0, 1, 7, 16, 17, 500, 1023):
+        o.cold_start(x0[b]); o.yref[:] = yref[b]; assert o.solve() == 0
+        assert np.abs(U[b] - o.U).max() < 1e-7
+    # moments
+    c = np.einsum("ls,psm->plm", sn.A, X[:, 1].reshape(P, S1, 8)[:, 1:])
+    np.testing.assert_allclose(mean, c[:, 0], atol=1e-10)
+    np.testing.assert_allclose(var, (c[:, 1:] ** 2).sum(axis=1), atol=1e-10)
+    assert np.abs(u0_nom - U[::S1, 0]).max() == 0.0
+
+
+def test_r2_backoff_two_consecutive_solves():
+    """BASELINE configs[4] protocol: solve, tighten (K7), solve again. The tightening is checked against a numpy
+    restatement of Reduced_Robustified_NMPC_class.py:286-366, the second solve against the oracle on the same bounds."""
+    from oracle.oracle import h_con
+    from tum_control_amd.r2nmpc import ReducedRobustifiedNMPC
+    from tum_control_amd.workloads import nominal_batch
+    N, B = 38, 12
+    x0, yref = nominal_batch(B, N=N, seed=21, track_name="modena")
+    r2 = ReducedRobustifiedNMPC(batch=B, N=N)
+    s = r2.solver
+    s.set_x0(x0); s.set_yref_all(yref); s.cold_start()
+    assert r2.solve() == 0
+    X, U = s.get_iterate()
+    bo = s.r2_backoff(r2.Sigma0, r2.BWB, r2.uph, r2.delta_f_min, r2.delta_f_max, 1.0, return_backoffs=True)
+    A = np.stack([s.get_from_qp_in(k, "A") for k in range(r2.uph)], axis=1)      # (B, uph, 8, 8)
+    for b in range(B):
+        Sig = r2.Sigma0.copy(); bd = bh = 0.0
+        for k in range(r2.uph):
+            if k > 0:
+                _, g = h_con(X[b, k])
+                bd = np.sqrt(Sig[6, 6]); bh = np.sqrt(g @ Sig @ g)
+                assert abs(bo[b, k, 0] - bd) < 1e-12 and abs(bo[b, k, 1] - bh) < 1e-10
+            Sig = A[b, k] @ Sig @ A[b, k].T + r2.BWB
+        for k in range(r2.uph, N):
+            assert abs(bo[b, k, 0] - bd) < 1e-12 and abs(bo[b, k, 1] - bh) < 1e-10
+    lbx3, ubx3, uh3 = s.constraints_get(3, "lbx"), s.constraints_get(3, "ubx"), s.constraints_get(3, "uh")
+    np.testing.assert_allclose(lbx3, r2.delta_f_min + bo[:, 3, 0], atol=1e-14)
+    np.testing.assert_allclose(ubx3, r2.delta_f_max - bo[:, 3, 0], atol=1e-14)
+    np.testing.assert_allclose(uh3, 1.0 - bo[:, 3, 1], atol=1e-14)
+    assert s.constraints_get(N, "uh").max() == 1.0 and s.constraints_get(0, "ubu").max() > 0    # terminal stage untouched
+    # second solve with the tightened bounds vs the oracle
+    assert r2.solve() == 0
+    X2, U2 = s.get_iterate()
+    for b in (0, 5, 11):
+        o = _oracle_default(N); o.cold_start(x0[b]); o.yref[:] = yref[b]; assert o.solve() == 0
+        o.lbx[1:N] = r2.delta_f_min + bo[b, 1:, 0]; o.ubx[1:N] = r2.delta_f_max - bo[b, 1:, 0]; o.uh[1:N] = 1.0 - bo[b, 1:, 1]
+        assert o.solve() == 0
+        assert np.abs(U2[b] - o.U).max() < 1e-6 and np.abs(X2[b] - o.X).max() < 1e-6

@@ -98,7 +98,7 @@ def test_cabi_exports_every_declared_symbol():
     g.build()
     from tum_control_amd import solver
     hdr = open(os.path.join(ROOT, "include", "tum_nmpc.h")).read()
-    declared = sorted(set(re.findall(r"\b(tum_ocp_\w+)\s*\(", hdr)))
+    declared = sorted(set(re.findall(r"\b(tum_(?:ocp|pce)_\w+)\s*\(", hdr)))
     assert len(declared) >= 20
     L = solver.load_library()
     for sym in declared:
@@ -124,3 +124,38 @@ def test_product_never_imports_oracle():
                 txt = open(os.path.join(dp, f)).read()
                 assert not re.search(r"^\s*(from|import)\s+oracle", txt, re.M), f
                 assert "liboracle" not in txt and "oracle/" not in txt, f
+
+
+def test_pce_helpers_match_reference_golden(golden_dir):
+    """alphaGeneration / hermiteGeneration / polyChaosExpansion / compute_x0dist restatements vs values captured
+    from the reference, and the Hammersley recipe vs the sigma points stored in acados_ocp_SNMPC.json."""
+    from tum_control_amd import snmpc
+    g = np.load(os.path.join(golden_dir, "pce.npz"))
+    assert np.array_equal(snmpc.alpha_generation(3, 2), g["alphas"])
+    for i, x in enumerate((-1.3, 0.0, 0.4, 2.2)):
+        for n in range(4):
+            assert abs(snmpc.hermite(x, n) - g["herm"][i, n]) < 1e-14
+    for i in range(g["w"].shape[1]):
+        np.testing.assert_allclose(snmpc.pce_basis(g["w"][:, i], g["alphas"]), g["phi"][i], atol=1e-13)
+    np.testing.assert_allclose(snmpc.compute_x0dist(g["x0"], g["w"], g["stds"]), g["x0dist"], atol=1e-14)
+    # sigma points of the exported SNMPC OCP: n_s = 10, stds at export time (1.1, 0.2, 0.05) on states 3,4,5
+    w = snmpc.hammersley_normal(10, 3)
+    lb = g["json_lbx0"]
+    off = snmpc.x0_offsets(w, [0, 0, 0, 1.1, 0.2, 0.05, 0, 0])
+    np.testing.assert_allclose(lb[1:] - lb[0], off, atol=1e-12)
+    A = snmpc.pce_matrix(w, snmpc.alpha_generation(3, 2))
+    assert A.shape == (10, 10)
+    # the PCE of a constant is that constant with zero variance
+    c = A @ np.full(10, 3.5)
+    assert abs(c[0] - 3.5) < 1e-9 and np.abs(c[1:]).max() < 1e-9
+
+
+def test_r2_setup_matches_reference_propagation(golden_dir):
+    from tum_control_amd.r2nmpc import r2_setup
+    g = np.load(os.path.join(golden_dir, "r2.npz"))
+    # P_propagation golden: A P A' + B W B'
+    for i in range(len(g["P"])):
+        np.testing.assert_allclose(g["A"][i] @ g["P"][i] @ g["A"][i].T + g["B"][i] @ g["W"] @ g["B"][i].T, g["Pn"][i], atol=1e-10)
+    S0, BWB = r2_setup([0, 0, 0, 0.8, 0.35, 0.035, 0, 0], 0.08)
+    assert S0.shape == (8, 8) and abs(S0[3, 3] - (0.5 * 0.8) ** 2) < 1e-15 and abs(S0[0, 0] - (0.5e-5) ** 2) < 1e-20
+    assert abs(BWB[4, 4] - 0.08 * 0.35 ** 2) < 1e-15 and BWB[6, 6] == 0.0 and BWB[2, 2] == 0.0

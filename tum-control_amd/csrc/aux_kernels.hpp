@@ -1,0 +1,101 @@
+// aux_kernels.hpp -- the small kernels either side of the SQP-RTI solve.
+#pragma once
+#include "nmpc_device.hpp"
+
+namespace tum {
+
+// K6a  sigma-point fan-out: instance p*S1 + 0 = pose p (nominal), p*S1 + s = pose p + offs[s-1]
+//      (Stochastic_NMPC/stochastic_mpc_utils.py:78-91 compute_x0dist, as a batch axis)
+__global__ void sigma_fanout_kernel(double *x0, const double *pose, const double *offs, int P, int S1)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;          // over P*S1*8
+    if (i >= P * S1 * NX) return;
+    const int c = i & 7, inst = i >> 3, p = inst / S1, s = inst - p * S1;
+    x0[i] = pose[p * NX + c] + (s > 0 ? offs[(s - 1) * NX + c] : 0.0);
+}
+
+// K6b  PCE moments over scenario groups: c = A v (A: L x S least-squares PCE matrix), E = c_0,
+//      Var = sum_{k>=1} c_k^2  (Stochastic_NMPC/SNMPC_acados_settings.py:116-133).
+//      V: [P*S1][m] per-instance quantities (row p*S1 is the nominal instance and is skipped);
+//      one thread per (group, component); A is small and read through the scalar/L1 path.
+__global__ void pce_moments_kernel(const double *V, const double *A, int P, int S1, int m, int L, double *mean, double *var)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;          // over P*m
+    if (i >= P * m) return;
+    const int p = i / m, c = i - p * m, S = S1 - 1;
+    const double *v = V + ((size_t)p * S1 + 1) * m + c;
+    double e = 0.0, va = 0.0;
+    for (int k = 0; k < L; k++) {
+        double ck = 0.0;
+        for (int s = 0; s < S; s++) ck += A[k * S + s] * v[(size_t)s * m];
+        if (k == 0) e = ck; else va += ck * ck;
+    }
+    mean[i] = e; var[i] = va;
+}
+
+// K7  R2NMPC constraint tightening (Reduced_Robustified_NMPC_class.py:286-366): per instance
+//      Sigma_{k+1} = A_k Sigma_k A_k' + B W B'   (Robust_NMPC_pred_model_utils.py:221-223),
+//      for k = 1..uph-1: steering back-off sqrt(Sigma_k[6][6]), gg back-off sqrt(grad_h(x_k)' Sigma_k grad_h(x_k)),
+//      lbx_k = delta_min + b_d, ubx_k = delta_max - b_d, uh_k = uh_nom - b_h; stages uph..N-1 reuse the last pair.
+//      One wavefront per instance, lane (i,j) owns entry (i,j) of the 8x8 covariance; the 8x8 blocks go
+//      through LDS (the "small-block LDS path" of BASELINE config 5).
+__global__ void __launch_bounds__(256) r2_backoff_kernel(const double *qpin, const double *X, double *bnd, const Model mp,
+                                                         const double *Sigma0, const double *BWB, int N, int uph, int batch,
+                                                         double dmin, double dmax, double uh_nom, double *backoff_out)
+{
+    __shared__ double sA[4][64], sS[4][64], sT[4][64];
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int b = blockIdx.x * 4 + w;
+    const bool on = b < batch;
+    const int i = lane >> 3, j = lane & 7;
+    double sig = Sigma0[lane];
+    const double bwb = BWB[lane];
+    double bd = 0.0, bh = 0.0;
+    const int NB = N + 1;
+    for (int k = 0; k < uph && k < N; k++) {
+        if (k > 0) {
+            // back-offs from Sigma_k at the new iterate x_k
+            sS[w][lane] = sig;
+            __syncthreads();
+            if (on) {
+                const double *x = X + ((size_t)b * (N + 1) + k) * NX;
+                double h, g3, g5, g7;
+                h_con(mp, x[3], x[5], x[7], h, g3, g5, g7);
+                const double q = g3 * (g3 * sS[w][3 * 8 + 3] + g5 * sS[w][3 * 8 + 5] + g7 * sS[w][3 * 8 + 7])
+                               + g5 * (g3 * sS[w][5 * 8 + 3] + g5 * sS[w][5 * 8 + 5] + g7 * sS[w][5 * 8 + 7])
+                               + g7 * (g3 * sS[w][7 * 8 + 3] + g5 * sS[w][7 * 8 + 5] + g7 * sS[w][7 * 8 + 7]);
+                bh = sqrt(q);
+                bd = sqrt(sS[w][6 * 8 + 6]);
+                if (lane == 0) {
+                    double *bb = bnd + (size_t)b * 6 * NB;
+                    bb[2 * NB + k] = dmin + bd; bb[3 * NB + k] = dmax - bd; bb[5 * NB + k] = uh_nom - bh;
+                    if (backoff_out) { backoff_out[((size_t)b * N + k) * 2] = bd; backoff_out[((size_t)b * N + k) * 2 + 1] = bh; }
+                }
+            }
+            __syncthreads();
+        }
+        // Sigma <- A Sigma A' + B W B'
+        sA[w][lane] = on ? qpin[((size_t)b * N + k) * 88 + lane] : 0.0;     // A row-major 8x8
+        sS[w][lane] = sig;
+        __syncthreads();
+        double t = 0.0;
+#pragma unroll
+        for (int l = 0; l < 8; l++) t += sA[w][i * 8 + l] * sS[w][l * 8 + j];
+        sT[w][lane] = t;
+        __syncthreads();
+        double s2 = bwb;
+#pragma unroll
+        for (int l = 0; l < 8; l++) s2 += sT[w][i * 8 + l] * sA[w][j * 8 + l];
+        sig = s2;
+        __syncthreads();
+    }
+    if (on && lane == 0) {
+        double *bb = bnd + (size_t)b * 6 * NB;
+        for (int k = uph; k < N; k++) {
+            bb[2 * NB + k] = dmin + bd; bb[3 * NB + k] = dmax - bd; bb[5 * NB + k] = uh_nom - bh;
+            if (backoff_out) { backoff_out[((size_t)b * N + k) * 2] = bd; backoff_out[((size_t)b * N + k) * 2 + 1] = bh; }
+        }
+    }
+}
+
+}  // namespace tum

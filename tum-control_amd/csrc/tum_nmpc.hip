@@ -10,6 +10,7 @@
 
 #include "../../include/tum_nmpc.h"
 #include "nmpc_kernel.hpp"
+#include "aux_kernels.hpp"
 
 using namespace tum;
 
@@ -440,4 +441,85 @@ extern "C" int tum_ocp_profile_phases(tum_ocp *c, long long *out)
     HIPCHK(hipStreamSynchronize(c->stream));
     HIPCHK(hipMemcpy(out, c->dprof, sizeof(long long) * 12 * (size_t)c->batch, hipMemcpyDeviceToHost));
     return 0;
+}
+
+// ---------------------------------------------------------------------------------------------- K6 / K7
+extern "C" int tum_ocp_set_x0_fanout(tum_ocp *c, const double *pose, const double *offs, int P, int S)
+{
+    if (!c || !pose || (S > 0 && !offs)) return fail("null argument");
+    const int S1 = S + 1;
+    if (P < 1 || S < 0 || (long long)P * S1 != c->batch) return fail("set_x0_fanout: P*(S+1) must equal the batch size");
+    double *dp = nullptr, *dofs = nullptr;
+    HIPCHK(hipMalloc((void **)&dp, sizeof(double) * P * NX));
+    HIPCHK(hipMalloc((void **)&dofs, sizeof(double) * (S > 0 ? S : 1) * NX));
+    HIPCHK(hipMemcpyAsync(dp, pose, sizeof(double) * P * NX, hipMemcpyHostToDevice, c->stream));
+    if (S > 0) HIPCHK(hipMemcpyAsync(dofs, offs, sizeof(double) * S * NX, hipMemcpyHostToDevice, c->stream));
+    const int n = P * S1 * NX;
+    hipLaunchKernelGGL(sigma_fanout_kernel, dim3((n + 255) / 256), dim3(256), 0, c->stream, c->dx0, dp, dofs, P, S1);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(c->stream));
+    (void)hipFree(dp); (void)hipFree(dofs);
+    return 0;
+}
+
+extern "C" int tum_pce_moments(tum_ocp *c, const char *field, int stage, const double *A, int L, int S, double *mean, double *var)
+{
+    if (!c || !field || !A || !mean || !var) return fail("null argument");
+    const int S1 = S + 1, N = c->N;
+    if (S < 1 || L < 1 || c->batch % S1 != 0) return fail("pce_moments: batch must be a multiple of S+1");
+    const int P = c->batch / S1;
+    const std::string f(field);
+    int m; const double *src; size_t rec, off;
+    if (f == "x") { if (stage < 0 || stage > N) return fail("pce_moments: stage"); m = NX; src = c->dX; rec = (size_t)(N + 1) * NX; off = (size_t)stage * NX; }
+    else if (f == "u") { if (stage < 0 || stage >= N) return fail("pce_moments: stage"); m = NU; src = c->dU; rec = (size_t)N * NU; off = (size_t)stage * NU; }
+    else return fail("pce_moments: unknown field '" + f + "'");
+    double *dV = nullptr, *dA = nullptr, *dm = nullptr, *dv = nullptr;
+    HIPCHK(hipMalloc((void **)&dV, sizeof(double) * c->batch * m));
+    HIPCHK(hipMalloc((void **)&dA, sizeof(double) * L * S));
+    HIPCHK(hipMalloc((void **)&dm, sizeof(double) * P * m));
+    HIPCHK(hipMalloc((void **)&dv, sizeof(double) * P * m));
+    HIPCHK(hipMemcpy2DAsync(dV, (size_t)m * 8, src + off, rec * 8, (size_t)m * 8, c->batch, hipMemcpyDeviceToDevice, c->stream));
+    HIPCHK(hipMemcpyAsync(dA, A, sizeof(double) * L * S, hipMemcpyHostToDevice, c->stream));
+    hipLaunchKernelGGL(pce_moments_kernel, dim3((P * m + 127) / 128), dim3(128), 0, c->stream, dV, dA, P, S1, m, L, dm, dv);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(mean, dm, sizeof(double) * P * m, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipMemcpyAsync(var, dv, sizeof(double) * P * m, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    (void)hipFree(dV); (void)hipFree(dA); (void)hipFree(dm); (void)hipFree(dv);
+    return 0;
+}
+
+extern "C" int tum_ocp_r2_backoff(tum_ocp *c, const double *Sigma0, const double *BWB, int uph,
+                                  double delta_min, double delta_max, double uh_nom, double *backoff)
+{
+    if (!c || !Sigma0 || !BWB) return fail("null argument");
+    if (!c->dqpin) return fail("r2_backoff: capsule created without store_qp_in");
+    if (!c->solved) return fail("r2_backoff: no solve yet");
+    if (uph < 1) return fail("r2_backoff: uncertainty propagation horizon < 1");
+    const int N = c->N;
+    double *dS = nullptr, *dB = nullptr, *dbo = nullptr;
+    HIPCHK(hipMalloc((void **)&dS, 64 * 8)); HIPCHK(hipMalloc((void **)&dB, 64 * 8));
+    if (backoff) { HIPCHK(hipMalloc((void **)&dbo, sizeof(double) * (size_t)c->batch * N * 2)); HIPCHK(hipMemsetAsync(dbo, 0, sizeof(double) * (size_t)c->batch * N * 2, c->stream)); }
+    HIPCHK(hipMemcpyAsync(dS, Sigma0, 64 * 8, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipMemcpyAsync(dB, BWB, 64 * 8, hipMemcpyHostToDevice, c->stream));
+    hipLaunchKernelGGL(r2_backoff_kernel, dim3((c->batch + 3) / 4), dim3(256), 0, c->stream, c->dqpin, c->dX, c->dbnd, c->ka.mp,
+                       dS, dB, N, uph, c->batch, delta_min, delta_max, uh_nom, dbo);
+    HIPCHK(hipGetLastError());
+    if (backoff) HIPCHK(hipMemcpyAsync(backoff, dbo, sizeof(double) * (size_t)c->batch * N * 2, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    (void)hipFree(dS); (void)hipFree(dB); if (dbo) (void)hipFree(dbo);
+    return 0;
+}
+
+extern "C" int tum_ocp_constraints_get(tum_ocp *c, int stage, const char *field, double *v, int b0, int nb)
+{
+    if (chk_range(c, b0, nb)) return 1;
+    if (!field || !v) return fail("null argument");
+    const int N = c->N, NB = N + 1;
+    const std::string f(field);
+    int row;
+    if (f == "lbu") row = 0; else if (f == "ubu") row = 1; else if (f == "lbx") row = 2; else if (f == "ubx") row = 3;
+    else if (f == "lh") row = 4; else if (f == "uh") row = 5; else return fail("constraints_get: unknown field '" + f + "'");
+    if (stage < 0 || stage > N) return fail("constraints_get: stage out of range");
+    return fetch(c, c->dbnd, (size_t)6 * NB, (size_t)row * NB + stage, v, 1, b0, nb, 1);
 }

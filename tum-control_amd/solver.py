@@ -47,7 +47,8 @@ C_SYMBOLS = ["tum_ocp_create", "tum_ocp_free", "tum_ocp_last_error", "tum_ocp_ba
              "tum_ocp_solve", "tum_ocp_solve_async", "tum_ocp_synchronize",
              "tum_ocp_get_cost", "tum_ocp_get_stats", "tum_ocp_reset", "tum_ocp_get_from_qp_in",
              "tum_ocp_set_stream", "tum_ocp_get_device", "tum_ocp_cold_start", "tum_ocp_last_kernel_ms",
-             "tum_ocp_debug_dump", "tum_ocp_profile_phases"]
+             "tum_ocp_debug_dump", "tum_ocp_profile_phases",
+             "tum_ocp_set_x0_fanout", "tum_pce_moments", "tum_ocp_r2_backoff", "tum_ocp_constraints_get"]
 
 
 def load_library(path=None):
@@ -85,6 +86,10 @@ def load_library(path=None):
     L.tum_ocp_last_kernel_ms.restype = ctypes.c_double; L.tum_ocp_last_kernel_ms.argtypes = [vp]
     L.tum_ocp_debug_dump.argtypes = [vp, ci, dp, ci]
     L.tum_ocp_profile_phases.argtypes = [vp, ctypes.POINTER(ctypes.c_longlong)]
+    L.tum_ocp_set_x0_fanout.argtypes = [vp, dp, dp, ci, ci]
+    L.tum_pce_moments.argtypes = [vp, cs, ci, dp, ci, ci, dp, dp]
+    L.tum_ocp_r2_backoff.argtypes = [vp, dp, dp, ci, ctypes.c_double, ctypes.c_double, ctypes.c_double, dp]
+    L.tum_ocp_constraints_get.argtypes = [vp, ci, cs, dp, ci, ci]
     if path is None:
         _lib = L
     return L
@@ -290,6 +295,37 @@ class BatchedOcpSolver:
 
     def last_kernel_ms(self):
         return float(self._L.tum_ocp_last_kernel_ms(self._h))
+
+    # ------------------------------------------------------------------ K6 / K7
+    def set_x0_fanout(self, pose, offsets):
+        """x0 of instance p*(S+1)+s = pose[p] (+ offsets[s-1] for s >= 1); batch must be P*(S+1)."""
+        pose = np.ascontiguousarray(pose, dtype=np.float64).reshape(-1, 8)
+        offsets = np.ascontiguousarray(offsets, dtype=np.float64).reshape(-1, 8)
+        self._chk(self._L.tum_ocp_set_x0_fanout(self._h, _dp(pose), _dp(offsets), pose.shape[0], offsets.shape[0]), "set_x0_fanout")
+
+    def pce_moments(self, field, stage, A):
+        """mean / variance over every scenario group of `field` ('x' or 'u') at `stage`; A is the L x S PCE matrix."""
+        A = np.ascontiguousarray(A, dtype=np.float64)
+        L_, S = A.shape
+        m = 8 if field == "x" else 2
+        P = self.batch // (S + 1)
+        mean = np.zeros((P, m)); var = np.zeros((P, m))
+        self._chk(self._L.tum_pce_moments(self._h, field.encode(), stage, _dp(A), L_, S, _dp(mean), _dp(var)), "pce_moments")
+        return mean, var
+
+    def r2_backoff(self, Sigma0, BWB, uph, delta_min, delta_max, uh_nom=1.0, return_backoffs=False):
+        """R2NMPC tightening of lbx/ubx/uh for the next solve from the last linearisation (store_qp_in capsules)."""
+        S0 = np.ascontiguousarray(Sigma0, dtype=np.float64).reshape(64)
+        BW = np.ascontiguousarray(BWB, dtype=np.float64).reshape(64)
+        bo = np.zeros((self.batch, self.N, 2)) if return_backoffs else None
+        self._chk(self._L.tum_ocp_r2_backoff(self._h, _dp(S0), _dp(BW), int(uph), float(delta_min), float(delta_max),
+                                             float(uh_nom), _dp(bo) if bo is not None else None), "r2_backoff")
+        return bo
+
+    def constraints_get(self, stage, field):
+        out = np.zeros(self.batch)
+        self._chk(self._L.tum_ocp_constraints_get(self._h, stage, field.encode(), _dp(out), 0, self.batch), "constraints_get")
+        return float(out[0]) if self.batch == 1 else out
 
     def profile_phases(self):
         """One solve with the in-kernel phase timers on: (batch, 12) shader-cycle counters."""
