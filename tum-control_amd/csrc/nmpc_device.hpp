@@ -50,8 +50,8 @@ constexpr int O_G = O_D + 2 * NMAX;                   //     (NMAX+1)*8  g_k (co
 constexpr int O_CH = O_M + LPK;                       // NMAX*(NMAX+1)         packed h rows
 constexpr int O_ROW = O_CH + NMAX * (NMAX + 1);       // 36*NMAX               IPM row state [field][row*2+side][lane]
 //   aliased into the row-state region (alive before the IPM initialises it / after it has been consumed):
-constexpr int O_X = O_ROW;                            //     (NMAX+1)*8  iterate X
-constexpr int O_U = O_X + (NMAX + 1) * NX;            //     NVP         iterate U
+constexpr int O_U = O_ROW + 36 * NMAX - NVP;          //     NVP         iterate U        (at the END of the region, so that
+constexpr int O_X = O_U - (NMAX + 1) * NX;            //     (NMAX+1)*8  iterate X         [O_CH, O_X) is one free block in phase 1)
 constexpr int O_GAMH = O_ROW + 36 * NMAX;             // NMAX                  gamma of the h rows
 constexpr int O_WH = O_GAMH;                          //   (same buffer: gamma while assembling, weights while forming the rhs)
 constexpr int O_WB = O_WH + NMAX;                     // NMAX                  box-row scalars (gamma / weights)

@@ -1,11 +1,13 @@
 // nmpc_kernel.hpp -- the fused SQP-RTI kernel (one wavefront = one OCP instance).
 #pragma once
+#include <type_traits>
+
 #include "nmpc_device.hpp"
 
 namespace tum {
 
 // optional in-kernel phase timers (flags & 4): cycles per phase accumulated into ka.prof[b][12]
-#define TUM_TICK(slot) do { asm volatile("; TUM_MARK " #slot); if (ka.flags & 4) { const long long t_ = __builtin_readcyclecounter(); pacc[slot] += t_ - tprev; tprev = t_; } } while (0)
+#define TUM_TICK(slot) do { asm volatile("; TUM_MARK " #slot); if (PROF) { const long long t_ = __builtin_readcyclecounter(); pacc[slot] += t_ - tprev; tprev = t_; } } while (0)
 
 __device__ __forceinline__ int acados_status(int qp_status) { return (qp_status == 0 || qp_status == 1) ? 0 : 4; }
 
@@ -65,6 +67,7 @@ __device__ __forceinline__ int acados_status(int qp_status) { return (qp_status 
     for (int I = 0; I < NT; I++) rb[I] = lpk(16 * I + lc, 0); \
     const int myrow0 = lpk(lane, 0), myrow1 = lpk(lane1, 0);
 
+template <bool PROF>
 __global__ void __launch_bounds__(64, 1) nmpc_rti_kernel(const KArgs ka)
 {
     extern __shared__ __attribute__((aligned(16))) double lds[];
@@ -94,18 +97,13 @@ __global__ void __launch_bounds__(64, 1) nmpc_rti_kernel(const KArgs ka)
     for (int i = lane; i < (N + 1) * NX; i += 64) sX[i] = gX[i];
     for (int i = lane; i < NVP; i += 64) sU[i] = (i < nv) ? gU[i] : 0.0;
     if (lane < 36) sPen[lane] = gpen[lane];
-    double Wd[6], We[4];
-#pragma unroll
-    for (int i = 0; i < 6; i++) Wd[i] = gW[i];
-#pragma unroll
-    for (int i = 0; i < 4; i++) We[i] = gW[6 + i];
     wsync();
 
     // ------------------------------------------------------------ phase 1: linearise (lane = stage)
-    double yr[6];
     {
         const int k = lane;
         if (k <= N) {
+            double yr[6];
 #pragma unroll
             for (int i = 0; i < 6; i++) yr[i] = gyref[k * 6 + i];
             double xk[8];
@@ -159,6 +157,12 @@ __global__ void __launch_bounds__(64, 1) nmpc_rti_kernel(const KArgs ka)
     const int lq = lane >> 4, lc = lane & 15;
     double q0 = 0.0, q1 = 0.0;
     d4 Ht[NTT];
+    {
+    double Wd[6], We[4];
+#pragma unroll
+    for (int i = 0; i < 6; i++) Wd[i] = gW[i];
+#pragma unroll
+    for (int i = 0; i < 4; i++) We[i] = gW[6 + i];
 #pragma unroll
     for (int i = 0; i < NTT; i++) Ht[i] = d4{0.0, 0.0, 0.0, 0.0};
     {
@@ -169,7 +173,10 @@ __global__ void __launch_bounds__(64, 1) nmpc_rti_kernel(const KArgs ka)
 #pragma unroll
             for (int i = 0; i < 8; i++) { w1[i] = gx0[i] - sX[i]; sG[i] = w1[i]; }
         }
-        for (int k = 0; k < N; k++) {
+        // One condensing stage. The number of 16-column tiles the stage touches (Ts) is a compile-time
+        // constant per segment of 8 stages, so every MFMA targets a fixed accumulator (no conditional tiles).
+        auto stage_body = [&](const int k, auto tsc) {
+            constexpr int Ts = decltype(tsc)::value;
             const double *rec = sAB + k * ABS;
             // bank 0
             if (j0 < k) apply_A(rec, w0);
@@ -224,21 +231,25 @@ __global__ void __launch_bounds__(64, 1) nmpc_rti_kernel(const KArgs ka)
                 if (lane < 16) q1 += a1;
             }
             // Gauss-Newton Hessian SYRK (rank-4 update per stage) on the matrix cores
-            const int Ts = (2 * s + 15) >> 4;
             const double wl = (lq == 0) ? wr[0] : (lq == 1) ? wr[1] : (lq == 2) ? wr[2] : wr[3];
-            double aop[NT], bop[NT];
+            double aop[Ts], bop[Ts];
 #pragma unroll
-            for (int T = 0; T < NT; T++) {
-                bop[T] = (T < Ts) ? sStage[lq * NVP + 16 * T + lc] : 0.0;
+            for (int T = 0; T < Ts; T++) {
+                bop[T] = sStage[lq * NVP + 16 * T + lc];
                 aop[T] = bop[T] * wl;
             }
 #pragma unroll
-            for (int K = 0; K < NT; K++)
+            for (int K = 0; K < Ts; K++)
 #pragma unroll
-                for (int I = K; I < NT; I++)
-                    if (I < Ts) Ht[tidx(K, I)] = mfma(aop[K], bop[I], Ht[tidx(K, I)]);
+                for (int I = K; I < Ts; I++) Ht[tidx(K, I)] = mfma(aop[K], bop[I], Ht[tidx(K, I)]);
             wsync();
-        }
+        };
+        // stage s = k+1 touches columns < 2s, i.e. ceil(s/8) tiles
+        for (int k = 0; k < N && k < 8; k++) stage_body(k, std::integral_constant<int, 1>());
+        for (int k = 8; k < N && k < 16; k++) stage_body(k, std::integral_constant<int, 2>());
+        for (int k = 16; k < N && k < 24; k++) stage_body(k, std::integral_constant<int, 3>());
+        for (int k = 24; k < N && k < 32; k++) stage_body(k, std::integral_constant<int, 4>());
+        for (int k = 32; k < N; k++) stage_body(k, std::integral_constant<int, 5>());
     }
     // input cost (R) and padding on the diagonal, gradient of the input cost
 #pragma unroll
@@ -255,6 +266,7 @@ __global__ void __launch_bounds__(64, 1) nmpc_rti_kernel(const KArgs ka)
         if (lane < nv) q0 += dt * Wd[4 + r0] * (sU[lane] - gyref[j0 * 6 + 4 + r0]);
         if (lane < 16 && 64 + lane < nv) q1 += dt * Wd[4 + r0] * (sU[64 + lane] - gyref[j1 * 6 + 4 + r0]);
     }
+    }   // Wd, We
 
     if ((ka.flags & 2) && b < 4) {   // debug dump of the condensed QP
         double *dbg = ka.dbg + (size_t)b * ka.dbg_stride;
@@ -530,7 +542,6 @@ __global__ void __launch_bounds__(64, 1) nmpc_rti_kernel(const KArgs ka)
         // ---- predictor / corrector
         double cross1[6], cross2[6];                 // dT*dL and dS*dMu of the affine step
         double dv0 = 0.0, dv1 = 0.0, alpha = 1.0, sigma = 0.0;
-        double dSt[4][6];                            // corrector step of (s, t, lam, mu), kept until alpha is known
         const double invd0 = frcp(sDd[lane]), invd1 = frcp(sDd[lane1]) * ((lane < 16) ? 1.0 : 0.0);
 #pragma unroll 1
         for (int pass = 0; pass < 2; pass++) {
@@ -711,10 +722,15 @@ __global__ void __launch_bounds__(64, 1) nmpc_rti_kernel(const KArgs ka)
                 sigma = ratio * ratio * ratio;
             } else {
                 alpha = (amax >= 1.0) ? 1.0 : 0.995 * amax;
+                if (alpha >= 1e-12 && rowlane) {
+                    const double om_ = 1.0 - alpha;
 #pragma unroll
-                for (int f = 0; f < 4; f++)
+                    for (int k = 0; k < 6; k++) {
 #pragma unroll
-                    for (int k = 0; k < 6; k++) dSt[f][k] = dcur[f][k];
+                        for (int f = 0; f < 4; f++) ROWF(f, k) += alpha * dcur[f][k];
+                        ROWF(4, k) *= om_; ROWF(5, k) *= om_;
+                    }
+                }
             }
             TUM_TICK(7);
         }
@@ -722,14 +738,6 @@ __global__ void __launch_bounds__(64, 1) nmpc_rti_kernel(const KArgs ka)
         v0 += alpha * dv0; v1 += alpha * dv1;
         const double om = 1.0 - alpha;
         rv0 *= om; rv1 *= om;
-        if (rowlane) {
-#pragma unroll
-            for (int k = 0; k < 6; k++) {
-#pragma unroll
-                for (int f = 0; f < 4; f++) ROWF(f, k) += alpha * dSt[f][k];
-                ROWF(4, k) *= om; ROWF(5, k) *= om;
-            }
-        }
         wsync();
     }
     const int status = acados_status(qp_status);
@@ -797,7 +805,13 @@ __global__ void __launch_bounds__(64, 1) nmpc_rti_kernel(const KArgs ka)
     }
     wsync();
     // cost at the (new) iterate: stage terms scaled by dt, terminal unscaled, slack penalties pre-scaled
+    // (weights and references are re-read here rather than kept in registers across the whole IPM)
     if (lane <= N) {
+        double Wd[6], We[4], yr[6];
+#pragma unroll
+        for (int i = 0; i < 6; i++) { Wd[i] = gW[i]; yr[i] = gyref[lane * 6 + i]; }
+#pragma unroll
+        for (int i = 0; i < 4; i++) We[i] = gW[6 + i];
         const int k = lane;
         const double sc = (k < N) ? dt : 1.0;
         double acc = 0.0, e;
@@ -817,7 +831,7 @@ __global__ void __launch_bounds__(64, 1) nmpc_rti_kernel(const KArgs ka)
     for (int i = lane; i < (N + 1) * NX; i += 64) gX[i] = sX[i];
     for (int i = lane; i < nv; i += 64) gU[i] = sU[i];
     TUM_TICK(9);
-    if ((ka.flags & 4) && lane == 0)
+    if (PROF && lane == 0)
         for (int i = 0; i < 12; i++) ka.prof[(size_t)b * 12 + i] = pacc[i];
     if (lane == 0) {
         ka.cost[b] = cost;

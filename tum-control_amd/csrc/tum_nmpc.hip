@@ -106,7 +106,8 @@ extern "C" tum_ocp *tum_ocp_create(const tum_ocp_desc *desc)
     ka.status = c->dstatus; ka.qp_iter = c->dqpiter; ka.qp_status = c->dqpstatus;
     ka.qpin = c->dqpin; ka.dbg = c->ddbg; ka.dbg_stride = DBG_STRIDE; ka.prof = c->dprof; ka.ws = c->dws;
 
-    if (hipFuncSetAttribute((const void *)nmpc_rti_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) != hipSuccess) {
+    if (hipFuncSetAttribute((const void *)nmpc_rti_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) != hipSuccess ||
+        hipFuncSetAttribute((const void *)nmpc_rti_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) != hipSuccess) {
         fail("hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed"); tum_ocp_free(c); return nullptr;
     }
     return c;
@@ -292,7 +293,8 @@ static int launch(tum_ocp *c)
 {
     HIPCHK(hipSetDevice(c->d.device));
     HIPCHK(hipEventRecord(c->ev0, c->stream));
-    hipLaunchKernelGGL(nmpc_rti_kernel, dim3(c->batch), dim3(64), LDS_BYTES, c->stream, c->ka);
+    if (c->ka.flags & 4) hipLaunchKernelGGL(nmpc_rti_kernel<true>, dim3(c->batch), dim3(64), LDS_BYTES, c->stream, c->ka);
+    else hipLaunchKernelGGL(nmpc_rti_kernel<false>, dim3(c->batch), dim3(64), LDS_BYTES, c->stream, c->ka);
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(c->ev1, c->stream));
     c->solved = true;

@@ -21,7 +21,7 @@ import numpy as np
 from . import config as _config
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libtumnmpc.so")
+LIB_PATH = os.environ.get("TUM_NMPC_LIB", os.path.join(_HERE, "libtumnmpc.so"))   # override: A/B testing of builds
 ALL_STAGES = -1
 
 
