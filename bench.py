@@ -182,6 +182,17 @@ def main():
         mean_it = float(it.mean())
         flops = algorithmic_flops(N, 3, mean_it) * B
         abytes = algorithmic_bytes(N, warm=False, per_instance_yref=True) * B
+        # HBM bytes per launch from the PMC counters cannot be collected from inside this process; they come
+        # from the committed rocprofv3 --pmc passes of this same command (profiles/*_traffic.json), only when
+        # the workload matches what was profiled.
+        traffic, traffic_src = None, None
+        try:
+            tj = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_traffic.json"))[-1]
+            tr = json.load(open(os.path.join(ROOT, "profiles", tj)))
+            if tr.get("batch") == B and tr.get("N") == N:
+                traffic, traffic_src = tr["traffic_bytes_per_launch"], "profiles/" + tj
+        except Exception:
+            pass
         ach_tf = flops / (kern_ms * 1e-3) / 1e12
         ach_gb = abytes / (kern_ms * 1e-3) / 1e9
         out = {
@@ -193,7 +204,7 @@ def main():
                                    "one wavefront per OCP", "N": N, "nx": 8, "nu": 2, "nsub": 3, "batch_per_gpu": B,
                        "global_batch": world * B, "parallelism": f"instances sharded x{world}, RCCL gather of (u0,cost,status,qp_iter)"},
             "roofline": {"bound": "mfma", "achieved": ach_tf, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": ach_tf / FP64_PEAK_TFLOPS, "traffic": None,
+                         "frac": ach_tf / FP64_PEAK_TFLOPS, "traffic": traffic, "traffic_source": traffic_src,
                          "kernel": "nmpc_rti_kernel", "kernel_ms": kern_ms, "mean_qp_iter": mean_it,
                          "flops_per_solve": flops / B,
                          "hbm": {"achieved": ach_gb, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": ach_gb / HBM_PEAK_GBPS,
