@@ -35,11 +35,13 @@ __host__ __device__ constexpr int lpk(int i, int j) { return i * (i + 1) / 2 + j
 //  row s of that block is dt on the odd (steering-rate) columns < 2s and 0 elsewhere.)
 __host__ __device__ constexpr int hoff(int s) { return s * (s - 1); }
 
-// LDS carve (offsets in doubles). Three workgroups per CU need <= 53.3 KiB each, so everything that is
-// only alive before the interior point loop (linearisation records, condensing scratch, the iterate) is
-// aliased into regions the IPM owns; the linearisation records are parked in HBM/L2 (KArgs::ws) while the
-// IPM runs and come back for the final expansion.
-constexpr int O_M = 0;                                // LPK                   KKT matrix / L D L' factor
+// LDS carve (offsets in doubles). FOUR workgroups per CU (one wavefront on every SIMD) need <= 40 KiB each:
+// only the KKT matrix, the packed gg rows and a handful of vectors stay in LDS during the interior point
+// loop. Everything that is alive only before the loop (linearisation records, condensing scratch, the
+// iterate) is aliased into those regions; the records are parked in HBM/L2 (KArgs::ws) while the IPM runs
+// and come back for the final expansion; the IPM row state lives in registers; the pivots d_j sit on the
+// diagonal of the (unit-lower) factor.
+constexpr int O_M = 0;                                // LPK                   KKT matrix / L D L' factor (d on the diagonal)
 //   aliased into the M region (dead before the first KKT assembly, reloaded after the last):
 constexpr int O_AB = O_M;                             //     NMAX*ABS    compact (Sp,S,b) per stage
 constexpr int O_STAGE = O_AB + NMAX * ABS;            //     4 x NVP     staging rows for the H SYRK
@@ -48,23 +50,22 @@ constexpr int O_GH = O_RES + (NMAX + 1) * 4;          //     (NMAX+1)*4  (gh3, g
 constexpr int O_D = O_GH + (NMAX + 1) * 4;            //     2*NMAX      constant term of the general rows
 constexpr int O_G = O_D + 2 * NMAX;                   //     (NMAX+1)*8  g_k (constant part of dx_k)
 constexpr int O_CH = O_M + LPK;                       // NMAX*(NMAX+1)         packed h rows
-constexpr int O_ROW = O_CH + NMAX * (NMAX + 1);       // 36*NMAX               IPM row state [field][row*2+side][lane]
-//   aliased into the row-state region (alive before the IPM initialises it / after it has been consumed):
-constexpr int O_U = O_ROW + 36 * NMAX - NVP;          //     NVP         iterate U        (at the END of the region, so that
-constexpr int O_X = O_U - (NMAX + 1) * NX;            //     (NMAX+1)*8  iterate X         [O_CH, O_X) is one free block in phase 1)
-constexpr int O_GAMH = O_ROW + 36 * NMAX;             // NMAX                  gamma of the h rows
+//   aliased into the h-row region (before condensing writes it / after the IPM):
+constexpr int O_X = O_CH;                             //     (NMAX+1)*8  iterate X
+constexpr int O_U1 = O_X + (NMAX + 1) * NX;           //     NVP         iterate U (after the IPM)
+constexpr int O_GAMH = O_CH + NMAX * (NMAX + 1);      // NMAX                  gamma of the h rows
 constexpr int O_WH = O_GAMH;                          //   (same buffer: gamma while assembling, weights while forming the rhs)
 constexpr int O_WB = O_WH + NMAX;                     // NMAX                  box-row scalars (gamma / weights)
-constexpr int O_SFX = O_WB + NMAX;                    // NMAX+8                suffix sums over the steering-angle rows
-constexpr int O_DV = O_SFX + NMAX + 8;                // NVP                   broadcast copy of a v-space vector
-constexpr int O_DD = O_DV + NVP;                      // NVP                   d_j (pivots of L D L')
-constexpr int O_PEN = O_DD + NVP;                     // 36 (+4)               slack penalties [class][slot][zl,zu,Zl,Zu]
-constexpr int LDS_DOUBLES = O_PEN + 40;
+constexpr int O_SFX = O_WB + NMAX;                    // NMAX+2                suffix sums over the steering-angle rows
+constexpr int O_XD = O_SFX;                           //   (before the IPM: steering angle of every stage of the iterate)
+constexpr int O_DV = O_SFX + NMAX + 2;                // NVP                   broadcast copy of a v-space vector
+constexpr int O_U0 = O_DV;                            //   (before the IPM: iterate U)
+constexpr int O_PEN = O_DV + NVP;                     // 36                    slack penalties [class][slot][zl,zu,Zl,Zu]
+constexpr int LDS_DOUBLES = O_PEN + 36;
 constexpr int LDS_BYTES = LDS_DOUBLES * 8;
 constexpr int WS_DOUBLES = NMAX * ABS;                // per-instance HBM workspace (parked linearisation records)
 static_assert(O_G + (NMAX + 1) * NX <= O_CH, "aliased condensing scratch must fit inside the KKT matrix region");
-static_assert(O_U + NVP <= O_GAMH, "aliased iterate must fit inside the row-state region");
-static_assert(LDS_BYTES <= 52 * 1024, "three workgroups per CU (allocation granularity leaves < 53.3 KiB)");
+static_assert(LDS_BYTES * 4 <= 160 * 1024, "four workgroups per CU");
 
 struct Model {
     double lf, lr, inv_m, inv_Iz, m, ka;            // ka = 0.5*ro*S*Cd

@@ -20,11 +20,10 @@ __device__ __forceinline__ int acados_status(int qp_status) { return (qp_status 
 // Everything derived from the lane id that the IPM uses. Instantiated from an OPAQUE copy of the lane id inside
 // the iteration loop: otherwise LICM hoists hundreds of lane predicates / LDS addresses out of the loop and the
 // register allocator spills them (SGPR masks to VGPR lanes, addresses to scratch).
-#define ROWF(f, k) sRowL[((f) * 6 + (k)) * NMAX]
+#define ROWF(f, k) rowst[f][k]
 #define TUM_LANE_DEFS \
     const bool rowlane = lane < N; \
     const int rl_ = rowlane ? lane : 0; \
-    double *sRowL = sRow + rl_; \
     const int cls0 = (rl_ == 0) ? 0 : 1, cls12 = (rl_ + 1 < N) ? 1 : 2; \
     const double sc12 = (rl_ + 1 < N) ? dt : 1.0; \
     auto pen = [&](int rr, int sd, int quad) -> double { \
@@ -59,7 +58,7 @@ __device__ __forceinline__ int acados_status(int qp_status) { return (qp_status 
         const double sfx = wave_suffix(rowlane ? wdel : 0.0, lane); \
         wsync(); \
         if (lane < NMAX) { sWb[lane] = rowlane ? wbox : 0.0; dstH[lane] = rowlane ? wh : 0.0; } \
-        if (lane < NMAX + 7) sSfx[lane + 1] = (lane < N) ? sfx : 0.0; \
+        if (lane < NMAX + 1) sSfx[lane + 1] = (lane < N) ? sfx : 0.0; \
         wsync(); \
     }; \
     int rb[NT]; \
@@ -81,7 +80,7 @@ __global__ void __launch_bounds__(64, 1) nmpc_rti_kernel(const KArgs ka)
     double *sAB = lds + O_AB, *sM = lds + O_M, *sStage = lds + O_STAGE, *sCh = lds + O_CH, *sX = lds + O_X;
     double *sG = lds + O_G, *sRes = lds + O_RES, *sGh = lds + O_GH, *sD = lds + O_D, *sGamH = lds + O_GAMH;
     double *sWh = lds + O_WH, *sWb = lds + O_WB, *sSfx = lds + O_SFX, *sDv = lds + O_DV;
-    double *sDd = lds + O_DD, *sU = lds + O_U, *sPen = lds + O_PEN, *sRow = lds + O_ROW;
+    double *sU0 = lds + O_U0, *sU1 = lds + O_U1, *sXd = lds + O_XD, *sPen = lds + O_PEN;
 
     double *gX = ka.X + (size_t)b * (N + 1) * NX;
     double *gU = ka.U + (size_t)b * N * NU;
@@ -95,7 +94,7 @@ __global__ void __launch_bounds__(64, 1) nmpc_rti_kernel(const KArgs ka)
     long long tprev = __builtin_readcyclecounter();
     // ------------------------------------------------------------ phase 0: loads
     for (int i = lane; i < (N + 1) * NX; i += 64) sX[i] = gX[i];
-    for (int i = lane; i < NVP; i += 64) sU[i] = (i < nv) ? gU[i] : 0.0;
+    for (int i = lane; i < NVP; i += 64) sU0[i] = (i < nv) ? gU[i] : 0.0;
     if (lane < 36) sPen[lane] = gpen[lane];
     wsync();
 
@@ -114,13 +113,14 @@ __global__ void __launch_bounds__(64, 1) nmpc_rti_kernel(const KArgs ka)
             sRes[k * 4 + 1] = xk[1] - yr[1];
             sRes[k * 4 + 2] = wrap_yaw(xk[2]) - yr[2];
             sRes[k * 4 + 3] = xk[3] - yr[3];
+            sXd[k] = xk[6];          // the condensing phase overwrites sX (it shares LDS with the packed gg rows)
             if (k >= 1) {
                 double h, g3, g5, g7;
                 h_con(mp, xk[3], xk[5], xk[7], h, g3, g5, g7);
                 sGh[k * 4 + 0] = g3; sGh[k * 4 + 1] = g5; sGh[k * 4 + 2] = g7; sGh[k * 4 + 3] = h;
             }
             if (k < N) {
-                double uk[2] = {sU[2 * k], sU[2 * k + 1]};
+                double uk[2] = {sU0[2 * k], sU0[2 * k + 1]};
                 double xn[8], Sp[2], S[6][7];
                 rk4_sens(mp, xk, uk, dt, ka.nsub, xn, Sp, S);
                 double *rec = sAB + k * ABS;
@@ -204,7 +204,7 @@ __global__ void __launch_bounds__(64, 1) nmpc_rti_kernel(const KArgs ka)
             if (isg) {
 #pragma unroll
                 for (int i = 0; i < 8; i++) sG[s * NX + i] = w1[i];
-                sD[2 * (s - 1)] = sX[s * NX + 6] + w1[6];
+                sD[2 * (s - 1)] = sXd[s] + w1[6];
                 sD[2 * (s - 1) + 1] = sGh[s * 4 + 3] + g3 * w1[3] + g5 * w1[5] + g7 * w1[7];
             }
             // gg-constraint row of stage s and staging of the 4 cost rows
@@ -263,8 +263,8 @@ __global__ void __launch_bounds__(64, 1) nmpc_rti_kernel(const KArgs ka)
             }
         }
     {
-        if (lane < nv) q0 += dt * Wd[4 + r0] * (sU[lane] - gyref[j0 * 6 + 4 + r0]);
-        if (lane < 16 && 64 + lane < nv) q1 += dt * Wd[4 + r0] * (sU[64 + lane] - gyref[j1 * 6 + 4 + r0]);
+        if (lane < nv) q0 += dt * Wd[4 + r0] * (sU0[lane] - gyref[j0 * 6 + 4 + r0]);
+        if (lane < 16 && 64 + lane < nv) q1 += dt * Wd[4 + r0] * (sU0[64 + lane] - gyref[j1 * 6 + 4 + r0]);
     }
     }   // Wd, We
 
@@ -302,6 +302,7 @@ __global__ void __launch_bounds__(64, 1) nmpc_rti_kernel(const KArgs ka)
     // phases only carry the 15 H tiles in registers. sRow[(field*6 + row*2 + side)*NMAX + lane],
     // fields: 0 s, 1 t, 2 lam, 3 mu, 4 rs (slack stationarity residual), 5 rt (primal residual).
     double v0 = 0.0, v1 = 0.0, rv0, rv1, qn;
+    double rowst[6][6];      // IPM row state of this lane: [s, t, lam, mu, rs, rt][row*2+side]
     const double npairs = 12.0 * N;
     const double inv_npairs = 1.0 / npairs;
     const int nchunk = (N + 3) >> 2;                 // chunks of 4 gg rows
@@ -312,7 +313,7 @@ __global__ void __launch_bounds__(64, 1) nmpc_rti_kernel(const KArgs ka)
     {
         const int NB = N + 1;
         double dval[3], lo[3], hi[3];
-        dval[0] = sU[2 * rl_ + 1]; lo[0] = gbnd[0 * NB + rl_]; hi[0] = gbnd[1 * NB + rl_];
+        dval[0] = sU0[2 * rl_ + 1]; lo[0] = gbnd[0 * NB + rl_]; hi[0] = gbnd[1 * NB + rl_];
         dval[1] = sD[2 * rl_];     lo[1] = gbnd[2 * NB + rl_ + 1]; hi[1] = gbnd[3 * NB + rl_ + 1];
         dval[2] = sD[2 * rl_ + 1]; lo[2] = gbnd[4 * NB + rl_ + 1]; hi[2] = gbnd[5 * NB + rl_ + 1];
         const double thr = sqrt(ka.mu0);
@@ -330,13 +331,11 @@ __global__ void __launch_bounds__(64, 1) nmpc_rti_kernel(const KArgs ka)
                 st[4][k] = pen(rr, sd, 0) + pen(rr, sd, 1) * thr - st[2][k] - st[3][k];
                 st[5][k] = t - r0v - thr;
             }
-        wsync();          // the aliased condensing scratch (sD) has been consumed
-        if (rowlane) {
 #pragma unroll
-            for (int f = 0; f < 6; f++)
+        for (int f = 0; f < 6; f++)
 #pragma unroll
-                for (int k = 0; k < 6; k++) ROWF(f, k) = st[f][k];
-        }
+            for (int k = 0; k < 6; k++) ROWF(f, k) = st[f][k];
+        wsync();          // the aliased condensing scratch (sD, sU0) has been consumed
     }
 
     // initial stationarity residual r_v = q - C'(lam_l - lam_u)   (v = 0)
@@ -436,7 +435,7 @@ __global__ void __launch_bounds__(64, 1) nmpc_rti_kernel(const KArgs ka)
 
         TUM_TICK(3);
         // ---- blocked L D L' factorisation. Unit-lower L overwrites the strict lower triangle of M, the
-        //      pivots go to sDd / sInvD. Block column J (16 wide): (1) left-looking update with the block
+        //      pivots go on its diagonal. Block column J (16 wide): (1) left-looking update with the block
         //      columns already factorised (MFMA, 4 per earlier block), result kept in registers as D-layout
         //      tiles; (2) four 4-column micro-panels: the 4x4 diagonal block is factorised redundantly by
         //      every lane from LDS broadcasts (all scalars stay in VGPRs: no readlane / SGPR traffic), every
@@ -459,7 +458,7 @@ __global__ void __launch_bounds__(64, 1) nmpc_rti_kernel(const KArgs ka)
 #pragma unroll
                     for (int kc = 0; kc < 4; kc++) {
                         const int kk = 16 * K + 4 * kc + lq;
-                        T[I] = mfma(-sM[rb[I] + kk] * sDd[kk], sM[rb[J] + kk], T[I]);
+                        T[I] = mfma(-sM[rb[I] + kk] * sM[lpk(kk, kk)], sM[rb[J] + kk], T[I]);
                     }
             }
 #pragma unroll
@@ -512,7 +511,7 @@ __global__ void __launch_bounds__(64, 1) nmpc_rti_kernel(const KArgs ka)
                 }
                 if (lane == 0) {
                     sM[r1] = l10; sM[r2] = l20; sM[r2 + 1] = l21; sM[r3] = l30; sM[r3 + 1] = l31; sM[r3 + 2] = l32;
-                    sDd[c0] = d0; sDd[c0 + 1] = d1; sDd[c0 + 2] = d2; sDd[c0 + 3] = d3;
+                    sM[lpk(c0, c0)] = d0; sM[lpk(c0 + 1, c0 + 1)] = d1; sM[lpk(c0 + 2, c0 + 2)] = d2; sM[lpk(c0 + 3, c0 + 3)] = d3;
                 }
                 wsync();
                 // (d) rank-4 update of the panel's remaining columns on the matrix cores
@@ -542,7 +541,7 @@ __global__ void __launch_bounds__(64, 1) nmpc_rti_kernel(const KArgs ka)
         // ---- predictor / corrector
         double cross1[6], cross2[6];                 // dT*dL and dS*dMu of the affine step
         double dv0 = 0.0, dv1 = 0.0, alpha = 1.0, sigma = 0.0;
-        const double invd0 = frcp(sDd[lane]), invd1 = frcp(sDd[lane1]) * ((lane < 16) ? 1.0 : 0.0);
+        const double invd0 = frcp(sM[lpk(lane, lane)]), invd1 = frcp(sM[lpk(lane1, lane1)]) * ((lane < 16) ? 1.0 : 0.0);
 #pragma unroll 1
         for (int pass = 0; pass < 2; pass++) {
             const double tau = (pass == 1) ? fmax(sigma * gap, 0.1 * ka.tol_comp) : 0.0;
@@ -580,7 +579,7 @@ __global__ void __launch_bounds__(64, 1) nmpc_rti_kernel(const KArgs ka)
             // readlane, solved against the 4x4 unit-lower diagonal block on uniform values, and every other
             // row applies them with 4 FMAs against its (contiguous, prefetched) entries of L.
             // forward: L y = b
-#pragma unroll
+#pragma unroll 4
             for (int c0 = 0; c0 < 64; c0 += 4) {
                 const int r1 = lpk(c0 + 1, c0), r2 = lpk(c0 + 2, c0), r3 = lpk(c0 + 3, c0);
                 const double l10 = sM[r1], l20 = sM[r2], l21 = sM[r2 + 1], l30 = sM[r3], l31 = sM[r3 + 1], l32 = sM[r3 + 2];
@@ -638,7 +637,7 @@ __global__ void __launch_bounds__(64, 1) nmpc_rti_kernel(const KArgs ka)
                 if (lane == c0 - 63) b1 = x1;
                 if (lane == c0 - 62) b1 = x2;
             }
-#pragma unroll
+#pragma unroll 4
             for (int c0 = 60; c0 >= 0; c0 -= 4) {
                 const int r1 = lpk(c0 + 1, 0), r2 = lpk(c0 + 2, 0), r3 = lpk(c0 + 3, 0), r0b = lpk(c0, 0);
                 const double l10 = sM[r1 + c0], l20 = sM[r2 + c0], l21 = sM[r2 + c0 + 1];
@@ -722,7 +721,7 @@ __global__ void __launch_bounds__(64, 1) nmpc_rti_kernel(const KArgs ka)
                 sigma = ratio * ratio * ratio;
             } else {
                 alpha = (amax >= 1.0) ? 1.0 : 0.995 * amax;
-                if (alpha >= 1e-12 && rowlane) {
+                if (alpha >= 1e-12) {
                     const double om_ = 1.0 - alpha;
 #pragma unroll
                     for (int k = 0; k < 6; k++) {
@@ -771,7 +770,7 @@ __global__ void __launch_bounds__(64, 1) nmpc_rti_kernel(const KArgs ka)
     if (lane < 16) sDv[64 + lane] = v1;
     // bring back the iterate and the linearisation records
     for (int i = lane; i < (N + 1) * NX; i += 64) sX[i] = gX[i];
-    for (int i = lane; i < NVP; i += 64) sU[i] = (i < nv) ? gU[i] : 0.0;
+    for (int i = lane; i < NVP; i += 64) sU1[i] = (i < nv) ? gU[i] : 0.0;
     {
         const double *ws = ka.ws + (size_t)b * WS_DOUBLES;
         for (int i = lane; i < N * ABS; i += 64) sAB[i] = ws[i];
@@ -800,8 +799,8 @@ __global__ void __launch_bounds__(64, 1) nmpc_rti_kernel(const KArgs ka)
             dx[7] += dt * du0 + rec[51];
             if (lane < 8) sX[(k + 1) * NX + lane] += pick(dx);
         }
-        sU[lane] += v0;
-        if (lane < 16) sU[64 + lane] += v1;
+        sU1[lane] += v0;
+        if (lane < 16) sU1[64 + lane] += v1;
     }
     wsync();
     // cost at the (new) iterate: stage terms scaled by dt, terminal unscaled, slack penalties pre-scaled
@@ -820,8 +819,8 @@ __global__ void __launch_bounds__(64, 1) nmpc_rti_kernel(const KArgs ka)
         e = wrap_yaw(sX[k * NX + 2]) - yr[2]; acc += ((k < N) ? Wd[2] : We[2]) * e * e;
         e = sX[k * NX + 3] - yr[3]; acc += ((k < N) ? Wd[3] : We[3]) * e * e;
         if (k < N) {
-            e = sU[2 * k] - yr[4]; acc += Wd[4] * e * e;
-            e = sU[2 * k + 1] - yr[5]; acc += Wd[5] * e * e;
+            e = sU1[2 * k] - yr[4]; acc += Wd[4] * e * e;
+            e = sU1[2 * k + 1] - yr[5]; acc += Wd[5] * e * e;
         }
         cl += 0.5 * sc * acc;
     }
@@ -829,7 +828,7 @@ __global__ void __launch_bounds__(64, 1) nmpc_rti_kernel(const KArgs ka)
 
     // ------------------------------------------------------------ stores
     for (int i = lane; i < (N + 1) * NX; i += 64) gX[i] = sX[i];
-    for (int i = lane; i < nv; i += 64) gU[i] = sU[i];
+    for (int i = lane; i < nv; i += 64) gU[i] = sU1[i];
     TUM_TICK(9);
     if (PROF && lane == 0)
         for (int i = 0; i < 12; i++) ka.prof[(size_t)b * 12 + i] = pacc[i];
