@@ -12,6 +12,7 @@ DATA (inputs + expected outputs), never reference source:
   planner.npz         PlannerEmulator input/output pairs
   pce.npz             alphaGeneration / polyChaosExpansion / compute_x0dist / sigma points of acados_ocp_SNMPC.json
   r2.npz              P_propagation input/output pairs
+  closed_loop_<t>_<n>.npz   first n steps of the 26 logged closed loops of one track (plant states, inputs, predictions)
 
 Reference call sites reproduced by the replay protocol:
   get_baseline_performances.py:101-131 (loop), Utils/SimulationMode_main_class.py:106-156
@@ -108,6 +109,17 @@ def make_replay(track, k, nsteps):
                         params=F[k], x0=x0s, yref=yrefs, **exp)
 
 
+def make_closed_loop(track="monteblanco", nsteps=150):
+    """First `nsteps` control steps of the 26 logged closed loops on one track (one per weight set of F.csv):
+    what the plant, the inputs and the stage-1 predictions were. Yaw columns are stored as logged (mod 2pi)."""
+    C, S, U = [], [], []
+    for k in range(26):
+        d = np.load(os.path.join(BASE, track, f"{k}.npz"))
+        C.append(d["CiLX"][:nsteps + 1]); S.append(d["MPC_SimX"][:nsteps + 1]); U.append(d["simU"][:nsteps])
+    np.savez_compressed(os.path.join(OUT, f"closed_loop_{track}_{nsteps}.npz"), params=F,
+                        CiLX=np.array(C, dtype=np.float64), MPC_SimX=np.array(S), simU=np.array(U))
+
+
 def make_planner():
     rng = np.random.default_rng(7)
     out = {}
@@ -158,7 +170,7 @@ def make_r2():
 
 
 if __name__ == "__main__":
-    what = sys.argv[1:] or ["kat0", "replay", "planner", "pce", "r2"]
+    what = sys.argv[1:] or ["kat0", "replay", "planner", "pce", "r2", "closed_loop"]
     if "kat0" in what:
         make_kat0()
     if "replay" in what:
@@ -170,4 +182,6 @@ if __name__ == "__main__":
         make_pce()
     if "r2" in what:
         make_r2()
+    if "closed_loop" in what:
+        make_closed_loop()
     print("golden fixtures written to", OUT)

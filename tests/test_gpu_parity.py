@@ -294,3 +294,22 @@ def test_r2_backoff_two_consecutive_solves():
         o.lbx[1:N] = r2.delta_f_min + bo[b, 1:, 0]; o.ubx[1:N] = r2.delta_f_max - bo[b, 1:, 0]; o.uh[1:N] = 1.0 - bo[b, 1:, 1]
         assert o.solve() == 0
         assert np.abs(U2[b] - o.U).max() < 1e-6 and np.abs(X2[b] - o.X).max() < 1e-6
+
+
+def test_closed_loop_weight_sweep_vs_logged_acados(golden_dir):
+    """End-to-end: the 26 weight sets of _parameters/F.csv driven as ONE batch through planner -> GPU SQP-RTI ->
+    plant -> state estimation for 150 control steps (3 s), against the reference's logged acados closed loops
+    (plant states CiLX, inputs simU). The first 50 steps agree to 5e-5 on the inputs and 1e-5 on the plant states for every weight set; differences at the
+    level of HPIPM's exit tolerance are then amplified by the closed loop for a few weight sets, so over all 150
+    steps the bound is 1e-4 for >= 85 % of the sets and 1e-2 for the worst one (observed: 23/26 and 4e-3)."""
+    from tum_control_amd.closed_loop import ClosedLoopBatch
+    d = np.load(os.path.join(golden_dir, "closed_loop_monteblanco_150.npz"))
+    cl = ClosedLoopBatch("monteblanco", batch=26, params=d["params"], N=38, Tp=3.04)
+    log = cl.run(150)
+    C = d["CiLX"].copy(); C[:, :, 2] = np.unwrap(C[:, :, 2], axis=1)
+    assert (log["simSolverDebug"][:, :, 4] == 0).all()
+    eu = np.abs(log["simU"].transpose(1, 0, 2) - d["simU"]).max(axis=2)          # (26, 150)
+    ec = np.abs(log["CiLX"].transpose(1, 0, 2) - C).max(axis=2)                  # (26, 151)
+    assert eu[:, :50].max() < 5e-5 and ec[:, :51].max() < 1e-5
+    per_set = np.maximum(eu.max(axis=1), ec.max(axis=1))
+    assert (per_set < 1e-4).mean() >= 0.85 and per_set.max() < 1e-2, np.sort(per_set)[::-1][:5]

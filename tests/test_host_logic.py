@@ -159,3 +159,21 @@ def test_r2_setup_matches_reference_propagation(golden_dir):
     S0, BWB = r2_setup([0, 0, 0, 0.8, 0.35, 0.035, 0, 0], 0.08)
     assert S0.shape == (8, 8) and abs(S0[3, 3] - (0.5 * 0.8) ** 2) < 1e-15 and abs(S0[0, 0] - (0.5e-5) ** 2) < 1e-20
     assert abs(BWB[4, 4] - 0.08 * 0.35 ** 2) < 1e-15 and BWB[6, 6] == 0.0 and BWB[2, 2] == 0.0
+
+
+def test_plant_restatement_reproduces_logged_closed_loops(golden_dir):
+    """7-state plant + RK4 x 4 over Ts = 0.02 s (Vehicle_Simulator/...): CiLX[i+1] from (CiLX[i], a = MPC_SimX[i+1][7],
+    steering rate = simU[i][1]) for the 26 logged closed loops x 150 steps."""
+    from tum_control_amd.closed_loop import plant_step, MovingAverageEstimator
+    from tum_control_amd import config
+    d = np.load(os.path.join(golden_dir, "closed_loop_monteblanco_150.npz"))
+    C = d["CiLX"].copy(); C[:, :, 2] = np.unwrap(C[:, :, 2], axis=1)
+    cfg = config.default_config()
+    for i in range(150):
+        xn = plant_step(C[:, i], d["MPC_SimX"][:, i + 1, 7], d["simU"][:, i, 1], cfg)
+        assert np.abs(xn - C[:, i + 1]).max() < 1e-12
+    # estimator: truncated moving averages with windows [1,1,4,2,2,3,4,2]
+    est = MovingAverageEstimator(1)
+    xs = np.arange(40.0).reshape(5, 1, 8)
+    outs = [est(x)[0] for x in xs]
+    assert outs[4][0] == xs[4, 0, 0] and outs[4][2] == xs[1:5, 0, 2].mean() and outs[1][6] == xs[:2, 0, 6].mean()

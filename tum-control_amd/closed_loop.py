@@ -1,0 +1,149 @@
+"""
+closed_loop.py -- counterpart of the reference's closed-loop harness for a BATCH of independent vehicles
+(SURVEY.md 8(f2), 8(f4)): planner -> batched SQP-RTI solve on the GPU -> plant step -> state estimation.
+
+Restates, for the code around the hot path only what is needed to drive it the way the reference does:
+  main.py:48-78 / Learning_To_Adapt/SafeRL_WMPC/get_baseline_performances.py:101-131   the loop
+  Utils/SimulationMode_main_class.py:106-156                                            sim_step (simMode 0), StateEstimation
+  Vehicle_Simulator/sim_model_dynamic_stm_pacejka.py:137-195 + VehicleSimulator.py:73-77 plant: 7-state single track
+                                                                                         (input = acceleration, steering rate),
+                                                                                         CasADi 'rk' with 4 finite elements = RK4 x 4
+  Utils/Logging_Plotting.py:124-146,357-372                                             what gets logged (npz schema)
+Every instance may carry its own cost weights / penalties (the BO / RL weight sweep as one batch).
+"""
+import numpy as np
+
+from . import config as _config
+from .planner import load_track, planner_emulator, yref_from_ref
+from .solver import BatchedOcpSolver
+
+WINDOWS = (1, 1, 4, 2, 2, 3, 4, 2)          # SimulationMode_main_class.py:86
+
+
+def plant_xdot(x, a, sr, cfg):
+    """xdot of the 7-state plant [posx,posy,yaw,vlong,vlat,yawrate,delta_f]; x: (B,7), a, sr: (B,)."""
+    veh, tire, ph = cfg["veh"], cfg["tire"], cfg["phys"]
+    lf, lr, m, Iz = veh["lf"], veh["lr"], veh["m"], veh["Iz"]
+    yaw, vl, vt, r, de = x[:, 2], x[:, 3], x[:, 4], x[:, 5], x[:, 6]
+    v = np.sqrt(vl ** 2 + vt ** 2) * 3.6
+    fr = ph["fr0"] + ph["fr1"] * v / 100 + ph["fr4"] * (v / 100) ** 4
+    Fz_f = m * lr * ph["g"] / (lf + lr); Fz_r = m * lf * ph["g"] / (lf + lr)
+    Fx_f = -fr * Fz_f
+    Fx_r = m * a - fr * Fz_r
+    Faero = 0.5 * veh["ro"] * veh["S"] * veh["Cd"] * vl ** 2
+    ok = vl > 0.001
+    vls = np.where(ok, vl, 1.0)
+    al_f = np.where(ok, de - np.arctan((vt + lf * r) / vls), 0.0)
+    al_r = np.where(ok, np.arctan((lr * r - vt) / vls), 0.0)
+    Bf, Cf, Df, Ef = tire["Bf"], tire["Cf"], tire["Df"], tire["Ef"]
+    Br, Cr, Dr, Er = tire["Br"], tire["Cr"], tire["Dr"], tire["Er"]
+    Fy_f_lat = Df * np.sin(Cf * np.arctan(Bf * al_f - Ef * (Bf * al_f - np.arctan(Bf * al_f))))
+    Fy_r_lat = Dr * np.sin(Cr * np.arctan(Br * al_r - Er * (Br * al_r - np.arctan(Br * al_r))))
+    Fmax_f = np.sqrt(Fz_f ** 2 + (Cf * Fz_f) ** 2); Fmax_r = np.sqrt(Fz_r ** 2 + (Cr * Fz_r) ** 2)
+    Gy_f = np.clip(Fx_f / Fmax_f, -0.98, 0.98); Gy_r = np.clip(Fx_r / Fmax_r, -0.98, 0.98)
+    Fy_f = Fy_f_lat * np.cos(np.arcsin(Gy_f)); Fy_r = Fy_r_lat * np.cos(np.arcsin(Gy_r))
+    xd = np.empty_like(x)
+    xd[:, 0] = vl * np.cos(yaw) - vt * np.sin(yaw)
+    xd[:, 1] = vl * np.sin(yaw) + vt * np.cos(yaw)
+    xd[:, 2] = r
+    xd[:, 3] = (Fx_r - Faero - Fy_f * np.sin(de) + Fx_f * np.cos(de) + m * vt * r) / m
+    xd[:, 4] = (Fy_r + Fy_f * np.cos(de) + Fx_f * np.sin(de) - m * vl * r) / m
+    xd[:, 5] = (lf * (Fy_f * np.cos(de) + Fx_f * np.sin(de)) - lr * Fy_r) / Iz
+    xd[:, 6] = sr
+    return xd
+
+
+def plant_step(x, a, sr, cfg, Ts=0.02, n_elem=4):
+    """One simulator step: classic RK4 with `n_elem` equal sub-steps over Ts, inputs held constant."""
+    h = Ts / n_elem
+    x = x.copy()
+    for _ in range(n_elem):
+        k1 = plant_xdot(x, a, sr, cfg)
+        k2 = plant_xdot(x + 0.5 * h * k1, a, sr, cfg)
+        k3 = plant_xdot(x + 0.5 * h * k2, a, sr, cfg)
+        k4 = plant_xdot(x + h * k3, a, sr, cfg)
+        x = x + h / 6.0 * (k1 + 2 * k2 + 2 * k3 + k4)
+    return x
+
+
+class MovingAverageEstimator:
+    """StateEstimation (SimulationMode_main_class.py:152-156): per-state moving average over the last
+    WINDOWS[i] samples (fewer while the buffer fills), buffers start empty."""
+
+    def __init__(self, batch):
+        self.hist = [[] for _ in range(8)]
+        self.batch = batch
+
+    def __call__(self, x_next):
+        out = np.empty_like(x_next)
+        for i in range(8):
+            self.hist[i].append(x_next[:, i].copy())
+            if len(self.hist[i]) > 15:
+                self.hist[i].pop(0)
+            out[:, i] = np.mean(self.hist[i][-WINDOWS[i]:], axis=0)
+        return out
+
+
+class ClosedLoopBatch:
+    """B independent closed loops on one track, one OCP instance each; `params` (B,7) are per-instance
+    [q_xy, q_yaw, q_vel, r_jerk, r_steer, L1, L2] as in update_cost_function_weights (None: YAML defaults x0.01)."""
+
+    def __init__(self, track_name, batch=1, params=None, N=38, Tp=3.04, Ts=0.02, idx_start=0, cfg=None, device=0):
+        self.cfg = cfg or _config.default_config()
+        self.track = load_track(track_name)
+        self.B, self.N, self.Tp, self.Ts = batch, N, Tp, Ts
+        tr = self.track
+        x0 = np.array([tr[idx_start, 0], tr[idx_start, 1], np.mod(tr[idx_start, 2], 2 * np.pi), tr[idx_start, 3], 0, 0, 0, 0.0])
+        self.x_mpc = np.tile(x0, (batch, 1))                     # X0_MPC
+        self.x_sim = self.x_mpc[:, :7].copy()                    # X0_sim
+        self.pose = self.x_mpc[:, :2].copy()
+        self.solver = BatchedOcpSolver(N=N, dt=Tp / N, nsub=3, batch=batch, device=device, cfg=self.cfg)
+        self.solver.install_reference_ocp()
+        if params is not None:
+            self.set_weights(np.asarray(params, dtype=float).reshape(batch, 7))
+        self.solver.set_x0(self.x_mpc)
+        self.solver.cold_start()
+        self.est = MovingAverageEstimator(batch)
+        self.log = dict(CiLX=[self.x_sim.copy()], MPC_SimX=[self.x_mpc.copy()], simU=[], simREF=[], simSolverDebug=[])
+
+    def set_weights(self, p):
+        s, B, N = self.solver, self.B, self.N
+        W = np.zeros((B, 6, 6))
+        for j in range(B):
+            W[j] = np.diag([p[j, 0], p[j, 0], p[j, 1], p[j, 2], p[j, 3], p[j, 4]])
+        s.cost_set(0, "W", W if B > 1 else W[0])
+        s.cost_set(N, "W", W[:, :4, :4] if B > 1 else W[0, :4, :4])
+        for st, n in ((0, 1), (1, 3), (N, 2)):
+            for f, col in (("zl", 5), ("zu", 5), ("Zl", 6), ("Zu", 6)):
+                v = np.repeat(p[:, col:col + 1], n, axis=1)
+                s.cost_set(st, f, v if B > 1 else v[0])
+
+    def step(self):
+        s, B, N = self.solver, self.B, self.N
+        yref = np.zeros((B, N + 1, 6)); ref0 = np.zeros((B, 4))
+        for b in range(B):
+            _, ref = planner_emulator(self.track, self.pose[b], N + 1, self.Tp, True)
+            yref[b] = yref_from_ref(ref, N); ref0[b] = ref[0]
+        s.set_yref_all(yref if B > 1 else yref[0])
+        status = s.solve()
+        X, U = s.get_iterate()
+        u0, x1 = U[:, 0], X[:, 1]
+        stats = np.stack([np.atleast_1d(s.get_cost()), np.full(B, s.get_stats("time_tot")), np.ones(B),
+                          s.get_stats("qp_iter").astype(float), s.get_stats("status").astype(float)], axis=1)
+        # sim_step, simMode 0: the plant takes the predicted acceleration of stage 1 and the steering rate
+        a_in, sr_in = x1[:, 7], u0[:, 1]
+        x_sim_next = plant_step(self.x_sim, a_in, sr_in, self.cfg, self.Ts)
+        x_next = np.concatenate([x_sim_next, a_in[:, None]], axis=1)
+        self.pose = x_sim_next[:, :2].copy()
+        self.x_sim = x_sim_next
+        self.x_mpc = self.est(x_next)
+        s.set_x0(self.x_mpc if B > 1 else self.x_mpc[0])
+        lg = self.log
+        lg["simU"].append(u0.copy()); lg["simREF"].append(ref0); lg["simSolverDebug"].append(stats)
+        lg["CiLX"].append(x_sim_next.copy()); lg["MPC_SimX"].append(x1.copy())
+        return status
+
+    def run(self, n_steps):
+        for _ in range(n_steps):
+            self.step()
+        return {k: np.array(v) for k, v in self.log.items()}          # arrays are (steps[+1], B, dim)
