@@ -152,7 +152,15 @@ __device__ __forceinline__ double frcp(double x)
     return r;
 }
 __device__ __forceinline__ d4 mfma(double a, double b, d4 c) { return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0); }
-__device__ __forceinline__ void wsync() { __syncthreads(); }   // 1 wave per workgroup: LDS ordering point
+// LDS ordering point between the lanes of the ONE wavefront of a workgroup. The LDS executes a wave's DS
+// instructions in issue order, so a later ds_read already observes an earlier ds_write of another lane: no
+// s_barrier and no counter drain are needed, only a fence that stops the compiler from reordering across it.
+__device__ __forceinline__ void wsync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
 
 // ---------------------------------------------------------------- model
 // Core of the single-track ODE: derivatives of (vlong, vlat, yawrate) and their partials w.r.t.
