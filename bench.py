@@ -108,13 +108,14 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group(backend="nccl")
+    distributed = world > 1 or os.environ.get("RANK") is not None     # launched by torch.distributed.run
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the solver has no CPU fallback)")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    if distributed:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group(backend="nccl", device_id=dev)
 
     from tum_control_amd.solver import BatchedOcpSolver
     from tum_control_amd.workloads import nominal_batch
@@ -135,7 +136,7 @@ def main():
     cost_t = torch.zeros((B,), dtype=torch.float64, device=dev)
     st_t = torch.zeros((B,), dtype=torch.int32, device=dev)
     it_t = torch.zeros((B,), dtype=torch.int32, device=dev)
-    gather = sharding.ResultGatherer(world, rank, B, dev) if world > 1 else None
+    gather = sharding.ResultGatherer(world, rank, B, dev) if distributed else None
 
     def step(ev=None):
         s.cold_start()
@@ -152,7 +153,7 @@ def main():
             gather.gather(res_f, res_i)
 
     def barrier():
-        if world > 1:
+        if distributed:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -166,7 +167,7 @@ def main():
     barrier()
     t1 = time.perf_counter()
     elapsed = t1 - t0
-    if world > 1:
+    if distributed:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
@@ -219,7 +220,7 @@ def main():
         elif world > 1:
             out["cpu_baseline"] = None
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if distributed:
         dist.barrier()
         dist.destroy_process_group()
 
