@@ -143,13 +143,13 @@ __device__ __forceinline__ double wave_max(double v)
     TUM_DPP_SCAN(op_max, 0.0)
     return rl(v, 63);
 }
-// 1/x to ~1 ulp without the IEEE division sequence: v_rcp_f64 + two Newton steps (5 VALU instead of ~27)
+// 1/x without the IEEE division sequence: v_rcp_f64 (4.4e-8 relative, measured) + ONE Newton step -> 2e-15
+// relative (measured over 40 decades, scripts/probes/probe_trisolve2.cpp); 3 VALU instead of ~27. The IPM only
+// uses it inside Newton-type iterations, which are self-correcting at that level.
 __device__ __forceinline__ double frcp(double x)
 {
     double r = __builtin_amdgcn_rcp(x);
-    r = fma(fma(-x, r, 1.0), r, r);
-    r = fma(fma(-x, r, 1.0), r, r);
-    return r;
+    return fma(fma(-x, r, 1.0), r, r);
 }
 __device__ __forceinline__ d4 mfma(double a, double b, d4 c) { return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0); }
 // LDS ordering point between the lanes of the ONE wavefront of a workgroup. The LDS executes a wave's DS

@@ -576,43 +576,41 @@ __global__ void __launch_bounds__(64, 1) nmpc_rti_kernel(const KArgs ka)
             }
             TUM_TICK(5);
             // Triangular solves in 4-wide micro-blocks: the 4 unknowns of a micro-block are broadcast with
-            // readlane, solved against the 4x4 unit-lower diagonal block on uniform values, and every other
-            // row applies them with 4 FMAs against its (contiguous, prefetched) entries of L.
+            // readlane and solved against the 4x4 unit-lower diagonal block on uniform values; then EVERY lane
+            // applies  b -= sum_j m_j y_j  with its (contiguous, prefetched) entries m_j of L masked by position
+            // (entry j is live iff it lies strictly below / left of the diagonal), which also leaves y_k in the
+            // block's own lanes -- no per-unknown write-back selects (a single wave is VALU-issue bound).
             // forward: L y = b
 #pragma unroll 4
             for (int c0 = 0; c0 < 64; c0 += 4) {
                 const int r1 = lpk(c0 + 1, c0), r2 = lpk(c0 + 2, c0), r3 = lpk(c0 + 3, c0);
                 const double l10 = sM[r1], l20 = sM[r2], l21 = sM[r2 + 1], l30 = sM[r3], l31 = sM[r3 + 1], l32 = sM[r3 + 2];
-                const bool below = lane > c0 + 3;
-                const int o0 = myrow0 + (below ? c0 : 0);
-                const double m0 = sM[o0], m1 = sM[o0 + 1], m2 = sM[o0 + 2], m3 = sM[o0 + 3];
+                const int k4 = lane - c0;
+                const int o0 = myrow0 + c0;
+                const double m0 = (k4 > 0) ? sM[o0] : 0.0, m1 = (k4 > 1) ? sM[o0 + 1] : 0.0;
+                const double m2 = (k4 > 2) ? sM[o0 + 2] : 0.0, m3 = (k4 > 3) ? sM[o0 + 3] : 0.0;
                 const int o1 = myrow1 + c0;
                 const double n0 = sM[o1], n1 = sM[o1 + 1], n2 = sM[o1 + 2], n3 = sM[o1 + 3];
                 const double y0 = rl(b0, c0);
                 const double y1 = rl(b0, c0 + 1) - l10 * y0;
                 const double y2 = rl(b0, c0 + 2) - l20 * y0 - l21 * y1;
                 const double y3 = rl(b0, c0 + 3) - l30 * y0 - l31 * y1 - l32 * y2;
-                if (below) b0 -= m0 * y0 + m1 * y1 + m2 * y2 + m3 * y3;
-                if (lane == c0 + 1) b0 = y1;
-                if (lane == c0 + 2) b0 = y2;
-                if (lane == c0 + 3) b0 = y3;
-                if (lane < 16) b1 -= n0 * y0 + n1 * y1 + n2 * y2 + n3 * y3;
+                b0 = b0 - m0 * y0 - m1 * y1 - m2 * y2 - m3 * y3;
+                b1 = b1 - n0 * y0 - n1 * y1 - n2 * y2 - n3 * y3;
             }
 #pragma unroll
             for (int c0 = 64; c0 < NVP; c0 += 4) {
                 const int r1 = lpk(c0 + 1, c0), r2 = lpk(c0 + 2, c0), r3 = lpk(c0 + 3, c0);
                 const double l10 = sM[r1], l20 = sM[r2], l21 = sM[r2 + 1], l30 = sM[r3], l31 = sM[r3 + 1], l32 = sM[r3 + 2];
-                const bool below = (lane < 16) && (lane1 > c0 + 3);
-                const int o1 = myrow1 + (below ? c0 : 0);
-                const double n0 = sM[o1], n1 = sM[o1 + 1], n2 = sM[o1 + 2], n3 = sM[o1 + 3];
+                const int k4 = lane1 - c0;
+                const int o1 = myrow1 + c0;
+                const double n0 = (k4 > 0) ? sM[o1] : 0.0, n1 = (k4 > 1) ? sM[o1 + 1] : 0.0;
+                const double n2 = (k4 > 2) ? sM[o1 + 2] : 0.0, n3 = (k4 > 3) ? sM[o1 + 3] : 0.0;
                 const double y0 = rl(b1, c0 - 64);
                 const double y1 = rl(b1, c0 - 63) - l10 * y0;
                 const double y2 = rl(b1, c0 - 62) - l20 * y0 - l21 * y1;
                 const double y3 = rl(b1, c0 - 61) - l30 * y0 - l31 * y1 - l32 * y2;
-                if (below) b1 -= n0 * y0 + n1 * y1 + n2 * y2 + n3 * y3;
-                if (lane == c0 - 63) b1 = y1;
-                if (lane == c0 - 62) b1 = y2;
-                if (lane == c0 - 61) b1 = y3;
+                b1 = b1 - n0 * y0 - n1 * y1 - n2 * y2 - n3 * y3;       // lanes >= 16 carry no rows (never read)
             }
             // z = D^-1 y
             b0 *= invd0; b1 *= invd1;
@@ -622,37 +620,32 @@ __global__ void __launch_bounds__(64, 1) nmpc_rti_kernel(const KArgs ka)
                 const int r1 = lpk(c0 + 1, 0), r2 = lpk(c0 + 2, 0), r3 = lpk(c0 + 3, 0), r0b = lpk(c0, 0);
                 const double l10 = sM[r1 + c0], l20 = sM[r2 + c0], l21 = sM[r2 + c0 + 1];
                 const double l30 = sM[r3 + c0], l31 = sM[r3 + c0 + 1], l32 = sM[r3 + c0 + 2];
-                // entries L[c0+k][col] for this lane's columns (bank 0: col = lane, bank 1: col = 64+lane < c0)
+                // entries L[c0+j][col] for this lane's columns: bank 0 col = lane (always left of the block),
+                // bank 1 col = 64 + lane, live iff col < c0 + j
                 const double m0 = sM[r0b + lane], m1 = sM[r1 + lane], m2 = sM[r2 + lane], m3 = sM[r3 + lane];
-                const bool left = (lane < 16) && (lane1 < c0);
-                const int oc = left ? lane1 : 0;
-                const double n0 = sM[r0b + oc], n1 = sM[r1 + oc], n2 = sM[r2 + oc], n3 = sM[r3 + oc];
+                const int k4 = lane1 - c0;
+                const double n0 = (k4 < 0) ? sM[r0b + lane1] : 0.0, n1 = (k4 < 1) ? sM[r1 + lane1] : 0.0;
+                const double n2 = (k4 < 2) ? sM[r2 + lane1] : 0.0, n3 = (k4 < 3) ? sM[r3 + lane1] : 0.0;
                 const double x3 = rl(b1, c0 - 61);
                 const double x2 = rl(b1, c0 - 62) - l32 * x3;
                 const double x1 = rl(b1, c0 - 63) - l21 * x2 - l31 * x3;
                 const double x0 = rl(b1, c0 - 64) - l10 * x1 - l20 * x2 - l30 * x3;
-                b0 -= m0 * x0 + m1 * x1 + m2 * x2 + m3 * x3;
-                if (left) b1 -= n0 * x0 + n1 * x1 + n2 * x2 + n3 * x3;
-                if (lane == c0 - 64) b1 = x0;
-                if (lane == c0 - 63) b1 = x1;
-                if (lane == c0 - 62) b1 = x2;
+                b0 = b0 - m3 * x3 - m2 * x2 - m1 * x1 - m0 * x0;
+                b1 = b1 - n3 * x3 - n2 * x2 - n1 * x1 - n0 * x0;
             }
 #pragma unroll 4
             for (int c0 = 60; c0 >= 0; c0 -= 4) {
                 const int r1 = lpk(c0 + 1, 0), r2 = lpk(c0 + 2, 0), r3 = lpk(c0 + 3, 0), r0b = lpk(c0, 0);
                 const double l10 = sM[r1 + c0], l20 = sM[r2 + c0], l21 = sM[r2 + c0 + 1];
                 const double l30 = sM[r3 + c0], l31 = sM[r3 + c0 + 1], l32 = sM[r3 + c0 + 2];
-                const bool left = lane < c0;
-                const int oc = left ? lane : 0;
-                const double m0 = sM[r0b + oc], m1 = sM[r1 + oc], m2 = sM[r2 + oc], m3 = sM[r3 + oc];
+                const int k4 = lane - c0;
+                const double m0 = (k4 < 0) ? sM[r0b + lane] : 0.0, m1 = (k4 < 1) ? sM[r1 + lane] : 0.0;
+                const double m2 = (k4 < 2) ? sM[r2 + lane] : 0.0, m3 = (k4 < 3) ? sM[r3 + lane] : 0.0;
                 const double x3 = rl(b0, c0 + 3);
                 const double x2 = rl(b0, c0 + 2) - l32 * x3;
                 const double x1 = rl(b0, c0 + 1) - l21 * x2 - l31 * x3;
                 const double x0 = rl(b0, c0) - l10 * x1 - l20 * x2 - l30 * x3;
-                if (left) b0 -= m0 * x0 + m1 * x1 + m2 * x2 + m3 * x3;
-                if (lane == c0) b0 = x0;
-                if (lane == c0 + 1) b0 = x1;
-                if (lane == c0 + 2) b0 = x2;
+                b0 = b0 - m3 * x3 - m2 * x2 - m1 * x1 - m0 * x0;
             }
             dv0 = b0; dv1 = b1;
             TUM_TICK(6);
