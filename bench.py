@@ -216,7 +216,9 @@ def main():
             cb, u_ref = cpu_baseline(N, x0, yref, s.cfg)
             out["cpu_baseline"] = cb
             n = len(u_ref)
-            out["parity_vs_oracle_max_abs_u0"] = float(np.abs(U[:n, 0] - u_ref).max())
+            err = np.abs(U[:n, 0] - u_ref).max(axis=1)
+            out["parity_vs_oracle_max_abs_u0"] = float(err.max())
+            out["parity_vs_oracle_frac_within_1e-6"] = float((err < 1e-6).mean())
         elif world > 1:
             out["cpu_baseline"] = None
         print(json.dumps(out), flush=True)

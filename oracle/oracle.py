@@ -160,6 +160,7 @@ class OracleOcp:
         self.sl, self.su = self._view("sl"), self._view("su")
         self.ipm_tol = self._view("ipm_tol")
         self.ipm_mu0 = self._view("ipm_mu0")
+        self.ipm_t0 = self._view("ipm_t0")
         self.ipm_reg = self._view("ipm_reg")
         self.res = self._view("res")
         # bounds of the shipped OCP (NMPC_STM_acados_settings.py:108-139)

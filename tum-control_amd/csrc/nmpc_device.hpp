@@ -81,7 +81,7 @@ struct KArgs {
     int N, nsub, batch, flags;                        // flags: 1 store_qp_in, 2 debug dump, 4 phase timers
     double dt;
     int iter_max;
-    double tol_stat, tol_ineq, tol_comp, mu0, reg;
+    double tol_stat, tol_ineq, tol_comp, mu0, t0, reg;
     Model mp;
     double *X, *U;                                    // iterate, [b][(N+1)*8], [b][N*2]
     const double *x0, *yref, *W, *pen, *bnd;          // [b][8], [b][(N+1)*6], [b][10], [b][36], [b][6][N+1]

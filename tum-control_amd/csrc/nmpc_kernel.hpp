@@ -316,7 +316,8 @@ __global__ void __launch_bounds__(64, 1) nmpc_rti_kernel(const KArgs ka)
         dval[0] = sU0[2 * rl_ + 1]; lo[0] = gbnd[0 * NB + rl_]; hi[0] = gbnd[1 * NB + rl_];
         dval[1] = sD[2 * rl_];     lo[1] = gbnd[2 * NB + rl_ + 1]; hi[1] = gbnd[3 * NB + rl_ + 1];
         dval[2] = sD[2 * rl_ + 1]; lo[2] = gbnd[4 * NB + rl_ + 1]; hi[2] = gbnd[5 * NB + rl_ + 1];
-        const double thr = sqrt(ka.mu0);
+        // slack-equation-feasible start (same rule as the oracle): s*z = mu0, mu_s from z + Z s - lam - mu_s = 0
+        // (floored), t = max(r0 + s, t0), lam = mu0 / t
         double st[6][6];
 #pragma unroll
         for (int rr = 0; rr < 3; rr++)
@@ -325,11 +326,17 @@ __global__ void __launch_bounds__(64, 1) nmpc_rti_kernel(const KArgs ka)
                 const int k = rr * 2 + sd;
                 const double eps = sd ? -1.0 : 1.0, bnd = sd ? hi[rr] : lo[rr];
                 const double r0v = eps * (dval[rr] - bnd);
-                double t = r0v + thr;
-                if (t < thr) t = thr;
-                st[0][k] = thr; st[1][k] = t; st[2][k] = ka.mu0 / t; st[3][k] = ka.mu0 / thr;
-                st[4][k] = pen(rr, sd, 0) + pen(rr, sd, 1) * thr - st[2][k] - st[3][k];
-                st[5][k] = t - r0v - thr;
+                const double z = pen(rr, sd, 0), Z = pen(rr, sd, 1);
+                const double s0 = ka.mu0 / (z > 1e-6 ? z : 1e-6);
+                double t = r0v + s0;
+                if (t < ka.t0) t = ka.t0;
+                const double lam = ka.mu0 / t;
+                double ms = z + Z * s0 - lam;
+                const double msf = 1e-2 * ka.mu0 / s0;
+                if (ms < msf) ms = msf;
+                st[0][k] = s0; st[1][k] = t; st[2][k] = lam; st[3][k] = ms;
+                st[4][k] = z + Z * s0 - lam - ms;
+                st[5][k] = t - r0v - s0;
             }
 #pragma unroll
         for (int f = 0; f < 6; f++)

@@ -36,7 +36,7 @@ class TumOcpDesc(ctypes.Structure):
            ("ggv_v", ctypes.c_double * 16), ("ggv_ax", ctypes.c_double * 16), ("ggv_ay", ctypes.c_double * 16),
            ("qp_iter_max", ctypes.c_int),
            ("qp_tol_stat", ctypes.c_double), ("qp_tol_ineq", ctypes.c_double), ("qp_tol_comp", ctypes.c_double),
-           ("qp_mu0", ctypes.c_double), ("store_qp_in", ctypes.c_int)]
+           ("qp_mu0", ctypes.c_double), ("qp_t0", ctypes.c_double), ("store_qp_in", ctypes.c_int)]
     )
 
 
@@ -96,7 +96,7 @@ def load_library(path=None):
 
 
 def make_desc(N, dt, nsub, batch, device=0, cfg=None, store_qp_in=False, qp_iter_max=50,
-              qp_tol=(1e-8, 1e-8, 1e-8), qp_mu0=1.0):
+              qp_tol=(1e-8, 1e-8, 1e-8), qp_mu0=0.1, qp_t0=0.1):
     cfg = cfg or _config.default_config()
     d = TumOcpDesc()
     d.N, d.nsub, d.dt, d.batch, d.device = int(N), int(nsub), float(dt), int(batch), int(device)
@@ -115,6 +115,7 @@ def make_desc(N, dt, nsub, batch, device=0, cfg=None, store_qp_in=False, qp_iter
     d.qp_iter_max = int(qp_iter_max)
     d.qp_tol_stat, d.qp_tol_ineq, d.qp_tol_comp = (float(t) for t in qp_tol)
     d.qp_mu0 = float(qp_mu0)
+    d.qp_t0 = float(qp_t0)
     d.store_qp_in = 1 if store_qp_in else 0
     return d
 
@@ -127,11 +128,11 @@ class BatchedOcpSolver:
     """`batch` independent copies of the nominal NMPC OCP on one MI355X; acados method names."""
 
     def __init__(self, N=38, dt=0.08, nsub=3, batch=1, device=0, cfg=None, store_qp_in=False,
-                 qp_iter_max=50, qp_tol=(1e-8, 1e-8, 1e-8), qp_mu0=1.0):
+                 qp_iter_max=50, qp_tol=(1e-8, 1e-8, 1e-8), qp_mu0=0.1, qp_t0=0.1):
         self._L = load_library()
         self.N, self.dt, self.nsub, self.batch = int(N), float(dt), int(nsub), int(batch)
         self.cfg = cfg or _config.default_config()
-        self._desc = make_desc(N, dt, nsub, batch, device, self.cfg, store_qp_in, qp_iter_max, qp_tol, qp_mu0)
+        self._desc = make_desc(N, dt, nsub, batch, device, self.cfg, store_qp_in, qp_iter_max, qp_tol, qp_mu0, qp_t0)
         self._h = self._L.tum_ocp_create(ctypes.byref(self._desc))
         if not self._h:
             raise RuntimeError("tum_ocp_create failed: " + self._err())
