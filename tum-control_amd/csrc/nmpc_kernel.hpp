@@ -777,27 +777,31 @@ __global__ void __launch_bounds__(64, 1) nmpc_rti_kernel(const KArgs ka)
     }
     wsync();
     if (status == 0) {
-        // dx_0 = x0 - X_0 ; dx_{k+1} = A_k dx_k + B_k du_k + b_k   (every lane runs the same recurrence)
-        double dx[8];
-#pragma unroll
-        for (int i = 0; i < 8; i++) dx[i] = gx0[i] - sX[i];
-        auto pick = [&](const double (&a)[8]) {
-            double m = a[0];
-#pragma unroll
-            for (int i = 1; i < 8; i++) if (lane == i) m = a[i];
-            return m;
-        };
+        // dx_0 = x0 - X_0 ; dx_{k+1} = A_k dx_k + B_k du_k + b_k, lane i < 8 carries row i of dx:
+        //   dx'_i = diag_i dx_i + cpsi_i dx_2 + sum_{c<5} S_i[c] dx_{3+c} + S_i[5] du0 + S_i[6] du1 + b_i
+        // (rows 6,7: pure integrators of the inputs). The six coupled entries are broadcast with readlane.
+        const int ri = (lane < 8) ? lane : 0;                 // lanes >= 8 shadow row 0 and never store
+        const bool core = ri < 6;
+        const double diag = (ri < 3 || ri >= 6) ? 1.0 : 0.0;
+        double dxi = gx0[ri] - sX[ri];
         wsync();
-        if (lane < 8) sX[lane] += pick(dx);
+        if (lane < 8) sX[lane] += dxi;
         for (int k = 0; k < N; k++) {
             const double *rec = sAB + k * ABS;
+            const double *Si = rec + 2 + (core ? ri : 0) * 7;
             const double du0 = sDv[2 * k], du1 = sDv[2 * k + 1];
-            apply_A(rec, dx);
-#pragma unroll
-            for (int i = 0; i < 6; i++) dx[i] += rec[2 + i * 7 + 5] * du0 + rec[2 + i * 7 + 6] * du1 + rec[44 + i];
-            dx[6] += dt * du1 + rec[50];
-            dx[7] += dt * du0 + rec[51];
-            if (lane < 8) sX[(k + 1) * NX + lane] += pick(dx);
+            const double cpsi = (ri < 2) ? rec[ri] : 0.0;
+            double c0 = Si[0], c1 = Si[1], c2 = Si[2], c3 = Si[3], c4 = Si[4], c5 = Si[5], c6 = Si[6];
+            if (!core) { c0 = c1 = c2 = c3 = c4 = 0.0; c5 = (ri == 7) ? dt : 0.0; c6 = (ri == 6) ? dt : 0.0; }
+            const double bi = rec[44 + ri];
+            const double x2 = rl(dxi, 2), x3 = rl(dxi, 3), x4 = rl(dxi, 4), x5 = rl(dxi, 5), x6 = rl(dxi, 6), x7 = rl(dxi, 7);
+            double acc0 = diag * dxi + cpsi * x2 + bi;
+            double acc1 = c5 * du0 + c6 * du1;
+            acc0 += c0 * x3; acc1 += c1 * x4;
+            acc0 += c2 * x5; acc1 += c3 * x6;
+            acc0 += c4 * x7;
+            dxi = acc0 + acc1;
+            if (lane < 8) sX[(k + 1) * NX + lane] += dxi;
         }
         sU1[lane] += v0;
         if (lane < 16) sU1[64 + lane] += v1;
