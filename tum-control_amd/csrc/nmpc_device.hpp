@@ -307,8 +307,8 @@ __device__ __forceinline__ void rk4_sens(const Model &p, const double x0[8], con
         for (int i = 0; i < 6; i++)
 #pragma unroll
             for (int c = 0; c < 7; c++) { Sacc[i][c] = 0.0; Kp[i][c] = 0.0; }
-#pragma unroll
-        for (int st = 0; st < 4; st++) {
+#pragma unroll 1
+        for (int st = 0; st < 4; st++) {     // not unrolled: keeps the live ranges of one stage from leaking into the next
             const double ci = (st == 0) ? 0.0 : (st == 3 ? 1.0 : 0.5);
             const double bi = (st == 0 || st == 3) ? (1.0 / 6.0) : (2.0 / 6.0);
             const double ch = ci * h;
