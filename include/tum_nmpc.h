@@ -142,6 +142,32 @@ int tum_ocp_r2_backoff(tum_ocp *c, const double *Sigma0, const double *BWB, int 
 /* read back a bound installed with constraints_set / r2_backoff (one value per instance) */
 int tum_ocp_constraints_get(tum_ocp *c, int stage, const char *field, double *v, int b0, int nb);
 
+/* ---- the producer and the consumer of the solve, on the device --------------------------
+ * PlannerEmulator(ref_traj, pose, n_points, Tp, loop_circuit)   Utils/MPC_sim_utils.py:137-194, called from
+ * main.py:52-54 / get_baseline_performances.py:105: stateless batched form. track: n_track x 4 row-major
+ * [pos_x,pos_y,ref_yaw,ref_v]; pose: P x 2; ref_out: P x n_points x 4; closest_out (optional): P. All host pointers. */
+int tum_planner_emulate(const double *track, int n_track, const double *pose, int P, int n_points, double Tp,
+                        int loop_circuit, double *ref_out, int *closest_out, int device);
+
+/* A batch of closed loops kept in HBM: planner -> solve -> plant step + state estimation
+ * (main.py:48-78; Utils/SimulationMode_main_class.py:106-156 sim_step simMode 0 / StateEstimation;
+ * Vehicle_Simulator/sim_model_dynamic_stm_pacejka.py:137-195 + VehicleSimulator.py:73-77: RK4 with n_elem elements over Ts).
+ * windows: the 8 moving-average lengths (1..4). log_capacity: control steps of logs kept on the device (0 = none). */
+typedef struct tum_sim tum_sim;
+tum_sim *tum_sim_create(tum_ocp *c, const double *track, int n_track, double Tp, int loop_circuit, double Ts, int n_elem,
+                        const int *windows, int log_capacity);
+void tum_sim_free(tum_sim *s);
+/* x_sim: batch x 7 plant states, x_mpc: batch x 8 controller states (host); resets the estimator and the step counter */
+int tum_sim_set_state(tum_sim *s, const double *x_sim, const double *x_mpc, int cold_start);
+int tum_sim_plan(tum_sim *s);        /* yref of every instance from its pose (async on the capsule's stream) */
+int tum_sim_advance(tum_sim *s);     /* plant step with (x1[7], u0[1]) of the iterate, estimator -> next x0 (async) */
+int tum_sim_run(tum_sim *s, int nsteps);   /* nsteps x (plan, solve, advance), then synchronises */
+int tum_sim_steps(const tum_sim *s);
+/* field: "x_sim" (B*7), "x_mpc" (B*8), "pose" (B*2), "ref0" (B*4), "closest" (B); logs with the npz schema of
+ * Utils/Logging_Plotting.py:357-372, step-major: "CiLX" ((steps+1)*B*7), "MPC_SimX" ((steps+1)*B*8), "simU" (steps*B*2),
+ * "simREF" (steps*B*4), "simSolverDebug" (steps*B*5: cost, 0, sqp_iter, qp_iter, status). len must match. */
+int tum_sim_get(tum_sim *s, const char *field, double *out, long long len);
+
 /* development aid: one solve with in-kernel phase timers; out = batch x 12 shader-cycle counters
  * [linearise, condense, ipm-residuals, M assembly, Cholesky, rhs, tri-solves, row updates, (iteration tail), expand+cost] */
 int tum_ocp_profile_phases(tum_ocp *c, long long *out);

@@ -42,6 +42,18 @@ def main():
     dbg = log["simSolverDebug"][:, 0]
     print(f"configs[0] closed loop 250 steps (5 s of driving), batch 1: all status 0 = {bool((dbg[:, 4] == 0).all())}, "
           f"mean qp_iter {dbg[:, 3].mean():.1f}, mean kernel {1e3 * dbg[:, 1].mean():.3f} ms/solve, wall {wall:.1f} s incl. host planner/plant")
+    # configs[0] as BASELINE states it (5000 steps), planner / plant / estimator as device kernels; then the same loop
+    # for the 26 weight sets of the BO sweep and for 4096 vehicles at once
+    for B, steps in ((1, 5000), (26, 5000), (4096, 500)):
+        cl = ClosedLoopBatch("monteblanco", batch=B, N=38, Tp=3.04, on_device=True, log_capacity=steps)
+        t0 = time.perf_counter()
+        lg = cl.run(steps)
+        wall = time.perf_counter() - t0
+        dbg = lg["simSolverDebug"]
+        print(f"configs[0] on-device closed loop, batch {B}, {steps} steps ({steps * 0.02:.0f} s of driving): wall {wall:.2f} s = "
+              f"{1e3 * wall / steps:.3f} ms/step, {B * steps / wall:,.0f} closed-loop solves/s, status 0 {(dbg[:, :, 4] == 0).mean():.4f}, "
+              f"mean qp_iter {dbg[:, :, 3].mean():.2f}, max |lateral speed| {np.abs(lg['CiLX'][:, :, 4]).max():.2f} m/s")
+        del cl
     # configs[1]
     x0, yref = nominal_batch(4096, N=N)
     s = BatchedOcpSolver(N=N, batch=4096); s.install_reference_ocp(); s.set_x0(x0); s.set_yref_all(yref)

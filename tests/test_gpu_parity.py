@@ -320,3 +320,78 @@ def test_closed_loop_weight_sweep_vs_logged_acados(golden_dir):
     assert eu[:, :50].max() < 5e-5 and ec[:, :51].max() < 1e-5
     per_set = np.maximum(eu.max(axis=1), ec.max(axis=1))
     assert (per_set < 1e-4).mean() >= 0.85 and per_set.max() < 5e-2, np.sort(per_set)[::-1][:5]
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# the planner and the plant + estimator as device kernels
+
+@pytest.mark.gpu
+def test_device_planner_matches_reference_golden(golden_dir):
+    """planner_kernel against outputs captured from the reference's PlannerEmulator (tests/golden/planner.npz):
+    closest index exact, resampled reference to 1e-12 (both the 39-point/3.04 s and the 41-point/3.2 s variants,
+    including segments that cross the 2*pi yaw seam and poses near the end of the track)."""
+    from tum_control_amd.planner import load_track
+    from tum_control_amd.solver import planner_emulate
+    g = np.load(os.path.join(golden_dir, "planner.npz"))
+    seam = 0
+    for track in ("monteblanco", "lvms", "modena"):
+        tr = load_track(track)
+        poses = g[f"{track}_pose"]
+        for npts, Tp, key in ((39, 3.04, "n39"), (41, 3.2, "n41")):
+            idx, ref = planner_emulate(tr, poses, npts, Tp, True)
+            if key == "n39":
+                assert (idx == g[f"{track}_idx"]).all()
+            exp = g[f"{track}_{key}"]
+            assert np.abs(ref - exp).max() < 1e-12, (track, key, np.abs(ref - exp).max())
+            seam += int((np.abs(np.diff(exp[:, :, 2], axis=1)) > 3.0).any(axis=1).sum())
+    assert seam > 0          # the fixtures do exercise the seam branch
+
+
+@pytest.mark.gpu
+def test_device_planner_matches_host_restatement_everywhere():
+    """Every waypoint of every track as a pose (plus off-track offsets): device planner == host restatement."""
+    from tum_control_amd.planner import load_track, planner_emulator
+    from tum_control_amd.solver import planner_emulate
+    rng = np.random.default_rng(5)
+    for track in ("monteblanco", "lvms", "modena"):
+        tr = load_track(track)
+        poses = tr[:, :2] + rng.normal(0, 1.5, (len(tr), 2))
+        idx, ref = planner_emulate(tr, poses, 41, 3.2, True)
+        for b in range(0, len(tr), 3):
+            i0, r = planner_emulator(tr, poses[b], 41, 3.2, True)
+            assert i0 == idx[b]
+            assert np.abs(r - ref[b]).max() < 1e-12
+        # open track: the walk stops at the last waypoint
+        idx2, ref2 = planner_emulate(tr, poses[-40:], 41, 3.2, False)
+        for b in range(40):
+            i0, r = planner_emulator(tr, poses[len(tr) - 40 + b], 41, 3.2, False)
+            assert i0 == idx2[b] and np.abs(r - ref2[b]).max() < 1e-12
+
+
+@pytest.mark.gpu
+def test_device_closed_loop_matches_host_loop_and_logs(golden_dir):
+    """26 closed loops (one per weight set of F.csv) for 150 steps entirely on the device (planner, solve, plant,
+    estimator kernels) against (1) the same loop with the host-side planner/plant restatements and (2) the reference's logs."""
+    from tum_control_amd.closed_loop import ClosedLoopBatch
+    g = np.load(os.path.join(golden_dir, "closed_loop_monteblanco_150.npz"))
+    P = g["params"]
+    n = 150
+    dev = ClosedLoopBatch("monteblanco", batch=26, params=P, on_device=True, log_capacity=n)
+    ld = dev.run(n)
+    host = ClosedLoopBatch("monteblanco", batch=26, params=P)
+    lh = host.run(n)
+    assert ld["simU"].shape == (n, 26, 2) and ld["CiLX"].shape == (n + 1, 26, 7)
+    assert (ld["simSolverDebug"][:, :, 4] == 0).all()
+    # device loop vs host loop: same arithmetic up to libm ulps, amplified by the closed loop
+    assert np.abs(ld["simU"][:30] - lh["simU"][:30]).max() < 1e-8
+    assert np.abs(ld["CiLX"][:31] - lh["CiLX"][:31]).max() < 1e-8
+    assert np.abs(ld["simREF"][:30] - lh["simREF"][:30]).max() < 1e-9
+    assert np.abs(ld["simU"] - lh["simU"]).max() < 5e-3
+    # vs the reference's logged closed loops (yaw is logged modulo 2*pi)
+    C = ld["CiLX"].transpose(1, 0, 2).copy(); C[:, :, 2] = np.mod(C[:, :, 2], 2 * np.pi)
+    U = ld["simU"].transpose(1, 0, 2)
+    eu = np.abs(U[:, :50] - g["simU"][:, :50]).max()
+    ec = np.abs(C[:, :51] - g["CiLX"][:, :51]).max()
+    assert eu < 5e-5 and ec < 1e-5, (eu, ec)
+    good = (np.abs(U - g["simU"]).max(axis=(1, 2)) < 1e-4).mean()
+    assert good >= 0.85, good

@@ -98,7 +98,7 @@ def test_cabi_exports_every_declared_symbol():
     g.build()
     from tum_control_amd import solver
     hdr = open(os.path.join(ROOT, "include", "tum_nmpc.h")).read()
-    declared = sorted(set(re.findall(r"\b(tum_(?:ocp|pce)_\w+)\s*\(", hdr)))
+    declared = sorted(set(re.findall(r"\b(tum_(?:ocp|pce|sim|planner)_\w+)\s*\(", hdr)))
     assert len(declared) >= 20
     L = solver.load_library()
     for sym in declared:

@@ -15,7 +15,7 @@ import numpy as np
 
 from . import config as _config
 from .planner import load_track, planner_emulator, yref_from_ref
-from .solver import BatchedOcpSolver
+from .solver import BatchedOcpSolver, DeviceClosedLoop
 
 WINDOWS = (1, 1, 4, 2, 2, 3, 4, 2)          # SimulationMode_main_class.py:86
 
@@ -88,7 +88,8 @@ class ClosedLoopBatch:
     """B independent closed loops on one track, one OCP instance each; `params` (B,7) are per-instance
     [q_xy, q_yaw, q_vel, r_jerk, r_steer, L1, L2] as in update_cost_function_weights (None: YAML defaults x0.01)."""
 
-    def __init__(self, track_name, batch=1, params=None, N=38, Tp=3.04, Ts=0.02, idx_start=0, cfg=None, device=0):
+    def __init__(self, track_name, batch=1, params=None, N=38, Tp=3.04, Ts=0.02, idx_start=0, cfg=None, device=0,
+                 on_device=False, log_capacity=0):
         self.cfg = cfg or _config.default_config()
         self.track = load_track(track_name)
         self.B, self.N, self.Tp, self.Ts = batch, N, Tp, Ts
@@ -104,6 +105,11 @@ class ClosedLoopBatch:
         self.solver.set_x0(self.x_mpc)
         self.solver.cold_start()
         self.est = MovingAverageEstimator(batch)
+        # on_device: planner, plant and estimator run as kernels next to the solve (no host round trip per step)
+        self.dev = None
+        if on_device:
+            self.dev = DeviceClosedLoop(self.solver, self.track, Tp, Ts=Ts, n_elem=4, windows=WINDOWS, log_capacity=log_capacity)
+            self.dev.set_state(self.x_sim, self.x_mpc, cold_start=True)
         self.log = dict(CiLX=[self.x_sim.copy()], MPC_SimX=[self.x_mpc.copy()], simU=[], simREF=[], simSolverDebug=[])
 
     def set_weights(self, p):
@@ -144,6 +150,10 @@ class ClosedLoopBatch:
         return status
 
     def run(self, n_steps):
+        if self.dev is not None:
+            self.dev.run(n_steps)
+            self.x_sim, self.x_mpc, self.pose = self.dev.get("x_sim"), self.dev.get("x_mpc"), self.dev.get("pose")
+            return self.dev.logs()
         for _ in range(n_steps):
             self.step()
         return {k: np.array(v) for k, v in self.log.items()}          # arrays are (steps[+1], B, dim)

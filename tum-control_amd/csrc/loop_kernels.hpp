@@ -1,0 +1,227 @@
+// loop_kernels.hpp -- the producer and the consumer of the SQP-RTI solve, on the device:
+//   K8 planner_kernel        local reference extraction for every instance (Utils/MPC_sim_utils.py:137-194 PlannerEmulator)
+//   K9 plant_advance_kernel  plant step + state estimation (Utils/SimulationMode_main_class.py:106-156 sim_step / StateEstimation,
+//                            Vehicle_Simulator/sim_model_dynamic_stm_pacejka.py:137-195, VehicleSimulator.py:73-77)
+// With them a batch of closed loops runs planner -> solve -> plant without leaving HBM.
+#pragma once
+#include "nmpc_device.hpp"
+
+namespace tum {
+
+constexpr int PLAN_MAXM = 512;      // longest extracted segment (points) the yaw-unwrap buffer holds
+
+// np.mod(x, 2*pi): result carries the sign of the divisor
+__device__ __forceinline__ double pymod_2pi(double x)
+{
+    const double P = 2.0 * M_PI;
+    double r = fmod(x, P);
+    if (r != 0.0 && r < 0.0) r += P;
+    return r;
+}
+
+// One wavefront per instance. track: n x 4 row-major [pos_x, pos_y, ref_yaw, ref_v]; pose: [b][pose_stride] (x, y first).
+// out: [b][npts][out_stride] gets [x, y, yaw, v] in its first four slots (the yref block: out_stride 6, slots 4,5 zeroed;
+// a bare reference: out_stride 4). Arithmetic follows numpy's order of operations (no contraction): nearest waypoint =
+// first minimum of (px-x)^2+(py-y)^2; walk forward while the accumulated travel time <= Tp; np.linspace / np.interp
+// resampling to npts samples; the yaw channel is interpolated on the unwrapped signal when the segment crosses the
+// 2*pi seam (any step > 250 degrees) and wrapped back into [0, 2*pi).
+__global__ void __launch_bounds__(64) planner_kernel(const double *track, int n, const double *pose, int pose_stride, int npts, double Tp,
+                                                     int loop_circuit, double *out, int out_stride, double *ref0, int *closest,
+                                                     int *err, int batch)
+{
+#pragma clang fp contract(off)
+    __shared__ double sYaw[PLAN_MAXM];
+    const int lane = threadIdx.x, b = blockIdx.x;
+    if (b >= batch) return;
+    const double x = pose[(size_t)b * pose_stride], y = pose[(size_t)b * pose_stride + 1];
+    // ---- closest waypoint (np.argmin: first minimum)
+    double best = INFINITY; int bi = 0x7fffffff;
+    for (int i = lane; i < n; i += 64) {
+        const double dx = track[4 * i] - x, dy = track[4 * i + 1] - y;
+        const double d = dx * dx + dy * dy;
+        if (d < best) { best = d; bi = i; }
+    }
+    for (int off = 32; off >= 1; off >>= 1) {
+        const double od = __shfl_xor(best, off, 64); const int oi = __shfl_xor(bi, off, 64);
+        if (od < best || (od == best && oi < bi)) { best = od; bi = oi; }
+    }
+    const int i0 = bi;
+    // ---- walk forward (wave-uniform): indices are consecutive modulo n
+    int m = 1, cur = i0; double T = 0.0; bool over = false;
+    while (T <= Tp) {
+        int nxt = cur + 1;
+        if (nxt >= n) { if (!loop_circuit) break; nxt = 0; }
+        T += hypot(track[4 * nxt] - track[4 * cur], track[4 * nxt + 1] - track[4 * cur + 1]) / track[4 * nxt + 3];
+        cur = nxt; m++;
+        if (m >= PLAN_MAXM) { over = true; break; }
+    }
+    if (over && lane == 0 && err) atomicOr(err, 1);
+    auto at = [&](int j) -> int { int i = i0 + j; return (i >= n) ? i - n * (i / n) : i; };
+    // ---- does the segment cross the yaw seam?
+    bool seam = false;
+    for (int j = lane; j + 1 < m; j += 64) seam |= fabs(track[4 * at(j + 1) + 2] - track[4 * at(j) + 2]) > 250.0 * (M_PI / 180.0);
+    seam = __any(seam);
+    if (seam && m != npts) {
+        if (lane == 0) {   // np.unwrap(period = 2*pi): sequential cumulative correction
+            double prev = track[4 * at(0) + 2], cum = 0.0;
+            sYaw[0] = prev;
+            for (int j = 1; j < m; j++) {
+                const double p = track[4 * at(j) + 2];
+                const double dd = p - prev;
+                double t = dd + M_PI;
+                double md = fmod(t, 2.0 * M_PI);
+                if (md != 0.0 && md < 0.0) md += 2.0 * M_PI;
+                double ddmod = md - M_PI;
+                if (ddmod == -M_PI && dd > 0.0) ddmod = M_PI;
+                double corr = ddmod - dd;
+                if (fabs(dd) < M_PI) corr = 0.0;
+                cum += corr;
+                sYaw[j] = p + cum;
+                prev = p;
+            }
+        }
+        __syncthreads();
+    }
+    // ---- resample: lane j -> sample j
+    for (int j = lane; j < npts; j += 64) {
+        double r[4];
+        if (m == npts) {
+            const int i = at(j);
+#pragma unroll
+            for (int c = 0; c < 4; c++) r[c] = track[4 * i + c];
+        } else {
+            const double step = (double)(m - 1) / (double)(npts - 1);
+            double xs = (double)j * step;
+            if (j == npts - 1) xs = (double)(m - 1);
+            const int jj = (int)xs;
+            if (jj >= m - 1) {
+                const int i = at(m - 1);
+#pragma unroll
+                for (int c = 0; c < 4; c++) r[c] = track[4 * i + c];
+                if (seam) r[2] = pymod_2pi(sYaw[m - 1]);
+            } else {
+                const int ia = at(jj), ib = at(jj + 1);
+                const double fx = xs - (double)jj;
+#pragma unroll
+                for (int c = 0; c < 4; c++) {
+                    double fa = track[4 * ia + c], fb = track[4 * ib + c];
+                    if (c == 2 && seam) { fa = sYaw[jj]; fb = sYaw[jj + 1]; }
+                    const double slope = (fb - fa) / 1.0;
+                    r[c] = (fx == 0.0) ? fa : slope * fx + fa;
+                }
+                if (seam) r[2] = pymod_2pi(r[2]);
+            }
+        }
+        double *o = out + ((size_t)b * npts + j) * out_stride;
+#pragma unroll
+        for (int c = 0; c < 4; c++) o[c] = r[c];
+        for (int c = 4; c < out_stride; c++) o[c] = 0.0;
+        if (j == 0 && ref0) {
+#pragma unroll
+            for (int c = 0; c < 4; c++) ref0[(size_t)b * 4 + c] = r[c];
+        }
+    }
+    if (lane == 0 && closest) closest[b] = i0;
+}
+
+// xdot of the 7-state plant [posx,posy,yaw,vlong,vlat,yawrate,delta_f] with inputs (a, steering rate)
+// (sim_model_dynamic_stm_pacejka.py:137-195: the prediction model's forces with the acceleration as an input)
+struct PlantModel {
+    double lf, lr, m, Iz, ka;
+    double Bf, Cf, Df, Ef, Br, Cr, Dr, Er;
+    double g, fr0, fr1, fr4;
+};
+
+__device__ __forceinline__ void plant_xdot(const PlantModel &p, const double x[7], double a, double sr, double xd[7])
+{
+#pragma clang fp contract(off)
+    const double yaw = x[2], vl = x[3], vt = x[4], r = x[5], de = x[6];
+    const double v = sqrt(vl * vl + vt * vt) * 3.6;
+    const double w = v / 100;
+    const double fr = p.fr0 + p.fr1 * v / 100 + p.fr4 * (w * w * w * w);
+    const double Fz_f = p.m * p.lr * p.g / (p.lf + p.lr), Fz_r = p.m * p.lf * p.g / (p.lf + p.lr);
+    const double Fx_f = -fr * Fz_f;
+    const double Fx_r = p.m * a - fr * Fz_r;
+    const double Faero = p.ka * (vl * vl);
+    const bool ok = vl > 0.001;
+    const double vls = ok ? vl : 1.0;
+    const double al_f = ok ? de - atan((vt + p.lf * r) / vls) : 0.0;
+    const double al_r = ok ? atan((p.lr * r - vt) / vls) : 0.0;
+    const double Fy_f_lat = p.Df * sin(p.Cf * atan(p.Bf * al_f - p.Ef * (p.Bf * al_f - atan(p.Bf * al_f))));
+    const double Fy_r_lat = p.Dr * sin(p.Cr * atan(p.Br * al_r - p.Er * (p.Br * al_r - atan(p.Br * al_r))));
+    const double Fmax_f = sqrt(Fz_f * Fz_f + (p.Cf * Fz_f) * (p.Cf * Fz_f)), Fmax_r = sqrt(Fz_r * Fz_r + (p.Cr * Fz_r) * (p.Cr * Fz_r));
+    double Gy_f = Fx_f / Fmax_f, Gy_r = Fx_r / Fmax_r;
+    Gy_f = fmin(fmax(Gy_f, -0.98), 0.98); Gy_r = fmin(fmax(Gy_r, -0.98), 0.98);
+    const double Fy_f = Fy_f_lat * cos(asin(Gy_f)), Fy_r = Fy_r_lat * cos(asin(Gy_r));
+    const double sy = sin(yaw), cy = cos(yaw), sd = sin(de), cd = cos(de);
+    xd[0] = vl * cy - vt * sy;
+    xd[1] = vl * sy + vt * cy;
+    xd[2] = r;
+    xd[3] = (Fx_r - Faero - Fy_f * sd + Fx_f * cd + p.m * vt * r) / p.m;
+    xd[4] = (Fy_r + Fy_f * cd + Fx_f * sd - p.m * vl * r) / p.m;
+    xd[5] = (p.lf * (Fy_f * cd + Fx_f * sd) - p.lr * Fy_r) / p.Iz;
+    xd[6] = sr;
+}
+
+struct SimArgs {
+    int N, batch, n_elem, step, log_cap;              // step = control steps done before this one
+    double Ts;
+    int win[8];
+    PlantModel pm;
+    const double *X, *U, *cost; const int *status, *qp_iter;   // the solver's outputs
+    double *x_sim, *x0, *pose, *hist;                 // [b][7], [b][8] (capsule x0), [b][2], [b][8][4]
+    const double *ref0;                               // [b][4] first reference point of this step (planner output)
+    double *lCiLX, *lSimX, *lU, *lREF, *lDBG;         // logs (nullable): (cap+1,B,7) (cap+1,B,8) (cap,B,2) (cap,B,4) (cap,B,5)
+};
+
+// One thread per instance: simMode 0 of sim_step. The plant takes the predicted acceleration of stage 1 and the steering
+// rate of stage 0, integrates Ts with classic RK4 in n_elem equal sub-steps; the estimator is a per-state moving average
+// over the last win[i] samples (fewer while the buffer fills); the filtered state becomes the next x0 of the OCP.
+__global__ void plant_advance_kernel(const SimArgs sa)
+{
+#pragma clang fp contract(off)
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= sa.batch) return;
+    const int N = sa.N, B = sa.batch;
+    const double *x1 = sa.X + ((size_t)b * (N + 1) + 1) * NX;
+    const double *u0 = sa.U + (size_t)b * N * NU;
+    const double a_in = x1[7], sr_in = u0[1];
+    double x[7];
+    for (int i = 0; i < 7; i++) x[i] = sa.x_sim[(size_t)b * 7 + i];
+    const double h = sa.Ts / sa.n_elem;
+    for (int e = 0; e < sa.n_elem; e++) {
+        double k1[7], k2[7], k3[7], k4[7], t[7];
+        plant_xdot(sa.pm, x, a_in, sr_in, k1);
+        for (int i = 0; i < 7; i++) t[i] = x[i] + 0.5 * h * k1[i];
+        plant_xdot(sa.pm, t, a_in, sr_in, k2);
+        for (int i = 0; i < 7; i++) t[i] = x[i] + 0.5 * h * k2[i];
+        plant_xdot(sa.pm, t, a_in, sr_in, k3);
+        for (int i = 0; i < 7; i++) t[i] = x[i] + h * k3[i];
+        plant_xdot(sa.pm, t, a_in, sr_in, k4);
+        for (int i = 0; i < 7; i++) x[i] = x[i] + h / 6.0 * (k1[i] + 2 * k2[i] + 2 * k3[i] + k4[i]);
+    }
+    for (int i = 0; i < 7; i++) sa.x_sim[(size_t)b * 7 + i] = x[i];
+    sa.pose[(size_t)b * 2] = x[0]; sa.pose[(size_t)b * 2 + 1] = x[1];
+    // state estimation: sample number k (1-based) goes to ring slot (k-1) & 3
+    const int k = sa.step + 1;
+    for (int i = 0; i < 8; i++) {
+        const double v = (i < 7) ? x[i] : a_in;
+        double *hst = sa.hist + ((size_t)b * 8 + i) * 4;
+        hst[(k - 1) & 3] = v;
+        const int cnt = (sa.win[i] < k) ? sa.win[i] : k;
+        double s = hst[(k - cnt) & 3];
+        for (int t = k - cnt + 1; t < k; t++) s = s + hst[t & 3];
+        sa.x0[(size_t)b * NX + i] = s / (double)cnt;
+    }
+    if (sa.lCiLX && sa.step < sa.log_cap) {
+        const size_t s = sa.step;
+        for (int i = 0; i < 7; i++) sa.lCiLX[((s + 1) * B + b) * 7 + i] = x[i];
+        for (int i = 0; i < 8; i++) sa.lSimX[((s + 1) * B + b) * 8 + i] = x1[i];
+        sa.lU[(s * B + b) * 2] = u0[0]; sa.lU[(s * B + b) * 2 + 1] = u0[1];
+        for (int i = 0; i < 4; i++) sa.lREF[(s * B + b) * 4 + i] = sa.ref0[(size_t)b * 4 + i];
+        double *d = sa.lDBG + (s * B + b) * 5;
+        d[0] = sa.cost[b]; d[1] = 0.0; d[2] = 1.0; d[3] = (double)sa.qp_iter[b]; d[4] = (double)sa.status[b];
+    }
+}
+
+}  // namespace tum

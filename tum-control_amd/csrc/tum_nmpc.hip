@@ -11,6 +11,7 @@
 #include "../../include/tum_nmpc.h"
 #include "nmpc_kernel.hpp"
 #include "aux_kernels.hpp"
+#include "loop_kernels.hpp"
 
 using namespace tum;
 
@@ -525,4 +526,181 @@ extern "C" int tum_ocp_constraints_get(tum_ocp *c, int stage, const char *field,
     else if (f == "lh") row = 4; else if (f == "uh") row = 5; else return fail("constraints_get: unknown field '" + f + "'");
     if (stage < 0 || stage > N) return fail("constraints_get: stage out of range");
     return fetch(c, c->dbnd, (size_t)6 * NB, (size_t)row * NB + stage, v, 1, b0, nb, 1);
+}
+
+// ---------------------------------------------------------------------------------------------- K8 / K9: device closed loop
+struct tum_sim {
+    tum_ocp *c;
+    int n_track, loop_circuit, n_elem, step, log_cap;
+    double Tp, Ts;
+    int win[8];
+    double *dtrack, *dxsim, *dpose, *dhist, *dref0;
+    int *dclosest, *derr;
+    double *lCiLX, *lSimX, *lU, *lREF, *lDBG;
+};
+
+extern "C" int tum_planner_emulate(const double *track, int n_track, const double *pose, int P, int n_points, double Tp,
+                                   int loop_circuit, double *ref_out, int *closest_out, int device)
+{
+    if (!track || !pose || !ref_out) return fail("null argument");
+    if (n_track < 2 || P < 1 || n_points < 2) return fail("planner_emulate: bad sizes");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return fail("no HIP device: libtumnmpc has no CPU fallback");
+    HIPCHK(hipSetDevice(device));
+    double *dt = nullptr, *dp = nullptr, *dout = nullptr; int *dcl = nullptr, *derr = nullptr;
+    HIPCHK(hipMalloc((void **)&dt, sizeof(double) * 4 * n_track));
+    HIPCHK(hipMalloc((void **)&dp, sizeof(double) * 2 * P));
+    HIPCHK(hipMalloc((void **)&dout, sizeof(double) * 4 * (size_t)P * n_points));
+    HIPCHK(hipMalloc((void **)&dcl, sizeof(int) * P));
+    HIPCHK(hipMalloc((void **)&derr, sizeof(int)));
+    HIPCHK(hipMemset(derr, 0, sizeof(int)));
+    HIPCHK(hipMemcpy(dt, track, sizeof(double) * 4 * n_track, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(dp, pose, sizeof(double) * 2 * P, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(planner_kernel, dim3(P), dim3(64), 0, 0, dt, n_track, dp, 2, n_points, Tp, loop_circuit, dout, 4,
+                       (double *)nullptr, dcl, derr, P);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipDeviceSynchronize());
+    int err = 0;
+    HIPCHK(hipMemcpy(&err, derr, sizeof(int), hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(ref_out, dout, sizeof(double) * 4 * (size_t)P * n_points, hipMemcpyDeviceToHost));
+    if (closest_out) HIPCHK(hipMemcpy(closest_out, dcl, sizeof(int) * P, hipMemcpyDeviceToHost));
+    (void)hipFree(dt); (void)hipFree(dp); (void)hipFree(dout); (void)hipFree(dcl); (void)hipFree(derr);
+    if (err) return fail("planner_emulate: extracted segment longer than PLAN_MAXM points");
+    return 0;
+}
+
+extern "C" void tum_sim_free(tum_sim *s)
+{
+    if (!s) return;
+    (void)hipFree(s->dtrack); (void)hipFree(s->dxsim); (void)hipFree(s->dpose); (void)hipFree(s->dhist); (void)hipFree(s->dref0);
+    (void)hipFree(s->dclosest); (void)hipFree(s->derr);
+    (void)hipFree(s->lCiLX); (void)hipFree(s->lSimX); (void)hipFree(s->lU); (void)hipFree(s->lREF); (void)hipFree(s->lDBG);
+    delete s;
+}
+
+extern "C" tum_sim *tum_sim_create(tum_ocp *c, const double *track, int n_track, double Tp, int loop_circuit, double Ts, int n_elem,
+                                   const int *windows, int log_capacity)
+{
+    if (!c || !track || !windows) { fail("null argument"); return nullptr; }
+    if (n_track < 2 || !(Tp > 0) || !(Ts > 0) || n_elem < 1 || log_capacity < 0) { fail("sim_create: bad arguments"); return nullptr; }
+    for (int i = 0; i < 8; i++) if (windows[i] < 1 || windows[i] > 4) { fail("sim_create: estimator windows must be 1..4"); return nullptr; }
+    if (hipSetDevice(c->d.device) != hipSuccess) { fail("hipSetDevice failed"); return nullptr; }
+    tum_sim *s = new tum_sim();
+    memset(s, 0, sizeof(*s));
+    s->c = c; s->n_track = n_track; s->loop_circuit = loop_circuit; s->n_elem = n_elem; s->Tp = Tp; s->Ts = Ts; s->log_cap = log_capacity;
+    for (int i = 0; i < 8; i++) s->win[i] = windows[i];
+    const size_t B = c->batch, L = log_capacity;
+    bool ok = true;
+    ok &= dalloc(&s->dtrack, (size_t)4 * n_track) == hipSuccess;
+    ok &= dalloc(&s->dxsim, B * 7) == hipSuccess && dalloc(&s->dpose, B * 2) == hipSuccess && dalloc(&s->dhist, B * 32) == hipSuccess;
+    ok &= dalloc(&s->dref0, B * 4) == hipSuccess && dalloc(&s->dclosest, B) == hipSuccess && dalloc(&s->derr, (size_t)1) == hipSuccess;
+    if (L > 0) {
+        ok &= dalloc(&s->lCiLX, (L + 1) * B * 7) == hipSuccess && dalloc(&s->lSimX, (L + 1) * B * 8) == hipSuccess;
+        ok &= dalloc(&s->lU, L * B * 2) == hipSuccess && dalloc(&s->lREF, L * B * 4) == hipSuccess && dalloc(&s->lDBG, L * B * 5) == hipSuccess;
+    }
+    ok = ok && hipMemcpy(s->dtrack, track, sizeof(double) * 4 * n_track, hipMemcpyHostToDevice) == hipSuccess;
+    if (!ok) { fail("sim_create: device allocation failed"); tum_sim_free(s); return nullptr; }
+    return s;
+}
+
+// initial plant state (batch x 7) and controller state (batch x 8): X0_sim / X0_MPC of SimulationMode_main_class.py:60-75
+extern "C" int tum_sim_set_state(tum_sim *s, const double *x_sim, const double *x_mpc, int cold_start)
+{
+    if (!s || !x_sim || !x_mpc) return fail("null argument");
+    tum_ocp *c = s->c; const size_t B = c->batch;
+    HIPCHK(hipSetDevice(c->d.device));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    HIPCHK(hipMemcpy(s->dxsim, x_sim, sizeof(double) * B * 7, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(c->dx0, x_mpc, sizeof(double) * B * 8, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy2D(s->dpose, 2 * 8, x_mpc, 8 * 8, 2 * 8, B, hipMemcpyHostToDevice));
+    HIPCHK(hipMemset(s->dhist, 0, sizeof(double) * B * 32));
+    s->step = 0;
+    if (s->log_cap > 0) {
+        HIPCHK(hipMemcpy(s->lCiLX, x_sim, sizeof(double) * B * 7, hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(s->lSimX, x_mpc, sizeof(double) * B * 8, hipMemcpyHostToDevice));
+    }
+    if (cold_start) return tum_ocp_cold_start(c);
+    return 0;
+}
+
+extern "C" int tum_sim_plan(tum_sim *s)
+{
+    if (!s) return fail("null argument");
+    tum_ocp *c = s->c;
+    hipLaunchKernelGGL(planner_kernel, dim3(c->batch), dim3(64), 0, c->stream, s->dtrack, s->n_track, s->dpose, 2, c->N + 1, s->Tp,
+                       s->loop_circuit, c->dyref, 6, s->dref0, s->dclosest, s->derr, c->batch);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+extern "C" int tum_sim_advance(tum_sim *s)
+{
+    if (!s) return fail("null argument");
+    tum_ocp *c = s->c;
+    if (!c->solved) return fail("sim_advance: no solve yet");
+    SimArgs sa;
+    memset(&sa, 0, sizeof(sa));
+    sa.N = c->N; sa.batch = c->batch; sa.n_elem = s->n_elem; sa.step = s->step; sa.log_cap = s->log_cap; sa.Ts = s->Ts;
+    for (int i = 0; i < 8; i++) sa.win[i] = s->win[i];
+    const tum_ocp_desc &d = c->d;
+    PlantModel &p = sa.pm;
+    p.lf = d.lf; p.lr = d.lr; p.m = d.m; p.Iz = d.Iz; p.ka = 0.5 * d.ro * d.S * d.Cd;
+    p.Bf = d.Bf; p.Cf = d.Cf; p.Df = d.Df; p.Ef = d.Ef; p.Br = d.Br; p.Cr = d.Cr; p.Dr = d.Dr; p.Er = d.Er;
+    p.g = d.g; p.fr0 = d.fr0; p.fr1 = d.fr1; p.fr4 = d.fr4;
+    sa.X = c->dX; sa.U = c->dU; sa.cost = c->dcost; sa.status = c->dstatus; sa.qp_iter = c->dqpiter;
+    sa.x_sim = s->dxsim; sa.x0 = c->dx0; sa.pose = s->dpose; sa.hist = s->dhist; sa.ref0 = s->dref0;
+    sa.lCiLX = s->lCiLX; sa.lSimX = s->lSimX; sa.lU = s->lU; sa.lREF = s->lREF; sa.lDBG = s->lDBG;
+    hipLaunchKernelGGL(plant_advance_kernel, dim3((c->batch + 63) / 64), dim3(64), 0, c->stream, sa);
+    HIPCHK(hipGetLastError());
+    s->step++;
+    return 0;
+}
+
+// nsteps x (planner, SQP-RTI solve, plant + estimator), enqueued back to back on the capsule's stream; returns after the last one
+extern "C" int tum_sim_run(tum_sim *s, int nsteps)
+{
+    if (!s || nsteps < 0) return fail("bad argument");
+    for (int i = 0; i < nsteps; i++) {
+        if (tum_sim_plan(s)) return 1;
+        if (launch(s->c)) return 1;
+        if (tum_sim_advance(s)) return 1;
+    }
+    HIPCHK(hipStreamSynchronize(s->c->stream));
+    int err = 0;
+    HIPCHK(hipMemcpy(&err, s->derr, sizeof(int), hipMemcpyDeviceToHost));
+    if (err) return fail("sim_run: planner segment longer than PLAN_MAXM points");
+    return 0;
+}
+
+extern "C" int tum_sim_steps(const tum_sim *s) { return s ? s->step : -1; }
+
+extern "C" int tum_sim_get(tum_sim *s, const char *field, double *out, long long len)
+{
+    if (!s || !field || !out) return fail("null argument");
+    tum_ocp *c = s->c; const long long B = c->batch;
+    const long long L = s->step < s->log_cap ? s->step : s->log_cap;
+    const std::string f(field);
+    HIPCHK(hipStreamSynchronize(c->stream));
+    const double *src = nullptr; long long want = 0;
+    if (f == "x_sim") { src = s->dxsim; want = B * 7; }
+    else if (f == "x_mpc") { src = c->dx0; want = B * 8; }
+    else if (f == "pose") { src = s->dpose; want = B * 2; }
+    else if (f == "ref0") { src = s->dref0; want = B * 4; }
+    else if (f == "closest") {
+        if (len != B) return fail("sim_get closest: len != batch");
+        std::vector<int> t(B);
+        HIPCHK(hipMemcpy(t.data(), s->dclosest, sizeof(int) * B, hipMemcpyDeviceToHost));
+        for (long long i = 0; i < B; i++) out[i] = t[i];
+        return 0;
+    }
+    else if (f == "CiLX") { src = s->lCiLX; want = (L + 1) * B * 7; }
+    else if (f == "MPC_SimX") { src = s->lSimX; want = (L + 1) * B * 8; }
+    else if (f == "simU") { src = s->lU; want = L * B * 2; }
+    else if (f == "simREF") { src = s->lREF; want = L * B * 4; }
+    else if (f == "simSolverDebug") { src = s->lDBG; want = L * B * 5; }
+    else return fail("sim_get: unknown field '" + f + "'");
+    if (!src) return fail("sim_get: logging disabled (log_capacity 0)");
+    if (len != want) return fail("sim_get " + f + ": len mismatch");
+    if (want > 0) HIPCHK(hipMemcpy(out, src, sizeof(double) * want, hipMemcpyDeviceToHost));
+    return 0;
 }

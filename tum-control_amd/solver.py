@@ -48,7 +48,9 @@ C_SYMBOLS = ["tum_ocp_create", "tum_ocp_free", "tum_ocp_last_error", "tum_ocp_ba
              "tum_ocp_get_cost", "tum_ocp_get_stats", "tum_ocp_reset", "tum_ocp_get_from_qp_in",
              "tum_ocp_set_stream", "tum_ocp_get_device", "tum_ocp_cold_start", "tum_ocp_last_kernel_ms",
              "tum_ocp_debug_dump", "tum_ocp_profile_phases",
-             "tum_ocp_set_x0_fanout", "tum_pce_moments", "tum_ocp_r2_backoff", "tum_ocp_constraints_get"]
+             "tum_ocp_set_x0_fanout", "tum_pce_moments", "tum_ocp_r2_backoff", "tum_ocp_constraints_get",
+             "tum_planner_emulate", "tum_sim_create", "tum_sim_free", "tum_sim_set_state", "tum_sim_plan", "tum_sim_advance",
+             "tum_sim_run", "tum_sim_steps", "tum_sim_get"]
 
 
 def load_library(path=None):
@@ -90,6 +92,14 @@ def load_library(path=None):
     L.tum_pce_moments.argtypes = [vp, cs, ci, dp, ci, ci, dp, dp]
     L.tum_ocp_r2_backoff.argtypes = [vp, dp, dp, ci, ctypes.c_double, ctypes.c_double, ctypes.c_double, dp]
     L.tum_ocp_constraints_get.argtypes = [vp, ci, cs, dp, ci, ci]
+    ip = ctypes.POINTER(ctypes.c_int); cd = ctypes.c_double
+    L.tum_planner_emulate.argtypes = [dp, ci, dp, ci, ci, cd, ci, dp, ip, ci]
+    L.tum_sim_create.restype = vp; L.tum_sim_create.argtypes = [vp, dp, ci, cd, ci, cd, ci, ip, ci]
+    L.tum_sim_free.restype = None; L.tum_sim_free.argtypes = [vp]
+    L.tum_sim_set_state.argtypes = [vp, dp, dp, ci]
+    L.tum_sim_plan.argtypes = [vp]; L.tum_sim_advance.argtypes = [vp]; L.tum_sim_run.argtypes = [vp, ci]
+    L.tum_sim_steps.argtypes = [vp]
+    L.tum_sim_get.argtypes = [vp, cs, dp, ctypes.c_longlong]
     if path is None:
         _lib = L
     return L
@@ -369,3 +379,76 @@ class BatchedOcpSolver:
             self.constraints_set(k, "ubx", np.array([veh["delta_f_max"]]))
             self.constraints_set(k, "lh", np.array([0.0]))
             self.constraints_set(k, "uh", np.array([1.0]))
+
+
+def planner_emulate(track, poses, n_points, Tp, loop_circuit=True, device=0):
+    """Batched PlannerEmulator on the GPU (Utils/MPC_sim_utils.py:137-194): track (n,4) [x,y,yaw,v], poses (P,2).
+    Returns (closest_index (P,), ref (P, n_points, 4))."""
+    L = load_library()
+    track = np.ascontiguousarray(track, dtype=np.float64); poses = np.ascontiguousarray(np.atleast_2d(poses), dtype=np.float64)
+    if track.ndim != 2 or track.shape[1] != 4 or poses.shape[1] != 2:
+        raise Exception("planner_emulate: track must be (n,4), poses (P,2)")
+    P = poses.shape[0]
+    ref = np.empty((P, n_points, 4)); idx = np.empty(P, dtype=np.int32)
+    rc = L.tum_planner_emulate(_dp(track), track.shape[0], _dp(poses), P, int(n_points), float(Tp), int(bool(loop_circuit)),
+                               _dp(ref), idx.ctypes.data_as(ctypes.POINTER(ctypes.c_int)), int(device))
+    if rc != 0:
+        raise Exception("planner_emulate: " + L.tum_ocp_last_error().decode())
+    return idx, ref
+
+
+class DeviceClosedLoop:
+    """Closed loops of every instance of a solver kept on the GPU: planner -> SQP-RTI -> plant + estimator
+    (main.py:48-78, SimulationMode_main_class.py:106-156). The logs use the reference's npz field names."""
+
+    def __init__(self, solver, track, Tp, Ts=0.02, n_elem=4, windows=(1, 1, 4, 2, 2, 3, 4, 2), loop_circuit=True, log_capacity=0):
+        self.solver, self._L = solver, solver._L
+        track = np.ascontiguousarray(track, dtype=np.float64)
+        win = (ctypes.c_int * 8)(*[int(w) for w in windows])
+        self._s = self._L.tum_sim_create(solver._h, _dp(track), track.shape[0], float(Tp), int(bool(loop_circuit)), float(Ts),
+                                         int(n_elem), win, int(log_capacity))
+        if not self._s:
+            raise Exception("tum_sim_create: " + self._L.tum_ocp_last_error().decode())
+        self.B = solver.batch
+
+    def __del__(self):
+        if getattr(self, "_s", None):
+            self._L.tum_sim_free(self._s); self._s = None
+
+    def _chk(self, rc, what):
+        if rc != 0:
+            raise Exception(f"{what}: " + self._L.tum_ocp_last_error().decode())
+
+    def set_state(self, x_sim, x_mpc, cold_start=True):
+        x_sim = np.ascontiguousarray(np.broadcast_to(x_sim, (self.B, 7)), dtype=np.float64)
+        x_mpc = np.ascontiguousarray(np.broadcast_to(x_mpc, (self.B, 8)), dtype=np.float64)
+        self._chk(self._L.tum_sim_set_state(self._s, _dp(x_sim), _dp(x_mpc), int(cold_start)), "sim_set_state")
+
+    def plan(self):
+        self._chk(self._L.tum_sim_plan(self._s), "sim_plan")
+
+    def advance(self):
+        self._chk(self._L.tum_sim_advance(self._s), "sim_advance")
+
+    def run(self, nsteps):
+        self._chk(self._L.tum_sim_run(self._s, int(nsteps)), "sim_run")
+
+    @property
+    def steps(self):
+        return self._L.tum_sim_steps(self._s)
+
+    _DIMS = dict(x_sim=7, x_mpc=8, pose=2, ref0=4, closest=1, CiLX=7, MPC_SimX=8, simU=2, simREF=4, simSolverDebug=5)
+
+    def get(self, field):
+        d = self._DIMS[field]
+        if field in ("x_sim", "x_mpc", "pose", "ref0", "closest"):
+            shape = (self.B, d)
+        else:
+            n = self.steps + (1 if field in ("CiLX", "MPC_SimX") else 0)
+            shape = (n, self.B, d)
+        out = np.empty(shape)
+        self._chk(self._L.tum_sim_get(self._s, field.encode(), _dp(out), out.size), "sim_get " + field)
+        return out[:, 0].astype(np.int64) if field == "closest" else out
+
+    def logs(self):
+        return {k: self.get(k) for k in ("CiLX", "MPC_SimX", "simU", "simREF", "simSolverDebug")}
