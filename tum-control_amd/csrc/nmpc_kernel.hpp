@@ -394,38 +394,55 @@ __global__ void __launch_bounds__(64, 1) nmpc_rti_kernel(const KArgs ka)
         }
         // ---- M = H + C' Gamma C, one 16x16 tile at a time (single accumulator live)
         {
+            // MFMA operands of the gg rows, fetched once: chunk c (rows 4c+1..4c+4) x tile column T, needed for c >= 2T
+            // (row s has 2s entries). chv = the row entries (B operand), the A operand is chv * gamma(row).
             double gch[10];
 #pragma unroll
             for (int c = 0; c < 10; c++) gch[c] = sGamH[(4 * c + lq < N) ? 4 * c + lq : 0] * ((4 * c + lq < N) ? 1.0 : 0.0);
+            double chv[10][NT];
+#pragma unroll
+            for (int T = 0; T < NT; T++)
+#pragma unroll
+                for (int c = 2 * T; c < 10; c++) {
+                    const int s = 4 * c + lq + 1;                     // <= 40 always
+                    const bool on = (16 * T + lc < 2 * s) && (s <= N);
+                    const double v = sCh[hoff(s) + (on ? 16 * T + lc : 0)];
+                    chv[c][T] = on ? v : 0.0;
+                }
             const double dt2 = dt * dt;
+            // steering-angle rows (structured): element (row, col), both odd, gets dt^2 * suffix(max(row, col)); in a tile
+            // right of the diagonal that is a function of the column only
+            double sfxo[NT];
+#pragma unroll
+            for (int I = 0; I < NT; I++) {
+                const int col = 16 * I + lc;
+                const double sf = sSfx[(col >> 1) + 1];
+                sfxo[I] = ((lq & 1) && (lc & 1) && col < nv) ? dt2 * sf : 0.0;
+            }
 #pragma unroll
             for (int K = 0; K < NT; K++)
 #pragma unroll
                 for (int I = K; I < NT; I++) {
                     d4 acc = Ht[tidx(K, I)];
-                    // steering-angle rows (structured), box rows and regularisation
+                    if (K == I) {
+                        // diagonal tile: steering rows, box rows and regularisation
 #pragma unroll
-                    for (int jj = 0; jj < 4; jj++) {
-                        const int row = 16 * K + lq + 4 * jj, col = 16 * I + lc;
-                        const int mx = (row > col) ? row : col;
-                        const double sf = sSfx[(mx >> 1) + 1];
-                        double add = ((row & 1) && (col & 1) && mx < nv) ? dt2 * sf : 0.0;
-                        if (K == I) {
+                        for (int jj = 0; jj < 4; jj++) {
+                            const int row = 16 * K + lq + 4 * jj, col = 16 * I + lc;
+                            const int mx = (row > col) ? row : col;
+                            const double sf = sSfx[(mx >> 1) + 1];
+                            double add = ((row & 1) && (col & 1) && mx < nv) ? dt2 * sf : 0.0;
                             const double wb = sWb[(row >> 1) < NMAX ? (row >> 1) : 0];
                             if (row == col) add += ka.reg + (((row & 1) && row < nv) ? wb : 0.0);
+                            acc[jj] += add;
                         }
-                        acc[jj] += add;
+                    } else {
+#pragma unroll
+                        for (int jj = 0; jj < 4; jj++) acc[jj] += sfxo[I];
                     }
                     // gg rows: SYRK over chunks of 4 rows (stages 4c+1 .. 4c+4); tile column I needs c >= 2I
 #pragma unroll
-                    for (int c = 2 * I; c < 10; c++) {
-                        const int s = 4 * c + lq + 1;                 // <= 40 always
-                        const int base = hoff(s);
-                        const bool ka_ = (16 * K + lc < 2 * s), kb_ = (16 * I + lc < 2 * s);
-                        const double av = sCh[base + (ka_ ? 16 * K + lc : 0)];
-                        const double bv = sCh[base + (kb_ ? 16 * I + lc : 0)];
-                        acc = mfma(ka_ ? av * gch[c] : 0.0, (kb_ && s <= N) ? bv : 0.0, acc);
-                    }
+                    for (int c = 2 * I; c < 10; c++) acc = mfma(chv[c][K] * gch[c], chv[c][I], acc);
                     // store as packed lower triangle: M[col_g][row_g] for col_g >= row_g
 #pragma unroll
                     for (int jj = 0; jj < 4; jj++) {
