@@ -16,6 +16,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <type_traits>
+
 namespace tum {
 
 typedef double d4 __attribute__((ext_vector_type(4)));
@@ -41,7 +43,10 @@ __host__ __device__ constexpr int hoff(int s) { return s * (s - 1); }
 // iterate) is aliased into those regions; the records are parked in HBM/L2 (KArgs::ws) while the IPM runs
 // and come back for the final expansion; the IPM row state lives in registers; the pivots d_j sit on the
 // diagonal of the (unit-lower) factor.
-constexpr int O_M = 0;                                // LPK                   KKT matrix / L D L' factor (d on the diagonal)
+constexpr int O_PEN = 0;                              // 36                    slack penalties [class][slot][zl,zu,Zl,Zu]
+//   (first on purpose: the diagonal-block substitution reads up to 15 doubles in front of a packed row with a zero
+//    multiplier; in front of row 0 that lands here, on finite data)
+constexpr int O_M = O_PEN + 36;                       // LPK                   KKT matrix / L D L' factor (d on the diagonal)
 //   aliased into the M region (dead before the first KKT assembly, reloaded after the last):
 constexpr int O_AB = O_M;                             //     NMAX*ABS    compact (Sp,S,b) per stage
 constexpr int O_STAGE = O_AB + NMAX * ABS;            //     4 x NVP     staging rows for the H SYRK
@@ -60,8 +65,8 @@ constexpr int O_SFX = O_WB + NMAX;                    // NMAX+2                s
 constexpr int O_XD = O_SFX;                           //   (before the IPM: steering angle of every stage of the iterate)
 constexpr int O_DV = O_SFX + NMAX + 2;                // NVP                   broadcast copy of a v-space vector
 constexpr int O_U0 = O_DV;                            //   (before the IPM: iterate U)
-constexpr int O_PEN = O_DV + NVP;                     // 36                    slack penalties [class][slot][zl,zu,Zl,Zu]
-constexpr int LDS_DOUBLES = O_PEN + 36;
+constexpr int O_DUMMY = O_DV + NVP;                   // 1                     target of masked-off stores
+constexpr int LDS_DOUBLES = O_DUMMY + 1;
 constexpr int LDS_BYTES = LDS_DOUBLES * 8;
 constexpr int WS_DOUBLES = NMAX * ABS;                // per-instance HBM workspace (parked linearisation records)
 static_assert(O_G + (NMAX + 1) * NX <= O_CH, "aliased condensing scratch must fit inside the KKT matrix region");
@@ -136,6 +141,15 @@ __device__ __forceinline__ double wave_sum(double v)
 {
     TUM_DPP_SCAN(op_add, 0.0)
     return rl(v, 63);
+}
+// value of lane l-K (row_shr) / l+K (row_shl) inside each row of 16 lanes, 0.0 where that lane is outside the row
+template <int K> __device__ __forceinline__ double row_shr(double v) { return dpp_f64<0x110 + K, 0xf>(0.0, v); }
+template <int K> __device__ __forceinline__ double row_shl(double v) { return dpp_f64<0x100 + K, 0xf>(0.0, v); }
+// compile-time loop: f(integral_constant<int, K>) for K = LO..HI
+template <int LO, int HI, typename F>
+__device__ __forceinline__ void static_for(F &&f)
+{
+    if constexpr (LO <= HI) { f(std::integral_constant<int, LO>()); static_for<LO + 1, HI>(f); }
 }
 // max of NON-NEGATIVE values (identity 0)
 __device__ __forceinline__ double wave_max(double v)

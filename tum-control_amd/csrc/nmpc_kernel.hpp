@@ -561,6 +561,37 @@ __global__ void __launch_bounds__(64, 1) nmpc_rti_kernel(const KArgs ka)
             for (int i = lane; i < LPK; i += 64) dbg[16540 + i] = sM[i];
         }
 
+        // ---- inverses of the unit-lower 16x16 diagonal blocks, in place (strict lower triangle of every diagonal block of
+        //      M now holds inv(L_JJ)): the substitutions below then treat 16 unknowns at a time. Lane = column c of its block:
+        //      X[r] = delta(r,c) - sum_{k<r} L[r][k] X[k]; entries above the diagonal stay 0, so no lane masks are needed.
+        {
+            auto inv_diag = [&](const int g, const bool own) {
+                const int gb = g & ~15, cl = g & 15;
+                double X[16];
+#pragma unroll
+                for (int k = 0; k < 16; k++) X[k] = (k == cl) ? 1.0 : 0.0;
+                int rowb = lpk(gb, gb);
+                int rows[16];
+#pragma unroll
+                for (int r = 1; r < 16; r++) {
+                    rowb += gb + r;                               // lpk(gb + r, gb)
+                    rows[r] = rowb;
+                    double a0 = 0.0, a1 = 0.0;
+#pragma unroll
+                    for (int k = 0; k < r; k++) {
+                        if (k & 1) a1 += sM[rowb + k] * X[k]; else a0 += sM[rowb + k] * X[k];
+                    }
+                    X[r] -= a0 + a1;
+                }
+                wsync();                                          // every lane has read its L entries
+#pragma unroll
+                for (int r = 1; r < 16; r++) sM[(own && r > cl) ? rows[r] + cl : (O_DUMMY - O_M)] = X[r];
+                wsync();
+            };
+            inv_diag(lane, true);
+            inv_diag(lane1, lane < 16);
+        }
+
         TUM_TICK(4);
         // ---- predictor / corrector
         double cross1[6], cross2[6];                 // dT*dL and dS*dMu of the affine step
@@ -599,77 +630,83 @@ __global__ void __launch_bounds__(64, 1) nmpc_rti_kernel(const KArgs ka)
                 if (lane < 16) dbg[19780 + 64 + lane] = b1;
             }
             TUM_TICK(5);
-            // Triangular solves in 4-wide micro-blocks: the 4 unknowns of a micro-block are broadcast with
-            // readlane and solved against the 4x4 unit-lower diagonal block on uniform values; then EVERY lane
-            // applies  b -= sum_j m_j y_j  with its (contiguous, prefetched) entries m_j of L masked by position
-            // (entry j is live iff it lies strictly below / left of the diagonal), which also leaves y_k in the
-            // block's own lanes -- no per-unknown write-back selects (a single wave is VALU-issue bound).
-            // forward: L y = b
-#pragma unroll 4
-            for (int c0 = 0; c0 < 64; c0 += 4) {
-                const int r1 = lpk(c0 + 1, c0), r2 = lpk(c0 + 2, c0), r3 = lpk(c0 + 3, c0);
-                const double l10 = sM[r1], l20 = sM[r2], l21 = sM[r2 + 1], l30 = sM[r3], l31 = sM[r3 + 1], l32 = sM[r3 + 2];
-                const int k4 = lane - c0;
-                const int o0 = myrow0 + c0;
-                const double m0 = (k4 > 0) ? sM[o0] : 0.0, m1 = (k4 > 1) ? sM[o0 + 1] : 0.0;
-                const double m2 = (k4 > 2) ? sM[o0 + 2] : 0.0, m3 = (k4 > 3) ? sM[o0 + 3] : 0.0;
-                const int o1 = myrow1 + c0;
-                const double n0 = sM[o1], n1 = sM[o1 + 1], n2 = sM[o1 + 2], n3 = sM[o1 + 3];
-                const double y0 = rl(b0, c0);
-                const double y1 = rl(b0, c0 + 1) - l10 * y0;
-                const double y2 = rl(b0, c0 + 2) - l20 * y0 - l21 * y1;
-                const double y3 = rl(b0, c0 + 3) - l30 * y0 - l31 * y1 - l32 * y2;
-                b0 = b0 - m0 * y0 - m1 * y1 - m2 * y2 - m3 * y3;
-                b1 = b1 - n0 * y0 - n1 * y1 - n2 * y2 - n3 * y3;
-            }
+            // Triangular solves, 16 unknowns at a time. Diagonal block: y_J = inv(L_JJ) b_J as a lane-local sum over the
+            // 15 lower neighbours inside the row of 16 lanes (DPP row shifts, zero fill outside the row, so neither masks
+            // nor a dependent chain); the same 15 coefficients per lane serve all four blocks of bank 0. Panel: the 16 new
+            // unknowns are broadcast through LDS and every row below (column left, for L') takes 16 FMAs.
+            {
+                const int dg0 = lpk(lane, lane), dg1 = lpk(lane1, lane1);
+                // ---- forward: L y = b
+                {
+                    double cf0[16], cf1[16];
+                    static_for<1, 15>([&](auto kc) { constexpr int k = decltype(kc)::value; cf0[k] = sM[dg0 - k]; cf1[k] = sM[dg1 - k]; });
+                    auto diag = [&](const double v, const double (&cf)[16]) {
+                        double a0 = v, a1 = 0.0;
+                        static_for<1, 15>([&](auto kc) {
+                            constexpr int k = decltype(kc)::value;
+                            const double t = row_shr<k>(v);
+                            if (k & 1) a1 += cf[k] * t; else a0 += cf[k] * t;
+                        });
+                        return a0 + a1;
+                    };
 #pragma unroll
-            for (int c0 = 64; c0 < NVP; c0 += 4) {
-                const int r1 = lpk(c0 + 1, c0), r2 = lpk(c0 + 2, c0), r3 = lpk(c0 + 3, c0);
-                const double l10 = sM[r1], l20 = sM[r2], l21 = sM[r2 + 1], l30 = sM[r3], l31 = sM[r3 + 1], l32 = sM[r3 + 2];
-                const int k4 = lane1 - c0;
-                const int o1 = myrow1 + c0;
-                const double n0 = (k4 > 0) ? sM[o1] : 0.0, n1 = (k4 > 1) ? sM[o1 + 1] : 0.0;
-                const double n2 = (k4 > 2) ? sM[o1 + 2] : 0.0, n3 = (k4 > 3) ? sM[o1 + 3] : 0.0;
-                const double y0 = rl(b1, c0 - 64);
-                const double y1 = rl(b1, c0 - 63) - l10 * y0;
-                const double y2 = rl(b1, c0 - 62) - l20 * y0 - l21 * y1;
-                const double y3 = rl(b1, c0 - 61) - l30 * y0 - l31 * y1 - l32 * y2;
-                b1 = b1 - n0 * y0 - n1 * y1 - n2 * y2 - n3 * y3;       // lanes >= 16 carry no rows (never read)
-            }
-            // z = D^-1 y
-            b0 *= invd0; b1 *= invd1;
-            // backward: L' x = z. Micro-block rows c0..c0+3 of L are contiguous in the packed layout.
+                    for (int J = 0; J < 4; J++) {
+                        const double y = diag(b0, cf0);
+                        b0 = (lq == J) ? y : b0;
+                        wsync();
+                        sDv[lane] = b0;
+                        wsync();
+                        double a0 = 0.0, a1 = 0.0, c0_ = 0.0, c1_ = 0.0;
 #pragma unroll
-            for (int c0 = NVP - 4; c0 >= 64; c0 -= 4) {
-                const int r1 = lpk(c0 + 1, 0), r2 = lpk(c0 + 2, 0), r3 = lpk(c0 + 3, 0), r0b = lpk(c0, 0);
-                const double l10 = sM[r1 + c0], l20 = sM[r2 + c0], l21 = sM[r2 + c0 + 1];
-                const double l30 = sM[r3 + c0], l31 = sM[r3 + c0 + 1], l32 = sM[r3 + c0 + 2];
-                // entries L[c0+j][col] for this lane's columns: bank 0 col = lane (always left of the block),
-                // bank 1 col = 64 + lane, live iff col < c0 + j
-                const double m0 = sM[r0b + lane], m1 = sM[r1 + lane], m2 = sM[r2 + lane], m3 = sM[r3 + lane];
-                const int k4 = lane1 - c0;
-                const double n0 = (k4 < 0) ? sM[r0b + lane1] : 0.0, n1 = (k4 < 1) ? sM[r1 + lane1] : 0.0;
-                const double n2 = (k4 < 2) ? sM[r2 + lane1] : 0.0, n3 = (k4 < 3) ? sM[r3 + lane1] : 0.0;
-                const double x3 = rl(b1, c0 - 61);
-                const double x2 = rl(b1, c0 - 62) - l32 * x3;
-                const double x1 = rl(b1, c0 - 63) - l21 * x2 - l31 * x3;
-                const double x0 = rl(b1, c0 - 64) - l10 * x1 - l20 * x2 - l30 * x3;
-                b0 = b0 - m3 * x3 - m2 * x2 - m1 * x1 - m0 * x0;
-                b1 = b1 - n3 * x3 - n2 * x2 - n1 * x1 - n0 * x0;
-            }
-#pragma unroll 4
-            for (int c0 = 60; c0 >= 0; c0 -= 4) {
-                const int r1 = lpk(c0 + 1, 0), r2 = lpk(c0 + 2, 0), r3 = lpk(c0 + 3, 0), r0b = lpk(c0, 0);
-                const double l10 = sM[r1 + c0], l20 = sM[r2 + c0], l21 = sM[r2 + c0 + 1];
-                const double l30 = sM[r3 + c0], l31 = sM[r3 + c0 + 1], l32 = sM[r3 + c0 + 2];
-                const int k4 = lane - c0;
-                const double m0 = (k4 < 0) ? sM[r0b + lane] : 0.0, m1 = (k4 < 1) ? sM[r1 + lane] : 0.0;
-                const double m2 = (k4 < 2) ? sM[r2 + lane] : 0.0, m3 = (k4 < 3) ? sM[r3 + lane] : 0.0;
-                const double x3 = rl(b0, c0 + 3);
-                const double x2 = rl(b0, c0 + 2) - l32 * x3;
-                const double x1 = rl(b0, c0 + 1) - l21 * x2 - l31 * x3;
-                const double x0 = rl(b0, c0) - l10 * x1 - l20 * x2 - l30 * x3;
-                b0 = b0 - m3 * x3 - m2 * x2 - m1 * x1 - m0 * x0;
+                        for (int c = 0; c < 16; c += 2) {
+                            const double y0 = sDv[16 * J + c], y1 = sDv[16 * J + c + 1];
+                            a0 += sM[myrow0 + 16 * J + c] * y0; a1 += sM[myrow0 + 16 * J + c + 1] * y1;
+                            c0_ += sM[myrow1 + 16 * J + c] * y0; c1_ += sM[myrow1 + 16 * J + c + 1] * y1;
+                        }
+                        b0 = (lq > J) ? b0 - (a0 + a1) : b0;
+                        b1 -= c0_ + c1_;
+                    }
+                    b1 = diag(b1, cf1);
+                }
+                // z = D^-1 y
+                b0 *= invd0; b1 *= invd1;
+                // ---- backward: L' x = z
+                {
+                    // x[c] = z[c] + sum_k inv(L_JJ)[c+k][c] z[c+k]
+                    double cb0[16], cb1[16];
+                    static_for<1, 15>([&](auto kc) {
+                        constexpr int k = decltype(kc)::value;
+                        cb0[k] = sM[lpk(lane + k, lane)];                                   // rows <= 78: always inside M
+                        cb1[k] = sM[(lc + k < 16) ? lpk(lane1 + k, lane1) : 0];
+                    });
+                    auto diagT = [&](const double v, const double (&cb)[16]) {
+                        double a0 = v, a1 = 0.0;
+                        static_for<1, 15>([&](auto kc) {
+                            constexpr int k = decltype(kc)::value;
+                            const double t = row_shl<k>(v);
+                            if (k & 1) a1 += cb[k] * t; else a0 += cb[k] * t;
+                        });
+                        return a0 + a1;
+                    };
+                    b1 = diagT(b1, cb1);
+                    b1 = (lane < 16) ? b1 : 0.0;
+#pragma unroll
+                    for (int J = 4; J >= 1; J--) {
+                        wsync();
+                        if (J == 4) { if (lane < 16) sDv[64 + lane] = b1; }
+                        else sDv[lane] = b0;
+                        wsync();
+                        double a0 = 0.0, a1 = 0.0;
+#pragma unroll
+                        for (int r = 0; r < 16; r += 2) {
+                            a0 += sM[lpk(16 * J + r, 0) + lane] * sDv[16 * J + r];
+                            a1 += sM[lpk(16 * J + r + 1, 0) + lane] * sDv[16 * J + r + 1];
+                        }
+                        b0 = (lq < J) ? b0 - (a0 + a1) : b0;
+                        const double x = diagT(b0, cb0);
+                        b0 = (lq == J - 1) ? x : b0;
+                    }
+                }
             }
             dv0 = b0; dv1 = b1;
             TUM_TICK(6);
