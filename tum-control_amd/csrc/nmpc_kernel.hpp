@@ -40,8 +40,8 @@ __device__ __forceinline__ int acados_status(int qp_status) { return (qp_status 
         double e0 = 0.0; \
     _Pragma("unroll 8") \
         for (int s = 1; s <= NMAX; s += 2) { \
-            const double c0 = sCh[hoff(s) + (s >= s00 ? lane : 0)]; \
-            const double c1 = sCh[hoff(s + 1) + (s + 1 >= s00 ? lane : 0)]; \
+            const double c0 = sCh[hoff(s) + lane]; \
+            const double c1 = sCh[hoff(s + 1) + lane]; \
             a0 += ((s >= s00 && s <= N) ? c0 : 0.0) * sWh[s - 1]; \
             e0 += ((s + 1 >= s00 && s + 1 <= N) ? c1 : 0.0) * sWh[s]; \
         } \
@@ -49,7 +49,7 @@ __device__ __forceinline__ int acados_status(int qp_status) { return (qp_status 
     _Pragma("unroll") \
         for (int s = 33; s <= NMAX; s++) { \
             const bool on = (lane < 16) && (lane1 < 2 * s) && (s <= N); \
-            const double c = sCh[hoff(s) + (lane1 < 2 * s ? lane1 : 0)]; \
+            const double c = sCh[hoff(s) + lane1]; \
             a1 += (on ? c : 0.0) * sWh[s - 1]; \
         } \
         o0 = v0on ? a0 : 0.0; o1 = v1on ? a1 : 0.0; \
@@ -447,7 +447,8 @@ __global__ void __launch_bounds__(64, 1) nmpc_rti_kernel(const KArgs ka)
 #pragma unroll
                     for (int jj = 0; jj < 4; jj++) {
                         const int rg = 16 * K + lq + 4 * jj, cg = 16 * I + lc;
-                        if (K < I || cg >= rg) sM[rb[I] + rg] = acc[jj];
+                        if (K < I) sM[rb[I] + rg] = acc[jj];
+                        else sM[(cg >= rg) ? rb[I] + rg : (O_DUMMY - O_M)] = acc[jj];
                     }
                 }
         }
@@ -731,7 +732,7 @@ __global__ void __launch_bounds__(64, 1) nmpc_rti_kernel(const KArgs ka)
 #pragma unroll 8
                 for (int c = 0; c < NVP; c += 2) {
                     const bool on = (c < 2 * s);
-                    const double x0_ = ch[on ? c : 0], x1_ = ch[on ? c + 1 : 0];
+                    const double x0_ = ch[c], x1_ = ch[c + 1];
                     a0 += (on ? x0_ : 0.0) * sDv[c];
                     a1 += (on ? x1_ : 0.0) * sDv[c + 1];
                 }
