@@ -395,4 +395,23 @@ __device__ __forceinline__ void apply_A(const double *rec, double w[8])
     for (int i = 0; i < 6; i++) w[i] = n[i];
 }
 
+// the same for two vectors at once (the two register banks of the condensing phase): every record entry is loaded once
+__device__ __forceinline__ void apply_A2(const double *rec, double w[8], double v[8])
+{
+    const double sp0 = rec[0], sp1 = rec[1];
+    double n[6], m[6];
+    n[0] = w[0] + sp0 * w[2]; m[0] = v[0] + sp0 * v[2];
+    n[1] = w[1] + sp1 * w[2]; m[1] = v[1] + sp1 * v[2];
+    n[2] = w[2]; m[2] = v[2];
+    n[3] = 0.0; n[4] = 0.0; n[5] = 0.0; m[3] = 0.0; m[4] = 0.0; m[5] = 0.0;
+#pragma unroll
+    for (int i = 0; i < 6; i++) {
+        const double *Si = rec + 2 + i * 7;
+#pragma unroll
+        for (int c = 0; c < 5; c++) { const double sv = Si[c]; n[i] += sv * w[3 + c]; m[i] += sv * v[3 + c]; }
+    }
+#pragma unroll
+    for (int i = 0; i < 6; i++) { w[i] = n[i]; v[i] = m[i]; }
+}
+
 }  // namespace tum

@@ -178,25 +178,21 @@ __global__ void __launch_bounds__(64, 1) nmpc_rti_kernel(const KArgs ka)
         auto stage_body = [&](const int k, auto tsc) {
             constexpr int Ts = decltype(tsc)::value;
             const double *rec = sAB + k * ABS;
-            // bank 0
-            if (j0 < k) apply_A(rec, w0);
-            else if (j0 == k) {
+            // Both banks advance together (shared record loads, no exec-mask regions): columns that have not started yet
+            // hold zeros, so w <- A_k w leaves them at zero; the column that starts at this stage adds B_k with a 0/1
+            // multiplier and the g column adds the defect b_k the same way.
+            apply_A2(rec, w0, w1);
+            {
+                const double sel0 = (j0 == k) ? 1.0 : 0.0, sel1 = (lane < 16 && j1 == k) ? 1.0 : 0.0, selg = isg ? 1.0 : 0.0;
 #pragma unroll
-                for (int i = 0; i < 6; i++) w0[i] = rec[2 + i * 7 + 5 + r0];
-                w0[6] = r0 ? dt : 0.0; w0[7] = r0 ? 0.0 : dt;
-            }
-            // bank 1 (columns 64.. only exist from stage 32 on; the g column runs from the start)
-            if (isg) {
-                apply_A(rec, w1);
-#pragma unroll
-                for (int i = 0; i < 8; i++) w1[i] += rec[44 + i];
-            } else if (lane < 16 && k >= 32) {
-                if (j1 < k) apply_A(rec, w1);
-                else if (j1 == k) {
-#pragma unroll
-                    for (int i = 0; i < 6; i++) w1[i] = rec[2 + i * 7 + 5 + r0];
-                    w1[6] = r0 ? dt : 0.0; w1[7] = r0 ? 0.0 : dt;
+                for (int i = 0; i < 6; i++) {
+                    const double bc = rec[2 + i * 7 + 5 + r0];
+                    w0[i] += sel0 * bc; w1[i] += sel1 * bc;
                 }
+                const double b6 = r0 ? dt : 0.0, b7 = r0 ? 0.0 : dt;
+                w0[6] += sel0 * b6; w0[7] += sel0 * b7; w1[6] += sel1 * b6; w1[7] += sel1 * b7;
+#pragma unroll
+                for (int i = 0; i < 8; i++) w1[i] += selg * rec[44 + i];
             }
             const int s = k + 1;                         // stage whose G_s the lanes now hold
             const double sc = (s < N) ? dt : 1.0;
