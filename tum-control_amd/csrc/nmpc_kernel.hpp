@@ -207,9 +207,10 @@ __global__ void __launch_bounds__(64, 1) nmpc_rti_kernel(const KArgs ka)
             if (lane < 2 * s) sCh[hoff(s) + lane] = g3 * w0[3] + g5 * w0[5] + g7 * w0[7];
             if (lane < 16 && 64 + lane < 2 * s) sCh[hoff(s) + 64 + lane] = g3 * w1[3] + g5 * w1[5] + g7 * w1[7];
 #pragma unroll
-            for (int r = 0; r < 4; r++) {
-                sStage[r * NVP + lane] = w0[r];
-                if (lane < 16) sStage[r * NVP + 64 + lane] = w1[r];
+            for (int r = 0; r < 4; r++) sStage[r * NVP + lane] = w0[r];
+            if (lane < 16) {
+#pragma unroll
+                for (int r = 0; r < 4; r++) sStage[r * NVP + 64 + lane] = w1[r];
             }
             wsync();
             // gradient: q += sum_r sc*W_r*(res_r + g_s[r]) * G_s[r,:]
@@ -224,7 +225,7 @@ __global__ void __launch_bounds__(64, 1) nmpc_rti_kernel(const KArgs ka)
                     a0 += e * w0[r]; a1 += e * w1[r];
                 }
                 q0 += a0;
-                if (lane < 16) q1 += a1;
+                q1 += (lane < 16) ? a1 : 0.0;
             }
             // Gauss-Newton Hessian SYRK (rank-4 update per stage) on the matrix cores
             const double wl = (lq == 0) ? wr[0] : (lq == 1) ? wr[1] : (lq == 2) ? wr[2] : wr[3];
