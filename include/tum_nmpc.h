@@ -161,9 +161,11 @@ void tum_sim_free(tum_sim *s);
 int tum_sim_set_state(tum_sim *s, const double *x_sim, const double *x_mpc, int cold_start);
 int tum_sim_plan(tum_sim *s);        /* yref of every instance from its pose (async on the capsule's stream) */
 int tum_sim_advance(tum_sim *s);     /* plant step with (x1[7], u0[1]) of the iterate, estimator -> next x0 (async) */
-int tum_sim_run(tum_sim *s, int nsteps);   /* nsteps x (plan, solve, advance), then synchronises */
+/* nsteps x (plan, solve, advance), then synchronises; chunks of 25 steps are captured once into a hipGraph and replayed
+ * (tum_sim_get "graph_steps" tells whether the capture succeeded) */
+int tum_sim_run(tum_sim *s, int nsteps);
 int tum_sim_steps(const tum_sim *s);
-/* field: "x_sim" (B*7), "x_mpc" (B*8), "pose" (B*2), "ref0" (B*4), "closest" (B); logs with the npz schema of
+/* field: "x_sim" (B*7), "x_mpc" (B*8), "pose" (B*2), "ref0" (B*4), "closest" (B), "graph_steps" (1); logs with the npz schema of
  * Utils/Logging_Plotting.py:357-372, step-major: "CiLX" ((steps+1)*B*7), "MPC_SimX" ((steps+1)*B*8), "simU" (steps*B*2),
  * "simREF" (steps*B*4), "simSolverDebug" (steps*B*5: cost, 0, sqp_iter, qp_iter, status). len must match. */
 int tum_sim_get(tum_sim *s, const char *field, double *out, long long len);

@@ -27,7 +27,7 @@ __device__ __forceinline__ double pymod_2pi(double x)
 // 2*pi seam (any step > 250 degrees) and wrapped back into [0, 2*pi).
 __global__ void __launch_bounds__(64) planner_kernel(const double *track, int n, const double *pose, int pose_stride, int npts, double Tp,
                                                      int loop_circuit, double *out, int out_stride, double *ref0, int *closest,
-                                                     int *err, int batch)
+                                                     int *err, int batch, int *step_counter)
 {
 #pragma clang fp contract(off)
     __shared__ double sYaw[PLAN_MAXM];
@@ -122,6 +122,9 @@ __global__ void __launch_bounds__(64) planner_kernel(const double *track, int n,
         }
     }
     if (lane == 0 && closest) closest[b] = i0;
+    // control-step counter of the closed loop (read by plant_advance_kernel of the same step): kept on the device so
+    // that a captured hipGraph of a step can be replayed without re-baking kernel arguments
+    if (b == 0 && lane == 0 && step_counter) atomicAdd(step_counter, 1);
 }
 
 // xdot of the 7-state plant [posx,posy,yaw,vlong,vlat,yawrate,delta_f] with inputs (a, steering rate)
@@ -164,7 +167,8 @@ __device__ __forceinline__ void plant_xdot(const PlantModel &p, const double x[7
 }
 
 struct SimArgs {
-    int N, batch, n_elem, step, log_cap;              // step = control steps done before this one
+    int N, batch, n_elem, log_cap;
+    const int *step_counter;                          // control steps started so far (this one included), device memory
     double Ts;
     int win[8];
     PlantModel pm;
@@ -183,6 +187,7 @@ __global__ void plant_advance_kernel(const SimArgs sa)
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= sa.batch) return;
     const int N = sa.N, B = sa.batch;
+    const int step = *sa.step_counter - 1;            // control steps done before this one
     const double *x1 = sa.X + ((size_t)b * (N + 1) + 1) * NX;
     const double *u0 = sa.U + (size_t)b * N * NU;
     const double a_in = x1[7], sr_in = u0[1];
@@ -203,7 +208,7 @@ __global__ void plant_advance_kernel(const SimArgs sa)
     for (int i = 0; i < 7; i++) sa.x_sim[(size_t)b * 7 + i] = x[i];
     sa.pose[(size_t)b * 2] = x[0]; sa.pose[(size_t)b * 2 + 1] = x[1];
     // state estimation: sample number k (1-based) goes to ring slot (k-1) & 3
-    const int k = sa.step + 1;
+    const int k = step + 1;
     for (int i = 0; i < 8; i++) {
         const double v = (i < 7) ? x[i] : a_in;
         double *hst = sa.hist + ((size_t)b * 8 + i) * 4;
@@ -213,8 +218,8 @@ __global__ void plant_advance_kernel(const SimArgs sa)
         for (int t = k - cnt + 1; t < k; t++) s = s + hst[t & 3];
         sa.x0[(size_t)b * NX + i] = s / (double)cnt;
     }
-    if (sa.lCiLX && sa.step < sa.log_cap) {
-        const size_t s = sa.step;
+    if (sa.lCiLX && step < sa.log_cap) {
+        const size_t s = step;
         for (int i = 0; i < 7; i++) sa.lCiLX[((s + 1) * B + b) * 7 + i] = x[i];
         for (int i = 0; i < 8; i++) sa.lSimX[((s + 1) * B + b) * 8 + i] = x1[i];
         sa.lU[(s * B + b) * 2] = u0[0]; sa.lU[(s * B + b) * 2 + 1] = u0[1];

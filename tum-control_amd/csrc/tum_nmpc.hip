@@ -291,14 +291,14 @@ extern "C" int tum_ocp_cost_set(tum_ocp *c, int stage, const char *field, const 
     return 0;
 }
 
-static int launch(tum_ocp *c)
+static int launch(tum_ocp *c, bool events = true)
 {
     HIPCHK(hipSetDevice(c->d.device));
-    HIPCHK(hipEventRecord(c->ev0, c->stream));
+    if (events) HIPCHK(hipEventRecord(c->ev0, c->stream));
     if (c->ka.flags & 4) hipLaunchKernelGGL(nmpc_rti_kernel<true>, dim3(c->batch), dim3(64), LDS_BYTES, c->stream, c->ka);
     else hipLaunchKernelGGL(nmpc_rti_kernel<false>, dim3(c->batch), dim3(64), LDS_BYTES, c->stream, c->ka);
     HIPCHK(hipGetLastError());
-    HIPCHK(hipEventRecord(c->ev1, c->stream));
+    if (events) HIPCHK(hipEventRecord(c->ev1, c->stream));
     c->solved = true;
     return 0;
 }
@@ -535,7 +535,8 @@ struct tum_sim {
     double Tp, Ts;
     int win[8];
     double *dtrack, *dxsim, *dpose, *dhist, *dref0;
-    int *dclosest, *derr;
+    int *dclosest, *derr, *dstep;
+    hipGraphExec_t graph; int graph_steps;            // captured chunk of control steps (tum_sim_run)
     double *lCiLX, *lSimX, *lU, *lREF, *lDBG;
 };
 
@@ -557,7 +558,7 @@ extern "C" int tum_planner_emulate(const double *track, int n_track, const doubl
     HIPCHK(hipMemcpy(dt, track, sizeof(double) * 4 * n_track, hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(dp, pose, sizeof(double) * 2 * P, hipMemcpyHostToDevice));
     hipLaunchKernelGGL(planner_kernel, dim3(P), dim3(64), 0, 0, dt, n_track, dp, 2, n_points, Tp, loop_circuit, dout, 4,
-                       (double *)nullptr, dcl, derr, P);
+                       (double *)nullptr, dcl, derr, P, (int *)nullptr);
     HIPCHK(hipGetLastError());
     HIPCHK(hipDeviceSynchronize());
     int err = 0;
@@ -573,7 +574,8 @@ extern "C" void tum_sim_free(tum_sim *s)
 {
     if (!s) return;
     (void)hipFree(s->dtrack); (void)hipFree(s->dxsim); (void)hipFree(s->dpose); (void)hipFree(s->dhist); (void)hipFree(s->dref0);
-    (void)hipFree(s->dclosest); (void)hipFree(s->derr);
+    (void)hipFree(s->dclosest); (void)hipFree(s->derr); (void)hipFree(s->dstep);
+    if (s->graph) (void)hipGraphExecDestroy(s->graph);
     (void)hipFree(s->lCiLX); (void)hipFree(s->lSimX); (void)hipFree(s->lU); (void)hipFree(s->lREF); (void)hipFree(s->lDBG);
     delete s;
 }
@@ -593,7 +595,7 @@ extern "C" tum_sim *tum_sim_create(tum_ocp *c, const double *track, int n_track,
     bool ok = true;
     ok &= dalloc(&s->dtrack, (size_t)4 * n_track) == hipSuccess;
     ok &= dalloc(&s->dxsim, B * 7) == hipSuccess && dalloc(&s->dpose, B * 2) == hipSuccess && dalloc(&s->dhist, B * 32) == hipSuccess;
-    ok &= dalloc(&s->dref0, B * 4) == hipSuccess && dalloc(&s->dclosest, B) == hipSuccess && dalloc(&s->derr, (size_t)1) == hipSuccess;
+    ok &= dalloc(&s->dref0, B * 4) == hipSuccess && dalloc(&s->dclosest, B) == hipSuccess && dalloc(&s->derr, (size_t)1) == hipSuccess && dalloc(&s->dstep, (size_t)1) == hipSuccess;
     if (L > 0) {
         ok &= dalloc(&s->lCiLX, (L + 1) * B * 7) == hipSuccess && dalloc(&s->lSimX, (L + 1) * B * 8) == hipSuccess;
         ok &= dalloc(&s->lU, L * B * 2) == hipSuccess && dalloc(&s->lREF, L * B * 4) == hipSuccess && dalloc(&s->lDBG, L * B * 5) == hipSuccess;
@@ -614,6 +616,7 @@ extern "C" int tum_sim_set_state(tum_sim *s, const double *x_sim, const double *
     HIPCHK(hipMemcpy(c->dx0, x_mpc, sizeof(double) * B * 8, hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy2D(s->dpose, 2 * 8, x_mpc, 8 * 8, 2 * 8, B, hipMemcpyHostToDevice));
     HIPCHK(hipMemset(s->dhist, 0, sizeof(double) * B * 32));
+    HIPCHK(hipMemset(s->dstep, 0, sizeof(int)));
     s->step = 0;
     if (s->log_cap > 0) {
         HIPCHK(hipMemcpy(s->lCiLX, x_sim, sizeof(double) * B * 7, hipMemcpyHostToDevice));
@@ -628,7 +631,7 @@ extern "C" int tum_sim_plan(tum_sim *s)
     if (!s) return fail("null argument");
     tum_ocp *c = s->c;
     hipLaunchKernelGGL(planner_kernel, dim3(c->batch), dim3(64), 0, c->stream, s->dtrack, s->n_track, s->dpose, 2, c->N + 1, s->Tp,
-                       s->loop_circuit, c->dyref, 6, s->dref0, s->dclosest, s->derr, c->batch);
+                       s->loop_circuit, c->dyref, 6, s->dref0, s->dclosest, s->derr, c->batch, s->dstep);
     HIPCHK(hipGetLastError());
     return 0;
 }
@@ -640,7 +643,7 @@ extern "C" int tum_sim_advance(tum_sim *s)
     if (!c->solved) return fail("sim_advance: no solve yet");
     SimArgs sa;
     memset(&sa, 0, sizeof(sa));
-    sa.N = c->N; sa.batch = c->batch; sa.n_elem = s->n_elem; sa.step = s->step; sa.log_cap = s->log_cap; sa.Ts = s->Ts;
+    sa.N = c->N; sa.batch = c->batch; sa.n_elem = s->n_elem; sa.step_counter = s->dstep; sa.log_cap = s->log_cap; sa.Ts = s->Ts;
     for (int i = 0; i < 8; i++) sa.win[i] = s->win[i];
     const tum_ocp_desc &d = c->d;
     PlantModel &p = sa.pm;
@@ -656,16 +659,48 @@ extern "C" int tum_sim_advance(tum_sim *s)
     return 0;
 }
 
-// nsteps x (planner, SQP-RTI solve, plant + estimator), enqueued back to back on the capsule's stream; returns after the last one
+// nsteps x (planner, SQP-RTI solve, plant + estimator) on the capsule's stream; returns after the last one. The loop is
+// launch-bound for small batches (3 short kernels per control step), so chunks of GRAPH_STEPS steps are captured once into
+// a hipGraph and replayed; all per-step state (step counter, ring buffers, logs) lives in device memory, so the captured
+// kernel arguments never change.
+static const int GRAPH_STEPS = 25;
+static int sim_enqueue_step(tum_sim *s, bool events)
+{
+    if (tum_sim_plan(s)) return 1;
+    if (launch(s->c, events)) return 1;
+    return tum_sim_advance(s);
+}
+
 extern "C" int tum_sim_run(tum_sim *s, int nsteps)
 {
     if (!s || nsteps < 0) return fail("bad argument");
-    for (int i = 0; i < nsteps; i++) {
-        if (tum_sim_plan(s)) return 1;
-        if (launch(s->c)) return 1;
-        if (tum_sim_advance(s)) return 1;
+    tum_ocp *c = s->c;
+    HIPCHK(hipSetDevice(c->d.device));
+    int done = 0;
+    if (nsteps >= 2 * GRAPH_STEPS) {
+        if (!s->graph) {
+            hipGraph_t g = nullptr;
+            const int step0 = s->step;
+            bool ok = hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal) == hipSuccess;
+            if (ok) {
+                c->solved = true;                                      // the captured solve precedes every captured advance
+                for (int i = 0; i < GRAPH_STEPS && ok; i++) ok = sim_enqueue_step(s, false) == 0;
+                ok = (hipStreamEndCapture(c->stream, &g) == hipSuccess) && ok;
+                s->step = step0;                                       // nothing ran yet
+            }
+            if (ok && g) ok = hipGraphInstantiate(&s->graph, g, nullptr, nullptr, 0) == hipSuccess;
+            if (g) (void)hipGraphDestroy(g);
+            if (!ok) { s->graph = nullptr; (void)hipGetLastError(); }  // fall back to plain launches
+            s->graph_steps = GRAPH_STEPS;
+        }
+        while (s->graph && nsteps - done >= s->graph_steps) {
+            HIPCHK(hipGraphLaunch(s->graph, c->stream));
+            done += s->graph_steps; s->step += s->graph_steps;
+        }
     }
-    HIPCHK(hipStreamSynchronize(s->c->stream));
+    for (; done < nsteps; done++)
+        if (sim_enqueue_step(s, true)) return 1;
+    HIPCHK(hipStreamSynchronize(c->stream));
     int err = 0;
     HIPCHK(hipMemcpy(&err, s->derr, sizeof(int), hipMemcpyDeviceToHost));
     if (err) return fail("sim_run: planner segment longer than PLAN_MAXM points");
@@ -686,6 +721,11 @@ extern "C" int tum_sim_get(tum_sim *s, const char *field, double *out, long long
     else if (f == "x_mpc") { src = c->dx0; want = B * 8; }
     else if (f == "pose") { src = s->dpose; want = B * 2; }
     else if (f == "ref0") { src = s->dref0; want = B * 4; }
+    else if (f == "graph_steps") {         // control steps per captured hipGraph chunk (0: plain launches)
+        if (len != 1) return fail("sim_get graph_steps: len != 1");
+        out[0] = s->graph ? s->graph_steps : 0;
+        return 0;
+    }
     else if (f == "closest") {
         if (len != B) return fail("sim_get closest: len != batch");
         std::vector<int> t(B);

@@ -450,5 +450,11 @@ class DeviceClosedLoop:
         self._chk(self._L.tum_sim_get(self._s, field.encode(), _dp(out), out.size), "sim_get " + field)
         return out[:, 0].astype(np.int64) if field == "closest" else out
 
+    @property
+    def graph_steps(self):
+        out = np.zeros(1)
+        self._chk(self._L.tum_sim_get(self._s, b"graph_steps", _dp(out), 1), "sim_get graph_steps")
+        return int(out[0])
+
     def logs(self):
         return {k: self.get(k) for k in ("CiLX", "MPC_SimX", "simU", "simREF", "simSolverDebug")}
