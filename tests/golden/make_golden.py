@@ -13,6 +13,7 @@ DATA (inputs + expected outputs), never reference source:
   pce.npz             alphaGeneration / polyChaosExpansion / compute_x0dist / sigma points of acados_ocp_SNMPC.json
   r2.npz              P_propagation input/output pairs
   closed_loop_<t>_<n>.npz   first n steps of the 26 logged closed loops of one track (plant states, inputs, predictions)
+  closed_loop_<t>_full_sub<k>.npz   the complete 5499-step loops, every k-th plant state + per-loop statistics
 
 Reference call sites reproduced by the replay protocol:
   get_baseline_performances.py:101-131 (loop), Utils/SimulationMode_main_class.py:106-156
@@ -120,6 +121,20 @@ def make_closed_loop(track="monteblanco", nsteps=150):
                         CiLX=np.array(C, dtype=np.float64), MPC_SimX=np.array(S), simU=np.array(U))
 
 
+def make_closed_loop_full(track="monteblanco", sub=25):
+    """The complete logged closed loops (5499 control steps, 26 weight sets), subsampled: plant state every `sub` steps,
+    the inputs at those steps, and per-loop statistics of the solver (mean / max QP iterations, worst status, lap cost)."""
+    C, U, st = [], [], []
+    for k in range(26):
+        d = np.load(os.path.join(BASE, track, f"{k}.npz"))
+        C.append(d["CiLX"][::sub]); U.append(d["simU"][::sub])
+        dbg = d["simSolverDebug"]
+        st.append([dbg[:, 3].mean(), dbg[:, 3].max(), dbg[:, 4].max(), dbg[:, 0].mean(),
+                   np.abs(d["dev_lat"]).max(), np.abs(d["dev_vel"]).max()])
+    np.savez_compressed(os.path.join(OUT, f"closed_loop_{track}_full_sub{sub}.npz"), params=F, sub=sub,
+                        CiLX=np.array(C), simU=np.array(U), stats=np.array(st))
+
+
 def make_planner():
     rng = np.random.default_rng(7)
     out = {}
@@ -184,4 +199,5 @@ if __name__ == "__main__":
         make_r2()
     if "closed_loop" in what:
         make_closed_loop()
+        make_closed_loop_full()
     print("golden fixtures written to", OUT)
