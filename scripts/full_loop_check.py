@@ -2,9 +2,10 @@ import sys, numpy as np, time
 sys.path.insert(0,'/root/repo')
 import torch
 from tum_control_amd.closed_loop import ClosedLoopBatch
-g=np.load('/root/repo/tests/golden/closed_loop_monteblanco_full_sub25.npz')
+track=sys.argv[1] if len(sys.argv)>1 else 'monteblanco'
+g=np.load(f'/root/repo/tests/golden/closed_loop_{track}_full_sub25.npz')
 P=g['params']; sub=int(g['sub']); n=5499
-cl=ClosedLoopBatch("monteblanco", batch=26, params=P, on_device=True, log_capacity=n)
+cl=ClosedLoopBatch(track, batch=26, params=P, on_device=True, log_capacity=n)
 t0=time.perf_counter(); lg=cl.run(n); print('wall',time.perf_counter()-t0)
 C=lg['CiLX'].transpose(1,0,2)[:, ::sub]; U=lg['simU'].transpose(1,0,2)[:, ::sub]
 dbg=lg['simSolverDebug']

@@ -199,5 +199,6 @@ if __name__ == "__main__":
         make_r2()
     if "closed_loop" in what:
         make_closed_loop()
-        make_closed_loop_full()
+        make_closed_loop_full("monteblanco")
+        make_closed_loop_full("lvms")
     print("golden fixtures written to", OUT)
