@@ -95,3 +95,40 @@ def test_model_structure():
     np.testing.assert_allclose(A[7], np.eye(8)[7], atol=1e-15)
     np.testing.assert_allclose(B[6], [0, 0.08], atol=1e-15)
     np.testing.assert_allclose(B[7], [0.08, 0], atol=1e-15)
+
+
+@pytest.mark.parametrize("track,k", [("monteblanco", 0), ("lvms", 7)])
+def test_oracle_closed_loop_full_length(golden_dir, track, k):
+    """The oracle in a CLOSED loop (planner -> oracle solve -> plant -> moving-average estimator, all on the host) for the
+    complete 5499 logged control steps of one weight set per track, against every 25th logged plant state: pins the oracle
+    together with the planner / plant / estimator restatements over a whole lap and a half (SURVEY 8(c) KAT-replay)."""
+    from tum_control_amd import config
+    from tum_control_amd.closed_loop import plant_step, MovingAverageEstimator
+    from tum_control_amd.planner import load_track, planner_emulator
+    g = np.load(os.path.join(golden_dir, f"closed_loop_{track}_full_sub25.npz"))
+    sub, n = int(g["sub"]), 5499
+    cfg = config.default_config()
+    tr = load_track(track)
+    o = OracleOcp(38, 0.08, 3)
+    o.set_weights(*g["params"][k])
+    x_mpc = np.array([tr[0, 0], tr[0, 1], np.mod(tr[0, 2], 2 * np.pi), tr[0, 3], 0, 0, 0, 0.0])
+    x_sim = x_mpc[None, :7].copy()
+    pose = x_mpc[:2].copy()
+    est = MovingAverageEstimator(1)
+    o.cold_start(x_mpc)
+    C = [x_sim[0].copy()]
+    for i in range(n):
+        _, ref = planner_emulator(tr, pose, 39, 3.04, True)
+        o.set_yref(ref[:, 0], ref[:, 1], ref[:, 2], ref[:, 3])
+        assert o.solve() == 0
+        x_sim = plant_step(x_sim, np.array([o.X[1][7]]), np.array([o.U[0][1]]), cfg)
+        pose = x_sim[0, :2].copy()
+        o.x0[:] = est(np.concatenate([x_sim, [[o.X[1][7]]]], axis=1))[0]
+        if (i + 1) % sub == 0:
+            C.append(x_sim[0].copy())
+    C = np.array(C)
+    ref_c = g["CiLX"][k][:len(C)]
+    ep = np.hypot(C[:, 0] - ref_c[:, 0], C[:, 1] - ref_c[:, 1])
+    # observed: median 1.7e-8 m, max 2.7e-6 m (monteblanco/0), 3.3e-7 m (lvms/7) over 110 s of driving
+    assert np.median(ep) < 1e-6 and ep.max() < 1e-4, (np.median(ep), ep.max())
+    assert np.abs(C[:, 3] - ref_c[:, 3]).max() < 1e-4
