@@ -280,6 +280,7 @@ static void chol_solve(int n, const double *L, int ld, double *b)
  * (what HPIPM's dense IPM does after removing the soft-constraint slacks).
  * Side index: 0 = lower, 1 = upper; arrays are [2*m] with side-major layout.
  */
+#define IPM_SO_ALPHA_MIN 0.1    /* second-order correction only if the affine step length reaches this */
 static void qp_ipm(int nv, int m, const double *H, const double *q, const double *C, const double *d,
                    const double *lb, const double *ub,
                    const double *zl, const double *zu, const double *Zl, const double *Zu,
@@ -369,7 +370,7 @@ static void qp_ipm(int nv, int m, const double *H, const double *q, const double
         }
         if (chol_lower(nv, Mx, nv)) { status = 3; break; }
 
-        double sigma = 0.0, mu_aff = 0.0, alpha = 1.0;
+        double sigma = 0.0, mu_aff = 0.0, alpha = 1.0, so = 1.0;
         for (int pass = 0; pass < 2; pass++) {
             /* complementarity residuals: predictor (tau = 0) then corrector */
             for (int k = 0; k < M2; k++) {
@@ -379,8 +380,8 @@ static void qp_ipm(int nv, int m, const double *H, const double *q, const double
                      * collapsing to 0 (which would blow up gamma = lam/t and the conditioning of M) */
                     double tau = sigma * gap;
                     if (tau < 0.1 * opt->tol_comp) tau = 0.1 * opt->tol_comp;
-                    rc1[k] = t[k] * lam[k] + dt[k] * dlam[k] - tau;
-                    rc2[k] = s[k] * mu[k] + ds[k] * dmu[k] - tau;
+                    rc1[k] = t[k] * lam[k] + so * dt[k] * dlam[k] - tau;
+                    rc2[k] = s[k] * mu[k] + so * ds[k] * dmu[k] - tau;
                 }
                 double Ds = Z[k] + mu[k] / s[k];
                 rho[k] = -rt[k] + rc1[k] / lam[k] - (rs[k] + rc2[k] / s[k]) / Ds;
@@ -399,6 +400,7 @@ static void qp_ipm(int nv, int m, const double *H, const double *q, const double
                 cdv[i] = acc;
             }
             double amax = 1.0;
+            int blk = -1, blkw = 0;
             for (int k = 0; k < M2; k++) {
                 int i = k % m;
                 double Ds = Z[k] + mu[k] / s[k];
@@ -406,10 +408,18 @@ static void qp_ipm(int nv, int m, const double *H, const double *q, const double
                 ds[k] = (dlam[k] - rs[k] - rc2[k] / s[k]) / Ds;
                 dmu[k] = (-rc2[k] - mu[k] * ds[k]) / s[k];
                 dt[k] = (-rc1[k] - t[k] * dlam[k]) / lam[k];
-                if (dt[k] < 0.0 && -t[k] / dt[k] < amax) amax = -t[k] / dt[k];
-                if (ds[k] < 0.0 && -s[k] / ds[k] < amax) amax = -s[k] / ds[k];
-                if (dlam[k] < 0.0 && -lam[k] / dlam[k] < amax) amax = -lam[k] / dlam[k];
-                if (dmu[k] < 0.0 && -mu[k] / dmu[k] < amax) amax = -mu[k] / dmu[k];
+                if (dt[k] < 0.0 && -t[k] / dt[k] < amax) { amax = -t[k] / dt[k]; blk = k; blkw = 0; }
+                if (ds[k] < 0.0 && -s[k] / ds[k] < amax) { amax = -s[k] / ds[k]; blk = k; blkw = 1; }
+                if (dlam[k] < 0.0 && -lam[k] / dlam[k] < amax) { amax = -lam[k] / dlam[k]; blk = k; blkw = 2; }
+                if (dmu[k] < 0.0 && -mu[k] / dmu[k] < amax) { amax = -mu[k] / dmu[k]; blk = k; blkw = 3; }
+            }
+            if (getenv("TUM_ORACLE_TRACE") && getenv("TUM_ORACLE_TRACE")[0] == '2') {
+                int kx = 0; double px = 0; int which = 0;
+                for (int k = 0; k < M2; k++) { if (t[k] * lam[k] > px) { px = t[k] * lam[k]; kx = k; which = 0; } if (s[k] * mu[k] > px) { px = s[k] * mu[k]; kx = k; which = 1; } }
+                fprintf(stderr, "   pass %d amax %.4f blocked by k=%d (row %d side %d) var %d: t %.3e s %.3e lam %.3e mu %.3e | dt %.3e ds %.3e dlam %.3e dmu %.3e || max product k=%d (row %d side %d) %s: t %.3e s %.3e lam %.3e mu %.3e dt %.3e ds %.3e dlam %.3e dmu %.3e Z %.3e z %.3e\n",
+                        pass, amax, blk, blk < 0 ? -1 : blk % m, blk < 0 ? -1 : blk / m, blkw, blk < 0 ? 0 : t[blk], blk < 0 ? 0 : s[blk], blk < 0 ? 0 : lam[blk], blk < 0 ? 0 : mu[blk],
+                        blk < 0 ? 0 : dt[blk], blk < 0 ? 0 : ds[blk], blk < 0 ? 0 : dlam[blk], blk < 0 ? 0 : dmu[blk],
+                        kx, kx % m, kx / m, which ? "s*mu" : "t*lam", t[kx], s[kx], lam[kx], mu[kx], dt[kx], ds[kx], dlam[kx], dmu[kx], Z[kx], z[kx]);
             }
             if (pass == 0) {
                 mu_aff = 0.0;
@@ -418,10 +428,18 @@ static void qp_ipm(int nv, int m, const double *H, const double *q, const double
                 mu_aff /= (2.0 * M2);
                 double ratio = mu_aff / gap;
                 sigma = ratio * ratio * ratio;
+                /* Safeguard: when the affine step is blocked almost immediately (a badly centred soft-constraint pair at
+                 * the kink of its L1 penalty), its second-order terms are a wild extrapolation and the corrector can cycle
+                 * between the two sides of the kink for all 50 iterations (seen on 7 of 286 000 logged closed-loop solves;
+                 * acados' own logs show iteration-cap hits in the same loops). Drop them for this iteration: the step becomes
+                 * a plain centring step and the next iteration proceeds normally. */
+                so = (amax < IPM_SO_ALPHA_MIN) ? 0.0 : 1.0;
             } else {
                 alpha = 0.995 * amax; if (amax >= 1.0) alpha = 1.0; if (alpha > 1.0) alpha = 1.0;
             }
         }
+        if (getenv("TUM_ORACLE_TRACE"))
+            fprintf(stderr, "ipm it %2d stat %.2e ineq %.2e comp %.2e gap %.2e sigma %.2e alpha %.4f\n", it, res_stat, res_ineq, res_comp, gap, sigma, alpha);
         if (alpha < 1e-12) { status = 2; break; }
         for (int j = 0; j < nv; j++) v[j] += alpha * dv[j];
         for (int k = 0; k < M2; k++) {

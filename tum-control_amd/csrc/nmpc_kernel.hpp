@@ -771,6 +771,13 @@ __global__ void __launch_bounds__(64, 1) nmpc_rti_kernel(const KArgs ka)
                 const double mu_aff = wave_sum(rowlane ? lmu : 0.0) * inv_npairs;
                 const double ratio = mu_aff * frcp(gap);
                 sigma = ratio * ratio * ratio;
+                // safeguard (same rule as the oracle): an affine step blocked almost immediately makes the second-order
+                // terms a wild extrapolation (a soft-constraint pair at the kink of its L1 penalty can then cycle for all
+                // 50 iterations); drop them for this iteration
+                if (amax < 0.1) {
+#pragma unroll
+                    for (int k = 0; k < 6; k++) { cross1[k] = 0.0; cross2[k] = 0.0; }
+                }
             } else {
                 alpha = (amax >= 1.0) ? 1.0 : 0.995 * amax;
                 if (alpha >= 1e-12) {
