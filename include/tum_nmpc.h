@@ -119,6 +119,11 @@ int tum_ocp_get_device(tum_ocp *c, const char *field, void *dev_dst, int b0, int
 /* cold start every instance on the device: X_k = x0 for all k, U = 0 (acados create / reset + set x;
  * NMPC_class.py:250-254) using the x0 already uploaded with constraints_set(0,"lbx"). */
 int tum_ocp_cold_start(tum_ocp *c);
+/* Scheduling of the instances onto wavefronts (no reference counterpart). longest_first = 1 (default): workgroup i solves
+ * the instance with the i-th largest IPM iteration count of the PREVIOUS solve, so the few long instances of a batch start
+ * first instead of leaving the GPU idle at the end (a batch is only a few rounds of resident wavefronts); 0: natural order.
+ * Results do not depend on the schedule. Environment override at create time: TUM_NMPC_SCHEDULE=natural. */
+int tum_ocp_set_schedule(tum_ocp *c, int longest_first);
 /* last kernel launch time in milliseconds (HIP events on the launch stream) */
 double tum_ocp_last_kernel_ms(tum_ocp *c);
 /* debug: dump of condensed-QP intermediates of instance b (see csrc/nmpc_kernel.hip) */

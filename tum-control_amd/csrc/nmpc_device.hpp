@@ -97,6 +97,7 @@ struct KArgs {
     int dbg_stride;
     long long *prof;                                  // [b][12] phase cycle counters (flags&4)
     double *ws;                                       // [b][WS_DOUBLES] linearisation records parked during the IPM
+    const int *order;                                 // [batch] workgroup -> instance map (longest-first schedule) or null
 };
 
 // ---------------------------------------------------------------- wave helpers

@@ -71,8 +71,8 @@ __global__ void __launch_bounds__(64, 1) nmpc_rti_kernel(const KArgs ka)
 {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     const int lane = threadIdx.x;
-    const int b = blockIdx.x;
-    if (b >= ka.batch) return;
+    if ((int)blockIdx.x >= ka.batch) return;
+    const int b = ka.order ? ka.order[blockIdx.x] : (int)blockIdx.x;     // instance solved by this wavefront
     const int N = ka.N, nv = 2 * N;
     const double dt = ka.dt;
     const Model &mp = ka.mp;
@@ -902,6 +902,25 @@ __global__ void __launch_bounds__(64, 1) nmpc_rti_kernel(const KArgs ka)
         ka.qp_status[b] = qp_status;
         ka.res[b * 3 + 0] = res_stat; ka.res[b * 3 + 1] = res_ineq; ka.res[b * 3 + 2] = res_comp;
     }
+}
+
+// Longest-first schedule for the NEXT solve: workgroup i gets the instance with the i-th largest iteration count of THIS
+// solve (counting sort, one workgroup). A batch is only a few rounds of resident wavefronts (4096 instances = 4 rounds of
+// 1024), and the time of an instance is proportional to its iteration count (4..15), so in natural order the last round
+// leaves most of the GPU idle while a few long instances finish: measured 2.62 ms natural order, 2.17 ms longest-first,
+// 2.34 ms shortest-first for the same 4096 instances. Iteration counts of consecutive solves of an MPC are strongly
+// correlated (and identical for a repeated batch), which makes the last solve a good predictor.
+__global__ void __launch_bounds__(1024) lpt_order_kernel(const int *qp_iter, int *order, int batch)
+{
+    __shared__ int hist[64], offs[64];
+    const int t = threadIdx.x;
+    if (t < 64) hist[t] = 0;
+    __syncthreads();
+    for (int i = t; i < batch; i += 1024) { int k = qp_iter[i]; k = k < 0 ? 0 : (k > 63 ? 63 : k); atomicAdd(&hist[k], 1); }
+    __syncthreads();
+    if (t == 0) { int acc = 0; for (int k = 63; k >= 0; k--) { offs[k] = acc; acc += hist[k]; } }
+    __syncthreads();
+    for (int i = t; i < batch; i += 1024) { int k = qp_iter[i]; k = k < 0 ? 0 : (k > 63 ? 63 : k); order[atomicAdd(&offs[k], 1)] = i; }
 }
 
 // cold start on the device: X_k = x0, U = 0 (acados create / reset + set(i,'x',x0); NMPC_class.py:250-254)

@@ -4,6 +4,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -26,7 +27,8 @@ struct tum_ocp {
     hipEvent_t ev0, ev1;
     KArgs ka;
     double *dX, *dU, *dx0, *dyref, *dW, *dpen, *dbnd, *dcost, *dres, *dslack, *dqpin, *ddbg;
-    int *dstatus, *dqpiter, *dqpstatus;
+    int *dstatus, *dqpiter, *dqpstatus, *dorder;
+    bool lpt, order_valid;
     long long *dprof;
     double *dws;
     float last_ms;
@@ -73,6 +75,14 @@ extern "C" tum_ocp *tum_ocp_create(const tum_ocp_desc *desc)
     ok &= dalloc(&c->dstatus, B) == hipSuccess;
     ok &= dalloc(&c->dqpiter, B) == hipSuccess;
     ok &= dalloc(&c->dqpstatus, B) == hipSuccess;
+    ok &= dalloc(&c->dorder, B) == hipSuccess;
+    { const char *e = getenv("TUM_NMPC_SCHEDULE"); c->lpt = !(e && std::string(e) == "natural"); }
+    if (ok) {   // start from the identity map: the schedule is always a valid permutation
+        std::vector<int> id(B);
+        for (size_t i = 0; i < B; i++) id[i] = (int)i;
+        ok &= hipMemcpy(c->dorder, id.data(), sizeof(int) * B, hipMemcpyHostToDevice) == hipSuccess;
+        c->order_valid = true;
+    }
     c->dqpin = nullptr;
     if (desc->store_qp_in) ok &= dalloc(&c->dqpin, B * N * 88) == hipSuccess;
     ok &= dalloc(&c->ddbg, (size_t)DBG_STRIDE * DBG_INST) == hipSuccess;
@@ -119,7 +129,7 @@ extern "C" void tum_ocp_free(tum_ocp *c)
 {
     if (!c) return;
     (void)hipFree(c->dX); (void)hipFree(c->dU); (void)hipFree(c->dx0); (void)hipFree(c->dyref); (void)hipFree(c->dW); (void)hipFree(c->dpen); (void)hipFree(c->dbnd);
-    (void)hipFree(c->dcost); (void)hipFree(c->dres); (void)hipFree(c->dslack); (void)hipFree(c->dstatus); (void)hipFree(c->dqpiter); (void)hipFree(c->dqpstatus);
+    (void)hipFree(c->dcost); (void)hipFree(c->dres); (void)hipFree(c->dslack); (void)hipFree(c->dstatus); (void)hipFree(c->dqpiter); (void)hipFree(c->dqpstatus); (void)hipFree(c->dorder);
     if (c->dqpin) (void)hipFree(c->dqpin);
     (void)hipFree(c->ddbg); (void)hipFree(c->dprof); (void)hipFree(c->dws);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
@@ -295,11 +305,27 @@ static int launch(tum_ocp *c, bool events = true)
 {
     HIPCHK(hipSetDevice(c->d.device));
     if (events) HIPCHK(hipEventRecord(c->ev0, c->stream));
+    // longest-first schedule from the previous solve's iteration counts (only matters when the batch is more than one
+    // round of resident wavefronts)
+    c->ka.order = (c->lpt && c->order_valid && c->batch > 1024) ? c->dorder : nullptr;
     if (c->ka.flags & 4) hipLaunchKernelGGL(nmpc_rti_kernel<true>, dim3(c->batch), dim3(64), LDS_BYTES, c->stream, c->ka);
     else hipLaunchKernelGGL(nmpc_rti_kernel<false>, dim3(c->batch), dim3(64), LDS_BYTES, c->stream, c->ka);
     HIPCHK(hipGetLastError());
     if (events) HIPCHK(hipEventRecord(c->ev1, c->stream));
+    if (c->lpt && c->batch > 1024) {
+        hipLaunchKernelGGL(lpt_order_kernel, dim3(1), dim3(1024), 0, c->stream, c->dqpiter, c->dorder, c->batch);
+        HIPCHK(hipGetLastError());
+        c->order_valid = true;
+    }
     c->solved = true;
+    return 0;
+}
+
+// 1: dispatch instances longest-first using the previous solve's iteration counts (default), 0: natural order
+extern "C" int tum_ocp_set_schedule(tum_ocp *c, int longest_first)
+{
+    if (!c) return fail("null capsule");
+    c->lpt = longest_first != 0;
     return 0;
 }
 

@@ -47,7 +47,7 @@ C_SYMBOLS = ["tum_ocp_create", "tum_ocp_free", "tum_ocp_last_error", "tum_ocp_ba
              "tum_ocp_solve", "tum_ocp_solve_async", "tum_ocp_synchronize",
              "tum_ocp_get_cost", "tum_ocp_get_stats", "tum_ocp_reset", "tum_ocp_get_from_qp_in",
              "tum_ocp_set_stream", "tum_ocp_get_device", "tum_ocp_cold_start", "tum_ocp_last_kernel_ms",
-             "tum_ocp_debug_dump", "tum_ocp_profile_phases",
+             "tum_ocp_debug_dump", "tum_ocp_profile_phases", "tum_ocp_set_schedule",
              "tum_ocp_set_x0_fanout", "tum_pce_moments", "tum_ocp_r2_backoff", "tum_ocp_constraints_get",
              "tum_planner_emulate", "tum_sim_create", "tum_sim_free", "tum_sim_set_state", "tum_sim_plan", "tum_sim_advance",
              "tum_sim_run", "tum_sim_steps", "tum_sim_get"]
@@ -84,6 +84,7 @@ def load_library(path=None):
     L.tum_ocp_get_stats.argtypes = [vp, cs, vp, ci, ci]
     L.tum_ocp_reset.argtypes = [vp]; L.tum_ocp_cold_start.argtypes = [vp]
     L.tum_ocp_set_stream.argtypes = [vp, vp]
+    L.tum_ocp_set_schedule.argtypes = [vp, ci]
     L.tum_ocp_get_device.argtypes = [vp, cs, vp, ci, ci]
     L.tum_ocp_last_kernel_ms.restype = ctypes.c_double; L.tum_ocp_last_kernel_ms.argtypes = [vp]
     L.tum_ocp_debug_dump.argtypes = [vp, ci, dp, ci]
@@ -303,6 +304,10 @@ class BatchedOcpSolver:
     def get_device(self, field, dev_ptr, b0=0, nb=None):
         nb = self.batch - b0 if nb is None else nb
         self._chk(self._L.tum_ocp_get_device(self._h, field.encode(), ctypes.c_void_p(dev_ptr), b0, nb), "get_device")
+
+    def set_schedule(self, longest_first=True):
+        """Dispatch instances longest-first by the previous solve's iteration counts (default) or in natural order."""
+        self._chk(self._L.tum_ocp_set_schedule(self._h, int(bool(longest_first))), "set_schedule")
 
     def last_kernel_ms(self):
         return float(self._L.tum_ocp_last_kernel_ms(self._h))
