@@ -100,6 +100,8 @@ def main():
     ap.add_argument("--batch", type=int, default=4096, help="instances per GPU")
     ap.add_argument("--horizon", type=int, default=40)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--compare-schedules", action="store_true",
+                    help="after the timed region, also time 5 launches with the instances in natural order")
     args = ap.parse_args()
 
     import torch
@@ -172,15 +174,17 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
     kern_ms = float(np.mean([a.elapsed_time(b) for a, b in evs]))
-    # for transparency: the same kernel with the instances dispatched in natural order (see config.schedule)
-    s.set_schedule(False)
-    nat = []
-    for _ in range(5):
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        s.cold_start(); e0.record(); s.solve_async(); e1.record(); torch.cuda.synchronize()
-        nat.append(e0.elapsed_time(e1))
-    s.set_schedule(True)
-    nat_ms = float(np.median(nat))
+    # on request: the same kernel with the instances dispatched in natural order (see config.schedule)
+    nat_ms = None
+    if args.compare_schedules:
+        s.set_schedule(False)
+        nat = []
+        for _ in range(5):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s.cold_start(); e0.record(); s.solve_async(); e1.record(); torch.cuda.synchronize()
+            nat.append(e0.elapsed_time(e1))
+        s.set_schedule(True)
+        nat_ms = float(np.median(nat))
 
     # correctness of what was timed: statuses, and a parity spot check against the oracle on rank 0
     st = s.get_stats("status"); it = s.get_stats("qp_iter")
@@ -214,8 +218,9 @@ def main():
                                    "one wavefront per OCP", "N": N, "nx": 8, "nu": 2, "nsub": 3, "batch_per_gpu": B,
                        "global_batch": world * B, "parallelism": f"instances sharded x{world}, RCCL gather of (u0,cost,status,qp_iter)",
                        "schedule": "workgroups take instances longest-first by the previous solve's IPM iteration count "
-                                   "(tum_ocp_set_schedule); natural order measured beside it",
-                       "kernel_ms_natural_order": nat_ms, "solves_per_s_per_gpu_natural_order": B / nat_ms * 1e3},
+                                   "(tum_ocp_set_schedule); natural order: --compare-schedules, profiles/*_schedules.json",
+                       "kernel_ms_natural_order": nat_ms,
+                       "solves_per_s_per_gpu_natural_order": (B / nat_ms * 1e3) if nat_ms else None},
             "roofline": {"bound": "mfma", "achieved": ach_tf, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": ach_tf / FP64_PEAK_TFLOPS, "traffic": traffic, "traffic_source": traffic_src,
                          "kernel": "nmpc_rti_kernel", "kernel_ms": kern_ms, "mean_qp_iter": mean_it,

@@ -10,6 +10,7 @@ rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch 
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -o p -- python bench.py --steps 4 --warmup 1 --no-cpu-baseline > /dev/null 2>&1
 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_INSTS_VALU SQ_INSTS_LDS --output-format csv -d $OUT/pmc_sq1 -o p -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline > /dev/null 2>&1
 rocprofv3 --kernel-trace --pmc SQ_INSTS_SALU SQ_INSTS_VALU_MFMA_F64 SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR --output-format csv -d $OUT/pmc_sq2 -o p -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline > /dev/null 2>&1
+python bench.py --steps 20 --warmup 3 --no-cpu-baseline --compare-schedules 2>&1 | grep metric > $OUT/schedules.json
 python scripts/phase_profile.py 2>&1 | grep -v amdgpu > $OUT/phase_cycles.txt
 python scripts/run_configs.py 2>&1 | grep configs > $OUT/configs.txt
 python scripts/pcie_inclusive.py 2>&1 | grep PCIe >> $OUT/configs.txt

@@ -6,6 +6,8 @@ src, dst = "gpurun_out/final", "profiles"
 shutil.copy(f"{src}/stats/s_kernel_stats.csv", f"{dst}/{tag}_kernel_stats.csv")
 shutil.copy(f"{src}/phase_cycles.txt", f"{dst}/{tag}_phase_cycles.txt")
 shutil.copy(f"{src}/configs.txt", f"{dst}/{tag}_configs.txt")
+if os.path.exists(f"{src}/schedules.json"):
+    shutil.copy(f"{src}/schedules.json", f"{dst}/{tag}_schedules.json")
 out = {"kernel": "nmpc_rti_kernel<false>", "batch": 4096, "N": 40,
        "units": "KB per launch (rocprofv3 --pmc, separate passes for FETCH_SIZE and WRITE_SIZE)",
        "calibration": "cold_start_kernel in the same runs reads 262 KB (x0) and writes 13 369 344 B (X,U): FETCH_SIZE / WRITE_SIZE "
