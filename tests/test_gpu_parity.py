@@ -11,6 +11,8 @@ import os
 import numpy as np
 import pytest
 
+from oracle.oracle import OracleOcp  # noqa: E402  (the checker)
+
 pytestmark = pytest.mark.gpu
 
 
@@ -423,3 +425,49 @@ def test_device_closed_loop_full_length_against_logs(golden_dir, track):
     assert (ep.max(axis=1) < 1e-3).sum() >= 20
     # lap-level statistics: mean stage cost per loop as logged
     np.testing.assert_allclose(dbg[:, :, 0].mean(axis=0), g["stats"][:, 3], rtol=2e-3)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", [1, 2, 3, 4, 5, 6, 7, 8])
+def test_randomised_problems_vs_oracle(seed):
+    """Random horizons, weights (log-uniform over two decades), penalties, tightened / widened per-stage bounds and
+    perturbed poses on all three tracks; a cold-start solve and a warm one, instance by instance against the oracle.
+    Same-iteration-count instances must agree to 1e-6, every instance to 1e-4 (the IPM exit test is the only
+    discontinuity between the two implementations)."""
+    from tum_control_amd.workloads import nominal_batch
+    rng = np.random.default_rng(100 + seed)
+    N = int(rng.integers(2, 41)); B = 24
+    track = ("monteblanco", "lvms", "modena")[seed % 3]
+    x0, yref = nominal_batch(B, N=N, track_name=track, stride=int(rng.integers(3, 60)), seed=seed)
+    x0[:, 7] = rng.uniform(-2.5, 2.0, B)                       # braking ... accelerating
+    x0[:, 6] = rng.uniform(-0.05, 0.05, B)
+    p = np.empty((B, 7))
+    p[:, 0] = 10 ** rng.uniform(-1, 1, B); p[:, 1] = 10 ** rng.uniform(-1.5, 0.5, B); p[:, 2] = 10 ** rng.uniform(-1, 1.3, B)
+    p[:, 3] = 10 ** rng.uniform(0, 2, B); p[:, 4] = 10 ** rng.uniform(1, 3, B)
+    p[:, 5] = 10 ** rng.uniform(1, 3.3, B); p[:, 6] = 10 ** rng.uniform(0, 3.3, B)
+    uh = rng.uniform(0.2, 1.5, (B, N + 1)); dlim = rng.uniform(0.01, 0.61, (B, N + 1)); slim = rng.uniform(0.05, 0.4, (B, N + 1))
+    s = _mk(N, B)
+    _set_params(s, p)
+    s.set_x0(x0); s.set_yref_all(yref); s.cold_start()
+    for k in range(1, N + 1):
+        s.constraints_set(k, "uh", uh[:, k]); s.constraints_set(k, "ubx", dlim[:, k]); s.constraints_set(k, "lbx", -dlim[:, k])
+    for k in range(N):
+        s.constraints_set(k, "ubu", slim[:, k]); s.constraints_set(k, "lbu", -slim[:, k])
+    os_ = []
+    for b in range(B):
+        o = OracleOcp(N, 0.08, 3); o.set_weights(*p[b]); o.cold_start(x0[b]); o.yref[:] = yref[b]
+        o.uh[1:] = uh[b, 1:]; o.ubx[1:] = dlim[b, 1:]; o.lbx[1:] = -dlim[b, 1:]; o.ubu[:] = slim[b, :N]; o.lbu[:] = -slim[b, :N]
+        os_.append(o)
+    for step in range(2):
+        assert s.solve() == 0
+        X, U = s.get_iterate(); it = s.get_stats("qp_iter"); cost = s.get_cost()
+        worst_same = worst_all = 0.0
+        for b in range(B):
+            assert os_[b].solve() == 0
+            e = max(np.abs(U[b] - os_[b].U).max(), np.abs(X[b] - os_[b].X).max())
+            worst_all = max(worst_all, e)
+            if it[b] == os_[b].qp_iter:
+                worst_same = max(worst_same, e)
+                assert abs(cost[b] - os_[b].cost) <= 1e-6 * max(1.0, abs(os_[b].cost))
+        assert worst_same < 1e-6 and worst_all < 1e-4, (N, track, step, worst_same, worst_all)
+        assert (np.abs(it - np.array([o.qp_iter for o in os_])) <= 1).all()

@@ -173,7 +173,8 @@ class BatchedOcpSolver:
             ln = v.shape[1]
             self._chk(fn(self._h, stage, field.encode(), _dp(v), ln, 0, self.batch, ln), what)
         else:
-            if self.batch > 1 and v.ndim >= 1 and v.shape[0] == self.batch and field in ("uh", "lh", "lbu", "ubu"):
+            scalar_field = field in ("uh", "lh", "lbu", "ubu") or (field in ("lbx", "ubx") and stage != 0)
+            if self.batch > 1 and v.ndim >= 1 and v.shape[0] == self.batch and scalar_field:   # one value per instance
                 v = v.reshape(self.batch, 1)
                 self._chk(fn(self._h, stage, field.encode(), _dp(v), 1, 0, self.batch, 1), what)
                 return
