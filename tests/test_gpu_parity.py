@@ -118,6 +118,11 @@ def test_properties_full_size():
     s.cold_start(); s.solve()
     X2, U2 = s.get_iterate()
     assert np.array_equal(X1, X2) and np.array_equal(U1, U2)
+    # the workgroup -> instance schedule (longest-first by the previous solve's iteration counts) never changes results
+    s.set_schedule(False); s.cold_start(); s.solve()
+    Xn, Un = s.get_iterate()
+    s.set_schedule(True)
+    assert np.array_equal(Xn, X1) and np.array_equal(Un, U1)
     perm = np.random.default_rng(5).permutation(B)
     s.set_x0(x0[perm]); s.set_yref_all(yref[perm]); s.cold_start(); s.solve()
     X3, U3 = s.get_iterate()
