@@ -60,6 +60,17 @@ def main():
     ms = timed(s, prepare=s.cold_start)
     print(f"configs[1] nominal batch 4096: {ms:.3f} ms -> {4096 / ms * 1e3:,.0f} solves/s, status0 {(s.get_stats('status') == 0).mean():.4f}, qp_iter {s.get_stats('qp_iter').mean():.2f}")
     del s
+    # the same at the reference's own horizon (N = 38, Tp = 3.04 s) for comparability with its logs (0.65-1.2 ms per acados call)
+    x0, yref = nominal_batch(4096, N=38)
+    s = BatchedOcpSolver(N=38, batch=4096); s.install_reference_ocp(); s.set_x0(x0); s.set_yref_all(yref)
+    ms = timed(s, prepare=s.cold_start)
+    print(f"configs[1] at N=38: {ms:.3f} ms -> {4096 / ms * 1e3:,.0f} solves/s, qp_iter {s.get_stats('qp_iter').mean():.2f}")
+    # warm-started RTI steps on the same batch (iterate kept, x0 moved to the predicted next state)
+    X, U = s.get_iterate(); s.set_x0(X[:, 1]); ws = []
+    for _ in range(5):
+        s.solve(); ws.append(s.last_kernel_ms()); X, U = s.get_iterate(); s.set_x0(X[:, 1])
+    print(f"configs[1] at N=38, warm RTI steps: {np.median(ws):.3f} ms -> {4096 / np.median(ws) * 1e3:,.0f} solves/s, qp_iter {s.get_stats('qp_iter').mean():.2f}")
+    del s
     # configs[2]
     P = 1024
     sn = ScenarioSNMPC(P, n_samples=15, N=N)
