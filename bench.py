@@ -131,14 +131,10 @@ def main():
     s.set_x0(x0); s.set_yref_all(yref)
     s.set_stream(torch.cuda.current_stream().cuda_stream)
 
-    # result slabs gathered to rank 0 each step: (u0 2, cost 1) doubles + (status, qp_iter) int32
-    res_f = torch.zeros((B, 3), dtype=torch.float64, device=dev)
-    res_i = torch.zeros((B, 2), dtype=torch.int32, device=dev)
-    u0_t = torch.zeros((B, 2), dtype=torch.float64, device=dev)
-    cost_t = torch.zeros((B,), dtype=torch.float64, device=dev)
-    st_t = torch.zeros((B,), dtype=torch.int32, device=dev)
-    it_t = torch.zeros((B,), dtype=torch.int32, device=dev)
-    gather = sharding.ResultGatherer(world, rank, B, dev) if distributed else None
+    # result slab gathered to rank 0 each step: (u0[2], cost, status, qp_iter) as 5 doubles per instance, packed on the
+    # device by the library (one kernel) and moved with ONE rooted gather
+    res = torch.zeros((B, 5), dtype=torch.float64, device=dev)
+    gather = sharding.ResultGatherer(world, rank, B, dev, nf=5, ni=1) if distributed else None
 
     def step(ev=None):
         s.cold_start()
@@ -148,11 +144,8 @@ def main():
         if ev is not None:
             ev[1].record()
         if gather is not None:
-            s.get_device("u0", u0_t.data_ptr()); s.get_device("cost", cost_t.data_ptr())
-            s.get_device("status", st_t.data_ptr()); s.get_device("qp_iter", it_t.data_ptr())
-            res_f[:, :2] = u0_t; res_f[:, 2] = cost_t
-            res_i[:, 0] = st_t; res_i[:, 1] = it_t
-            gather.gather(res_f, res_i)
+            s.get_device("summary", res.data_ptr())
+            gather.gather(res)
 
     def barrier():
         if distributed:
@@ -216,7 +209,7 @@ def main():
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": "BASELINE configs[1]: nominal NMPC, perturbed x0, Monteblanco reftraj, cold-start SQP-RTI, "
                                    "one wavefront per OCP", "N": N, "nx": 8, "nu": 2, "nsub": 3, "batch_per_gpu": B,
-                       "global_batch": world * B, "parallelism": f"instances sharded x{world}, RCCL gather of (u0,cost,status,qp_iter)",
+                       "global_batch": world * B, "parallelism": f"instances sharded x{world}, RCCL gather of (u0,cost,status,qp_iter), 40 B per instance, one collective per step",
                        "schedule": "workgroups take instances longest-first by the previous solve's IPM iteration count "
                                    "(tum_ocp_set_schedule); natural order: --compare-schedules, profiles/*_schedules.json",
                        "kernel_ms_natural_order": nat_ms,

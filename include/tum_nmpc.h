@@ -114,7 +114,7 @@ int tum_ocp_get_from_qp_in(tum_ocp *c, int stage, const char *field, double *out
  * stream) and copy results device-to-device into caller-owned HBM (for the RCCL gather). */
 int tum_ocp_set_stream(tum_ocp *c, void *hip_stream);
 /* field: "u0" (nb x 2), "x1" (nb x 8), "cost" (nb), "X" (nb x (N+1)*8), "U" (nb x N*2),
- * "status" / "qp_iter" (nb int32) */
+ * "status" / "qp_iter" (nb int32), "summary" (nb x 5 doubles: u0[2], cost, status, qp_iter -- the slab of the rooted gather) */
 int tum_ocp_get_device(tum_ocp *c, const char *field, void *dev_dst, int b0, int nb);
 /* cold start every instance on the device: X_k = x0 for all k, U = 0 (acados create / reset + set x;
  * NMPC_class.py:250-254) using the x0 already uploaded with constraints_set(0,"lbx"). */

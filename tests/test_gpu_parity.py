@@ -476,3 +476,22 @@ def test_randomised_problems_vs_oracle(seed):
                 assert abs(cost[b] - os_[b].cost) <= 1e-6 * max(1.0, abs(os_[b].cost))
         assert worst_same < 1e-6 and worst_all < 1e-4, (N, track, step, worst_same, worst_all)
         assert (np.abs(it - np.array([o.qp_iter for o in os_])) <= 1).all()
+
+
+@pytest.mark.gpu
+def test_device_result_summary_slab():
+    """get_device("summary"): the 5-double slab (u0[2], cost, status, qp_iter) that the multi-GPU job gathers with one collective."""
+    import torch
+    from tum_control_amd.workloads import nominal_batch
+    N, B = 40, 70
+    x0, yref = nominal_batch(B, N=N, seed=21)
+    s = _mk(N, B)
+    s.set_stream(torch.cuda.current_stream().cuda_stream)
+    s.set_x0(x0); s.set_yref_all(yref); s.cold_start(); assert s.solve() == 0
+    r = torch.zeros((B - 6, 5), dtype=torch.float64, device="cuda")
+    s.get_device("summary", r.data_ptr(), b0=3, nb=B - 6)
+    torch.cuda.synchronize()
+    r = r.cpu().numpy()
+    X, U = s.get_iterate()
+    assert np.array_equal(r[:, :2], U[3:B - 3, 0]) and np.array_equal(r[:, 2], s.get_cost()[3:B - 3])
+    assert np.array_equal(r[:, 3], s.get_stats("status")[3:B - 3]) and np.array_equal(r[:, 4], s.get_stats("qp_iter")[3:B - 3])

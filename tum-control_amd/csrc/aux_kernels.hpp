@@ -98,4 +98,15 @@ __global__ void __launch_bounds__(256) r2_backoff_kernel(const double *qpin, con
     }
 }
 
+// result summary of every instance as 5 doubles [u0_jerk, u0_steering_rate, cost, status, qp_iter]: one buffer, one
+// collective for the rooted gather of the multi-GPU job
+__global__ void pack_summary_kernel(const double *U, const double *cost, const int *status, const int *qp_iter, int N, int b0, int nb, double *dst)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nb) return;
+    const int b = b0 + i;
+    dst[5 * i + 0] = U[(size_t)b * N * NU]; dst[5 * i + 1] = U[(size_t)b * N * NU + 1];
+    dst[5 * i + 2] = cost[b]; dst[5 * i + 3] = (double)status[b]; dst[5 * i + 4] = (double)qp_iter[b];
+}
+
 }  // namespace tum

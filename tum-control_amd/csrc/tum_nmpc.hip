@@ -437,6 +437,11 @@ extern "C" int tum_ocp_get_device(tum_ocp *c, const char *field, void *dst, int 
     const int N = c->N;
     const std::string f(field);
     hipStream_t s = c->stream;
+    if (f == "summary") {
+        hipLaunchKernelGGL(pack_summary_kernel, dim3((nb + 255) / 256), dim3(256), 0, s, c->dU, c->dcost, c->dstatus, c->dqpiter, N, b0, nb, (double *)dst);
+        HIPCHK(hipGetLastError());
+        return 0;
+    }
     if (f == "u0") { HIPCHK(hipMemcpy2DAsync(dst, 2 * 8, c->dU + (size_t)b0 * N * NU, (size_t)N * NU * 8, 2 * 8, nb, hipMemcpyDeviceToDevice, s)); return 0; }
     if (f == "x1") { HIPCHK(hipMemcpy2DAsync(dst, 8 * 8, c->dX + (size_t)b0 * (N + 1) * NX + NX, (size_t)(N + 1) * NX * 8, 8 * 8, nb, hipMemcpyDeviceToDevice, s)); return 0; }
     if (f == "cost") { HIPCHK(hipMemcpyAsync(dst, c->dcost + b0, 8 * (size_t)nb, hipMemcpyDeviceToDevice, s)); return 0; }

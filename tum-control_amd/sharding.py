@@ -4,7 +4,7 @@ sharding.py -- multi-GPU layout of the batch dimension.
 OCP instances are independent, so the batch is cut into contiguous blocks, one per rank (one
 process per GPU); there is no collective inside a solve. The only exchange is the rooted gather
 of the per-instance result slabs to rank 0 (RCCL over xGMI on GPUs, gloo in the CPU tests):
-payload (u0, cost) doubles + (status, qp_iter) int32 = 32 B per instance.
+payload (u0[2], cost, status, qp_iter) as 5 doubles = 40 B per instance, ONE collective per step.
 """
 import torch
 import torch.distributed as dist
@@ -38,7 +38,8 @@ class ResultGatherer:
             self.all_f = self.all_i = None
             self._lf = self._li = None
 
-    def gather(self, res_f, res_i):
+    def gather(self, res_f, res_i=None):
         dist.gather(res_f, self._lf, dst=self.root)
-        dist.gather(res_i, self._li, dst=self.root)
+        if res_i is not None:
+            dist.gather(res_i, self._li, dst=self.root)
         return self.all_f, self.all_i
