@@ -130,39 +130,43 @@ __global__ void __launch_bounds__(64) planner_kernel(const double *track, int n,
 // xdot of the 7-state plant [posx,posy,yaw,vlong,vlat,yawrate,delta_f] with inputs (a, steering rate)
 // (sim_model_dynamic_stm_pacejka.py:137-195: the prediction model's forces with the acceleration as an input)
 struct PlantModel {
-    double lf, lr, m, Iz, ka;
+    double lf, lr, m, inv_m, inv_Iz, ka;
     double Bf, Cf, Df, Ef, Br, Cr, Dr, Er;
-    double g, fr0, fr1, fr4;
+    double Fz_f, Fz_r, invFmax_f, invFmax_r;          // static axle loads, 1 / (Fz * sqrt(1 + C^2))
+    double fr0, fr1, fr4;
 };
 
+// Same formulas as the reference's plant, arranged for a short instruction stream (this kernel is one thread's latency
+// per instance): constants folded on the host, one reciprocal of vlong, sincos, cos(asin(G)) = sqrt(1 - G^2).
 __device__ __forceinline__ void plant_xdot(const PlantModel &p, const double x[7], double a, double sr, double xd[7])
 {
-#pragma clang fp contract(off)
     const double yaw = x[2], vl = x[3], vt = x[4], r = x[5], de = x[6];
-    const double v = sqrt(vl * vl + vt * vt) * 3.6;
-    const double w = v / 100;
-    const double fr = p.fr0 + p.fr1 * v / 100 + p.fr4 * (w * w * w * w);
-    const double Fz_f = p.m * p.lr * p.g / (p.lf + p.lr), Fz_r = p.m * p.lf * p.g / (p.lf + p.lr);
-    const double Fx_f = -fr * Fz_f;
-    const double Fx_r = p.m * a - fr * Fz_r;
-    const double Faero = p.ka * (vl * vl);
-    const bool ok = vl > 0.001;
-    const double vls = ok ? vl : 1.0;
-    const double al_f = ok ? de - atan((vt + p.lf * r) / vls) : 0.0;
-    const double al_r = ok ? atan((p.lr * r - vt) / vls) : 0.0;
-    const double Fy_f_lat = p.Df * sin(p.Cf * atan(p.Bf * al_f - p.Ef * (p.Bf * al_f - atan(p.Bf * al_f))));
-    const double Fy_r_lat = p.Dr * sin(p.Cr * atan(p.Br * al_r - p.Er * (p.Br * al_r - atan(p.Br * al_r))));
-    const double Fmax_f = sqrt(Fz_f * Fz_f + (p.Cf * Fz_f) * (p.Cf * Fz_f)), Fmax_r = sqrt(Fz_r * Fz_r + (p.Cr * Fz_r) * (p.Cr * Fz_r));
-    double Gy_f = Fx_f / Fmax_f, Gy_r = Fx_r / Fmax_r;
-    Gy_f = fmin(fmax(Gy_f, -0.98), 0.98); Gy_r = fmin(fmax(Gy_r, -0.98), 0.98);
-    const double Fy_f = Fy_f_lat * cos(asin(Gy_f)), Fy_r = Fy_r_lat * cos(asin(Gy_r));
-    const double sy = sin(yaw), cy = cos(yaw), sd = sin(de), cd = cos(de);
+    const double w = 0.036 * sqrt(vl * vl + vt * vt);          // v[km/h] / 100
+    const double w2 = w * w;
+    const double fr = p.fr0 + p.fr1 * w + p.fr4 * w2 * w2;
+    const double Fx_f = -fr * p.Fz_f;
+    const double Fx_r = p.m * a - fr * p.Fz_r;
+    double al_f = 0.0, al_r = 0.0;
+    if (vl > 0.001) {
+        const double ivl = 1.0 / vl;
+        al_f = de - atan((vt + p.lf * r) * ivl);
+        al_r = atan((p.lr * r - vt) * ivl);
+    }
+    const double xf = p.Bf * al_f, xr = p.Br * al_r;
+    const double Fy_f_lat = p.Df * sin(p.Cf * atan(xf - p.Ef * (xf - atan(xf))));
+    const double Fy_r_lat = p.Dr * sin(p.Cr * atan(xr - p.Er * (xr - atan(xr))));
+    const double Gf = fmin(fmax(Fx_f * p.invFmax_f, -0.98), 0.98), Gr = fmin(fmax(Fx_r * p.invFmax_r, -0.98), 0.98);
+    const double Fy_f = Fy_f_lat * sqrt(1.0 - Gf * Gf), Fy_r = Fy_r_lat * sqrt(1.0 - Gr * Gr);
+    double sy, cy, sd, cd;
+    sincos(yaw, &sy, &cy);
+    sincos(de, &sd, &cd);
+    const double front = Fy_f * cd + Fx_f * sd;
     xd[0] = vl * cy - vt * sy;
     xd[1] = vl * sy + vt * cy;
     xd[2] = r;
-    xd[3] = (Fx_r - Faero - Fy_f * sd + Fx_f * cd + p.m * vt * r) / p.m;
-    xd[4] = (Fy_r + Fy_f * cd + Fx_f * sd - p.m * vl * r) / p.m;
-    xd[5] = (p.lf * (Fy_f * cd + Fx_f * sd) - p.lr * Fy_r) / p.Iz;
+    xd[3] = (Fx_r - p.ka * vl * vl - Fy_f * sd + Fx_f * cd) * p.inv_m + vt * r;
+    xd[4] = (Fy_r + front) * p.inv_m - vl * r;
+    xd[5] = (p.lf * front - p.lr * Fy_r) * p.inv_Iz;
     xd[6] = sr;
 }
 
@@ -181,7 +185,7 @@ struct SimArgs {
 // One thread per instance: simMode 0 of sim_step. The plant takes the predicted acceleration of stage 1 and the steering
 // rate of stage 0, integrates Ts with classic RK4 in n_elem equal sub-steps; the estimator is a per-state moving average
 // over the last win[i] samples (fewer while the buffer fills); the filtered state becomes the next x0 of the OCP.
-__global__ void plant_advance_kernel(const SimArgs sa)
+__global__ void __launch_bounds__(64) plant_advance_kernel(const SimArgs sa)
 {
 #pragma clang fp contract(off)
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
@@ -192,23 +196,36 @@ __global__ void plant_advance_kernel(const SimArgs sa)
     const double *u0 = sa.U + (size_t)b * N * NU;
     const double a_in = x1[7], sr_in = u0[1];
     double x[7];
+#pragma unroll
     for (int i = 0; i < 7; i++) x[i] = sa.x_sim[(size_t)b * 7 + i];
     const double h = sa.Ts / sa.n_elem;
     for (int e = 0; e < sa.n_elem; e++) {
-        double k1[7], k2[7], k3[7], k4[7], t[7];
-        plant_xdot(sa.pm, x, a_in, sr_in, k1);
-        for (int i = 0; i < 7; i++) t[i] = x[i] + 0.5 * h * k1[i];
-        plant_xdot(sa.pm, t, a_in, sr_in, k2);
-        for (int i = 0; i < 7; i++) t[i] = x[i] + 0.5 * h * k2[i];
-        plant_xdot(sa.pm, t, a_in, sr_in, k3);
-        for (int i = 0; i < 7; i++) t[i] = x[i] + h * k3[i];
-        plant_xdot(sa.pm, t, a_in, sr_in, k4);
-        for (int i = 0; i < 7; i++) x[i] = x[i] + h / 6.0 * (k1[i] + 2 * k2[i] + 2 * k3[i] + k4[i]);
+        // The four RK stages share ONE inlined copy of the model (stage loop not unrolled): this kernel runs its code
+        // once per control step, so its time is instruction fetch -- four inlined copies (63 KB) cost 107 us per call,
+        // all of it cold instruction-cache misses. State loops are unrolled so the vectors stay in registers.
+        double kprev[7], acc[7];
+#pragma unroll
+        for (int i = 0; i < 7; i++) { kprev[i] = 0.0; acc[i] = 0.0; }
+#pragma unroll 1
+        for (int st = 0; st < 4; st++) {
+            const double ci = (st == 0) ? 0.0 : (st == 3 ? 1.0 : 0.5);
+            const double wi = (st == 0 || st == 3) ? 1.0 : 2.0;
+            double t[7], k[7];
+#pragma unroll
+            for (int i = 0; i < 7; i++) t[i] = (st == 0) ? x[i] : x[i] + ci * h * kprev[i];
+            plant_xdot(sa.pm, t, a_in, sr_in, k);
+#pragma unroll
+            for (int i = 0; i < 7; i++) { acc[i] = (st == 0) ? k[i] : acc[i] + wi * k[i]; kprev[i] = k[i]; }
+        }
+#pragma unroll
+        for (int i = 0; i < 7; i++) x[i] = x[i] + h / 6.0 * acc[i];
     }
+#pragma unroll
     for (int i = 0; i < 7; i++) sa.x_sim[(size_t)b * 7 + i] = x[i];
     sa.pose[(size_t)b * 2] = x[0]; sa.pose[(size_t)b * 2 + 1] = x[1];
     // state estimation: sample number k (1-based) goes to ring slot (k-1) & 3
     const int k = step + 1;
+#pragma unroll
     for (int i = 0; i < 8; i++) {
         const double v = (i < 7) ? x[i] : a_in;
         double *hst = sa.hist + ((size_t)b * 8 + i) * 4;
@@ -220,6 +237,7 @@ __global__ void plant_advance_kernel(const SimArgs sa)
     }
     if (sa.lCiLX && step < sa.log_cap) {
         const size_t s = step;
+#pragma unroll
         for (int i = 0; i < 7; i++) sa.lCiLX[((s + 1) * B + b) * 7 + i] = x[i];
         for (int i = 0; i < 8; i++) sa.lSimX[((s + 1) * B + b) * 8 + i] = x1[i];
         sa.lU[(s * B + b) * 2] = u0[0]; sa.lU[(s * B + b) * 2 + 1] = u0[1];

@@ -678,9 +678,12 @@ extern "C" int tum_sim_advance(tum_sim *s)
     for (int i = 0; i < 8; i++) sa.win[i] = s->win[i];
     const tum_ocp_desc &d = c->d;
     PlantModel &p = sa.pm;
-    p.lf = d.lf; p.lr = d.lr; p.m = d.m; p.Iz = d.Iz; p.ka = 0.5 * d.ro * d.S * d.Cd;
+    p.lf = d.lf; p.lr = d.lr; p.m = d.m; p.inv_m = 1.0 / d.m; p.inv_Iz = 1.0 / d.Iz; p.ka = 0.5 * d.ro * d.S * d.Cd;
     p.Bf = d.Bf; p.Cf = d.Cf; p.Df = d.Df; p.Ef = d.Ef; p.Br = d.Br; p.Cr = d.Cr; p.Dr = d.Dr; p.Er = d.Er;
-    p.g = d.g; p.fr0 = d.fr0; p.fr1 = d.fr1; p.fr4 = d.fr4;
+    p.Fz_f = d.m * d.lr * d.g / (d.lf + d.lr); p.Fz_r = d.m * d.lf * d.g / (d.lf + d.lr);
+    p.invFmax_f = 1.0 / std::sqrt(p.Fz_f * p.Fz_f + (d.Cf * p.Fz_f) * (d.Cf * p.Fz_f));
+    p.invFmax_r = 1.0 / std::sqrt(p.Fz_r * p.Fz_r + (d.Cr * p.Fz_r) * (d.Cr * p.Fz_r));
+    p.fr0 = d.fr0; p.fr1 = d.fr1; p.fr4 = d.fr4;
     sa.X = c->dX; sa.U = c->dU; sa.cost = c->dcost; sa.status = c->dstatus; sa.qp_iter = c->dqpiter;
     sa.x_sim = s->dxsim; sa.x0 = c->dx0; sa.pose = s->dpose; sa.hist = s->dhist; sa.ref0 = s->dref0;
     sa.lCiLX = s->lCiLX; sa.lSimX = s->lSimX; sa.lU = s->lU; sa.lREF = s->lREF; sa.lDBG = s->lDBG;
