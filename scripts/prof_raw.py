@@ -3,8 +3,10 @@ sys.path.insert(0,'/root/repo')
 import torch
 from tum_control_amd.solver import BatchedOcpSolver
 from tum_control_amd.workloads import nominal_batch
-x0,yref=nominal_batch(4096,N=40)
-s=BatchedOcpSolver(N=40,batch=4096); s.install_reference_ocp(); s.set_x0(x0); s.set_yref_all(yref)
+import sys as _s
+B=int(_s.argv[1]) if len(_s.argv)>1 else 4096
+x0,yref=nominal_batch(B,N=40)
+s=BatchedOcpSolver(N=40,batch=B); s.install_reference_ocp(); s.set_x0(x0); s.set_yref_all(yref)
 s.cold_start(); s.solve(); s.cold_start()
 p=s.profile_phases().astype(float)
 it=s.get_stats('qp_iter').mean()

@@ -88,20 +88,18 @@ class Nonlinear_Model_Predictive_Controller:
     def solve(self, current_ref_traj):
         """NMPC_class.py:163-241: set yref on every stage, one SQP-RTI step, read u0 / predictions / stats."""
         s, N = self.acados_solver, self.N
-        for j in range(N):
-            yref = np.array([current_ref_traj['pos_x'][j], current_ref_traj['pos_y'][j],
-                             current_ref_traj['ref_yaw'][j], current_ref_traj['ref_v'][j], 0, 0])
-            s.set(j, "yref", yref)
-        yref_N = np.array([current_ref_traj['pos_x'][N], current_ref_traj['pos_y'][N],
-                           current_ref_traj['ref_yaw'][N], current_ref_traj['ref_v'][N]])
-        s.set(N, "yref", yref_N)
+        # (the reference issues one set() per stage and one get() per stage, 79 ctypes calls per step; the batched
+        # setters / getters of the binding move the same data in three)
+        y = np.zeros((N + 1, 6))
+        y[:, 0] = np.asarray(current_ref_traj['pos_x'][:N + 1]); y[:, 1] = np.asarray(current_ref_traj['pos_y'][:N + 1])
+        y[:, 2] = np.asarray(current_ref_traj['ref_yaw'][:N + 1]); y[:, 3] = np.asarray(current_ref_traj['ref_v'][:N + 1])
+        s.set_yref_all(y)
         status = s.solve()
-        u0 = s.get(0, "u")
+        X, U = s.get_iterate()
+        X, U = np.asarray(X).reshape(-1, N + 1, self.nx)[0], np.asarray(U).reshape(-1, N, 2)[0]     # batch = 1
+        u0 = np.array(U[0])
         if status == 0:
-            pred_X = np.empty((0, self.nx))
-            for j in range(N):
-                pred_X = np.concatenate((pred_X, np.array(s.get(j, "x")).reshape(1, -1)), axis=0)
-            self.pred_X = pred_X
+            self.pred_X = np.array(X[:N])
         self.stats[0] = s.get_cost()
         self.stats[1] = s.get_stats('time_tot')
         self.stats[2] = s.get_stats('sqp_iter')
