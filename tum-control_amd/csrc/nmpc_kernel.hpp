@@ -377,8 +377,9 @@ __global__ void __launch_bounds__(64, 1) nmpc_rti_kernel(const KArgs ka)
                     const double c1 = t_ * l_, c2 = s_ * m_;
                     lcmp = fmax(lcmp, rowlane ? fmax(c1, c2) : 0.0);
                     lg += rowlane ? c1 + c2 : 0.0;
-                    const double Ds = pen(rr, sd, 1) + m_ * frcp(s_);
-                    gsum[rr] += frcp(t_ * frcp(l_) + frcp(Ds));
+                    // gamma = 1 / (t/l + 1/(Z + mu/s)) with two reciprocals instead of four: 1/(Z + mu/s) = s / (Z s + mu)
+                    const double iDs = s_ * frcp(pen(rr, sd, 1) * s_ + m_);
+                    gsum[rr] += l_ * frcp(t_ + l_ * iDs);
                 }
             }
             res_stat = wave_max(ls); res_ineq = wave_max(li); res_comp = wave_max(lcmp);
@@ -608,13 +609,14 @@ __global__ void __launch_bounds__(64, 1) nmpc_rti_kernel(const KArgs ka)
                     for (int sd = 0; sd < 2; sd++) {
                         const int k = rr * 2 + sd;
                         const double s_ = ROWF(0, k), t_ = ROWF(1, k), l_ = ROWF(2, k), m_ = ROWF(3, k);
-                        const double is_ = frcp(s_), il_ = frcp(l_);
-                        const double iDs = frcp(pen(rr, sd, 1) + m_ * is_);
-                        const double gam = frcp(t_ * il_ + iDs);
+                        // gam * rho with gam = l G, G = 1/(t + l s D), D = 1/(Z s + mu):
+                        //   gam * rho = G * (rc1 - l * (rt + (rs s + rc2) D))       (two reciprocals instead of four)
+                        const double D = frcp(pen(rr, sd, 1) * s_ + m_);
+                        const double G = frcp(t_ + l_ * s_ * D);
                         double rc1 = t_ * l_, rc2 = s_ * m_;
                         if (pass == 1) { rc1 += cross1[k] - tau; rc2 += cross2[k] - tau; }
-                        const double rho = -ROWF(5, k) + rc1 * il_ - (ROWF(4, k) + rc2 * is_) * iDs;
-                        w[rr] += (sd ? -1.0 : 1.0) * gam * rho;
+                        const double gr = G * (rc1 - l_ * (ROWF(5, k) + (ROWF(4, k) * s_ + rc2) * D));
+                        w[rr] += sd ? -gr : gr;
                     }
                 }
                 publish(w[0], w[1], w[2], sWh);
