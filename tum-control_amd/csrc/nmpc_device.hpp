@@ -190,7 +190,7 @@ __device__ __forceinline__ void pacejka(double B, double C, double D, double E, 
     double sn, cs;
     sincos(C * th, &sn, &cs);
     Fy = D * sn;
-    dFy = D * cs * C / (1.0 + inner * inner) * (1.0 - E + E / (1.0 + x1 * x1)) * B;
+    dFy = D * cs * C * frcp(1.0 + inner * inner) * (1.0 - E + E * frcp(1.0 + x1 * x1)) * B;
 }
 
 __device__ __forceinline__ void stm_core(const Model &p, double vl, double vt, double r, double de, double a,
@@ -202,17 +202,17 @@ __device__ __forceinline__ void stm_core(const Model &p, double vl, double vt, d
     const double w2 = w * w;
     const double fr = p.fr0 + p.fr1 * w + p.fr4 * w2 * w2;
     const double dfr_dw = p.fr1 + 4.0 * p.fr4 * w2 * w;
-    const double isp = 0.036 / sp;
+    const double isp = 0.036 * frcp(sp);
     const double fr_vl = dfr_dw * isp * vl, fr_vt = dfr_dw * isp * vt;
     const double Fxf = -fr * p.Fz_f;
     const double Fxr = p.m * a - fr * p.Fz_r;
     double alf = 0, alf_vl = 0, alf_vt = 0, alf_r = 0, alf_de = 0, alr = 0, alr_vl = 0, alr_vt = 0, alr_r = 0;
     if (vl > 0.001) {
-        const double ivl = 1.0 / vl;
-        const double qf = (vt + p.lf * r) * ivl, cf2 = 1.0 / (1.0 + qf * qf);
+        const double ivl = frcp(vl);
+        const double qf = (vt + p.lf * r) * ivl, cf2 = frcp(1.0 + qf * qf);
         alf = de - atan(qf);
         alf_vl = qf * ivl * cf2; alf_vt = -ivl * cf2; alf_r = -p.lf * ivl * cf2; alf_de = 1.0;
-        const double qr = (p.lr * r - vt) * ivl, cr2 = 1.0 / (1.0 + qr * qr);
+        const double qr = (p.lr * r - vt) * ivl, cr2 = frcp(1.0 + qr * qr);
         alr = atan(qr);
         alr_vl = -qr * ivl * cr2; alr_vt = -ivl * cr2; alr_r = p.lr * ivl * cr2;
     }
@@ -225,8 +225,8 @@ __device__ __forceinline__ void stm_core(const Model &p, double vl, double vt, d
     double Gr = Fxr * p.invFmax_r, gr_on = 1.0;
     if (Gr > 0.98) { Gr = 0.98; gr_on = 0.0; } else if (Gr < -0.98) { Gr = -0.98; gr_on = 0.0; }
     const double cgf = sqrt(1.0 - Gf * Gf), cgr = sqrt(1.0 - Gr * Gr);       // cos(asin(G))
-    const double dcgf = -Gf / cgf * gf_on * p.invFmax_f;                      // d cgf / d Fxf
-    const double dcgr = -Gr / cgr * gr_on * p.invFmax_r;                      // d cgr / d Fxr
+    const double dcgf = -Gf * frcp(cgf) * gf_on * p.invFmax_f;                // d cgf / d Fxf
+    const double dcgr = -Gr * frcp(cgr) * gr_on * p.invFmax_r;                // d cgr / d Fxr
     const double Fxf_vl = -p.Fz_f * fr_vl, Fxf_vt = -p.Fz_f * fr_vt;
     const double Fxr_vl = -p.Fz_r * fr_vl, Fxr_vt = -p.Fz_r * fr_vt;
     const double Fyf = Fyf_lat * cgf, Fyr = Fyr_lat * cgr;
