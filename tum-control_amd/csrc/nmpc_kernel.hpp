@@ -725,17 +725,23 @@ __global__ void __launch_bounds__(64, 1) nmpc_rti_kernel(const KArgs ka)
                 const double xo = rowlane ? sDv[2 * rl_ + 1] : 0.0;
                 cdv[0] = xo;
                 cdv[1] = dt * wave_prefix(xo, lane);
-                const int s = rl_ + 1;
-                const double *ch = sCh + hoff(s);
+                // gg rows: row s has 2s entries (up to 80). Rows 17..40 are split in two halves of s entries, the second
+                // half goes to the otherwise idle lanes 40..63, so no lane walks more than 40 entries.
+                const int hs = (lane < NMAX) ? lane + 1 : lane - 23;              // row handled (lanes 40..63: rows 17..40)
+                const int cstart = (lane < NMAX) ? 0 : hs, ncol = (hs <= 16) ? 2 * hs : hs;
+                const bool hon = hs <= N;
+                const double *ch = sCh + hoff(hs) + cstart;
+                const double *dvp = sDv + cstart;
                 double a0 = 0.0, a1 = 0.0;
-#pragma unroll 8
-                for (int c = 0; c < NVP; c += 2) {
-                    const bool on = (c < 2 * s);
-                    const double x0_ = ch[c], x1_ = ch[c + 1];
-                    a0 += (on ? x0_ : 0.0) * sDv[c];
-                    a1 += (on ? x1_ : 0.0) * sDv[c + 1];
+#pragma unroll 10
+                for (int i = 0; i < NMAX; i += 2) {
+                    const double x0_ = ch[i], x1_ = ch[i + 1];
+                    a0 += ((hon && i < ncol) ? x0_ : 0.0) * dvp[i];
+                    a1 += ((hon && i + 1 < ncol) ? x1_ : 0.0) * dvp[i + 1];
                 }
-                cdv[2] = a0 + a1;
+                const double part = a0 + a1;
+                const double other = __shfl(part, (lane + 24) & 63, 64);           // second half of rows 17..40
+                cdv[2] = (lane >= 16 && lane < NMAX) ? part + other : part;
             }
             double amax = 1.0, lmu = 0.0;
             double dcur[4][6];
