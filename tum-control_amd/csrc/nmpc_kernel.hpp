@@ -11,24 +11,28 @@ namespace tum {
 
 __device__ __forceinline__ int acados_status(int qp_status) { return (qp_status == 0 || qp_status == 1) ? 0 : 4; }
 
-// Row-side state of the interior point method held by lane l < N:
-//   row 0: steering-rate box of stage l      (variable 2l+1)
-//   row 1: steering-angle bound of stage l+1 (structured row: dt on the odd columns < 2(l+1))
-//   row 2: gg-circle constraint of stage l+1 (packed row l+1 of sCh)
-// side 0 = lower, 1 = upper.
+// Row-side state of the interior point method: every lane owns TWO rows (slots) x two sides (0 lower, 1 upper):
+//   lanes 0..N-1   slot 0: steering-rate box of stage l (variable 2l+1)
+//                  slot 1: steering-angle bound of stage l+1 (structured row: dt on the odd columns < 2(l+1))
+//   lanes 40..59   slots 0,1: gg-circle constraints of stages 2j+1, 2j+2, j = lane-40 (packed rows of sCh)
+// (240 row sides over 60 lanes: 4 per lane instead of 6 on 40 lanes.)
 
 // Everything derived from the lane id that the IPM uses. Instantiated from an OPAQUE copy of the lane id inside
 // the iteration loop: otherwise LICM hoists hundreds of lane predicates / LDS addresses out of the loop and the
 // register allocator spills them (SGPR masks to VGPR lanes, addresses to scratch).
 #define ROWF(f, k) rowst[f][k]
 #define TUM_LANE_DEFS \
-    const bool rowlane = lane < N; \
-    const int rl_ = rowlane ? lane : 0; \
-    const int cls0 = (rl_ == 0) ? 0 : 1, cls12 = (rl_ + 1 < N) ? 1 : 2; \
-    const double sc12 = (rl_ + 1 < N) ? dt : 1.0; \
-    auto pen = [&](int rr, int sd, int quad) -> double { \
-        const int cls = rr == 0 ? cls0 : cls12; \
-        return (rr == 0 ? dt : sc12) * sPen[(cls * 3 + rr) * 4 + 2 * quad + sd]; \
+    const bool boxlane = lane < N; \
+    const bool gglane = lane >= NMAX && lane < NMAX + 20; \
+    const int gj = gglane ? lane - NMAX : 0; \
+    const int stg0 = gglane ? 2 * gj + 1 : lane, stg1 = gglane ? 2 * gj + 2 : lane + 1;   /* stage of each slot */ \
+    const bool on0 = gglane ? (stg0 <= N) : boxlane, on1 = gglane ? (stg1 <= N) : boxlane; \
+    const int ty0 = gglane ? 2 : 0, ty1 = gglane ? 2 : 1;                                  /* 0 box, 1 steering, 2 gg */ \
+    const int pc0 = gglane ? ((stg0 < N) ? 1 : 2) : ((lane == 0) ? 0 : 1), pc1 = (stg1 < N) ? 1 : 2; \
+    const double psc0 = (gglane && stg0 >= N) ? 1.0 : dt, psc1 = (stg1 < N) ? dt : 1.0; \
+    const int pix0 = (pc0 * 3 + ty0) * 4, pix1 = (pc1 * 3 + ty1) * 4; \
+    auto pen = [&](int slot, int sd, int quad) -> double { \
+        return (slot == 0 ? psc0 : psc1) * sPen[(slot == 0 ? pix0 : pix1) + 2 * quad + sd]; \
     }; \
     const bool v0on = lane < nv, v1on = (lane < 16) && (64 + lane < nv); \
     const bool odd = lane & 1; \
@@ -54,11 +58,12 @@ __device__ __forceinline__ int acados_status(int qp_status) { return (qp_status 
         } \
         o0 = v0on ? a0 : 0.0; o1 = v1on ? a1 : 0.0; \
     }; \
-    auto publish = [&](double wbox, double wdel, double wh, double *dstH) { \
-        const double sfx = wave_suffix(rowlane ? wdel : 0.0, lane); \
+    auto publish = [&](double w0_, double w1_, double *dstH) {   /* slot values: (box, steering) or (gg, gg) */ \
+        const double sfx = wave_suffix(boxlane ? w1_ : 0.0, lane); \
         wsync(); \
-        if (lane < NMAX) { sWb[lane] = rowlane ? wbox : 0.0; dstH[lane] = rowlane ? wh : 0.0; } \
+        if (lane < NMAX) sWb[lane] = boxlane ? w0_ : 0.0; \
         if (lane < NMAX + 1) sSfx[lane + 1] = (lane < N) ? sfx : 0.0; \
+        if (gglane) { dstH[2 * gj] = on0 ? w0_ : 0.0; dstH[2 * gj + 1] = on1 ? w1_ : 0.0; } \
         wsync(); \
     }; \
     int rb[NT]; \
@@ -299,7 +304,7 @@ __global__ void __launch_bounds__(64, 1) nmpc_rti_kernel(const KArgs ka)
     // phases only carry the 15 H tiles in registers. sRow[(field*6 + row*2 + side)*NMAX + lane],
     // fields: 0 s, 1 t, 2 lam, 3 mu, 4 rs (slack stationarity residual), 5 rt (primal residual).
     double v0 = 0.0, v1 = 0.0, rv0, rv1, qn;
-    double rowst[6][6];      // IPM row state of this lane: [s, t, lam, mu, rs, rt][row*2+side]
+    double rowst[6][4];      // IPM row state of this lane: [s, t, lam, mu, rs, rt][slot*2+side]
     const double npairs = 12.0 * N;
     const double inv_npairs = 1.0 / npairs;
     const int nchunk = (N + 3) >> 2;                 // chunks of 4 gg rows
@@ -309,18 +314,23 @@ __global__ void __launch_bounds__(64, 1) nmpc_rti_kernel(const KArgs ka)
         TUM_LANE_DEFS
     {
         const int NB = N + 1;
-        double dval[3], lo[3], hi[3];
-        dval[0] = sU0[2 * rl_ + 1]; lo[0] = gbnd[0 * NB + rl_]; hi[0] = gbnd[1 * NB + rl_];
-        dval[1] = sD[2 * rl_];     lo[1] = gbnd[2 * NB + rl_ + 1]; hi[1] = gbnd[3 * NB + rl_ + 1];
-        dval[2] = sD[2 * rl_ + 1]; lo[2] = gbnd[4 * NB + rl_ + 1]; hi[2] = gbnd[5 * NB + rl_ + 1];
+        double dval[2], lo[2], hi[2];
+        {
+            // slot 0: box of stage `lane` (value = current steering rate) or gg row of stage stg0
+            const int i0 = on0 ? stg0 : (gglane ? 1 : 0), i1 = on1 ? stg1 : 1;
+            dval[0] = gglane ? sD[2 * (i0 - 1) + 1] : sU0[2 * i0 + 1];
+            lo[0] = gbnd[(gglane ? 4 : 0) * NB + i0]; hi[0] = gbnd[(gglane ? 5 : 1) * NB + i0];
+            dval[1] = gglane ? sD[2 * (i1 - 1) + 1] : sD[2 * (i1 - 1)];
+            lo[1] = gbnd[(gglane ? 4 : 2) * NB + i1]; hi[1] = gbnd[(gglane ? 5 : 3) * NB + i1];
+        }
         // slack-equation-feasible start (same rule as the oracle): s*z = mu0, mu_s from z + Z s - lam - mu_s = 0
         // (floored), t = max(r0 + s, t0), lam = mu0 / t
-        double st[6][6];
 #pragma unroll
-        for (int rr = 0; rr < 3; rr++)
+        for (int rr = 0; rr < 2; rr++)
 #pragma unroll
             for (int sd = 0; sd < 2; sd++) {
                 const int k = rr * 2 + sd;
+                const bool on = rr ? on1 : on0;
                 const double eps = sd ? -1.0 : 1.0, bnd = sd ? hi[rr] : lo[rr];
                 const double r0v = eps * (dval[rr] - bnd);
                 const double z = pen(rr, sd, 0), Z = pen(rr, sd, 1);
@@ -331,20 +341,17 @@ __global__ void __launch_bounds__(64, 1) nmpc_rti_kernel(const KArgs ka)
                 double ms = z + Z * s0 - lam;
                 const double msf = 1e-2 * ka.mu0 / s0;
                 if (ms < msf) ms = msf;
-                st[0][k] = s0; st[1][k] = t; st[2][k] = lam; st[3][k] = ms;
-                st[4][k] = z + Z * s0 - lam - ms;
-                st[5][k] = t - r0v - s0;
+                // slots without a row keep a neutral state (never read into any reduction)
+                ROWF(0, k) = on ? s0 : 1.0; ROWF(1, k) = on ? t : 1.0; ROWF(2, k) = on ? lam : 1.0; ROWF(3, k) = on ? ms : 1.0;
+                ROWF(4, k) = on ? z + Z * s0 - lam - ms : 0.0;
+                ROWF(5, k) = on ? t - r0v - s0 : 0.0;
             }
-#pragma unroll
-        for (int f = 0; f < 6; f++)
-#pragma unroll
-            for (int k = 0; k < 6; k++) ROWF(f, k) = st[f][k];
         wsync();          // the aliased condensing scratch (sD, sU0) has been consumed
     }
 
     // initial stationarity residual r_v = q - C'(lam_l - lam_u)   (v = 0)
     wsync();
-    publish(ROWF(2, 0) - ROWF(2, 1), ROWF(2, 2) - ROWF(2, 3), ROWF(2, 4) - ROWF(2, 5), sWh);
+    publish(ROWF(2, 0) - ROWF(2, 1), ROWF(2, 2) - ROWF(2, 3), sWh);
     {
         double c0, c1;
         ctw(c0, c1);
@@ -364,19 +371,20 @@ __global__ void __launch_bounds__(64, 1) nmpc_rti_kernel(const KArgs ka)
         double gap;
         {
             double ls = fmax(fabs(rv0), fabs(rv1)), li = 0.0, lcmp = 0.0, lg = 0.0;
-            double gsum[3];
+            double gsum[2];
 #pragma unroll
-            for (int rr = 0; rr < 3; rr++) {
+            for (int rr = 0; rr < 2; rr++) {
                 gsum[rr] = 0.0;
+                const bool on = rr ? on1 : on0;
 #pragma unroll
                 for (int sd = 0; sd < 2; sd++) {
                     const int k = rr * 2 + sd;
                     const double s_ = ROWF(0, k), t_ = ROWF(1, k), l_ = ROWF(2, k), m_ = ROWF(3, k);
-                    ls = fmax(ls, rowlane ? fabs(ROWF(4, k)) : 0.0);
-                    li = fmax(li, rowlane ? fabs(ROWF(5, k)) : 0.0);
+                    ls = fmax(ls, on ? fabs(ROWF(4, k)) : 0.0);
+                    li = fmax(li, on ? fabs(ROWF(5, k)) : 0.0);
                     const double c1 = t_ * l_, c2 = s_ * m_;
-                    lcmp = fmax(lcmp, rowlane ? fmax(c1, c2) : 0.0);
-                    lg += rowlane ? c1 + c2 : 0.0;
+                    lcmp = fmax(lcmp, on ? fmax(c1, c2) : 0.0);
+                    lg += on ? c1 + c2 : 0.0;
                     // gamma = 1 / (t/l + 1/(Z + mu/s)) with two reciprocals instead of four: 1/(Z + mu/s) = s / (Z s + mu)
                     const double iDs = s_ * frcp(pen(rr, sd, 1) * s_ + m_);
                     gsum[rr] += l_ * frcp(t_ + l_ * iDs);
@@ -388,7 +396,7 @@ __global__ void __launch_bounds__(64, 1) nmpc_rti_kernel(const KArgs ka)
             if (res_stat <= ka.tol_stat * qn && res_ineq <= ka.tol_ineq && res_comp <= ka.tol_comp) { qp_status = 0; break; }
             if (it >= ka.iter_max) { qp_status = 1; break; }
             TUM_TICK(2);
-            publish(gsum[0], gsum[1], gsum[2], sGamH);
+            publish(gsum[0], gsum[1], sGamH);
         }
         // ---- M = H + C' Gamma C, one 16x16 tile at a time (single accumulator live)
         {
@@ -593,7 +601,7 @@ __global__ void __launch_bounds__(64, 1) nmpc_rti_kernel(const KArgs ka)
 
         TUM_TICK(4);
         // ---- predictor / corrector
-        double cross1[6], cross2[6];                 // dT*dL and dS*dMu of the affine step
+        double cross1[4], cross2[4];                 // dT*dL and dS*dMu of the affine step
         double dv0 = 0.0, dv1 = 0.0, alpha = 1.0, sigma = 0.0;
         const double invd0 = frcp(sM[lpk(lane, lane)]), invd1 = frcp(sM[lpk(lane1, lane1)]) * ((lane < 16) ? 1.0 : 0.0);
 #pragma unroll 1
@@ -601,9 +609,9 @@ __global__ void __launch_bounds__(64, 1) nmpc_rti_kernel(const KArgs ka)
             const double tau = (pass == 1) ? fmax(sigma * gap, 0.1 * ka.tol_comp) : 0.0;
             // row phase B1: rhs weights  w = gam_l*rho_l - gam_u*rho_u
             {
-                double w[3];
+                double w[2];
 #pragma unroll
-                for (int rr = 0; rr < 3; rr++) {
+                for (int rr = 0; rr < 2; rr++) {
                     w[rr] = 0.0;
 #pragma unroll
                     for (int sd = 0; sd < 2; sd++) {
@@ -619,7 +627,7 @@ __global__ void __launch_bounds__(64, 1) nmpc_rti_kernel(const KArgs ka)
                         w[rr] += sd ? -gr : gr;
                     }
                 }
-                publish(w[0], w[1], w[2], sWh);
+                publish(w[0], w[1], sWh);
             }
             double b0, b1;
             ctw(b0, b1);
@@ -720,13 +728,14 @@ __global__ void __launch_bounds__(64, 1) nmpc_rti_kernel(const KArgs ka)
                 if (lane < 16) dbg[19860 + 64 + lane] = dv1;
             }
             // row phase B2: C*dv for this lane's rows, step in (s,t,lam,mu), step length
-            double cdv[3];
+            double cdv[2];
             {
-                const double xo = rowlane ? sDv[2 * rl_ + 1] : 0.0;
-                cdv[0] = xo;
-                cdv[1] = dt * wave_prefix(xo, lane);
+                const double xo = boxlane ? sDv[2 * lane + 1] : 0.0;
+                const double pfx = dt * wave_prefix(xo, lane);
                 // gg rows: row s has 2s entries (up to 80). Rows 17..40 are split in two halves of s entries, the second
-                // half goes to the otherwise idle lanes 40..63, so no lane walks more than 40 entries.
+                // half goes to lanes 40..63, so no lane walks more than 40 entries; the row sums then travel through LDS
+                // (the weight buffer is free between the right-hand side and the next publish) to the lanes that own
+                // the gg rows.
                 const int hs = (lane < NMAX) ? lane + 1 : lane - 23;              // row handled (lanes 40..63: rows 17..40)
                 const int cstart = (lane < NMAX) ? 0 : hs, ncol = (hs <= 16) ? 2 * hs : hs;
                 const bool hon = hs <= N;
@@ -741,15 +750,20 @@ __global__ void __launch_bounds__(64, 1) nmpc_rti_kernel(const KArgs ka)
                 }
                 const double part = a0 + a1;
                 const double other = __shfl(part, (lane + 24) & 63, 64);           // second half of rows 17..40
-                cdv[2] = (lane >= 16 && lane < NMAX) ? part + other : part;
+                wsync();
+                if (lane < NMAX) sWh[lane] = (lane >= 16) ? part + other : part;    // C dv of gg row lane+1
+                wsync();
+                cdv[0] = gglane ? sWh[2 * gj] : xo;
+                cdv[1] = gglane ? sWh[2 * gj + 1] : pfx;
             }
             double amax = 1.0, lmu = 0.0;
-            double dcur[4][6];
+            double dcur[4][4];
 #pragma unroll
-            for (int rr = 0; rr < 3; rr++)
+            for (int rr = 0; rr < 2; rr++)
 #pragma unroll
                 for (int sd = 0; sd < 2; sd++) {
                     const int k = rr * 2 + sd;
+                    const bool on = rr ? on1 : on0;
                     const double eps = sd ? -1.0 : 1.0;
                     const double s_ = ROWF(0, k), t_ = ROWF(1, k), l_ = ROWF(2, k), m_ = ROWF(3, k);
                     const double is_ = frcp(s_), il_ = frcp(l_), it_ = frcp(t_), im_ = frcp(m_);
@@ -763,20 +777,22 @@ __global__ void __launch_bounds__(64, 1) nmpc_rti_kernel(const KArgs ka)
                     const double dsl = (dl - rsk - rc2 * is_) * iDs;
                     const double dm = (-rc2 - m_ * dsl) * is_;
                     const double dtt = (-rc1 - t_ * dl) * il_;
-                    dcur[0][k] = dsl; dcur[1][k] = dtt; dcur[2][k] = dl; dcur[3][k] = dm;
+                    dcur[0][k] = on ? dsl : 0.0; dcur[1][k] = on ? dtt : 0.0; dcur[2][k] = on ? dl : 0.0; dcur[3][k] = on ? dm : 0.0;
                     // largest alpha keeping x + alpha*dx >= 0:  alpha <= 1 / max(-dx/x)
                     double q = fmax(fmax(-dsl * is_, -dtt * it_), fmax(-dl * il_, -dm * im_));
-                    q = rowlane ? q : 0.0;
+                    q = on ? q : 0.0;
                     amax = fmax(amax, q);                 // amax temporarily holds max(1, max ratio)
-                    if (pass == 0) { cross1[k] = dtt * dl; cross2[k] = dsl * dm; }
+                    if (pass == 0) { cross1[k] = on ? dtt * dl : 0.0; cross2[k] = on ? dsl * dm : 0.0; }
                 }
             amax = frcp(wave_max(amax));                  // = min(1, 1/max ratio)
             if (pass == 0) {
 #pragma unroll
-                for (int k = 0; k < 6; k++)
-                    lmu += (ROWF(1, k) + amax * dcur[1][k]) * (ROWF(2, k) + amax * dcur[2][k])
-                         + (ROWF(0, k) + amax * dcur[0][k]) * (ROWF(3, k) + amax * dcur[3][k]);
-                const double mu_aff = wave_sum(rowlane ? lmu : 0.0) * inv_npairs;
+                for (int k = 0; k < 4; k++) {
+                    const double pr = (ROWF(1, k) + amax * dcur[1][k]) * (ROWF(2, k) + amax * dcur[2][k])
+                                    + (ROWF(0, k) + amax * dcur[0][k]) * (ROWF(3, k) + amax * dcur[3][k]);
+                    lmu += ((k < 2) ? on0 : on1) ? pr : 0.0;
+                }
+                const double mu_aff = wave_sum(lmu) * inv_npairs;
                 const double ratio = mu_aff * frcp(gap);
                 sigma = ratio * ratio * ratio;
                 // safeguard (same rule as the oracle): an affine step blocked almost immediately makes the second-order
@@ -784,14 +800,14 @@ __global__ void __launch_bounds__(64, 1) nmpc_rti_kernel(const KArgs ka)
                 // 50 iterations); drop them for this iteration
                 if (amax < 0.1) {
 #pragma unroll
-                    for (int k = 0; k < 6; k++) { cross1[k] = 0.0; cross2[k] = 0.0; }
+                    for (int k = 0; k < 4; k++) { cross1[k] = 0.0; cross2[k] = 0.0; }
                 }
             } else {
                 alpha = (amax >= 1.0) ? 1.0 : 0.995 * amax;
                 if (alpha >= 1e-12) {
                     const double om_ = 1.0 - alpha;
 #pragma unroll
-                    for (int k = 0; k < 6; k++) {
+                    for (int k = 0; k < 4; k++) {
 #pragma unroll
                         for (int f = 0; f < 4; f++) ROWF(f, k) += alpha * dcur[f][k];
                         ROWF(4, k) *= om_; ROWF(5, k) *= om_;
@@ -813,22 +829,26 @@ __global__ void __launch_bounds__(64, 1) nmpc_rti_kernel(const KArgs ka)
     // ------------------------------------------------------------ phase 4: expand, full step, cost
     // slack part of the cost and the slack outputs first: the row state is about to be overwritten by X, U
     double cl = 0.0;
-    if (rowlane) {
+    {
 #pragma unroll
-        for (int rr = 0; rr < 3; rr++)
+        for (int rr = 0; rr < 2; rr++)
 #pragma unroll
             for (int sd = 0; sd < 2; sd++) {
                 const double sv = ROWF(0, rr * 2 + sd);
-                cl += pen(rr, sd, 0) * sv + 0.5 * pen(rr, sd, 1) * sv * sv;
+                const double c = pen(rr, sd, 0) * sv + 0.5 * pen(rr, sd, 1) * sv * sv;
+                cl += (rr ? on1 : on0) ? c : 0.0;
             }
         if (ka.slack) {
             double *sl = ka.slack + (size_t)b * 6 * N;
             // order: [lower: box_k (N) | (bx_k, h_k) k=1..N] then the same for upper
 #pragma unroll
             for (int sd = 0; sd < 2; sd++) {
-                sl[sd * 3 * N + lane] = ROWF(0, 0 + sd);
-                sl[sd * 3 * N + N + 2 * lane] = ROWF(0, 2 + sd);
-                sl[sd * 3 * N + N + 2 * lane + 1] = ROWF(0, 4 + sd);
+                if (boxlane) {
+                    sl[sd * 3 * N + lane] = ROWF(0, 0 + sd);
+                    sl[sd * 3 * N + N + 2 * lane] = ROWF(0, 2 + sd);
+                }
+                if (gglane && on0) sl[sd * 3 * N + N + 2 * (stg0 - 1) + 1] = ROWF(0, 0 + sd);
+                if (gglane && on1) sl[sd * 3 * N + N + 2 * (stg1 - 1) + 1] = ROWF(0, 2 + sd);
             }
         }
     }
