@@ -369,6 +369,7 @@ __global__ void __launch_bounds__(64, 1) nmpc_rti_kernel(const KArgs ka)
         TUM_LANE_DEFS
         // ---- row phase A: residual norms, gamma
         double gap;
+        double rD[4], rG[4];       // D = 1/(Z s + mu), G = 1/(t + lam s D) of every row side: fixed until the end of the iteration
         {
             double ls = fmax(fabs(rv0), fabs(rv1)), li = 0.0, lcmp = 0.0, lg = 0.0;
             double gsum[2];
@@ -386,8 +387,9 @@ __global__ void __launch_bounds__(64, 1) nmpc_rti_kernel(const KArgs ka)
                     lcmp = fmax(lcmp, on ? fmax(c1, c2) : 0.0);
                     lg += on ? c1 + c2 : 0.0;
                     // gamma = 1 / (t/l + 1/(Z + mu/s)) with two reciprocals instead of four: 1/(Z + mu/s) = s / (Z s + mu)
-                    const double iDs = s_ * frcp(pen(rr, sd, 1) * s_ + m_);
-                    gsum[rr] += l_ * frcp(t_ + l_ * iDs);
+                    rD[k] = frcp(pen(rr, sd, 1) * s_ + m_);
+                    rG[k] = frcp(t_ + l_ * s_ * rD[k]);
+                    gsum[rr] += l_ * rG[k];
                 }
             }
             res_stat = wave_max(ls); res_ineq = wave_max(li); res_comp = wave_max(lcmp);
@@ -619,8 +621,7 @@ __global__ void __launch_bounds__(64, 1) nmpc_rti_kernel(const KArgs ka)
                         const double s_ = ROWF(0, k), t_ = ROWF(1, k), l_ = ROWF(2, k), m_ = ROWF(3, k);
                         // gam * rho with gam = l G, G = 1/(t + l s D), D = 1/(Z s + mu):
                         //   gam * rho = G * (rc1 - l * (rt + (rs s + rc2) D))       (two reciprocals instead of four)
-                        const double D = frcp(pen(rr, sd, 1) * s_ + m_);
-                        const double G = frcp(t_ + l_ * s_ * D);
+                        const double D = rD[k], G = rG[k];
                         double rc1 = t_ * l_, rc2 = s_ * m_;
                         if (pass == 1) { rc1 += cross1[k] - tau; rc2 += cross2[k] - tau; }
                         const double gr = G * (rc1 - l_ * (ROWF(5, k) + (ROWF(4, k) * s_ + rc2) * D));
@@ -767,8 +768,8 @@ __global__ void __launch_bounds__(64, 1) nmpc_rti_kernel(const KArgs ka)
                     const double eps = sd ? -1.0 : 1.0;
                     const double s_ = ROWF(0, k), t_ = ROWF(1, k), l_ = ROWF(2, k), m_ = ROWF(3, k);
                     const double is_ = frcp(s_), il_ = frcp(l_), it_ = frcp(t_), im_ = frcp(m_);
-                    const double iDs = frcp(pen(rr, sd, 1) + m_ * is_);
-                    const double gam = frcp(t_ * il_ + iDs);
+                    const double iDs = s_ * rD[k];
+                    const double gam = l_ * rG[k];
                     double rc1 = t_ * l_, rc2 = s_ * m_;
                     if (pass == 1) { rc1 += cross1[k] - tau; rc2 += cross2[k] - tau; }
                     const double rsk = ROWF(4, k);
