@@ -495,3 +495,26 @@ def test_device_result_summary_slab():
     X, U = s.get_iterate()
     assert np.array_equal(r[:, :2], U[3:B - 3, 0]) and np.array_equal(r[:, 2], s.get_cost()[3:B - 3])
     assert np.array_equal(r[:, 3], s.get_stats("status")[3:B - 3]) and np.array_equal(r[:, 4], s.get_stats("qp_iter")[3:B - 3])
+
+
+@pytest.mark.gpu
+def test_nan_input_fails_only_its_own_instance():
+    """A NaN in one instance's x0 makes THAT instance return status 4 (acados: QP failure) with its iterate left as it
+    was; every other instance of the batch is solved exactly as without it."""
+    from tum_control_amd.workloads import nominal_batch
+    N, B = 40, 12
+    x0, yref = nominal_batch(B, N=N, seed=4)
+    s = _mk(N, B)
+    s.set_x0(x0); s.set_yref_all(yref); s.cold_start(); assert s.solve() == 0
+    Xg, Ug = s.get_iterate()
+    bad = x0.copy(); bad[5, 3] = np.nan
+    s.set_x0(bad); s.cold_start()
+    X0, U0 = s.get_iterate()
+    assert s.solve() == 4
+    st = s.get_stats("status")
+    assert st[5] == 4 and (np.delete(st, 5) == 0).all()
+    X, U = s.get_iterate()
+    keep = np.arange(B) != 5
+    assert np.array_equal(X[keep], Xg[keep]) and np.array_equal(U[keep], Ug[keep])
+    assert np.array_equal(U[5], U0[5])                       # the failed instance keeps its inputs
+    assert np.array_equal(np.isnan(X[5]), np.isnan(X0[5]))   # and its (NaN-carrying) states
