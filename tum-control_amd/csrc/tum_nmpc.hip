@@ -43,6 +43,14 @@ extern "C" const char *tum_ocp_last_error(void) { return g_err.c_str(); }
 extern "C" int tum_ocp_batch(const tum_ocp *c) { return c->batch; }
 extern "C" int tum_ocp_horizon(const tum_ocp *c) { return c->N; }
 
+// temporary device buffer that cannot leak on an early error return
+struct DevTmp {
+    void *p = nullptr;
+    ~DevTmp() { if (p) (void)hipFree(p); }
+    hipError_t alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 8); }
+    template <typename T> T *as() const { return (T *)p; }
+};
+
 template <typename T>
 static hipError_t dalloc(T **p, size_t n) { hipError_t e = hipMalloc((void **)p, n * sizeof(T)); if (e == hipSuccess) e = hipMemset(*p, 0, n * sizeof(T)); return e; }
 
@@ -484,16 +492,16 @@ extern "C" int tum_ocp_set_x0_fanout(tum_ocp *c, const double *pose, const doubl
     if (!c || !pose || (S > 0 && !offs)) return fail("null argument");
     const int S1 = S + 1;
     if (P < 1 || S < 0 || (long long)P * S1 != c->batch) return fail("set_x0_fanout: P*(S+1) must equal the batch size");
-    double *dp = nullptr, *dofs = nullptr;
-    HIPCHK(hipMalloc((void **)&dp, sizeof(double) * P * NX));
-    HIPCHK(hipMalloc((void **)&dofs, sizeof(double) * (S > 0 ? S : 1) * NX));
+    DevTmp tp, to;
+    HIPCHK(tp.alloc(sizeof(double) * P * NX));
+    HIPCHK(to.alloc(sizeof(double) * (S > 0 ? S : 1) * NX));
+    double *dp = tp.as<double>(), *dofs = to.as<double>();
     HIPCHK(hipMemcpyAsync(dp, pose, sizeof(double) * P * NX, hipMemcpyHostToDevice, c->stream));
     if (S > 0) HIPCHK(hipMemcpyAsync(dofs, offs, sizeof(double) * S * NX, hipMemcpyHostToDevice, c->stream));
     const int n = P * S1 * NX;
     hipLaunchKernelGGL(sigma_fanout_kernel, dim3((n + 255) / 256), dim3(256), 0, c->stream, c->dx0, dp, dofs, P, S1);
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(c->stream));
-    (void)hipFree(dp); (void)hipFree(dofs);
     return 0;
 }
 
@@ -508,11 +516,10 @@ extern "C" int tum_pce_moments(tum_ocp *c, const char *field, int stage, const d
     if (f == "x") { if (stage < 0 || stage > N) return fail("pce_moments: stage"); m = NX; src = c->dX; rec = (size_t)(N + 1) * NX; off = (size_t)stage * NX; }
     else if (f == "u") { if (stage < 0 || stage >= N) return fail("pce_moments: stage"); m = NU; src = c->dU; rec = (size_t)N * NU; off = (size_t)stage * NU; }
     else return fail("pce_moments: unknown field '" + f + "'");
-    double *dV = nullptr, *dA = nullptr, *dm = nullptr, *dv = nullptr;
-    HIPCHK(hipMalloc((void **)&dV, sizeof(double) * c->batch * m));
-    HIPCHK(hipMalloc((void **)&dA, sizeof(double) * L * S));
-    HIPCHK(hipMalloc((void **)&dm, sizeof(double) * P * m));
-    HIPCHK(hipMalloc((void **)&dv, sizeof(double) * P * m));
+    DevTmp tV, tA, tm, tv;
+    HIPCHK(tV.alloc(sizeof(double) * c->batch * m)); HIPCHK(tA.alloc(sizeof(double) * L * S));
+    HIPCHK(tm.alloc(sizeof(double) * P * m)); HIPCHK(tv.alloc(sizeof(double) * P * m));
+    double *dV = tV.as<double>(), *dA = tA.as<double>(), *dm = tm.as<double>(), *dv = tv.as<double>();
     HIPCHK(hipMemcpy2DAsync(dV, (size_t)m * 8, src + off, rec * 8, (size_t)m * 8, c->batch, hipMemcpyDeviceToDevice, c->stream));
     HIPCHK(hipMemcpyAsync(dA, A, sizeof(double) * L * S, hipMemcpyHostToDevice, c->stream));
     hipLaunchKernelGGL(pce_moments_kernel, dim3((P * m + 127) / 128), dim3(128), 0, c->stream, dV, dA, P, S1, m, L, dm, dv);
@@ -520,7 +527,6 @@ extern "C" int tum_pce_moments(tum_ocp *c, const char *field, int stage, const d
     HIPCHK(hipMemcpyAsync(mean, dm, sizeof(double) * P * m, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipMemcpyAsync(var, dv, sizeof(double) * P * m, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
-    (void)hipFree(dV); (void)hipFree(dA); (void)hipFree(dm); (void)hipFree(dv);
     return 0;
 }
 
@@ -532,9 +538,13 @@ extern "C" int tum_ocp_r2_backoff(tum_ocp *c, const double *Sigma0, const double
     if (!c->solved) return fail("r2_backoff: no solve yet");
     if (uph < 1) return fail("r2_backoff: uncertainty propagation horizon < 1");
     const int N = c->N;
-    double *dS = nullptr, *dB = nullptr, *dbo = nullptr;
-    HIPCHK(hipMalloc((void **)&dS, 64 * 8)); HIPCHK(hipMalloc((void **)&dB, 64 * 8));
-    if (backoff) { HIPCHK(hipMalloc((void **)&dbo, sizeof(double) * (size_t)c->batch * N * 2)); HIPCHK(hipMemsetAsync(dbo, 0, sizeof(double) * (size_t)c->batch * N * 2, c->stream)); }
+    DevTmp tS, tB, tbo;
+    HIPCHK(tS.alloc(64 * 8)); HIPCHK(tB.alloc(64 * 8));
+    double *dS = tS.as<double>(), *dB = tB.as<double>(), *dbo = nullptr;
+    if (backoff) {
+        HIPCHK(tbo.alloc(sizeof(double) * (size_t)c->batch * N * 2)); dbo = tbo.as<double>();
+        HIPCHK(hipMemsetAsync(dbo, 0, sizeof(double) * (size_t)c->batch * N * 2, c->stream));
+    }
     HIPCHK(hipMemcpyAsync(dS, Sigma0, 64 * 8, hipMemcpyHostToDevice, c->stream));
     HIPCHK(hipMemcpyAsync(dB, BWB, 64 * 8, hipMemcpyHostToDevice, c->stream));
     hipLaunchKernelGGL(r2_backoff_kernel, dim3((c->batch + 3) / 4), dim3(256), 0, c->stream, c->dqpin, c->dX, c->dbnd, c->ka.mp,
@@ -542,7 +552,6 @@ extern "C" int tum_ocp_r2_backoff(tum_ocp *c, const double *Sigma0, const double
     HIPCHK(hipGetLastError());
     if (backoff) HIPCHK(hipMemcpyAsync(backoff, dbo, sizeof(double) * (size_t)c->batch * N * 2, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
-    (void)hipFree(dS); (void)hipFree(dB); if (dbo) (void)hipFree(dbo);
     return 0;
 }
 
@@ -579,12 +588,10 @@ extern "C" int tum_planner_emulate(const double *track, int n_track, const doubl
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return fail("no HIP device: libtumnmpc has no CPU fallback");
     HIPCHK(hipSetDevice(device));
-    double *dt = nullptr, *dp = nullptr, *dout = nullptr; int *dcl = nullptr, *derr = nullptr;
-    HIPCHK(hipMalloc((void **)&dt, sizeof(double) * 4 * n_track));
-    HIPCHK(hipMalloc((void **)&dp, sizeof(double) * 2 * P));
-    HIPCHK(hipMalloc((void **)&dout, sizeof(double) * 4 * (size_t)P * n_points));
-    HIPCHK(hipMalloc((void **)&dcl, sizeof(int) * P));
-    HIPCHK(hipMalloc((void **)&derr, sizeof(int)));
+    DevTmp tt, tp, tout, tcl, terr;
+    HIPCHK(tt.alloc(sizeof(double) * 4 * n_track)); HIPCHK(tp.alloc(sizeof(double) * 2 * P));
+    HIPCHK(tout.alloc(sizeof(double) * 4 * (size_t)P * n_points)); HIPCHK(tcl.alloc(sizeof(int) * P)); HIPCHK(terr.alloc(sizeof(int)));
+    double *dt = tt.as<double>(), *dp = tp.as<double>(), *dout = tout.as<double>(); int *dcl = tcl.as<int>(), *derr = terr.as<int>();
     HIPCHK(hipMemset(derr, 0, sizeof(int)));
     HIPCHK(hipMemcpy(dt, track, sizeof(double) * 4 * n_track, hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(dp, pose, sizeof(double) * 2 * P, hipMemcpyHostToDevice));
@@ -596,7 +603,6 @@ extern "C" int tum_planner_emulate(const double *track, int n_track, const doubl
     HIPCHK(hipMemcpy(&err, derr, sizeof(int), hipMemcpyDeviceToHost));
     HIPCHK(hipMemcpy(ref_out, dout, sizeof(double) * 4 * (size_t)P * n_points, hipMemcpyDeviceToHost));
     if (closest_out) HIPCHK(hipMemcpy(closest_out, dcl, sizeof(int) * P, hipMemcpyDeviceToHost));
-    (void)hipFree(dt); (void)hipFree(dp); (void)hipFree(dout); (void)hipFree(dcl); (void)hipFree(derr);
     if (err) return fail("planner_emulate: extracted segment longer than PLAN_MAXM points");
     return 0;
 }
