@@ -37,24 +37,25 @@ __device__ __forceinline__ int acados_status(int qp_status) { return (qp_status 
     const bool v0on = lane < nv, v1on = (lane < 16) && (64 + lane < nv); \
     const bool odd = lane & 1; \
     const int lane1 = 64 + lc; \
-    auto ctw = [&](double &o0, double &o1) { \
+    auto ctw = [&](double &o0, double &o1) {   /* C' w for this lane's columns */ \
         double a0 = (odd && v0on) ? sWb[lane >> 1] + dt * sSfx[(lane >> 1) + 1] : 0.0; \
         double a1 = (odd && v1on) ? sWb[32 + (lane >> 1)] + dt * sSfx[32 + (lane >> 1) + 1] : 0.0; \
-        const int s00 = (lane >> 1) + 1; \
-        double e0 = 0.0; \
-    _Pragma("unroll 8") \
-        for (int s = 1; s <= NMAX; s += 2) { \
-            const double c0 = sCh[hoff(s) + lane]; \
-            const double c1 = sCh[hoff(s + 1) + lane]; \
-            a0 += ((s >= s00 && s <= N) ? c0 : 0.0) * sWh[s - 1]; \
-            e0 += ((s + 1 >= s00 && s + 1 <= N) ? c1 : 0.0) * sWh[s]; \
+        /* gg rows, fully unrolled: one base register, immediate offsets, column j belongs to row s iff j < 2s (a compile \
+           time bound per s: no mask at all for s >= 32); rows beyond N are zero-filled after condensing and carry weight 0 */ \
+        const double *pc = sCh + lane; \
+        double e0 = 0.0, e1 = 0.0, e2 = 0.0; \
+    _Pragma("unroll") \
+        for (int s = 1; s <= NMAX; s++) { \
+            const double c = pc[hoff(s)]; \
+            const double t_ = ((lane < 2 * s) ? c : 0.0) * sWh[s - 1]; \
+            if ((s & 3) == 0) a0 += t_; else if ((s & 3) == 1) e0 += t_; else if ((s & 3) == 2) e1 += t_; else e2 += t_; \
         } \
-        a0 += e0; \
+        a0 += (e0 + e1) + e2; \
+        const double *pc1 = sCh + lane1; \
     _Pragma("unroll") \
         for (int s = 33; s <= NMAX; s++) { \
-            const bool on = (lane < 16) && (lane1 < 2 * s) && (s <= N); \
-            const double c = sCh[hoff(s) + lane1]; \
-            a1 += (on ? c : 0.0) * sWh[s - 1]; \
+            const double c = pc1[hoff(s)]; \
+            a1 += ((lane1 < 2 * s) ? c : 0.0) * sWh[s - 1]; \
         } \
         o0 = v0on ? a0 : 0.0; o1 = v1on ? a1 : 0.0; \
     }; \
@@ -252,6 +253,9 @@ __global__ void __launch_bounds__(64, 1) nmpc_rti_kernel(const KArgs ka)
         for (int k = 16; k < N && k < 24; k++) stage_body(k, std::integral_constant<int, 3>());
         for (int k = 24; k < N && k < 32; k++) stage_body(k, std::integral_constant<int, 4>());
         for (int k = 32; k < N; k++) stage_body(k, std::integral_constant<int, 5>());
+        // rows of the packed gg block beyond the horizon: zero (they are multiplied by zero weights later; they must be finite)
+        for (int s = N + 1; s <= NMAX; s++)
+            for (int c = lane; c < 2 * s; c += 64) sCh[hoff(s) + c] = 0.0;
     }
     // input cost (R) and padding on the diagonal, gradient of the input cost
 #pragma unroll
