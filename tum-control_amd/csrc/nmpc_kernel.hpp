@@ -742,16 +742,16 @@ __global__ void __launch_bounds__(64, 1) nmpc_rti_kernel(const KArgs ka)
                 // (the weight buffer is free between the right-hand side and the next publish) to the lanes that own
                 // the gg rows.
                 const int hs = (lane < NMAX) ? lane + 1 : lane - 23;              // row handled (lanes 40..63: rows 17..40)
-                const int cstart = (lane < NMAX) ? 0 : hs, ncol = (hs <= 16) ? 2 * hs : hs;
-                const bool hon = hs <= N;
+                const int cstart = (lane < NMAX) ? 0 : hs;
+                const int ncol = (hs <= N) ? ((hs <= 16) ? 2 * hs : hs) : 0;       // 0: no such row at this horizon
                 const double *ch = sCh + hoff(hs) + cstart;
                 const double *dvp = sDv + cstart;
                 double a0 = 0.0, a1 = 0.0;
-#pragma unroll 10
+#pragma unroll
                 for (int i = 0; i < NMAX; i += 2) {
                     const double x0_ = ch[i], x1_ = ch[i + 1];
-                    a0 += ((hon && i < ncol) ? x0_ : 0.0) * dvp[i];
-                    a1 += ((hon && i + 1 < ncol) ? x1_ : 0.0) * dvp[i + 1];
+                    a0 += ((i < ncol) ? x0_ : 0.0) * dvp[i];
+                    a1 += ((i + 1 < ncol) ? x1_ : 0.0) * dvp[i + 1];
                 }
                 const double part = a0 + a1;
                 const double other = __shfl(part, (lane + 24) & 63, 64);           // second half of rows 17..40
