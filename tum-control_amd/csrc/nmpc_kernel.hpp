@@ -410,16 +410,15 @@ __global__ void __launch_bounds__(64, 1) nmpc_rti_kernel(const KArgs ka)
             // (row s has 2s entries). chv = the row entries (B operand), the A operand is chv * gamma(row).
             double gch[10];
 #pragma unroll
-            for (int c = 0; c < 10; c++) gch[c] = sGamH[(4 * c + lq < N) ? 4 * c + lq : 0] * ((4 * c + lq < N) ? 1.0 : 0.0);
+            for (int c = 0; c < 10; c++) gch[c] = sGamH[4 * c + lq];        // rows beyond the horizon were published as 0
             double chv[10][NT];
 #pragma unroll
             for (int T = 0; T < NT; T++)
 #pragma unroll
                 for (int c = 2 * T; c < 10; c++) {
-                    const int s = 4 * c + lq + 1;                     // <= 40 always
-                    const bool on = (16 * T + lc < 2 * s) && (s <= N);
-                    const double v = sCh[hoff(s) + (on ? 16 * T + lc : 0)];
-                    chv[c][T] = on ? v : 0.0;
+                    const int s = 4 * c + lq + 1;                     // <= 40 always; rows beyond the horizon are zero
+                    const double v = sCh[hoff(s) + 16 * T + lc];     // in range for every lane, masked below
+                    chv[c][T] = (16 * T + lc < 2 * s) ? v : 0.0;
                 }
             const double dt2 = dt * dt;
             // steering-angle rows (structured): element (row, col), both odd, gets dt^2 * suffix(max(row, col)); in a tile
