@@ -486,7 +486,7 @@ __global__ void __launch_bounds__(64, 1) nmpc_rti_kernel(const KArgs ka)
                 for (int jj = 0; jj < 4; jj++) {
                     const int rg = 16 * I + lq + 4 * jj, cg = 16 * J + lc;
                     const bool valid = (I > J) || (rg >= cg);
-                    const double v = sM[lpk(rg, valid ? cg : rg)];
+                    const double v = sM[lpk(rg, cg)];             // right of the diagonal this reads the next packed row: masked
                     T[I][jj] = valid ? v : 0.0;
                 }
 #pragma unroll
@@ -555,7 +555,7 @@ __global__ void __launch_bounds__(64, 1) nmpc_rti_kernel(const KArgs ka)
                     const double dsel = (lq == 0) ? d0 : (lq == 1) ? d1 : (lq == 2) ? d2 : d3;
                     const int kcol = c0 + lq;
                     const int rowJ = 16 * J + lc;
-                    const double bl = sM[lpk(rowJ, rowJ > kcol ? kcol : 0)];
+                    const double bl = sM[lpk(rowJ, kcol)];        // (finite whatever it is; selected below)
                     const double bval = (rowJ > kcol) ? bl : ((rowJ == kcol) ? 1.0 : 0.0);
 #pragma unroll
                     for (int I = J; I < NT; I++) {
