@@ -479,37 +479,36 @@ __global__ void __launch_bounds__(64, 1) nmpc_rti_kernel(const KArgs ka)
         bool chol_ok = true;
 #pragma unroll
         for (int J = 0; J < NT; J++) {
+            // Register tiles of the ROW panel A_JI (rows of block J, columns of block I; by symmetry the same numbers as
+            // the column panel): element jj of lane (lq, lc) is A[16J + lq + 4jj][16I + lc]. In this orientation the four
+            // columns of micro-panel m are element m of EVERY lane, so publishing them is one unmasked store per tile with
+            // a trivial address (rb[I] + column), and the diagonal tile is simply kept symmetric.
             d4 T[NT];
 #pragma unroll
             for (int I = J; I < NT; I++) {
 #pragma unroll
                 for (int jj = 0; jj < 4; jj++) {
-                    const int rg = 16 * I + lq + 4 * jj, cg = 16 * J + lc;
-                    const bool valid = (I > J) || (rg >= cg);
-                    const double v = sM[lpk(rg, cg)];             // right of the diagonal this reads the next packed row: masked
-                    T[I][jj] = valid ? v : 0.0;
+                    const int r = lq + 4 * jj;
+                    if (I > J) T[I][jj] = sM[rb[I] + 16 * J + r];
+                    else { const int hi = (r > lc) ? r : lc, lo = (r > lc) ? lc : r; T[I][jj] = sM[lpk(16 * J + hi, 16 * J + lo)]; }
                 }
-#pragma unroll
-                for (int K = 0; K < J; K++)
-#pragma unroll
-                    for (int kc = 0; kc < 4; kc++) {
-                        const int kk = 16 * K + 4 * kc + lq;
-                        T[I] = mfma(-sM[rb[I] + kk] * sM[lpk(kk, kk)], sM[rb[J] + kk], T[I]);
-                    }
             }
+#pragma unroll
+            for (int K = 0; K < J; K++)
+#pragma unroll
+                for (int kc = 0; kc < 4; kc++) {
+                    const int kk = 16 * K + 4 * kc + lq;
+                    const double aJ = -sM[rb[J] + kk] * sM[lpk(kk, kk)];
+#pragma unroll
+                    for (int I = J; I < NT; I++) T[I] = mfma(aJ, sM[rb[I] + kk], T[I]);
+                }
 #pragma unroll
             for (int m = 0; m < 4; m++) {
                 const int c0 = 16 * J + 4 * m;
                 // (a) publish columns c0..c0+3 of the panel tiles (rows >= column) for the lane = row readers
-                if ((lc >> 2) == m) {
 #pragma unroll
-                    for (int I = J; I < NT; I++)
-#pragma unroll
-                        for (int jj = 0; jj < 4; jj++) {
-                            const int rg = 16 * I + lq + 4 * jj, cg = 16 * J + lc;
-                            if ((I > J) || (rg >= cg)) sM[lpk(rg, cg)] = T[I][jj];
-                        }
-                }
+                for (int I = J; I < NT; I++)
+                    sM[(I > J || lc >= 4 * m + lq) ? rb[I] + c0 + lq : (O_DUMMY - O_M)] = T[I][m];
                 wsync();
                 // (b) 4x4 diagonal block, L D L' on uniform values
                 const int r1 = lpk(c0 + 1, c0), r2 = lpk(c0 + 2, c0), r3 = lpk(c0 + 3, c0);
@@ -562,7 +561,7 @@ __global__ void __launch_bounds__(64, 1) nmpc_rti_kernel(const KArgs ka)
                         double aval;
                         if (I == J) aval = bval;
                         else aval = sM[rb[I] + kcol];                 // rows of later blocks are always below
-                        T[I] = mfma(-aval * dsel, bval, T[I]);
+                        T[I] = mfma(-bval * dsel, aval, T[I]);
                     }
                 }
             }
