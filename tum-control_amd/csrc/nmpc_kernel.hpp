@@ -418,7 +418,8 @@ __global__ void __launch_bounds__(64, 1) nmpc_rti_kernel(const KArgs ka)
                 for (int c = 2 * T; c < 10; c++) {
                     const int s = 4 * c + lq + 1;                     // <= 40 always; rows beyond the horizon are zero
                     const double v = sCh[hoff(s) + 16 * T + lc];     // in range for every lane, masked below
-                    chv[c][T] = (16 * T + lc < 2 * s) ? v : 0.0;
+                    // the row-length mask only bites for the first two chunks of a tile column (16T + 15 < 2(4c + 1) beyond)
+                    chv[c][T] = (c >= 2 * T + 2) ? v : ((16 * T + lc < 2 * s) ? v : 0.0);
                 }
             const double dt2 = dt * dt;
             // steering-angle rows (structured): element (row, col), both odd, gets dt^2 * suffix(max(row, col)); in a tile
