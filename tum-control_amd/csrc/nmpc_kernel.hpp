@@ -274,7 +274,7 @@ __global__ void __launch_bounds__(64, 1) nmpc_rti_kernel(const KArgs ka)
     }
     }   // Wd, We
 
-    if ((ka.flags & 2) && b < 4) {   // debug dump of the condensed QP
+    if (PROF && (ka.flags & 2) && b < 4) {   // debug dump of the condensed QP
         double *dbg = ka.dbg + (size_t)b * ka.dbg_stride;
 #pragma unroll
         for (int K = 0; K < NT; K++)
@@ -465,7 +465,7 @@ __global__ void __launch_bounds__(64, 1) nmpc_rti_kernel(const KArgs ka)
                 }
         }
         wsync();
-        if ((ka.flags & 2) && b < 4 && it == 0) {
+        if (PROF && (ka.flags & 2) && b < 4 && it == 0) {
             double *dbg = ka.dbg + (size_t)b * ka.dbg_stride;
             for (int i = lane; i < LPK; i += 64) dbg[13300 + i] = sM[i];
         }
@@ -568,7 +568,7 @@ __global__ void __launch_bounds__(64, 1) nmpc_rti_kernel(const KArgs ka)
             }
         }
         if (!chol_ok) { qp_status = 3; break; }
-        if ((ka.flags & 2) && b < 4 && it == 0) {
+        if (PROF && (ka.flags & 2) && b < 4 && it == 0) {
             double *dbg = ka.dbg + (size_t)b * ka.dbg_stride;
             for (int i = lane; i < LPK; i += 64) dbg[16540 + i] = sM[i];
         }
@@ -636,7 +636,7 @@ __global__ void __launch_bounds__(64, 1) nmpc_rti_kernel(const KArgs ka)
             double b0, b1;
             ctw(b0, b1);
             b0 = v0on ? -rv0 - b0 : 0.0; b1 = v1on ? -rv1 - b1 : 0.0;
-            if ((ka.flags & 2) && b < 4 && it == 0 && pass == 0) {
+            if (PROF && (ka.flags & 2) && b < 4 && it == 0 && pass == 0) {
                 double *dbg = ka.dbg + (size_t)b * ka.dbg_stride;
                 dbg[19780 + lane] = b0;
                 if (lane < 16) dbg[19780 + 64 + lane] = b1;
@@ -726,7 +726,7 @@ __global__ void __launch_bounds__(64, 1) nmpc_rti_kernel(const KArgs ka)
             sDv[lane] = dv0;
             if (lane < 16) sDv[64 + lane] = dv1;
             wsync();
-            if ((ka.flags & 2) && b < 4 && it == 0 && pass == 0) {
+            if (PROF && (ka.flags & 2) && b < 4 && it == 0 && pass == 0) {
                 double *dbg = ka.dbg + (size_t)b * ka.dbg_stride;
                 dbg[19860 + lane] = dv0;
                 if (lane < 16) dbg[19860 + 64 + lane] = dv1;

@@ -316,7 +316,8 @@ static int launch(tum_ocp *c, bool events = true)
     // longest-first schedule from the previous solve's iteration counts (only matters when the batch is more than one
     // round of resident wavefronts)
     c->ka.order = (c->lpt && c->order_valid && c->batch > 1024) ? c->dorder : nullptr;
-    if (c->ka.flags & 4) hipLaunchKernelGGL(nmpc_rti_kernel<true>, dim3(c->batch), dim3(64), LDS_BYTES, c->stream, c->ka);
+    // the instrumented instantiation carries the phase timers (flag 4) and the debug dump (flag 2)
+    if (c->ka.flags & 6) hipLaunchKernelGGL(nmpc_rti_kernel<true>, dim3(c->batch), dim3(64), LDS_BYTES, c->stream, c->ka);
     else hipLaunchKernelGGL(nmpc_rti_kernel<false>, dim3(c->batch), dim3(64), LDS_BYTES, c->stream, c->ka);
     HIPCHK(hipGetLastError());
     if (events) HIPCHK(hipEventRecord(c->ev1, c->stream));
