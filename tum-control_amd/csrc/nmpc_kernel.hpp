@@ -477,7 +477,7 @@ __global__ void __launch_bounds__(64, 1) nmpc_rti_kernel(const KArgs ka)
         //      tiles; (2) four 4-column micro-panels: the 4x4 diagonal block is factorised redundantly by
         //      every lane from LDS broadcasts (all scalars stay in VGPRs: no readlane / SGPR traffic), every
         //      row below solves its 4 entries against it, and the rest of the panel gets a rank-4 MFMA update.
-        bool chol_ok = true;
+        double dmin = 1.0;                               // smallest pivot seen (the matrix must be positive definite)
 #pragma unroll
         for (int J = 0; J < NT; J++) {
             // Register tiles of the ROW panel A_JI (rows of block J, columns of block I; by symmetry the same numbers as
@@ -537,7 +537,7 @@ __global__ void __launch_bounds__(64, 1) nmpc_rti_kernel(const KArgs ka)
                 const double y32 = a32 - l30 * a20 - l31 * y21;
                 const double l32 = y32 * i2;
                 const double d3 = a33 - l30 * a30 - l31 * y31 - l32 * y32, i3 = frcp(d3);
-                if (!(d0 > 1e-300) || !(d1 > 1e-300) || !(d2 > 1e-300) || !(d3 > 1e-300)) chol_ok = false;
+                dmin = fmin(dmin, fmin(fmin(d0, d1), fmin(d2, d3)));      // (fmin drops NaNs: those surface in the residual test)
                 // forward substitution of every row below against L4 (y = L * d), then L = y / d
                 e1 -= l10 * e0; e2 -= l20 * e0 + l21 * e1; e3 -= l30 * e0 + l31 * e1 + l32 * e2;
                 if (rin) { sM[rbase] = e0 * i0; sM[rbase + 1] = e1 * i1; sM[rbase + 2] = e2 * i2; sM[rbase + 3] = e3 * i3; }
@@ -567,7 +567,7 @@ __global__ void __launch_bounds__(64, 1) nmpc_rti_kernel(const KArgs ka)
                 }
             }
         }
-        if (!chol_ok) { qp_status = 3; break; }
+        if (!(dmin > 1e-300)) { qp_status = 3; break; }
         if (PROF && (ka.flags & 2) && b < 4 && it == 0) {
             double *dbg = ka.dbg + (size_t)b * ka.dbg_stride;
             for (int i = lane; i < LPK; i += 64) dbg[16540 + i] = sM[i];
