@@ -396,10 +396,14 @@ __global__ void __launch_bounds__(64, 1) nmpc_rti_kernel(const KArgs ka)
                     gsum[rr] += l_ * rG[k];
                 }
             }
-            res_stat = wave_max(ls); res_ineq = wave_max(li); res_comp = wave_max(lcmp);
+            // convergence: "no lane above its tolerance" is one ballot; the three norms themselves are only reported, so
+            // their wave-wide maxima are taken once after the loop (res_* hold this lane's values until then)
+            res_stat = ls; res_ineq = li; res_comp = lcmp;
             gap = wave_sum(lg) * inv_npairs;
-            if (!(res_stat == res_stat) || !(gap == gap)) { qp_status = 3; break; }
-            if (res_stat <= ka.tol_stat * qn && res_ineq <= ka.tol_ineq && res_comp <= ka.tol_comp) { qp_status = 0; break; }
+            const bool lane_nan = !(ls == ls) || !(li == li) || !(lcmp == lcmp);
+            if (__any(lane_nan) || !(gap == gap)) { qp_status = 3; break; }
+            const bool lane_open = (ls > ka.tol_stat * qn) || (li > ka.tol_ineq) || (lcmp > ka.tol_comp);
+            if (!__any(lane_open)) { qp_status = 0; break; }
             if (it >= ka.iter_max) { qp_status = 1; break; }
             TUM_TICK(2);
             publish(gsum[0], gsum[1], sGamH);
@@ -827,6 +831,7 @@ __global__ void __launch_bounds__(64, 1) nmpc_rti_kernel(const KArgs ka)
         wsync();
     }
     const int status = acados_status(qp_status);
+    res_stat = wave_max(res_stat); res_ineq = wave_max(res_ineq); res_comp = wave_max(res_comp);
     TUM_LANE_DEFS
 
     TUM_TICK(8);
