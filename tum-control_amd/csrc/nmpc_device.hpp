@@ -177,6 +177,28 @@ __device__ __forceinline__ void wsync()
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+// sin and cos together for moderate arguments (|x| < ~1e5: tyre-model angles, steering angle, yaw): two-constant
+// Cody-Waite reduction by pi/2 with FMAs, then the classic minimax kernels on [-pi/4, pi/4] (coefficients of the
+// fdlibm k_sin / k_cos kernels, < 1 ulp there). About a third of the instructions of the general-range library routine,
+// which matters because the linearisation evaluates it 48 times per lane.
+__device__ __forceinline__ void fast_sincos(double x, double *sn, double *cs)
+{
+    const double n = rint(x * 6.36619772367581382433e-01);              // x * 2/pi
+    double r = fma(-n, 1.57079632679489655800e+00, x);
+    r = fma(-n, 6.12323399573676603587e-17, r);
+    const int q = (int)n & 3;
+    const double z = r * r;
+    const double ps = fma(z, fma(z, fma(z, fma(z, fma(z, 1.58969099521155010221e-10, -2.50507602534068634195e-08),
+                       2.75573137070700676789e-06), -1.98412698298579493134e-04), 8.33333333332248946124e-03), -1.66666666666666324348e-01);
+    const double s = fma(r * z, ps, r);
+    const double pc = fma(z, fma(z, fma(z, fma(z, fma(z, -1.13596475577881948265e-11, 2.08757232129817482790e-09),
+                       -2.75573143513906633035e-07), 2.48015872894767294178e-05), -1.38888888888741095749e-03), 4.16666666666666019037e-02);
+    const double c = fma(z * z, pc, fma(-0.5, z, 1.0));
+    const double s_ = (q & 1) ? c : s, c_ = (q & 1) ? s : c;
+    *sn = (q & 2) ? -s_ : s_;
+    *cs = ((q + 1) & 2) ? -c_ : c_;
+}
+
 // ---------------------------------------------------------------- model
 // Core of the single-track ODE: derivatives of (vlong, vlat, yawrate) and their partials w.r.t.
 // (vl, vt, r, delta, a). pred_model_dynamic_stm_pacejka.py:118-175; derivative conventions follow
@@ -188,7 +210,7 @@ __device__ __forceinline__ void pacejka(double B, double C, double D, double E, 
     const double inner = x1 - E * (x1 - at1);
     const double th = atan(inner);
     double sn, cs;
-    sincos(C * th, &sn, &cs);
+    fast_sincos(C * th, &sn, &cs);
     Fy = D * sn;
     dFy = D * cs * C * frcp(1.0 + inner * inner) * (1.0 - E + E * frcp(1.0 + x1 * x1)) * B;
 }
@@ -239,7 +261,7 @@ __device__ __forceinline__ void stm_core(const Model &p, double vl, double vt, d
     const double Fyr_r = dFyr * alr_r * cgr;
     const double Fyr_a = Fyr_lat * dcgr * p.m;
     double sd, cd;
-    sincos(de, &sd, &cd);
+    fast_sincos(de, &sd, &cd);
     const double im = p.inv_m;
     f[0] = (Fxr - p.ka * vl * vl - Fyf * sd + Fxf * cd) * im + vt * r;
     J[0][0] = (Fxr_vl - 2.0 * p.ka * vl - Fyf_vl * sd + Fxf_vl * cd) * im;
@@ -334,7 +356,7 @@ __device__ __forceinline__ void rk4_sens(const Model &p, const double x0[8], con
             double f[3], J[3][5];
             stm_core(p, vl, vt, r, de, a, f, J);
             double sn, cs;
-            sincos(psi, &sn, &cs);
+            fast_sincos(psi, &sn, &cs);
             double k[6];
             k[0] = vl * cs - vt * sn; k[1] = vl * sn + vt * cs; k[2] = r;
             k[3] = f[0]; k[4] = f[1]; k[5] = f[2];
