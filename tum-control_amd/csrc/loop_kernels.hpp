@@ -158,8 +158,8 @@ __device__ __forceinline__ void plant_xdot(const PlantModel &p, const double x[7
     const double Gf = fmin(fmax(Fx_f * p.invFmax_f, -0.98), 0.98), Gr = fmin(fmax(Fx_r * p.invFmax_r, -0.98), 0.98);
     const double Fy_f = Fy_f_lat * sqrt(1.0 - Gf * Gf), Fy_r = Fy_r_lat * sqrt(1.0 - Gr * Gr);
     double sy, cy, sd, cd;
-    sincos(yaw, &sy, &cy);
-    sincos(de, &sd, &cd);
+    fast_sincos(yaw, &sy, &cy);
+    fast_sincos(de, &sd, &cd);
     const double front = Fy_f * cd + Fx_f * sd;
     xd[0] = vl * cy - vt * sy;
     xd[1] = vl * sy + vt * cy;
