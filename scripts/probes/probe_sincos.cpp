@@ -3,6 +3,12 @@
 #include <cstdio>
 #include <cmath>
 #include "../../tum-control_amd/csrc/nmpc_device.hpp"
+__global__ void k2(const double *x, double *o, int n) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x; if (i >= n) return;
+    o[2 * i] = fabs(tum::fast_atan(x[i]) - atan(x[i]));
+    const double p = fabs(x[i]) + 1e-6;
+    o[2 * i + 1] = fabs(tum::fast_sqrt_pos(p) - sqrt(p)) / sqrt(p);
+}
 __global__ void k(const double *x, double *o, int n) {
     int i = blockIdx.x * blockDim.x + threadIdx.x; if (i >= n) return;
     double s, c, s2, c2; tum::fast_sincos(x[i], &s, &c); sincos(x[i], &s2, &c2);
@@ -20,6 +26,11 @@ int main() {
         hipMemcpy(ho, dout, 2 * n * 8, hipMemcpyDeviceToHost);
         for (int i = 0; i < 2 * n; i++) if (ho[i] > worst[r]) worst[r] = ho[i];
         printf("|x| < %g: max abs error vs sincos %.3e\n", ranges[r], worst[r]);
+        hipLaunchKernelGGL(k2, dim3(n / 256), dim3(256), 0, 0, dx, dout, n);
+        hipMemcpy(ho, dout, 2 * n * 8, hipMemcpyDeviceToHost);
+        double wa = 0, wsq = 0;
+        for (int i = 0; i < n; i++) { if (ho[2 * i] > wa) wa = ho[2 * i]; if (ho[2 * i + 1] > wsq) wsq = ho[2 * i + 1]; }
+        printf("|x| < %g: atan max abs error %.3e, sqrt max rel error %.3e\n", ranges[r], wa, wsq);
         hipFree(dx); hipFree(dout);
     }
     return 0;
