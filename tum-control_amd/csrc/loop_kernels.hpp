@@ -149,14 +149,16 @@ __device__ __forceinline__ void plant_xdot(const PlantModel &p, const double x[7
     double al_f = 0.0, al_r = 0.0;
     if (vl > 0.001) {
         const double ivl = 1.0 / vl;
-        al_f = de - atan((vt + p.lf * r) * ivl);
-        al_r = atan((p.lr * r - vt) * ivl);
+        al_f = de - fast_atan((vt + p.lf * r) * ivl);
+        al_r = fast_atan((p.lr * r - vt) * ivl);
     }
     const double xf = p.Bf * al_f, xr = p.Br * al_r;
-    const double Fy_f_lat = p.Df * sin(p.Cf * atan(xf - p.Ef * (xf - atan(xf))));
-    const double Fy_r_lat = p.Dr * sin(p.Cr * atan(xr - p.Er * (xr - atan(xr))));
+    double sf, sr_, unused;
+    fast_sincos(p.Cf * fast_atan(xf - p.Ef * (xf - fast_atan(xf))), &sf, &unused);
+    fast_sincos(p.Cr * fast_atan(xr - p.Er * (xr - fast_atan(xr))), &sr_, &unused);
+    const double Fy_f_lat = p.Df * sf, Fy_r_lat = p.Dr * sr_;
     const double Gf = fmin(fmax(Fx_f * p.invFmax_f, -0.98), 0.98), Gr = fmin(fmax(Fx_r * p.invFmax_r, -0.98), 0.98);
-    const double Fy_f = Fy_f_lat * sqrt(1.0 - Gf * Gf), Fy_r = Fy_r_lat * sqrt(1.0 - Gr * Gr);
+    const double Fy_f = Fy_f_lat * fast_sqrt_pos(1.0 - Gf * Gf), Fy_r = Fy_r_lat * fast_sqrt_pos(1.0 - Gr * Gr);
     double sy, cy, sd, cd;
     fast_sincos(yaw, &sy, &cy);
     fast_sincos(de, &sd, &cd);
