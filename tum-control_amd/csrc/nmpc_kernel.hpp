@@ -865,12 +865,21 @@ __global__ void __launch_bounds__(64, 1) nmpc_rti_kernel(const KArgs ka)
     sDv[lane] = v0;
     if (lane < 16) sDv[64 + lane] = v1;
     // bring back the iterate and the linearisation records
-    for (int i = lane; i < (N + 1) * NX; i += 64) sX[i] = gX[i];
-    for (int i = lane; i < NVP; i += 64) sU1[i] = (i < nv) ? gU[i] : 0.0;
+    // (compile-time trip counts: every global load of these copies is in flight before the first one is consumed)
     {
+        constexpr int NXI = ((NMAX + 1) * NX + 63) / 64, NWI = (NMAX * ABS + 63) / 64;
         const double *ws = ka.ws + (size_t)b * WS_DOUBLES;
-        for (int i = lane; i < N * ABS; i += 64) sAB[i] = ws[i];
+        double tx[NXI], tw[NWI];
+#pragma unroll
+        for (int j = 0; j < NXI; j++) { const int i = lane + 64 * j; tx[j] = (i < (N + 1) * NX) ? gX[i] : 0.0; }
+#pragma unroll
+        for (int j = 0; j < NWI; j++) { const int i = lane + 64 * j; tw[j] = (i < N * ABS) ? ws[i] : 0.0; }
+#pragma unroll
+        for (int j = 0; j < NXI; j++) { const int i = lane + 64 * j; if (i < (N + 1) * NX) sX[i] = tx[j]; }
+#pragma unroll
+        for (int j = 0; j < NWI; j++) { const int i = lane + 64 * j; if (i < N * ABS) sAB[i] = tw[j]; }
     }
+    for (int i = lane; i < NVP; i += 64) sU1[i] = (i < nv) ? gU[i] : 0.0;
     wsync();
     if (status == 0) {
         // dx_0 = x0 - X_0 ; dx_{k+1} = A_k dx_k + B_k du_k + b_k, lane i < 8 carries row i of dx:
