@@ -99,8 +99,17 @@ __global__ void __launch_bounds__(64, 1) nmpc_rti_kernel(const KArgs ka)
     long long pacc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     long long tprev = __builtin_readcyclecounter();
     // ------------------------------------------------------------ phase 0: loads
-    for (int i = lane; i < (N + 1) * NX; i += 64) sX[i] = gX[i];
-    for (int i = lane; i < NVP; i += 64) sU0[i] = (i < nv) ? gU[i] : 0.0;
+    {   // compile-time trip counts: all loads in flight together
+        constexpr int NXI = ((NMAX + 1) * NX + 63) / 64;
+        double tx[NXI];
+#pragma unroll
+        for (int j = 0; j < NXI; j++) { const int i = lane + 64 * j; tx[j] = (i < (N + 1) * NX) ? gX[i] : 0.0; }
+        const double u0_ = (lane < nv) ? gU[lane] : 0.0, u1_ = (lane < 16 && 64 + lane < nv) ? gU[64 + lane] : 0.0;
+#pragma unroll
+        for (int j = 0; j < NXI; j++) { const int i = lane + 64 * j; if (i < (N + 1) * NX) sX[i] = tx[j]; }
+        sU0[lane] = u0_;
+        if (lane < 16) sU0[64 + lane] = u1_;
+    }
     if (lane < 36) sPen[lane] = gpen[lane];
     wsync();
 
