@@ -875,10 +875,16 @@ __global__ void __launch_bounds__(64, 1) nmpc_rti_kernel(const KArgs ka)
     if (lane < 16) sDv[64 + lane] = v1;
     // bring back the iterate and the linearisation records
     // (compile-time trip counts: every global load of these copies is in flight before the first one is consumed)
+    double gx0r, Wc[10], yrc[6];
     {
         constexpr int NXI = ((NMAX + 1) * NX + 63) / 64, NWI = (NMAX * ABS + 63) / 64;
         const double *ws = ka.ws + (size_t)b * WS_DOUBLES;
         double tx[NXI], tw[NWI];
+        gx0r = gx0[(lane < 8) ? lane : 0];                   // (used by the expansion and the cost below)
+#pragma unroll
+        for (int i = 0; i < 10; i++) Wc[i] = gW[i];
+#pragma unroll
+        for (int i = 0; i < 6; i++) yrc[i] = gyref[((lane <= N) ? lane : 0) * 6 + i];
 #pragma unroll
         for (int j = 0; j < NXI; j++) { const int i = lane + 64 * j; tx[j] = (i < (N + 1) * NX) ? gX[i] : 0.0; }
 #pragma unroll
@@ -897,7 +903,7 @@ __global__ void __launch_bounds__(64, 1) nmpc_rti_kernel(const KArgs ka)
         const int ri = (lane < 8) ? lane : 0;                 // lanes >= 8 shadow row 0 and never store
         const bool core = ri < 6;
         const double diag = (ri < 3 || ri >= 6) ? 1.0 : 0.0;
-        double dxi = gx0[ri] - sX[ri];
+        double dxi = gx0r - sX[ri];
         wsync();
         if (lane < 8) sX[lane] += dxi;
         for (int k = 0; k < N; k++) {
@@ -926,9 +932,9 @@ __global__ void __launch_bounds__(64, 1) nmpc_rti_kernel(const KArgs ka)
     if (lane <= N) {
         double Wd[6], We[4], yr[6];
 #pragma unroll
-        for (int i = 0; i < 6; i++) { Wd[i] = gW[i]; yr[i] = gyref[lane * 6 + i]; }
+        for (int i = 0; i < 6; i++) { Wd[i] = Wc[i]; yr[i] = yrc[i]; }
 #pragma unroll
-        for (int i = 0; i < 4; i++) We[i] = gW[6 + i];
+        for (int i = 0; i < 4; i++) We[i] = Wc[6 + i];
         const int k = lane;
         const double sc = (k < N) ? dt : 1.0;
         double acc = 0.0, e;
