@@ -624,6 +624,13 @@ __global__ void __launch_bounds__(64, 1) nmpc_rti_kernel(const KArgs ka)
         const double invd0 = frcp(sM[lpk(lane, lane)]), invd1 = frcp(sM[lpk(lane1, lane1)]) * ((lane < 16) ? 1.0 : 0.0);
 #pragma unroll 1
         for (int pass = 0; pass < 2; pass++) {
+            // the lane-derived predicates / addresses are derived afresh for the solve passes: kept from the top of the
+            // iteration they would sit in (spilled) SGPRs across the whole factorisation
+            int lane_p = lane_outer;
+            asm volatile("" : "+v"(lane_p));
+            const int lane = lane_p;
+            const int lq = lane >> 4, lc = lane & 15;
+            TUM_LANE_DEFS
             const double tau = (pass == 1) ? fmax(sigma * gap, 0.1 * ka.tol_comp) : 0.0;
             // row phase B1: rhs weights  w = gam_l*rho_l - gam_u*rho_u
             {
