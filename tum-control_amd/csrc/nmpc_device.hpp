@@ -7,8 +7,12 @@
 //                        over the 4 cost rows of every stage, accumulated with v_mfma_f64_16x16x4_f64
 //                        into 15 register-resident 16x16 tiles (upper triangle of the 80x80 H)
 //   phase 3  dense IPM   Mehrotra predictor-corrector on the condensed soft-constrained QP; per
-//                        iteration  M = H + C' Gamma C  (MFMA SYRK), blocked Cholesky (MFMA trailing
-//                        updates, register panel factorisation with readlane broadcasts), two solves
+//                        iteration  M = H + C' Gamma C  (MFMA SYRK into the packed lower triangle in
+//                        LDS), LDL' over 4-column micro-panels held as row-panel register tiles (MFMA
+//                        rank-4 trailing updates), in-place inverses of the five 16x16 diagonal blocks,
+//                        then two 16-wide block substitutions (DPP row shifts inside a block, LDS
+//                        broadcast across blocks). The row state (s, t, lam, mu and residuals of the
+//                        six soft rows of a stage) stays in registers, two slots x two sides per lane
 //   phase 4  expand      dx trajectory, full step, cost at the new iterate
 // Everything between the initial loads and the final stores lives in LDS / registers.
 //

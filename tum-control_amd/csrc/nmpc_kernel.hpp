@@ -313,8 +313,8 @@ __global__ void __launch_bounds__(64, 1) nmpc_rti_kernel(const KArgs ka)
     }
     TUM_TICK(1);
     // ------------------------------------------------------------ phase 3: interior point
-    // Row state lives in LDS between the (short) row phases so that the long factorisation / substitution
-    // phases only carry the 15 H tiles in registers. sRow[(field*6 + row*2 + side)*NMAX + lane],
+    // Row state lives in registers: rowst[field][slot*2 + side], two row slots and both sides per lane
+    // (box rows on lanes 0..39, the gg rows on lanes 40..59, see TUM_LANE_DEFS).
     // fields: 0 s, 1 t, 2 lam, 3 mu, 4 rs (slack stationarity residual), 5 rt (primal residual).
     double v0 = 0.0, v1 = 0.0, rv0, rv1, qn;
     double rowst[6][4];      // IPM row state of this lane: [s, t, lam, mu, rs, rt][slot*2+side]
