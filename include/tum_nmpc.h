@@ -138,6 +138,17 @@ int tum_ocp_set_x0_fanout(tum_ocp *c, const double *pose, const double *offs, in
  * c = A v with the L x S least-squares PCE matrix A (row-major, host), mean = c_0, var = sum_{k>=1} c_k^2, for
  * every component of field "x" (8) / "u" (2) at `stage` of the current iterate. mean, var: P x m (host). */
 int tum_pce_moments(tum_ocp *c, const char *field, int stage, const double *A, int L, int S, double *mean, double *var);
+/* The coupled SNMPC OCP (Stochastic_NMPC/SNMPC_acados_settings.py:19-320 with the DISCRETE stacked dynamics
+ * of Stochastic_NMPC/pred_model_dynamic_disc.py:121-220): turns the capsule (created with nsub = 1) into the solver the
+ * reference builds at SNMPC_acados_settings.py:318 and calls at SNMPC_class.py:198. The stacked state is the nominal
+ * copy followed by `ns` sample copies (nx = 8 (ns+1)); Apce (L x ns, row-major, host) and `uph` replace the per-stage
+ * parameter vector p = [A_pce.flatten(), risk_parameter, stop_flag] (SNMPC_class.py:103-104,124: stop_flag = 1 from
+ * stage uph on); gamma is the chance-constraint level (kappa = sqrt((1-gamma)/gamma), SNMPC_acados_settings.py:187).
+ * Afterwards set/get "x" and constraints_set "lbx"/"ubx" at stage 0 also accept 8 (ns+1) values, cold_start copies the
+ * stacked x0 to every stage (SNMPC_class.py:126-127), and solve runs prologue + fused kernel + epilogue. The cost acts
+ * on the nominal copy with |v| as the speed row; the gg limits are looked up at |v|. 0 <= uph <= min(N, 31). */
+int tum_ocp_snmpc_attach(tum_ocp *c, int ns, int L, const double *Apce, int uph, double gamma);
+int tum_ocp_snmpc_samples(const tum_ocp *c);   /* ns, or 0 for a nominal capsule */
 /* R2NMPC constraint tightening after a solve (Reduced_Robustified_NMPC_class.py:286-366): propagates
  * Sigma_{k+1} = A_k Sigma_k A_k' + B W B' with the A_k of the last linearisation (needs store_qp_in) and rewrites the
  * capsule's lbx/ubx (steering angle) and uh (gg circle) of stages 1..N-1 for the NEXT solve.

@@ -703,3 +703,331 @@ void oracle_solve_batch_cold(const oracle_ocp *tmpl, int nb, const double *x0, c
         free(o);
     }
 }
+
+/* ================================================================== coupled SNMPC OCP
+ *
+ * One acados SQP-RTI step of the reference's stochastic NMPC, i.e. of `acados_solver.solve()` at
+ *   Model_Predictive_Controller/Stochastic_NMPC/SNMPC_class.py:198
+ * for the OCP of Stochastic_NMPC/SNMPC_acados_settings.py:19-320 with the DISCRETE dynamics of
+ *   Stochastic_NMPC/pred_model_dynamic_disc.py:121-220.
+ * State: the nominal copy followed by n_s sample copies of the 8 single-track states (nx = 8 (n_s+1));
+ * ONE shared input. Per stage k the parameter vector carries the PCE matrix A (L x n_s, row-major,
+ * SNMPC_class.py:124) and stop_flag_k (1 from the uncertainty propagation horizon on, SNMPC_class.py:103-104):
+ *   stop_flag = 0: sample i advances by ONE RK4 step of length Ts (pred_model_dynamic_disc.py:185-203),
+ *                  nominal_next = sum_i A[0,i] sample_next_i                     (:208-210)
+ *                  h = E + kappa sqrt(Var) of the sample values of the gg circle (SNMPC_acados_settings.py:116-133,187)
+ *   stop_flag = 1: samples are frozen, the nominal copy takes its own RK4 step, h = h(nominal copy).
+ * Cost on the nominal copy with |v| as the speed row (:153-154); bounds as in the nominal OCP (:208-218),
+ * no h row at stage 0 (dims nh_0 = 0, acados_ocp_SNMPC.json:704-740).
+ * Deliberately the generic dense formulation: 8(n_s+1) x 8(n_s+1) stage matrices, dense condensing.
+ * PARITY UNPINNED by reference outputs: the reference holds no SNMPC solver outputs with a known
+ * configuration (ACC24 logs: weights/track configuration not recorded); pinned only
+ *  - against the nominal restatement above (n_s copies with zero spread / stop_flag = 1 everywhere), and
+ *  - against finite differences of its own nonlinear functions (tests/test_snmpc.py).
+ */
+#define NSMAX 16                 /* max samples */
+#define NLMAX 16                 /* max PCE terms */
+#define NXS   (NX * (NSMAX + 1))
+
+typedef struct {
+    int N, ns, L;
+    double dt, kappa;
+    stm_model model;
+    ipm_opts ipm;
+    double X[(NMAXH + 1) * NXS], U[NMAXH * NU];      /* X: stage-major, (ns+1)*8 per stage */
+    double x0[NXS];
+    double yref[(NMAXH + 1) * 6], W[(NMAXH + 1) * 6];
+    double lbu[NMAXH], ubu[NMAXH], lbx[NMAXH + 1], ubx[NMAXH + 1], lh[NMAXH + 1], uh[NMAXH + 1];
+    double zl[(NMAXH + 1) * 3], zu[(NMAXH + 1) * 3], Zl[(NMAXH + 1) * 3], Zu[(NMAXH + 1) * 3];
+    double Apce[NLMAX * NSMAX];                      /* L x ns, row-major */
+    double stop[NMAXH + 1];
+    double sl[MMAX], su[MMAX], lam[2 * MMAX];
+    double hval[NMAXH + 1];                          /* constraint value per stage at the linearisation point */
+    double cost;
+    int qp_iter, status;
+    double res[3];
+} snmpc_ocp;
+
+snmpc_ocp *snmpc_create(int N, double dt, int ns, int L, double gamma)
+{
+    if (N < 1 || N > NMAXH || ns < 1 || ns > NSMAX || L < 1 || L > NLMAX) return NULL;
+    snmpc_ocp *o = calloc(1, sizeof(snmpc_ocp));
+    o->N = N; o->dt = dt; o->ns = ns; o->L = L;
+    o->kappa = sqrt((1.0 - gamma) / gamma);          /* SNMPC_acados_settings.py:187 */
+    o->ipm.iter_max = 50; o->ipm.tol_stat = 1e-8; o->ipm.tol_ineq = 1e-8; o->ipm.tol_comp = 1e-8;
+    o->ipm.mu0 = 0.1; o->ipm.t0 = 0.1; o->ipm.reg = 0.0;
+    return o;
+}
+void snmpc_free(snmpc_ocp *o) { free(o); }
+void snmpc_set_model(snmpc_ocp *o, const stm_model *m) { o->model = *m; }
+void snmpc_set_iter_max(snmpc_ocp *o, int it) { o->ipm.iter_max = it; }
+int snmpc_qp_iter(const snmpc_ocp *o) { return o->qp_iter; }
+int snmpc_status(const snmpc_ocp *o) { return o->status; }
+
+double *snmpc_field(snmpc_ocp *o, const char *name, int *len)
+{
+    const int N = o->N, nxs = NX * (o->ns + 1);
+#define F(nm, ptr, n) if (!strcmp(name, nm)) { *len = (n); return (ptr); }
+    F("X", o->X, (N + 1) * nxs) F("U", o->U, N * NU) F("x0", o->x0, nxs)
+    F("yref", o->yref, (N + 1) * 6) F("W", o->W, (N + 1) * 6)
+    F("lbu", o->lbu, N) F("ubu", o->ubu, N)
+    F("lbx", o->lbx, N + 1) F("ubx", o->ubx, N + 1) F("lh", o->lh, N + 1) F("uh", o->uh, N + 1)
+    F("zl", o->zl, (N + 1) * 3) F("zu", o->zu, (N + 1) * 3) F("Zl", o->Zl, (N + 1) * 3) F("Zu", o->Zu, (N + 1) * 3)
+    F("Apce", o->Apce, o->L * o->ns) F("stop", o->stop, N + 1) F("kappa", &o->kappa, 1)
+    F("sl", o->sl, 3 * N) F("su", o->su, 3 * N) F("lam", o->lam, 6 * N) F("hval", o->hval, N + 1)
+    F("cost", &o->cost, 1) F("res", o->res, 3)
+    F("ipm_tol", &o->ipm.tol_stat, 3) F("ipm_mu0", &o->ipm.mu0, 1) F("ipm_t0", &o->ipm.t0, 1) F("ipm_reg", &o->ipm.reg, 1)
+#undef F
+    *len = 0; return NULL;
+}
+
+/* gg circle with the limits looked up at |v| (SNMPC_acados_settings.py:60-67,100-113) */
+void oracle_h_vabs(const stm_model *p, const double *x, double *h, double *gh)
+{
+    const double vabs = sqrt(x[3] * x[3] + x[4] * x[4]);
+    double ax, dax, ay, day;
+    interp_lin(p->n_ggv, p->ggv_v, p->ggv_ax, vabs, &ax, &dax);
+    interp_lin(p->n_ggv, p->ggv_v, p->ggv_ay, vabs, &ay, &day);
+    if (x[7] < 0.0) { ax = -p->acc_min; dax = 0.0; }
+    const double alat = x[3] * x[5];
+    const double nlon = x[7] / ax, nlat = alat / ay;
+    *h = nlon * nlon + nlat * nlat;
+    if (gh) {
+        for (int i = 0; i < NX; i++) gh[i] = 0.0;
+        /* d/d|v| through the two tables, then |v| -> (vl, vt) */
+        const double dv = -2.0 * nlat * alat / (ay * ay) * day - 2.0 * nlon * x[7] / (ax * ax) * dax;
+        const double ivl = (vabs > 0.0) ? x[3] / vabs : 0.0, ivt = (vabs > 0.0) ? x[4] / vabs : 0.0;
+        gh[3] = 2.0 * nlat * x[5] / ay + dv * ivl;
+        gh[4] = dv * ivt;
+        gh[5] = 2.0 * nlat * x[3] / ay;
+        gh[7] = 2.0 * nlon / ax;
+    }
+}
+
+/* constraint value of one stage and its gradient w.r.t. the full stacked state (nxs) */
+static double snmpc_h(const snmpc_ocp *o, int k, const double *x, double *grad)
+{
+    const int ns = o->ns, L = o->L, nxs = NX * (ns + 1);
+    for (int i = 0; i < nxs; i++) grad[i] = 0.0;
+    if (o->stop[k] == 1.0) {
+        double h;
+        oracle_h_vabs(&o->model, x, &h, grad);
+        return h;
+    }
+    double hs[NSMAX], ghs[NSMAX][NX], c[NLMAX];
+    for (int i = 0; i < ns; i++) oracle_h_vabs(&o->model, x + NX * (i + 1), &hs[i], ghs[i]);
+    for (int l = 0; l < L; l++) {
+        c[l] = 0.0;
+        for (int i = 0; i < ns; i++) c[l] += o->Apce[l * ns + i] * hs[i];
+    }
+    double var = 0.0;
+    for (int l = 1; l < L; l++) var += c[l] * c[l];
+    const double sd = sqrt(var);
+    for (int i = 0; i < ns; i++) {
+        double w = o->Apce[i];                                   /* d mean / d h_i */
+        if (sd > 0.0) {
+            double acc = 0.0;
+            for (int l = 1; l < L; l++) acc += c[l] * o->Apce[l * ns + i];
+            w += o->kappa * acc / sd;
+        }
+        for (int r = 0; r < NX; r++) grad[NX * (i + 1) + r] = w * ghs[i][r];
+    }
+    return c[0] + o->kappa * sd;
+}
+
+static double snmpc_eval_cost(const snmpc_ocp *o)
+{
+    const int N = o->N, nxs = NX * (o->ns + 1);
+    double c = 0.0;
+    for (int k = 0; k <= N; k++) {
+        const double sc = (k < N) ? o->dt : 1.0;
+        const double *x = o->X + (size_t)k * nxs, *yr = o->yref + k * 6, *W = o->W + k * 6;
+        double y[6] = {x[0], x[1], wrap_yaw(x[2]), sqrt(x[3] * x[3] + x[4] * x[4]), 0, 0};
+        int ny = 4;
+        if (k < N) { y[4] = o->U[k * NU]; y[5] = o->U[k * NU + 1]; ny = 6; }
+        double acc = 0.0;
+        for (int i = 0; i < ny; i++) { double r = y[i] - yr[i]; acc += 0.5 * W[i] * r * r; }
+        c += sc * acc;
+    }
+    for (int i = 0; i < 3 * N; i++) {
+        int k, slot;
+        if (i < N) { k = i; slot = 0; } else { k = 1 + (i - N) / 2; slot = 1 + (i - N) % 2; }
+        const double sc = (k < N) ? o->dt : 1.0;
+        c += sc * (o->zl[k * 3 + slot] * o->sl[i] + 0.5 * o->Zl[k * 3 + slot] * o->sl[i] * o->sl[i]);
+        c += sc * (o->zu[k * 3 + slot] * o->su[i] + 0.5 * o->Zu[k * 3 + slot] * o->su[i] * o->su[i]);
+    }
+    return c;
+}
+
+static double *g_sdbg = NULL;    /* [H nv*nv | q nv | C m*nv | d m] of the next snmpc_solve calls (tests only) */
+void snmpc_set_debug(double *buf) { g_sdbg = buf; }
+
+int snmpc_solve(snmpc_ocp *o)
+{
+    const int N = o->N, ns = o->ns, nxs = NX * (ns + 1), nv = NU * N, m = 3 * N;
+    const double dt = o->dt;
+    double *Ab = calloc((size_t)N * nxs * nxs, sizeof(double));      /* stage matrices, dense */
+    double *Bb = calloc((size_t)N * nxs * NU, sizeof(double));
+    double *bb = calloc((size_t)N * nxs, sizeof(double));
+    double *G = calloc((size_t)(N + 1) * nxs * nv, sizeof(double));
+    double *g = calloc((size_t)(N + 1) * nxs, sizeof(double));
+    double *H = calloc((size_t)nv * nv, sizeof(double)), *q = calloc(nv, sizeof(double));
+    double *C = calloc((size_t)m * nv, sizeof(double)), *d = calloc(m, sizeof(double));
+    double *lb = calloc(6 * m, sizeof(double)), *ub = lb + m, *zl = ub + m, *zu = zl + m, *Zl = zu + m, *Zu = Zl + m;
+    double *v = calloc(nv, sizeof(double));
+    double *row = calloc(nv, sizeof(double));
+
+    /* 1. discrete dynamics and their Jacobians */
+    for (int k = 0; k < N; k++) {
+        const double *x = o->X + (size_t)k * nxs, *u = o->U + k * NU;
+        double *A = Ab + (size_t)k * nxs * nxs, *B = Bb + (size_t)k * nxs * NU;
+        double xn[NXS];
+        const int stop = (o->stop[k] == 1.0);
+        for (int i = 1; i <= ns; i++) {
+            if (!stop) {
+                double Ai[64], Bi[16];
+                oracle_rk4_sens(&o->model, x + NX * i, u, dt, 1, xn + NX * i, Ai, Bi);
+                for (int r = 0; r < NX; r++) {
+                    for (int c = 0; c < NX; c++) A[(NX * i + r) * nxs + NX * i + c] = Ai[r * NX + c];
+                    for (int c = 0; c < NU; c++) B[(NX * i + r) * NU + c] = Bi[r * NU + c];
+                }
+            } else {
+                for (int r = 0; r < NX; r++) { xn[NX * i + r] = x[NX * i + r]; A[(NX * i + r) * nxs + NX * i + r] = 1.0; }
+            }
+        }
+        if (stop) {
+            double A0[64], B0[16];
+            oracle_rk4_sens(&o->model, x, u, dt, 1, xn, A0, B0);
+            for (int r = 0; r < NX; r++) {
+                for (int c = 0; c < NX; c++) A[r * nxs + c] = A0[r * NX + c];
+                for (int c = 0; c < NU; c++) B[r * NU + c] = B0[r * NU + c];
+            }
+        } else {
+            /* nominal_next = first row of A_pce times the sample successors */
+            for (int r = 0; r < NX; r++) {
+                double acc = 0.0;
+                for (int i = 1; i <= ns; i++) acc += o->Apce[i - 1] * xn[NX * i + r];
+                xn[r] = acc;
+                for (int i = 1; i <= ns; i++) {
+                    const double a = o->Apce[i - 1];
+                    for (int c = 0; c < NX; c++) A[r * nxs + NX * i + c] = a * A[(NX * i + r) * nxs + NX * i + c];
+                    for (int c = 0; c < NU; c++) B[r * NU + c] += a * B[(NX * i + r) * NU + c];
+                }
+            }
+        }
+        for (int i = 0; i < nxs; i++) bb[(size_t)k * nxs + i] = xn[i] - o->X[(size_t)(k + 1) * nxs + i];
+    }
+    /* 4./5. condensing, dx_k = G_k v + g_k */
+    for (int i = 0; i < nxs; i++) g[i] = o->x0[i] - o->X[i];
+    for (int k = 0; k < N; k++) {
+        const double *A = Ab + (size_t)k * nxs * nxs, *B = Bb + (size_t)k * nxs * NU;
+        double *Gn = G + (size_t)(k + 1) * nxs * nv, *Gk = G + (size_t)k * nxs * nv;
+        for (int i = 0; i < nxs; i++) {
+            double acc = bb[(size_t)k * nxs + i];
+            for (int l = 0; l < nxs; l++) {
+                const double a = A[i * nxs + l];
+                if (a == 0.0) continue;
+                acc += a * g[(size_t)k * nxs + l];
+                for (int j = 0; j < NU * k; j++) Gn[(size_t)i * nv + j] += a * Gk[(size_t)l * nv + j];
+            }
+            for (int j = 0; j < NU; j++) Gn[(size_t)i * nv + NU * k + j] = B[i * NU + j];
+            g[(size_t)(k + 1) * nxs + i] = acc;
+        }
+    }
+    /* 2. Gauss-Newton cost on the nominal copy, y = [x, y, wrap(yaw), |v|, u] */
+    for (int k = 0; k <= N; k++) {
+        const double sc = (k < N) ? dt : 1.0;
+        const double *x = o->X + (size_t)k * nxs, *yr = o->yref + k * 6, *W = o->W + k * 6;
+        const double *Gk = G + (size_t)k * nxs * nv, *gk = g + (size_t)k * nxs;
+        const double vabs = sqrt(x[3] * x[3] + x[4] * x[4]);
+        const double y[4] = {x[0], x[1], wrap_yaw(x[2]), vabs};
+        for (int r = 0; r < 4; r++) {
+            const double w = sc * W[r];
+            double res = y[r] - yr[r];
+            if (r < 3) {
+                res += gk[r];
+                for (int j = 0; j < nv; j++) row[j] = Gk[(size_t)r * nv + j];
+            } else {
+                const double cl = (vabs > 0.0) ? x[3] / vabs : 0.0, ct = (vabs > 0.0) ? x[4] / vabs : 0.0;
+                res += cl * gk[3] + ct * gk[4];
+                for (int j = 0; j < nv; j++) row[j] = cl * Gk[(size_t)3 * nv + j] + ct * Gk[(size_t)4 * nv + j];
+            }
+            for (int j = 0; j < NU * k; j++) {
+                if (row[j] == 0.0) continue;
+                q[j] += w * res * row[j];
+                for (int l = 0; l <= j; l++) H[j * nv + l] += w * row[j] * row[l];
+            }
+        }
+        if (k < N)
+            for (int r = 0; r < NU; r++) {
+                const double w = sc * W[4 + r];
+                H[(NU * k + r) * nv + NU * k + r] += w;
+                q[NU * k + r] += w * (o->U[k * NU + r] - yr[4 + r]);
+            }
+    }
+    for (int j = 0; j < nv; j++) for (int l = 0; l < j; l++) H[l * nv + j] = H[j * nv + l];
+    /* 3. constraints, rows [bu_k k=0..N-1 | (bx_k, h_k) k=1..N] */
+    for (int k = 0; k < N; k++) {
+        C[k * nv + NU * k + 1] = 1.0;
+        d[k] = o->U[k * NU + 1];
+        lb[k] = o->lbu[k]; ub[k] = o->ubu[k];
+        zl[k] = dt * o->zl[k * 3]; zu[k] = dt * o->zu[k * 3]; Zl[k] = dt * o->Zl[k * 3]; Zu[k] = dt * o->Zu[k * 3];
+    }
+    double *gh = calloc(nxs, sizeof(double));
+    for (int k = 1; k <= N; k++) {
+        const double sc = (k < N) ? dt : 1.0;
+        const double *x = o->X + (size_t)k * nxs;
+        const double *Gk = G + (size_t)k * nxs * nv, *gk = g + (size_t)k * nxs;
+        const int ib = N + 2 * (k - 1), ih = ib + 1;
+        for (int j = 0; j < NU * k; j++) C[ib * nv + j] = Gk[(size_t)6 * nv + j];
+        d[ib] = x[6] + gk[6];
+        lb[ib] = o->lbx[k]; ub[ib] = o->ubx[k];
+        const double h = snmpc_h(o, k, x, gh);
+        o->hval[k] = h;
+        double acc = h;
+        for (int l = 0; l < nxs; l++) acc += gh[l] * gk[l];
+        d[ih] = acc;
+        for (int l = 0; l < nxs; l++) {
+            if (gh[l] == 0.0) continue;
+            for (int j = 0; j < NU * k; j++) C[ih * nv + j] += gh[l] * Gk[(size_t)l * nv + j];
+        }
+        lb[ih] = o->lh[k]; ub[ih] = o->uh[k];
+        for (int s = 1; s <= 2; s++) {
+            const int i = (s == 1) ? ib : ih;
+            zl[i] = sc * o->zl[k * 3 + s]; zu[i] = sc * o->zu[k * 3 + s];
+            Zl[i] = sc * o->Zl[k * 3 + s]; Zu[i] = sc * o->Zu[k * 3 + s];
+        }
+    }
+    if (g_sdbg) {
+        double *p = g_sdbg;
+        memcpy(p, H, sizeof(double) * nv * nv); p += nv * nv;
+        memcpy(p, q, sizeof(double) * nv); p += nv;
+        memcpy(p, C, sizeof(double) * m * nv); p += m * nv;
+        memcpy(p, d, sizeof(double) * m);
+    }
+    /* 6. QP */
+    double *sall = calloc(2 * m, sizeof(double));
+    ipm_info info;
+    qp_ipm(nv, m, H, q, C, d, lb, ub, zl, zu, Zl, Zu, &o->ipm, v, sall, o->lam, &info);
+    memcpy(o->sl, sall, sizeof(double) * m);
+    memcpy(o->su, sall + m, sizeof(double) * m);
+    o->qp_iter = info.iter;
+    o->res[0] = info.res_stat; o->res[1] = info.res_ineq; o->res[2] = info.res_comp;
+    o->status = (info.status == 0 || info.status == 1) ? 0 : 4;
+    /* 7. full step on all copies */
+    if (o->status == 0) {
+        for (int k = 0; k <= N; k++) {
+            const double *Gk = G + (size_t)k * nxs * nv;
+            for (int i = 0; i < nxs; i++) {
+                double acc = g[(size_t)k * nxs + i];
+                for (int j = 0; j < NU * k; j++) acc += Gk[(size_t)i * nv + j] * v[j];
+                o->X[(size_t)k * nxs + i] += acc;
+            }
+        }
+        for (int j = 0; j < nv; j++) o->U[j] += v[j];
+    }
+    o->cost = snmpc_eval_cost(o);
+    free(Ab); free(Bb); free(bb); free(G); free(g); free(H); free(q); free(C); free(d); free(lb); free(v);
+    free(row); free(gh); free(sall);
+    return o->status;
+}

@@ -248,3 +248,136 @@ class OracleOcp:
         u0 = np.zeros((nb, 2)); X1 = np.zeros((nb, 8)); stats = np.zeros((nb, 3))
         lib().oracle_solve_batch_cold(self._h, nb, _dp(x0), _dp(yref), _dp(u0), _dp(X1), _dp(stats), int(nthreads))
         return u0, X1, stats
+
+
+def _snmpc_bind(L):
+    if getattr(L, "_snmpc_bound", False):
+        return L
+    dp = ctypes.POINTER(ctypes.c_double)
+    L.snmpc_create.restype = ctypes.c_void_p
+    L.snmpc_create.argtypes = [ctypes.c_int, ctypes.c_double, ctypes.c_int, ctypes.c_int, ctypes.c_double]
+    L.snmpc_free.argtypes = [ctypes.c_void_p]
+    L.snmpc_field.restype = dp
+    L.snmpc_field.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.POINTER(ctypes.c_int)]
+    L.snmpc_set_model.argtypes = [ctypes.c_void_p, ctypes.POINTER(StmModel)]
+    L.snmpc_set_iter_max.argtypes = [ctypes.c_void_p, ctypes.c_int]
+    L.snmpc_solve.argtypes = [ctypes.c_void_p]
+    L.snmpc_solve.restype = ctypes.c_int
+    L.snmpc_qp_iter.argtypes = [ctypes.c_void_p]
+    L.snmpc_status.argtypes = [ctypes.c_void_p]
+    L.snmpc_set_debug.argtypes = [dp]
+    L.oracle_h_vabs.argtypes = [ctypes.POINTER(StmModel), dp, dp, dp]
+    L._snmpc_bound = True
+    return L
+
+
+def h_con_vabs(x, model=None):
+    """gg circle with the limits looked up at |v| (SNMPC_acados_settings.py:60-67)."""
+    model = model or edgar_model()
+    x = np.ascontiguousarray(x, dtype=np.float64)
+    h = np.zeros(1); gh = np.zeros(8)
+    _snmpc_bind(lib()).oracle_h_vabs(ctypes.byref(model), _dp(x), _dp(h), _dp(gh))
+    return float(h[0]), gh
+
+
+class OracleSnmpcOcp:
+    """The coupled SNMPC OCP (nominal copy + n_s sample copies, one shared input), CPU FP64.
+
+    Restates `acados_solver.solve()` at Stochastic_NMPC/SNMPC_class.py:198 (see the C file's SNMPC section).
+    X (N+1, n_s+1, 8); x0 (n_s+1, 8); Apce (L, n_s); stop (N+1); the rest as OracleOcp.
+    """
+
+    def __init__(self, N=38, dt=0.08, Apce=None, uph=5, gamma=0.8, model=None):
+        L = _snmpc_bind(lib())
+        Apce = np.ascontiguousarray(Apce, dtype=np.float64)
+        self.L, self.ns = Apce.shape
+        self._h = L.snmpc_create(int(N), float(dt), int(self.ns), int(self.L), float(gamma))
+        if not self._h:
+            raise ValueError("bad dimensions")
+        self.N, self.dt = N, dt
+        self._model = model or edgar_model()
+        L.snmpc_set_model(self._h, ctypes.byref(self._model))
+        ns = self.ns
+        self.X = self._view("X").reshape(N + 1, ns + 1, 8)
+        self.U = self._view("U").reshape(N, 2)
+        self.x0 = self._view("x0").reshape(ns + 1, 8)
+        self.yref = self._view("yref").reshape(N + 1, 6)
+        self.W = self._view("W").reshape(N + 1, 6)
+        self.lbu, self.ubu = self._view("lbu"), self._view("ubu")
+        self.lbx, self.ubx = self._view("lbx"), self._view("ubx")
+        self.lh, self.uh = self._view("lh"), self._view("uh")
+        self.zl, self.zu = self._view("zl").reshape(N + 1, 3), self._view("zu").reshape(N + 1, 3)
+        self.Zl, self.Zu = self._view("Zl").reshape(N + 1, 3), self._view("Zu").reshape(N + 1, 3)
+        self.Apce = self._view("Apce").reshape(self.L, ns)
+        self.stop = self._view("stop")
+        self.sl, self.su = self._view("sl"), self._view("su")
+        self.hval = self._view("hval")
+        self.ipm_tol = self._view("ipm_tol")
+        self.res = self._view("res")
+        self.Apce[:] = Apce
+        # stop flags of the uncertainty propagation horizon (SNMPC_class.py:103-104)
+        self.stop[:] = 0.0
+        self.stop[uph:] = 1.0
+        self.lbu[:] = EDGAR["delta_f_dot_min"]; self.ubu[:] = EDGAR["delta_f_dot_max"]
+        self.lbx[:] = EDGAR["delta_f_min"]; self.ubx[:] = EDGAR["delta_f_max"]
+        self.lh[:] = 0.0; self.uh[:] = 1.0
+
+    def _view(self, name):
+        n = ctypes.c_int(0)
+        p = lib().snmpc_field(self._h, name.encode(), ctypes.byref(n))
+        if not p:
+            raise KeyError(name)
+        return np.ctypeslib.as_array(p, shape=(n.value,))
+
+    def __del__(self):
+        try:
+            if self._h:
+                lib().snmpc_free(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+    set_weights = OracleOcp.set_weights
+    set_yref = OracleOcp.set_yref
+
+    def cold_start(self, x0_samples):
+        """SNMPC_class.py:119-127: lbx_0 = ubx_0 = x0_samples, x_k = x0_samples for all k, u = 0."""
+        self.x0[:] = x0_samples
+        self.X[:] = np.asarray(x0_samples)[None]
+        self.U[:] = 0.0
+
+    def set_initial_state(self, x0_samples):
+        self.x0[:] = x0_samples
+
+    def set_iter_max(self, it):
+        lib().snmpc_set_iter_max(self._h, int(it))
+
+    def solve(self):
+        return lib().snmpc_solve(self._h)
+
+    def solve_debug(self):
+        N = self.N; nv, m = 2 * N, 3 * N
+        buf = np.zeros(nv * nv + nv + m * nv + m)
+        lib().snmpc_set_debug(_dp(buf))
+        try:
+            st = lib().snmpc_solve(self._h)
+        finally:
+            lib().snmpc_set_debug(None)
+        o = 0
+        H = buf[o:o + nv * nv].reshape(nv, nv); o += nv * nv
+        q = buf[o:o + nv]; o += nv
+        C = buf[o:o + m * nv].reshape(m, nv); o += m * nv
+        d = buf[o:o + m]
+        return st, dict(H=H, q=q, C=C, d=d)
+
+    @property
+    def cost(self):
+        return float(self._view("cost")[0])
+
+    @property
+    def qp_iter(self):
+        return lib().snmpc_qp_iter(self._h)
+
+    @property
+    def status(self):
+        return lib().snmpc_status(self._h)

@@ -102,6 +102,10 @@ struct KArgs {
     long long *prof;                                  // [b][12] phase cycle counters (flags&4)
     double *ws;                                       // [b][WS_DOUBLES] linearisation records parked during the IPM
     const int *order;                                 // [batch] workgroup -> instance map (longest-first schedule) or null
+    // coupled SNMPC OCP only (nmpc_rti_kernel<., true>, snmpc_kernels.hpp)
+    int uph;                                          // uncertainty propagation horizon: stages 1..uph come from `pro`
+    const double *pro;                                // [b][uph][SN_PRO_STAGE] G_nom,s | chance-constraint row of stage s
+    double *dv;                                       // [b][NVP] QP solution for the epilogue kernel
 };
 
 // ---------------------------------------------------------------- wave helpers

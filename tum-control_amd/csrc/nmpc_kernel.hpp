@@ -3,6 +3,7 @@
 #include <type_traits>
 
 #include "nmpc_device.hpp"
+#include "snmpc_kernels.hpp"
 
 namespace tum {
 
@@ -72,7 +73,9 @@ __device__ __forceinline__ int acados_status(int qp_status) { return (qp_status 
     for (int I = 0; I < NT; I++) rb[I] = lpk(16 * I + lc, 0); \
     const int myrow0 = lpk(lane, 0), myrow1 = lpk(lane1, 0);
 
-template <bool PROF>
+// SN = true: the fused kernel of the coupled SNMPC OCP (snmpc_kernels.hpp): the stages 1..uph come condensed from the
+// prologue kernel (KArgs::pro), the speed row of the cost is |v| and the gg limits are looked up at |v|.
+template <bool PROF, bool SN = false>
 __global__ void __launch_bounds__(64, 1) nmpc_rti_kernel(const KArgs ka)
 {
     extern __shared__ __attribute__((aligned(16))) double lds[];
@@ -95,6 +98,8 @@ __global__ void __launch_bounds__(64, 1) nmpc_rti_kernel(const KArgs ka)
     const double *gW = ka.W + (size_t)b * 10;
     const double *gpen = ka.pen + (size_t)b * 36;
     const double *gbnd = ka.bnd + (size_t)b * 6 * (N + 1);
+    const int uph = SN ? ka.uph : 0;
+    const double *gpro = SN ? ka.pro + (size_t)b * uph * SN_PRO_STAGE : nullptr;
 
     long long pacc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     long long tprev = __builtin_readcyclecounter();
@@ -127,14 +132,22 @@ __global__ void __launch_bounds__(64, 1) nmpc_rti_kernel(const KArgs ka)
             sRes[k * 4 + 0] = xk[0] - yr[0];
             sRes[k * 4 + 1] = xk[1] - yr[1];
             sRes[k * 4 + 2] = wrap_yaw(xk[2]) - yr[2];
-            sRes[k * 4 + 3] = xk[3] - yr[3];
+            if (SN) {   // speed row |v| (SNMPC_acados_settings.py:153): its gradient (vl, vt)/|v| rides in the unused g slots
+                const double vabs = sqrt(xk[3] * xk[3] + xk[4] * xk[4]), iv = (vabs > 0.0) ? 1.0 / vabs : 0.0;
+                sRes[k * 4 + 3] = vabs - yr[3];
+                sG[k * NX + 6] = xk[3] * iv; sG[k * NX + 7] = xk[4] * iv;
+            } else sRes[k * 4 + 3] = xk[3] - yr[3];
             sXd[k] = xk[6];          // the condensing phase overwrites sX (it shares LDS with the packed gg rows)
             if (k >= 1) {
                 double h, g3, g5, g7;
-                h_con(mp, xk[3], xk[5], xk[7], h, g3, g5, g7);
+                if (SN) {
+                    double g4;
+                    h_con_vabs(mp, xk[3], xk[4], xk[5], xk[7], h, g3, g4, g5, g7);
+                    sG[k * NX + 5] = g4;
+                } else h_con(mp, xk[3], xk[5], xk[7], h, g3, g5, g7);
                 sGh[k * 4 + 0] = g3; sGh[k * 4 + 1] = g5; sGh[k * 4 + 2] = g7; sGh[k * 4 + 3] = h;
             }
-            if (k < N) {
+            if (k < N && k >= uph) {
                 double uk[2] = {sU0[2 * k], sU0[2 * k + 1]};
                 double xn[8], Sp[2], S[6][7];
                 rk4_sens(mp, xk, uk, dt, ka.nsub, xn, Sp, S);
@@ -186,7 +199,7 @@ __global__ void __launch_bounds__(64, 1) nmpc_rti_kernel(const KArgs ka)
         for (int i = 0; i < 8; i++) { w0[i] = 0.0; w1[i] = 0.0; }
         if (isg) {
 #pragma unroll
-            for (int i = 0; i < 8; i++) { w1[i] = gx0[i] - sX[i]; sG[i] = w1[i]; }
+            for (int i = 0; i < 8; i++) { w1[i] = gx0[i] - sX[i]; if (!SN || i < 5) sG[i] = w1[i]; }
         }
         // One condensing stage. The number of 16-column tiles the stage touches (Ts) is a compile-time
         // constant per segment of 8 stages, so every MFMA targets a fixed accumulator (no conditional tiles).
@@ -196,6 +209,16 @@ __global__ void __launch_bounds__(64, 1) nmpc_rti_kernel(const KArgs ka)
             // Both banks advance together (shared record loads, no exec-mask regions): columns that have not started yet
             // hold zeros, so w <- A_k w leaves them at zero; the column that starts at this stage adds B_k with a 0/1
             // multiplier and the g column adds the defect b_k the same way.
+            if (SN && k < uph) {
+                // stage s = k+1 <= uph: G_nom,s and g_nom,s are PCE means of the sample recursions (prologue kernel)
+                const double *pg = gpro + (size_t)k * SN_PRO_STAGE;
+#pragma unroll
+                for (int i = 0; i < 8; i++) {
+                    const double gv = pg[i * 64 + lane], gg = pg[i * 64 + 2 * uph];
+                    w0[i] = (lane < 2 * uph) ? gv : 0.0;
+                    w1[i] = isg ? gg : 0.0;
+                }
+            } else {
             apply_A2(rec, w0, w1);
             {
                 const double sel0 = (j0 == k) ? 1.0 : 0.0, sel1 = (lane < 16 && j1 == k) ? 1.0 : 0.0, selg = isg ? 1.0 : 0.0;
@@ -209,23 +232,39 @@ __global__ void __launch_bounds__(64, 1) nmpc_rti_kernel(const KArgs ka)
 #pragma unroll
                 for (int i = 0; i < 8; i++) w1[i] += selg * rec[44 + i];
             }
+            }
             const int s = k + 1;                         // stage whose G_s the lanes now hold
             const double sc = (s < N) ? dt : 1.0;
             const double g3 = sGh[s * 4 + 0], g5 = sGh[s * 4 + 1], g7 = sGh[s * 4 + 2];
+            const double g4 = SN ? sG[s * NX + 5] : 0.0, cvl = SN ? sG[s * NX + 6] : 1.0, cvt = SN ? sG[s * NX + 7] : 0.0;
+            double hr0 = g3 * w0[3] + g5 * w0[5] + g7 * w0[7], hr1 = g3 * w1[3] + g5 * w1[5] + g7 * w1[7];
+            double hd = sGh[s * 4 + 3];
+            if (SN) {
+                hr0 += g4 * w0[4]; hr1 += g4 * w1[4];
+                if (s < uph) {   // chance-constraint row E + kappa sqrt(Var) over the samples (prologue kernel)
+                    const double *pr = gpro + (size_t)k * SN_PRO_STAGE + SN_PRO_G;
+                    const double rv = pr[lane], rg = pr[2 * uph];
+                    hr0 = (lane < 2 * uph) ? rv : 0.0; hr1 = isg ? rg : 0.0; hd = 0.0;
+                }
+            }
+            // the speed row of the cost: vl (nominal OCP) or |v| (SNMPC: gradient (vl, vt)/|v|)
+            const double c30 = SN ? cvl * w0[3] + cvt * w0[4] : w0[3], c31 = SN ? cvl * w1[3] + cvt * w1[4] : w1[3];
             if (isg) {
 #pragma unroll
-                for (int i = 0; i < 8; i++) sG[s * NX + i] = w1[i];
+                for (int i = 0; i < 8; i++) if (!SN || i < 5) sG[s * NX + i] = w1[i];
                 sD[2 * (s - 1)] = sXd[s] + w1[6];
-                sD[2 * (s - 1) + 1] = sGh[s * 4 + 3] + g3 * w1[3] + g5 * w1[5] + g7 * w1[7];
+                sD[2 * (s - 1) + 1] = hd + hr1;
             }
             // gg-constraint row of stage s and staging of the 4 cost rows
-            if (lane < 2 * s) sCh[hoff(s) + lane] = g3 * w0[3] + g5 * w0[5] + g7 * w0[7];
-            if (lane < 16 && 64 + lane < 2 * s) sCh[hoff(s) + 64 + lane] = g3 * w1[3] + g5 * w1[5] + g7 * w1[7];
+            if (lane < 2 * s) sCh[hoff(s) + lane] = hr0;
+            if (lane < 16 && 64 + lane < 2 * s) sCh[hoff(s) + 64 + lane] = hr1;
 #pragma unroll
-            for (int r = 0; r < 4; r++) sStage[r * NVP + lane] = w0[r];
+            for (int r = 0; r < 3; r++) sStage[r * NVP + lane] = w0[r];
+            sStage[3 * NVP + lane] = c30;
             if (lane < 16) {
 #pragma unroll
-                for (int r = 0; r < 4; r++) sStage[r * NVP + 64 + lane] = w1[r];
+                for (int r = 0; r < 3; r++) sStage[r * NVP + 64 + lane] = w1[r];
+                sStage[3 * NVP + 64 + lane] = c31;
             }
             wsync();
             // gradient: q += sum_r sc*W_r*(res_r + g_s[r]) * G_s[r,:]
@@ -236,8 +275,9 @@ __global__ void __launch_bounds__(64, 1) nmpc_rti_kernel(const KArgs ka)
                 double a0 = 0.0, a1 = 0.0;
 #pragma unroll
                 for (int r = 0; r < 4; r++) {
-                    const double e = wr[r] * (sRes[s * 4 + r] + sG[s * NX + r]);
-                    a0 += e * w0[r]; a1 += e * w1[r];
+                    const double gs = (SN && r == 3) ? cvl * sG[s * NX + 3] + cvt * sG[s * NX + 4] : sG[s * NX + r];
+                    const double e = wr[r] * (sRes[s * 4 + r] + gs);
+                    a0 += e * ((r == 3) ? c30 : w0[r]); a1 += e * ((r == 3) ? c31 : w1[r]);
                 }
                 q0 += a0;
                 q1 += (lane < 16) ? a1 : 0.0;
@@ -880,6 +920,10 @@ __global__ void __launch_bounds__(64, 1) nmpc_rti_kernel(const KArgs ka)
     wsync();
     sDv[lane] = v0;
     if (lane < 16) sDv[64 + lane] = v1;
+    if (SN) {   // the sample copies take their step in the epilogue kernel
+        ka.dv[(size_t)b * NVP + lane] = v0;
+        if (lane < 16) ka.dv[(size_t)b * NVP + 64 + lane] = v1;
+    }
     // bring back the iterate and the linearisation records
     // (compile-time trip counts: every global load of these copies is in flight before the first one is consumed)
     double gx0r, Wc[10], yrc[6];
@@ -913,7 +957,17 @@ __global__ void __launch_bounds__(64, 1) nmpc_rti_kernel(const KArgs ka)
         double dxi = gx0r - sX[ri];
         wsync();
         if (lane < 8) sX[lane] += dxi;
-        for (int k = 0; k < N; k++) {
+        if (SN) {
+            // stages 1..uph: dx_s = G_nom,s dU + g_nom,s straight from the prologue's matrices (2s columns each)
+            for (int s = 1; s <= uph; s++) {
+                const double *pg = gpro + (size_t)(s - 1) * SN_PRO_STAGE + ri * 64;
+                double acc = pg[2 * uph];
+                for (int j = 0; j < 2 * s; j++) acc += pg[j] * sDv[j];
+                dxi = acc;
+                if (lane < 8) sX[s * NX + lane] += dxi;
+            }
+        }
+        for (int k = uph; k < N; k++) {
             const double *rec = sAB + k * ABS;
             const double *Si = rec + 2 + (core ? ri : 0) * 7;
             const double du0 = sDv[2 * k], du1 = sDv[2 * k + 1];
@@ -948,7 +1002,8 @@ __global__ void __launch_bounds__(64, 1) nmpc_rti_kernel(const KArgs ka)
         e = sX[k * NX + 0] - yr[0]; acc += ((k < N) ? Wd[0] : We[0]) * e * e;
         e = sX[k * NX + 1] - yr[1]; acc += ((k < N) ? Wd[1] : We[1]) * e * e;
         e = wrap_yaw(sX[k * NX + 2]) - yr[2]; acc += ((k < N) ? Wd[2] : We[2]) * e * e;
-        e = sX[k * NX + 3] - yr[3]; acc += ((k < N) ? Wd[3] : We[3]) * e * e;
+        e = (SN ? sqrt(sX[k * NX + 3] * sX[k * NX + 3] + sX[k * NX + 4] * sX[k * NX + 4]) : sX[k * NX + 3]) - yr[3];
+        acc += ((k < N) ? Wd[3] : We[3]) * e * e;
         if (k < N) {
             e = sU1[2 * k] - yr[4]; acc += Wd[4] * e * e;
             e = sU1[2 * k + 1] - yr[5]; acc += Wd[5] * e * e;

@@ -34,6 +34,10 @@ struct tum_ocp {
     float last_ms;
     bool solved;
     std::vector<double> stage;     // host staging
+    // coupled SNMPC OCP (tum_ocp_snmpc_attach)
+    bool sn;
+    SnArgs sa;
+    double *dXS, *dxs0, *dApce, *dws2, *dpro, *ddv;
 };
 
 static const int DBG_STRIDE = 20480;
@@ -66,6 +70,7 @@ extern "C" tum_ocp *tum_ocp_create(const tum_ocp_desc *desc)
     if (hipSetDevice(desc->device) != hipSuccess) { fail("hipSetDevice failed"); return nullptr; }
     tum_ocp *c = new tum_ocp();
     c->d = *desc; c->N = desc->N; c->batch = desc->batch; c->last_ms = 0; c->solved = false;
+    c->sn = false; c->dXS = c->dxs0 = c->dApce = c->dws2 = c->dpro = c->ddv = nullptr;
     const int N = c->N; const size_t B = c->batch;
     bool ok = true;
     ok &= hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) == hipSuccess; c->own_stream = true;
@@ -127,7 +132,9 @@ extern "C" tum_ocp *tum_ocp_create(const tum_ocp_desc *desc)
     ka.qpin = c->dqpin; ka.dbg = c->ddbg; ka.dbg_stride = DBG_STRIDE; ka.prof = c->dprof; ka.ws = c->dws;
 
     if (hipFuncSetAttribute((const void *)nmpc_rti_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) != hipSuccess ||
-        hipFuncSetAttribute((const void *)nmpc_rti_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) != hipSuccess) {
+        hipFuncSetAttribute((const void *)nmpc_rti_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) != hipSuccess ||
+        hipFuncSetAttribute((const void *)nmpc_rti_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) != hipSuccess ||
+        hipFuncSetAttribute((const void *)nmpc_rti_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) != hipSuccess) {
         fail("hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed"); tum_ocp_free(c); return nullptr;
     }
     return c;
@@ -140,11 +147,49 @@ extern "C" void tum_ocp_free(tum_ocp *c)
     (void)hipFree(c->dcost); (void)hipFree(c->dres); (void)hipFree(c->dslack); (void)hipFree(c->dstatus); (void)hipFree(c->dqpiter); (void)hipFree(c->dqpstatus); (void)hipFree(c->dorder);
     if (c->dqpin) (void)hipFree(c->dqpin);
     (void)hipFree(c->ddbg); (void)hipFree(c->dprof); (void)hipFree(c->dws);
+    (void)hipFree(c->dXS); (void)hipFree(c->dxs0); (void)hipFree(c->dApce); (void)hipFree(c->dws2); (void)hipFree(c->dpro); (void)hipFree(c->ddv);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
+
+// Turn the capsule into the coupled SNMPC OCP: the stacked state is the nominal copy followed by `ns`
+// sample copies; A_pce (L x ns, row-major) and the uncertainty propagation horizon replace the per-stage parameter
+// vector p = [A_pce.flatten(), risk_parameter, stop_flag] of the reference (SNMPC_class.py:103-104,124).
+extern "C" int tum_ocp_snmpc_attach(tum_ocp *c, int ns, int L, const double *Apce, int uph, double gamma)
+{
+    if (!c || !Apce) return fail("null argument");
+    if (c->sn) return fail("snmpc_attach: already attached");
+    if (ns < 1 || ns > SN_NSMAX) return fail("snmpc_attach: n_samples out of range (1..16)");
+    if (L < 1 || L > SN_LMAX) return fail("snmpc_attach: number of PCE terms out of range (1..16)");
+    if (uph < 0 || uph > c->N || uph > SN_UPHMAX) return fail("snmpc_attach: uncertainty propagation horizon out of range (0..min(N,31))");
+    if (!(gamma > 0.0 && gamma <= 1.0)) return fail("snmpc_attach: gamma out of range (0,1]");
+    if (c->d.nsub != 1) return fail("snmpc_attach: the SNMPC model is DISCRETE with one RK4 step per stage: create the capsule with nsub = 1");
+    if (c->d.store_qp_in) return fail("snmpc_attach: store_qp_in is not available for the stacked state");
+    HIPCHK(hipSetDevice(c->d.device));
+    const size_t B = c->batch; const int N = c->N;
+    bool ok = true;
+    ok &= dalloc(&c->dXS, B * (N + 1) * ns * NX) == hipSuccess;
+    ok &= dalloc(&c->dxs0, B * ns * NX) == hipSuccess;
+    ok &= dalloc(&c->dApce, (size_t)L * ns) == hipSuccess;
+    ok &= dalloc(&c->dws2, B * (size_t)(uph > 0 ? uph : 1) * ns * ABS) == hipSuccess;
+    ok &= dalloc(&c->dpro, B * (size_t)(uph > 0 ? uph : 1) * SN_PRO_STAGE) == hipSuccess;
+    ok &= dalloc(&c->ddv, B * NVP) == hipSuccess;
+    if (!ok) return fail("snmpc_attach: device allocation failed");
+    HIPCHK(hipMemcpy(c->dApce, Apce, sizeof(double) * L * ns, hipMemcpyHostToDevice));
+    SnArgs &sa = c->sa;
+    memset(&sa, 0, sizeof(sa));
+    sa.N = N; sa.batch = c->batch; sa.ns = ns; sa.L = L; sa.uph = uph; sa.dt = c->ka.dt;
+    sa.kappa = std::sqrt((1.0 - gamma) / gamma);      // SNMPC_acados_settings.py:187
+    sa.mp = c->ka.mp;
+    sa.X = c->dX; sa.U = c->dU; sa.XS = c->dXS; sa.xs0 = c->dxs0; sa.Apce = c->dApce; sa.ws2 = c->dws2; sa.pro = c->dpro;
+    sa.dv = c->ddv; sa.status = c->dstatus;
+    c->ka.uph = uph; c->ka.pro = c->dpro; c->ka.dv = c->ddv;
+    c->sn = true;
+    return 0;
+}
+extern "C" int tum_ocp_snmpc_samples(const tum_ocp *c) { return (c && c->sn) ? c->sa.ns : 0; }
 
 static int chk_range(tum_ocp *c, int b0, int nb)
 {
@@ -187,6 +232,12 @@ extern "C" int tum_ocp_set(tum_ocp *c, int stage, const char *field, const doubl
     if (f == "x") {
         if (stage == TUM_ALL_STAGES) { if (len != (N + 1) * NX) return fail("set x: len != (N+1)*8"); return put(c, c->dX, (N + 1) * NX, 0, v, len, b0, nb, stride); }
         if (stage < 0 || stage > N) return fail("set x: stage out of range");
+        if (c->sn && len == NX * (c->sa.ns + 1)) {   // stacked state: nominal copy, then the sample copies (SNMPC_class.py:126-127)
+            if (stride != 0 && stride < len) return fail("stride < len");
+            const int ns = c->sa.ns;
+            if (put(c, c->dX, (N + 1) * NX, (size_t)stage * NX, v, NX, b0, nb, stride)) return 1;
+            return put(c, c->dXS, (size_t)(N + 1) * ns * NX, (size_t)stage * ns * NX, v + NX, ns * NX, b0, nb, stride);
+        }
         if (len != NX) return fail("set x: mismatching dimension, expected 8");
         return put(c, c->dX, (N + 1) * NX, (size_t)stage * NX, v, len, b0, nb, stride);
     }
@@ -214,6 +265,12 @@ extern "C" int tum_ocp_get(tum_ocp *c, int stage, const char *field, double *v, 
     const std::string f(field);
     if (f == "x") {
         if (stage == TUM_ALL_STAGES) { if (len != (N + 1) * NX) return fail("get x: len"); return fetch(c, c->dX, (N + 1) * NX, 0, v, len, b0, nb, stride); }
+        if (c->sn && stage >= 0 && stage <= N && len == NX * (c->sa.ns + 1)) {
+            const int ns = c->sa.ns;
+            if (stride < len) return fail("stride < len");
+            if (fetch(c, c->dX, (N + 1) * NX, (size_t)stage * NX, v, NX, b0, nb, stride)) return 1;
+            return fetch(c, c->dXS, (size_t)(N + 1) * ns * NX, (size_t)stage * ns * NX, v + NX, ns * NX, b0, nb, stride);
+        }
         if (stage < 0 || stage > N || len != NX) return fail("get x: bad stage/len");
         return fetch(c, c->dX, (N + 1) * NX, (size_t)stage * NX, v, len, b0, nb, stride);
     }
@@ -249,6 +306,11 @@ extern "C" int tum_ocp_constraints_set(tum_ocp *c, int stage, const char *field,
     if (stage < 0 || stage > N) return fail("constraints_set: stage out of range");
     if (f == "lbx" || f == "ubx") {
         if (stage == 0) {   // x0 equality: lbx_0 = ubx_0 = x0 (NMPC_class.py:243-246)
+            if (c->sn && len == NX * (c->sa.ns + 1)) {   // x0 of all copies (SNMPC_class.py:262-264)
+                if (stride != 0 && stride < len) return fail("stride < len");
+                if (put(c, c->dx0, NX, 0, v, NX, b0, nb, stride)) return 1;
+                return put(c, c->dxs0, (size_t)c->sa.ns * NX, 0, v + NX, c->sa.ns * NX, b0, nb, stride);
+            }
             if (len != NX) return fail("constraints_set lbx/ubx at stage 0: expected 8 values (x0)");
             return put(c, c->dx0, NX, 0, v, len, b0, nb, stride);
         }
@@ -317,7 +379,12 @@ static int launch(tum_ocp *c, bool events = true)
     // round of resident wavefronts)
     c->ka.order = (c->lpt && c->order_valid && c->batch > 1024) ? c->dorder : nullptr;
     // the instrumented instantiation carries the phase timers (flag 4) and the debug dump (flag 2)
-    if (c->ka.flags & 6) hipLaunchKernelGGL(nmpc_rti_kernel<true>, dim3(c->batch), dim3(64), LDS_BYTES, c->stream, c->ka);
+    if (c->sn) {
+        hipLaunchKernelGGL(snmpc_prologue_kernel, dim3(c->batch), dim3(64), 0, c->stream, c->sa);
+        if (c->ka.flags & 6) hipLaunchKernelGGL((nmpc_rti_kernel<true, true>), dim3(c->batch), dim3(64), LDS_BYTES, c->stream, c->ka);
+        else hipLaunchKernelGGL((nmpc_rti_kernel<false, true>), dim3(c->batch), dim3(64), LDS_BYTES, c->stream, c->ka);
+        hipLaunchKernelGGL(snmpc_epilogue_kernel, dim3(c->batch), dim3(64), 0, c->stream, c->sa);
+    } else if (c->ka.flags & 6) hipLaunchKernelGGL(nmpc_rti_kernel<true>, dim3(c->batch), dim3(64), LDS_BYTES, c->stream, c->ka);
     else hipLaunchKernelGGL(nmpc_rti_kernel<false>, dim3(c->batch), dim3(64), LDS_BYTES, c->stream, c->ka);
     HIPCHK(hipGetLastError());
     if (events) HIPCHK(hipEventRecord(c->ev1, c->stream));
@@ -398,6 +465,7 @@ extern "C" int tum_ocp_reset(tum_ocp *c)
     if (!c) return fail("null capsule");
     HIPCHK(hipMemsetAsync(c->dX, 0, sizeof(double) * (size_t)c->batch * (c->N + 1) * NX, c->stream));
     HIPCHK(hipMemsetAsync(c->dU, 0, sizeof(double) * (size_t)c->batch * c->N * NU, c->stream));
+    if (c->sn) HIPCHK(hipMemsetAsync(c->dXS, 0, sizeof(double) * (size_t)c->batch * (c->N + 1) * c->sa.ns * NX, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
     return 0;
 }
@@ -406,6 +474,7 @@ extern "C" int tum_ocp_cold_start(tum_ocp *c)
 {
     if (!c) return fail("null capsule");
     hipLaunchKernelGGL(cold_start_kernel, dim3(c->batch), dim3(64), 0, c->stream, c->dX, c->dU, c->dx0, c->N, c->batch);
+    if (c->sn) hipLaunchKernelGGL(snmpc_cold_start_kernel, dim3(c->batch), dim3(256), 0, c->stream, c->dXS, c->dxs0, c->N, c->sa.ns, c->batch);
     HIPCHK(hipGetLastError());
     return 0;
 }

@@ -16,7 +16,7 @@ import numpy as np
 from scipy.special import ndtri
 
 from . import config as _config
-from .solver import BatchedOcpSolver
+from .solver import BatchedOcpSolver, CoupledSnmpcSolver
 
 
 def hermite(x, n):
@@ -125,3 +125,98 @@ class ScenarioSNMPC:
         if self.A is not None:
             mean, var = s.pce_moments("x", 1, self.A)
         return st, U[::self.S + 1, 0], mean, var
+
+
+class Stochastic_Nonlinear_Model_Predictive_Controller:
+    """Host-side mirror of the reference's SNMPC controller on the coupled OCP:
+    Model_Predictive_Controller/Stochastic_NMPC/SNMPC_class.py:38-349, same method names, arguments and returns
+    (`solve` -> u0, pred_X of the nominal copy, stats = [cost, time_tot, sqp_iter, max qp_iter, status]).
+    The RL weight-switching branch (SNMPC_class.py:134-177,215-246) is out of scope as in nmpc.py."""
+
+    def __init__(self, config_path=None, MPC_params_file=None, sim_main_params=None, X0_MPC=None, device=0):
+        if config_path is not None and MPC_params_file is not None:
+            self.cfg = _config.load_reference_config(config_path, sim_main_params, MPC_params_file)
+        else:
+            self.cfg = _config.default_config()
+        sim = dict(self.cfg["sim"])
+        if sim_main_params:
+            sim.update({k: sim_main_params[k] for k in ("Tp", "Ts", "Ts_MPC") if k in sim_main_params})
+        m = self.MPC_params = self.cfg["mpc"]
+        self.Tp, self.Ts, self.Ts_MPC = sim["Tp"], sim["Ts"], sim["Ts_MPC"]
+        self.N = int(self.Tp / self.Ts_MPC)
+        self.L1_pen, self.L2_pen = m["L1_pen"], m["L2_pen"]
+        self.Q = np.diag([m["q_lon"] / m["s_lon"] ** 2, m["q_lat"] / m["s_lat"] ** 2,
+                          m["q_yaw"] / m["s_yaw"] ** 2, m["q_vel"] / m["s_vel"] ** 2])
+        self.R = np.diag([m["r_jerk"] / m["s_jerk"] ** 2, m["r_steering_rate"] / m["s_steering_rate"] ** 2])
+        self.Qe = self.Q
+        if m["combined_acc_limits"] != 2:
+            raise NotImplementedError("only combined_acc_limits == 2 (circle), the shipped variant, is built")
+        # PCE set-up, SNMPC_class.py:81-104
+        self.n_samples = m["n_samples"]
+        self.stds = np.asarray(m["stds"], dtype=float)
+        self.expansion_degree = m["expansion_degree"]
+        self.n_vars = int(np.count_nonzero(self.stds))
+        self.alphas = alpha_generation(self.n_vars, self.expansion_degree)
+        self.num_poly_terms = len(self.alphas)
+        self.w_samples = hammersley_normal(self.n_samples, self.n_vars)
+        self.A = pce_matrix(self.w_samples, self.alphas)
+        uph = int(m["uncertainty_propagation_horizon"])
+        self.stop_flags = np.zeros(self.N + 1)
+        self.stop_flags[uph:] = 1
+        self.risk_parameter = np.array(m["gamma"]).reshape(1)
+        X0_MPC = np.zeros(8) if X0_MPC is None else np.asarray(X0_MPC, dtype=float)
+        x0_samples = compute_x0dist(X0_MPC, self.w_samples, self.stds)
+        s = self.acados_solver = CoupledSnmpcSolver(N=self.N, dt=self.Tp / self.N, batch=1, Apce=self.A, uph=min(uph, self.N),
+                                                    gamma=m["gamma"], device=device, cfg=self.cfg)
+        s.install_reference_ocp(Q=self.Q, R=self.R, Qe=self.Qe, L1=self.L1_pen, L2=self.L2_pen, w_scale=0.01)
+        self.nx = 8
+        self.x0 = X0_MPC
+        self.costfunction_type = "NONLINEAR_LS"
+        self.nh, self.nh_e = 1, 1
+        s.constraints_set(0, "lbx", x0_samples.flatten())
+        s.constraints_set(0, "ubx", x0_samples.flatten())
+        for i in range(self.N + 1):
+            s.set(i, "p", np.concatenate((self.A.flatten(), self.risk_parameter, self.stop_flags[i].reshape(1))))
+        s.cold_start()                  # SNMPC_class.py:126-127: x_j = x0_samples for all j
+        self.stats = np.zeros(5)
+        self.pred_X = np.empty((0, self.nx))
+        self.WMPC = False
+
+    def solve(self, current_ref_traj):
+        """SNMPC_class.py:179-257"""
+        s, N = self.acados_solver, self.N
+        y = np.zeros((N + 1, 6))
+        y[:, 0] = np.asarray(current_ref_traj['pos_x'][:N + 1]); y[:, 1] = np.asarray(current_ref_traj['pos_y'][:N + 1])
+        y[:, 2] = np.asarray(current_ref_traj['ref_yaw'][:N + 1]); y[:, 3] = np.asarray(current_ref_traj['ref_v'][:N + 1])
+        s.set_yref_all(y)
+        status = s.solve()
+        X, U = s.get_iterate()          # nominal copy
+        X, U = np.asarray(X).reshape(-1, N + 1, 8)[0], np.asarray(U).reshape(-1, N, 2)[0]
+        u0 = np.array(U[0])
+        if status == 0:
+            self.pred_X = np.array(X[:N])
+        self.stats[0] = s.get_cost()
+        self.stats[1] = s.get_stats('time_tot')
+        self.stats[2] = s.get_stats('sqp_iter')
+        self.stats[3] = np.max(s.get_stats('qp_iter'))
+        self.stats[4] = status
+        return u0, self.pred_X, self.stats
+
+    def set_initial_state(self, x0):
+        self.x0 = x0
+        x0_samples = compute_x0dist(x0, self.w_samples, self.stds)
+        self.acados_solver.constraints_set(0, "lbx", x0_samples.flatten())
+        self.acados_solver.constraints_set(0, "ubx", x0_samples.flatten())
+
+    def reset(self, x0):
+        self.acados_solver.reset()
+        x0_samples = compute_x0dist(x0, self.w_samples, self.stds)
+        self.acados_solver.constraints_set(0, "lbx", x0_samples.flatten())
+        self.acados_solver.constraints_set(0, "ubx", x0_samples.flatten())
+        for i in range(self.N + 1):
+            self.acados_solver.set(i, 'x', x0_samples.flatten())
+
+    def update_cost_function_weights(self, params):
+        """SNMPC_class.py:283-331 (same protocol as NMPC_class.py:269-317)"""
+        from .nmpc import Nonlinear_Model_Predictive_Controller as _N
+        _N.update_cost_function_weights(self, params)

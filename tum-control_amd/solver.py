@@ -49,6 +49,7 @@ C_SYMBOLS = ["tum_ocp_create", "tum_ocp_free", "tum_ocp_last_error", "tum_ocp_ba
              "tum_ocp_set_stream", "tum_ocp_get_device", "tum_ocp_cold_start", "tum_ocp_last_kernel_ms",
              "tum_ocp_debug_dump", "tum_ocp_profile_phases", "tum_ocp_set_schedule",
              "tum_ocp_set_x0_fanout", "tum_pce_moments", "tum_ocp_r2_backoff", "tum_ocp_constraints_get",
+             "tum_ocp_snmpc_attach", "tum_ocp_snmpc_samples",
              "tum_planner_emulate", "tum_sim_create", "tum_sim_free", "tum_sim_set_state", "tum_sim_plan", "tum_sim_advance",
              "tum_sim_run", "tum_sim_steps", "tum_sim_get"]
 
@@ -93,6 +94,8 @@ def load_library(path=None):
     L.tum_pce_moments.argtypes = [vp, cs, ci, dp, ci, ci, dp, dp]
     L.tum_ocp_r2_backoff.argtypes = [vp, dp, dp, ci, ctypes.c_double, ctypes.c_double, ctypes.c_double, dp]
     L.tum_ocp_constraints_get.argtypes = [vp, ci, cs, dp, ci, ci]
+    L.tum_ocp_snmpc_attach.argtypes = [vp, ci, ci, dp, ci, ctypes.c_double]
+    L.tum_ocp_snmpc_samples.argtypes = [vp]
     ip = ctypes.POINTER(ctypes.c_int); cd = ctypes.c_double
     L.tum_planner_emulate.argtypes = [dp, ci, dp, ci, ci, cd, ci, dp, ip, ci]
     L.tum_sim_create.restype = vp; L.tum_sim_create.argtypes = [vp, dp, ci, cd, ci, cd, ci, ip, ci]
@@ -385,6 +388,52 @@ class BatchedOcpSolver:
             self.constraints_set(k, "ubx", np.array([veh["delta_f_max"]]))
             self.constraints_set(k, "lh", np.array([0.0]))
             self.constraints_set(k, "uh", np.array([1.0]))
+
+
+class CoupledSnmpcSolver(BatchedOcpSolver):
+    """`batch` copies of the reference's coupled SNMPC OCP: what
+    Stochastic_NMPC/SNMPC_acados_settings.py:318 builds and SNMPC_class.py:198 solves, acados method names.
+
+    The stacked state is the nominal copy followed by n_s sample copies (nx = 8 (n_s+1)). `Apce` (L x n_s) and `uph`
+    stand for the per-stage parameter vector p = [A_pce.flatten(), risk_parameter, stop_flag]; set(stage, "p", ...)
+    is accepted and checked against them (the reference re-sends the same p before every solve, SNMPC_class.py:184-193).
+    """
+
+    def __init__(self, N=38, dt=0.08, batch=1, Apce=None, uph=5, gamma=0.8, device=0, cfg=None,
+                 qp_iter_max=50, qp_tol=(1e-8, 1e-8, 1e-8), qp_mu0=0.1, qp_t0=0.1):
+        super().__init__(N=N, dt=dt, nsub=1, batch=batch, device=device, cfg=cfg, qp_iter_max=qp_iter_max,
+                         qp_tol=qp_tol, qp_mu0=qp_mu0, qp_t0=qp_t0)
+        self.Apce = np.ascontiguousarray(Apce, dtype=np.float64)
+        if self.Apce.ndim != 2:
+            raise Exception("CoupledSnmpcSolver: Apce must be (num_poly_terms, n_samples)")
+        self.L, self.ns = self.Apce.shape
+        self.uph, self.gamma = int(uph), float(gamma)
+        self.nx = 8 * (self.ns + 1)
+        self._chk(self._L.tum_ocp_snmpc_attach(self._h, self.ns, self.L, _dp(self.Apce), self.uph, self.gamma), "snmpc_attach")
+
+    def set(self, stage, field, value):
+        if field == "p":
+            v = np.asarray(value, dtype=np.float64).reshape(-1)
+            if v.size != self.L * self.ns + 2:
+                raise Exception(f"CoupledSnmpcSolver.set: mismatching dimension for field \"p\" with dimension "
+                                f"{self.L * self.ns + 2} (you have {v.size})")
+            if not np.array_equal(v[:-2], self.Apce.reshape(-1)):
+                raise Exception("CoupledSnmpcSolver.set: A_pce differs from the matrix the solver was built with")
+            if float(v[-1]) != (1.0 if stage >= self.uph else 0.0):
+                raise Exception("CoupledSnmpcSolver.set: stop_flag does not match the uncertainty propagation horizon "
+                                f"the solver was built with (uph = {self.uph})")
+            return
+        super().set(stage, field, value)
+
+    def get(self, stage, field):
+        if field == "x":
+            out = np.zeros((self.batch, self.nx))
+            self._chk(self._L.tum_ocp_get(self._h, stage, b"x", _dp(out), self.nx, 0, self.batch, self.nx), "get")
+            return self._out(out)
+        return super().get(stage, field)
+
+    def get_from_qp_in(self, stage, field):
+        raise Exception("CoupledSnmpcSolver.get_from_qp_in: not available for the stacked state")
 
 
 def planner_emulate(track, poses, n_points, Tp, loop_circuit=True, device=0):
