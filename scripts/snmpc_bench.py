@@ -1,0 +1,55 @@
+#!/usr/bin/env python3
+"""Throughput of the coupled SNMPC OCP on one MI355X: batches of the reference's stochastic controller
+solve (prologue + fused kernel + epilogue, timed together with HIP events), cold start and warm real-time iterations,
+next to the dense CPU restatement (oracle, one thread) on a few instances and the reference's logged acados time
+(about 6.1 ms per SNMPC solve)."""
+import os, sys, time
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch  # noqa: F401
+from tum_control_amd import config, snmpc as snm
+from tum_control_amd.solver import CoupledSnmpcSolver
+from tum_control_amd.workloads import nominal_batch
+
+
+def main():
+    B = int(os.environ.get("SN_BATCH", 4096))
+    stds = np.asarray(config.MPC["stds"], dtype=float)
+    w = snm.hammersley_normal(10, 3)
+    A = snm.pce_matrix(w, snm.alpha_generation(3, 2))
+    offs = snm.x0_offsets(w, stds)
+    for N, uph in ((38, 5), (40, 5), (40, 15)):
+        x0, yref = nominal_batch(B, N=N)
+        X0 = np.concatenate([x0[:, None, :], x0[:, None, :] + offs[None]], axis=1)          # (B, 11, 8)
+        s = CoupledSnmpcSolver(N=N, dt=0.08, batch=B, Apce=A, uph=uph, gamma=config.MPC["gamma"])
+        s.install_reference_ocp()
+        s.constraints_set(0, "lbx", X0.reshape(B, -1)); s.constraints_set(0, "ubx", X0.reshape(B, -1))
+        s.set_yref_all(yref)
+        cold = []
+        for _ in range(5):
+            s.cold_start(); st = s.solve(); cold.append(s.last_kernel_ms())
+        it_c = s.get_stats("qp_iter").mean(); ok_c = (s.get_stats("status") == 0).mean()
+        warm = []
+        for _ in range(5):
+            st = s.solve(); warm.append(s.last_kernel_ms())
+        it_w = s.get_stats("qp_iter").mean()
+        mc, mw = float(np.median(cold)), float(np.median(warm))
+        print(f"coupled SNMPC N={N} uph={uph} ns=10 batch {B}: cold {mc:.3f} ms -> {B / mc * 1e3:,.0f} solves/s (qp_iter {it_c:.2f}, status0 {ok_c:.4f}); "
+              f"warm RTI {mw:.3f} ms -> {B / mw * 1e3:,.0f} solves/s (qp_iter {it_w:.2f})")
+        if N == 38:
+            from oracle import oracle as orc
+            m = config.MPC
+            t = []
+            for j in range(4):
+                o = orc.OracleSnmpcOcp(N=N, dt=0.08, Apce=A, uph=uph)
+                o.set_weights(m["q_lon"], m["q_yaw"], m["q_vel"], m["r_jerk"], m["r_steering_rate"], m["L1_pen"], m["L2_pen"], scale=0.01)
+                o.yref[:] = yref[j]; o.cold_start(X0[j])
+                t0 = time.perf_counter(); o.solve(); t.append(time.perf_counter() - t0)
+            print(f"  CPU restatement (88-state condensing that skips the zero blocks, one thread): {1e3 * np.median(t):.1f} ms per solve; "
+                  f"reference acados SNMPC: about 6.1 ms per solve (its logs)")
+        del s
+
+
+if __name__ == "__main__":
+    main()

@@ -65,9 +65,12 @@ __device__ __forceinline__ void h_con_vabs(const Model &p, double vl, double vt,
     g7 = 2.0 * nlon / ax;
 }
 
+// NSM: compile-time bound of the number of samples (register file of the column recursions: NSM x 8 doubles per lane)
+template <int NSM>
 __global__ void __launch_bounds__(64) snmpc_prologue_kernel(const SnArgs sa)
 {
     __shared__ double sH[SN_ITEMS], sGh[SN_ITEMS * 4], sCoef[SN_ITEMS], sHval[SN_UPHMAX + 1];
+    __shared__ double sRec[NSM * ABS];      // the records of one stage, all samples
     const int lane = threadIdx.x, b = blockIdx.x;
     if (b >= sa.batch) return;
     const int N = sa.N, ns = sa.ns, L = sa.L, uph = sa.uph;
@@ -129,9 +132,16 @@ __global__ void __launch_bounds__(64) snmpc_prologue_kernel(const SnArgs sa)
     const int gl = 2 * uph;
     const bool isg = (lane == gl);
     const int jst = lane >> 1, r0 = lane & 1;
-    double w[SN_NSMAX][8];
+    double w[NSM][8];
+    // the records of a stage are contiguous in ws2: staged through LDS one stage ahead (uniform-address vector loads of
+    // 530 doubles per stage straight from L2 cost more than the arithmetic of this phase)
+    constexpr int NCH = (NSM * ABS + 63) / 64;
+    const int nrec = ns * ABS;
+    double pre[NCH];
 #pragma unroll
-    for (int i = 0; i < SN_NSMAX; i++) {
+    for (int c = 0; c < NCH; c++) { const int idx = lane + 64 * c; pre[c] = (uph > 0 && idx < nrec) ? ws2[idx] : 0.0; }
+#pragma unroll
+    for (int i = 0; i < NSM; i++) {
 #pragma unroll
         for (int r = 0; r < 8; r++) w[i][r] = 0.0;
         if (i < ns && isg) {
@@ -141,14 +151,22 @@ __global__ void __launch_bounds__(64) snmpc_prologue_kernel(const SnArgs sa)
     }
     for (int k = 0; k < uph; k++) {
         const int s = k + 1;
+        __syncthreads();
+#pragma unroll
+        for (int c = 0; c < NCH; c++) { const int idx = lane + 64 * c; if (idx < nrec) sRec[idx] = pre[c]; }
+        __syncthreads();
+        if (k + 1 < uph) {
+#pragma unroll
+            for (int c = 0; c < NCH; c++) { const int idx = lane + 64 * c; pre[c] = (idx < nrec) ? ws2[(size_t)(k + 1) * nrec + idx] : 0.0; }
+        }
         double gn[8], row = 0.0;
 #pragma unroll
         for (int r = 0; r < 8; r++) gn[r] = 0.0;
         const double sel = (lane < gl && jst == k) ? 1.0 : 0.0, selg = isg ? 1.0 : 0.0;
 #pragma unroll
-        for (int i = 0; i < SN_NSMAX; i++) {
+        for (int i = 0; i < NSM; i++) {
             if (i < ns) {
-                const double *rec = ws2 + (size_t)(k * ns + i) * ABS;
+                const double *rec = sRec + i * ABS;
                 apply_A(rec, w[i]);
 #pragma unroll
                 for (int r = 0; r < 6; r++) w[i][r] += sel * rec[2 + r * 7 + 5 + r0];

@@ -380,7 +380,8 @@ static int launch(tum_ocp *c, bool events = true)
     c->ka.order = (c->lpt && c->order_valid && c->batch > 1024) ? c->dorder : nullptr;
     // the instrumented instantiation carries the phase timers (flag 4) and the debug dump (flag 2)
     if (c->sn) {
-        hipLaunchKernelGGL(snmpc_prologue_kernel, dim3(c->batch), dim3(64), 0, c->stream, c->sa);
+        if (c->sa.ns <= 10) hipLaunchKernelGGL(snmpc_prologue_kernel<10>, dim3(c->batch), dim3(64), 0, c->stream, c->sa);
+        else hipLaunchKernelGGL(snmpc_prologue_kernel<SN_NSMAX>, dim3(c->batch), dim3(64), 0, c->stream, c->sa);
         if (c->ka.flags & 6) hipLaunchKernelGGL((nmpc_rti_kernel<true, true>), dim3(c->batch), dim3(64), LDS_BYTES, c->stream, c->ka);
         else hipLaunchKernelGGL((nmpc_rti_kernel<false, true>), dim3(c->batch), dim3(64), LDS_BYTES, c->stream, c->ka);
         hipLaunchKernelGGL(snmpc_epilogue_kernel, dim3(c->batch), dim3(64), 0, c->stream, c->sa);
