@@ -1,0 +1,19 @@
+import os, sys
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+import torch
+from tum_control_amd import config, snmpc as snm
+from tum_control_amd.solver import CoupledSnmpcSolver
+from tum_control_amd.workloads import nominal_batch
+stds = np.asarray(config.MPC["stds"], dtype=float); w = snm.hammersley_normal(10, 3)
+A = snm.pce_matrix(w, snm.alpha_generation(3, 2)); offs = snm.x0_offsets(w, stds)
+for N, uph in ((40, 5), (40, 15)):
+    B = 4096
+    x0, yref = nominal_batch(B, N=N)
+    X0 = np.concatenate([x0[:, None, :], x0[:, None, :] + offs[None]], axis=1)
+    s = CoupledSnmpcSolver(N=N, dt=0.08, batch=B, Apce=A, uph=uph, gamma=0.8)
+    s.install_reference_ocp()
+    s.constraints_set(0, "lbx", X0.reshape(B, -1)); s.constraints_set(0, "ubx", X0.reshape(B, -1))
+    s.set_yref_all(yref); s.cold_start(); s.solve(); s.cold_start()
+    d = s.debug_dump(0)
+    print(N, uph, "prologue cycles P1, P2+def, P3:", d[20000:20003])

@@ -14,7 +14,7 @@
 //   * at stage s the sample matrices G^(i)_s only have 2s <= 2 uph non-zero columns.
 // So the solve is three launches on one stream:
 //   snmpc_prologue_kernel   sample stages: linearise ns*uph RK4 steps (lane = (stage, sample)), PCE weights of the chance
-//                           rows, column recursions of all samples in registers (lane = column), hands G_nom,s, g_nom,s
+//                           rows, column recursions of all samples (lane = (sample, column slot)), hands G_nom,s, g_nom,s
 //                           and the chance-constraint rows of the stages 1..uph to the fused kernel through `pro`
 //   nmpc_rti_kernel<.,true> the fused kernel: cost rows / gg rows / Hessian of stages <= uph from `pro`, nominal recursion
 //                           from stage uph, interior point, expansion of the nominal copy
@@ -44,6 +44,7 @@ struct SnArgs {
     double *pro;              // [b][uph][SN_PRO_STAGE]
     const double *dv;         // [b][NVP]        QP solution of the fused kernel (epilogue)
     const int *status;        // [b]
+    double *dbg;              // development aid: phase cycle counters of instance 0 (or null)
 };
 
 // gg circle with the limits looked up at |v| (SNMPC_acados_settings.py:60-67,100-113): value and d/d(vl, vt, r, a)
@@ -65,23 +66,34 @@ __device__ __forceinline__ void h_con_vabs(const Model &p, double vl, double vt,
     g7 = 2.0 * nlon / ax;
 }
 
-// NSM: compile-time bound of the number of samples (register file of the column recursions: NSM x 8 doubles per lane)
-template <int NSM>
+// dynamic LDS of the prologue (doubles): per (stage, sample) item the gg value, its 4 gradient entries and the PCE weight;
+// the constraint value per stage; the records of one stage; the reduction buffer of P3; the nominal copy's own defect per
+// stage; the column state of P3 (8 doubles per lane and pass); A_pce and the PCE coefficients per stage
+__host__ __device__ inline int sn_prologue_passes(int uph, int ns) { const int cs = 64 / ns; return (2 * uph + 1 + cs - 1) / cs; }
+__host__ __device__ inline int sn_prologue_lds_doubles(int uph, int ns)
+{
+    return 6 * uph * ns + (uph + 1) + ns * ABS + 9 * 64 + uph * 8 + sn_prologue_passes(uph, ns) * 8 * 64 +
+           SN_LMAX * SN_NSMAX + uph * SN_LMAX;
+}
+
 __global__ void __launch_bounds__(64) snmpc_prologue_kernel(const SnArgs sa)
 {
-    __shared__ double sH[SN_ITEMS], sGh[SN_ITEMS * 4], sCoef[SN_ITEMS], sHval[SN_UPHMAX + 1];
-    __shared__ double sRec[NSM * ABS];      // the records of one stage, all samples
+    extern __shared__ __attribute__((aligned(16))) double sn_lds[];
     const int lane = threadIdx.x, b = blockIdx.x;
     if (b >= sa.batch) return;
     const int N = sa.N, ns = sa.ns, L = sa.L, uph = sa.uph;
+    const int nitem = uph * ns;
+    double *sH = sn_lds, *sGh = sH + nitem, *sCoef = sGh + 4 * nitem, *sHval = sCoef + nitem;
+    double *sRec = sHval + (uph + 1), *sRed = sRec + ns * ABS, *sDef = sRed + 9 * 64, *sW = sDef + uph * 8;
+    double *sA = sW + sn_prologue_passes(uph, ns) * 8 * 64, *sC = sA + SN_LMAX * SN_NSMAX;
     const double dt = sa.dt;
     const double *gX = sa.X + (size_t)b * (N + 1) * NX;
     const double *gU = sa.U + (size_t)b * N * NU;
     const double *gXS = sa.XS + (size_t)b * (N + 1) * ns * NX;
     double *ws2 = sa.ws2 + (size_t)b * uph * ns * ABS;
     double *pro = sa.pro + (size_t)b * uph * SN_PRO_STAGE;
-    const int nitem = uph * ns;
 
+    const long long t0 = __builtin_readcyclecounter();
     // ---- P1: one RK4 step with sensitivities per (stage, sample); chance-constraint terms of the sample
     for (int item = lane; item < nitem; item += 64) {
         const int k = item / ns, i = item - k * ns;
@@ -107,97 +119,125 @@ __global__ void __launch_bounds__(64) snmpc_prologue_kernel(const SnArgs sa)
     }
     __threadfence_block();      // the records are read back by other lanes below
     __syncthreads();
+    const long long t1 = __builtin_readcyclecounter();
 
-    // ---- P2: PCE coefficients of the sample values, weights d(E + kappa sqrt(Var)) / d h_i  (stages 1..uph-1)
+    // ---- P2: PCE coefficients c = A h of the sample values per stage, weights d(E + kappa sqrt(Var)) / d h_i (stages
+    // 1..uph-1). A_pce sits in LDS; the short sums have compile-time bounds so that their operands are in flight together.
+    for (int o = lane; o < L * ns; o += 64) sA[o] = sa.Apce[o];
+    __syncthreads();
+    for (int o = lane; o < uph * L; o += 64) {          // c[k][l]
+        const int k = o / L, l = o - k * L;
+        double cl = 0.0;
+#pragma unroll
+        for (int j = 0; j < SN_NSMAX; j++) cl += (j < ns) ? sA[l * ns + j] * sH[k * ns + j] : 0.0;
+        sC[o] = cl;
+    }
+    __syncthreads();
     for (int item = lane; item < nitem; item += 64) {
         const int k = item / ns, i = item - k * ns;
         double w = 0.0;
         if (k >= 1) {
-            double c0 = 0.0, var = 0.0, acc = 0.0;
-            for (int l = 0; l < L; l++) {
-                double cl = 0.0;
-                for (int j = 0; j < ns; j++) cl += sa.Apce[l * ns + j] * sH[k * ns + j];
-                if (l == 0) c0 = cl;
-                else { var += cl * cl; acc += cl * sa.Apce[l * ns + i]; }
+            double var = 0.0, acc = 0.0;
+#pragma unroll
+            for (int l = 1; l < SN_LMAX; l++) {
+                const double cl = (l < L) ? sC[k * L + l] : 0.0;
+                var += cl * cl; acc += (l < L) ? cl * sA[l * ns + i] : 0.0;
             }
             const double sd = sqrt(var);
-            w = sa.Apce[i] + ((sd > 0.0) ? sa.kappa * acc / sd : 0.0);
-            if (i == 0) sHval[k] = c0 + sa.kappa * sd;
+            w = sA[i] + ((sd > 0.0) ? sa.kappa * acc / sd : 0.0);
+            if (i == 0) sHval[k] = sC[k * L] + sa.kappa * sd;
         }
         sCoef[item] = w;
     }
-    __syncthreads();
 
-    // ---- P3: column recursions of all samples, lane = column of G (2 uph of them), lane 2 uph = the constant column g
-    const int gl = 2 * uph;
-    const bool isg = (lane == gl);
-    const int jst = lane >> 1, r0 = lane & 1;
-    double w[NSM][8];
-    // the records of a stage are contiguous in ws2: staged through LDS one stage ahead (uniform-address vector loads of
-    // 530 doubles per stage straight from L2 cost more than the arithmetic of this phase)
-    constexpr int NCH = (NSM * ABS + 63) / 64;
+    // the nominal copy's own defect: sum_i a_i X^(i)_s - X_nom,s
+    for (int o = lane; o < uph * 8; o += 64) {
+        const int s = (o >> 3) + 1, r = o & 7;
+        double acc = -gX[s * NX + r];
+#pragma unroll
+        for (int ii = 0; ii < SN_NSMAX; ii++) acc += (ii < ns) ? sA[ii] * gXS[((size_t)s * ns + ii) * NX + r] : 0.0;
+        sDef[o] = acc;
+    }
+
+    const long long t2 = __builtin_readcyclecounter();
+    // ---- P3: column recursions G^(i)_{k+1} = A^(i)_k G^(i)_k + B^(i)_k e_k of all samples. lane = (sample i, column slot c):
+    // floor(64 / ns) columns of every sample advance together; slot 0 is the constant column g, slot q >= 1 column q-1 of G.
+    // Stage k only has 2(k+1) live columns, so it takes ceil((2k+3) / slots) passes; the column state of the passes waits in
+    // LDS. The PCE mean over the samples (G_nom) and the weighted sum of the chance-constraint row are reductions over the
+    // sample lanes through LDS. The records of a stage are contiguous in ws2 and staged through LDS one stage ahead.
+    // (wsync, not __syncthreads: one wavefront per workgroup, and a barrier would drain the outstanding stores to `pro`
+    // and the record prefetch in every pass)
+    const int CS = 64 / ns;
+    const int si = lane / CS, sc = lane - si * CS;
+    const bool act = si < ns;
+    const int i = act ? si : 0;
     const int nrec = ns * ABS;
+    constexpr int NCH = (SN_NSMAX * ABS + 63) / 64;
+    const double ai = sA[i];
+    const int npass = sn_prologue_passes(uph, ns);
+    for (int pass = 0; pass < npass; pass++) {
+        const bool isg = act && pass == 0 && sc == 0;
+#pragma unroll
+        for (int r = 0; r < 8; r++)
+            sW[(pass * 8 + r) * 64 + lane] = isg ? sa.xs0[((size_t)b * ns + i) * NX + r] - gXS[(size_t)i * NX + r] : 0.0;
+    }
     double pre[NCH];
 #pragma unroll
     for (int c = 0; c < NCH; c++) { const int idx = lane + 64 * c; pre[c] = (uph > 0 && idx < nrec) ? ws2[idx] : 0.0; }
-#pragma unroll
-    for (int i = 0; i < NSM; i++) {
-#pragma unroll
-        for (int r = 0; r < 8; r++) w[i][r] = 0.0;
-        if (i < ns && isg) {
-#pragma unroll
-            for (int r = 0; r < 8; r++) w[i][r] = sa.xs0[((size_t)b * ns + i) * NX + r] - gXS[(size_t)i * NX + r];
-        }
-    }
     for (int k = 0; k < uph; k++) {
         const int s = k + 1;
-        __syncthreads();
+        wsync();
 #pragma unroll
         for (int c = 0; c < NCH; c++) { const int idx = lane + 64 * c; if (idx < nrec) sRec[idx] = pre[c]; }
-        __syncthreads();
+        wsync();
         if (k + 1 < uph) {
 #pragma unroll
             for (int c = 0; c < NCH; c++) { const int idx = lane + 64 * c; pre[c] = (idx < nrec) ? ws2[(size_t)(k + 1) * nrec + idx] : 0.0; }
         }
-        double gn[8], row = 0.0;
+        const double *rec = sRec + i * ABS;
+        double *pg = pro + (size_t)k * SN_PRO_STAGE;
+        const int np_k = (2 * k + 3 + CS - 1) / CS;
+        for (int pass = 0; pass < np_k; pass++) {
+            const int q = pass * CS + sc;
+            const bool isg = act && q == 0, valid = act && q <= 2 * uph;
+            const int col = q - 1, jst = col >> 1, r0 = col & 1;
+            double w[8];
 #pragma unroll
-        for (int r = 0; r < 8; r++) gn[r] = 0.0;
-        const double sel = (lane < gl && jst == k) ? 1.0 : 0.0, selg = isg ? 1.0 : 0.0;
+            for (int r = 0; r < 8; r++) w[r] = sW[(pass * 8 + r) * 64 + lane];
+            const double sel = (valid && !isg && jst == k) ? 1.0 : 0.0, selg = isg ? 1.0 : 0.0;
+            apply_A(rec, w);
 #pragma unroll
-        for (int i = 0; i < NSM; i++) {
-            if (i < ns) {
-                const double *rec = sRec + i * ABS;
-                apply_A(rec, w[i]);
+            for (int r = 0; r < 6; r++) w[r] += sel * rec[2 + r * 7 + 5 + r0];
+            w[6] += sel * (r0 ? dt : 0.0);
+            w[7] += sel * (r0 ? 0.0 : dt);
 #pragma unroll
-                for (int r = 0; r < 6; r++) w[i][r] += sel * rec[2 + r * 7 + 5 + r0];
-                w[i][6] += sel * (r0 ? dt : 0.0);
-                w[i][7] += sel * (r0 ? 0.0 : dt);
+            for (int r = 0; r < 8; r++) w[r] += selg * rec[44 + r];
 #pragma unroll
-                for (int r = 0; r < 8; r++) w[i][r] += selg * rec[44 + r];
-                const double a = sa.Apce[i];
-#pragma unroll
-                for (int r = 0; r < 8; r++) gn[r] += a * w[i][r];
-                if (isg) {   // the nominal copy's own defect: sum_i a_i X^(i)_s - X_nom,s
-                    const double *xq = gXS + ((size_t)s * ns + i) * NX;
-#pragma unroll
-                    for (int r = 0; r < 8; r++) gn[r] += a * xq[r];
-                }
-                if (s < uph) {
-                    const int it = s * ns + i;
-                    row += sCoef[it] * (sGh[it * 4 + 0] * w[i][3] + sGh[it * 4 + 1] * w[i][4] + sGh[it * 4 + 2] * w[i][5] +
-                                        sGh[it * 4 + 3] * w[i][7]);
+            for (int r = 0; r < 8; r++) { sW[(pass * 8 + r) * 64 + lane] = w[r]; sRed[r * 64 + lane] = valid ? ai * w[r] : 0.0; }
+            double rowv = 0.0;
+            if (s < uph) {
+                const int it = s * ns + i;
+                rowv = sCoef[it] * (sGh[it * 4 + 0] * w[3] + sGh[it * 4 + 1] * w[4] + sGh[it * 4 + 2] * w[5] + sGh[it * 4 + 3] * w[7]);
+            }
+            sRed[8 * 64 + lane] = valid ? rowv : 0.0;
+            wsync();
+            for (int o = lane; o < 9 * CS; o += 64) {
+                const int r = o / CS, cc = o - r * CS, qo = pass * CS + cc;
+                double acc = 0.0;
+                for (int ii = 0; ii < ns; ii++) acc += sRed[r * 64 + ii * CS + cc];
+                if (qo <= 2 * uph) {
+                    const bool og = (qo == 0);
+                    const int colo = og ? 2 * uph : qo - 1;
+                    if (r < 8) pg[r * 64 + colo] = acc + (og ? sDef[k * 8 + r] : 0.0);
+                    else pg[SN_PRO_G + colo] = acc + ((og && s < uph) ? sHval[s] : 0.0);
                 }
             }
+            wsync();
         }
-        if (isg) {
-#pragma unroll
-            for (int r = 0; r < 8; r++) gn[r] -= gX[s * NX + r];
-            if (s < uph) row += sHval[s];
-        }
-        double *pg = pro + (size_t)k * SN_PRO_STAGE;
-#pragma unroll
-        for (int r = 0; r < 8; r++) pg[r * 64 + lane] = gn[r];
-        pg[SN_PRO_G + lane] = row;
+    }
+    if (sa.dbg && b == 0 && lane == 0) {
+        const long long t3 = __builtin_readcyclecounter();
+        sa.dbg[0] = (double)(t1 - t0); sa.dbg[1] = (double)(t2 - t1); sa.dbg[2] = (double)(t3 - t2);
     }
 }
 

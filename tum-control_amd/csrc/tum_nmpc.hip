@@ -167,6 +167,11 @@ extern "C" int tum_ocp_snmpc_attach(tum_ocp *c, int ns, int L, const double *Apc
     if (!(gamma > 0.0 && gamma <= 1.0)) return fail("snmpc_attach: gamma out of range (0,1]");
     if (c->d.nsub != 1) return fail("snmpc_attach: the SNMPC model is DISCRETE with one RK4 step per stage: create the capsule with nsub = 1");
     if (c->d.store_qp_in) return fail("snmpc_attach: store_qp_in is not available for the stacked state");
+    {
+        const size_t lds = sizeof(double) * sn_prologue_lds_doubles(uph, ns);
+        if (lds > 128 * 1024) return fail("snmpc_attach: n_samples x uph too large for the prologue kernel's LDS");
+        HIPCHK(hipFuncSetAttribute((const void *)snmpc_prologue_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+    }
     HIPCHK(hipSetDevice(c->d.device));
     const size_t B = c->batch; const int N = c->N;
     bool ok = true;
@@ -185,6 +190,7 @@ extern "C" int tum_ocp_snmpc_attach(tum_ocp *c, int ns, int L, const double *Apc
     sa.mp = c->ka.mp;
     sa.X = c->dX; sa.U = c->dU; sa.XS = c->dXS; sa.xs0 = c->dxs0; sa.Apce = c->dApce; sa.ws2 = c->dws2; sa.pro = c->dpro;
     sa.dv = c->ddv; sa.status = c->dstatus;
+    sa.dbg = c->ddbg + 20000;                            // tail of instance 0's dump area (tum_ocp_debug_dump), unused by the fused kernel
     c->ka.uph = uph; c->ka.pro = c->dpro; c->ka.dv = c->ddv;
     c->sn = true;
     return 0;
@@ -380,8 +386,8 @@ static int launch(tum_ocp *c, bool events = true)
     c->ka.order = (c->lpt && c->order_valid && c->batch > 1024) ? c->dorder : nullptr;
     // the instrumented instantiation carries the phase timers (flag 4) and the debug dump (flag 2)
     if (c->sn) {
-        if (c->sa.ns <= 10) hipLaunchKernelGGL(snmpc_prologue_kernel<10>, dim3(c->batch), dim3(64), 0, c->stream, c->sa);
-        else hipLaunchKernelGGL(snmpc_prologue_kernel<SN_NSMAX>, dim3(c->batch), dim3(64), 0, c->stream, c->sa);
+        hipLaunchKernelGGL(snmpc_prologue_kernel, dim3(c->batch), dim3(64), sizeof(double) * sn_prologue_lds_doubles(c->sa.uph, c->sa.ns),
+                           c->stream, c->sa);
         if (c->ka.flags & 6) hipLaunchKernelGGL((nmpc_rti_kernel<true, true>), dim3(c->batch), dim3(64), LDS_BYTES, c->stream, c->ka);
         else hipLaunchKernelGGL((nmpc_rti_kernel<false, true>), dim3(c->batch), dim3(64), LDS_BYTES, c->stream, c->ka);
         hipLaunchKernelGGL(snmpc_epilogue_kernel, dim3(c->batch), dim3(64), 0, c->stream, c->sa);
