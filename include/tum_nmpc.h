@@ -149,6 +149,11 @@ int tum_pce_moments(tum_ocp *c, const char *field, int stage, const double *A, i
  * on the nominal copy with |v| as the speed row; the gg limits are looked up at |v|. 0 <= uph <= min(N, 31). */
 int tum_ocp_snmpc_attach(tum_ocp *c, int ns, int L, const double *Apce, int uph, double gamma);
 int tum_ocp_snmpc_samples(const tum_ocp *c);   /* ns, or 0 for a nominal capsule */
+/* Offsets of the sample initial conditions from the nominal one (compute_x0dist, Stochastic_NMPC/stochastic_mpc_utils.py:78-91;
+ * SNMPC_class.py:259-264 recomputes x0_samples from x0 before every solve): ns x 8 (host). Once registered, an 8-value
+ * lbx_0 / ubx_0 -- and the device closed loop (tum_sim_*), whose state estimator writes the nominal x0 -- fans out to the
+ * sample copies on the device at every solve; a stacked 8 (ns+1) lbx_0 switches back to explicit samples. */
+int tum_ocp_snmpc_set_offsets(tum_ocp *c, const double *offs);
 /* R2NMPC constraint tightening after a solve (Reduced_Robustified_NMPC_class.py:286-366): propagates
  * Sigma_{k+1} = A_k Sigma_k A_k' + B W B' with the A_k of the last linearisation (needs store_qp_in) and rewrites the
  * capsule's lbx/ubx (steering angle) and uh (gg circle) of stages 1..N-1 for the NEXT solve.

@@ -49,6 +49,15 @@ def main():
             print(f"  CPU restatement (88-state condensing that skips the zero blocks, one thread): {1e3 * np.median(t):.1f} ms per solve; "
                   f"reference acados SNMPC: about 6.1 ms per solve (its logs)")
         del s
+    # the SNMPC controller in closed loop, planner / plant / estimator / x0 fan-out as device kernels
+    from tum_control_amd.closed_loop import ClosedLoopBatch
+    for Bc, steps in ((1, 1000), (4096, 200)):
+        cl = ClosedLoopBatch("monteblanco", batch=Bc, N=38, Tp=3.04, controller="snmpc", on_device=True, log_capacity=steps)
+        t0 = time.perf_counter(); lg = cl.run(steps); wall = time.perf_counter() - t0
+        dbg = lg["simSolverDebug"]
+        print(f"SNMPC closed loop on the device, batch {Bc}, {steps} steps: {1e3 * wall / steps:.3f} ms/step, {Bc * steps / wall:,.0f} closed-loop solves/s, "
+              f"status 0 {(dbg[:, :, 4] == 0).mean():.4f}, mean qp_iter {dbg[:, :, 3].mean():.2f}")
+        del cl
 
 
 if __name__ == "__main__":

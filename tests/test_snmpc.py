@@ -250,3 +250,43 @@ def test_gpu_snmpc_controller_mirror(golden_dir):
     c.reset(x0)
     xf = c.acados_solver.get(3, "x")
     np.testing.assert_array_equal(xf, snm.compute_x0dist(x0, w, stds).flatten())
+
+
+@pytest.mark.gpu
+def test_gpu_snmpc_closed_loop(golden_dir):
+    """The SNMPC controller in closed loop (planner -> coupled solve -> plant -> estimator, main.py:48-78 with
+    MPC_type SNMPC): host loop around the GPU solver vs the same loop around the oracle, and the loop that never leaves
+    the device (x0 fan-out to the samples as a kernel) vs the host loop."""
+    from tum_control_amd.closed_loop import ClosedLoopBatch, plant_step, MovingAverageEstimator
+    from tum_control_amd.planner import planner_emulator, yref_from_ref
+    from tum_control_amd import config
+    snm, stds, w, A = _pce()
+    steps, N, Tp = 30, 38, 3.04
+    cl = ClosedLoopBatch("monteblanco", batch=1, N=N, Tp=Tp, controller="snmpc")
+    lg = cl.run(steps)
+    # the same loop around the oracle
+    m = config.MPC
+    o = orc.OracleSnmpcOcp(N=N, dt=Tp / N, Apce=A, uph=5)
+    o.set_weights(m["q_lon"], m["q_yaw"], m["q_vel"], m["r_jerk"], m["r_steering_rate"], m["L1_pen"], m["L2_pen"], scale=0.01)
+    x_mpc = lg["MPC_SimX"][0][0].copy(); x_sim = x_mpc[:7].copy()[None]; pose = x_mpc[:2].copy()
+    o.cold_start(snm.compute_x0dist(x_mpc, w, stds))
+    est = MovingAverageEstimator(1)
+    cfg = config.default_config()
+    for t in range(steps):
+        _, ref = planner_emulator(cl.track, pose, N + 1, Tp, True)
+        o.yref[:] = yref_from_ref(ref, N)
+        assert o.solve() == 0
+        u0, x1 = o.U[0].copy(), o.X[1, 0].copy()
+        np.testing.assert_allclose(lg["simU"][t][0], u0, rtol=1e-6, atol=1e-7, err_msg=f"step {t}")
+        x_sim = plant_step(x_sim, np.array([x1[7]]), np.array([u0[1]]), cfg, 0.02)
+        pose = x_sim[0, :2].copy()
+        x_mpc = est(np.concatenate([x_sim, [[x1[7]]]], axis=1))[0]
+        o.set_initial_state(snm.compute_x0dist(x_mpc, w, stds))
+    np.testing.assert_allclose(lg["CiLX"][-1][0], x_sim[0], rtol=1e-7, atol=1e-7)
+    assert (lg["simSolverDebug"][:, 0, 4] == 0).all()
+    # entirely on the device, three vehicles
+    cd = ClosedLoopBatch("monteblanco", batch=3, N=N, Tp=Tp, controller="snmpc", on_device=True, log_capacity=steps)
+    ld = cd.run(steps)
+    for b in range(3):
+        np.testing.assert_allclose(ld["simU"][:, b], lg["simU"][:, 0], rtol=1e-7, atol=1e-8)
+        np.testing.assert_allclose(ld["CiLX"][:, b], lg["CiLX"][:, 0], rtol=1e-9, atol=1e-9)

@@ -15,7 +15,7 @@ import numpy as np
 
 from . import config as _config
 from .planner import load_track, planner_emulator, yref_from_ref
-from .solver import BatchedOcpSolver, DeviceClosedLoop
+from .solver import BatchedOcpSolver, CoupledSnmpcSolver, DeviceClosedLoop
 
 WINDOWS = (1, 1, 4, 2, 2, 3, 4, 2)          # SimulationMode_main_class.py:86
 
@@ -89,7 +89,7 @@ class ClosedLoopBatch:
     [q_xy, q_yaw, q_vel, r_jerk, r_steer, L1, L2] as in update_cost_function_weights (None: YAML defaults x0.01)."""
 
     def __init__(self, track_name, batch=1, params=None, N=38, Tp=3.04, Ts=0.02, idx_start=0, cfg=None, device=0,
-                 on_device=False, log_capacity=0):
+                 on_device=False, log_capacity=0, controller="nominal"):
         self.cfg = cfg or _config.default_config()
         self.track = load_track(track_name)
         self.B, self.N, self.Tp, self.Ts = batch, N, Tp, Ts
@@ -98,7 +98,19 @@ class ClosedLoopBatch:
         self.x_mpc = np.tile(x0, (batch, 1))                     # X0_MPC
         self.x_sim = self.x_mpc[:, :7].copy()                    # X0_sim
         self.pose = self.x_mpc[:, :2].copy()
-        self.solver = BatchedOcpSolver(N=N, dt=Tp / N, nsub=3, batch=batch, device=device, cfg=self.cfg)
+        if controller == "nominal":       # main.py:33-36 picks the controller class by MPC_params['MPC_type']
+            self.solver = BatchedOcpSolver(N=N, dt=Tp / N, nsub=3, batch=batch, device=device, cfg=self.cfg)
+        elif controller == "snmpc":       # the coupled SNMPC OCP; x0_samples = compute_x0dist(x0) before every solve
+            from . import snmpc as _snm
+            m = self.cfg["mpc"]
+            stds = np.asarray(m["stds"], dtype=float)
+            nvar = int(np.count_nonzero(stds))
+            w = _snm.hammersley_normal(m["n_samples"], nvar)
+            A = _snm.pce_matrix(w, _snm.alpha_generation(nvar, m["expansion_degree"]))
+            self.solver = CoupledSnmpcSolver(N=N, dt=Tp / N, batch=batch, Apce=A, uph=min(int(m["uncertainty_propagation_horizon"]), N),
+                                             gamma=m["gamma"], device=device, cfg=self.cfg, x0_offsets=_snm.x0_offsets(w, stds))
+        else:
+            raise ValueError("controller must be 'nominal' or 'snmpc'")
         self.solver.install_reference_ocp()
         if params is not None:
             self.set_weights(np.asarray(params, dtype=float).reshape(batch, 7))

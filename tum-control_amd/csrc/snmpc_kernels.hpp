@@ -280,6 +280,15 @@ __global__ void __launch_bounds__(64) snmpc_epilogue_kernel(const SnArgs sa)
     }
 }
 
+// sample initial conditions from the nominal one: xs0[b][i] = x0[b] + offs[i]  (compute_x0dist, stochastic_mpc_utils.py:78-91)
+__global__ void snmpc_fanout_kernel(double *xs0, const double *x0, const double *offs, int ns, int batch)
+{
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= batch * ns * NX) return;
+    const int r = t & 7, bi = t >> 3, b = bi / ns, i = bi - b * ns;
+    xs0[t] = x0[b * NX + r] + offs[i * NX + r];
+}
+
 // cold start of the sample copies: X^(i)_k = xs0^(i) for all k (SNMPC_class.py:126-127)
 __global__ void snmpc_cold_start_kernel(double *XS, const double *xs0, int N, int ns, int batch)
 {

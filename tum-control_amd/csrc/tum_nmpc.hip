@@ -37,7 +37,8 @@ struct tum_ocp {
     // coupled SNMPC OCP (tum_ocp_snmpc_attach)
     bool sn;
     SnArgs sa;
-    double *dXS, *dxs0, *dApce, *dws2, *dpro, *ddv;
+    double *dXS, *dxs0, *dApce, *dws2, *dpro, *ddv, *doffs;
+    bool have_offs, fanout;        // sample initial conditions derived from the nominal x0 at every solve
 };
 
 static const int DBG_STRIDE = 20480;
@@ -70,7 +71,8 @@ extern "C" tum_ocp *tum_ocp_create(const tum_ocp_desc *desc)
     if (hipSetDevice(desc->device) != hipSuccess) { fail("hipSetDevice failed"); return nullptr; }
     tum_ocp *c = new tum_ocp();
     c->d = *desc; c->N = desc->N; c->batch = desc->batch; c->last_ms = 0; c->solved = false;
-    c->sn = false; c->dXS = c->dxs0 = c->dApce = c->dws2 = c->dpro = c->ddv = nullptr;
+    c->sn = false; c->dXS = c->dxs0 = c->dApce = c->dws2 = c->dpro = c->ddv = c->doffs = nullptr;
+    c->have_offs = c->fanout = false;
     const int N = c->N; const size_t B = c->batch;
     bool ok = true;
     ok &= hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) == hipSuccess; c->own_stream = true;
@@ -147,7 +149,7 @@ extern "C" void tum_ocp_free(tum_ocp *c)
     (void)hipFree(c->dcost); (void)hipFree(c->dres); (void)hipFree(c->dslack); (void)hipFree(c->dstatus); (void)hipFree(c->dqpiter); (void)hipFree(c->dqpstatus); (void)hipFree(c->dorder);
     if (c->dqpin) (void)hipFree(c->dqpin);
     (void)hipFree(c->ddbg); (void)hipFree(c->dprof); (void)hipFree(c->dws);
-    (void)hipFree(c->dXS); (void)hipFree(c->dxs0); (void)hipFree(c->dApce); (void)hipFree(c->dws2); (void)hipFree(c->dpro); (void)hipFree(c->ddv);
+    (void)hipFree(c->dXS); (void)hipFree(c->dxs0); (void)hipFree(c->dApce); (void)hipFree(c->dws2); (void)hipFree(c->dpro); (void)hipFree(c->ddv); (void)hipFree(c->doffs);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
@@ -181,6 +183,7 @@ extern "C" int tum_ocp_snmpc_attach(tum_ocp *c, int ns, int L, const double *Apc
     ok &= dalloc(&c->dws2, B * (size_t)(uph > 0 ? uph : 1) * ns * ABS) == hipSuccess;
     ok &= dalloc(&c->dpro, B * (size_t)(uph > 0 ? uph : 1) * SN_PRO_STAGE) == hipSuccess;
     ok &= dalloc(&c->ddv, B * NVP) == hipSuccess;
+    ok &= dalloc(&c->doffs, (size_t)ns * NX) == hipSuccess;
     if (!ok) return fail("snmpc_attach: device allocation failed");
     HIPCHK(hipMemcpy(c->dApce, Apce, sizeof(double) * L * ns, hipMemcpyHostToDevice));
     SnArgs &sa = c->sa;
@@ -196,6 +199,26 @@ extern "C" int tum_ocp_snmpc_attach(tum_ocp *c, int ns, int L, const double *Apc
     return 0;
 }
 extern "C" int tum_ocp_snmpc_samples(const tum_ocp *c) { return (c && c->sn) ? c->sa.ns : 0; }
+
+// Offsets of the sample initial conditions from the nominal one (compute_x0dist, stochastic_mpc_utils.py:78-91:
+// row s = x0 + stds * w_s), ns x 8 (host). Once registered, an 8-value lbx_0 / ubx_0 (and the device closed loop, whose
+// state estimator writes the nominal x0) fans out to the sample copies on the device at every solve.
+extern "C" int tum_ocp_snmpc_set_offsets(tum_ocp *c, const double *offs)
+{
+    if (!c || !offs) return fail("null argument");
+    if (!c->sn) return fail("snmpc_set_offsets: not an SNMPC capsule (tum_ocp_snmpc_attach)");
+    HIPCHK(hipSetDevice(c->d.device));
+    HIPCHK(hipMemcpy(c->doffs, offs, sizeof(double) * c->sa.ns * NX, hipMemcpyHostToDevice));
+    c->have_offs = true;
+    return 0;
+}
+static int sn_fanout(tum_ocp *c)
+{
+    const int n = c->batch * c->sa.ns * NX;
+    hipLaunchKernelGGL(snmpc_fanout_kernel, dim3((n + 255) / 256), dim3(256), 0, c->stream, c->dxs0, c->dx0, c->doffs, c->sa.ns, c->batch);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
 
 static int chk_range(tum_ocp *c, int b0, int nb)
 {
@@ -314,10 +337,15 @@ extern "C" int tum_ocp_constraints_set(tum_ocp *c, int stage, const char *field,
         if (stage == 0) {   // x0 equality: lbx_0 = ubx_0 = x0 (NMPC_class.py:243-246)
             if (c->sn && len == NX * (c->sa.ns + 1)) {   // x0 of all copies (SNMPC_class.py:262-264)
                 if (stride != 0 && stride < len) return fail("stride < len");
+                c->fanout = false;
                 if (put(c, c->dx0, NX, 0, v, NX, b0, nb, stride)) return 1;
                 return put(c, c->dxs0, (size_t)c->sa.ns * NX, 0, v + NX, c->sa.ns * NX, b0, nb, stride);
             }
             if (len != NX) return fail("constraints_set lbx/ubx at stage 0: expected 8 values (x0)");
+            if (c->sn) {
+                if (!c->have_offs) return fail("constraints_set lbx/ubx at stage 0: an SNMPC capsule takes 8 (n_samples+1) values, or 8 after tum_ocp_snmpc_set_offsets");
+                c->fanout = true;
+            }
             return put(c, c->dx0, NX, 0, v, len, b0, nb, stride);
         }
         if (len != 1) return fail("constraints_set lbx/ubx: expected 1 value (steering angle)");
@@ -386,6 +414,7 @@ static int launch(tum_ocp *c, bool events = true)
     c->ka.order = (c->lpt && c->order_valid && c->batch > 1024) ? c->dorder : nullptr;
     // the instrumented instantiation carries the phase timers (flag 4) and the debug dump (flag 2)
     if (c->sn) {
+        if (c->fanout && sn_fanout(c)) return 1;
         hipLaunchKernelGGL(snmpc_prologue_kernel, dim3(c->batch), dim3(64), sizeof(double) * sn_prologue_lds_doubles(c->sa.uph, c->sa.ns),
                            c->stream, c->sa);
         if (c->ka.flags & 6) hipLaunchKernelGGL((nmpc_rti_kernel<true, true>), dim3(c->batch), dim3(64), LDS_BYTES, c->stream, c->ka);
@@ -481,6 +510,7 @@ extern "C" int tum_ocp_cold_start(tum_ocp *c)
 {
     if (!c) return fail("null capsule");
     hipLaunchKernelGGL(cold_start_kernel, dim3(c->batch), dim3(64), 0, c->stream, c->dX, c->dU, c->dx0, c->N, c->batch);
+    if (c->sn && c->fanout && sn_fanout(c)) return 1;
     if (c->sn) hipLaunchKernelGGL(snmpc_cold_start_kernel, dim3(c->batch), dim3(256), 0, c->stream, c->dXS, c->dxs0, c->N, c->sa.ns, c->batch);
     HIPCHK(hipGetLastError());
     return 0;
@@ -701,6 +731,10 @@ extern "C" tum_sim *tum_sim_create(tum_ocp *c, const double *track, int n_track,
     if (n_track < 2 || !(Tp > 0) || !(Ts > 0) || n_elem < 1 || log_capacity < 0) { fail("sim_create: bad arguments"); return nullptr; }
     for (int i = 0; i < 8; i++) if (windows[i] < 1 || windows[i] > 4) { fail("sim_create: estimator windows must be 1..4"); return nullptr; }
     if (hipSetDevice(c->d.device) != hipSuccess) { fail("hipSetDevice failed"); return nullptr; }
+    if (c->sn) {   // the state estimator writes the nominal x0 only: the samples follow by fan-out
+        if (!c->have_offs) { fail("sim_create: an SNMPC capsule needs its sample offsets (tum_ocp_snmpc_set_offsets)"); return nullptr; }
+        c->fanout = true;
+    }
     tum_sim *s = new tum_sim();
     memset(s, 0, sizeof(*s));
     s->c = c; s->n_track = n_track; s->loop_circuit = loop_circuit; s->n_elem = n_elem; s->Tp = Tp; s->Ts = Ts; s->log_cap = log_capacity;

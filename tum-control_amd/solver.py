@@ -49,7 +49,7 @@ C_SYMBOLS = ["tum_ocp_create", "tum_ocp_free", "tum_ocp_last_error", "tum_ocp_ba
              "tum_ocp_set_stream", "tum_ocp_get_device", "tum_ocp_cold_start", "tum_ocp_last_kernel_ms",
              "tum_ocp_debug_dump", "tum_ocp_profile_phases", "tum_ocp_set_schedule",
              "tum_ocp_set_x0_fanout", "tum_pce_moments", "tum_ocp_r2_backoff", "tum_ocp_constraints_get",
-             "tum_ocp_snmpc_attach", "tum_ocp_snmpc_samples",
+             "tum_ocp_snmpc_attach", "tum_ocp_snmpc_samples", "tum_ocp_snmpc_set_offsets",
              "tum_planner_emulate", "tum_sim_create", "tum_sim_free", "tum_sim_set_state", "tum_sim_plan", "tum_sim_advance",
              "tum_sim_run", "tum_sim_steps", "tum_sim_get"]
 
@@ -96,6 +96,7 @@ def load_library(path=None):
     L.tum_ocp_constraints_get.argtypes = [vp, ci, cs, dp, ci, ci]
     L.tum_ocp_snmpc_attach.argtypes = [vp, ci, ci, dp, ci, ctypes.c_double]
     L.tum_ocp_snmpc_samples.argtypes = [vp]
+    L.tum_ocp_snmpc_set_offsets.argtypes = [vp, dp]
     ip = ctypes.POINTER(ctypes.c_int); cd = ctypes.c_double
     L.tum_planner_emulate.argtypes = [dp, ci, dp, ci, ci, cd, ci, dp, ip, ci]
     L.tum_sim_create.restype = vp; L.tum_sim_create.argtypes = [vp, dp, ci, cd, ci, cd, ci, ip, ci]
@@ -400,7 +401,7 @@ class CoupledSnmpcSolver(BatchedOcpSolver):
     """
 
     def __init__(self, N=38, dt=0.08, batch=1, Apce=None, uph=5, gamma=0.8, device=0, cfg=None,
-                 qp_iter_max=50, qp_tol=(1e-8, 1e-8, 1e-8), qp_mu0=0.1, qp_t0=0.1):
+                 qp_iter_max=50, qp_tol=(1e-8, 1e-8, 1e-8), qp_mu0=0.1, qp_t0=0.1, x0_offsets=None):
         super().__init__(N=N, dt=dt, nsub=1, batch=batch, device=device, cfg=cfg, qp_iter_max=qp_iter_max,
                          qp_tol=qp_tol, qp_mu0=qp_mu0, qp_t0=qp_t0)
         self.Apce = np.ascontiguousarray(Apce, dtype=np.float64)
@@ -410,6 +411,16 @@ class CoupledSnmpcSolver(BatchedOcpSolver):
         self.uph, self.gamma = int(uph), float(gamma)
         self.nx = 8 * (self.ns + 1)
         self._chk(self._L.tum_ocp_snmpc_attach(self._h, self.ns, self.L, _dp(self.Apce), self.uph, self.gamma), "snmpc_attach")
+        if x0_offsets is not None:
+            self.set_x0_offsets(x0_offsets)
+
+    def set_x0_offsets(self, offsets):
+        """(n_s, 8) offsets of the sample initial conditions (stds * w_s): afterwards set_x0 / constraints_set(0, 'lbx', x0)
+        with the 8 nominal values fan out to the samples on the device (compute_x0dist as a kernel)."""
+        o = np.ascontiguousarray(offsets, dtype=np.float64)
+        if o.shape != (self.ns, 8):
+            raise Exception(f"CoupledSnmpcSolver.set_x0_offsets: expected shape ({self.ns}, 8)")
+        self._chk(self._L.tum_ocp_snmpc_set_offsets(self._h, _dp(o)), "set_x0_offsets")
 
     def set(self, stage, field, value):
         if field == "p":
