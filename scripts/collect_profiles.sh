@@ -14,4 +14,6 @@ python bench.py --steps 20 --warmup 3 --no-cpu-baseline --compare-schedules 2>&1
 python scripts/phase_profile.py 2>&1 | grep -v amdgpu > $OUT/phase_cycles.txt
 python scripts/run_configs.py 2>&1 | grep configs > $OUT/configs.txt
 python scripts/pcie_inclusive.py 2>&1 | grep PCIe >> $OUT/configs.txt
+python scripts/snmpc_bench.py 2>&1 | grep -v amdgpu.ids > $OUT/snmpc_bench.txt
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/sn_stats -o s -- python scripts/snmpc_bench.py > /dev/null 2>&1
 head -3 $OUT/stats/s_kernel_stats.csv; cut -c1-200 $OUT/bench.json

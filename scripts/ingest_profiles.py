@@ -6,6 +6,9 @@ src, dst = "gpurun_out/final", "profiles"
 shutil.copy(f"{src}/stats/s_kernel_stats.csv", f"{dst}/{tag}_kernel_stats.csv")
 shutil.copy(f"{src}/phase_cycles.txt", f"{dst}/{tag}_phase_cycles.txt")
 shutil.copy(f"{src}/configs.txt", f"{dst}/{tag}_configs.txt")
+if os.path.exists(f"{src}/snmpc_bench.txt"):
+    shutil.copy(f"{src}/snmpc_bench.txt", f"{dst}/{tag}_snmpc_bench.txt")
+    shutil.copy(f"{src}/sn_stats/s_kernel_stats.csv", f"{dst}/{tag}_snmpc_kernel_stats.csv")
 if os.path.exists(f"{src}/schedules.json"):
     shutil.copy(f"{src}/schedules.json", f"{dst}/{tag}_schedules.json")
 out = {"kernel": "nmpc_rti_kernel<false>", "batch": 4096, "N": 40,
