@@ -290,3 +290,29 @@ def test_gpu_snmpc_closed_loop(golden_dir):
     for b in range(3):
         np.testing.assert_allclose(ld["simU"][:, b], lg["simU"][:, 0], rtol=1e-7, atol=1e-8)
         np.testing.assert_allclose(ld["CiLX"][:, b], lg["CiLX"][:, 0], rtol=1e-9, atol=1e-9)
+
+
+@pytest.mark.gpu
+def test_gpu_snmpc_errors():
+    """acados-style failures of the coupled solver: wrong dimensions and unsupported configurations raise, nothing is silent"""
+    from tum_control_amd.solver import CoupledSnmpcSolver, BatchedOcpSolver, _dp
+    snm, stds, w, A = _pce()
+    with pytest.raises(Exception, match="propagation horizon"):
+        CoupledSnmpcSolver(N=40, batch=1, Apce=A, uph=32)
+    with pytest.raises(Exception, match="n_samples"):
+        CoupledSnmpcSolver(N=10, batch=1, Apce=np.zeros((3, 17)), uph=2)
+    n = BatchedOcpSolver(N=10, nsub=3, batch=1)
+    assert n._L.tum_ocp_snmpc_attach(n._h, 10, 10, _dp(A), 5, 0.8) != 0 and "nsub = 1" in n._err()
+    s = CoupledSnmpcSolver(N=10, batch=2, Apce=A, uph=3)
+    with pytest.raises(Exception, match="snmpc_set_offsets"):
+        s.set_x0(np.zeros(8))                                   # 8 values need the registered sample offsets
+    with pytest.raises(Exception, match="mismatching dimension"):
+        s.set(1, "x", np.zeros(87))
+    with pytest.raises(Exception):
+        s.get_from_qp_in(0, "A")
+    s.set_x0_offsets(snm.x0_offsets(w, stds))
+    x0 = np.array([[0, 0, 0.3, 30, 0, 0, 0, 0.0], [1, 2, 0.1, 25, 0.1, 0, 0, 0.5]])
+    s.set_x0(x0); s.cold_start()
+    full = s.get(4, "x").reshape(2, 11, 8)                      # fan-out happened on the device
+    np.testing.assert_array_equal(full[:, 0], x0)
+    np.testing.assert_allclose(full[:, 1:], x0[:, None, :] + snm.x0_offsets(w, stds)[None], rtol=0, atol=1e-15)
