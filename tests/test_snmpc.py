@@ -222,6 +222,51 @@ def test_gpu_coupled_snmpc_condensed_qp(golden_dir, N, uph):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("ns,L,N,uph", [(15, 10, 20, 6), (16, 16, 14, 14), (7, 4, 40, 11), (1, 1, 10, 3), (3, 2, 40, 31)])
+def test_gpu_coupled_snmpc_other_sample_counts(golden_dir, ns, L, N, uph):
+    """sample counts / PCE sizes other than the shipped 10 x 10 (any L x n_s matrix defines a valid OCP): condensed QP and
+    one full step of every copy against the oracle"""
+    from tum_control_amd.solver import CoupledSnmpcSolver
+    from tum_control_amd import config
+    x0, yref, p = _kat(golden_dir)
+    x0 = x0.copy(); x0[7] = -0.6; x0[5] = 0.1; x0[4] = -0.2
+    rng = np.random.default_rng(100 + ns)
+    A = rng.normal(0, 0.3, (L, ns)); A[0] = np.abs(A[0]) + 0.1; A[0] /= A[0].sum()
+    xs = np.tile(x0, (ns + 1, 1)); xs[1:, 3:6] += rng.normal(0, 1, (ns, 3)) * np.array([.8, .35, .035])
+    U = np.stack([rng.normal(0, 1.0, N), rng.normal(0, 0.05, N)], axis=1)
+    X, _ = _rollout(xs, U, A, uph, N, 0.08, 0.5)
+    X += rng.normal(0, 1e-3, X.shape)
+    Y = np.zeros((N + 1, 6)); Y[:min(N, 38) + 1, :4] = yref[:min(N, 38) + 1]
+    for k in range(39, N + 1):
+        Y[k, :4] = 2 * Y[k - 1, :4] - Y[k - 2, :4]
+    m = config.MPC
+    o = orc.OracleSnmpcOcp(N=N, dt=0.08, Apce=A, uph=uph)
+    o.set_weights(m["q_lon"], m["q_yaw"], m["q_vel"], m["r_jerk"], m["r_steering_rate"], m["L1_pen"], m["L2_pen"], scale=0.01)
+    o.yref[:] = Y; o.x0[:] = xs; o.X[:] = X; o.U[:] = U
+    s = CoupledSnmpcSolver(N=N, dt=0.08, batch=1, Apce=A, uph=uph, gamma=0.8)
+    s.install_reference_ocp()
+    s.constraints_set(0, "lbx", xs.flatten()); s.constraints_set(0, "ubx", xs.flatten())
+    s.set_yref_all(Y)
+    for k in range(N + 1):
+        s.set(k, "x", X[k].flatten())
+    s.set_iterate(U=U)
+    dbg = s.debug_dump(0)                                          # (this is a solve)
+    _, qp = o.solve_debug()
+    nv = 2 * N
+    H = dbg[:6400].reshape(80, 80)[:nv, :nv]
+    rows = dbg[6480:6480 + 2 * N * 80].reshape(2 * N, 80)[:, :nv]
+    np.testing.assert_allclose(H, qp["H"], rtol=0, atol=1e-11 * np.abs(qp["H"]).max())
+    Ch = qp["C"][N + 1::2]
+    np.testing.assert_allclose(rows[1::2], Ch, rtol=0, atol=1e-11 * max(1.0, np.abs(Ch).max()))
+    np.testing.assert_allclose(dbg[12880:12880 + 2 * N][1::2], qp["d"][N + 1::2], rtol=0, atol=1e-11)
+    assert o.status == 0 and int(np.atleast_1d(s.get_stats("status"))[0]) == 0
+    Xn, Un = s.get_iterate()
+    np.testing.assert_allclose(Un[0], o.U, rtol=1e-6, atol=1e-7)
+    for k in (0, 1, uph, N):
+        np.testing.assert_allclose(s.get(k, "x").reshape(ns + 1, 8), o.X[k], rtol=1e-6, atol=1e-7, err_msg=f"stage {k}")
+
+
+@pytest.mark.gpu
 def test_gpu_snmpc_controller_mirror(golden_dir):
     """the SNMPC_class.py mirror drives the coupled solver like the reference's controller does"""
     from tum_control_amd.snmpc import Stochastic_Nonlinear_Model_Predictive_Controller as C
