@@ -518,3 +518,27 @@ def test_nan_input_fails_only_its_own_instance():
     assert np.array_equal(X[keep], Xg[keep]) and np.array_equal(U[keep], Ug[keep])
     assert np.array_equal(U[5], U0[5])                       # the failed instance keeps its inputs
     assert np.array_equal(np.isnan(X[5]), np.isnan(X0[5]))   # and its (NaN-carrying) states
+
+
+def test_r2_controller_mirror(golden_dir):
+    """Reduced_Robustified_NMPC_class.py mirror: two control steps equal the batch-1 ReducedRobustifiedNMPC path (solve,
+    tighten, solve with the tightened bounds) and the tightened bounds are in the solver after the first call."""
+    from tum_control_amd.r2nmpc import Reduced_Robustified_Nonlinear_Model_Predictive_Controller as C, ReducedRobustifiedNMPC
+    d = np.load(os.path.join(golden_dir, "kat0.npz"))
+    x0, yr = d["x0"][0], d["yref"][0]
+    ref = dict(pos_x=yr[:, 0], pos_y=yr[:, 1], ref_yaw=yr[:, 2], ref_v=yr[:, 3])
+    c = C(X0_MPC=x0)
+    r = ReducedRobustifiedNMPC(batch=1, N=c.N, dt=c.Tp / c.N)
+    y = np.zeros((c.N + 1, 6)); y[:, :4] = yr
+    r.solver.set_x0(x0); r.solver.set_yref_all(y); r.solver.cold_start()
+    for step in range(2):
+        u0, pred, stats = c.solve(ref)
+        assert r.solve() == 0 and stats[4] == 0
+        X, U = r.solver.get_iterate()
+        np.testing.assert_array_equal(u0, U[0, 0])
+        np.testing.assert_array_equal(pred, X[0, :c.N])
+        x1 = pred[1].copy()
+        c.set_initial_state(x1); r.solver.set_x0(x1)
+    uh = c.acados_solver.constraints_get(3, "uh")
+    assert 0.0 < float(np.atleast_1d(uh)[0]) < 1.0
+    np.testing.assert_array_equal(uh, r.solver.constraints_get(3, "uh"))

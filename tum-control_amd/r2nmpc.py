@@ -40,3 +40,46 @@ class ReducedRobustifiedNMPC:
         if ok.all():
             self.solver.r2_backoff(self.Sigma0, self.BWB, self.uph, self.delta_f_min, self.delta_f_max, self.acc_max)
         return st
+
+
+class Reduced_Robustified_Nonlinear_Model_Predictive_Controller:
+    """Host-side mirror of Reduced_Robustified_NMPC_class.py:37-470 (same constructor arguments, `solve(current_ref_traj)
+    -> (u0, pred_X, stats)`, `set_initial_state`, `reset`, `update_cost_function_weights`): the nominal controller with
+    `store_qp_in`, plus -- after every successful solve -- the covariance propagation and constraint tightening for the next
+    one (:276-378; `ZoRo: False`, the shipped setting) as one device kernel (K7)."""
+
+    def __init__(self, config_path=None, MPC_params_file=None, sim_main_params=None, X0_MPC=None, device=0):
+        from .nmpc import Nonlinear_Model_Predictive_Controller as _Nominal
+        self._nom = _Nominal(config_path, MPC_params_file, sim_main_params, X0_MPC, device=device, store_qp_in=True)
+        n = self._nom
+        m, veh = n.cfg["mpc"], n.cfg["veh"]
+        self.cfg, self.MPC_params = n.cfg, n.MPC_params
+        self.N, self.Tp, self.Ts, self.Ts_MPC, self.nx = n.N, n.Tp, n.Ts, n.Ts_MPC, n.nx
+        self.acados_solver, self.model, self.constraint, self.ocp = n.acados_solver, n.model, n.constraint, n.ocp
+        self.uncertainty_propagation_horizon = int(m["uncertainty_propagation_horizon"])
+        self.Sigma0, self.BWB = r2_setup(m["stds"], self.Ts_MPC)
+        self.delta_f_min, self.delta_f_max = veh["delta_f_min"], veh["delta_f_max"]
+        self.acc_max = 1.0
+        self.stats, self.pred_X = n.stats, n.pred_X
+        self.WMPC = False
+
+    def solve(self, current_ref_traj):
+        import time
+        u0, pred_X, stats = self._nom.solve(current_ref_traj)
+        if stats[4] == 0:
+            t0 = time.time()
+            self.acados_solver.r2_backoff(self.Sigma0, self.BWB, self.uncertainty_propagation_horizon,
+                                          self.delta_f_min, self.delta_f_max, self.acc_max)
+            stats[1] += time.time() - t0          # :379-381: time_tot includes the tightening
+        self.pred_X, self.stats = pred_X, stats
+        return u0, pred_X, stats
+
+    def set_initial_state(self, x0):
+        self.x0 = x0
+        self._nom.set_initial_state(x0)
+
+    def reset(self, x0):
+        self._nom.reset(x0)
+
+    def update_cost_function_weights(self, params):
+        self._nom.update_cost_function_weights(params)
