@@ -15,6 +15,37 @@ from . import config as _config
 from .solver import BatchedOcpSolver
 
 
+class _Sym:
+    """stand-in for the CasADi symbol vectors main.py only asks the size of (`MPC.model.u.size()[0]`, main.py:41)"""
+
+    def __init__(self, n):
+        self._n = int(n)
+
+    def size(self):
+        return (self._n, 1)
+
+    @property
+    def shape(self):
+        return (self._n, 1)
+
+
+def model_namespaces(cfg, nx=8, name="pred_dynamic_bicycle_model"):
+    """(constraints, model) with the attributes the reference's harness reads from the controller
+    (main.py:41, Utils/SimulationMode_main_class.py, Utils/Logging_Plotting.py)."""
+    veh = cfg["veh"]
+    constraints = types.SimpleNamespace(lat_acc_min=veh["lat_acc_min"], lat_acc_max=veh["lat_acc_max"],
+                                        alat=lambda x: x[3] * x[5], a_lat=lambda x: x[3] * x[5])
+    model = types.SimpleNamespace(
+        name=name, nx=nx, nu=2, x=_Sym(nx), u=_Sym(2),
+        jerk_min=veh["jerk_min"], jerk_max=veh["jerk_max"], acc_min=veh["acc_min"], acc_max=veh["acc_max"],
+        delta_f_min=veh["delta_f_min"], delta_f_max=veh["delta_f_max"],
+        delta_f_dot_min=veh["delta_f_dot_min"], delta_f_dot_max=veh["delta_f_dot_max"],
+        params=types.SimpleNamespace(lf=veh["lf"], lr=veh["lr"], m=veh["m"], Iz=veh["Iz"],
+                                     veh_length=veh["veh_length"], veh_width=veh["veh_width"], **cfg["tire"]),
+        x0=np.zeros(nx))
+    return constraints, model
+
+
 def acados_settings(Tf, N, x0, Q, R, Qe, L1_pen, L2_pen, ax_max_interpolant=None, ay_max_interpolant=None,
                     combined_acc_limits=2, veh_params_file=None, tire_params_file=None,
                     solver_generate_C_code=True, solver_build=True, cfg=None, batch=1, device=0,
@@ -32,16 +63,7 @@ def acados_settings(Tf, N, x0, Q, R, Qe, L1_pen, L2_pen, ax_max_interpolant=None
     solver.constraints_set(0, "lbx", np.asarray(x0, dtype=float))
     solver.constraints_set(0, "ubx", np.asarray(x0, dtype=float))
     solver.cold_start()          # acados create: x_k = x0, u = 0
-    constraints = types.SimpleNamespace(lat_acc_min=veh["lat_acc_min"], lat_acc_max=veh["lat_acc_max"],
-                                        alat=lambda x: x[3] * x[5], a_lat=lambda x: x[3] * x[5])
-    model = types.SimpleNamespace(
-        name="pred_dynamic_bicycle_model", nx=8, nu=2,
-        jerk_min=veh["jerk_min"], jerk_max=veh["jerk_max"], acc_min=veh["acc_min"], acc_max=veh["acc_max"],
-        delta_f_min=veh["delta_f_min"], delta_f_max=veh["delta_f_max"],
-        delta_f_dot_min=veh["delta_f_dot_min"], delta_f_dot_max=veh["delta_f_dot_max"],
-        params=types.SimpleNamespace(lf=veh["lf"], lr=veh["lr"], m=veh["m"], Iz=veh["Iz"],
-                                     veh_length=veh["veh_length"], veh_width=veh["veh_width"], **cfg["tire"]),
-        x0=np.zeros(8))
+    constraints, model = model_namespaces(cfg)
     ocp = types.SimpleNamespace(cost=types.SimpleNamespace(cost_type="NONLINEAR_LS"), dims=types.SimpleNamespace(N=N),
                                 nh=1, nh_e=1)
     return constraints, model, solver, ocp

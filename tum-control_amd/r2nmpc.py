@@ -81,5 +81,9 @@ class Reduced_Robustified_Nonlinear_Model_Predictive_Controller:
     def reset(self, x0):
         self._nom.reset(x0)
 
+    def reintialize_solver(self, X0_MPC, solver_generate_C_code=False, solver_build=False):
+        self._nom.reintialize_solver(X0_MPC)
+        self.acados_solver = self._nom.acados_solver
+
     def update_cost_function_weights(self, params):
         self._nom.update_cost_function_weights(params)

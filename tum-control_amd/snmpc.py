@@ -169,7 +169,10 @@ class Stochastic_Nonlinear_Model_Predictive_Controller:
         s = self.acados_solver = CoupledSnmpcSolver(N=self.N, dt=self.Tp / self.N, batch=1, Apce=self.A, uph=min(uph, self.N),
                                                     gamma=m["gamma"], device=device, cfg=self.cfg)
         s.install_reference_ocp(Q=self.Q, R=self.R, Qe=self.Qe, L1=self.L1_pen, L2=self.L2_pen, w_scale=0.01)
-        self.nx = 8
+        from .nmpc import model_namespaces
+        self.constraint, self.model = model_namespaces(self.cfg, nx=8 * (self.n_samples + 1), name="SNMPC")
+        self.nx = int(self.model.x.size()[0] / (self.n_samples + 1))          # SNMPC_class.py:113
+        self._device = device
         self.x0 = X0_MPC
         self.costfunction_type = "NONLINEAR_LS"
         self.nh, self.nh_e = 1, 1
@@ -215,6 +218,13 @@ class Stochastic_Nonlinear_Model_Predictive_Controller:
         self.acados_solver.constraints_set(0, "ubx", x0_samples.flatten())
         for i in range(self.N + 1):
             self.acados_solver.set(i, 'x', x0_samples.flatten())
+
+    def reintialize_solver(self, X0_MPC, solver_generate_C_code=False, solver_build=False):
+        """SNMPC_class.py:274-281: a fresh solver (cold start) at the given state"""
+        fresh = Stochastic_Nonlinear_Model_Predictive_Controller(X0_MPC=X0_MPC, device=self._device)
+        fresh.cfg = self.cfg
+        self.acados_solver = fresh.acados_solver
+        self.set_initial_state(X0_MPC)
 
     def update_cost_function_weights(self, params):
         """SNMPC_class.py:283-331 (same protocol as NMPC_class.py:269-317)"""
