@@ -160,6 +160,12 @@ int tum_ocp_snmpc_set_offsets(tum_ocp *c, const double *offs);
  * Sigma0, BWB: 8x8 row-major (host); backoff (optional, host): batch x N x 2 (steering, gg) back-offs. */
 int tum_ocp_r2_backoff(tum_ocp *c, const double *Sigma0, const double *BWB, int uph,
                        double delta_min, double delta_max, double uh_nom, double *backoff);
+/* The same tightening as part of EVERY solve (Reduced_Robustified_NMPC_class.py:276-378 runs it after each successful acados
+ * call, and counts it in the reported solver time, :379-381): after the SQP-RTI kernel the back-off kernel rewrites the bounds
+ * for the next solve on the capsule's stream; instances whose solve failed keep their bounds. Needs store_qp_in. This is what
+ * lets the robustified controller run in the device closed loop (tum_sim_*). uph = 0 detaches. */
+int tum_ocp_r2_attach(tum_ocp *c, const double *Sigma0, const double *BWB, int uph,
+                      double delta_min, double delta_max, double uh_nom);
 /* read back a bound installed with constraints_set / r2_backoff (one value per instance) */
 int tum_ocp_constraints_get(tum_ocp *c, int stage, const char *field, double *v, int b0, int nb);
 

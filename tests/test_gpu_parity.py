@@ -542,3 +542,32 @@ def test_r2_controller_mirror(golden_dir):
     uh = c.acados_solver.constraints_get(3, "uh")
     assert 0.0 < float(np.atleast_1d(uh)[0]) < 1.0
     np.testing.assert_array_equal(uh, r.solver.constraints_get(3, "uh"))
+
+
+def test_r2_closed_loop_attached(golden_dir):
+    """R2NMPC in closed loop: the tightening attached to the solve (host loop and all-device loop) reproduces the loop that
+    calls the back-off explicitly after every solve, as the reference's controller class does."""
+    from tum_control_amd.closed_loop import ClosedLoopBatch, plant_step, MovingAverageEstimator
+    from tum_control_amd.r2nmpc import Reduced_Robustified_Nonlinear_Model_Predictive_Controller as C
+    from tum_control_amd.planner import planner_emulator
+    from tum_control_amd import config
+    steps = 25
+    cl = ClosedLoopBatch("monteblanco", batch=1, N=38, Tp=3.04, controller="r2")
+    lg = cl.run(steps)
+    cd = ClosedLoopBatch("monteblanco", batch=2, N=38, Tp=3.04, controller="r2", on_device=True, log_capacity=steps)
+    ld = cd.run(steps)
+    cfg = config.default_config()
+    x0 = lg["MPC_SimX"][0][0].copy()
+    MPC = C(X0_MPC=x0)
+    x_sim = x0[:7].copy()[None]; pose = x0[:2].copy(); est = MovingAverageEstimator(1)
+    for i in range(steps):
+        _, ref = planner_emulator(cl.track, pose, MPC.N + 1, MPC.Tp, True)
+        u0, pred_X, stats = MPC.solve(dict(pos_x=ref[:, 0], pos_y=ref[:, 1], ref_yaw=ref[:, 2], ref_v=ref[:, 3]))
+        assert stats[-1] == 0
+        np.testing.assert_array_equal(lg["simU"][i][0], u0)
+        np.testing.assert_allclose(ld["simU"][i], np.tile(u0, (2, 1)), rtol=1e-7, atol=1e-8)
+        x_sim = plant_step(x_sim, np.array([pred_X[1, 7]]), np.array([u0[1]]), cfg, 0.02)
+        pose = x_sim[0, :2].copy()
+        MPC.set_initial_state(est(np.concatenate([x_sim, [[pred_X[1, 7]]]], axis=1))[0])
+    uh = cl.solver.constraints_get(3, "uh")
+    assert 0.0 < float(np.atleast_1d(uh)[0]) < 1.0             # the bounds really are tightened

@@ -109,8 +109,14 @@ class ClosedLoopBatch:
             A = _snm.pce_matrix(w, _snm.alpha_generation(nvar, m["expansion_degree"]))
             self.solver = CoupledSnmpcSolver(N=N, dt=Tp / N, batch=batch, Apce=A, uph=min(int(m["uncertainty_propagation_horizon"]), N),
                                              gamma=m["gamma"], device=device, cfg=self.cfg, x0_offsets=_snm.x0_offsets(w, stds))
+        elif controller == "r2":          # nominal OCP + covariance back-off after every solve (K7 attached to the solve)
+            from .r2nmpc import r2_setup
+            m, veh = self.cfg["mpc"], self.cfg["veh"]
+            self.solver = BatchedOcpSolver(N=N, dt=Tp / N, nsub=3, batch=batch, device=device, cfg=self.cfg, store_qp_in=True)
+            S0, BWB = r2_setup(m["stds"], Tp / N)
+            self.solver.r2_attach(S0, BWB, int(m["uncertainty_propagation_horizon"]), veh["delta_f_min"], veh["delta_f_max"], 1.0)
         else:
-            raise ValueError("controller must be 'nominal' or 'snmpc'")
+            raise ValueError("controller must be 'nominal', 'snmpc' or 'r2'")
         self.solver.install_reference_ocp()
         if params is not None:
             self.set_weights(np.asarray(params, dtype=float).reshape(batch, 7))

@@ -41,12 +41,14 @@ __global__ void pce_moments_kernel(const double *V, const double *A, int P, int 
 //      through LDS (the "small-block LDS path" of BASELINE config 5).
 __global__ void __launch_bounds__(256) r2_backoff_kernel(const double *qpin, const double *X, double *bnd, const Model mp,
                                                          const double *Sigma0, const double *BWB, int N, int uph, int batch,
-                                                         double dmin, double dmax, double uh_nom, double *backoff_out)
+                                                         double dmin, double dmax, double uh_nom, double *backoff_out,
+                                                         const int *status)
 {
     __shared__ double sA[4][64], sS[4][64], sT[4][64];
     const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int b = blockIdx.x * 4 + w;
-    const bool on = b < batch;
+    // an instance whose solve failed keeps its previous bounds (`if status == 0:`, Reduced_Robustified_NMPC_class.py:276)
+    const bool on = b < batch && (!status || status[b] == 0);
     const int i = lane >> 3, j = lane & 7;
     double sig = Sigma0[lane];
     const double bwb = BWB[lane];

@@ -39,6 +39,8 @@ struct tum_ocp {
     SnArgs sa;
     double *dXS, *dxs0, *dApce, *dws2, *dpro, *ddv, *doffs;
     bool have_offs, fanout;        // sample initial conditions derived from the nominal x0 at every solve
+    // R2NMPC tightening after every solve (tum_ocp_r2_attach)
+    bool r2; int r2_uph; double r2_dmin, r2_dmax, r2_uh; double *dr2S, *dr2B;
 };
 
 static const int DBG_STRIDE = 20480;
@@ -73,6 +75,7 @@ extern "C" tum_ocp *tum_ocp_create(const tum_ocp_desc *desc)
     c->d = *desc; c->N = desc->N; c->batch = desc->batch; c->last_ms = 0; c->solved = false;
     c->sn = false; c->dXS = c->dxs0 = c->dApce = c->dws2 = c->dpro = c->ddv = c->doffs = nullptr;
     c->have_offs = c->fanout = false;
+    c->r2 = false; c->dr2S = c->dr2B = nullptr;
     const int N = c->N; const size_t B = c->batch;
     bool ok = true;
     ok &= hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) == hipSuccess; c->own_stream = true;
@@ -150,6 +153,7 @@ extern "C" void tum_ocp_free(tum_ocp *c)
     if (c->dqpin) (void)hipFree(c->dqpin);
     (void)hipFree(c->ddbg); (void)hipFree(c->dprof); (void)hipFree(c->dws);
     (void)hipFree(c->dXS); (void)hipFree(c->dxs0); (void)hipFree(c->dApce); (void)hipFree(c->dws2); (void)hipFree(c->dpro); (void)hipFree(c->ddv); (void)hipFree(c->doffs);
+    (void)hipFree(c->dr2S); (void)hipFree(c->dr2B);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
@@ -423,6 +427,11 @@ static int launch(tum_ocp *c, bool events = true)
     } else if (c->ka.flags & 6) hipLaunchKernelGGL(nmpc_rti_kernel<true>, dim3(c->batch), dim3(64), LDS_BYTES, c->stream, c->ka);
     else hipLaunchKernelGGL(nmpc_rti_kernel<false>, dim3(c->batch), dim3(64), LDS_BYTES, c->stream, c->ka);
     HIPCHK(hipGetLastError());
+    if (c->r2) {   // constraint tightening for the NEXT solve from this one's linearisation (skipped per instance on failure)
+        hipLaunchKernelGGL(r2_backoff_kernel, dim3((c->batch + 3) / 4), dim3(256), 0, c->stream, c->dqpin, c->dX, c->dbnd, c->ka.mp,
+                           c->dr2S, c->dr2B, c->N, c->r2_uph, c->batch, c->r2_dmin, c->r2_dmax, c->r2_uh, (double *)nullptr, c->dstatus);
+        HIPCHK(hipGetLastError());
+    }
     if (events) HIPCHK(hipEventRecord(c->ev1, c->stream));
     if (c->lpt && c->batch > 1024) {
         hipLaunchKernelGGL(lpt_order_kernel, dim3(1), dim3(1024), 0, c->stream, c->dqpiter, c->dorder, c->batch);
@@ -655,10 +664,31 @@ extern "C" int tum_ocp_r2_backoff(tum_ocp *c, const double *Sigma0, const double
     HIPCHK(hipMemcpyAsync(dS, Sigma0, 64 * 8, hipMemcpyHostToDevice, c->stream));
     HIPCHK(hipMemcpyAsync(dB, BWB, 64 * 8, hipMemcpyHostToDevice, c->stream));
     hipLaunchKernelGGL(r2_backoff_kernel, dim3((c->batch + 3) / 4), dim3(256), 0, c->stream, c->dqpin, c->dX, c->dbnd, c->ka.mp,
-                       dS, dB, N, uph, c->batch, delta_min, delta_max, uh_nom, dbo);
+                       dS, dB, N, uph, c->batch, delta_min, delta_max, uh_nom, dbo, c->dstatus);
     HIPCHK(hipGetLastError());
     if (backoff) HIPCHK(hipMemcpyAsync(backoff, dbo, sizeof(double) * (size_t)c->batch * N * 2, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+// Make the R2NMPC tightening part of every solve (what Reduced_Robustified_NMPC_class.py:276-378 does after each successful
+// acados call): after the SQP-RTI kernel the back-off kernel rewrites lbx / ubx / uh of the stages 1..N-1 for the NEXT solve,
+// on the capsule's stream, inside the time `get_stats("time_tot")` reports (:379-381). uph = 0 detaches.
+extern "C" int tum_ocp_r2_attach(tum_ocp *c, const double *Sigma0, const double *BWB, int uph,
+                                 double delta_min, double delta_max, double uh_nom)
+{
+    if (!c) return fail("null capsule");
+    if (uph == 0) { c->r2 = false; return 0; }
+    if (!Sigma0 || !BWB) return fail("null argument");
+    if (!c->dqpin) return fail("r2_attach: capsule created without store_qp_in");
+    if (c->sn) return fail("r2_attach: not available for an SNMPC capsule");
+    if (uph < 1) return fail("r2_attach: uncertainty propagation horizon < 1");
+    HIPCHK(hipSetDevice(c->d.device));
+    if (!c->dr2S && (dalloc(&c->dr2S, 64) != hipSuccess || dalloc(&c->dr2B, 64) != hipSuccess)) return fail("r2_attach: device allocation failed");
+    HIPCHK(hipMemcpy(c->dr2S, Sigma0, 64 * 8, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(c->dr2B, BWB, 64 * 8, hipMemcpyHostToDevice));
+    c->r2_uph = uph; c->r2_dmin = delta_min; c->r2_dmax = delta_max; c->r2_uh = uh_nom;
+    c->r2 = true;
     return 0;
 }
 

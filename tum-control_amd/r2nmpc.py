@@ -36,9 +36,7 @@ class ReducedRobustifiedNMPC:
         """One SQP-RTI step for every instance, then the tightening of lbx/ubx/uh for the next call
         (instances whose solve failed keep their previous bounds, like `if status == 0:` at :276)."""
         st = self.solver.solve()
-        ok = self.solver.get_stats("status") == 0
-        if ok.all():
-            self.solver.r2_backoff(self.Sigma0, self.BWB, self.uph, self.delta_f_min, self.delta_f_max, self.acc_max)
+        self.solver.r2_backoff(self.Sigma0, self.BWB, self.uph, self.delta_f_min, self.delta_f_max, self.acc_max)
         return st
 
 

@@ -48,7 +48,7 @@ C_SYMBOLS = ["tum_ocp_create", "tum_ocp_free", "tum_ocp_last_error", "tum_ocp_ba
              "tum_ocp_get_cost", "tum_ocp_get_stats", "tum_ocp_reset", "tum_ocp_get_from_qp_in",
              "tum_ocp_set_stream", "tum_ocp_get_device", "tum_ocp_cold_start", "tum_ocp_last_kernel_ms",
              "tum_ocp_debug_dump", "tum_ocp_profile_phases", "tum_ocp_set_schedule",
-             "tum_ocp_set_x0_fanout", "tum_pce_moments", "tum_ocp_r2_backoff", "tum_ocp_constraints_get",
+             "tum_ocp_set_x0_fanout", "tum_pce_moments", "tum_ocp_r2_backoff", "tum_ocp_r2_attach", "tum_ocp_constraints_get",
              "tum_ocp_snmpc_attach", "tum_ocp_snmpc_samples", "tum_ocp_snmpc_set_offsets",
              "tum_planner_emulate", "tum_sim_create", "tum_sim_free", "tum_sim_set_state", "tum_sim_plan", "tum_sim_advance",
              "tum_sim_run", "tum_sim_steps", "tum_sim_get"]
@@ -94,6 +94,7 @@ def load_library(path=None):
     L.tum_pce_moments.argtypes = [vp, cs, ci, dp, ci, ci, dp, dp]
     L.tum_ocp_r2_backoff.argtypes = [vp, dp, dp, ci, ctypes.c_double, ctypes.c_double, ctypes.c_double, dp]
     L.tum_ocp_constraints_get.argtypes = [vp, ci, cs, dp, ci, ci]
+    L.tum_ocp_r2_attach.argtypes = [vp, dp, dp, ci, ctypes.c_double, ctypes.c_double, ctypes.c_double]
     L.tum_ocp_snmpc_attach.argtypes = [vp, ci, ci, dp, ci, ctypes.c_double]
     L.tum_ocp_snmpc_samples.argtypes = [vp]
     L.tum_ocp_snmpc_set_offsets.argtypes = [vp, dp]
@@ -342,6 +343,11 @@ class BatchedOcpSolver:
         self._chk(self._L.tum_ocp_r2_backoff(self._h, _dp(S0), _dp(BW), int(uph), float(delta_min), float(delta_max),
                                              float(uh_nom), _dp(bo) if bo is not None else None), "r2_backoff")
         return bo
+
+    def r2_attach(self, Sigma0, BWB, uph, delta_min, delta_max, uh_nom=1.0):
+        """make the R2NMPC tightening part of every solve (device closed loops); uph = 0 detaches"""
+        S = np.ascontiguousarray(Sigma0, dtype=np.float64).reshape(64); B = np.ascontiguousarray(BWB, dtype=np.float64).reshape(64)
+        self._chk(self._L.tum_ocp_r2_attach(self._h, _dp(S), _dp(B), int(uph), float(delta_min), float(delta_max), float(uh_nom)), "r2_attach")
 
     def constraints_get(self, stage, field):
         out = np.zeros(self.batch)
