@@ -393,3 +393,72 @@ def test_gpu_main_loop_protocol(golden_dir, kind):
             MPC.reintialize_solver(x_next)          # what main.py does after a failed solve
         MPC.set_initial_state(x_next)
     assert abs(x_sim[0, 4]) < 0.5                   # still driving straight down the start straight
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", range(6))
+def test_gpu_coupled_snmpc_randomised(golden_dir, seed):
+    """random horizons, propagation horizons, sample counts, PCE matrices, weights, tightened bounds and iterates: one
+    real-time iteration of every instance of a small batch against the oracle (instances whose QP hit the iteration cap
+    in either implementation are compared at the looser 1e-4 of north_star)."""
+    from tum_control_amd.solver import CoupledSnmpcSolver, _dp
+    rng = np.random.default_rng(1000 + seed)
+    N = int(rng.integers(5, 41)); uph = int(rng.integers(0, min(N, 31) + 1)); ns = int(rng.integers(1, 17)); L = int(rng.integers(1, 17))
+    B = 5
+    d = np.load(os.path.join(golden_dir, "kat0.npz"))
+    A = rng.normal(0, 0.25, (L, ns)); A[0] = np.abs(A[0]) + 0.05; A[0] /= A[0].sum()
+    s = CoupledSnmpcSolver(N=N, dt=0.08, batch=B, Apce=A, uph=uph, gamma=float(rng.uniform(0.6, 0.95)))
+    s.install_reference_ocp()
+    q = np.array([2.8, 0.4, 0.2, 38.1, 101.4]) * 0.01 * rng.uniform(0.3, 3.0, 5)
+    W = np.diag([q[0], q[0], q[1], q[2], q[3], q[4]])
+    s.cost_set(0, "W", W); s.cost_set(N, "W", W[:4, :4])
+    L1, L2 = float(rng.uniform(20, 200)), float(rng.uniform(2, 50))
+    for st, n in ((0, 1), (1, 3), (N, 2)) if N > 1 else ((0, 1), (N, 2)):
+        for f, v in (("zl", L1), ("zu", L1), ("Zl", L2), ("Zu", L2)):
+            s.cost_set(st, f, np.ones(n) * v)
+    uh = float(rng.uniform(0.05, 1.0)); sr = float(rng.uniform(0.02, 0.322))
+    for k in range(1, N + 1):
+        s.constraints_set(k, "uh", np.array([uh]))
+    for k in range(N):
+        s.constraints_set(k, "lbu", np.array([-sr])); s.constraints_set(k, "ubu", np.array([sr]))
+    orcs = []
+    for j in range(B):
+        i = int(rng.integers(0, 52))
+        x0 = d["x0"][i].copy(); x0[3:8] += rng.normal(0, 1, 5) * np.array([1.5, .3, .05, .02, .5])
+        xs = np.tile(x0, (ns + 1, 1)); xs[1:, 3:6] += rng.normal(0, 1, (ns, 3)) * np.array([.8, .35, .035])
+        U = np.stack([rng.normal(0, 0.5, N), rng.normal(0, 0.03, N)], axis=1)
+        X, _ = _rollout(xs, U, A, uph, N, 0.08, 0.5)
+        X += rng.normal(0, 2e-3, X.shape)
+        Y = np.zeros((N + 1, 6)); Y[:min(N, 38) + 1, :4] = d["yref"][i][:min(N, 38) + 1]
+        for k in range(39, N + 1):
+            Y[k, :4] = 2 * Y[k - 1, :4] - Y[k - 2, :4]
+        o = orc.OracleSnmpcOcp(N=N, dt=0.08, Apce=A, uph=uph, gamma=0.8)
+        o._view("kappa")[0] = np.sqrt((1 - s.gamma) / s.gamma)
+        o.W[:] = np.diag(W); o.zl[:] = L1; o.zu[:] = L1; o.Zl[:] = L2; o.Zu[:] = L2
+        o.uh[:] = uh; o.lbu[:] = -sr; o.ubu[:] = sr
+        o.yref[:] = Y; o.x0[:] = xs; o.X[:] = X; o.U[:] = U
+        orcs.append(o)
+        s._chk(s._L.tum_ocp_constraints_set(s._h, 0, b"lbx", _dp(xs),
+                                            xs.size, j, 1, xs.size), "lbx")
+        for k in range(N + 1):
+            v = np.ascontiguousarray(X[k].reshape(-1))
+            s._chk(s._L.tum_ocp_set(s._h, k, b"x", _dp(v), v.size, j, 1, v.size), "x")
+        s._chk(s._L.tum_ocp_set(s._h, -1, b"u", _dp(np.ascontiguousarray(U.reshape(-1))),
+                                2 * N, j, 1, 2 * N), "u")
+        s._chk(s._L.tum_ocp_set(s._h, -1, b"yref", _dp(np.ascontiguousarray(Y.reshape(-1))),
+                                6 * (N + 1), j, 1, 6 * (N + 1)), "yref")
+    s.solve()
+    Xn, Un = s.get_iterate()
+    it = s.get_stats("qp_iter"); st = s.get_stats("status")
+    for j, o in enumerate(orcs):
+        so = o.solve()
+        assert so == int(st[j]), f"status inst {j}"
+        if so != 0:
+            continue
+        tol = 1e-6 if (it[j] < 50 and o.qp_iter < 50) else 1e-4
+        np.testing.assert_allclose(Un[j], o.U, rtol=tol, atol=tol, err_msg=f"seed {seed} N {N} uph {uph} ns {ns} L {L} inst {j} it {it[j]}/{o.qp_iter}")
+        np.testing.assert_allclose(Xn[j], o.X[:, 0], rtol=tol, atol=tol)
+        full = np.zeros((B, 8 * (ns + 1)))
+        s._chk(s._L.tum_ocp_get(s._h, min(uph, N), b"x", _dp(full),
+                                8 * (ns + 1), 0, B, 8 * (ns + 1)), "get")
+        np.testing.assert_allclose(full[j].reshape(ns + 1, 8), o.X[min(uph, N)], rtol=tol, atol=tol)
