@@ -11,6 +11,7 @@ DATA (inputs + expected outputs), never reference source:
   replay_<t>_<k>_<a>_<b>.npz   sequential closed-loop windows (x0_i, yref_i, expected u0/x1/cost/qp_iter)
   planner.npz         PlannerEmulator input/output pairs
   pce.npz             alphaGeneration / polyChaosExpansion / compute_x0dist / sigma points of acados_ocp_SNMPC.json
+  snmpc_json.npz      dimensions, weights, penalties, bounds and solver options of the exported SNMPC OCP (acados_ocp_SNMPC.json)
   r2.npz              P_propagation input/output pairs
   closed_loop_<t>_<n>.npz   first n steps of the 26 logged closed loops of one track (plant states, inputs, predictions)
   closed_loop_<t>_full_sub<k>.npz   the complete 5499-step loops, every k-th plant state + per-loop statistics
@@ -175,6 +176,29 @@ def make_pce():
                         x0=x0, stds=stds, x0dist=x0d, json_lbx0=lbx0)
 
 
+def make_snmpc_json():
+    """Problem data of the exported SNMPC OCP (acados_ocp_SNMPC.json): dimensions, weights, slack penalties, bounds and the
+    solver options the coupled solver has to agree with. Data only."""
+    with open(os.path.join(REF, "acados_ocp_SNMPC.json")) as f:
+        js = json.load(f)
+    d, c, k, so = js["dims"], js["cost"], js["constraints"], js["solver_options"]
+    dims = {q: int(d[q]) for q in ("N", "nx", "nu", "np", "nh", "nh_0", "nh_e", "ns", "ns_0", "ns_e", "nbx", "nbu", "nbx_0", "nbx_e",
+                                   "nsbx", "nsbu", "nsh", "nsh_e", "nsbx_e", "ny", "ny_e")}
+    opts = {q: so[q] for q in ("integrator_type", "nlp_solver_type", "qp_solver", "hessian_approx", "qp_solver_iter_max",
+                               "qp_solver_warm_start", "nlp_solver_step_length", "tf", "levenberg_marquardt", "regularize_method",
+                               "hpipm_mode")}
+    np.savez_compressed(os.path.join(OUT, "snmpc_json.npz"),
+                        dims=json.dumps(dims), opts=json.dumps(opts),
+                        W=np.array(c["W"], float), W_e=np.array(c["W_e"], float),
+                        Zl=np.array(c["Zl"], float), Zu=np.array(c["Zu"], float), zl=np.array(c["zl"], float), zu=np.array(c["zu"], float),
+                        Zl_0=np.array(c["Zl_0"], float), zl_0=np.array(c["zl_0"], float), Zl_e=np.array(c["Zl_e"], float), zl_e=np.array(c["zl_e"], float),
+                        lbx=np.array(k["lbx"], float), ubx=np.array(k["ubx"], float), lbu=np.array(k["lbu"], float), ubu=np.array(k["ubu"], float),
+                        lh=np.array(k["lh"], float), uh=np.array(k["uh"], float), lh_e=np.array(k["lh_e"], float), uh_e=np.array(k["uh_e"], float),
+                        lbx_e=np.array(k["lbx_e"], float), ubx_e=np.array(k["ubx_e"], float),
+                        idxbx=np.array(k["idxbx"], int), idxbu=np.array(k["idxbu"], int), idxbx_e=np.array(k["idxbx_e"], int),
+                        cost_type=c["cost_type"], cost_type_e=c["cost_type_e"], n_param=len(js["parameter_values"]))
+
+
 def make_r2():
     from Model_Predictive_Controller.Reduced_Robustified_NMPC.Robust_NMPC_pred_model_utils import P_propagation
     rng = np.random.default_rng(11)
@@ -185,7 +209,7 @@ def make_r2():
 
 
 if __name__ == "__main__":
-    what = sys.argv[1:] or ["kat0", "replay", "planner", "pce", "r2", "closed_loop"]
+    what = sys.argv[1:] or ["kat0", "replay", "planner", "pce", "snmpc_json", "r2", "closed_loop"]
     if "kat0" in what:
         make_kat0()
     if "replay" in what:
@@ -195,6 +219,8 @@ if __name__ == "__main__":
         make_planner()
     if "pce" in what:
         make_pce()
+    if "snmpc_json" in what:
+        make_snmpc_json()
     if "r2" in what:
         make_r2()
     if "closed_loop" in what:

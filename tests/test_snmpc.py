@@ -123,6 +123,46 @@ def test_wrapper_rejects_inconsistent_parameters():
         s.set(2, "p", good[:-1])
 
 
+def test_problem_data_matches_exported_ocp(golden_dir):
+    """acados_ocp_SNMPC.json (the reference's exported OCP) against the constants this build installs: dimensions of the
+    stacked problem, W = 0.01 blockdiag(Q, R), slack penalties per class, bounds, solver options (CPU: configuration only)."""
+    import json
+    from tum_control_amd import config
+    from tum_control_amd.solver import TumOcpDesc, make_desc
+    g = np.load(os.path.join(golden_dir, "snmpc_json.npz"))
+    dims, opts = json.loads(str(g["dims"])), json.loads(str(g["opts"]))
+    cfg = config.default_config(); m, veh = cfg["mpc"], cfg["veh"]
+    ns = m["n_samples"]
+    L = len(_pce()[0].alpha_generation(int(np.count_nonzero(m["stds"])), m["expansion_degree"]))
+    assert dims["nx"] == 8 * (ns + 1) and dims["nu"] == 2 and dims["np"] == L * ns + 2 == int(g["n_param"])
+    assert dims["N"] == int(cfg["sim"]["Tp"] / cfg["sim"]["Ts_MPC"]) == 38
+    assert (dims["nh"], dims["nh_0"], dims["nh_e"]) == (1, 0, 1)                     # no gg row at stage 0
+    assert (dims["ns_0"], dims["ns"], dims["ns_e"]) == (1, 3, 2)                     # penalty classes of cost_set
+    assert (dims["nbx_0"], dims["nbx"], dims["nbu"], dims["nbx_e"]) == (dims["nx"], 1, 1, 1)
+    assert (dims["ny"], dims["ny_e"]) == (6, 4)
+    Q = np.diag([m["q_lon"] / m["s_lon"] ** 2, m["q_lat"] / m["s_lat"] ** 2, m["q_yaw"] / m["s_yaw"] ** 2, m["q_vel"] / m["s_vel"] ** 2])
+    R = np.diag([m["r_jerk"] / m["s_jerk"] ** 2, m["r_steering_rate"] / m["s_steering_rate"] ** 2])
+    W = np.zeros((6, 6)); W[:4, :4] = Q; W[4:, 4:] = R
+    np.testing.assert_allclose(g["W"], 0.01 * W, rtol=1e-12)
+    np.testing.assert_allclose(g["W_e"], 0.01 * Q, rtol=1e-12)
+    for f in ("Zl", "Zu", "Zl_0", "Zl_e"):
+        if f in g.files:
+            assert np.all(g[f] == m["L2_pen"])
+    for f in ("zl", "zu", "zl_0", "zl_e"):
+        if f in g.files:
+            assert np.all(g[f] == m["L1_pen"])
+    assert g["lbx"][0] == veh["delta_f_min"] == g["lbx_e"][0] and g["ubx"][0] == veh["delta_f_max"] == g["ubx_e"][0]
+    assert g["lbu"][0] == veh["delta_f_dot_min"] and g["ubu"][0] == veh["delta_f_dot_max"]
+    assert (g["lh"][0], g["uh"][0], g["lh_e"][0], g["uh_e"][0]) == (0.0, 1.0, 0.0, 1.0)
+    assert (int(g["idxbx"][0]), int(g["idxbu"][0]), int(g["idxbx_e"][0])) == (6, 1, 6)   # steering angle of the NOMINAL copy, steering rate
+    assert str(g["cost_type"]) == str(g["cost_type_e"]) == "NONLINEAR_LS"
+    assert opts["integrator_type"] == "DISCRETE" and opts["nlp_solver_type"] == "SQP_RTI"
+    assert opts["qp_solver"] == "FULL_CONDENSING_HPIPM" and opts["hessian_approx"] == "GAUSS_NEWTON"
+    assert opts["nlp_solver_step_length"] == 1.0 and opts["levenberg_marquardt"] == 0.0 and opts["regularize_method"] == "NO_REGULARIZE"
+    d = make_desc(dims["N"], opts["tf"] / dims["N"], 1, 1, cfg=cfg)
+    assert d.qp_iter_max == opts["qp_solver_iter_max"] == 50 and abs(d.dt - 0.08) < 1e-15 and d.nsub == 1
+
+
 # ---------------------------------------------------------------------------------------------- GPU
 def _gpu_vs_oracle(golden_dir, N, uph, poses, nsolve=3, shift_ref=0):
     from tum_control_amd.solver import CoupledSnmpcSolver
@@ -462,3 +502,20 @@ def test_gpu_coupled_snmpc_randomised(golden_dir, seed):
         s._chk(s._L.tum_ocp_get(s._h, min(uph, N), b"x", _dp(full),
                                 8 * (ns + 1), 0, B, 8 * (ns + 1)), "get")
         np.testing.assert_allclose(full[j].reshape(ns + 1, 8), o.X[min(uph, N)], rtol=tol, atol=tol)
+
+
+@pytest.mark.gpu
+def test_gpu_installed_bounds_match_exported_ocp(golden_dir):
+    """what install_reference_ocp leaves in the solver, read back through the C-ABI, against acados_ocp_SNMPC.json"""
+    from tum_control_amd.solver import CoupledSnmpcSolver
+    g = np.load(os.path.join(golden_dir, "snmpc_json.npz"))
+    snm, stds, w, A = _pce()
+    s = CoupledSnmpcSolver(N=38, dt=0.08, batch=1, Apce=A, uph=5)
+    s.install_reference_ocp()
+    for k in (1, 17, 37):
+        assert float(np.atleast_1d(s.constraints_get(k, "lbx"))[0]) == g["lbx"][0] and float(np.atleast_1d(s.constraints_get(k, "ubx"))[0]) == g["ubx"][0]
+        assert float(np.atleast_1d(s.constraints_get(k, "lh"))[0]) == g["lh"][0] and float(np.atleast_1d(s.constraints_get(k, "uh"))[0]) == g["uh"][0]
+    for k in (0, 20, 37):
+        assert float(np.atleast_1d(s.constraints_get(k, "lbu"))[0]) == g["lbu"][0] and float(np.atleast_1d(s.constraints_get(k, "ubu"))[0]) == g["ubu"][0]
+    assert float(np.atleast_1d(s.constraints_get(38, "ubx"))[0]) == g["ubx_e"][0] and float(np.atleast_1d(s.constraints_get(38, "uh"))[0]) == g["uh_e"][0]
+    assert s.nx == 88 and s.L * s.ns + 2 == int(g["n_param"])
