@@ -720,10 +720,14 @@ void oracle_solve_batch_cold(const oracle_ocp *tmpl, int nb, const double *x0, c
  * Cost on the nominal copy with |v| as the speed row (:153-154); bounds as in the nominal OCP (:208-218),
  * no h row at stage 0 (dims nh_0 = 0, acados_ocp_SNMPC.json:704-740).
  * Deliberately the generic dense formulation: 8(n_s+1) x 8(n_s+1) stage matrices, dense condensing.
- * PARITY UNPINNED by reference outputs: the reference holds no SNMPC solver outputs with a known
- * configuration (ACC24 logs: weights/track configuration not recorded); pinned only
- *  - against the nominal restatement above (n_s copies with zero spread / stop_flag = 1 everywhere), and
- *  - against finite differences of its own nonlinear functions (tests/test_snmpc.py).
+ * SOLVER OUTPUTS PARITY-UNPINNED: the reference holds no SNMPC solver outputs with a known configuration (ACC24 logs:
+ * weights / lateral model of that campaign not recorded). What IS pinned (tests/test_snmpc.py):
+ *  - the model functions -- stacked discrete dynamics, cost output, chance constraint -- against the reference's own
+ *    expressions as exported in acados_ocp_SNMPC.json (CasADi text evaluated at random points by tests/golden/make_golden.py:
+ *    dynamics to the 6 printed digits of the constants, the chance constraint to 2e-16), and the problem data against the
+ *    same file (dimensions, weights, penalties, bounds, options);
+ *  - the solve against the golden-pinned nominal restatement above (stop_flag = 1 everywhere), and its rows against finite
+ *    differences of an independent rollout.
  */
 #define NSMAX 16                 /* max samples */
 #define NLMAX 16                 /* max PCE terms */
@@ -835,6 +839,62 @@ static double snmpc_h(const snmpc_ocp *o, int k, const double *x, double *grad)
     return c[0] + o->kappa * sd;
 }
 
+/* the stacked DISCRETE dynamics of one stage (pred_model_dynamic_disc.py:170-212): successor state and, if asked for,
+ * the dense stage matrices A (nxs x nxs) and B (nxs x 2), both expected zero-filled */
+static void snmpc_step(const snmpc_ocp *o, int stop, const double *x, const double *u, double *xn, double *A, double *B)
+{
+    const int ns = o->ns, nxs = NX * (ns + 1);
+    const double dt = o->dt;
+    double Ai[NSMAX + 1][64], Bi[NSMAX + 1][16];
+    for (int i = 1; i <= ns; i++) {
+        if (!stop) {
+            oracle_rk4_sens(&o->model, x + NX * i, u, dt, 1, xn + NX * i, Ai[i], Bi[i]);
+            if (A)
+                for (int r = 0; r < NX; r++) {
+                    for (int c = 0; c < NX; c++) A[(NX * i + r) * nxs + NX * i + c] = Ai[i][r * NX + c];
+                    for (int c = 0; c < NU; c++) B[(NX * i + r) * NU + c] = Bi[i][r * NU + c];
+                }
+        } else {
+            for (int r = 0; r < NX; r++) { xn[NX * i + r] = x[NX * i + r]; if (A) A[(NX * i + r) * nxs + NX * i + r] = 1.0; }
+        }
+    }
+    if (stop) {
+        oracle_rk4_sens(&o->model, x, u, dt, 1, xn, Ai[0], Bi[0]);
+        if (A)
+            for (int r = 0; r < NX; r++) {
+                for (int c = 0; c < NX; c++) A[r * nxs + c] = Ai[0][r * NX + c];
+                for (int c = 0; c < NU; c++) B[r * NU + c] = Bi[0][r * NU + c];
+            }
+    } else {
+        /* nominal_next = first row of A_pce times the sample successors */
+        for (int r = 0; r < NX; r++) {
+            double acc = 0.0;
+            for (int i = 1; i <= ns; i++) acc += o->Apce[i - 1] * xn[NX * i + r];
+            xn[r] = acc;
+            if (A)
+                for (int i = 1; i <= ns; i++) {
+                    const double a = o->Apce[i - 1];
+                    for (int c = 0; c < NX; c++) A[r * nxs + NX * i + c] = a * Ai[i][r * NX + c];
+                    for (int c = 0; c < NU; c++) B[r * NU + c] += a * Bi[i][r * NU + c];
+                }
+        }
+    }
+}
+
+/* model functions of one stage at a given point, for the checks against the reference's exported expressions
+ * (acados_ocp_SNMPC.json model.disc_dyn_expr / cost_y_expr / con_h_expr; tests/golden/snmpc_expr.npz):
+ * xn = f_disc(x, u, p), y = cost_y_expr(x, u) (6 entries), h = con_h_expr(x, p); stop = the stage's stop_flag */
+void snmpc_eval(snmpc_ocp *o, double stop, const double *x, const double *u, double *xn, double *y, double *h)
+{
+    double grad[NXS];
+    snmpc_step(o, stop == 1.0, x, u, xn, NULL, NULL);
+    y[0] = x[0]; y[1] = x[1]; y[2] = wrap_yaw(x[2]); y[3] = sqrt(x[3] * x[3] + x[4] * x[4]); y[4] = u[0]; y[5] = u[1];
+    const double keep = o->stop[0];
+    o->stop[0] = stop;
+    *h = snmpc_h(o, 0, x, grad);
+    o->stop[0] = keep;
+}
+
 static double snmpc_eval_cost(const snmpc_ocp *o)
 {
     const int N = o->N, nxs = NX * (o->ns + 1);
@@ -879,42 +939,9 @@ int snmpc_solve(snmpc_ocp *o)
 
     /* 1. discrete dynamics and their Jacobians */
     for (int k = 0; k < N; k++) {
-        const double *x = o->X + (size_t)k * nxs, *u = o->U + k * NU;
-        double *A = Ab + (size_t)k * nxs * nxs, *B = Bb + (size_t)k * nxs * NU;
         double xn[NXS];
-        const int stop = (o->stop[k] == 1.0);
-        for (int i = 1; i <= ns; i++) {
-            if (!stop) {
-                double Ai[64], Bi[16];
-                oracle_rk4_sens(&o->model, x + NX * i, u, dt, 1, xn + NX * i, Ai, Bi);
-                for (int r = 0; r < NX; r++) {
-                    for (int c = 0; c < NX; c++) A[(NX * i + r) * nxs + NX * i + c] = Ai[r * NX + c];
-                    for (int c = 0; c < NU; c++) B[(NX * i + r) * NU + c] = Bi[r * NU + c];
-                }
-            } else {
-                for (int r = 0; r < NX; r++) { xn[NX * i + r] = x[NX * i + r]; A[(NX * i + r) * nxs + NX * i + r] = 1.0; }
-            }
-        }
-        if (stop) {
-            double A0[64], B0[16];
-            oracle_rk4_sens(&o->model, x, u, dt, 1, xn, A0, B0);
-            for (int r = 0; r < NX; r++) {
-                for (int c = 0; c < NX; c++) A[r * nxs + c] = A0[r * NX + c];
-                for (int c = 0; c < NU; c++) B[r * NU + c] = B0[r * NU + c];
-            }
-        } else {
-            /* nominal_next = first row of A_pce times the sample successors */
-            for (int r = 0; r < NX; r++) {
-                double acc = 0.0;
-                for (int i = 1; i <= ns; i++) acc += o->Apce[i - 1] * xn[NX * i + r];
-                xn[r] = acc;
-                for (int i = 1; i <= ns; i++) {
-                    const double a = o->Apce[i - 1];
-                    for (int c = 0; c < NX; c++) A[r * nxs + NX * i + c] = a * A[(NX * i + r) * nxs + NX * i + c];
-                    for (int c = 0; c < NU; c++) B[r * NU + c] += a * B[(NX * i + r) * NU + c];
-                }
-            }
-        }
+        snmpc_step(o, o->stop[k] == 1.0, o->X + (size_t)k * nxs, o->U + k * NU, xn,
+                   Ab + (size_t)k * nxs * nxs, Bb + (size_t)k * nxs * NU);
         for (int i = 0; i < nxs; i++) bb[(size_t)k * nxs + i] = xn[i] - o->X[(size_t)(k + 1) * nxs + i];
     }
     /* 4./5. condensing, dx_k = G_k v + g_k */

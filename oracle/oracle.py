@@ -267,6 +267,7 @@ def _snmpc_bind(L):
     L.snmpc_status.argtypes = [ctypes.c_void_p]
     L.snmpc_set_debug.argtypes = [dp]
     L.oracle_h_vabs.argtypes = [ctypes.POINTER(StmModel), dp, dp, dp]
+    L.snmpc_eval.argtypes = [ctypes.c_void_p, ctypes.c_double, dp, dp, dp, dp, dp]
     L._snmpc_bound = True
     return L
 
@@ -354,6 +355,13 @@ class OracleSnmpcOcp:
 
     def solve(self):
         return lib().snmpc_solve(self._h)
+
+    def eval_stage(self, x, u, stop):
+        """model functions at one point: (f_disc(x,u,p), cost_y_expr(x,u), con_h_expr(x,p)) for a stage with this stop_flag"""
+        x = np.ascontiguousarray(x, dtype=np.float64).reshape(-1); u = np.ascontiguousarray(u, dtype=np.float64)
+        xn = np.zeros_like(x); y = np.zeros(6); h = np.zeros(1)
+        lib().snmpc_eval(self._h, float(stop), _dp(x), _dp(u), _dp(xn), _dp(y), _dp(h))
+        return xn, y, float(h[0])
 
     def solve_debug(self):
         N = self.N; nv, m = 2 * N, 3 * N

@@ -11,6 +11,7 @@ DATA (inputs + expected outputs), never reference source:
   replay_<t>_<k>_<a>_<b>.npz   sequential closed-loop windows (x0_i, yref_i, expected u0/x1/cost/qp_iter)
   planner.npz         PlannerEmulator input/output pairs
   pce.npz             alphaGeneration / polyChaosExpansion / compute_x0dist / sigma points of acados_ocp_SNMPC.json
+  snmpc_expr.npz      stacked dynamics / cost output / chance constraint of the exported SNMPC OCP evaluated at random points
   snmpc_json.npz      dimensions, weights, penalties, bounds and solver options of the exported SNMPC OCP (acados_ocp_SNMPC.json)
   r2.npz              P_propagation input/output pairs
   closed_loop_<t>_<n>.npz   first n steps of the 26 logged closed loops of one track (plant states, inputs, predictions)
@@ -22,6 +23,7 @@ Reference call sites reproduced by the replay protocol:
   Utils/Logging_Plotting.py:124-146,341-343 (what the logs hold; yaw is stored wrapped).
 """
 import json
+import re
 import os
 import sys
 import types
@@ -199,6 +201,63 @@ def make_snmpc_json():
                         cost_type=c["cost_type"], cost_type_e=c["cost_type_e"], n_param=len(js["parameter_values"]))
 
 
+def make_snmpc_expr(n=48):
+    """The model functions of the exported SNMPC OCP evaluated at random points: acados_ocp_SNMPC.json carries the CasADi
+    expressions of the stacked discrete dynamics, the cost output and the chance constraint as text; casadi_expr.py
+    evaluates them numerically (gg tables from Config/EDGAR/ggv.csv). Stored: inputs (x 88, u 2, A_pce 10x10, stop_flag) and
+    outputs (f_disc 88, y 6, y_e 4, h). The printed constants have 6 significant digits."""
+    import csv
+    import casadi_expr as ce
+    with open(os.path.join(REF, "acados_ocp_SNMPC.json")) as f:
+        js = json.load(f)
+    model = js["model"]
+    xnames = [t.strip() for t in re.match(r"vertcat\((.*)\)$", model["x"]).group(1).split(",")]
+    ns, L = len(xnames) // 8 - 1, 10
+    with open(os.path.join(REF, "Config", "EDGAR", "ggv.csv")) as f:
+        rows = list(csv.DictReader(f))
+    gv = np.array([float(r["vel_max_mps"]) for r in rows]); gax = np.array([float(r["ax_max_mps2"]) for r in rows])
+    gay = np.array([float(r["ay_max_mps2"]) for r in rows])
+    progs = {k: ce.parse_program(model[k]) for k in ("disc_dyn_expr", "cost_y_expr", "cost_y_expr_e", "con_h_expr")}
+    ddefs = progs["disc_dyn_expr"][0]
+    xdot_id = [k for k, a in ddefs.items() if a[0] == "call" and a[1] == "vertcat" and len(a[2]) == 8 and a[2][-1] == ("id", "jerk")][0]
+
+    def reshape(arg_ast, val):
+        val = np.asarray(val, dtype=float)
+        if arg_ast == ("id", "A_pce"):
+            return val.reshape((ns, L), order="F")            # reshape(A_pce, n_samples, num_poly_terms)
+        return val.reshape((8, ns), order="F")                 # reshape(f_disc, 8, n_samples)
+
+    def ode(ev, X, U):
+        env = dict(ev.env)
+        for i, nm in enumerate(xnames[:8]):
+            env[nm] = float(X[i])
+        env["jerk"], env["steering_rate"] = float(U[0]), float(U[1])
+        return ev.child(env).ev(("tmp", xdot_id))
+
+    funcs = {"f": ode,
+             "ax_max_interpolant": lambda ev, v: float(np.interp(v, gv, gax)),
+             "ay_max_interpolant": lambda ev, v: float(np.interp(v, gv, gay))}
+    rng = np.random.default_rng(2024)
+    from Model_Predictive_Controller.Stochastic_NMPC.stochastic_mpc_utils import alphaGeneration, polyChaosExpansion
+    X = np.zeros((n, 8 * (ns + 1))); U = np.zeros((n, 2)); A = np.zeros((n, L, ns)); stop = np.zeros(n)
+    F = np.zeros((n, 8 * (ns + 1))); Y = np.zeros((n, 6)); Ye = np.zeros((n, 4)); H = np.zeros(n)
+    for j in range(n):
+        base = np.array([rng.uniform(-200, 200), rng.uniform(-200, 200), rng.uniform(-7, 7), rng.uniform(5, 40) if j % 3 else rng.uniform(9, 13),
+                         rng.uniform(-1.5, 1.5), rng.uniform(-0.4, 0.4), rng.uniform(-0.2, 0.2), rng.uniform(-3, 3)])
+        xs = np.tile(base, (ns + 1, 1)); xs[1:] += rng.normal(0, 1, (ns, 8)) * np.array([1, 1, .05, .8, .35, .035, .01, .3])
+        if j % 4 == 0:
+            xs[:, 3] = np.abs(xs[:, 3]) * 1e-4                 # the vlong <= 0.001 branch of the slip angles
+        a = rng.normal(0, 0.3, (L, ns)); a[0] = np.abs(a[0]) + 0.05; a[0] /= a[0].sum()
+        X[j] = xs.reshape(-1); U[j] = [rng.uniform(-5, 5), rng.uniform(-0.3, 0.3)]; A[j] = a; stop[j] = float(j % 2)
+        env = {nm: float(X[j, i]) for i, nm in enumerate(xnames)}
+        env.update(jerk=float(U[j, 0]), steering_rate=float(U[j, 1]), A_pce=a.reshape(-1), risk_parameter=0.8, stop_flag=stop[j])
+        F[j] = ce.Evaluator(progs["disc_dyn_expr"][0], env, funcs, reshape).ev(progs["disc_dyn_expr"][1])
+        Y[j] = ce.Evaluator(progs["cost_y_expr"][0], env, funcs, reshape).ev(progs["cost_y_expr"][1])
+        Ye[j] = ce.Evaluator(progs["cost_y_expr_e"][0], env, funcs, reshape).ev(progs["cost_y_expr_e"][1])
+        H[j] = ce.Evaluator(progs["con_h_expr"][0], env, funcs, reshape).ev(progs["con_h_expr"][1])
+    np.savez_compressed(os.path.join(OUT, "snmpc_expr.npz"), X=X, U=U, A=A, stop=stop, F=F, Y=Y, Ye=Ye, H=H, Ts=0.08, gamma=0.8)
+
+
 def make_r2():
     from Model_Predictive_Controller.Reduced_Robustified_NMPC.Robust_NMPC_pred_model_utils import P_propagation
     rng = np.random.default_rng(11)
@@ -209,7 +268,7 @@ def make_r2():
 
 
 if __name__ == "__main__":
-    what = sys.argv[1:] or ["kat0", "replay", "planner", "pce", "snmpc_json", "r2", "closed_loop"]
+    what = sys.argv[1:] or ["kat0", "replay", "planner", "pce", "snmpc_json", "snmpc_expr", "r2", "closed_loop"]
     if "kat0" in what:
         make_kat0()
     if "replay" in what:
@@ -221,6 +280,8 @@ if __name__ == "__main__":
         make_pce()
     if "snmpc_json" in what:
         make_snmpc_json()
+    if "snmpc_expr" in what:
+        make_snmpc_expr()
     if "r2" in what:
         make_r2()
     if "closed_loop" in what:

@@ -2,7 +2,9 @@
 The coupled SNMPC OCP (Stochastic_NMPC/SNMPC_acados_settings.py, pred_model_dynamic_disc.py).
 
 The reference holds no solver outputs of this OCP with a recorded configuration (ACC24 logs are "weak"), so
-the oracle's SNMPC section is PARITY-UNPINNED against acados. What pins it here:
+the SOLVER OUTPUTS of the oracle's SNMPC section are parity-unpinned against acados. What pins it here:
+  * its model functions (stacked dynamics, cost output, chance constraint) and problem data against the reference's own
+    exported OCP, acados_ocp_SNMPC.json (snmpc_expr.npz / snmpc_json.npz),
   * with stop_flag = 1 everywhere it must reduce to the (golden-pinned) nominal restatement with one RK4 step,
   * its constraint rows and defects must agree with finite differences of an independent numpy rollout of
     pred_model_dynamic_disc.py (written from the reference text, sharing only the single-track RK4 step),
@@ -161,6 +163,26 @@ def test_problem_data_matches_exported_ocp(golden_dir):
     assert opts["nlp_solver_step_length"] == 1.0 and opts["levenberg_marquardt"] == 0.0 and opts["regularize_method"] == "NO_REGULARIZE"
     d = make_desc(dims["N"], opts["tf"] / dims["N"], 1, 1, cfg=cfg)
     assert d.qp_iter_max == opts["qp_solver_iter_max"] == 50 and abs(d.dt - 0.08) < 1e-15 and d.nsub == 1
+
+
+def test_oracle_model_functions_against_exported_expressions(golden_dir):
+    """The oracle's stacked dynamics, cost output and chance constraint against the reference's OWN expressions: the exported
+    OCP (acados_ocp_SNMPC.json) prints them as CasADi text, tests/golden/make_golden.py evaluated that text at 48 random
+    points (both stop_flag values, the low-speed branch of the slip angles, the sloped part of the gg table). The printed
+    constants carry 6 significant digits, hence the tolerance."""
+    g = np.load(os.path.join(golden_dir, "snmpc_expr.npz"))
+    n = g["X"].shape[0]
+    worst = np.zeros(3)
+    for j in range(n):
+        o = orc.OracleSnmpcOcp(N=2, dt=float(g["Ts"]), Apce=g["A"][j], uph=1, gamma=float(g["gamma"]))
+        xn, y, h = o.eval_stage(g["X"][j], g["U"][j], g["stop"][j])
+        scale = 1.0 + np.abs(g["F"][j])
+        worst[0] = max(worst[0], np.max(np.abs(xn - g["F"][j]) / scale))
+        worst[1] = max(worst[1], np.max(np.abs(y - g["Y"][j]) / (1.0 + np.abs(g["Y"][j]))))
+        worst[2] = max(worst[2], abs(h - g["H"][j]) / (1.0 + abs(g["H"][j])))
+        np.testing.assert_allclose(y[:4], g["Ye"][j], rtol=0, atol=1e-4)
+    assert worst[0] < 2e-5 and worst[1] < 2e-5 and worst[2] < 2e-5, worst
+    assert set(g["stop"]) == {0.0, 1.0}
 
 
 # ---------------------------------------------------------------------------------------------- GPU
