@@ -541,3 +541,34 @@ def test_gpu_installed_bounds_match_exported_ocp(golden_dir):
         assert float(np.atleast_1d(s.constraints_get(k, "lbu"))[0]) == g["lbu"][0] and float(np.atleast_1d(s.constraints_get(k, "ubu"))[0]) == g["ubu"][0]
     assert float(np.atleast_1d(s.constraints_get(38, "ubx"))[0]) == g["ubx_e"][0] and float(np.atleast_1d(s.constraints_get(38, "uh"))[0]) == g["uh_e"][0]
     assert s.nx == 88 and s.L * s.ns + 2 == int(g["n_param"])
+
+
+@pytest.mark.gpu
+def test_gpu_snmpc_nan_isolation(golden_dir):
+    """a poisoned instance fails alone (status 4, iterate untouched) and its neighbours are bit-identical to a clean batch"""
+    from tum_control_amd.solver import CoupledSnmpcSolver
+    snm, stds, w, A = _pce()
+    x0, yref, p = _kat(golden_dir)
+    N, B = 38, 3
+    Y = np.zeros((N + 1, 6)); Y[:, :4] = yref
+    xs = snm.compute_x0dist(x0, w, stds)
+
+    def run(poison):
+        s = CoupledSnmpcSolver(N=N, dt=0.08, batch=B, Apce=A, uph=5)
+        s.install_reference_ocp()
+        X0 = np.tile(xs.reshape(1, -1), (B, 1))
+        if poison:
+            X0[1, 8 * 3 + 4] = np.nan                     # lateral speed of sample 3 of instance 1
+        s.constraints_set(0, "lbx", X0); s.constraints_set(0, "ubx", X0)
+        s.set_yref_all(Y); s.cold_start()
+        st = s.solve()
+        Xn, U = s.get_iterate()
+        return st, s.get_stats("status").copy(), Xn, U, np.array([np.atleast_2d(s.get(2, "x"))[j] for j in range(B)])
+
+    st0, stat0, X0n, U0, F0 = run(False)
+    st1, stat1, X1n, U1, F1 = run(True)
+    assert st0 == 0 and list(stat0) == [0, 0, 0]
+    assert st1 == 4 and list(stat1) == [0, 4, 0]
+    for j in (0, 2):
+        np.testing.assert_array_equal(U1[j], U0[j]); np.testing.assert_array_equal(X1n[j], X0n[j]); np.testing.assert_array_equal(F1[j], F0[j])
+    assert np.all(U1[1] == 0.0)                           # failed instance: inputs stay at the cold start
