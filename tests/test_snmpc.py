@@ -572,3 +572,27 @@ def test_gpu_snmpc_nan_isolation(golden_dir):
     for j in (0, 2):
         np.testing.assert_array_equal(U1[j], U0[j]); np.testing.assert_array_equal(X1n[j], X0n[j]); np.testing.assert_array_equal(F1[j], F0[j])
     assert np.all(U1[1] == 0.0)                           # failed instance: inputs stay at the cold start
+
+
+def test_casadi_text_evaluator():
+    """the evaluator that turned the exported CasADi text into snmpc_expr.npz, on hand-checkable expressions of the same
+    printed form (sub-expression definitions, selections, function calls with output selectors, element assignment,
+    column-major reshape / slice / transpose, mac)"""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+    import casadi_expr as ce
+    prog = ("@1=(2<a), @2=sqrt((sq(a)+sq(b))), @3=vertcat(a, b, ((@1?(6.28319+@2):0)+((!@1)?@2:0))), "
+            "@4=g((@3+((0.08*@3)/2)), 7.35294e-05){0}, "
+            "vertcat(@4, mac(reshape(M)',(dense((project((zeros(2x1,1nz)[0] = (a/2.)))[1] = (-b)))),zeros(2x1))[:2:1]', fmax(fmin((-(a/4)),0.98),-0.98))")
+    defs, res = ce.parse_program(prog)
+    M = np.array([1.0, 2.0, 3.0, 4.0])                                    # reshape(M, 2, 2) column-major = [[1,3],[2,4]]
+    for a, b in ((3.0, 4.0), (1.0, -2.0)):
+        ev = ce.Evaluator(defs, dict(a=a, b=b, M=M), {"g": lambda e, x, s: np.asarray(x) * 2.0 + s},
+                          lambda ast, v: np.asarray(v, float).reshape((2, 2), order="F"))
+        out = ev.ev(res)
+        n = np.hypot(a, b)
+        t3 = np.array([a, b, 6.28319 + n if 2 < a else n])
+        g = (t3 + 0.08 * t3 / 2) * 2.0 + 7.35294e-05
+        mv = np.array([[1.0, 3.0], [2.0, 4.0]]).T @ np.array([a / 2.0, -b])
+        want = np.concatenate([g, mv, [max(min(-(a / 4), 0.98), -0.98)]])
+        np.testing.assert_allclose(out, want, rtol=1e-15, atol=0)
