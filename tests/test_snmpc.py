@@ -596,3 +596,39 @@ def test_casadi_text_evaluator():
         mv = np.array([[1.0, 3.0], [2.0, 4.0]]).T @ np.array([a / 2.0, -b])
         want = np.concatenate([g, mv, [max(min(-(a / 4), 0.98), -0.98)]])
         np.testing.assert_allclose(out, want, rtol=1e-15, atol=0)
+
+
+@pytest.mark.gpu
+def test_gpu_dynamics_against_exported_expression(golden_dir):
+    """The HIP single-track step itself (RK4 x 1 over 0.08 s, what both the fused kernel and the SNMPC prologue integrate)
+    against the reference's exported CasADi expression (snmpc_expr.npz), without the oracle in between: 264 random points
+    placed on the stages of a small batch, Phi(x_k, u_k) read back as b_k + x_{k+1} through get_from_qp_in."""
+    from tum_control_amd.solver import BatchedOcpSolver
+    g = np.load(os.path.join(golden_dir, "snmpc_expr.npz"))
+    pts = []
+    for j in range(g["X"].shape[0]):
+        X, F = g["X"][j].reshape(11, 8), g["F"][j].reshape(11, 8)
+        if g["stop"][j] == 1.0:
+            pts.append((X[0], g["U"][j], F[0]))                    # the nominal copy integrates on its own
+        else:
+            pts += [(X[i], g["U"][j], F[i]) for i in range(1, 11)]   # the sample copies do
+    N = 40; B = (len(pts) + N - 1) // N
+    Xi = np.zeros((B, N + 1, 8)); Ui = np.zeros((B, N, 2)); want = np.zeros((B, N, 8)); used = np.zeros((B, N), bool)
+    for n, (x, u, f) in enumerate(pts):
+        Xi[n // N, n % N] = x; Ui[n // N, n % N] = u; want[n // N, n % N] = f; used[n // N, n % N] = True
+    Xi[~np.isfinite(Xi)] = 0.0
+    for b in range(B):                                             # unused stages: a harmless state
+        for k in range(N + 1):
+            if k == N or not used[b, k]:
+                Xi[b, k] = [0, 0, 0, 20, 0, 0, 0, 0]
+    s = BatchedOcpSolver(N=N, dt=float(g["Ts"]), nsub=1, batch=B, store_qp_in=True)
+    s.install_reference_ocp()
+    s.set_x0(Xi[:, 0]); s.set_iterate(X=Xi, U=Ui)
+    s.solve()
+    worst = 0.0
+    for k in range(N):
+        phi = s.get_from_qp_in(k, "b").reshape(B, 8) + Xi[:, k + 1]
+        for b in range(B):
+            if used[b, k]:
+                worst = max(worst, float(np.max(np.abs(phi[b] - want[b, k]) / (1.0 + np.abs(want[b, k])))))
+    assert len(pts) == 264 and worst < 2e-5, worst
