@@ -632,3 +632,32 @@ def test_gpu_dynamics_against_exported_expression(golden_dir):
             if used[b, k]:
                 worst = max(worst, float(np.max(np.abs(phi[b] - want[b, k]) / (1.0 + np.abs(want[b, k])))))
     assert len(pts) == 264 and worst < 2e-5, worst
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind", ["nominal", "snmpc"])
+def test_gpu_instrumented_kernels_agree(kind):
+    """The four instantiations of the fused kernel (plain / instrumented x nominal / SNMPC) are the same arithmetic: a solve
+    through the phase-timer entry point and one through the debug dump leave exactly the iterate of a plain solve. (The
+    instrumented SNMPC instantiation is the largest one; a build of it once came out wrong while the others were right.)"""
+    from tum_control_amd.solver import BatchedOcpSolver, CoupledSnmpcSolver
+    from tum_control_amd.workloads import nominal_batch
+    snm, stds, w, A = _pce()
+    x0, yref = nominal_batch(8, N=40)
+    res = {}
+    for mode in ("plain", "phases", "dump"):
+        if kind == "snmpc":
+            s = CoupledSnmpcSolver(N=40, batch=8, Apce=A, uph=5, x0_offsets=snm.x0_offsets(w, stds))
+        else:
+            s = BatchedOcpSolver(N=40, batch=8)
+        s.install_reference_ocp(); s.set_x0(x0); s.set_yref_all(yref); s.cold_start()
+        if mode == "plain":
+            s.solve()
+        elif mode == "phases":
+            s.profile_phases()
+        else:
+            s.debug_dump(0)
+        res[mode] = (s.get_iterate()[1].copy(), s.get_stats("qp_iter").copy())
+    for mode in ("phases", "dump"):
+        np.testing.assert_array_equal(res[mode][1], res["plain"][1])
+        np.testing.assert_array_equal(res[mode][0], res["plain"][0])

@@ -161,6 +161,29 @@ __device__ __forceinline__ void static_for(F &&f)
     if constexpr (LO <= HI) { f(std::integral_constant<int, LO>()); static_for<LO + 1, HI>(f); }
 }
 // max of NON-NEGATIVE values (identity 0)
+// ---- cross-lane moves for vectors replicated over the four DPP rows of a wavefront (lane = (q, c) = (l >> 4, l & 15)).
+// quad_sum: sum over the four lanes (0..3, c) that share a column index c, result in all four; gfx950 row swaps
+// (v_permlane16_swap / v_permlane32_swap, VALU, no LDS), measured 105 cycles as a dependent step (scripts/probes/probe_permlane.cpp).
+typedef unsigned int tum_u32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ double quad_sum(double v)
+{
+    unsigned lo = __double2loint(v), hi = __double2hiint(v);
+    tum_u32x2 a = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
+    tum_u32x2 b = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+    const double s = __hiloint2double(b[0], a[0]) + __hiloint2double(b[1], a[1]);
+    lo = __double2loint(s); hi = __double2hiint(s);
+    a = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
+    b = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+    return __hiloint2double(b[0], a[0]) + __hiloint2double(b[1], a[1]);
+}
+// lane_gather: value of the lane whose byte address (4 * lane id) is `addr4` (ds_bpermute: the LDS crossbar, no LDS memory;
+// 82 cycles as a dependent step)
+__device__ __forceinline__ double lane_gather(double v, int addr4)
+{
+    const int lo = __builtin_amdgcn_ds_bpermute(addr4, __double2loint(v));
+    const int hi = __builtin_amdgcn_ds_bpermute(addr4, __double2hiint(v));
+    return __hiloint2double(hi, lo);
+}
 __device__ __forceinline__ double wave_max(double v)
 {
     TUM_DPP_SCAN(op_max, 0.0)

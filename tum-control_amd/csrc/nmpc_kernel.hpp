@@ -661,7 +661,7 @@ __global__ void __launch_bounds__(64, 1) nmpc_rti_kernel(const KArgs ka)
         // ---- predictor / corrector
         double cross1[4], cross2[4];                 // dT*dL and dS*dMu of the affine step
         double dv0 = 0.0, dv1 = 0.0, alpha = 1.0, sigma = 0.0;
-        const double invd0 = frcp(sM[lpk(lane, lane)]), invd1 = frcp(sM[lpk(lane1, lane1)]) * ((lane < 16) ? 1.0 : 0.0);
+
 #pragma unroll 1
         for (int pass = 0; pass < 2; pass++) {
             // the lane-derived predicates / addresses are derived afresh for the solve passes: kept from the top of the
@@ -702,83 +702,81 @@ __global__ void __launch_bounds__(64, 1) nmpc_rti_kernel(const KArgs ka)
                 if (lane < 16) dbg[19780 + 64 + lane] = b1;
             }
             TUM_TICK(5);
-            // Triangular solves, 16 unknowns at a time. Diagonal block: y_J = inv(L_JJ) b_J as a lane-local sum over the
-            // 15 lower neighbours inside the row of 16 lanes (DPP row shifts, zero fill outside the row, so neither masks
-            // nor a dependent chain); the same 15 coefficients per lane serve all four blocks of bank 0. Panel: the 16 new
-            // unknowns are broadcast through LDS and every row below (column left, for L') takes 16 FMAs.
+            // Triangular solves on 16x16 tiles. Lane (q, c) = (lane >> 4, lane & 15); a vector block is kept REPLICATED over the
+            // four DPP rows (lane (q, c) holds v[c]); a tile X is read from the packed factor as X[c][q + 4 jj], jj = 0..3 (row c,
+            // four of its columns), so every lane adds 4 products per tile, the four partial sums of a row meet in a quad_sum
+            // (row swaps, VALU) and the only other cross-lane step is handing the 16 new unknowns to the lanes that need them
+            // as column values (v[q + 4 jj]: four lane gathers per block). No LDS broadcasts, no DPP chains: per block row two
+            // quad_sums and two rounds of gathers on the critical path, 60 tile reads + 60 FMAs per solve.
             {
-                const int dg0 = lpk(lane, lane), dg1 = lpk(lane1, lane1);
+                int ga[4];
+#pragma unroll
+                for (int jj = 0; jj < 4; jj++) ga[jj] = ((lane & 48) | ((lq + 4 * jj) & 15)) << 2;
+                const bool ondiag = (lc >= lq) && (((lc - lq) & 3) == 0);      // this lane holds the unit diagonal entry of its row
+                double bj[NT], vs[NT][4];
+#pragma unroll
+                for (int J = 0; J < 4; J++) bj[J] = lane_gather(b0, (16 * J + lc) << 2);
+                bj[4] = lane_gather(b1, lc << 2);
                 // ---- forward: L y = b
-                {
-                    double cf0[16], cf1[16];
-                    static_for<1, 15>([&](auto kc) { constexpr int k = decltype(kc)::value; cf0[k] = sM[dg0 - k]; cf1[k] = sM[dg1 - k]; });
-                    auto diag = [&](const double v, const double (&cf)[16]) {
-                        double a0 = v, a1 = 0.0;
-                        static_for<1, 15>([&](auto kc) {
-                            constexpr int k = decltype(kc)::value;
-                            const double t = row_shr<k>(v);
-                            if (k & 1) a1 += cf[k] * t; else a0 += cf[k] * t;
-                        });
-                        return a0 + a1;
-                    };
 #pragma unroll
-                    for (int J = 0; J < 4; J++) {
-                        const double y = diag(b0, cf0);
-                        b0 = (lq == J) ? y : b0;
-                        wsync();
-                        sDv[lane] = b0;
-                        wsync();
-                        double a0 = 0.0, a1 = 0.0, c0_ = 0.0, c1_ = 0.0;
+                for (int J = 0; J < NT; J++) {
+                    double t = bj[J];
+                    if (J > 0) {
+                        double acc = 0.0, acc1 = 0.0;
 #pragma unroll
-                        for (int c = 0; c < 16; c += 2) {
-                            const double y0 = sDv[16 * J + c], y1 = sDv[16 * J + c + 1];
-                            a0 += sM[myrow0 + 16 * J + c] * y0; a1 += sM[myrow0 + 16 * J + c + 1] * y1;
-                            c0_ += sM[myrow1 + 16 * J + c] * y0; c1_ += sM[myrow1 + 16 * J + c + 1] * y1;
-                        }
-                        b0 = (lq > J) ? b0 - (a0 + a1) : b0;
-                        b1 -= c0_ + c1_;
+                        for (int K = 0; K < J; K++)
+#pragma unroll
+                            for (int jj = 0; jj < 4; jj++) {
+                                const double lv = sM[rb[J] + 16 * K + lq + 4 * jj];
+                                if (jj & 1) acc1 += lv * vs[K][jj]; else acc += lv * vs[K][jj];
+                            }
+                        t -= quad_sum(acc + acc1);
                     }
-                    b1 = diag(b1, cf1);
+                    double a2 = ondiag ? t : 0.0;                  // inv(L_JJ) has a unit diagonal
+#pragma unroll
+                    for (int jj = 0; jj < 4; jj++) {
+                        const double lv = sM[rb[J] + 16 * J + lq + 4 * jj];          // entry (c, q + 4 jj) of the block: inside M for any jj
+                        const double tv = lane_gather(t, ga[jj]);
+                        a2 += ((lq + 4 * jj < lc) ? lv : 0.0) * tv;
+                    }
+                    const double y = quad_sum(a2);
+                    bj[J] = y * frcp(sM[rb[J] + 16 * J + lc]);       // z = D^-1 y rides along (pivot d on the diagonal of M)
+                    if (J < NT - 1) {
+#pragma unroll
+                        for (int jj = 0; jj < 4; jj++) vs[J][jj] = lane_gather(y, ga[jj]);
+                    }
                 }
-                // z = D^-1 y
-                b0 *= invd0; b1 *= invd1;
                 // ---- backward: L' x = z
-                {
-                    // x[c] = z[c] + sum_k inv(L_JJ)[c+k][c] z[c+k]
-                    double cb0[16], cb1[16];
-                    static_for<1, 15>([&](auto kc) {
-                        constexpr int k = decltype(kc)::value;
-                        cb0[k] = sM[lpk(lane + k, lane)];                                   // rows <= 78: always inside M
-                        cb1[k] = sM[(lc + k < 16) ? lpk(lane1 + k, lane1) : 0];
-                    });
-                    auto diagT = [&](const double v, const double (&cb)[16]) {
-                        double a0 = v, a1 = 0.0;
-                        static_for<1, 15>([&](auto kc) {
-                            constexpr int k = decltype(kc)::value;
-                            const double t = row_shl<k>(v);
-                            if (k & 1) a1 += cb[k] * t; else a0 += cb[k] * t;
-                        });
-                        return a0 + a1;
-                    };
-                    b1 = diagT(b1, cb1);
-                    b1 = (lane < 16) ? b1 : 0.0;
 #pragma unroll
-                    for (int J = 4; J >= 1; J--) {
-                        wsync();
-                        if (J == 4) { if (lane < 16) sDv[64 + lane] = b1; }
-                        else sDv[lane] = b0;
-                        wsync();
-                        double a0 = 0.0, a1 = 0.0;
+                for (int J = NT - 1; J >= 0; J--) {
+                    double t = bj[J];
+                    if (J < NT - 1) {
+                        double acc = 0.0, acc1 = 0.0;
 #pragma unroll
-                        for (int r = 0; r < 16; r += 2) {
-                            a0 += sM[lpk(16 * J + r, 0) + lane] * sDv[16 * J + r];
-                            a1 += sM[lpk(16 * J + r + 1, 0) + lane] * sDv[16 * J + r + 1];
-                        }
-                        b0 = (lq < J) ? b0 - (a0 + a1) : b0;
-                        const double x = diagT(b0, cb0);
-                        b0 = (lq == J - 1) ? x : b0;
+                        for (int I = J + 1; I < NT; I++)
+#pragma unroll
+                            for (int jj = 0; jj < 4; jj++) {
+                                const double lv = sM[lpk(16 * I + lq + 4 * jj, 0) + 16 * J + lc];   // L[16I + q + 4jj][16J + c]
+                                if (jj & 1) acc1 += lv * vs[I][jj]; else acc += lv * vs[I][jj];
+                            }
+                        t -= quad_sum(acc + acc1);
+                    }
+                    double a2 = ondiag ? t : 0.0;
+#pragma unroll
+                    for (int jj = 0; jj < 4; jj++) {
+                        const double lv = sM[lpk(16 * J + lq + 4 * jj, 0) + 16 * J + lc];           // inv(L_JJ)[q + 4jj][c]
+                        const double tv = lane_gather(t, ga[jj]);
+                        a2 += ((lq + 4 * jj > lc) ? lv : 0.0) * tv;
+                    }
+                    const double x = quad_sum(a2);
+                    bj[J] = x;
+                    if (J > 0) {
+#pragma unroll
+                        for (int jj = 0; jj < 4; jj++) vs[J][jj] = lane_gather(x, ga[jj]);
                     }
                 }
+                b0 = (lq == 0) ? bj[0] : (lq == 1) ? bj[1] : (lq == 2) ? bj[2] : bj[3];
+                b1 = (lane < 16) ? bj[4] : 0.0;
             }
             dv0 = b0; dv1 = b1;
             TUM_TICK(6);
