@@ -84,6 +84,12 @@ __global__ void __launch_bounds__(64, 1) nmpc_rti_kernel(const KArgs ka)
     const int b = ka.order ? ka.order[blockIdx.x] : (int)blockIdx.x;     // instance solved by this wavefront
     const int N = ka.N, nv = 2 * N;
     const double dt = ka.dt;
+    // The scalars of the interior point method are copied into vector registers here. As kernel arguments they would be
+    // fetched through the kernel-argument base pointer where the IPM starts, and in the largest instantiation of this
+    // kernel exactly those late scalar loads once came out wrong ("An unexplained build failure").
+    double p_mu0 = ka.mu0, p_t0 = ka.t0, p_reg = ka.reg, p_ts = ka.tol_stat, p_ti = ka.tol_ineq, p_tc = ka.tol_comp;
+    int p_itmax = ka.iter_max;
+    asm volatile("" : "+v"(p_mu0), "+v"(p_t0), "+v"(p_reg), "+v"(p_ts), "+v"(p_ti), "+v"(p_tc), "+v"(p_itmax));
     const Model &mp = ka.mp;
 
     double *sAB = lds + O_AB, *sM = lds + O_M, *sStage = lds + O_STAGE, *sCh = lds + O_CH, *sX = lds + O_X;
@@ -387,12 +393,12 @@ __global__ void __launch_bounds__(64, 1) nmpc_rti_kernel(const KArgs ka)
                 const double eps = sd ? -1.0 : 1.0, bnd = sd ? hi[rr] : lo[rr];
                 const double r0v = eps * (dval[rr] - bnd);
                 const double z = pen(rr, sd, 0), Z = pen(rr, sd, 1);
-                const double s0 = ka.mu0 / (z > 1e-6 ? z : 1e-6);
+                const double s0 = p_mu0 / (z > 1e-6 ? z : 1e-6);
                 double t = r0v + s0;
-                if (t < ka.t0) t = ka.t0;
-                const double lam = ka.mu0 / t;
+                if (t < p_t0) t = p_t0;
+                const double lam = p_mu0 / t;
                 double ms = z + Z * s0 - lam;
-                const double msf = 1e-2 * ka.mu0 / s0;
+                const double msf = 1e-2 * p_mu0 / s0;
                 if (ms < msf) ms = msf;
                 // slots without a row keep a neutral state (never read into any reduction)
                 ROWF(0, k) = on ? s0 : 1.0; ROWF(1, k) = on ? t : 1.0; ROWF(2, k) = on ? lam : 1.0; ROWF(3, k) = on ? ms : 1.0;
@@ -451,9 +457,9 @@ __global__ void __launch_bounds__(64, 1) nmpc_rti_kernel(const KArgs ka)
             gap = wave_sum(lg) * inv_npairs;
             const bool lane_nan = !(ls == ls) || !(li == li) || !(lcmp == lcmp);
             if (__any(lane_nan) || !(gap == gap)) { qp_status = 3; break; }
-            const bool lane_open = (ls > ka.tol_stat * qn) || (li > ka.tol_ineq) || (lcmp > ka.tol_comp);
+            const bool lane_open = (ls > p_ts * qn) || (li > p_ti) || (lcmp > p_tc);
             if (!__any(lane_open)) { qp_status = 0; break; }
-            if (it >= ka.iter_max) { qp_status = 1; break; }
+            if (it >= p_itmax) { qp_status = 1; break; }
             TUM_TICK(2);
             publish(gsum[0], gsum[1], sGamH);
         }
@@ -498,7 +504,7 @@ __global__ void __launch_bounds__(64, 1) nmpc_rti_kernel(const KArgs ka)
                             const double sf = sSfx[(mx >> 1) + 1];
                             double add = ((row & 1) && (col & 1) && mx < nv) ? dt2 * sf : 0.0;
                             const double wb = sWb[(row >> 1) < NMAX ? (row >> 1) : 0];
-                            if (row == col) add += ka.reg + (((row & 1) && row < nv) ? wb : 0.0);
+                            if (row == col) add += p_reg + (((row & 1) && row < nv) ? wb : 0.0);
                             acc[jj] += add;
                         }
                     } else {
@@ -671,7 +677,7 @@ __global__ void __launch_bounds__(64, 1) nmpc_rti_kernel(const KArgs ka)
             const int lane = lane_p;
             const int lq = lane >> 4, lc = lane & 15;
             TUM_LANE_DEFS
-            const double tau = (pass == 1) ? fmax(sigma * gap, 0.1 * ka.tol_comp) : 0.0;
+            const double tau = (pass == 1) ? fmax(sigma * gap, 0.1 * p_tc) : 0.0;
             // row phase B1: rhs weights  w = gam_l*rho_l - gam_u*rho_u
             {
                 double w[2];
