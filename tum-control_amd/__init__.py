@@ -4,7 +4,9 @@ bzarr/TUM-CONTROL's NMPC controllers (drop-in for `acados_solver.solve()` and no
 
   csrc/            hand-written HIP (gfx950) kernels + the C-ABI (include/tum_nmpc.h) -> libtumnmpc.so
   solver.py        ctypes binding with acados method names (BatchedOcpSolver)
+  nmpc.py / snmpc.py / r2nmpc.py   mirrors of the reference's three controller classes (same names, arguments, returns)
+  planner.py, closed_loop.py        the producer (PlannerEmulator) and the consumer (plant + estimator) of the solve
+  workloads.py, sharding.py         synthetic batches of the BASELINE configs and their group-aligned multi-GPU layout
   config.py        EDGAR vehicle / tyre / MPC constants
-  (more host-side mirrors of the reference's controller interface are added as the path widens)
 """
 __version__ = "0.1.0"

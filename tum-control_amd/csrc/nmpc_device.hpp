@@ -10,9 +10,12 @@
 //                        iteration  M = H + C' Gamma C  (MFMA SYRK into the packed lower triangle in
 //                        LDS), LDL' over 4-column micro-panels held as row-panel register tiles (MFMA
 //                        rank-4 trailing updates), in-place inverses of the five 16x16 diagonal blocks,
-//                        then two 16-wide block substitutions (DPP row shifts inside a block, LDS
-//                        broadcast across blocks). The row state (s, t, lam, mu and residuals of the
-//                        six soft rows of a stage) stays in registers, two slots x two sides per lane
+//                        then two block substitutions on 16x16 register tiles: a vector block is kept
+//                        replicated over the four DPP rows, the four partial sums of a row meet in a
+//                        quad_sum of gfx950 row swaps (v_permlane16_swap / v_permlane32_swap) and the
+//                        new unknowns reach the lanes that need them through ds_bpermute gathers.
+//                        The row state (s, t, lam, mu and residuals of the six soft rows of a stage)
+//                        stays in registers, two slots x two sides per lane
 //   phase 4  expand      dx trajectory, full step, cost at the new iterate
 // Everything between the initial loads and the final stores lives in LDS / registers.
 //
