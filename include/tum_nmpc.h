@@ -68,7 +68,12 @@ int tum_ocp_batch(const tum_ocp *c);
 int tum_ocp_horizon(const tum_ocp *c);
 
 /* acados_solver.set(stage, field, value)   NMPC_class.py:172,178,254; SNMPC_class.py:124,130
- * field: "x" (8), "u" (2), "yref" (6 for stage<N, 4 for stage N).
+ * field: "x" (8), "u" (2), "yref" (6 for stage<N, 4 for stage N); on an SNMPC capsule also
+ * "p" (L*ns + 2 values = [A_pce.flatten(), risk_parameter, stop_flag], SNMPC_class.py:124,185,193; b0 = 0, nb = batch,
+ * stride 0: the parameter vector is shared by the batch). A_pce and the risk parameter are shared by all stages (the
+ * reference sends every stage the same values; a differing risk parameter is an error at the next solve); the stop flags
+ * must be 0 on the stages < uph and 1 from stage uph on (SNMPC_class.py:103-104) and DEFINE the uncertainty propagation
+ * horizon of the next solve (any other pattern is an error at the next solve).
  * stage == TUM_ALL_STAGES: v holds all stages back to back ("x": (N+1)*8, "u": N*2, "yref": (N+1)*6
  * with the terminal record padded to 6). */
 int tum_ocp_set(tum_ocp *c, int stage, const char *field, const double *v, int len, int b0, int nb, int stride);
@@ -85,7 +90,8 @@ int tum_ocp_constraints_set(tum_ocp *c, int stage, const char *field, const doub
 
 /* acados_solver.cost_set(stage, field, value)   NMPC_class.py:295-317
  * "W": ny*ny (stage<N: 36, stage N: 16) column-major, must be diagonal (the reference only installs
- * blockdiag(Q,R)); all stages < N share one W per instance (the reference sets them identically).
+ * blockdiag(Q,R)). RESTRICTION: all stages < N share ONE W per instance (the reference sets them identically,
+ * NMPC_class.py:295-296): cost_set at any stage < N overwrites the weight of all of them; stage-dependent W is not built.
  * "zl","zu","Zl","Zu": 1 value at stage 0 [sbu], 3 at stages 1..N-1 [sbu,sbx,sh], 2 at stage N [sbx,sh]. */
 int tum_ocp_cost_set(tum_ocp *c, int stage, const char *field, const double *v, int len, int b0, int nb, int stride);
 
@@ -116,6 +122,9 @@ int tum_ocp_set_stream(tum_ocp *c, void *hip_stream);
 /* field: "u0" (nb x 2), "x1" (nb x 8), "cost" (nb), "X" (nb x (N+1)*8), "U" (nb x N*2),
  * "status" / "qp_iter" (nb int32), "summary" (nb x 5 doubles: u0[2], cost, status, qp_iter -- the slab of the rooted gather) */
 int tum_ocp_get_device(tum_ocp *c, const char *field, void *dev_dst, int b0, int nb);
+/* The other direction: per-instance inputs from caller-owned DEVICE memory (asynchronous D2D on the capsule's stream).
+ * field: "x0" (nb x 8, = constraints_set(0,"lbx")), "yref" (nb x (N+1)*6), "X" (nb x (N+1)*8), "U" (nb x N*2). */
+int tum_ocp_put_device(tum_ocp *c, const char *field, const void *dev_src, int b0, int nb);
 /* cold start every instance on the device: X_k = x0 for all k, U = 0 (acados create / reset + set x;
  * NMPC_class.py:250-254) using the x0 already uploaded with constraints_set(0,"lbx"). */
 int tum_ocp_cold_start(tum_ocp *c);
@@ -138,6 +147,11 @@ int tum_ocp_set_x0_fanout(tum_ocp *c, const double *pose, const double *offs, in
  * c = A v with the L x S least-squares PCE matrix A (row-major, host), mean = c_0, var = sum_{k>=1} c_k^2, for
  * every component of field "x" (8) / "u" (2) at `stage` of the current iterate. mean, var: P x m (host). */
 int tum_pce_moments(tum_ocp *c, const char *field, int stage, const double *A, int L, int S, double *mean, double *var);
+/* The same reduction without a host round trip: tum_pce_attach keeps A (L x S, row-major, host) on the device,
+ * tum_pce_moments_device enqueues the reduction on the capsule's stream and writes P x m doubles each into caller-owned
+ * DEVICE buffers (the slab of the rooted gather of BASELINE config 3). */
+int tum_pce_attach(tum_ocp *c, const double *A, int L, int S);
+int tum_pce_moments_device(tum_ocp *c, const char *field, int stage, double *mean_dev, double *var_dev);
 /* The coupled SNMPC OCP (Stochastic_NMPC/SNMPC_acados_settings.py:19-320 with the DISCRETE stacked dynamics
  * of Stochastic_NMPC/pred_model_dynamic_disc.py:121-220): turns the capsule (created with nsub = 1) into the solver the
  * reference builds at SNMPC_acados_settings.py:318 and calls at SNMPC_class.py:198. The stacked state is the nominal
@@ -166,6 +180,10 @@ int tum_ocp_r2_backoff(tum_ocp *c, const double *Sigma0, const double *BWB, int 
  * lets the robustified controller run in the device closed loop (tum_sim_*). uph = 0 detaches. */
 int tum_ocp_r2_attach(tum_ocp *c, const double *Sigma0, const double *BWB, int uph,
                       double delta_min, double delta_max, double uh_nom);
+/* Snapshot / restore (asynchronous) of ALL per-stage bounds on the device: the tightening rewrites them after every solve,
+ * a sweep or a benchmark that restarts from the nominal problem puts them back without a host copy. */
+int tum_ocp_bounds_snapshot(tum_ocp *c);
+int tum_ocp_bounds_restore(tum_ocp *c);
 /* read back a bound installed with constraints_set / r2_backoff (one value per instance) */
 int tum_ocp_constraints_get(tum_ocp *c, int stage, const char *field, double *v, int b0, int nb);
 
@@ -187,7 +205,10 @@ void tum_sim_free(tum_sim *s);
 /* x_sim: batch x 7 plant states, x_mpc: batch x 8 controller states (host); resets the estimator and the step counter */
 int tum_sim_set_state(tum_sim *s, const double *x_sim, const double *x_mpc, int cold_start);
 int tum_sim_plan(tum_sim *s);        /* yref of every instance from its pose (async on the capsule's stream) */
-int tum_sim_advance(tum_sim *s);     /* plant step with (x1[7], u0[1]) of the iterate, estimator -> next x0 (async) */
+/* plant step with (x1[7], u0[1]) of the iterate, estimator -> next x0 (async). An instance whose solve FAILED (status != 0)
+ * is then treated as main.py:59-61 treats it (MPC.reintialize_solver(x_next)): its iterate is cold-started at the state the
+ * failed solve started from (sample copies included), an R2 capsule gets its nominal bounds back. */
+int tum_sim_advance(tum_sim *s);
 /* nsteps x (plan, solve, advance), then synchronises; chunks of 25 steps are captured once into a hipGraph and replayed
  * (tum_sim_get "graph_steps" tells whether the capture succeeded) */
 int tum_sim_run(tum_sim *s, int nsteps);

@@ -67,6 +67,25 @@ def build(force=False):
     return _LIB_PATH
 
 
+def use_native():
+    """bench.py's cpu_baseline leg: rebuild the checker with -march=native on THIS host (oracle/_native/, next to the shipped
+    x86-64-v3 build) and switch this module to it. Returns a description of the build in use; falls back to the shipped
+    library when no compiler is present."""
+    global _lib, _LIB_PATH
+    try:
+        out_dir = os.path.join(_HERE, "_native")
+        os.makedirs(out_dir, exist_ok=True)
+        out = os.path.join(out_dir, "liboracle_native.so")
+        subprocess.check_call(["gcc", "-O3", "-march=native", "-fPIC", "-fopenmp", "-std=c11", "-shared", "-o", out,
+                               os.path.join(_HERE, "nmpc_oracle.c"), "-lm"], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        _LIB_PATH, _lib = out, None
+        lib()
+        return "gcc -O3 -march=native -fopenmp, rebuilt on this host"
+    except Exception:
+        _LIB_PATH, _lib = os.path.join(_HERE, "liboracle.so"), None
+        return "gcc -O3 -march=x86-64-v3 -fopenmp (shipped build; no compiler on this host)"
+
+
 _lib = None
 
 

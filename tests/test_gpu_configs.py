@@ -1,0 +1,287 @@
+"""
+BASELINE.json configs 3, 4 and 5 at their per-GPU sizes through the C-ABI (-m gpu), plus the entry points added for them
+(device-side PCE moments, bounds snapshot / restore, device-to-device inputs), the per-stage parameter vector of the SNMPC
+OCP at the C level, and the recovery from a failed solve in the closed loops.
+
+Protocol per config (the oracle cannot solve 16384 instances in seconds): the oracle on a strided subset of the instances,
+size-independent properties (bitwise determinism, independence of the batch composition, group reductions against numpy)
+at the full size.
+"""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+N = 40
+
+
+def _mk(B, **kw):
+    from tum_control_amd.solver import BatchedOcpSolver
+    s = BatchedOcpSolver(N=N, dt=0.08, nsub=3, batch=B, **kw)
+    s.install_reference_ocp()
+    return s
+
+
+def _oracle():
+    from oracle.oracle import OracleOcp
+    from tum_control_amd import config
+    m = config.MPC
+    o = OracleOcp(N, 0.08, 3)
+    o.set_weights(m["q_lon"], m["q_yaw"], m["q_vel"], m["r_jerk"], m["r_steering_rate"], m["L1_pen"], m["L2_pen"], scale=0.01)
+    return o
+
+
+def _check_subset_against_oracle(s, x0, yref, idx, tol=1e-6):
+    X, U = s.get_iterate()
+    it = s.get_stats("qp_iter")
+    u0, X1, st = _oracle().solve_batch_cold(x0[idx], yref[idx], 8)
+    assert (st[:, 2] == 0).all()
+    same = it[idx] == st[:, 1]          # (an instance whose termination test sits on the tolerance edge may stop one iteration apart)
+    assert same.mean() > 0.98 and np.abs(it[idx] - st[:, 1]).max() <= 1
+    eu = np.abs(U[idx, 0] - u0).max(axis=1); ex = np.abs(X[idx, 1] - X1).max(axis=1)
+    assert eu[same].max() < tol and ex[same].max() < tol
+    assert eu.max() < 5e-5 and ex.max() < 5e-5
+    np.testing.assert_allclose(s.get_cost()[idx][same], st[same, 0], rtol=1e-7)
+
+
+def test_config3_sigma_points_full_size():
+    """configs[2]: 16384 scenarios = 1024 poses x (nominal + 15 Hammersley sigma points), Monteblanco; cold-start SQP-RTI
+    and the PCE moments of x_1 per scenario group (K6), host and device flavour."""
+    import torch
+    from tum_control_amd.snmpc import alpha_generation, hammersley_normal, pce_matrix, x0_offsets
+    from tum_control_amd.workloads import config_groups, sigma_point_groups
+    from tum_control_amd import config
+    P, S1 = 1024, 16
+    x0, yref, g = config_groups(3, 0, P, P, N=N)
+    assert g == S1 and len(x0) == P * S1
+    s = _mk(P * S1)
+    # the fan-out kernel (compute_x0dist as a batch axis) produces the same x0 as the host generator
+    w = hammersley_normal(15, 3)
+    off = x0_offsets(w, config.MPC["stds"])
+    pose, yg, _, _ = sigma_point_groups(0, P, P, off, N=N)
+    s.set_x0_fanout(pose, off)
+    s.set_yref_all(yref); s.cold_start()
+    np.testing.assert_array_equal(s.get(0, "x"), x0)
+    assert s.solve() == 0
+    assert (s.get_stats("status") == 0).all()
+    X, U = s.get_iterate()
+    _check_subset_against_oracle(s, x0, yref, np.arange(5, P * S1, 257))
+    # PCE moments at full size against numpy, host-pointer and device-pointer entry points
+    A = pce_matrix(w, alpha_generation(3, 2))
+    c = np.einsum("ls,psm->plm", A, X[:, 1].reshape(P, S1, 8)[:, 1:])
+    mean, var = s.pce_moments("x", 1, A)
+    np.testing.assert_allclose(mean, c[:, 0], atol=1e-10)
+    np.testing.assert_allclose(var, (c[:, 1:] ** 2).sum(axis=1), atol=1e-10)
+    s.pce_attach(A)
+    mv = torch.zeros((2, P, 8), dtype=torch.float64, device="cuda")
+    s.pce_moments_device("x", 1, mv[0].data_ptr(), mv[1].data_ptr())
+    s.synchronize()
+    assert np.array_equal(mv[0].cpu().numpy(), mean) and np.array_equal(mv[1].cpu().numpy(), var)
+    # the propagated uncertainty is what the sigma points say: the spread of vlong after one stage stays near its std
+    assert 0.5 < np.sqrt(var[:, 3]).mean() / config.MPC["stds"][3] < 1.2
+    # determinism and independence of the batch composition: the second half of the groups alone gives the same bits
+    s.cold_start(); s.solve()
+    X2, U2 = s.get_iterate()
+    assert np.array_equal(X, X2) and np.array_equal(U, U2)
+    h = _mk(P * S1 // 2)
+    h.set_x0(x0[P * S1 // 2:]); h.set_yref_all(yref[P * S1 // 2:]); h.cold_start(); assert h.solve() == 0
+    Xh, Uh = h.get_iterate()
+    assert np.array_equal(Xh, X[P * S1 // 2:]) and np.array_equal(Uh, U[P * S1 // 2:])
+
+
+def test_config4_monte_carlo_full_size():
+    """configs[3]: the per-GPU share (16384 scenarios = 1024 poses x 16) of the 131072-scenario Monte-Carlo job on LVMS:
+    rank 5 of 8 by the group-aligned sharding; oracle on a strided subset, determinism, permutation of whole groups."""
+    from tum_control_amd.sharding import shard_groups
+    from tum_control_amd.workloads import CONFIGS, config_groups
+    world, rank = 8, 5
+    gt = world * CONFIGS[4]["groups_per_gpu"]
+    g_lo, g_hi, b_lo, b_hi = shard_groups(gt, 16, world, rank)
+    assert (g_hi - g_lo, b_hi - b_lo) == (1024, 16384) and b_lo == 16 * g_lo
+    x0, yref, _ = config_groups(4, g_lo, g_hi, gt, N=N)
+    B = len(x0)
+    s = _mk(B)
+    s.set_x0(x0); s.set_yref_all(yref); s.cold_start()
+    assert s.solve() == 0
+    st = s.get_stats("status")
+    assert (st == 0).all()
+    X, U = s.get_iterate()
+    _check_subset_against_oracle(s, x0, yref, np.arange(3, B, 251))
+    # every scenario of a group starts from the pose's position / heading and only differs in (vlong, vlat, yawrate)
+    d = x0.reshape(1024, 16, 8) - x0.reshape(1024, 16, 8)[:, :1]
+    assert (d[:, :, [0, 1, 2, 6, 7]] == 0).all() and (np.abs(d[:, 1:, 3]) > 0).all()
+    # permuting whole groups permutes the results (bitwise); so does the schedule
+    perm = np.random.default_rng(3).permutation(1024)
+    idx = (perm[:, None] * 16 + np.arange(16)[None]).reshape(-1)
+    s.set_x0(x0[idx]); s.set_yref_all(yref[idx]); s.cold_start(); assert s.solve() == 0
+    Xp, Up = s.get_iterate()
+    assert np.array_equal(Xp, X[idx]) and np.array_equal(Up, U[idx])
+    s.set_schedule(False); s.cold_start(); s.solve(); s.set_schedule(True)
+    Xn, Un = s.get_iterate()
+    assert np.array_equal(Xn, Xp) and np.array_equal(Un, Up)
+
+
+def test_config5_r2_full_size():
+    """configs[4]: 4096 R2NMPC instances (the per-GPU share of 32768) on Modena: solve, covariance back-off (K7), solve with
+    the tightened bounds. The one-shot path (tum_ocp_r2_backoff between two solves) against numpy / the oracle on a subset;
+    the attached path with bounds snapshot / restore (what bench.py --config 5 times) bitwise against the one-shot path."""
+    from oracle.oracle import h_con
+    from tum_control_amd.r2nmpc import r2_setup
+    from tum_control_amd.workloads import config_groups
+    from tum_control_amd import config
+    B = 4096
+    x0, yref, _ = config_groups(5, 0, B, 8 * B, N=N)
+    m, veh = config.MPC, config.VEH
+    S0, BWB = r2_setup(m["stds"], 0.08)
+    uph, dmin, dmax = int(m["uncertainty_propagation_horizon"]), veh["delta_f_min"], veh["delta_f_max"]
+    a = _mk(B, store_qp_in=True)
+    a.set_x0(x0); a.set_yref_all(yref); a.cold_start()
+    assert a.solve() == 0
+    X1, U1 = a.get_iterate()
+    idx = np.arange(7, B, 273)
+    _check_subset_against_oracle(a, x0, yref, idx)
+    bo = a.r2_backoff(S0, BWB, uph, dmin, dmax, 1.0, return_backoffs=True)
+    A = np.stack([a.get_from_qp_in(k, "A") for k in range(uph)], axis=1)
+    for b in idx:
+        Sig = S0.copy(); bd = bh = 0.0
+        for k in range(uph):
+            if k > 0:
+                _, g = h_con(X1[b, k])
+                bd = np.sqrt(Sig[6, 6]); bh = np.sqrt(g @ Sig @ g)
+                assert abs(bo[b, k, 0] - bd) < 1e-12 and abs(bo[b, k, 1] - bh) < 1e-10
+            Sig = A[b, k] @ Sig @ A[b, k].T + BWB
+        assert np.abs(bo[b, uph:, 0] - bd).max() < 1e-12 and np.abs(bo[b, uph:, 1] - bh).max() < 1e-10
+    assert (bo[:, 1:, 1] > 0).all() and bo[:, 1:, 1].max() < 0.5
+    assert a.solve() == 0
+    X2, U2 = a.get_iterate()
+    for b in idx[:6]:
+        o = _oracle(); o.cold_start(x0[b]); o.yref[:] = yref[b]; assert o.solve() == 0
+        o.lbx[1:N] = dmin + bo[b, 1:, 0]; o.ubx[1:N] = dmax - bo[b, 1:, 0]; o.uh[1:N] = 1.0 - bo[b, 1:, 1]
+        assert o.solve() == 0
+        assert np.abs(U2[b] - o.U).max() < 1e-6 and np.abs(X2[b] - o.X).max() < 1e-6
+    # the attached path: two steps of (restore nominal bounds, cold start, solve + K7, solve + K7)
+    c = _mk(B, store_qp_in=True)
+    c.set_x0(x0); c.set_yref_all(yref)
+    c.r2_attach(S0, BWB, uph, dmin, dmax, 1.0)
+    c.bounds_snapshot()
+    for _ in range(2):
+        c.bounds_restore(); c.cold_start()
+        assert c.constraints_get(3, "uh").min() == 1.0
+        c.solve_async(); c.solve_async(); c.synchronize()
+        Xc, Uc = c.get_iterate()
+        assert np.array_equal(Xc, X2) and np.array_equal(Uc, U2)
+        assert (c.get_stats("status") == 0).all()
+    np.testing.assert_allclose(c.constraints_get(3, "uh"), 1.0 - a.r2_backoff(S0, BWB, uph, dmin, dmax, 1.0, return_backoffs=True)[:, 3, 1], atol=1e-14)
+
+
+def test_put_device_inputs():
+    """per-instance inputs straight from caller-owned HBM (the fresh-batch leg of bench.py)"""
+    import torch
+    from tum_control_amd.workloads import nominal_batch
+    B = 64
+    x0, yref = nominal_batch(B, N=N, seed=9)
+    a = _mk(B); a.set_x0(x0); a.set_yref_all(yref); a.cold_start(); assert a.solve() == 0
+    Xa, Ua = a.get_iterate()
+    b = _mk(B)
+    tx, ty = torch.from_numpy(x0).cuda(), torch.from_numpy(yref.copy()).cuda()
+    torch.cuda.synchronize()
+    b.put_device("x0", tx.data_ptr()); b.put_device("yref", ty.data_ptr()); b.cold_start(); assert b.solve() == 0
+    Xb, Ub = b.get_iterate()
+    assert np.array_equal(Xa, Xb) and np.array_equal(Ua, Ub)
+    with pytest.raises(Exception, match="unknown field"):
+        b.put_device("nope", tx.data_ptr())
+
+
+def test_gpu_per_stage_parameters():
+    """set(stage, "p", [A_pce.flatten(), risk_parameter, stop_flag]) at the C level (SNMPC_class.py:124,185,193): the stop
+    flags define the uncertainty propagation horizon, A_pce and the risk parameter are shared by the stages."""
+    from tum_control_amd import config
+    from tum_control_amd import snmpc as snm
+    from tum_control_amd.solver import CoupledSnmpcSolver
+    from tum_control_amd.workloads import nominal_batch
+    stds = np.asarray(config.MPC["stds"]); w = snm.hammersley_normal(10, 3)
+    A = snm.pce_matrix(w, snm.alpha_generation(3, 2)); off = snm.x0_offsets(w, stds)
+    Nn, B = 38, 5
+    x0, yref = nominal_batch(B, N=Nn, seed=4)
+
+    def run(s):
+        s.install_reference_ocp()
+        s.set_x0(x0); s.set_yref_all(yref); s.cold_start()
+        assert s.solve() == 0
+        return s.get_iterate()
+
+    def setp(s, A_, gam, uph):
+        for k in range(Nn + 1):
+            s.set(k, "p", np.concatenate([A_.flatten(), [gam], [1.0 if k >= uph else 0.0]]))
+
+    ref7 = run(CoupledSnmpcSolver(N=Nn, dt=0.08, batch=B, Apce=A, uph=7, gamma=0.8, x0_offsets=off))
+    ref3g = run(CoupledSnmpcSolver(N=Nn, dt=0.08, batch=B, Apce=0.9 * A, uph=3, gamma=0.7, x0_offsets=off))
+    s = CoupledSnmpcSolver(N=Nn, dt=0.08, batch=B, Apce=A, uph=5, gamma=0.8, x0_offsets=off)
+    base = run(s)
+    assert not np.array_equal(base[1], ref7[1])
+    setp(s, A, 0.8, 7)                       # longer horizon than the capsule was attached with: buffers grow
+    got = run(s)
+    assert np.array_equal(got[0], ref7[0]) and np.array_equal(got[1], ref7[1])
+    setp(s, 0.9 * A, 0.7, 3)                 # other PCE matrix, risk level and horizon
+    got = run(s)
+    assert np.array_equal(got[0], ref3g[0]) and np.array_equal(got[1], ref3g[1])
+    # patterns the stacked model is not built for are refused at the next solve
+    s.set(10, "p", np.concatenate([0.9 * A.flatten(), [0.7], [0.0]]))
+    with pytest.raises(Exception, match="stop_flag pattern"):
+        s.solve()
+    setp(s, 0.9 * A, 0.7, 3)
+    s.set(2, "p", np.concatenate([0.9 * A.flatten(), [0.6], [0.0]]))
+    with pytest.raises(Exception, match="risk parameter"):
+        s.solve()
+    setp(s, 0.9 * A, 0.7, 3)
+    assert s.solve() == 0
+    with pytest.raises(Exception, match="mismatching dimension"):
+        s.set(1, "p", np.zeros(5))
+    nom = _mk(2)
+    with pytest.raises(Exception, match="not an SNMPC capsule"):
+        nom._chk(nom._L.tum_ocp_set(nom._h, 0, b"p", np.zeros(3).ctypes.data_as(nom._L.tum_ocp_set.argtypes[3]), 3, 0, 2, 0), "set")
+
+
+@pytest.mark.parametrize("controller", ["nominal", "r2", "snmpc"])
+def test_closed_loop_recovers_from_a_failed_solve(controller):
+    """main.py:59-61: a failed solve is followed by MPC.reintialize_solver(x_next) -- a fresh solver cold-started at the
+    state the failed solve started from. Here one vehicle's iterate is poisoned (NaN) in the middle of a closed loop: that
+    solve returns status 4, the loop applies the stale control, re-initialises the instance and carries on; the all-device
+    loop (recovery inside plant_advance_kernel) and the host loop (ClosedLoopBatch._reinitialise) agree step for step."""
+    from tum_control_amd.closed_loop import ClosedLoopBatch
+    B, n1, n2, Nn = 3, 6, 8, 38
+    loops = []
+    for on_device in (False, True):
+        cl = ClosedLoopBatch("monteblanco", batch=B, N=Nn, Tp=3.04, controller=controller, on_device=on_device,
+                             log_capacity=n1 + n2, idx_start=100)
+        cl.run(n1)
+        X, U = cl.solver.get_iterate()
+        X[1, 3:7, :] = np.nan
+        cl.solver.set_iterate(X, U)
+        if controller == "r2":
+            assert cl.solver.constraints_get(3, "uh").max() < 1.0       # tightened by the solves so far
+        if on_device and controller == "r2":
+            cl.dev.run(1)
+            uh = cl.solver.constraints_get(3, "uh")
+            assert uh[1] == 1.0 and uh[0] < 1.0 and uh[2] < 1.0         # nominal bounds again for the failed instance only
+            lg = cl.run(n2 - 1)
+        else:
+            lg = cl.run(n2)
+        loops.append(lg)
+    host, dev = loops
+    dbg = dev["simSolverDebug"]
+    assert dbg.shape[0] == n1 + n2
+    assert dbg[n1, 1, 4] == 4 and (dbg[n1, [0, 2], 4] == 0).all()
+    assert (dbg[:n1, :, 4] == 0).all() and (dbg[n1 + 1:, :, 4] == 0).all()      # back to normal from the next step on
+    for k in ("simU", "CiLX", "MPC_SimX"):
+        assert np.isfinite(dev[k]).all()
+        np.testing.assert_allclose(dev[k], host[k], rtol=1e-7, atol=1e-8, err_msg=k)
+    np.testing.assert_array_equal(dev["simSolverDebug"][:, :, 4], host["simSolverDebug"][:, :, 4])
+    # the stale control was applied at the failed step: u0 of that step equals the previous step's
+    np.testing.assert_array_equal(dev["simU"][n1, 1], dev["simU"][n1 - 1, 1])
+    # and the other vehicles never noticed
+    ref = ClosedLoopBatch("monteblanco", batch=1, N=Nn, Tp=3.04, controller=controller, on_device=True,
+                          log_capacity=n1 + n2, idx_start=100).run(n1 + n2)
+    np.testing.assert_allclose(dev["CiLX"][:, 0], ref["CiLX"][:, 0], rtol=1e-9, atol=1e-9)

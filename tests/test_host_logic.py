@@ -55,6 +55,107 @@ def test_shard_ranges_partition():
         assert max(shard_sizes(total, world)) - min(shard_sizes(total, world)) <= 1
 
 
+def test_group_sharding_never_splits_a_scenario_group():
+    """ranks own whole scenario groups (a pose with its sigma points / Monte-Carlo draws)."""
+    from tum_control_amd.sharding import shard_groups
+    for n_groups, gsz, world in ((8192, 16, 8), (1024, 16, 1), (7, 16, 3), (5, 11, 8), (32768, 1, 8)):
+        sh = [shard_groups(n_groups, gsz, world, r) for r in range(world)]
+        assert sh[0][0] == 0 and sh[0][2] == 0 and sh[-1][1] == n_groups and sh[-1][3] == n_groups * gsz
+        for r in range(world):
+            g_lo, g_hi, b_lo, b_hi = sh[r]
+            assert b_lo == g_lo * gsz and b_hi == g_hi * gsz and b_lo % gsz == 0 and b_hi % gsz == 0
+            if r:
+                assert sh[r - 1][1] == g_lo and sh[r - 1][3] == b_lo
+        # every instance of a group lands on the rank that owns the group
+        owner = np.empty(n_groups * gsz, dtype=int)
+        for r, (_, _, b_lo, b_hi) in enumerate(sh):
+            owner[b_lo:b_hi] = r
+        assert (owner.reshape(n_groups, gsz) == owner.reshape(n_groups, gsz)[:, :1]).all()
+
+
+@pytest.mark.parametrize("cid", [3, 4, 5])
+def test_config_workloads_are_shard_invariant(cid):
+    """The union of the shards of any world size IS the unsharded batch (per-group random streams keyed by the global
+    group index), groups share one yref, and the scenario offsets have the configured statistics."""
+    from tum_control_amd import config
+    from tum_control_amd.sharding import shard_groups
+    from tum_control_amd.workloads import CONFIGS, config_groups
+    G, N = 12, 10
+    gsz = CONFIGS[cid]["group"]
+    x0, yref, g = config_groups(cid, 0, G, G, N=N)
+    assert g == gsz and x0.shape == (G * gsz, 8) and yref.shape == (G * gsz, N + 1, 6)
+    for world in (2, 5):
+        xs, ys = [], []
+        for r in range(world):
+            g_lo, g_hi, _, _ = shard_groups(G, gsz, world, r)
+            a, b, _ = config_groups(cid, g_lo, g_hi, G, N=N)
+            xs.append(a); ys.append(b)
+        assert np.array_equal(np.vstack(xs), x0) and np.array_equal(np.vstack(ys), yref)
+    if gsz > 1:
+        yg = yref.reshape(G, gsz, N + 1, 6)
+        assert (yg == yg[:, :1]).all()
+        d = x0.reshape(G, gsz, 8)[:, 1:] - x0.reshape(G, gsz, 8)[:, :1]
+        stds = np.asarray(config.MPC["stds"])
+        assert (d[:, :, stds == 0] == 0).all()
+        if cid == 3:        # the same 15 sigma points for every pose
+            assert np.allclose(d, d[:1], atol=1e-12)
+        else:               # i.i.d. draws: different per pose, sample std near the configured one
+            assert not np.allclose(d[0], d[1])
+            sd = d[:, :, stds > 0].reshape(-1, 3).std(axis=0)
+            assert np.all(np.abs(sd / stds[stds > 0] - 1) < 0.25)
+
+
+def _gloo_group_worker(rank, world, port, out):
+    import torch
+    import torch.distributed as dist
+    sys.path.insert(0, ROOT)
+    from tum_control_amd.sharding import ResultGatherer, shard_groups
+    from tum_control_amd.workloads import config_groups
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    G, gsz, N = 6, 16, 6
+    g_lo, g_hi, b_lo, b_hi = shard_groups(G, gsz, world, rank)
+    x0, yref, _ = config_groups(4, g_lo, g_hi, G, N=N)
+    # stand-in for the result slab of bench.py: 5 doubles per instance (first = the instance's global index, then x0[3:7])
+    # followed by one 16-double record per group (its index and the group mean of x0): ONE flat buffer, ONE gather
+    per = np.concatenate([np.arange(b_lo, b_hi)[:, None].astype(float), x0[:, 3:7]], axis=1)
+    grp = np.concatenate([np.arange(g_lo, g_hi)[:, None].astype(float), x0.reshape(-1, gsz, 8).mean(axis=1), np.zeros((g_hi - g_lo, 7))], axis=1)
+    slab = torch.from_numpy(np.concatenate([per.reshape(-1), grp.reshape(-1)])).reshape(1, -1)
+    g = ResultGatherer(world, rank, 1, torch.device("cpu"), nf=slab.shape[1], ni=1)
+    af, _ = g.gather(slab)
+    if rank == 0:
+        out.put(af.numpy().copy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_group_sharded_gather_world2_gloo():
+    """N > 1 path of bench.py --config 3/4 on CPU: two processes (gloo), group-aligned shards of the Monte-Carlo workload,
+    one rooted gather of the flat slab (per-instance part + per-group part); the root reassembles the unsharded job."""
+    import torch.multiprocessing as mp
+    from tum_control_amd.workloads import config_groups
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31500 + (os.getpid() % 2000)
+    ps = [ctx.Process(target=_gloo_group_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in ps:
+        p.start()
+    af = q.get(timeout=180)
+    for p in ps:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    G, gsz, N = 6, 16, 6
+    x0, _, _ = config_groups(4, 0, G, G, N=N)
+    nper = (G // 2) * gsz
+    per = np.vstack([af[r, 0, :nper * 5].reshape(nper, 5) for r in range(2)])
+    grp = np.vstack([af[r, 0, nper * 5:].reshape(G // 2, 16) for r in range(2)])
+    assert np.array_equal(per[:, 0], np.arange(G * gsz)) and np.array_equal(per[:, 1:], x0[:, 3:7])
+    assert np.array_equal(grp[:, 0], np.arange(G))
+    np.testing.assert_allclose(grp[:, 1:9], x0.reshape(G, gsz, 8).mean(axis=1), atol=1e-13)
+    # rank boundaries fall on group boundaries
+    assert nper % gsz == 0
+
+
 def _gloo_worker(rank, world, port, out):
     import torch
     import torch.distributed as dist

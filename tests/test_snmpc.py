@@ -110,19 +110,65 @@ def test_oracle_h_vabs_gradient():
             assert abs(fd - g[i]) < 1e-6 * max(1.0, abs(fd))
 
 
-def test_wrapper_rejects_inconsistent_parameters():
-    """host logic only: the checks of set(stage, 'p', ...) need no GPU, they run before any device call"""
+def test_wrapper_rejects_wrong_parameter_dimension():
+    """host logic only: the dimension check of set(stage, 'p', ...) runs before any device call (acados' message); the
+    meaning of the parameter vector is handled by the C-ABI (test_gpu_per_stage_parameters)"""
     from tum_control_amd.solver import CoupledSnmpcSolver
     s = CoupledSnmpcSolver.__new__(CoupledSnmpcSolver)
     s.Apce = np.arange(6.0).reshape(2, 3); s.L, s.ns, s.uph = 2, 3, 4
     good = np.concatenate((s.Apce.flatten(), [0.8], [0.0]))
-    s.set(2, "p", good)
-    with pytest.raises(Exception, match="stop_flag"):
-        s.set(5, "p", good)
-    with pytest.raises(Exception, match="A_pce"):
-        s.set(2, "p", good + 1e-3 * np.r_[np.ones(6), 0, 0])
     with pytest.raises(Exception, match="mismatching dimension"):
         s.set(2, "p", good[:-1])
+
+
+def test_reintialize_solver_keeps_the_controller_configuration(monkeypatch):
+    """SNMPC_class.py:274-281 rebuilds the solver with the SAME Tp / N / Q / R / penalties / PCE set-up (main.py:59-61 calls
+    it after every failed solve). CPU test with a recording stand-in for the device solver."""
+    from tum_control_amd import snmpc
+    built = []
+
+    class FakeSolver:
+        def __init__(self, **kw):
+            self.kw = kw; self.calls = []; built.append(self)
+
+        def install_reference_ocp(self, **kw):
+            self.ocp = kw
+
+        def constraints_set(self, *a):
+            self.calls.append(("constraints_set", a[0], a[1], np.array(a[2])))
+
+        def set(self, stage, field, v):
+            self.calls.append(("set", stage, field, np.array(v)))
+
+        def cold_start(self):
+            self.calls.append(("cold_start",))
+
+    monkeypatch.setattr(snmpc, "CoupledSnmpcSolver", FakeSolver)
+    cfg = snmpc._config.default_config()
+    cfg["mpc"].update(q_lon=7.5, r_jerk=11.0, L1_pen=55.0, n_samples=12, uncertainty_propagation_horizon=9, gamma=0.9,
+                      stds=[0, 0, 0, 0.5, 0.2, 0.02, 0, 0])
+    monkeypatch.setattr(snmpc._config, "default_config", lambda: cfg)
+    x0 = np.array([1.0, 2.0, 0.3, 20.0, 0.0, 0.0, 0.0, 0.0])
+    c = snmpc.Stochastic_Nonlinear_Model_Predictive_Controller(sim_main_params=dict(Tp=2.0, Ts=0.02, Ts_MPC=0.1), X0_MPC=x0)
+    assert c.N == 20 and len(built) == 1
+    monkeypatch.setattr(snmpc._config, "default_config", lambda: (_ for _ in ()).throw(AssertionError("defaults must not be re-read")))
+    x1 = x0 + 0.5
+    c.reintialize_solver(x1)
+    assert len(built) == 2 and c.acados_solver is built[1]
+    a, b = built
+    assert b.kw["N"] == 20 and b.kw["uph"] == 9 and b.kw["gamma"] == 0.9 and b.kw["cfg"] is cfg
+    assert b.kw["Apce"].shape == (10, 12) and np.array_equal(b.kw["Apce"], a.kw["Apce"])
+    assert abs(b.kw["dt"] - 0.1) < 1e-15
+    for k in ("Q", "R", "Qe"):
+        assert np.array_equal(b.ocp[k], a.ocp[k])
+    assert b.ocp["Q"][0, 0] == 7.5 and b.ocp["R"][0, 0] == 11.0 and b.ocp["L1"] == 55.0
+    # cold start at the sample states of the NEW x0, every stage parameterised like at construction
+    lbx = [cl for cl in b.calls if cl[0] == "constraints_set" and cl[2] == "lbx"]
+    np.testing.assert_allclose(lbx[0][3].reshape(13, 8)[0], x1)
+    np.testing.assert_allclose(lbx[0][3].reshape(13, 8)[1:, 3] - x1[3], 0.5 * c.w_samples[0], atol=1e-14)
+    ps = [cl for cl in b.calls if cl[0] == "set" and cl[2] == "p"]
+    assert len(ps) == 21 and [int(q[3][-1]) for q in ps] == [0] * 9 + [1] * 12
+    assert ("cold_start",) in b.calls
 
 
 def test_problem_data_matches_exported_ocp(golden_dir):

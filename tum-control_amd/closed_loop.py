@@ -98,6 +98,7 @@ class ClosedLoopBatch:
         self.x_mpc = np.tile(x0, (batch, 1))                     # X0_MPC
         self.x_sim = self.x_mpc[:, :7].copy()                    # X0_sim
         self.pose = self.x_mpc[:, :2].copy()
+        self.controller = controller
         if controller == "nominal":       # main.py:33-36 picks the controller class by MPC_params['MPC_type']
             self.solver = BatchedOcpSolver(N=N, dt=Tp / N, nsub=3, batch=batch, device=device, cfg=self.cfg)
         elif controller == "snmpc":       # the coupled SNMPC OCP; x0_samples = compute_x0dist(x0) before every solve
@@ -107,8 +108,9 @@ class ClosedLoopBatch:
             nvar = int(np.count_nonzero(stds))
             w = _snm.hammersley_normal(m["n_samples"], nvar)
             A = _snm.pce_matrix(w, _snm.alpha_generation(nvar, m["expansion_degree"]))
+            self._x0_offsets = _snm.x0_offsets(w, stds)
             self.solver = CoupledSnmpcSolver(N=N, dt=Tp / N, batch=batch, Apce=A, uph=min(int(m["uncertainty_propagation_horizon"]), N),
-                                             gamma=m["gamma"], device=device, cfg=self.cfg, x0_offsets=_snm.x0_offsets(w, stds))
+                                             gamma=m["gamma"], device=device, cfg=self.cfg, x0_offsets=self._x0_offsets)
         elif controller == "r2":          # nominal OCP + covariance back-off after every solve (K7 attached to the solve)
             from .r2nmpc import r2_setup
             m, veh = self.cfg["mpc"], self.cfg["veh"]
@@ -155,7 +157,10 @@ class ClosedLoopBatch:
         stats = np.stack([np.atleast_1d(s.get_cost()), np.full(B, s.get_stats("time_tot")), np.ones(B),
                           s.get_stats("qp_iter").astype(float), s.get_stats("status").astype(float)], axis=1)
         # sim_step, simMode 0: the plant takes the predicted acceleration of stage 1 and the steering rate
-        a_in, sr_in = x1[:, 7], u0[:, 1]
+        a_in, sr_in = x1[:, 7].copy(), u0[:, 1].copy()
+        failed = np.nonzero(stats[:, 4] != 0)[0]
+        if len(failed):
+            self._reinitialise(failed, X, U)
         x_sim_next = plant_step(self.x_sim, a_in, sr_in, self.cfg, self.Ts)
         x_next = np.concatenate([x_sim_next, a_in[:, None]], axis=1)
         self.pose = x_sim_next[:, :2].copy()
@@ -166,6 +171,31 @@ class ClosedLoopBatch:
         lg["simU"].append(u0.copy()); lg["simREF"].append(ref0); lg["simSolverDebug"].append(stats)
         lg["CiLX"].append(x_sim_next.copy()); lg["MPC_SimX"].append(x1.copy())
         return status
+
+    def _reinitialise(self, failed, X, U):
+        """main.py:59-61: `if MPC_stats[-1] != 0: MPC.reintialize_solver(x_next)` -- the failed instances get a fresh solver,
+        cold-started at the state the failed solve started from (NMPC_class.py:256-267; sample copies included for the SNMPC
+        controller, SNMPC_class.py:274-281; nominal bounds again for R2NMPC). The control of this step is still the failed
+        solver's u0 and the last good prediction. Host mirror of what plant_advance_kernel does on the device."""
+        s, N, B = self.solver, self.N, self.B
+        X = X.copy(); U = U.copy()
+        X[failed] = self.x_mpc[failed][:, None, :]
+        U[failed] = 0.0
+        s.set_iterate(X if B > 1 else X[0], U if B > 1 else U[0])
+        if self.controller == "snmpc":
+            ns = s.ns
+            x0s = self.x_mpc[failed][:, None, :] + np.concatenate([np.zeros((1, 8)), self._x0_offsets])[None]    # (F, ns+1, 8)
+            for k in range(N + 1):
+                xk = np.asarray(s.get(k, "x")).reshape(B, 8 * (ns + 1))
+                xk[failed] = x0s.reshape(len(failed), -1)
+                s.set(k, "x", xk if B > 1 else xk[0])
+        if self.controller == "r2":
+            veh = self.cfg["veh"]
+            for k in range(1, N):
+                for f, val in (("lbx", veh["delta_f_min"]), ("ubx", veh["delta_f_max"]), ("uh", 1.0)):
+                    v = np.atleast_1d(s.constraints_get(k, f)).copy()
+                    v[failed] = val
+                    s.constraints_set(k, f, v if B > 1 else v[:1])
 
     def run(self, n_steps):
         if self.dev is not None:

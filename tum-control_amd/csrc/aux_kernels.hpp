@@ -16,18 +16,18 @@ __global__ void sigma_fanout_kernel(double *x0, const double *pose, const double
 
 // K6b  PCE moments over scenario groups: c = A v (A: L x S least-squares PCE matrix), E = c_0,
 //      Var = sum_{k>=1} c_k^2  (Stochastic_NMPC/SNMPC_acados_settings.py:116-133).
-//      V: [P*S1][m] per-instance quantities (row p*S1 is the nominal instance and is skipped);
-//      one thread per (group, component); A is small and read through the scalar/L1 path.
-__global__ void pce_moments_kernel(const double *V, const double *A, int P, int S1, int m, int L, double *mean, double *var)
+//      V: per-instance records `rec` doubles apart, the m quantities at their start (read straight from the iterate; row
+//      p*S1 is the nominal instance and is skipped); one thread per (group, component); A is small (L1 / scalar path).
+__global__ void pce_moments_kernel(const double *V, size_t rec, const double *A, int P, int S1, int m, int L, double *mean, double *var)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;          // over P*m
     if (i >= P * m) return;
     const int p = i / m, c = i - p * m, S = S1 - 1;
-    const double *v = V + ((size_t)p * S1 + 1) * m + c;
+    const double *v = V + ((size_t)p * S1 + 1) * rec + c;
     double e = 0.0, va = 0.0;
     for (int k = 0; k < L; k++) {
         double ck = 0.0;
-        for (int s = 0; s < S; s++) ck += A[k * S + s] * v[(size_t)s * m];
+        for (int s = 0; s < S; s++) ck += A[k * S + s] * v[(size_t)s * rec];
         if (k == 0) e = ck; else va += ck * ck;
     }
     mean[i] = e; var[i] = va;

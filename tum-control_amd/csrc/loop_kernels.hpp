@@ -124,7 +124,6 @@ __global__ void __launch_bounds__(64) planner_kernel(const double *track, int n,
     if (lane == 0 && closest) closest[b] = i0;
     // control-step counter of the closed loop (read by plant_advance_kernel of the same step): kept on the device so
     // that a captured hipGraph of a step can be replayed without re-baking kernel arguments
-    if (b == 0 && lane == 0 && step_counter) atomicAdd(step_counter, 1);
 }
 
 // xdot of the 7-state plant [posx,posy,yaw,vlong,vlat,yawrate,delta_f] with inputs (a, steering rate)
@@ -174,11 +173,14 @@ __device__ __forceinline__ void plant_xdot(const PlantModel &p, const double x[7
 
 struct SimArgs {
     int N, batch, n_elem, log_cap;
-    const int *step_counter;                          // control steps started so far (this one included), device memory
+    int *step_counter;                                // [0] control steps completed, [1] ticket of the blocks of this launch (device)
     double Ts;
     int win[8];
     PlantModel pm;
-    const double *X, *U, *cost; const int *status, *qp_iter;   // the solver's outputs
+    double *X, *U; const double *cost; const int *status, *qp_iter;   // the solver's outputs (the iterate is rewritten on failure)
+    // recovery from a failed solve (main.py:59-61 -> reintialize_solver): sample copies of an SNMPC capsule, bounds of an R2 capsule
+    double *XS; const double *xs0; int ns;
+    double *bnd; int r2; double r2_dmin, r2_dmax, r2_uh;
     double *x_sim, *x0, *pose, *hist;                 // [b][7], [b][8] (capsule x0), [b][2], [b][8][4]
     const double *ref0;                               // [b][4] first reference point of this step (planner output)
     double *lCiLX, *lSimX, *lU, *lREF, *lDBG;         // logs (nullable): (cap+1,B,7) (cap+1,B,8) (cap,B,2) (cap,B,4) (cap,B,5)
@@ -193,10 +195,34 @@ __global__ void __launch_bounds__(64) plant_advance_kernel(const SimArgs sa)
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= sa.batch) return;
     const int N = sa.N, B = sa.batch;
-    const int step = *sa.step_counter - 1;            // control steps done before this one
-    const double *x1 = sa.X + ((size_t)b * (N + 1) + 1) * NX;
-    const double *u0 = sa.U + (size_t)b * N * NU;
+    const int step = sa.step_counter[0];              // control steps done before this one
+    double x1[8], u0[2];
+#pragma unroll
+    for (int i = 0; i < 8; i++) x1[i] = sa.X[((size_t)b * (N + 1) + 1) * NX + i];
+    u0[0] = sa.U[(size_t)b * N * NU]; u0[1] = sa.U[(size_t)b * N * NU + 1];
     const double a_in = x1[7], sr_in = u0[1];
+    const int st_b = sa.status[b];
+    if (st_b != 0) {
+        // main.py:59-61: a failed solve is followed by MPC.reintialize_solver(x_next) -- a FRESH solver, cold-started at the
+        // state the failed solve started from (x_k = x0 for all k, u = 0; NMPC_class.py:256-267), with the nominal bounds
+        // (R2NMPC: the tightening of the previous solves is gone) and the sample copies at their initial conditions (SNMPC).
+        // The control applied this step is still the failed solver's u0 / the last good prediction (read above).
+        const double *xo = sa.x0 + (size_t)b * NX;
+        double xv[8];
+#pragma unroll
+        for (int i = 0; i < 8; i++) xv[i] = xo[i];
+        for (int k = 0; k <= N; k++)
+#pragma unroll
+            for (int i = 0; i < 8; i++) sa.X[((size_t)b * (N + 1) + k) * NX + i] = xv[i];
+        for (int i = 0; i < N * NU; i++) sa.U[(size_t)b * N * NU + i] = 0.0;
+        if (sa.ns > 0)
+            for (int k = 0; k <= N; k++)
+                for (int i = 0; i < sa.ns * NX; i++) sa.XS[((size_t)b * (N + 1) + k) * sa.ns * NX + i] = sa.xs0[(size_t)b * sa.ns * NX + i];
+        if (sa.r2) {
+            double *bb = sa.bnd + (size_t)b * 6 * (N + 1);
+            for (int k = 1; k < N; k++) { bb[2 * (N + 1) + k] = sa.r2_dmin; bb[3 * (N + 1) + k] = sa.r2_dmax; bb[5 * (N + 1) + k] = sa.r2_uh; }
+        }
+    }
     double x[7];
 #pragma unroll
     for (int i = 0; i < 7; i++) x[i] = sa.x_sim[(size_t)b * 7 + i];
@@ -245,7 +271,12 @@ __global__ void __launch_bounds__(64) plant_advance_kernel(const SimArgs sa)
         sa.lU[(s * B + b) * 2] = u0[0]; sa.lU[(s * B + b) * 2 + 1] = u0[1];
         for (int i = 0; i < 4; i++) sa.lREF[(s * B + b) * 4 + i] = sa.ref0[(size_t)b * 4 + i];
         double *d = sa.lDBG + (s * B + b) * 5;
-        d[0] = sa.cost[b]; d[1] = 0.0; d[2] = 1.0; d[3] = (double)sa.qp_iter[b]; d[4] = (double)sa.status[b];
+        d[0] = sa.cost[b]; d[1] = 0.0; d[2] = 1.0; d[3] = (double)sa.qp_iter[b]; d[4] = (double)st_b;
+    }
+    // the last block to get here closes the control step (every block has read the counter by then)
+    if (threadIdx.x == 0) {
+        __threadfence();
+        if (atomicAdd(&sa.step_counter[1], 1) == (int)gridDim.x - 1) { sa.step_counter[1] = 0; atomicAdd(&sa.step_counter[0], 1); }
     }
 }
 

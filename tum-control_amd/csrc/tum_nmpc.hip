@@ -41,6 +41,10 @@ struct tum_ocp {
     bool have_offs, fanout;        // sample initial conditions derived from the nominal x0 at every solve
     // R2NMPC tightening after every solve (tum_ocp_r2_attach)
     bool r2; int r2_uph; double r2_dmin, r2_dmax, r2_uh; double *dr2S, *dr2B;
+    // per-stage parameter vector of the SNMPC OCP as the caller last set it (tum_ocp_set "p")
+    std::vector<double> hApce, p_gamma, p_stop; bool p_dirty; int uph_cap; double gamma;
+    // PCE matrix of the scenario fan-out (tum_pce_attach), snapshot of the bounds (tum_ocp_bounds_snapshot)
+    double *dpceA; int pce_L, pce_S; double *dbnd_snap;
 };
 
 static const int DBG_STRIDE = 20480;
@@ -49,6 +53,14 @@ static const int DBG_INST = 4;
 extern "C" const char *tum_ocp_last_error(void) { return g_err.c_str(); }
 extern "C" int tum_ocp_batch(const tum_ocp *c) { return c->batch; }
 extern "C" int tum_ocp_horizon(const tum_ocp *c) { return c->N; }
+
+// Every entry point that touches the device runs under the capsule's device and leaves the caller's (torch's) current
+// device as it found it: two capsules on different GPUs may live in one process.
+struct DevGuard {
+    int prev = -1, dev; bool changed = false;
+    explicit DevGuard(int d) : dev(d) { if (hipGetDevice(&prev) == hipSuccess && prev != d) changed = hipSetDevice(d) == hipSuccess; }
+    ~DevGuard() { if (changed) (void)hipSetDevice(prev); }
+};
 
 // temporary device buffer that cannot leak on an early error return
 struct DevTmp {
@@ -70,12 +82,14 @@ extern "C" tum_ocp *tum_ocp_create(const tum_ocp_desc *desc)
     if (desc->n_ggv < 2 || desc->n_ggv > 16) { fail("n_ggv out of range (2..16)"); return nullptr; }
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) { fail("no HIP device: libtumnmpc has no CPU fallback"); return nullptr; }
-    if (hipSetDevice(desc->device) != hipSuccess) { fail("hipSetDevice failed"); return nullptr; }
+    if (desc->device < 0 || desc->device >= ndev) { fail("device ordinal out of range"); return nullptr; }
+    DevGuard guard(desc->device);
     tum_ocp *c = new tum_ocp();
     c->d = *desc; c->N = desc->N; c->batch = desc->batch; c->last_ms = 0; c->solved = false;
     c->sn = false; c->dXS = c->dxs0 = c->dApce = c->dws2 = c->dpro = c->ddv = c->doffs = nullptr;
     c->have_offs = c->fanout = false;
     c->r2 = false; c->dr2S = c->dr2B = nullptr;
+    c->p_dirty = false; c->uph_cap = 0; c->gamma = 0.0; c->dpceA = nullptr; c->pce_L = c->pce_S = 0; c->dbnd_snap = nullptr;
     const int N = c->N; const size_t B = c->batch;
     bool ok = true;
     ok &= hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) == hipSuccess; c->own_stream = true;
@@ -148,12 +162,13 @@ extern "C" tum_ocp *tum_ocp_create(const tum_ocp_desc *desc)
 extern "C" void tum_ocp_free(tum_ocp *c)
 {
     if (!c) return;
+    DevGuard guard(c->d.device);
     (void)hipFree(c->dX); (void)hipFree(c->dU); (void)hipFree(c->dx0); (void)hipFree(c->dyref); (void)hipFree(c->dW); (void)hipFree(c->dpen); (void)hipFree(c->dbnd);
     (void)hipFree(c->dcost); (void)hipFree(c->dres); (void)hipFree(c->dslack); (void)hipFree(c->dstatus); (void)hipFree(c->dqpiter); (void)hipFree(c->dqpstatus); (void)hipFree(c->dorder);
     if (c->dqpin) (void)hipFree(c->dqpin);
     (void)hipFree(c->ddbg); (void)hipFree(c->dprof); (void)hipFree(c->dws);
     (void)hipFree(c->dXS); (void)hipFree(c->dxs0); (void)hipFree(c->dApce); (void)hipFree(c->dws2); (void)hipFree(c->dpro); (void)hipFree(c->ddv); (void)hipFree(c->doffs);
-    (void)hipFree(c->dr2S); (void)hipFree(c->dr2B);
+    (void)hipFree(c->dr2S); (void)hipFree(c->dr2B); (void)hipFree(c->dpceA); (void)hipFree(c->dbnd_snap);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
@@ -173,12 +188,12 @@ extern "C" int tum_ocp_snmpc_attach(tum_ocp *c, int ns, int L, const double *Apc
     if (!(gamma > 0.0 && gamma <= 1.0)) return fail("snmpc_attach: gamma out of range (0,1]");
     if (c->d.nsub != 1) return fail("snmpc_attach: the SNMPC model is DISCRETE with one RK4 step per stage: create the capsule with nsub = 1");
     if (c->d.store_qp_in) return fail("snmpc_attach: store_qp_in is not available for the stacked state");
+    DevGuard guard(c->d.device);
     {
         const size_t lds = sizeof(double) * sn_prologue_lds_doubles(uph, ns);
         if (lds > 128 * 1024) return fail("snmpc_attach: n_samples x uph too large for the prologue kernel's LDS");
         HIPCHK(hipFuncSetAttribute((const void *)snmpc_prologue_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
     }
-    HIPCHK(hipSetDevice(c->d.device));
     const size_t B = c->batch; const int N = c->N;
     bool ok = true;
     ok &= dalloc(&c->dXS, B * (N + 1) * ns * NX) == hipSuccess;
@@ -200,6 +215,68 @@ extern "C" int tum_ocp_snmpc_attach(tum_ocp *c, int ns, int L, const double *Apc
     sa.dbg = c->ddbg + 20000;                            // tail of instance 0's dump area (tum_ocp_debug_dump), unused by the fused kernel
     c->ka.uph = uph; c->ka.pro = c->dpro; c->ka.dv = c->ddv;
     c->sn = true;
+    c->hApce.assign(Apce, Apce + (size_t)L * ns);
+    c->gamma = gamma; c->uph_cap = uph > 0 ? uph : 1;
+    c->p_gamma.assign(N + 1, gamma); c->p_stop.assign(N + 1, 0.0);
+    for (int k = uph; k <= N; k++) c->p_stop[k] = 1.0;
+    c->p_dirty = false;
+    return 0;
+}
+
+// acados_solver.set(stage, "p", [A_pce.flatten(), risk_parameter, stop_flag])   SNMPC_class.py:124,185,193.
+// A_pce and the risk parameter are shared by all stages of the stacked model (the reference sends the same values to every
+// stage); the stop flags must form the pattern the model is built for -- 0 on the stages < uph, 1 from stage uph on
+// (SNMPC_class.py:103-104) -- and define the uncertainty propagation horizon. Applied at the next solve.
+static int sn_set_p(tum_ocp *c, int stage, const double *v, int len, int nb, int stride)
+{
+    if (!c->sn) return fail("set p: not an SNMPC capsule (tum_ocp_snmpc_attach)");
+    const int L = c->sa.L, ns = c->sa.ns, N = c->N;
+    if (stage < 0 || stage > N) return fail("set p: stage out of range");
+    if (len != L * ns + 2) return fail("set p: mismatching dimension for field \"p\" with dimension " + std::to_string(L * ns + 2) +
+                                       " (you have " + std::to_string(len) + ")");
+    if (stride != 0)
+        for (int i = 1; i < nb; i++)
+            if (memcmp(v, v + (size_t)i * stride, sizeof(double) * len) != 0) return fail("set p: the parameter vector is shared by all instances of the batch");
+    const double g = v[L * ns], sf = v[L * ns + 1];
+    if (!(g > 0.0 && g <= 1.0)) return fail("set p: risk parameter out of range (0,1]");
+    if (sf != 0.0 && sf != 1.0) return fail("set p: stop_flag must be 0 or 1");
+    if (memcmp(v, c->hApce.data(), sizeof(double) * L * ns) != 0) {
+        DevGuard guard(c->d.device);
+        HIPCHK(hipStreamSynchronize(c->stream));
+        HIPCHK(hipMemcpy(c->dApce, v, sizeof(double) * L * ns, hipMemcpyHostToDevice));
+        c->hApce.assign(v, v + (size_t)L * ns);
+    }
+    c->p_gamma[stage] = g; c->p_stop[stage] = sf;
+    c->p_dirty = true;
+    return 0;
+}
+// resolve the per-stage parameters into (uph, kappa) before a solve
+static int sn_apply_p(tum_ocp *c)
+{
+    if (!c->p_dirty) return 0;
+    const int N = c->N, ns = c->sa.ns;
+    for (int k = 1; k <= N; k++)
+        if (c->p_gamma[k] != c->p_gamma[0]) return fail("solve: the risk parameter p[-2] differs between stages (stage " + std::to_string(k) + ")");
+    int uph = N + 1;
+    for (int k = 0; k <= N; k++) if (c->p_stop[k] == 1.0) { uph = k; break; }
+    for (int k = uph; k <= N; k++)
+        if (c->p_stop[k] != 1.0) return fail("solve: stop_flag pattern not supported: it must be 0 on the stages < uph and 1 from stage uph on (stage " + std::to_string(k) + " is 0 after a 1)");
+    if (uph > N) uph = N;                      // no stop flag at all: the samples are propagated over the whole horizon
+    if (uph > SN_UPHMAX) return fail("solve: uncertainty propagation horizon from the stop flags exceeds " + std::to_string(SN_UPHMAX));
+    if (sizeof(double) * sn_prologue_lds_doubles(uph, ns) > 128 * 1024) return fail("solve: n_samples x uph too large for the prologue kernel's LDS");
+    if (uph > c->uph_cap) {
+        DevGuard guard(c->d.device);
+        HIPCHK(hipStreamSynchronize(c->stream));
+        (void)hipFree(c->dws2); (void)hipFree(c->dpro); c->dws2 = c->dpro = nullptr;
+        const size_t B = c->batch;
+        if (dalloc(&c->dws2, B * (size_t)uph * ns * ABS) != hipSuccess || dalloc(&c->dpro, B * (size_t)uph * SN_PRO_STAGE) != hipSuccess)
+            return fail("solve: device allocation failed for the longer uncertainty propagation horizon");
+        c->uph_cap = uph; c->sa.ws2 = c->dws2; c->sa.pro = c->dpro; c->ka.pro = c->dpro;
+    }
+    c->gamma = c->p_gamma[0];
+    c->sa.kappa = std::sqrt((1.0 - c->gamma) / c->gamma);
+    c->sa.uph = uph; c->ka.uph = uph;
+    c->p_dirty = false;
     return 0;
 }
 extern "C" int tum_ocp_snmpc_samples(const tum_ocp *c) { return (c && c->sn) ? c->sa.ns : 0; }
@@ -211,7 +288,7 @@ extern "C" int tum_ocp_snmpc_set_offsets(tum_ocp *c, const double *offs)
 {
     if (!c || !offs) return fail("null argument");
     if (!c->sn) return fail("snmpc_set_offsets: not an SNMPC capsule (tum_ocp_snmpc_attach)");
-    HIPCHK(hipSetDevice(c->d.device));
+    DevGuard guard(c->d.device);
     HIPCHK(hipMemcpy(c->doffs, offs, sizeof(double) * c->sa.ns * NX, hipMemcpyHostToDevice));
     c->have_offs = true;
     return 0;
@@ -235,6 +312,7 @@ static int chk_range(tum_ocp *c, int b0, int nb)
 static int put(tum_ocp *c, double *dbase, size_t rec, size_t off, const double *v, int len, int b0, int nb, int stride)
 {
     if (stride != 0 && stride < len) return fail("stride < len");
+    DevGuard guard(c->d.device);
     const double *src = v;
     size_t spitch = (size_t)stride * sizeof(double);
     if (stride == 0) {
@@ -250,6 +328,7 @@ static int put(tum_ocp *c, double *dbase, size_t rec, size_t off, const double *
 static int fetch(tum_ocp *c, const double *dbase, size_t rec, size_t off, double *v, int len, int b0, int nb, int stride)
 {
     if (stride < len) return fail("stride < len");
+    DevGuard guard(c->d.device);
     HIPCHK(hipMemcpy2DAsync(v, (size_t)stride * sizeof(double), dbase + (size_t)b0 * rec + off, rec * sizeof(double),
                             (size_t)len * sizeof(double), nb, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
@@ -286,6 +365,10 @@ extern "C" int tum_ocp_set(tum_ocp *c, int stage, const char *field, const doubl
         const int want = (stage < N) ? TUM_NY : TUM_NYE;
         if (len != want) return fail("set yref: mismatching dimension for this stage");
         return put(c, c->dyref, (N + 1) * 6, (size_t)stage * 6, v, len, b0, nb, stride);
+    }
+    if (f == "p") {
+        if (b0 != 0 || nb != c->batch) return fail("set p: the parameter vector is shared by all instances (b0 = 0, nb = batch)");
+        return sn_set_p(c, stage, v, len, nb, stride);
     }
     return fail("set: unknown field '" + f + "'");
 }
@@ -411,13 +494,14 @@ extern "C" int tum_ocp_cost_set(tum_ocp *c, int stage, const char *field, const 
 
 static int launch(tum_ocp *c, bool events = true)
 {
-    HIPCHK(hipSetDevice(c->d.device));
+    DevGuard guard(c->d.device);
     if (events) HIPCHK(hipEventRecord(c->ev0, c->stream));
     // longest-first schedule from the previous solve's iteration counts (only matters when the batch is more than one
     // round of resident wavefronts)
     c->ka.order = (c->lpt && c->order_valid && c->batch > 1024) ? c->dorder : nullptr;
     // the instrumented instantiation carries the phase timers (flag 4) and the debug dump (flag 2)
     if (c->sn) {
+        if (sn_apply_p(c)) return 1;
         if (c->fanout && sn_fanout(c)) return 1;
         hipLaunchKernelGGL(snmpc_prologue_kernel, dim3(c->batch), dim3(64), sizeof(double) * sn_prologue_lds_doubles(c->sa.uph, c->sa.ns),
                            c->stream, c->sa);
@@ -458,6 +542,7 @@ extern "C" int tum_ocp_solve_async(tum_ocp *c)
 extern "C" int tum_ocp_synchronize(tum_ocp *c)
 {
     if (!c) return fail("null capsule");
+    DevGuard guard(c->d.device);
     HIPCHK(hipStreamSynchronize(c->stream));
     return 0;
 }
@@ -465,6 +550,7 @@ extern "C" int tum_ocp_synchronize(tum_ocp *c)
 extern "C" int tum_ocp_solve(tum_ocp *c)
 {
     if (!c) { fail("null capsule"); return -1; }
+    DevGuard guard(c->d.device);
     if (launch(c)) return -1;
     if (hipStreamSynchronize(c->stream) != hipSuccess) { fail("kernel execution failed"); return -1; }
     std::vector<int> st(c->batch);
@@ -477,6 +563,7 @@ extern "C" int tum_ocp_solve(tum_ocp *c)
 extern "C" double tum_ocp_last_kernel_ms(tum_ocp *c)
 {
     if (!c || !c->solved) return 0.0;
+    DevGuard guard(c->d.device);
     if (hipEventSynchronize(c->ev1) != hipSuccess) return 0.0;
     float ms = 0;
     if (hipEventElapsedTime(&ms, c->ev0, c->ev1) != hipSuccess) return 0.0;
@@ -487,6 +574,7 @@ extern "C" double tum_ocp_last_kernel_ms(tum_ocp *c)
 extern "C" int tum_ocp_get_cost(tum_ocp *c, double *out, int b0, int nb)
 {
     if (chk_range(c, b0, nb)) return 1;
+    DevGuard guard(c->d.device);
     HIPCHK(hipMemcpy(out, c->dcost + b0, sizeof(double) * nb, hipMemcpyDeviceToHost));
     return 0;
 }
@@ -497,6 +585,7 @@ extern "C" int tum_ocp_get_stats(tum_ocp *c, const char *field, void *out, int b
     const std::string f(field);
     if (f == "time_tot") { *(double *)out = tum_ocp_last_kernel_ms(c) * 1e-3; return 0; }
     if (chk_range(c, b0, nb)) return 1;
+    DevGuard guard(c->d.device);
     if (f == "sqp_iter") { int *o = (int *)out; for (int i = 0; i < nb; i++) o[i] = 1; return 0; }
     if (f == "qp_iter") { HIPCHK(hipMemcpy(out, c->dqpiter + b0, sizeof(int) * nb, hipMemcpyDeviceToHost)); return 0; }
     if (f == "status") { HIPCHK(hipMemcpy(out, c->dstatus + b0, sizeof(int) * nb, hipMemcpyDeviceToHost)); return 0; }
@@ -508,6 +597,7 @@ extern "C" int tum_ocp_get_stats(tum_ocp *c, const char *field, void *out, int b
 extern "C" int tum_ocp_reset(tum_ocp *c)
 {
     if (!c) return fail("null capsule");
+    DevGuard guard(c->d.device);
     HIPCHK(hipMemsetAsync(c->dX, 0, sizeof(double) * (size_t)c->batch * (c->N + 1) * NX, c->stream));
     HIPCHK(hipMemsetAsync(c->dU, 0, sizeof(double) * (size_t)c->batch * c->N * NU, c->stream));
     if (c->sn) HIPCHK(hipMemsetAsync(c->dXS, 0, sizeof(double) * (size_t)c->batch * (c->N + 1) * c->sa.ns * NX, c->stream));
@@ -518,6 +608,7 @@ extern "C" int tum_ocp_reset(tum_ocp *c)
 extern "C" int tum_ocp_cold_start(tum_ocp *c)
 {
     if (!c) return fail("null capsule");
+    DevGuard guard(c->d.device);
     hipLaunchKernelGGL(cold_start_kernel, dim3(c->batch), dim3(64), 0, c->stream, c->dX, c->dU, c->dx0, c->N, c->batch);
     if (c->sn && c->fanout && sn_fanout(c)) return 1;
     if (c->sn) hipLaunchKernelGGL(snmpc_cold_start_kernel, dim3(c->batch), dim3(256), 0, c->stream, c->dXS, c->dxs0, c->N, c->sa.ns, c->batch);
@@ -560,6 +651,7 @@ extern "C" int tum_ocp_get_device(tum_ocp *c, const char *field, void *dst, int 
     if (!field || !dst) return fail("null argument");
     const int N = c->N;
     const std::string f(field);
+    DevGuard guard(c->d.device);
     hipStream_t s = c->stream;
     if (f == "summary") {
         hipLaunchKernelGGL(pack_summary_kernel, dim3((nb + 255) / 256), dim3(256), 0, s, c->dU, c->dcost, c->dstatus, c->dqpiter, N, b0, nb, (double *)dst);
@@ -576,10 +668,30 @@ extern "C" int tum_ocp_get_device(tum_ocp *c, const char *field, void *dst, int 
     return fail("get_device: unknown field '" + f + "'");
 }
 
+// device-to-device upload of per-instance inputs from caller-owned HBM (asynchronous, on the capsule's stream)
+extern "C" int tum_ocp_put_device(tum_ocp *c, const char *field, const void *src, int b0, int nb)
+{
+    if (chk_range(c, b0, nb)) return 1;
+    if (!field || !src) return fail("null argument");
+    const int N = c->N;
+    const std::string f(field);
+    DevGuard guard(c->d.device);
+    hipStream_t s = c->stream;
+    if (f == "x0") {
+        if (c->sn) { if (!c->have_offs) return fail("put_device x0: an SNMPC capsule needs its sample offsets (tum_ocp_snmpc_set_offsets)"); c->fanout = true; }
+        HIPCHK(hipMemcpyAsync(c->dx0 + (size_t)b0 * NX, src, 8 * (size_t)nb * NX, hipMemcpyDeviceToDevice, s)); return 0;
+    }
+    if (f == "yref") { HIPCHK(hipMemcpyAsync(c->dyref + (size_t)b0 * (N + 1) * 6, src, 8 * (size_t)nb * (N + 1) * 6, hipMemcpyDeviceToDevice, s)); return 0; }
+    if (f == "X") { HIPCHK(hipMemcpyAsync(c->dX + (size_t)b0 * (N + 1) * NX, src, 8 * (size_t)nb * (N + 1) * NX, hipMemcpyDeviceToDevice, s)); return 0; }
+    if (f == "U") { HIPCHK(hipMemcpyAsync(c->dU + (size_t)b0 * N * NU, src, 8 * (size_t)nb * N * NU, hipMemcpyDeviceToDevice, s)); return 0; }
+    return fail("put_device: unknown field '" + f + "'");
+}
+
 extern "C" int tum_ocp_debug_dump(tum_ocp *c, int b, double *out, int len)
 {
     if (!c) return fail("null capsule");
     if (b < 0 || b >= DBG_INST || b >= c->batch) return fail("debug_dump: instance out of range");
+    DevGuard guard(c->d.device);
     if (len > DBG_STRIDE) len = DBG_STRIDE;
     c->ka.flags |= 2;
     if (launch(c)) return 1;
@@ -593,6 +705,7 @@ extern "C" int tum_ocp_debug_dump(tum_ocp *c, int b, double *out, int len)
 extern "C" int tum_ocp_profile_phases(tum_ocp *c, long long *out)
 {
     if (!c || !out) return fail("null argument");
+    DevGuard guard(c->d.device);
     c->ka.flags |= 4;
     int rc = launch(c);
     c->ka.flags &= ~4;
@@ -608,6 +721,7 @@ extern "C" int tum_ocp_set_x0_fanout(tum_ocp *c, const double *pose, const doubl
     if (!c || !pose || (S > 0 && !offs)) return fail("null argument");
     const int S1 = S + 1;
     if (P < 1 || S < 0 || (long long)P * S1 != c->batch) return fail("set_x0_fanout: P*(S+1) must equal the batch size");
+    DevGuard guard(c->d.device);
     DevTmp tp, to;
     HIPCHK(tp.alloc(sizeof(double) * P * NX));
     HIPCHK(to.alloc(sizeof(double) * (S > 0 ? S : 1) * NX));
@@ -621,28 +735,80 @@ extern "C" int tum_ocp_set_x0_fanout(tum_ocp *c, const double *pose, const doubl
     return 0;
 }
 
-extern "C" int tum_pce_moments(tum_ocp *c, const char *field, int stage, const double *A, int L, int S, double *mean, double *var)
+// PCE matrix of the scenario fan-out kept on the device (L x S, row-major, host) for tum_pce_moments_device
+extern "C" int tum_pce_attach(tum_ocp *c, const double *A, int L, int S)
 {
-    if (!c || !field || !A || !mean || !var) return fail("null argument");
-    const int S1 = S + 1, N = c->N;
-    if (S < 1 || L < 1 || c->batch % S1 != 0) return fail("pce_moments: batch must be a multiple of S+1");
-    const int P = c->batch / S1;
-    const std::string f(field);
+    if (!c || !A) return fail("null argument");
+    if (S < 1 || L < 1 || c->batch % (S + 1) != 0) return fail("pce_attach: batch must be a multiple of S+1");
+    DevGuard guard(c->d.device);
+    HIPCHK(hipStreamSynchronize(c->stream));
+    (void)hipFree(c->dpceA); c->dpceA = nullptr;
+    if (dalloc(&c->dpceA, (size_t)L * S) != hipSuccess) return fail("pce_attach: device allocation failed");
+    HIPCHK(hipMemcpy(c->dpceA, A, sizeof(double) * L * S, hipMemcpyHostToDevice));
+    c->pce_L = L; c->pce_S = S;
+    return 0;
+}
+
+static int pce_launch(tum_ocp *c, const std::string &f, int stage, const double *dA, int L, int S, double *dmean, double *dvar)
+{
+    const int S1 = S + 1, N = c->N, P = c->batch / S1;
     int m; const double *src; size_t rec, off;
     if (f == "x") { if (stage < 0 || stage > N) return fail("pce_moments: stage"); m = NX; src = c->dX; rec = (size_t)(N + 1) * NX; off = (size_t)stage * NX; }
     else if (f == "u") { if (stage < 0 || stage >= N) return fail("pce_moments: stage"); m = NU; src = c->dU; rec = (size_t)N * NU; off = (size_t)stage * NU; }
     else return fail("pce_moments: unknown field '" + f + "'");
-    DevTmp tV, tA, tm, tv;
-    HIPCHK(tV.alloc(sizeof(double) * c->batch * m)); HIPCHK(tA.alloc(sizeof(double) * L * S));
-    HIPCHK(tm.alloc(sizeof(double) * P * m)); HIPCHK(tv.alloc(sizeof(double) * P * m));
-    double *dV = tV.as<double>(), *dA = tA.as<double>(), *dm = tm.as<double>(), *dv = tv.as<double>();
-    HIPCHK(hipMemcpy2DAsync(dV, (size_t)m * 8, src + off, rec * 8, (size_t)m * 8, c->batch, hipMemcpyDeviceToDevice, c->stream));
-    HIPCHK(hipMemcpyAsync(dA, A, sizeof(double) * L * S, hipMemcpyHostToDevice, c->stream));
-    hipLaunchKernelGGL(pce_moments_kernel, dim3((P * m + 127) / 128), dim3(128), 0, c->stream, dV, dA, P, S1, m, L, dm, dv);
+    hipLaunchKernelGGL(pce_moments_kernel, dim3((P * m + 127) / 128), dim3(128), 0, c->stream, src + off, rec, dA, P, S1, m, L, dmean, dvar);
     HIPCHK(hipGetLastError());
+    return 0;
+}
+
+// Asynchronous, device-to-device flavour (the reduction of BASELINE config 3 inside the timed step): mean_dev / var_dev are
+// caller-owned device buffers of P x m doubles; the matrix is the one registered with tum_pce_attach.
+extern "C" int tum_pce_moments_device(tum_ocp *c, const char *field, int stage, double *mean_dev, double *var_dev)
+{
+    if (!c || !field || !mean_dev || !var_dev) return fail("null argument");
+    if (!c->dpceA) return fail("pce_moments_device: no PCE matrix registered (tum_pce_attach)");
+    DevGuard guard(c->d.device);
+    return pce_launch(c, field, stage, c->dpceA, c->pce_L, c->pce_S, mean_dev, var_dev);
+}
+
+extern "C" int tum_pce_moments(tum_ocp *c, const char *field, int stage, const double *A, int L, int S, double *mean, double *var)
+{
+    if (!c || !field || !A || !mean || !var) return fail("null argument");
+    const int S1 = S + 1;
+    if (S < 1 || L < 1 || c->batch % S1 != 0) return fail("pce_moments: batch must be a multiple of S+1");
+    const int P = c->batch / S1;
+    const int m = (std::string(field) == "u") ? NU : NX;
+    DevGuard guard(c->d.device);
+    DevTmp tA, tm, tv;
+    HIPCHK(tA.alloc(sizeof(double) * L * S));
+    HIPCHK(tm.alloc(sizeof(double) * P * m)); HIPCHK(tv.alloc(sizeof(double) * P * m));
+    double *dA = tA.as<double>(), *dm = tm.as<double>(), *dv = tv.as<double>();
+    HIPCHK(hipMemcpyAsync(dA, A, sizeof(double) * L * S, hipMemcpyHostToDevice, c->stream));
+    if (pce_launch(c, field, stage, dA, L, S, dm, dv)) return 1;
     HIPCHK(hipMemcpyAsync(mean, dm, sizeof(double) * P * m, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipMemcpyAsync(var, dv, sizeof(double) * P * m, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+// Snapshot / restore of all per-stage bounds (lbu, ubu, lbx, ubx, lh, uh) on the device. The R2NMPC tightening rewrites the
+// bounds after every solve; a benchmark or a sweep that restarts from the nominal problem restores them without a host copy.
+extern "C" int tum_ocp_bounds_snapshot(tum_ocp *c)
+{
+    if (!c) return fail("null capsule");
+    DevGuard guard(c->d.device);
+    const size_t n = (size_t)c->batch * 6 * (c->N + 1);
+    if (!c->dbnd_snap && dalloc(&c->dbnd_snap, n) != hipSuccess) return fail("bounds_snapshot: device allocation failed");
+    HIPCHK(hipMemcpyAsync(c->dbnd_snap, c->dbnd, sizeof(double) * n, hipMemcpyDeviceToDevice, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return 0;
+}
+extern "C" int tum_ocp_bounds_restore(tum_ocp *c)
+{
+    if (!c) return fail("null capsule");
+    if (!c->dbnd_snap) return fail("bounds_restore: no snapshot taken");
+    DevGuard guard(c->d.device);
+    HIPCHK(hipMemcpyAsync(c->dbnd, c->dbnd_snap, sizeof(double) * (size_t)c->batch * 6 * (c->N + 1), hipMemcpyDeviceToDevice, c->stream));
     return 0;
 }
 
@@ -653,6 +819,7 @@ extern "C" int tum_ocp_r2_backoff(tum_ocp *c, const double *Sigma0, const double
     if (!c->dqpin) return fail("r2_backoff: capsule created without store_qp_in");
     if (!c->solved) return fail("r2_backoff: no solve yet");
     if (uph < 1) return fail("r2_backoff: uncertainty propagation horizon < 1");
+    DevGuard guard(c->d.device);
     const int N = c->N;
     DevTmp tS, tB, tbo;
     HIPCHK(tS.alloc(64 * 8)); HIPCHK(tB.alloc(64 * 8));
@@ -683,7 +850,7 @@ extern "C" int tum_ocp_r2_attach(tum_ocp *c, const double *Sigma0, const double 
     if (!c->dqpin) return fail("r2_attach: capsule created without store_qp_in");
     if (c->sn) return fail("r2_attach: not available for an SNMPC capsule");
     if (uph < 1) return fail("r2_attach: uncertainty propagation horizon < 1");
-    HIPCHK(hipSetDevice(c->d.device));
+    DevGuard guard(c->d.device);
     if (!c->dr2S && (dalloc(&c->dr2S, 64) != hipSuccess || dalloc(&c->dr2B, 64) != hipSuccess)) return fail("r2_attach: device allocation failed");
     HIPCHK(hipMemcpy(c->dr2S, Sigma0, 64 * 8, hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(c->dr2B, BWB, 64 * 8, hipMemcpyHostToDevice));
@@ -724,7 +891,8 @@ extern "C" int tum_planner_emulate(const double *track, int n_track, const doubl
     if (n_track < 2 || P < 1 || n_points < 2) return fail("planner_emulate: bad sizes");
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return fail("no HIP device: libtumnmpc has no CPU fallback");
-    HIPCHK(hipSetDevice(device));
+    if (device < 0 || device >= ndev) return fail("planner_emulate: device ordinal out of range");
+    DevGuard guard(device);
     DevTmp tt, tp, tout, tcl, terr;
     HIPCHK(tt.alloc(sizeof(double) * 4 * n_track)); HIPCHK(tp.alloc(sizeof(double) * 2 * P));
     HIPCHK(tout.alloc(sizeof(double) * 4 * (size_t)P * n_points)); HIPCHK(tcl.alloc(sizeof(int) * P)); HIPCHK(terr.alloc(sizeof(int)));
@@ -747,6 +915,7 @@ extern "C" int tum_planner_emulate(const double *track, int n_track, const doubl
 extern "C" void tum_sim_free(tum_sim *s)
 {
     if (!s) return;
+    DevGuard guard(s->c->d.device);
     (void)hipFree(s->dtrack); (void)hipFree(s->dxsim); (void)hipFree(s->dpose); (void)hipFree(s->dhist); (void)hipFree(s->dref0);
     (void)hipFree(s->dclosest); (void)hipFree(s->derr); (void)hipFree(s->dstep);
     if (s->graph) (void)hipGraphExecDestroy(s->graph);
@@ -760,7 +929,7 @@ extern "C" tum_sim *tum_sim_create(tum_ocp *c, const double *track, int n_track,
     if (!c || !track || !windows) { fail("null argument"); return nullptr; }
     if (n_track < 2 || !(Tp > 0) || !(Ts > 0) || n_elem < 1 || log_capacity < 0) { fail("sim_create: bad arguments"); return nullptr; }
     for (int i = 0; i < 8; i++) if (windows[i] < 1 || windows[i] > 4) { fail("sim_create: estimator windows must be 1..4"); return nullptr; }
-    if (hipSetDevice(c->d.device) != hipSuccess) { fail("hipSetDevice failed"); return nullptr; }
+    DevGuard guard(c->d.device);
     if (c->sn) {   // the state estimator writes the nominal x0 only: the samples follow by fan-out
         if (!c->have_offs) { fail("sim_create: an SNMPC capsule needs its sample offsets (tum_ocp_snmpc_set_offsets)"); return nullptr; }
         c->fanout = true;
@@ -773,7 +942,7 @@ extern "C" tum_sim *tum_sim_create(tum_ocp *c, const double *track, int n_track,
     bool ok = true;
     ok &= dalloc(&s->dtrack, (size_t)4 * n_track) == hipSuccess;
     ok &= dalloc(&s->dxsim, B * 7) == hipSuccess && dalloc(&s->dpose, B * 2) == hipSuccess && dalloc(&s->dhist, B * 32) == hipSuccess;
-    ok &= dalloc(&s->dref0, B * 4) == hipSuccess && dalloc(&s->dclosest, B) == hipSuccess && dalloc(&s->derr, (size_t)1) == hipSuccess && dalloc(&s->dstep, (size_t)1) == hipSuccess;
+    ok &= dalloc(&s->dref0, B * 4) == hipSuccess && dalloc(&s->dclosest, B) == hipSuccess && dalloc(&s->derr, (size_t)1) == hipSuccess && dalloc(&s->dstep, (size_t)2) == hipSuccess;
     if (L > 0) {
         ok &= dalloc(&s->lCiLX, (L + 1) * B * 7) == hipSuccess && dalloc(&s->lSimX, (L + 1) * B * 8) == hipSuccess;
         ok &= dalloc(&s->lU, L * B * 2) == hipSuccess && dalloc(&s->lREF, L * B * 4) == hipSuccess && dalloc(&s->lDBG, L * B * 5) == hipSuccess;
@@ -788,13 +957,13 @@ extern "C" int tum_sim_set_state(tum_sim *s, const double *x_sim, const double *
 {
     if (!s || !x_sim || !x_mpc) return fail("null argument");
     tum_ocp *c = s->c; const size_t B = c->batch;
-    HIPCHK(hipSetDevice(c->d.device));
+    DevGuard guard(c->d.device);
     HIPCHK(hipStreamSynchronize(c->stream));
     HIPCHK(hipMemcpy(s->dxsim, x_sim, sizeof(double) * B * 7, hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(c->dx0, x_mpc, sizeof(double) * B * 8, hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy2D(s->dpose, 2 * 8, x_mpc, 8 * 8, 2 * 8, B, hipMemcpyHostToDevice));
     HIPCHK(hipMemset(s->dhist, 0, sizeof(double) * B * 32));
-    HIPCHK(hipMemset(s->dstep, 0, sizeof(int)));
+    HIPCHK(hipMemset(s->dstep, 0, 2 * sizeof(int)));
     s->step = 0;
     if (s->log_cap > 0) {
         HIPCHK(hipMemcpy(s->lCiLX, x_sim, sizeof(double) * B * 7, hipMemcpyHostToDevice));
@@ -808,8 +977,9 @@ extern "C" int tum_sim_plan(tum_sim *s)
 {
     if (!s) return fail("null argument");
     tum_ocp *c = s->c;
+    DevGuard guard(c->d.device);
     hipLaunchKernelGGL(planner_kernel, dim3(c->batch), dim3(64), 0, c->stream, s->dtrack, s->n_track, s->dpose, 2, c->N + 1, s->Tp,
-                       s->loop_circuit, c->dyref, 6, s->dref0, s->dclosest, s->derr, c->batch, s->dstep);
+                       s->loop_circuit, c->dyref, 6, s->dref0, s->dclosest, s->derr, c->batch, (int *)nullptr);
     HIPCHK(hipGetLastError());
     return 0;
 }
@@ -819,6 +989,7 @@ extern "C" int tum_sim_advance(tum_sim *s)
     if (!s) return fail("null argument");
     tum_ocp *c = s->c;
     if (!c->solved) return fail("sim_advance: no solve yet");
+    DevGuard guard(c->d.device);
     SimArgs sa;
     memset(&sa, 0, sizeof(sa));
     sa.N = c->N; sa.batch = c->batch; sa.n_elem = s->n_elem; sa.step_counter = s->dstep; sa.log_cap = s->log_cap; sa.Ts = s->Ts;
@@ -832,6 +1003,8 @@ extern "C" int tum_sim_advance(tum_sim *s)
     p.invFmax_r = 1.0 / std::sqrt(p.Fz_r * p.Fz_r + (d.Cr * p.Fz_r) * (d.Cr * p.Fz_r));
     p.fr0 = d.fr0; p.fr1 = d.fr1; p.fr4 = d.fr4;
     sa.X = c->dX; sa.U = c->dU; sa.cost = c->dcost; sa.status = c->dstatus; sa.qp_iter = c->dqpiter;
+    sa.ns = c->sn ? c->sa.ns : 0; sa.XS = c->dXS; sa.xs0 = c->dxs0;
+    sa.bnd = c->dbnd; sa.r2 = c->r2 ? 1 : 0; sa.r2_dmin = c->r2_dmin; sa.r2_dmax = c->r2_dmax; sa.r2_uh = c->r2_uh;
     sa.x_sim = s->dxsim; sa.x0 = c->dx0; sa.pose = s->dpose; sa.hist = s->dhist; sa.ref0 = s->dref0;
     sa.lCiLX = s->lCiLX; sa.lSimX = s->lSimX; sa.lU = s->lU; sa.lREF = s->lREF; sa.lDBG = s->lDBG;
     hipLaunchKernelGGL(plant_advance_kernel, dim3((c->batch + 63) / 64), dim3(64), 0, c->stream, sa);
@@ -856,7 +1029,7 @@ extern "C" int tum_sim_run(tum_sim *s, int nsteps)
 {
     if (!s || nsteps < 0) return fail("bad argument");
     tum_ocp *c = s->c;
-    HIPCHK(hipSetDevice(c->d.device));
+    DevGuard guard(c->d.device);
     int done = 0;
     if (nsteps >= 2 * GRAPH_STEPS) {
         if (!s->graph) {
@@ -896,6 +1069,7 @@ extern "C" int tum_sim_get(tum_sim *s, const char *field, double *out, long long
     tum_ocp *c = s->c; const long long B = c->batch;
     const long long L = s->step < s->log_cap ? s->step : s->log_cap;
     const std::string f(field);
+    DevGuard guard(c->d.device);
     HIPCHK(hipStreamSynchronize(c->stream));
     const double *src = nullptr; long long want = 0;
     if (f == "x_sim") { src = s->dxsim; want = B * 7; }

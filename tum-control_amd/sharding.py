@@ -19,6 +19,14 @@ def shard_range(total, world, rank):
     return lo, hi
 
 
+def shard_groups(n_groups, group_size, world, rank):
+    """Group-aligned block of a batch made of `n_groups` scenario groups of `group_size` instances each (configs 3/4: one
+    pose with its sigma points / Monte-Carlo draws): ranks own whole groups, so the PCE moment reduction of a group never
+    needs another GPU. Returns (g_lo, g_hi, b_lo, b_hi): group range and instance range of `rank`."""
+    g_lo, g_hi = shard_range(n_groups, world, rank)
+    return g_lo, g_hi, g_lo * int(group_size), g_hi * int(group_size)
+
+
 def shard_sizes(total, world):
     return [shard_range(total, world, r)[1] - shard_range(total, world, r)[0] for r in range(world)]
 

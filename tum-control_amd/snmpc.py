@@ -165,25 +165,34 @@ class Stochastic_Nonlinear_Model_Predictive_Controller:
         self.stop_flags[uph:] = 1
         self.risk_parameter = np.array(m["gamma"]).reshape(1)
         X0_MPC = np.zeros(8) if X0_MPC is None else np.asarray(X0_MPC, dtype=float)
-        x0_samples = compute_x0dist(X0_MPC, self.w_samples, self.stds)
-        s = self.acados_solver = CoupledSnmpcSolver(N=self.N, dt=self.Tp / self.N, batch=1, Apce=self.A, uph=min(uph, self.N),
-                                                    gamma=m["gamma"], device=device, cfg=self.cfg)
-        s.install_reference_ocp(Q=self.Q, R=self.R, Qe=self.Qe, L1=self.L1_pen, L2=self.L2_pen, w_scale=0.01)
+        self._uph = min(uph, self.N)
+        self._device = device
         from .nmpc import model_namespaces
         self.constraint, self.model = model_namespaces(self.cfg, nx=8 * (self.n_samples + 1), name="SNMPC")
         self.nx = int(self.model.x.size()[0] / (self.n_samples + 1))          # SNMPC_class.py:113
-        self._device = device
         self.x0 = X0_MPC
         self.costfunction_type = "NONLINEAR_LS"
         self.nh, self.nh_e = 1, 1
+        self.acados_solver = self._build_solver(X0_MPC)
+        self.stats = np.zeros(5)
+        self.pred_X = np.empty((0, self.nx))
+        self.WMPC = False
+
+    def _build_solver(self, X0_MPC):
+        """acados_settings(self.Tp, self.N, x0_samples.flatten(), self.Q, self.R, self.Qe, self.L1_pen, self.L2_pen, ...)
+        (SNMPC_class.py:106-111 at construction and :274-281 in reintialize_solver): a fresh solver built from THIS
+        controller's horizon, weights, penalties and PCE set-up, cold-started at the sample states of X0_MPC."""
+        m = self.MPC_params
+        x0_samples = compute_x0dist(np.asarray(X0_MPC, dtype=float), self.w_samples, self.stds)
+        s = CoupledSnmpcSolver(N=self.N, dt=self.Tp / self.N, batch=1, Apce=self.A, uph=self._uph,
+                               gamma=m["gamma"], device=self._device, cfg=self.cfg)
+        s.install_reference_ocp(Q=self.Q, R=self.R, Qe=self.Qe, L1=self.L1_pen, L2=self.L2_pen, w_scale=0.01)
         s.constraints_set(0, "lbx", x0_samples.flatten())
         s.constraints_set(0, "ubx", x0_samples.flatten())
         for i in range(self.N + 1):
             s.set(i, "p", np.concatenate((self.A.flatten(), self.risk_parameter, self.stop_flags[i].reshape(1))))
         s.cold_start()                  # SNMPC_class.py:126-127: x_j = x0_samples for all j
-        self.stats = np.zeros(5)
-        self.pred_X = np.empty((0, self.nx))
-        self.WMPC = False
+        return s
 
     def solve(self, current_ref_traj):
         """SNMPC_class.py:179-257"""
@@ -220,10 +229,9 @@ class Stochastic_Nonlinear_Model_Predictive_Controller:
             self.acados_solver.set(i, 'x', x0_samples.flatten())
 
     def reintialize_solver(self, X0_MPC, solver_generate_C_code=False, solver_build=False):
-        """SNMPC_class.py:274-281: a fresh solver (cold start) at the given state"""
-        fresh = Stochastic_Nonlinear_Model_Predictive_Controller(X0_MPC=X0_MPC, device=self._device)
-        fresh.cfg = self.cfg
-        self.acados_solver = fresh.acados_solver
+        """SNMPC_class.py:274-281: a fresh solver with the SAME Q / R / N / penalties / PCE set-up, cold-started at the
+        sample states of X0_MPC (called by main.py:59-61 after every failed solve)."""
+        self.acados_solver = self._build_solver(X0_MPC)
         self.set_initial_state(X0_MPC)
 
     def update_cost_function_weights(self, params):

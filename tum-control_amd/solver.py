@@ -46,9 +46,10 @@ C_SYMBOLS = ["tum_ocp_create", "tum_ocp_free", "tum_ocp_last_error", "tum_ocp_ba
              "tum_ocp_set", "tum_ocp_get", "tum_ocp_constraints_set", "tum_ocp_cost_set",
              "tum_ocp_solve", "tum_ocp_solve_async", "tum_ocp_synchronize",
              "tum_ocp_get_cost", "tum_ocp_get_stats", "tum_ocp_reset", "tum_ocp_get_from_qp_in",
-             "tum_ocp_set_stream", "tum_ocp_get_device", "tum_ocp_cold_start", "tum_ocp_last_kernel_ms",
+             "tum_ocp_set_stream", "tum_ocp_get_device", "tum_ocp_put_device", "tum_ocp_cold_start", "tum_ocp_last_kernel_ms",
              "tum_ocp_debug_dump", "tum_ocp_profile_phases", "tum_ocp_set_schedule",
-             "tum_ocp_set_x0_fanout", "tum_pce_moments", "tum_ocp_r2_backoff", "tum_ocp_r2_attach", "tum_ocp_constraints_get",
+             "tum_ocp_set_x0_fanout", "tum_pce_moments", "tum_pce_attach", "tum_pce_moments_device",
+             "tum_ocp_bounds_snapshot", "tum_ocp_bounds_restore", "tum_ocp_r2_backoff", "tum_ocp_r2_attach", "tum_ocp_constraints_get",
              "tum_ocp_snmpc_attach", "tum_ocp_snmpc_samples", "tum_ocp_snmpc_set_offsets",
              "tum_planner_emulate", "tum_sim_create", "tum_sim_free", "tum_sim_set_state", "tum_sim_plan", "tum_sim_advance",
              "tum_sim_run", "tum_sim_steps", "tum_sim_get"]
@@ -87,11 +88,15 @@ def load_library(path=None):
     L.tum_ocp_set_stream.argtypes = [vp, vp]
     L.tum_ocp_set_schedule.argtypes = [vp, ci]
     L.tum_ocp_get_device.argtypes = [vp, cs, vp, ci, ci]
+    L.tum_ocp_put_device.argtypes = [vp, cs, vp, ci, ci]
     L.tum_ocp_last_kernel_ms.restype = ctypes.c_double; L.tum_ocp_last_kernel_ms.argtypes = [vp]
     L.tum_ocp_debug_dump.argtypes = [vp, ci, dp, ci]
     L.tum_ocp_profile_phases.argtypes = [vp, ctypes.POINTER(ctypes.c_longlong)]
     L.tum_ocp_set_x0_fanout.argtypes = [vp, dp, dp, ci, ci]
     L.tum_pce_moments.argtypes = [vp, cs, ci, dp, ci, ci, dp, dp]
+    L.tum_pce_attach.argtypes = [vp, dp, ci, ci]
+    L.tum_pce_moments_device.argtypes = [vp, cs, ci, vp, vp]
+    L.tum_ocp_bounds_snapshot.argtypes = [vp]; L.tum_ocp_bounds_restore.argtypes = [vp]
     L.tum_ocp_r2_backoff.argtypes = [vp, dp, dp, ci, ctypes.c_double, ctypes.c_double, ctypes.c_double, dp]
     L.tum_ocp_constraints_get.argtypes = [vp, ci, cs, dp, ci, ci]
     L.tum_ocp_r2_attach.argtypes = [vp, dp, dp, ci, ctypes.c_double, ctypes.c_double, ctypes.c_double]
@@ -213,6 +218,9 @@ class BatchedOcpSolver:
         self._put(self._L.tum_ocp_constraints_set, stage, field, value, "constraints_set")
 
     def cost_set(self, stage, field, value):
+        """acados_solver.cost_set. RESTRICTION (include/tum_nmpc.h): all stages < N share ONE W per instance -- the
+        reference installs the same blockdiag(Q, R) on every stage (NMPC_class.py:295-296); a W set at any stage < N
+        replaces the weight of all of them."""
         v = np.asarray(value, dtype=np.float64)
         if field == "W":
             ny = 6 if stage < self.N else 4
@@ -311,6 +319,11 @@ class BatchedOcpSolver:
         nb = self.batch - b0 if nb is None else nb
         self._chk(self._L.tum_ocp_get_device(self._h, field.encode(), ctypes.c_void_p(dev_ptr), b0, nb), "get_device")
 
+    def put_device(self, field, dev_ptr, b0=0, nb=None):
+        """'x0' | 'yref' | 'X' | 'U' from caller-owned device memory (asynchronous D2D on the capsule's stream)"""
+        nb = self.batch - b0 if nb is None else nb
+        self._chk(self._L.tum_ocp_put_device(self._h, field.encode(), ctypes.c_void_p(dev_ptr), b0, nb), "put_device")
+
     def set_schedule(self, longest_first=True):
         """Dispatch instances longest-first by the previous solve's iteration counts (default) or in natural order."""
         self._chk(self._L.tum_ocp_set_schedule(self._h, int(bool(longest_first))), "set_schedule")
@@ -334,6 +347,23 @@ class BatchedOcpSolver:
         mean = np.zeros((P, m)); var = np.zeros((P, m))
         self._chk(self._L.tum_pce_moments(self._h, field.encode(), stage, _dp(A), L_, S, _dp(mean), _dp(var)), "pce_moments")
         return mean, var
+
+    def pce_attach(self, A):
+        """keep the L x S PCE matrix on the device for pce_moments_device"""
+        A = np.ascontiguousarray(A, dtype=np.float64)
+        self._chk(self._L.tum_pce_attach(self._h, _dp(A), A.shape[0], A.shape[1]), "pce_attach")
+
+    def pce_moments_device(self, field, stage, mean_ptr, var_ptr):
+        """asynchronous PCE mean / variance into caller-owned device buffers (P x m doubles each)"""
+        self._chk(self._L.tum_pce_moments_device(self._h, field.encode(), int(stage), ctypes.c_void_p(mean_ptr),
+                                                 ctypes.c_void_p(var_ptr)), "pce_moments_device")
+
+    def bounds_snapshot(self):
+        self._chk(self._L.tum_ocp_bounds_snapshot(self._h), "bounds_snapshot")
+
+    def bounds_restore(self):
+        """put back the bounds of the last snapshot (asynchronous, on the capsule's stream)"""
+        self._chk(self._L.tum_ocp_bounds_restore(self._h), "bounds_restore")
 
     def r2_backoff(self, Sigma0, BWB, uph, delta_min, delta_max, uh_nom=1.0, return_backoffs=False):
         """R2NMPC tightening of lbx/ubx/uh for the next solve from the last linearisation (store_qp_in capsules)."""
@@ -430,15 +460,14 @@ class CoupledSnmpcSolver(BatchedOcpSolver):
 
     def set(self, stage, field, value):
         if field == "p":
-            v = np.asarray(value, dtype=np.float64).reshape(-1)
+            # [A_pce.flatten(), risk_parameter, stop_flag] (SNMPC_class.py:124,185,193): handled by the C-ABI -- A_pce and the
+            # risk parameter are shared by all stages, the stop flags define the uncertainty propagation horizon of the
+            # next solve (include/tum_nmpc.h, tum_ocp_set)
+            v = np.ascontiguousarray(value, dtype=np.float64).reshape(-1)
             if v.size != self.L * self.ns + 2:
                 raise Exception(f"CoupledSnmpcSolver.set: mismatching dimension for field \"p\" with dimension "
                                 f"{self.L * self.ns + 2} (you have {v.size})")
-            if not np.array_equal(v[:-2], self.Apce.reshape(-1)):
-                raise Exception("CoupledSnmpcSolver.set: A_pce differs from the matrix the solver was built with")
-            if float(v[-1]) != (1.0 if stage >= self.uph else 0.0):
-                raise Exception("CoupledSnmpcSolver.set: stop_flag does not match the uncertainty propagation horizon "
-                                f"the solver was built with (uph = {self.uph})")
+            self._chk(self._L.tum_ocp_set(self._h, int(stage), b"p", _dp(v), v.size, 0, self.batch, 0), "set")
             return
         super().set(stage, field, value)
 
@@ -482,6 +511,7 @@ class DeviceClosedLoop:
         if not self._s:
             raise Exception("tum_sim_create: " + self._L.tum_ocp_last_error().decode())
         self.B = solver.batch
+        self.log_capacity = int(log_capacity)
 
     def __del__(self):
         if getattr(self, "_s", None):
@@ -516,7 +546,9 @@ class DeviceClosedLoop:
         if field in ("x_sim", "x_mpc", "pose", "ref0", "closest"):
             shape = (self.B, d)
         else:
-            n = self.steps + (1 if field in ("CiLX", "MPC_SimX") else 0)
+            if self.log_capacity == 0:
+                raise Exception(f"DeviceClosedLoop.get('{field}'): created with log_capacity=0 (no logs kept on the device)")
+            n = min(self.steps, self.log_capacity) + (1 if field in ("CiLX", "MPC_SimX") else 0)   # the first log_capacity steps
             shape = (n, self.B, d)
         out = np.empty(shape)
         self._chk(self._L.tum_sim_get(self._s, field.encode(), _dp(out), out.size), "sim_get " + field)
