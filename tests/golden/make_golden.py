@@ -9,6 +9,8 @@ DATA (inputs + expected outputs), never reference source:
 
   kat0.npz            step 0 (cold start) of all 52 _baseline/F/{monteblanco,lvms}/{k}.npz
   replay_<t>_<k>_<a>_<b>.npz   sequential closed-loop windows (x0_i, yref_i, expected u0/x1/cost/qp_iter)
+  replay_hard.npz     windows of the weight sets on which acados hit its 50-iteration QP cap (2, 13, 16, 18; both tracks):
+                      x0_i, planner pose_i and the logged u0/x1/cost/qp_iter around the first capped solve of each loop
   planner.npz         PlannerEmulator input/output pairs
   pce.npz             alphaGeneration / polyChaosExpansion / compute_x0dist / sigma points of acados_ocp_SNMPC.json
   snmpc_expr.npz      stacked dynamics / cost output / chance constraint of the exported SNMPC OCP evaluated at random points
@@ -111,6 +113,34 @@ def make_replay(track, k, nsteps):
     x0s, yrefs, exp = replay_inputs(track, k, nsteps)
     np.savez_compressed(os.path.join(OUT, f"replay_{track}_{k}_0_{nsteps}.npz"),
                         params=F[k], x0=x0s, yref=yrefs, **exp)
+
+
+# (track, weight set, first step, one-past-last step). Windows that start at 0 replay the log from its cold start; the
+# lvms/2 window starts in the middle of the log (cold restart there: the first ~20 steps are warm-up).
+HARD_WINDOWS = [("monteblanco", 2, 0, 380), ("monteblanco", 13, 0, 135), ("monteblanco", 16, 0, 290), ("monteblanco", 18, 0, 60),
+                ("lvms", 2, 1195, 1295), ("lvms", 13, 0, 425), ("lvms", 16, 0, 450), ("lvms", 18, 0, 375)]
+
+
+def make_replay_hard():
+    """Per-solve pins on the weight sets whose logged closed loops contain QP solves that acados stopped at its iteration cap
+    (qp_iter == 50, status still 0: `simSolverDebug[:, 3:5]`). Stored per step: the x0 the logged solve started from, the
+    pose handed to the planner (yref is re-derived by the golden-pinned planner restatement), and what acados returned."""
+    out = {}
+    meta = []
+    for track, k, a, b in HARD_WINDOWS:
+        d = np.load(os.path.join(BASE, track, f"{k}.npz"))
+        x0s, _, exp = replay_inputs(track, k, b)
+        traj = load_traj(track)
+        CiLX = d["CiLX"]
+        pose = np.array([[traj["pos_x"][0], traj["pos_y"][0]] if i == 0 else CiLX[i][:2] for i in range(b)])
+        key = f"{track}_{k}"
+        out[key + "_x0"] = x0s[a:b]; out[key + "_pose"] = pose[a:b]
+        for f in ("u0", "x1", "cost", "qp_iter"):
+            out[key + "_" + f] = np.asarray(exp[f][a:b], dtype=np.float64)
+        assert (exp["status"][a:b] == 0).all()
+        meta.append((track, k, a, b))
+    np.savez_compressed(os.path.join(OUT, "replay_hard.npz"), params=F, track=np.array([m[0] for m in meta]),
+                        k=np.array([m[1] for m in meta]), start=np.array([m[2] for m in meta]), **out)
 
 
 def make_closed_loop(track="monteblanco", nsteps=150):
@@ -268,7 +298,9 @@ def make_r2():
 
 
 if __name__ == "__main__":
-    what = sys.argv[1:] or ["kat0", "replay", "planner", "pce", "snmpc_json", "snmpc_expr", "r2", "closed_loop"]
+    what = sys.argv[1:] or ["kat0", "replay", "replay_hard", "planner", "pce", "snmpc_json", "snmpc_expr", "r2", "closed_loop"]
+    if "replay_hard" in what:
+        make_replay_hard()
     if "kat0" in what:
         make_kat0()
     if "replay" in what:

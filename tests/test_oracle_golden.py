@@ -58,6 +58,76 @@ def test_sequential_replay(golden_dir, name, tol):
     assert worst < tol
 
 
+def hard_window_check(golden_dir, solve_step):
+    """Shared by the oracle test (here) and the HIP test (test_gpu_parity.py): replays every window of replay_hard.npz --
+    the logged closed loops of the weight sets 2, 13, 16, 18 around the first QP solve that acados stopped at its
+    50-iteration cap -- through `solve_step(key, i, params, x0, yref) -> (u0, x1, qp_iter, converged)` and holds every solve
+    to what acados logged, split by what acados itself reports about that solve:
+      * a solve is COMPARABLE when acados converged on it (qp_iter < 50) and on the 25 solves before it (a capped solve
+        leaves a different warm start behind; the RTI sequence forgets it within about 20 steps) and, in the window that
+        starts in the middle of a log, after 20 warm-up steps: those must match to 2e-4 (observed <= 7e-5; north_star 1e-4
+        relative) -- this is every solve of the converged stretch before the first capped one, hundreds per window;
+      * on the CAPPED solves themselves this solver must have converged (status 0, KKT residuals at tolerance, <= 20
+        iterations): the deviation there is acados' unfinished QP step, not this solver's.
+    Returns per window (n comparable, worst comparable error, worst error at / after capped solves)."""
+    from tum_control_amd.planner import load_track, planner_emulator, yref_from_ref
+    g = np.load(os.path.join(golden_dir, "replay_hard.npz"))
+    out = {}
+    for track, k, start in zip(g["track"], g["k"], g["start"]):
+        key = f"{track}_{k}"
+        tr = load_track(str(track))
+        x0s, poses, aq = g[key + "_x0"], g[key + "_pose"], g[key + "_qp_iter"]
+        n = len(x0s)
+        capped = aq >= 50
+        assert capped.any() or start > 0
+        tainted = np.zeros(n, bool)
+        for c in np.nonzero(capped)[0]:
+            tainted[c:c + 26] = True
+        warm = np.zeros(n, bool)
+        if start > 0:
+            warm[:20] = True
+        worst_ok = worst_cap = 0.0
+        for i in range(n):
+            _, ref = planner_emulator(tr, poses[i], 39, 3.04, True)
+            u0, x1, it, converged = solve_step(key, i, g["params"][int(k)], x0s[i], yref_from_ref(ref, 38))
+            assert converged and it <= 20, (key, i, it)
+            dx = x1 - g[key + "_x1"][i]
+            dx[2] = (dx[2] + np.pi) % (2 * np.pi) - np.pi            # the logs hold yaw mod 2 pi
+            e = max(np.abs(u0 - g[key + "_u0"][i]).max(), np.abs(dx).max())
+            if warm[i]:
+                continue
+            if tainted[i]:
+                worst_cap = max(worst_cap, e)
+            else:
+                worst_ok = max(worst_ok, e)
+                assert e < 2e-4, (key, i, e, int(aq[i]))
+        out[key] = (int((~tainted & ~warm).sum()), worst_ok, worst_cap)
+    return out
+
+
+def test_hard_weight_sets_per_solve(golden_dir):
+    """Per-solve parity on the weight sets where acados hit its QP iteration cap (VERDICT r1 weak #2)."""
+    state = {}
+
+    def step(key, i, params, x0, yref):
+        if i == 0:
+            o = state[key] = OracleOcp(38, 0.08, 3)
+            o.set_weights(*params)
+            o.cold_start(x0)
+        o = state[key]
+        o.x0[:] = x0
+        o.yref[:] = yref
+        st = o.solve()
+        return o.U[0].copy(), o.X[1].copy(), o.qp_iter, st == 0 and o.res.max() < 1e-6
+
+    res = hard_window_check(golden_dir, step)
+    assert sum(r[0] for r in res.values()) > 1500                       # comparable solves held to 2e-4
+    # where the logged loops part from this solver it is at a capped solve: on several windows the deviation at / right
+    # after the first capped solve is orders of magnitude above anything on the converged stretches (some capped solves
+    # were almost converged and deviate little: not every window shows it)
+    assert sum(r[2] > 1e-3 and r[2] > 40 * r[1] for r in res.values()) >= 2, res
+
+
 def test_jacobians_finite_difference():
     rng = np.random.default_rng(0)
     for _ in range(20):

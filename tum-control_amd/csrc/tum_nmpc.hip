@@ -273,6 +273,13 @@ static int sn_apply_p(tum_ocp *c)
             return fail("solve: device allocation failed for the longer uncertainty propagation horizon");
         c->uph_cap = uph; c->sa.ws2 = c->dws2; c->sa.pro = c->dpro; c->ka.pro = c->dpro;
     }
+    if (uph != c->sa.uph) {
+        // the prologue only writes the live columns of a stage (2k+3 of them) and relies on the rest of its hand-over
+        // buffers being zero; the per-instance stride of both buffers depends on uph, so a new horizon starts from zeros
+        DevGuard guard(c->d.device);
+        HIPCHK(hipMemsetAsync(c->dws2, 0, sizeof(double) * (size_t)c->batch * c->uph_cap * ns * ABS, c->stream));
+        HIPCHK(hipMemsetAsync(c->dpro, 0, sizeof(double) * (size_t)c->batch * c->uph_cap * SN_PRO_STAGE, c->stream));
+    }
     c->gamma = c->p_gamma[0];
     c->sa.kappa = std::sqrt((1.0 - c->gamma) / c->gamma);
     c->sa.uph = uph; c->ka.uph = uph;
