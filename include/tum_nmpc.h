@@ -133,6 +133,12 @@ int tum_ocp_cold_start(tum_ocp *c);
  * first instead of leaving the GPU idle at the end (a batch is only a few rounds of resident wavefronts); 0: natural order.
  * Results do not depend on the schedule. Environment override at create time: TUM_NMPC_SCHEDULE=natural. */
 int tum_ocp_set_schedule(tum_ocp *c, int longest_first);
+/* Kernel variant of the nominal solve (no reference counterpart): "fused" (one kernel per solve), "pipeline" (linearise /
+ * condense / interior point / expand as four kernels, each at its own occupancy, handing over through the L2-resident
+ * workspace), "auto" (default: the pipeline for batches of more than 1024 instances, where it is 4-8 % faster, the fused kernel
+ * below). Results agree to rounding (same arithmetic per phase). Environment override at create time: TUM_NMPC_KERNEL. The
+ * coupled SNMPC OCP always runs the fused kernel. get_stats("time_ipm") reports the interior point kernel of the pipeline. */
+int tum_ocp_set_kernel(tum_ocp *c, const char *name);
 /* last kernel launch time in milliseconds (HIP events on the launch stream) */
 double tum_ocp_last_kernel_ms(tum_ocp *c);
 /* debug: dump of condensed-QP intermediates of instance b (see csrc/nmpc_kernel.hip) */

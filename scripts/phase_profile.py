@@ -8,14 +8,17 @@ import torch
 from tum_control_amd.solver import BatchedOcpSolver
 from tum_control_amd.workloads import nominal_batch
 N, B = 40, int(sys.argv[1]) if len(sys.argv) > 1 else 4096
+KERNEL = sys.argv[2] if len(sys.argv) > 2 else os.environ.get("TUM_NMPC_KERNEL", "auto")
 x0, yref = nominal_batch(B, N=N)
 s = BatchedOcpSolver(N=N, dt=0.08, nsub=3, batch=B)
-s.install_reference_ocp(); s.set_x0(x0); s.set_yref_all(yref)
+s.install_reference_ocp(); s.set_x0(x0); s.set_yref_all(yref); s.set_kernel(KERNEL)
 s.cold_start(); s.solve(); ms0 = s.last_kernel_ms()
 s.cold_start(); p = s.profile_phases(); ms1 = s.last_kernel_ms()
 it = s.get_stats("qp_iter")
 names = ["load+linearise", "condense", "ipm residuals", "M assembly (SYRK)", "Cholesky", "rhs (C'w)", "tri-solves", "C*dv + steps", "ipm exit", "expand+cost+store"]
 tot = p[:, :10].sum(axis=1)
-print(f"batch {B}: kernel {ms0:.3f} ms plain, {ms1:.3f} ms with timers; mean qp_iter {it.mean():.2f}; mean cycles/OCP {tot.mean():.0f}")
+if KERNEL == "pipeline" or (KERNEL == "auto" and B > 1024):
+    names = ["(unused)", "load + initial point", "ipm residuals", "M assembly (SYRK)", "Cholesky", "rhs (C'w)", "tri-solves", "C*dv + steps", "ipm exit", "outputs"]
+print(f"kernel variant {KERNEL}; batch {B}: kernel {ms0:.3f} ms plain, {ms1:.3f} ms with timers; mean qp_iter {it.mean():.2f}; mean cycles/OCP {tot.mean():.0f}")
 for i, n in enumerate(names):
     print(f"  {n:22s} {p[:, i].mean():12.0f} cyc  {100*p[:, i].mean()/tot.mean():5.1f} %   per-iter {p[:, i].mean()/it.mean():9.0f}")

@@ -1,0 +1,131 @@
+"""
+The two kernel variants of the nominal solve (include/tum_nmpc.h, tum_ocp_set_kernel) against each other and against the
+oracle: "fused" (one kernel per solve) and "pipeline" (linearise / condense / interior point / expand as four kernels,
+csrc/pipe_kernels.hpp). Same arithmetic per phase, so they agree to rounding (the order of a few sums differs) and
+take the same number of interior point iterations. With the default "auto" the large-batch tests of test_gpu_parity.py /
+test_gpu_configs.py already run the pipeline and the small-batch ones the fused kernel; here both are forced.
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _mk(N, B, kernel, **kw):
+    from tum_control_amd.solver import BatchedOcpSolver
+    s = BatchedOcpSolver(N=N, dt=0.08, nsub=3, batch=B, **kw)
+    s.install_reference_ocp()
+    s.set_kernel(kernel)
+    return s
+
+
+def _oracle(N):
+    from oracle.oracle import OracleOcp
+    from tum_control_amd import config
+    m = config.MPC
+    o = OracleOcp(N, 0.08, 3)
+    o.set_weights(m["q_lon"], m["q_yaw"], m["q_vel"], m["r_jerk"], m["r_steering_rate"], m["L1_pen"], m["L2_pen"], scale=0.01)
+    return o
+
+
+@pytest.mark.parametrize("N,B", [(40, 4096), (40, 700), (38, 9), (17, 5), (5, 7), (1, 3), (40, 1)])
+def test_pipeline_matches_fused_and_oracle(N, B):
+    from tum_control_amd.workloads import nominal_batch
+    x0, yref = nominal_batch(B, N=N, dt=0.08, seed=100 + N)
+    out = {}
+    for k in ("fused", "pipeline"):
+        s = _mk(N, B, k)
+        s.set_x0(x0); s.set_yref_all(yref); s.cold_start()
+        assert s.solve() == 0
+        X, U = s.get_iterate()
+        # two warm RTI steps on a moving initial state
+        for _ in range(2):
+            s.set_x0(X[:, 1]); assert s.solve() == 0
+            X, U = s.get_iterate()
+        out[k] = (X, U, s.get_stats("qp_iter"), s.get_cost(), s.get_stats("res"), np.stack([s.get(3 if N > 3 else 0, "sl")]))
+        if k == "pipeline":
+            assert s.get_stats("time_ipm") > 0.0
+    f, p = out["fused"], out["pipeline"]
+    assert np.array_equal(f[2], p[2])                                   # same interior point iteration counts
+    assert np.abs(f[1] - p[1]).max() < 2e-6 and np.abs(f[0] - p[0]).max() < 2e-6
+    np.testing.assert_allclose(f[3], p[3], rtol=1e-7)
+    np.testing.assert_allclose(f[5], p[5], atol=1e-7)
+    assert p[4].max() < 1e-6
+    # the pipeline against the oracle directly (cold start) on a subset
+    s = _mk(N, B, "pipeline")
+    s.set_x0(x0); s.set_yref_all(yref); s.cold_start(); assert s.solve() == 0
+    X, U = s.get_iterate()
+    idx = np.unique(np.linspace(0, B - 1, min(B, 40)).astype(int))
+    u0, X1, st = _oracle(N).solve_batch_cold(x0[idx], yref[idx], 8)
+    same = s.get_stats("qp_iter")[idx] == st[:, 1]
+    assert same.mean() > 0.9
+    assert np.abs(U[idx, 0] - u0)[same].max() < 1e-6 and np.abs(X[idx, 1] - X1)[same].max() < 1e-6
+    np.testing.assert_allclose(s.get_cost()[idx][same] if B > 1 else np.atleast_1d(s.get_cost())[same], st[same, 0], rtol=1e-7)
+
+
+def test_pipeline_properties():
+    """bitwise determinism, independence of the schedule and of the batch composition, NaN isolation"""
+    from tum_control_amd.workloads import nominal_batch
+    N, B = 40, 2048
+    x0, yref = nominal_batch(B, N=N, seed=77)
+    s = _mk(N, B, "pipeline")
+    s.set_x0(x0); s.set_yref_all(yref); s.cold_start(); s.solve()
+    X1, U1 = s.get_iterate()
+    s.cold_start(); s.solve()
+    X2, U2 = s.get_iterate()
+    assert np.array_equal(X1, X2) and np.array_equal(U1, U2)
+    s.set_schedule(False); s.cold_start(); s.solve(); s.set_schedule(True)
+    Xn, Un = s.get_iterate()
+    assert np.array_equal(Xn, X1) and np.array_equal(Un, U1)
+    perm = np.random.default_rng(1).permutation(B)
+    s.set_x0(x0[perm]); s.set_yref_all(yref[perm]); s.cold_start(); s.solve()
+    Xp, Up = s.get_iterate()
+    assert np.array_equal(Xp, X1[perm]) and np.array_equal(Up, U1[perm])
+    # one poisoned instance fails alone and keeps its iterate
+    xb = x0[perm].copy(); xb[5, 3] = np.nan
+    s.set_x0(xb); s.cold_start()
+    assert s.solve() == 4
+    st = s.get_stats("status")
+    assert st[5] == 4 and (np.delete(st, 5) == 0).all()
+    Xq, Uq = s.get_iterate()
+    assert np.array_equal(np.delete(Uq, 5, axis=0), np.delete(Up, 5, axis=0)) and (Uq[5] == 0).all()
+
+
+def test_pipeline_qp_in_and_r2():
+    """the linearisation kernel keeps A, B, b for get_from_qp_in; the attached covariance back-off runs behind the pipeline"""
+    from tum_control_amd import config
+    from tum_control_amd.r2nmpc import r2_setup
+    from tum_control_amd.workloads import nominal_batch
+    N, B = 38, 40
+    x0, yref = nominal_batch(B, N=N, seed=5, track_name="modena")
+    m, veh = config.MPC, config.VEH
+    S0, BWB = r2_setup(m["stds"], 0.08)
+    res = {}
+    for k in ("fused", "pipeline"):
+        s = _mk(N, B, k, store_qp_in=True)
+        s.r2_attach(S0, BWB, int(m["uncertainty_propagation_horizon"]), veh["delta_f_min"], veh["delta_f_max"], 1.0)
+        s.set_x0(x0); s.set_yref_all(yref); s.cold_start()
+        assert s.solve() == 0
+        A, Bm, b = s.get_from_qp_in(3, "A"), s.get_from_qp_in(3, "B"), s.get_from_qp_in(N - 1, "b")
+        uh = s.constraints_get(3, "uh")
+        assert s.solve() == 0
+        res[k] = (A, Bm, b, uh, s.get_iterate()[1])
+    for a, c in zip(res["fused"], res["pipeline"]):
+        np.testing.assert_allclose(a, c, rtol=1e-9, atol=2e-7)
+    assert res["pipeline"][3].max() < 1.0
+
+
+def test_pipeline_in_the_device_closed_loop(golden_dir):
+    """planner -> pipeline -> plant + estimator entirely on the device (hipGraph chunks of 25 steps) against the same loop on
+    the fused kernel"""
+    from tum_control_amd.closed_loop import ClosedLoopBatch
+    logs = {}
+    for k in ("fused", "pipeline"):
+        cl = ClosedLoopBatch("lvms", batch=4, N=38, Tp=3.04, on_device=True, log_capacity=80)
+        cl.solver.set_kernel(k)
+        logs[k] = cl.run(80)
+        assert cl.dev.graph_steps == 25
+    for f in ("simU", "CiLX", "MPC_SimX"):
+        np.testing.assert_allclose(logs["pipeline"][f], logs["fused"][f], rtol=1e-7, atol=1e-7, err_msg=f)
+    assert (logs["pipeline"]["simSolverDebug"][:, :, 4] == 0).all()
+    assert np.array_equal(logs["pipeline"]["simSolverDebug"][:, :, 3], logs["fused"]["simSolverDebug"][:, :, 3])

@@ -43,6 +43,9 @@ __host__ __device__ constexpr int lpk(int i, int j) { return i * (i + 1) / 2 + j
 // (The steering-angle rows need no storage: delta is a pure integrator of the steering rate, so
 //  row s of that block is dt on the odd (steering-rate) columns < 2s and 0 elsewhere.)
 __host__ __device__ constexpr int hoff(int s) { return s * (s - 1); }
+// the same rows as MFMA operands: (chunk c = rows 4c+1..4c+4, tile column T) pairs with c >= 2T, 30 of them
+constexpr int NCHV = 30;
+__host__ __device__ constexpr int chidx(int c, int T) { return (T == 0 ? 0 : T == 1 ? 8 : T == 2 ? 14 : T == 3 ? 18 : 20) + c; }
 
 // LDS carve (offsets in doubles). FOUR workgroups per CU (one wavefront on every SIMD) need <= 40 KiB each:
 // only the KKT matrix, the packed gg rows and a handful of vectors stay in LDS during the interior point

@@ -1,0 +1,973 @@
+// pipe_kernels.hpp -- the SQP-RTI step as a PIPELINE of four kernels, each at the occupancy its phase allows
+// (the fused kernel of nmpc_kernel.hpp runs every phase at the occupancy of its most demanding one: one wavefront per SIMD).
+//
+//   K1  lin_kernel      lane = (instance, stage): ERK4 x nsub with forward sensitivities, cost residuals, gg constraint.
+//                       Full lanes (the fused kernel has 41 of 64 busy), no LDS, two wavefronts per SIMD.
+//   K2  cond_kernel     one wavefront per OCP: column recursion G_{k+1} = A_k G_k, Gauss-Newton SYRK on the matrix cores
+//                       (15 register tiles), gg rows; hands H (tiles), C (MFMA operand layout), q, d to the workspace.
+//   K3  ipm_kernel      one wavefront per OCP, <= 256 registers and <= 27 KiB of LDS so that SIX OCPs share a CU (two
+//                       wavefronts on half of the SIMDs): the KKT matrix is the only large LDS resident, the gg rows live
+//                       in registers in MFMA operand layout, H is streamed tile by tile from the workspace (L2).
+//   K4  expand_kernel   one wavefront per OCP: dx recursion, full step, cost at the new iterate.
+//
+// Workspace per instance (HBM/L2): stage records 41 x 64 doubles, H 15 x 64 x 4, C 30 x 64, q | d | dv 3 x 80.
+// Reference semantics as in nmpc_kernel.hpp; the arithmetic of every phase is the fused kernel's.
+#pragma once
+#include "nmpc_device.hpp"
+
+namespace tum {
+
+constexpr int PREC = 64;                        // doubles per stage record
+// record fields: [0,1] Sp | [2..43] S[6][7] | [44..51] defect b | [52..55] cost residuals | [56..59] g3 g5 g7 h | [60] delta_f
+constexpr int PR_RES = 52, PR_GH = 56, PR_XD = 60;
+constexpr int NCH = NCHV;                       // (chunk, tile column) pairs of the gg-row operands (nmpc_device.hpp)
+__host__ __device__ constexpr int cidx(int c, int T) { return chidx(c, T); }
+constexpr int PV_Q = 0, PV_D = NVP, PV_DV = 2 * NVP, PVEC = 3 * NVP + 16;      // per-instance vectors: q | d | dv | [slack cost, ...]
+constexpr int PV_SC = 3 * NVP;
+
+struct PArgs {
+    KArgs ka;
+    double *rec;          // [b][N+1][PREC]
+    double *hws;          // [b][NTT][64][4]
+    double *cws;          // [b][NCH][64]
+    double *vec;          // [b][PVEC]
+};
+
+// ---------------------------------------------------------------------------------------------------------------- K1
+__global__ void __launch_bounds__(64, 1) lin_kernel(const PArgs pa)
+{
+    const KArgs &ka = pa.ka;
+    const int N = ka.N, NB = N + 1;
+    const long long g = (long long)blockIdx.x * 64 + threadIdx.x;
+    if (g >= (long long)ka.batch * NB) return;
+    const int b = (int)(g / NB), k = (int)(g - (long long)b * NB);
+    const double *gX = ka.X + ((size_t)b * NB + k) * NX;
+    double xk[8];
+#pragma unroll
+    for (int i = 0; i < 8; i++) xk[i] = gX[i];
+    const double *yr = ka.yref + ((size_t)b * NB + k) * 6;
+    double r[PREC];
+#pragma unroll
+    for (int i = 0; i < PREC; i++) r[i] = 0.0;
+    r[PR_RES + 0] = xk[0] - yr[0];
+    r[PR_RES + 1] = xk[1] - yr[1];
+    r[PR_RES + 2] = wrap_yaw(xk[2]) - yr[2];
+    r[PR_RES + 3] = xk[3] - yr[3];
+    r[PR_XD] = xk[6];
+    if (k >= 1) {
+        double h, g3, g5, g7;
+        h_con(ka.mp, xk[3], xk[5], xk[7], h, g3, g5, g7);
+        r[PR_GH + 0] = g3; r[PR_GH + 1] = g5; r[PR_GH + 2] = g7; r[PR_GH + 3] = h;
+    }
+    if (k < N) {
+        const double *gU = ka.U + ((size_t)b * N + k) * NU;
+        double uk[2] = {gU[0], gU[1]};
+        double xn[8], Sp[2], S[6][7];
+        rk4_sens(ka.mp, xk, uk, ka.dt, ka.nsub, xn, Sp, S);
+        r[0] = Sp[0]; r[1] = Sp[1];
+#pragma unroll
+        for (int i = 0; i < 6; i++)
+#pragma unroll
+            for (int c = 0; c < 7; c++) r[2 + i * 7 + c] = S[i][c];
+#pragma unroll
+        for (int i = 0; i < 8; i++) r[44 + i] = xn[i] - gX[NX + i];
+        if (ka.flags & 1) {   // full A (8x8), B (8x2), b (8) of this linearisation, row-major (get_from_qp_in)
+            double *q = ka.qpin + ((size_t)b * N + k) * 88;
+            for (int i = 0; i < 64; i++) q[i] = 0.0;
+            q[0 * 8 + 0] = 1.0; q[1 * 8 + 1] = 1.0; q[2 * 8 + 2] = 1.0; q[6 * 8 + 6] = 1.0; q[7 * 8 + 7] = 1.0;
+            q[0 * 8 + 2] = Sp[0]; q[1 * 8 + 2] = Sp[1];
+            for (int i = 0; i < 6; i++) {
+                for (int c = 0; c < 5; c++) q[i * 8 + 3 + c] = S[i][c];
+                q[64 + i * 2 + 0] = S[i][5]; q[64 + i * 2 + 1] = S[i][6];
+            }
+            q[64 + 6 * 2 + 0] = 0.0; q[64 + 6 * 2 + 1] = ka.dt; q[64 + 7 * 2 + 0] = ka.dt; q[64 + 7 * 2 + 1] = 0.0;
+            for (int i = 0; i < 8; i++) q[80 + i] = r[44 + i];
+        }
+    }
+    typedef double d2 __attribute__((ext_vector_type(2)));
+    d2 *dst = reinterpret_cast<d2 *>(pa.rec + (size_t)g * PREC);
+#pragma unroll
+    for (int i = 0; i < 31; i++) dst[i] = d2{r[2 * i], r[2 * i + 1]};
+}
+
+// ---------------------------------------------------------------------------------------------------------------- K2
+// LDS of the condensing kernel (doubles)
+constexpr int C_REC = 0;                        // 2 x PREC   stage record double buffer
+constexpr int C_STAGE = C_REC + 2 * PREC;       // 4 x NVP    staging rows of the SYRK
+constexpr int C_GS = C_STAGE + 4 * NVP;         // 8          g_s of the current stage
+constexpr int C_U0 = C_GS + 8;                  // NVP        iterate U
+constexpr int C_CH = C_U0 + NVP;                // NMAX*(NMAX+1) packed gg rows (staging for the operand layout)
+constexpr int C_LDS_DOUBLES = C_CH + NMAX * (NMAX + 1);
+
+__global__ void __launch_bounds__(64, 2) cond_kernel(const PArgs pa)
+{
+    __shared__ __attribute__((aligned(16))) double lds[C_LDS_DOUBLES];
+    const KArgs &ka = pa.ka;
+    const int lane = threadIdx.x, b = blockIdx.x;
+    if (b >= ka.batch) return;
+    const int N = ka.N, nv = 2 * N;
+    const double dt = ka.dt;
+    double *sRec = lds + C_REC, *sStage = lds + C_STAGE, *sGs = lds + C_GS, *sU0 = lds + C_U0, *sCh = lds + C_CH;
+    const double *grec = pa.rec + (size_t)b * (N + 1) * PREC;
+    const double *gx0 = ka.x0 + (size_t)b * NX;
+    const double *gX = ka.X + (size_t)b * (N + 1) * NX;
+    const double *gU = ka.U + (size_t)b * N * NU;
+    const double *gyref = ka.yref + (size_t)b * (N + 1) * 6;
+    const double *gW = ka.W + (size_t)b * 10;
+    double *gvec = pa.vec + (size_t)b * PVEC;
+
+    // stage slot k & 1: fields 0..51 of record k (A_k, B_k, b_k), fields 52..60 of record k+1 (residuals, gg row, delta of stage k+1)
+    auto fetch = [&](int k) -> double { return (lane < PR_RES) ? grec[(size_t)k * PREC + lane] : ((lane <= PR_XD) ? grec[(size_t)(k + 1) * PREC + lane] : 0.0); };
+    double pre = fetch(0);
+    sU0[lane] = (lane < nv) ? gU[lane] : 0.0;
+    if (lane < 16) sU0[64 + lane] = (64 + lane < nv) ? gU[64 + lane] : 0.0;
+    sRec[lane] = pre;
+    if (N > 1) pre = fetch(1);
+    wsync();
+
+    const int j0 = lane >> 1, r0 = lane & 1, j1 = 32 + (lane >> 1);
+    const bool isg = (lane == 16);
+    const int lq = lane >> 4, lc = lane & 15;
+    double q0 = 0.0, q1 = 0.0;
+    d4 Ht[NTT];
+    double Wd[6], We[4];
+#pragma unroll
+    for (int i = 0; i < 6; i++) Wd[i] = gW[i];
+#pragma unroll
+    for (int i = 0; i < 4; i++) We[i] = gW[6 + i];
+#pragma unroll
+    for (int i = 0; i < NTT; i++) Ht[i] = d4{0.0, 0.0, 0.0, 0.0};
+    {
+        double w0[8], w1[8];
+#pragma unroll
+        for (int i = 0; i < 8; i++) { w0[i] = 0.0; w1[i] = 0.0; }
+        if (isg) {
+#pragma unroll
+            for (int i = 0; i < 8; i++) w1[i] = gx0[i] - gX[i];
+        }
+        auto stage_body = [&](const int k, auto tsc) {
+            constexpr int Ts = decltype(tsc)::value;
+            const double *rec = sRec + (k & 1) * PREC;
+            apply_A2(rec, w0, w1);
+            {
+                const double sel0 = (j0 == k) ? 1.0 : 0.0, sel1 = (lane < 16 && j1 == k) ? 1.0 : 0.0, selg = isg ? 1.0 : 0.0;
+#pragma unroll
+                for (int i = 0; i < 6; i++) {
+                    const double bc = rec[2 + i * 7 + 5 + r0];
+                    w0[i] += sel0 * bc; w1[i] += sel1 * bc;
+                }
+                const double b6 = r0 ? dt : 0.0, b7 = r0 ? 0.0 : dt;
+                w0[6] += sel0 * b6; w0[7] += sel0 * b7; w1[6] += sel1 * b6; w1[7] += sel1 * b7;
+#pragma unroll
+                for (int i = 0; i < 8; i++) w1[i] += selg * rec[44 + i];
+            }
+            const int s = k + 1;                         // stage whose G_s the lanes now hold
+            const double sc = (s < N) ? dt : 1.0;
+            const double g3 = rec[PR_GH + 0], g5 = rec[PR_GH + 1], g7 = rec[PR_GH + 2];
+            const double hr0 = g3 * w0[3] + g5 * w0[5] + g7 * w0[7], hr1 = g3 * w1[3] + g5 * w1[5] + g7 * w1[7];
+            const double hd = rec[PR_GH + 3];
+            if (isg) {
+#pragma unroll
+                for (int i = 0; i < 8; i++) sGs[i] = w1[i];
+                gvec[PV_D + 2 * (s - 1)] = rec[PR_XD] + w1[6];
+                gvec[PV_D + 2 * (s - 1) + 1] = hd + hr1;
+            }
+            if (lane < 2 * s) sCh[hoff(s) + lane] = hr0;
+            if (lane < 16 && 64 + lane < 2 * s) sCh[hoff(s) + 64 + lane] = hr1;
+#pragma unroll
+            for (int r = 0; r < 4; r++) sStage[r * NVP + lane] = w0[r];
+            if (lane < 16) {
+#pragma unroll
+                for (int r = 0; r < 4; r++) sStage[r * NVP + 64 + lane] = w1[r];
+            }
+            wsync();
+            double wr[4];
+#pragma unroll
+            for (int r = 0; r < 4; r++) wr[r] = sc * ((s < N) ? Wd[r] : We[r]);
+            {
+                double a0 = 0.0, a1 = 0.0;
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    const double e = wr[r] * (rec[PR_RES + r] + sGs[r]);
+                    a0 += e * w0[r]; a1 += e * w1[r];
+                }
+                q0 += a0;
+                q1 += (lane < 16) ? a1 : 0.0;
+            }
+            const double wl = (lq == 0) ? wr[0] : (lq == 1) ? wr[1] : (lq == 2) ? wr[2] : wr[3];
+            double aop[Ts], bop[Ts];
+#pragma unroll
+            for (int T = 0; T < Ts; T++) {
+                bop[T] = sStage[lq * NVP + 16 * T + lc];
+                aop[T] = bop[T] * wl;
+            }
+#pragma unroll
+            for (int K = 0; K < Ts; K++)
+#pragma unroll
+                for (int I = K; I < Ts; I++) Ht[tidx(K, I)] = mfma(aop[K], bop[I], Ht[tidx(K, I)]);
+            // next stage's record into the other slot (its global load has been in flight for a whole stage)
+            sRec[((k + 1) & 1) * PREC + lane] = pre;
+            if (k + 2 < N) pre = fetch(k + 2);
+            wsync();
+        };
+        for (int k = 0; k < N && k < 8; k++) stage_body(k, std::integral_constant<int, 1>());
+        for (int k = 8; k < N && k < 16; k++) stage_body(k, std::integral_constant<int, 2>());
+        for (int k = 16; k < N && k < 24; k++) stage_body(k, std::integral_constant<int, 3>());
+        for (int k = 24; k < N && k < 32; k++) stage_body(k, std::integral_constant<int, 4>());
+        for (int k = 32; k < N; k++) stage_body(k, std::integral_constant<int, 5>());
+        for (int s = N + 1; s <= NMAX; s++)
+            for (int c = lane; c < 2 * s; c += 64) sCh[hoff(s) + c] = 0.0;
+    }
+    // input cost (R) and padding on the diagonal, gradient of the input cost
+#pragma unroll
+    for (int K = 0; K < NT; K++)
+#pragma unroll
+        for (int jj = 0; jj < 4; jj++) {
+            const int row = lq + 4 * jj;
+            if (row == lc) {
+                const int idx = 16 * K + row;
+                Ht[tidx(K, K)][jj] += (idx < nv) ? dt * Wd[4 + (idx & 1)] : 1.0;
+            }
+        }
+    if (lane < nv) q0 += dt * Wd[4 + r0] * (sU0[lane] - gyref[j0 * 6 + 4 + r0]);
+    if (lane < 16 && 64 + lane < nv) q1 += dt * Wd[4 + r0] * (sU0[64 + lane] - gyref[j1 * 6 + 4 + r0]);
+    // ---- hand-over: H tiles, q, the gg rows in MFMA operand layout (masked: entries right of a row's end are zero)
+    {
+        d4 *gh = reinterpret_cast<d4 *>(pa.hws) + (size_t)b * NTT * 64 + lane;
+#pragma unroll
+        for (int t = 0; t < NTT; t++) gh[t * 64] = Ht[t];
+        gvec[PV_Q + lane] = q0;
+        if (lane < 16) gvec[PV_Q + 64 + lane] = q1;
+        wsync();
+        double *gc = pa.cws + (size_t)b * NCH * 64 + lane;
+#pragma unroll
+        for (int T = 0; T < NT; T++)
+#pragma unroll
+            for (int c = 2 * T; c < 10; c++) {
+                const int s = 4 * c + lq + 1;
+                const double v = sCh[hoff(s) + 16 * T + lc];
+                gc[cidx(c, T) * 64] = (c >= 2 * T + 2) ? v : ((16 * T + lc < 2 * s) ? v : 0.0);
+            }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------- K4
+constexpr int E_REC = 0;                          // 2 x PREC
+constexpr int E_X = E_REC + 2 * PREC;             // (NMAX+1)*8
+constexpr int E_U = E_X + (NMAX + 1) * NX;        // NVP
+constexpr int E_DV = E_U + NVP;                   // NVP
+constexpr int E_LDS_DOUBLES = E_DV + NVP;
+
+__global__ void __launch_bounds__(64) expand_kernel(const PArgs pa)
+{
+    __shared__ __attribute__((aligned(16))) double lds[E_LDS_DOUBLES];
+    const KArgs &ka = pa.ka;
+    const int lane = threadIdx.x, b = blockIdx.x;
+    if (b >= ka.batch) return;
+    const int N = ka.N, nv = 2 * N;
+    const double dt = ka.dt;
+    double *sRec = lds + E_REC, *sX = lds + E_X, *sU1 = lds + E_U, *sDv = lds + E_DV;
+    const double *grec = pa.rec + (size_t)b * (N + 1) * PREC;
+    double *gX = ka.X + (size_t)b * (N + 1) * NX;
+    double *gU = ka.U + (size_t)b * N * NU;
+    const double *gx0 = ka.x0 + (size_t)b * NX;
+    const double *gyref = ka.yref + (size_t)b * (N + 1) * 6;
+    const double *gW = ka.W + (size_t)b * 10;
+    const double *gvec = pa.vec + (size_t)b * PVEC;
+    const int status = ka.status[b];
+    for (int i = lane; i < (N + 1) * NX; i += 64) sX[i] = gX[i];
+    for (int i = lane; i < NVP; i += 64) { sU1[i] = (i < nv) ? gU[i] : 0.0; sDv[i] = gvec[PV_DV + i]; }
+    double pre = (lane < PR_RES) ? grec[lane] : 0.0;
+    sRec[lane] = pre;
+    if (N > 1) pre = (lane < PR_RES) ? grec[PREC + lane] : 0.0;
+    const double gx0r = gx0[(lane < 8) ? lane : 0];
+    wsync();
+    if (status == 0) {
+        const int ri = (lane < 8) ? lane : 0;
+        const bool core = ri < 6;
+        const double diag = (ri < 3 || ri >= 6) ? 1.0 : 0.0;
+        double dxi = gx0r - sX[ri];
+        wsync();
+        if (lane < 8) sX[lane] += dxi;
+        for (int k = 0; k < N; k++) {
+            const double *rec = sRec + (k & 1) * PREC;
+            const double *Si = rec + 2 + (core ? ri : 0) * 7;
+            const double du0 = sDv[2 * k], du1 = sDv[2 * k + 1];
+            const double cpsi = (ri < 2) ? rec[ri] : 0.0;
+            double c0 = Si[0], c1 = Si[1], c2 = Si[2], c3 = Si[3], c4 = Si[4], c5 = Si[5], c6 = Si[6];
+            if (!core) { c0 = c1 = c2 = c3 = c4 = 0.0; c5 = (ri == 7) ? dt : 0.0; c6 = (ri == 6) ? dt : 0.0; }
+            const double bi = rec[44 + ri];
+            const double x2 = rl(dxi, 2), x3 = rl(dxi, 3), x4 = rl(dxi, 4), x5 = rl(dxi, 5), x6 = rl(dxi, 6), x7 = rl(dxi, 7);
+            double acc0 = diag * dxi + cpsi * x2 + bi;
+            double acc1 = c5 * du0 + c6 * du1;
+            acc0 += c0 * x3; acc1 += c1 * x4;
+            acc0 += c2 * x5; acc1 += c3 * x6;
+            acc0 += c4 * x7;
+            dxi = acc0 + acc1;
+            if (lane < 8) sX[(k + 1) * NX + lane] += dxi;
+            sRec[((k + 1) & 1) * PREC + lane] = pre;
+            if (k + 2 < N) pre = (lane < PR_RES) ? grec[(size_t)(k + 2) * PREC + lane] : 0.0;
+            wsync();
+        }
+        sU1[lane] += sDv[lane];
+        if (lane < 16) sU1[64 + lane] += sDv[64 + lane];
+    }
+    wsync();
+    double cl = (lane == 0) ? gvec[PV_SC] : 0.0;      // slack part of the cost (interior point kernel)
+    if (lane <= N) {
+        double Wd[6], We[4], yr[6];
+#pragma unroll
+        for (int i = 0; i < 6; i++) { Wd[i] = gW[i]; yr[i] = gyref[lane * 6 + i]; }
+#pragma unroll
+        for (int i = 0; i < 4; i++) We[i] = gW[6 + i];
+        const int k = lane;
+        const double sc = (k < N) ? dt : 1.0;
+        double acc = 0.0, e;
+        e = sX[k * NX + 0] - yr[0]; acc += ((k < N) ? Wd[0] : We[0]) * e * e;
+        e = sX[k * NX + 1] - yr[1]; acc += ((k < N) ? Wd[1] : We[1]) * e * e;
+        e = wrap_yaw(sX[k * NX + 2]) - yr[2]; acc += ((k < N) ? Wd[2] : We[2]) * e * e;
+        e = sX[k * NX + 3] - yr[3]; acc += ((k < N) ? Wd[3] : We[3]) * e * e;
+        if (k < N) {
+            e = sU1[2 * k] - yr[4]; acc += Wd[4] * e * e;
+            e = sU1[2 * k + 1] - yr[5]; acc += Wd[5] * e * e;
+        }
+        cl += 0.5 * sc * acc;
+    }
+    const double cost = wave_sum(cl);
+    for (int i = lane; i < (N + 1) * NX; i += 64) gX[i] = sX[i];
+    for (int i = lane; i < nv; i += 64) gU[i] = sU1[i];
+    if (lane == 0) ka.cost[b] = cost;
+}
+
+// ---------------------------------------------------------------------------------------------------------------- K3
+// LDS of the interior point kernel (doubles): the small vectors first (the diagonal-block substitution reads up to 15 doubles
+// in front of a packed row with a zero multiplier: in front of row 0 that lands on them, finite data), then the KKT matrix.
+constexpr int I_WH = 0;                           // NMAX     gamma / weights / C dv of the gg rows (index stage - 1)
+constexpr int I_WB = I_WH + NMAX;                 // NMAX     box-row scalars
+constexpr int I_SFX = I_WB + NMAX;                // NMAX+2   suffix sums over the steering-angle rows
+constexpr int I_DV = I_WB;                        //   (alias: a v-space vector lives here between a solve and the next publish;
+                                                  //    the box scalars and suffix sums are dead in that window)
+constexpr int I_DUMMY = I_SFX + NMAX + 2;         // 1        target of masked-off stores
+constexpr int I_PZ = I_DUMMY + 1;                 // 18       quadratic slack penalties Zl, Zu of the 9 (class, row type) pairs
+constexpr int I_M = I_PZ + 18;                    // LPK      KKT matrix / L D L' factor
+constexpr int I_LDS_DOUBLES = I_M + LPK;
+constexpr int I_LDS_BYTES = I_LDS_DOUBLES * 8;
+static_assert(NVP <= 2 * NMAX + 2, "the v-space alias must fit in the box / suffix buffers");
+static_assert(((I_LDS_BYTES + 511) / 512 * 512) * 6 <= 160 * 1024, "six workgroups per CU");
+
+// lane-derived quantities of the interior point kernel (instantiated from an opaque copy of the lane id inside the loop, see
+// TUM_LANE_DEFS in nmpc_kernel.hpp). The gg rows are held in registers in MFMA operand layout: chv[cidx(c, T)] of lane
+// (lq, lc) is entry (row 4c+lq+1, column 16T+lc), zero right of the row's end.
+#define PIPE_LANE_DEFS \
+    const bool boxlane = lane < N; \
+    const bool gglane = lane >= NMAX && lane < NMAX + 20; \
+    const int gj = gglane ? lane - NMAX : 0; \
+    const int stg0 = gglane ? 2 * gj + 1 : lane, stg1 = gglane ? 2 * gj + 2 : lane + 1; \
+    const bool on0 = gglane ? (stg0 <= N) : boxlane, on1 = gglane ? (stg1 <= N) : boxlane; \
+    const int ty0 = gglane ? 2 : 0, ty1 = gglane ? 2 : 1; \
+    const int pc0 = gglane ? ((stg0 < N) ? 1 : 2) : ((lane == 0) ? 0 : 1), pc1 = (stg1 < N) ? 1 : 2; \
+    const double psc0 = (gglane && stg0 >= N) ? 1.0 : dt, psc1 = (stg1 < N) ? dt : 1.0; \
+    const int pix0 = (pc0 * 3 + ty0) * 4, pix1 = (pc1 * 3 + ty1) * 4; \
+    auto pen = [&](int slot, int sd, int quad) -> double {   /* z from the workspace (start / end of the solve), Z from LDS */ \
+        const int pix = (slot == 0 ? pix0 : pix1); \
+        return (slot == 0 ? psc0 : psc1) * (quad ? sPZ[(pix >> 1) + sd] : gpen[pix + sd]); \
+    }; \
+    const bool v0on = lane < nv, v1on = (lane < 16) && (64 + lane < nv); \
+    const bool odd = lane & 1; \
+    auto ctw = [&](double &o0, double &o1) {   /* C' w for this lane's columns */ \
+        double a0 = (odd && v0on) ? sWb[lane >> 1] + dt * sSfx[(lane >> 1) + 1] : 0.0; \
+        double a1 = (odd && v1on) ? sWb[32 + (lane >> 1)] + dt * sSfx[32 + (lane >> 1) + 1] : 0.0; \
+        double wv[10]; \
+    _Pragma("unroll") \
+        for (int c = 0; c < 10; c++) wv[c] = sWh[4 * c + lq]; \
+        double t[NT]; \
+    _Pragma("unroll") \
+        for (int T = 0; T < NT; T++) { \
+            double e0 = 0.0, e1 = 0.0; \
+    _Pragma("unroll") \
+            for (int c = 2 * T; c < 10; c++) { if (c & 1) e1 += chv[cidx(c, T)] * wv[c]; else e0 += chv[cidx(c, T)] * wv[c]; } \
+            t[T] = quad_sum(e0 + e1); \
+        } \
+        a0 += (lq == 0) ? t[0] : (lq == 1) ? t[1] : (lq == 2) ? t[2] : t[3]; \
+        a1 += t[4]; \
+        o0 = v0on ? a0 : 0.0; o1 = v1on ? a1 : 0.0; \
+    }; \
+    auto publish = [&](double w0_, double w1_, double *dstH) { \
+        const double sfx = wave_suffix(boxlane ? w1_ : 0.0, lane); \
+        wsync(); \
+        if (lane < NMAX) sWb[lane] = boxlane ? w0_ : 0.0; \
+        if (lane < NMAX + 1) sSfx[lane + 1] = (lane < N) ? sfx : 0.0; \
+        if (gglane) { dstH[2 * gj] = on0 ? w0_ : 0.0; dstH[2 * gj + 1] = on1 ? w1_ : 0.0; } \
+        wsync(); \
+    }; \
+    int rb[NT]; \
+    _Pragma("unroll") \
+    for (int I = 0; I < NT; I++) rb[I] = lpk(16 * I + lc, 0); \
+    const int lane1 = 64 + lc;
+
+#ifndef IPM_WPS
+#define IPM_WPS 1
+#endif
+template <bool PROF>
+__global__ void __launch_bounds__(64, IPM_WPS) ipm_kernel(const PArgs pa)
+{
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    const KArgs &ka = pa.ka;
+    const int lane = threadIdx.x;
+    if ((int)blockIdx.x >= ka.batch) return;
+    const int b = ka.order ? ka.order[blockIdx.x] : (int)blockIdx.x;
+    const int N = ka.N, nv = 2 * N;
+    const double dt = ka.dt;
+    double p_mu0 = ka.mu0, p_t0 = ka.t0, p_reg = ka.reg, p_ts = ka.tol_stat, p_ti = ka.tol_ineq, p_tc = ka.tol_comp;
+    int p_itmax = ka.iter_max;
+    asm volatile("" : "+v"(p_mu0), "+v"(p_t0), "+v"(p_reg), "+v"(p_ts), "+v"(p_ti), "+v"(p_tc), "+v"(p_itmax));
+
+    double *sPZ = lds + I_PZ;
+    double *sM = lds + I_M, *sWh = lds + I_WH, *sGamH = lds + I_WH, *sWb = lds + I_WB, *sSfx = lds + I_SFX, *sDv = lds + I_DV;
+    const double *gU = ka.U + (size_t)b * N * NU;
+    const double *gpen = ka.pen + (size_t)b * 36;
+    const double *gbnd = ka.bnd + (size_t)b * 6 * (N + 1);
+    double *gvec = pa.vec + (size_t)b * PVEC;
+    const d4 *ghws = reinterpret_cast<const d4 *>(pa.hws) + (size_t)b * NTT * 64 + lane;
+
+    long long pacc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    long long tprev = __builtin_readcyclecounter();
+    for (int i = lane; i < I_PZ; i += 64) lds[i] = 0.0;
+    if (lane < 18) sPZ[lane] = gpen[(lane >> 1) * 4 + 2 + (lane & 1)];
+    // the gg rows, MFMA operand layout (30 coalesced loads). They are needed by the KKT assembly and by the row phases, not by
+    // the factorisation: every iteration re-reads them from the workspace (L2) after the factorisation instead of holding 60
+    // registers across it (the register file is the resource that decides whether two wavefronts share a SIMD).
+    double chv[NCH];
+    const double *gcw = pa.cws + (size_t)b * NCH * 64 + lane;
+#pragma unroll
+    for (int i = 0; i < NCH; i++) chv[i] = gcw[i * 64];
+    const double q0 = gvec[PV_Q + lane], q1 = (lane < 16) ? gvec[PV_Q + 64 + lane] : 0.0;
+    const int lq = lane >> 4, lc = lane & 15;
+    wsync();
+
+    double v0 = 0.0, v1 = 0.0, rv0, rv1, qn;
+    double rowst[6][4];      // IPM row state of this lane: [s, t, lam, mu, rs, rt][slot*2+side]
+    const double npairs = 12.0 * N;
+    const double inv_npairs = 1.0 / npairs;
+    int it = 0, qp_status = 1;
+    double res_stat = 0.0, res_ineq = 0.0, res_comp = 0.0;
+    {
+        PIPE_LANE_DEFS
+        {
+            const int NB = N + 1;
+            double dval[2], lo[2], hi[2];
+            {
+                const int i0 = on0 ? stg0 : (gglane ? 1 : 0), i1 = on1 ? stg1 : 1;
+                dval[0] = gglane ? gvec[PV_D + 2 * (i0 - 1) + 1] : gU[2 * i0 + 1];
+                lo[0] = gbnd[(gglane ? 4 : 0) * NB + i0]; hi[0] = gbnd[(gglane ? 5 : 1) * NB + i0];
+                dval[1] = gglane ? gvec[PV_D + 2 * (i1 - 1) + 1] : gvec[PV_D + 2 * (i1 - 1)];
+                lo[1] = gbnd[(gglane ? 4 : 2) * NB + i1]; hi[1] = gbnd[(gglane ? 5 : 3) * NB + i1];
+            }
+#pragma unroll
+            for (int rr = 0; rr < 2; rr++)
+#pragma unroll
+                for (int sd = 0; sd < 2; sd++) {
+                    const int k = rr * 2 + sd;
+                    const bool on = rr ? on1 : on0;
+                    const double eps = sd ? -1.0 : 1.0, bnd = sd ? hi[rr] : lo[rr];
+                    const double r0v = eps * (dval[rr] - bnd);
+                    const double z = pen(rr, sd, 0), Z = pen(rr, sd, 1);
+                    const double s0 = p_mu0 / (z > 1e-6 ? z : 1e-6);
+                    double t = r0v + s0;
+                    if (t < p_t0) t = p_t0;
+                    const double lam = p_mu0 / t;
+                    double ms = z + Z * s0 - lam;
+                    const double msf = 1e-2 * p_mu0 / s0;
+                    if (ms < msf) ms = msf;
+                    ROWF(0, k) = on ? s0 : 1.0; ROWF(1, k) = on ? t : 1.0; ROWF(2, k) = on ? lam : 1.0; ROWF(3, k) = on ? ms : 1.0;
+                    ROWF(4, k) = on ? z + Z * s0 - lam - ms : 0.0;
+                    ROWF(5, k) = on ? t - r0v - s0 : 0.0;
+                }
+        }
+        wsync();
+        publish(ROWF(2, 0) - ROWF(2, 1), ROWF(2, 2) - ROWF(2, 3), sWh);
+        {
+            double c0, c1;
+            ctw(c0, c1);
+            rv0 = v0on ? q0 - c0 : 0.0; rv1 = v1on ? q1 - c1 : 0.0;
+        }
+        qn = wave_max(fmax(fabs(q0), (lane < 16) ? fabs(q1) : 0.0));
+        if (qn < 1.0) qn = 1.0;
+    }
+    TUM_TICK(1);
+    const int lane_outer = lane;
+    for (;; it++) {
+        int lane_v = lane_outer;
+        asm volatile("" : "+v"(lane_v));
+        const int lane = lane_v;
+        const int lq = lane >> 4, lc = lane & 15;
+        PIPE_LANE_DEFS
+        // ---- row phase A: residual norms, gamma
+        double gap;
+        {
+            double ls = fmax(fabs(rv0), fabs(rv1)), li = 0.0, lcmp = 0.0, lg = 0.0;
+            double gsum[2];
+#pragma unroll
+            for (int rr = 0; rr < 2; rr++) {
+                gsum[rr] = 0.0;
+                const bool on = rr ? on1 : on0;
+#pragma unroll
+                for (int sd = 0; sd < 2; sd++) {
+                    const int k = rr * 2 + sd;
+                    const double s_ = ROWF(0, k), t_ = ROWF(1, k), l_ = ROWF(2, k), m_ = ROWF(3, k);
+                    ls = fmax(ls, on ? fabs(ROWF(4, k)) : 0.0);
+                    li = fmax(li, on ? fabs(ROWF(5, k)) : 0.0);
+                    const double c1 = t_ * l_, c2 = s_ * m_;
+                    lcmp = fmax(lcmp, on ? fmax(c1, c2) : 0.0);
+                    lg += on ? c1 + c2 : 0.0;
+                    // D = 1/(Z s + mu), G = 1/(t + lam s D): recomputed behind the factorisation rather than held across it
+                    const double D_ = frcp(pen(rr, sd, 1) * s_ + m_);
+                    gsum[rr] += l_ * frcp(t_ + l_ * s_ * D_);
+                }
+            }
+            res_stat = ls; res_ineq = li; res_comp = lcmp;
+            gap = wave_sum(lg) * inv_npairs;
+            const bool lane_nan = !(ls == ls) || !(li == li) || !(lcmp == lcmp);
+            if (__any(lane_nan) || !(gap == gap)) { qp_status = 3; break; }
+            const bool lane_open = (ls > p_ts * qn) || (li > p_ti) || (lcmp > p_tc);
+            if (!__any(lane_open)) { qp_status = 0; break; }
+            if (it >= p_itmax) { qp_status = 1; break; }
+            TUM_TICK(2);
+            publish(gsum[0], gsum[1], sGamH);
+        }
+        // ---- M = H + C' Gamma C, tile columns outermost; H streamed from the workspace two tiles ahead
+        {
+            double gch[10];
+#pragma unroll
+            for (int c = 0; c < 10; c++) gch[c] = sGamH[4 * c + lq];
+            const double dt2 = dt * dt;
+            // H comes back from the workspace HD tiles ahead of its use (tile order (0,0) (0,1) (1,1) (0,2) ...: tile n of that
+            // order is (K, I) with n = I (I + 1) / 2 + K)
+            constexpr int HD = 4;
+            auto hseq = [&](const int n) -> d4 {
+                int I2 = 0;
+                while ((I2 + 1) * (I2 + 2) / 2 <= n) I2++;
+                return ghws[tidx(n - I2 * (I2 + 1) / 2, I2) * 64];
+            };
+            d4 hq[HD];
+#pragma unroll
+            for (int n = 0; n < HD; n++) hq[n] = hseq(n);
+#pragma unroll
+            for (int I = 0; I < NT; I++) {
+                const int col = 16 * I + lc;
+                const double sfxoI = ((lq & 1) && (lc & 1) && col < nv) ? dt2 * sSfx[(col >> 1) + 1] : 0.0;
+                // gamma-scaled operands of tile column I (at most 10, reused by every K <= I; scaling the column operand
+                // instead of the row operand keeps the number of live products at 10 instead of 30)
+                double bs[10];
+#pragma unroll
+                for (int c = 2 * I; c < 10; c++) bs[c] = chv[cidx(c, I)] * gch[c];
+#pragma unroll
+                for (int K = 0; K <= I; K++) {
+                    const int n = I * (I + 1) / 2 + K;
+                    d4 acc = hq[n % HD];
+                    if (n + HD < NTT) hq[n % HD] = hseq(n + HD);
+                    if (K == I) {
+#pragma unroll
+                        for (int jj = 0; jj < 4; jj++) {
+                            const int row = 16 * K + lq + 4 * jj;
+                            const int mx = (row > col) ? row : col;
+                            const double sf = sSfx[(mx >> 1) + 1];
+                            double add = ((row & 1) && (col & 1) && mx < nv) ? dt2 * sf : 0.0;
+                            const double wb = sWb[(row >> 1) < NMAX ? (row >> 1) : 0];
+                            if (row == col) add += p_reg + (((row & 1) && row < nv) ? wb : 0.0);
+                            acc[jj] += add;
+                        }
+                    } else {
+#pragma unroll
+                        for (int jj = 0; jj < 4; jj++) acc[jj] += sfxoI;
+                    }
+#pragma unroll
+                    for (int c = 2 * I; c < 10; c++) acc = mfma(chv[cidx(c, K)], bs[c], acc);
+#pragma unroll
+                    for (int jj = 0; jj < 4; jj++) {
+                        const int rg = 16 * K + lq + 4 * jj, cg = 16 * I + lc;
+                        if (K < I) sM[rb[I] + rg] = acc[jj];
+                        else sM[(cg >= rg) ? rb[I] + rg : (I_DUMMY - I_M)] = acc[jj];
+                    }
+                }
+            }
+        }
+        wsync();
+        TUM_TICK(3);
+        // ---- blocked L D L' factorisation (as in the fused kernel: row-panel register tiles, 4-column micro-panels)
+        double dmin = 1.0;
+#pragma unroll
+        for (int J = 0; J < NT; J++) {
+            d4 T[NT];
+#pragma unroll
+            for (int I = J; I < NT; I++) {
+#pragma unroll
+                for (int jj = 0; jj < 4; jj++) {
+                    const int r = lq + 4 * jj;
+                    if (I > J) T[I][jj] = sM[rb[I] + 16 * J + r];
+                    else { const int hi = (r > lc) ? r : lc, lo = (r > lc) ? lc : r; T[I][jj] = sM[lpk(16 * J + hi, 16 * J + lo)]; }
+                }
+            }
+#pragma unroll
+            for (int K = 0; K < J; K++)
+#pragma unroll
+                for (int kc = 0; kc < 4; kc++) {
+                    const int kk = 16 * K + 4 * kc + lq;
+                    const double aJ = -sM[rb[J] + kk] * sM[lpk(kk, kk)];
+#pragma unroll
+                    for (int I = J; I < NT; I++) T[I] = mfma(aJ, sM[rb[I] + kk], T[I]);
+                }
+#pragma unroll
+            for (int m = 0; m < 4; m++) {
+                const int c0 = 16 * J + 4 * m;
+#pragma unroll
+                for (int I = J; I < NT; I++)
+                    sM[(I > J || lc >= 4 * m + lq) ? rb[I] + c0 + lq : (I_DUMMY - I_M)] = T[I][m];
+                wsync();
+                const int r1 = lpk(c0 + 1, c0), r2 = lpk(c0 + 2, c0), r3 = lpk(c0 + 3, c0);
+                const double a00 = sM[lpk(c0, c0)];
+                const double a10 = sM[r1], a11 = sM[r1 + 1];
+                const double a20 = sM[r2], a21 = sM[r2 + 1], a22 = sM[r2 + 2];
+                const double a30 = sM[r3], a31 = sM[r3 + 1], a32 = sM[r3 + 2], a33 = sM[r3 + 3];
+                const int row = c0 + 4 + lane;
+                const bool rin = row < NVP;
+                const int rbase = lpk(rin ? row : NVP - 1, c0);
+                double e0 = sM[rbase], e1 = sM[rbase + 1], e2 = sM[rbase + 2], e3 = sM[rbase + 3];
+                const bool two = (J == 0) && (m < 3);
+                const int row1 = c0 + 68 + lane;
+                const bool rin1 = two && (row1 < NVP);
+                const int rbase1 = lpk(rin1 ? row1 : NVP - 1, c0);
+                double f0 = 0, f1 = 0, f2 = 0, f3 = 0;
+                if (two) { f0 = sM[rbase1]; f1 = sM[rbase1 + 1]; f2 = sM[rbase1 + 2]; f3 = sM[rbase1 + 3]; }
+                const double d0 = a00, i0 = frcp(d0);
+                const double l10 = a10 * i0, l20 = a20 * i0, l30 = a30 * i0;
+                const double d1 = a11 - l10 * a10, i1 = frcp(d1);
+                const double y21 = a21 - l20 * a10, y31 = a31 - l30 * a10;
+                const double l21 = y21 * i1, l31 = y31 * i1;
+                const double d2 = a22 - l20 * a20 - l21 * y21, i2 = frcp(d2);
+                const double y32 = a32 - l30 * a20 - l31 * y21;
+                const double l32 = y32 * i2;
+                const double d3 = a33 - l30 * a30 - l31 * y31 - l32 * y32, i3 = frcp(d3);
+                dmin = fmin(dmin, fmin(fmin(d0, d1), fmin(d2, d3)));
+                e1 -= l10 * e0; e2 -= l20 * e0 + l21 * e1; e3 -= l30 * e0 + l31 * e1 + l32 * e2;
+                if (rin) { sM[rbase] = e0 * i0; sM[rbase + 1] = e1 * i1; sM[rbase + 2] = e2 * i2; sM[rbase + 3] = e3 * i3; }
+                if (two) {
+                    f1 -= l10 * f0; f2 -= l20 * f0 + l21 * f1; f3 -= l30 * f0 + l31 * f1 + l32 * f2;
+                    if (rin1) { sM[rbase1] = f0 * i0; sM[rbase1 + 1] = f1 * i1; sM[rbase1 + 2] = f2 * i2; sM[rbase1 + 3] = f3 * i3; }
+                }
+                if (lane == 0) {
+                    sM[r1] = l10; sM[r2] = l20; sM[r2 + 1] = l21; sM[r3] = l30; sM[r3 + 1] = l31; sM[r3 + 2] = l32;
+                    sM[lpk(c0, c0)] = d0; sM[lpk(c0 + 1, c0 + 1)] = d1; sM[lpk(c0 + 2, c0 + 2)] = d2; sM[lpk(c0 + 3, c0 + 3)] = d3;
+                }
+                wsync();
+                if (m < 3) {
+                    const double dsel = (lq == 0) ? d0 : (lq == 1) ? d1 : (lq == 2) ? d2 : d3;
+                    const int kcol = c0 + lq;
+                    const int rowJ = 16 * J + lc;
+                    const double bl = sM[lpk(rowJ, kcol)];
+                    const double bval = (rowJ > kcol) ? bl : ((rowJ == kcol) ? 1.0 : 0.0);
+#pragma unroll
+                    for (int I = J; I < NT; I++) {
+                        double aval;
+                        if (I == J) aval = bval;
+                        else aval = sM[rb[I] + kcol];
+                        T[I] = mfma(-bval * dsel, aval, T[I]);
+                    }
+                }
+            }
+        }
+        // (a failed factorisation -- a pivot that is not positive -- is acted upon after the parked registers are back:
+        //  leaving the loop here would keep all of them alive across the factorisation for the code behind the loop)
+        // bounded to two wavefronts per SIMD (IPM_WPS 2) the gg rows come back now, their latency running under the block
+        // inverses; with the whole register file (IPM_WPS 1) they simply stay
+        if (IPM_WPS > 1) {
+            const double *gc2 = gcw;
+            asm volatile("" : "+v"(gc2));          // (opaque: the reload must stay behind the micro-panels)
+#pragma unroll
+            for (int i = 0; i < NCH; i++) chv[i] = gc2[i * 64];
+        }
+        // ---- inverses of the unit-lower 16x16 diagonal blocks, in place
+        {
+            auto inv_diag = [&](const int g, const bool own) {
+                const int gb = g & ~15, cl = g & 15;
+                double X[16];
+#pragma unroll
+                for (int k = 0; k < 16; k++) X[k] = (k == cl) ? 1.0 : 0.0;
+                int rowb = lpk(gb, gb);
+                int rows[16];
+#pragma unroll
+                for (int r = 1; r < 16; r++) {
+                    rowb += gb + r;
+                    rows[r] = rowb;
+                    double a0 = 0.0, a1 = 0.0;
+#pragma unroll
+                    for (int k = 0; k < r; k++) {
+                        if (k & 1) a1 += sM[rowb + k] * X[k]; else a0 += sM[rowb + k] * X[k];
+                    }
+                    X[r] -= a0 + a1;
+                }
+                wsync();
+#pragma unroll
+                for (int r = 1; r < 16; r++) sM[(own && r > cl) ? rows[r] + cl : (I_DUMMY - I_M)] = X[r];
+                wsync();
+            };
+            inv_diag(lane, true);
+            inv_diag(lane1, lane < 16);
+        }
+        TUM_TICK(4);
+
+        if (!(dmin > 1e-300)) { qp_status = 3; break; }
+        // ---- predictor / corrector
+        double rD[4], rG[4];       // D, G of every row side: fixed for both solves of this iteration
+        {
+            int lane_r = lane_outer;
+            asm volatile("" : "+v"(lane_r));
+            const int lane = lane_r;
+            const int lq = lane >> 4, lc = lane & 15;
+            PIPE_LANE_DEFS
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                rD[k] = frcp(pen(k >> 1, k & 1, 1) * ROWF(0, k) + ROWF(3, k));
+                rG[k] = frcp(ROWF(1, k) + ROWF(2, k) * ROWF(0, k) * rD[k]);
+            }
+        }
+        double cross1[4], cross2[4];
+        double dv0 = 0.0, dv1 = 0.0, alpha = 1.0, sigma = 0.0;
+#pragma unroll 1
+        for (int pass = 0; pass < 2; pass++) {
+            int lane_p = lane_outer;
+            asm volatile("" : "+v"(lane_p));
+            const int lane = lane_p;
+            const int lq = lane >> 4, lc = lane & 15;
+            PIPE_LANE_DEFS
+            const double tau = (pass == 1) ? fmax(sigma * gap, 0.1 * p_tc) : 0.0;
+            {
+                double w[2];
+#pragma unroll
+                for (int rr = 0; rr < 2; rr++) {
+                    w[rr] = 0.0;
+#pragma unroll
+                    for (int sd = 0; sd < 2; sd++) {
+                        const int k = rr * 2 + sd;
+                        const double s_ = ROWF(0, k), t_ = ROWF(1, k), l_ = ROWF(2, k), m_ = ROWF(3, k);
+                        const double D = rD[k], G = rG[k];
+                        double rc1 = t_ * l_, rc2 = s_ * m_;
+                        if (pass == 1) { rc1 += cross1[k] - tau; rc2 += cross2[k] - tau; }
+                        const double gr = G * (rc1 - l_ * (ROWF(5, k) + (ROWF(4, k) * s_ + rc2) * D));
+                        w[rr] += sd ? -gr : gr;
+                    }
+                }
+                publish(w[0], w[1], sWh);
+            }
+            double b0, b1;
+            ctw(b0, b1);
+            b0 = v0on ? -rv0 - b0 : 0.0; b1 = v1on ? -rv1 - b1 : 0.0;
+            TUM_TICK(5);
+            {
+                int ga[4];
+#pragma unroll
+                for (int jj = 0; jj < 4; jj++) ga[jj] = ((lane & 48) | ((lq + 4 * jj) & 15)) << 2;
+                const bool ondiag = (lc >= lq) && (((lc - lq) & 3) == 0);
+                double bj[NT], vs[NT][4];
+#pragma unroll
+                for (int J = 0; J < 4; J++) bj[J] = lane_gather(b0, (16 * J + lc) << 2);
+                bj[4] = lane_gather(b1, lc << 2);
+#pragma unroll
+                for (int J = 0; J < NT; J++) {
+                    double t = bj[J];
+                    if (J > 0) {
+                        double acc = 0.0, acc1 = 0.0;
+#pragma unroll
+                        for (int K = 0; K < J; K++)
+#pragma unroll
+                            for (int jj = 0; jj < 4; jj++) {
+                                const double lv = sM[rb[J] + 16 * K + lq + 4 * jj];
+                                if (jj & 1) acc1 += lv * vs[K][jj]; else acc += lv * vs[K][jj];
+                            }
+                        t -= quad_sum(acc + acc1);
+                    }
+                    double a2 = ondiag ? t : 0.0;
+#pragma unroll
+                    for (int jj = 0; jj < 4; jj++) {
+                        const double lv = sM[rb[J] + 16 * J + lq + 4 * jj];
+                        const double tv = lane_gather(t, ga[jj]);
+                        a2 += ((lq + 4 * jj < lc) ? lv : 0.0) * tv;
+                    }
+                    const double y = quad_sum(a2);
+                    bj[J] = y * frcp(sM[rb[J] + 16 * J + lc]);
+                    if (J < NT - 1) {
+#pragma unroll
+                        for (int jj = 0; jj < 4; jj++) vs[J][jj] = lane_gather(y, ga[jj]);
+                    }
+                }
+#pragma unroll
+                for (int J = NT - 1; J >= 0; J--) {
+                    double t = bj[J];
+                    if (J < NT - 1) {
+                        double acc = 0.0, acc1 = 0.0;
+#pragma unroll
+                        for (int I = J + 1; I < NT; I++)
+#pragma unroll
+                            for (int jj = 0; jj < 4; jj++) {
+                                const double lv = sM[lpk(16 * I + lq + 4 * jj, 0) + 16 * J + lc];
+                                if (jj & 1) acc1 += lv * vs[I][jj]; else acc += lv * vs[I][jj];
+                            }
+                        t -= quad_sum(acc + acc1);
+                    }
+                    double a2 = ondiag ? t : 0.0;
+#pragma unroll
+                    for (int jj = 0; jj < 4; jj++) {
+                        const double lv = sM[lpk(16 * J + lq + 4 * jj, 0) + 16 * J + lc];
+                        const double tv = lane_gather(t, ga[jj]);
+                        a2 += ((lq + 4 * jj > lc) ? lv : 0.0) * tv;
+                    }
+                    const double x = quad_sum(a2);
+                    bj[J] = x;
+                    if (J > 0) {
+#pragma unroll
+                        for (int jj = 0; jj < 4; jj++) vs[J][jj] = lane_gather(x, ga[jj]);
+                    }
+                }
+                b0 = (lq == 0) ? bj[0] : (lq == 1) ? bj[1] : (lq == 2) ? bj[2] : bj[3];
+                b1 = (lane < 16) ? bj[4] : 0.0;
+            }
+            dv0 = b0; dv1 = b1;
+            TUM_TICK(6);
+            wsync();
+            sDv[lane] = dv0;
+            if (lane < 16) sDv[64 + lane] = dv1;
+            wsync();
+            // row phase B2: C*dv for this lane's rows, step in (s,t,lam,mu), step length
+            double cdv[2];
+            {
+                const double xo = boxlane ? sDv[2 * lane + 1] : 0.0;
+                const double pfx = dt * wave_prefix(xo, lane);
+                // gg rows from the operand registers: this lane's partial sums over its column of every tile, then a 16-lane
+                // row reduction per chunk (row_shr 8, 4, 2, 1: lane 15 of a DPP row ends up with the row total of rows 4c+lq+1)
+                double dvT[NT];
+#pragma unroll
+                for (int T = 0; T < NT; T++) dvT[T] = sDv[16 * T + lc];
+                double pr[10];
+#pragma unroll
+                for (int c = 0; c < 10; c++) {
+                    double a = 0.0;
+#pragma unroll
+                    for (int T = 0; 2 * T <= c; T++) a += chv[cidx(c, T)] * dvT[T];
+                    a += row_shr<8>(a); a += row_shr<4>(a); a += row_shr<2>(a); a += row_shr<1>(a);
+                    pr[c] = a;
+                }
+                wsync();
+                if (lc == 15) {
+#pragma unroll
+                    for (int c = 0; c < 10; c++) sWh[4 * c + lq] = pr[c];
+                }
+                wsync();
+                cdv[0] = gglane ? sWh[2 * gj] : xo;
+                cdv[1] = gglane ? sWh[2 * gj + 1] : pfx;
+            }
+            double amax = 1.0, lmu = 0.0;
+            double dcur[4][4];
+#pragma unroll
+            for (int rr = 0; rr < 2; rr++)
+#pragma unroll
+                for (int sd = 0; sd < 2; sd++) {
+                    const int k = rr * 2 + sd;
+                    const bool on = rr ? on1 : on0;
+                    const double eps = sd ? -1.0 : 1.0;
+                    const double s_ = ROWF(0, k), t_ = ROWF(1, k), l_ = ROWF(2, k), m_ = ROWF(3, k);
+                    const double is_ = frcp(s_), il_ = frcp(l_), it_ = frcp(t_), im_ = frcp(m_);
+                    const double iDs = s_ * rD[k];
+                    const double gam = l_ * rG[k];
+                    double rc1 = t_ * l_, rc2 = s_ * m_;
+                    if (pass == 1) { rc1 += cross1[k] - tau; rc2 += cross2[k] - tau; }
+                    const double rsk = ROWF(4, k);
+                    const double rho = -ROWF(5, k) + rc1 * il_ - (rsk + rc2 * is_) * iDs;
+                    const double dl = -gam * (eps * cdv[rr] + rho);
+                    const double dsl = (dl - rsk - rc2 * is_) * iDs;
+                    const double dm = (-rc2 - m_ * dsl) * is_;
+                    const double dtt = (-rc1 - t_ * dl) * il_;
+                    dcur[0][k] = on ? dsl : 0.0; dcur[1][k] = on ? dtt : 0.0; dcur[2][k] = on ? dl : 0.0; dcur[3][k] = on ? dm : 0.0;
+                    double q = fmax(fmax(-dsl * is_, -dtt * it_), fmax(-dl * il_, -dm * im_));
+                    q = on ? q : 0.0;
+                    amax = fmax(amax, q);
+                    if (pass == 0) { cross1[k] = on ? dtt * dl : 0.0; cross2[k] = on ? dsl * dm : 0.0; }
+                }
+            amax = frcp(wave_max(amax));
+            if (pass == 0) {
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    const double pr_ = (ROWF(1, k) + amax * dcur[1][k]) * (ROWF(2, k) + amax * dcur[2][k])
+                                     + (ROWF(0, k) + amax * dcur[0][k]) * (ROWF(3, k) + amax * dcur[3][k]);
+                    lmu += ((k < 2) ? on0 : on1) ? pr_ : 0.0;
+                }
+                const double mu_aff = wave_sum(lmu) * inv_npairs;
+                const double ratio = mu_aff * frcp(gap);
+                sigma = ratio * ratio * ratio;
+                if (amax < 0.1) {
+#pragma unroll
+                    for (int k = 0; k < 4; k++) { cross1[k] = 0.0; cross2[k] = 0.0; }
+                }
+            } else {
+                alpha = (amax >= 1.0) ? 1.0 : 0.995 * amax;
+                if (alpha >= 1e-12) {
+                    const double om_ = 1.0 - alpha;
+#pragma unroll
+                    for (int k = 0; k < 4; k++) {
+#pragma unroll
+                        for (int f = 0; f < 4; f++) ROWF(f, k) += alpha * dcur[f][k];
+                        ROWF(4, k) *= om_; ROWF(5, k) *= om_;
+                    }
+                }
+            }
+            TUM_TICK(7);
+        }
+        if (alpha < 1e-12) { qp_status = 2; break; }
+        v0 += alpha * dv0; v1 += alpha * dv1;
+        const double om = 1.0 - alpha;
+        rv0 *= om; rv1 *= om;
+        wsync();
+    }
+    const int status = acados_status(qp_status);
+    res_stat = wave_max(res_stat); res_ineq = wave_max(res_ineq); res_comp = wave_max(res_comp);
+    PIPE_LANE_DEFS
+    TUM_TICK(8);
+    // slack part of the cost and the slack outputs; the step of the inputs goes to the expansion kernel
+    double cl = 0.0;
+    {
+#pragma unroll
+        for (int rr = 0; rr < 2; rr++)
+#pragma unroll
+            for (int sd = 0; sd < 2; sd++) {
+                const double sv = ROWF(0, rr * 2 + sd);
+                const double c = pen(rr, sd, 0) * sv + 0.5 * pen(rr, sd, 1) * sv * sv;
+                cl += (rr ? on1 : on0) ? c : 0.0;
+            }
+        if (ka.slack) {
+            double *sl = ka.slack + (size_t)b * 6 * N;
+#pragma unroll
+            for (int sd = 0; sd < 2; sd++) {
+                if (boxlane) {
+                    sl[sd * 3 * N + lane] = ROWF(0, 0 + sd);
+                    sl[sd * 3 * N + N + 2 * lane] = ROWF(0, 2 + sd);
+                }
+                if (gglane && on0) sl[sd * 3 * N + N + 2 * (stg0 - 1) + 1] = ROWF(0, 0 + sd);
+                if (gglane && on1) sl[sd * 3 * N + N + 2 * (stg1 - 1) + 1] = ROWF(0, 2 + sd);
+            }
+        }
+    }
+    const double scost = wave_sum(cl);
+    gvec[PV_DV + lane] = v0;
+    if (lane < 16) gvec[PV_DV + 64 + lane] = v1;
+    TUM_TICK(9);
+    if (PROF && lane == 0)
+        for (int i = 0; i < 12; i++) ka.prof[(size_t)b * 12 + i] = pacc[i];
+    if (lane == 0) {
+        gvec[PV_SC] = scost;
+        ka.status[b] = status;
+        ka.qp_iter[b] = it;
+        ka.qp_status[b] = qp_status;
+        ka.res[b * 3 + 0] = res_stat; ka.res[b * 3 + 1] = res_ineq; ka.res[b * 3 + 2] = res_comp;
+    }
+}
+
+}  // namespace tum

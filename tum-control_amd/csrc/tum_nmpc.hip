@@ -11,6 +11,7 @@
 
 #include "../../include/tum_nmpc.h"
 #include "nmpc_kernel.hpp"
+#include "pipe_kernels.hpp"
 #include "aux_kernels.hpp"
 #include "loop_kernels.hpp"
 
@@ -30,7 +31,11 @@ struct tum_ocp {
     int *dstatus, *dqpiter, *dqpstatus, *dorder;
     bool lpt, order_valid;
     long long *dprof;
-    double *dws;
+    double *dws, *dhws;
+    int kmode;                     // 0 auto (pipeline for batches of more than one round of wavefronts), 1 fused, 2 pipeline
+    bool pipe;                     // this solve runs the four-kernel pipeline (resolved from kmode at launch)
+    double *drec, *dcws, *dvec;    // pipeline workspace: stage records, gg rows in operand layout, q | d | dv
+    hipEvent_t evi0, evi1;         // around the interior point kernel of the pipeline
     float last_ms;
     bool solved;
     std::vector<double> stage;     // host staging
@@ -120,6 +125,10 @@ extern "C" tum_ocp *tum_ocp_create(const tum_ocp_desc *desc)
     ok &= dalloc(&c->ddbg, (size_t)DBG_STRIDE * DBG_INST) == hipSuccess;
     ok &= dalloc(&c->dprof, B * 12) == hipSuccess;
     ok &= dalloc(&c->dws, B * WS_DOUBLES) == hipSuccess;
+    c->dhws = nullptr;
+    { const char *e = getenv("TUM_NMPC_KERNEL"); const std::string k(e ? e : "auto"); c->kmode = (k == "fused") ? 1 : (k == "pipeline") ? 2 : 0; c->pipe = false; }
+    c->drec = c->dcws = c->dvec = nullptr; c->evi0 = c->evi1 = nullptr;
+    ok &= hipEventCreate(&c->evi0) == hipSuccess && hipEventCreate(&c->evi1) == hipSuccess;
     if (!ok) { fail("device allocation failed"); tum_ocp_free(c); return nullptr; }
 
     KArgs &ka = c->ka;
@@ -150,7 +159,9 @@ extern "C" tum_ocp *tum_ocp_create(const tum_ocp_desc *desc)
     ka.status = c->dstatus; ka.qp_iter = c->dqpiter; ka.qp_status = c->dqpstatus;
     ka.qpin = c->dqpin; ka.dbg = c->ddbg; ka.dbg_stride = DBG_STRIDE; ka.prof = c->dprof; ka.ws = c->dws;
 
-    if (hipFuncSetAttribute((const void *)nmpc_rti_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) != hipSuccess ||
+    if (hipFuncSetAttribute((const void *)ipm_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024) != hipSuccess ||
+        hipFuncSetAttribute((const void *)ipm_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024) != hipSuccess ||
+        hipFuncSetAttribute((const void *)nmpc_rti_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) != hipSuccess ||
         hipFuncSetAttribute((const void *)nmpc_rti_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) != hipSuccess ||
         hipFuncSetAttribute((const void *)nmpc_rti_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) != hipSuccess ||
         hipFuncSetAttribute((const void *)nmpc_rti_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) != hipSuccess) {
@@ -166,7 +177,9 @@ extern "C" void tum_ocp_free(tum_ocp *c)
     (void)hipFree(c->dX); (void)hipFree(c->dU); (void)hipFree(c->dx0); (void)hipFree(c->dyref); (void)hipFree(c->dW); (void)hipFree(c->dpen); (void)hipFree(c->dbnd);
     (void)hipFree(c->dcost); (void)hipFree(c->dres); (void)hipFree(c->dslack); (void)hipFree(c->dstatus); (void)hipFree(c->dqpiter); (void)hipFree(c->dqpstatus); (void)hipFree(c->dorder);
     if (c->dqpin) (void)hipFree(c->dqpin);
-    (void)hipFree(c->ddbg); (void)hipFree(c->dprof); (void)hipFree(c->dws);
+    (void)hipFree(c->ddbg); (void)hipFree(c->dprof); (void)hipFree(c->dws); (void)hipFree(c->dhws); (void)hipFree(c->drec); (void)hipFree(c->dcws); (void)hipFree(c->dvec);
+    if (c->evi0) (void)hipEventDestroy(c->evi0);
+    if (c->evi1) (void)hipEventDestroy(c->evi1);
     (void)hipFree(c->dXS); (void)hipFree(c->dxs0); (void)hipFree(c->dApce); (void)hipFree(c->dws2); (void)hipFree(c->dpro); (void)hipFree(c->ddv); (void)hipFree(c->doffs);
     (void)hipFree(c->dr2S); (void)hipFree(c->dr2B); (void)hipFree(c->dpceA); (void)hipFree(c->dbnd_snap);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
@@ -499,24 +512,80 @@ extern "C" int tum_ocp_cost_set(tum_ocp *c, int stage, const char *field, const 
     return 0;
 }
 
+// workspaces of the kernel variants, allocated when a variant is first used
+static int ensure_workspace(tum_ocp *c)
+{
+    const size_t B = c->batch;
+    if (c->pipe && !c->dhws) {
+        if (dalloc(&c->dhws, B * (size_t)NTT * 256) != hipSuccess) return fail("workspace allocation failed (H tiles)");
+    }
+    if (c->pipe && !c->drec) {
+        if (dalloc(&c->drec, B * (size_t)(c->N + 1) * PREC) != hipSuccess || dalloc(&c->dcws, B * (size_t)NCH * 64) != hipSuccess ||
+            dalloc(&c->dvec, B * (size_t)PVEC) != hipSuccess) return fail("workspace allocation failed (pipeline)");
+    }
+    return 0;
+}
+
+// "fused": one kernel per solve; "pipeline": linearise / condense / interior point / expand as four kernels, each at its own
+// occupancy (measured 4-8 % faster than the fused kernel from 4096 instances up, a few per cent slower below 1024: three
+// more launches and the hand-over through L2); "auto" (default): the pipeline when the batch is more than one round of
+// resident wavefronts (> 1024 instances). The coupled SNMPC OCP always runs the fused kernel.
+extern "C" int tum_ocp_set_kernel(tum_ocp *c, const char *name)
+{
+    if (!c || !name) return fail("null argument");
+    const std::string n(name);
+    if (n == "auto") c->kmode = 0;
+    else if (n == "fused") c->kmode = 1;
+    else if (n == "pipeline") c->kmode = 2;
+    else return fail("set_kernel: unknown kernel '" + n + "' (auto | fused | pipeline)");
+    return 0;
+}
+
+// which kernel variant this solve runs, and its workspace (allocated on first use; never inside a stream capture)
+static int resolve_kernel(tum_ocp *c)
+{
+    c->pipe = !c->sn && !(c->ka.flags & 2) && (c->kmode == 2 || (c->kmode == 0 && c->batch > 1024));
+    return ensure_workspace(c);
+}
+
+static int launch_pipeline(tum_ocp *c, bool events)
+{
+    PArgs pa;
+    pa.ka = c->ka; pa.rec = c->drec; pa.hws = c->dhws; pa.cws = c->dcws; pa.vec = c->dvec;
+    const bool prof = (c->ka.flags & 4) != 0;
+    const long long items = (long long)c->batch * (c->N + 1);
+    hipLaunchKernelGGL(lin_kernel, dim3((unsigned)((items + 63) / 64)), dim3(64), 0, c->stream, pa);
+    hipLaunchKernelGGL(cond_kernel, dim3(c->batch), dim3(64), 0, c->stream, pa);
+    if (events) HIPCHK(hipEventRecord(c->evi0, c->stream));
+    static const int ipm_lds = [] { const char *e = getenv("TUM_IPM_LDS"); const int v = e ? atoi(e) : 0; return (v > I_LDS_BYTES && v <= 64 * 1024) ? v : I_LDS_BYTES; }();
+    // (development aid: a larger request lowers the number of OCPs that share a CU)
+    if (prof) hipLaunchKernelGGL(ipm_kernel<true>, dim3(c->batch), dim3(64), ipm_lds, c->stream, pa);
+    else hipLaunchKernelGGL(ipm_kernel<false>, dim3(c->batch), dim3(64), ipm_lds, c->stream, pa);
+    if (events) HIPCHK(hipEventRecord(c->evi1, c->stream));
+    hipLaunchKernelGGL(expand_kernel, dim3(c->batch), dim3(64), 0, c->stream, pa);
+    return 0;
+}
+
 static int launch(tum_ocp *c, bool events = true)
 {
     DevGuard guard(c->d.device);
+    if (resolve_kernel(c)) return 1;
     if (events) HIPCHK(hipEventRecord(c->ev0, c->stream));
     // longest-first schedule from the previous solve's iteration counts (only matters when the batch is more than one
     // round of resident wavefronts)
     c->ka.order = (c->lpt && c->order_valid && c->batch > 1024) ? c->dorder : nullptr;
     // the instrumented instantiation carries the phase timers (flag 4) and the debug dump (flag 2)
+    const bool prof = (c->ka.flags & 6) != 0;
+    auto fused = [&](auto kern) { hipLaunchKernelGGL(kern, dim3(c->batch), dim3(64), LDS_BYTES, c->stream, c->ka); };
     if (c->sn) {
         if (sn_apply_p(c)) return 1;
         if (c->fanout && sn_fanout(c)) return 1;
         hipLaunchKernelGGL(snmpc_prologue_kernel, dim3(c->batch), dim3(64), sizeof(double) * sn_prologue_lds_doubles(c->sa.uph, c->sa.ns),
                            c->stream, c->sa);
-        if (c->ka.flags & 6) hipLaunchKernelGGL((nmpc_rti_kernel<true, true>), dim3(c->batch), dim3(64), LDS_BYTES, c->stream, c->ka);
-        else hipLaunchKernelGGL((nmpc_rti_kernel<false, true>), dim3(c->batch), dim3(64), LDS_BYTES, c->stream, c->ka);
+        if (prof) fused(nmpc_rti_kernel<true, true>); else fused(nmpc_rti_kernel<false, true>);
         hipLaunchKernelGGL(snmpc_epilogue_kernel, dim3(c->batch), dim3(64), 0, c->stream, c->sa);
-    } else if (c->ka.flags & 6) hipLaunchKernelGGL(nmpc_rti_kernel<true>, dim3(c->batch), dim3(64), LDS_BYTES, c->stream, c->ka);
-    else hipLaunchKernelGGL(nmpc_rti_kernel<false>, dim3(c->batch), dim3(64), LDS_BYTES, c->stream, c->ka);
+    } else if (c->pipe) { if (launch_pipeline(c, events)) return 1; }
+    else { if (prof) fused(nmpc_rti_kernel<true>); else fused(nmpc_rti_kernel<false>); }
     HIPCHK(hipGetLastError());
     if (c->r2) {   // constraint tightening for the NEXT solve from this one's linearisation (skipped per instance on failure)
         hipLaunchKernelGGL(r2_backoff_kernel, dim3((c->batch + 3) / 4), dim3(256), 0, c->stream, c->dqpin, c->dX, c->dbnd, c->ka.mp,
@@ -591,6 +660,13 @@ extern "C" int tum_ocp_get_stats(tum_ocp *c, const char *field, void *out, int b
     if (!c || !field || !out) return fail("null argument");
     const std::string f(field);
     if (f == "time_tot") { *(double *)out = tum_ocp_last_kernel_ms(c) * 1e-3; return 0; }
+    if (f == "time_ipm") {    // pipeline only: device seconds of the interior point kernel of the last solve
+        if (!c->pipe || !c->solved) return fail("get_stats time_ipm: pipeline kernel only, after a solve");
+        DevGuard guard(c->d.device);
+        float ms = 0;
+        if (hipEventSynchronize(c->evi1) != hipSuccess || hipEventElapsedTime(&ms, c->evi0, c->evi1) != hipSuccess) return fail("get_stats time_ipm: no timing");
+        *(double *)out = ms * 1e-3; return 0;
+    }
     if (chk_range(c, b0, nb)) return 1;
     DevGuard guard(c->d.device);
     if (f == "sqp_iter") { int *o = (int *)out; for (int i = 0; i < nb; i++) o[i] = 1; return 0; }
@@ -1037,6 +1113,7 @@ extern "C" int tum_sim_run(tum_sim *s, int nsteps)
     if (!s || nsteps < 0) return fail("bad argument");
     tum_ocp *c = s->c;
     DevGuard guard(c->d.device);
+    if (resolve_kernel(c)) return 1;          // (workspace allocation must not happen inside the capture below)
     int done = 0;
     if (nsteps >= 2 * GRAPH_STEPS) {
         if (!s->graph) {

@@ -47,7 +47,7 @@ C_SYMBOLS = ["tum_ocp_create", "tum_ocp_free", "tum_ocp_last_error", "tum_ocp_ba
              "tum_ocp_solve", "tum_ocp_solve_async", "tum_ocp_synchronize",
              "tum_ocp_get_cost", "tum_ocp_get_stats", "tum_ocp_reset", "tum_ocp_get_from_qp_in",
              "tum_ocp_set_stream", "tum_ocp_get_device", "tum_ocp_put_device", "tum_ocp_cold_start", "tum_ocp_last_kernel_ms",
-             "tum_ocp_debug_dump", "tum_ocp_profile_phases", "tum_ocp_set_schedule",
+             "tum_ocp_debug_dump", "tum_ocp_profile_phases", "tum_ocp_set_schedule", "tum_ocp_set_kernel",
              "tum_ocp_set_x0_fanout", "tum_pce_moments", "tum_pce_attach", "tum_pce_moments_device",
              "tum_ocp_bounds_snapshot", "tum_ocp_bounds_restore", "tum_ocp_r2_backoff", "tum_ocp_r2_attach", "tum_ocp_constraints_get",
              "tum_ocp_snmpc_attach", "tum_ocp_snmpc_samples", "tum_ocp_snmpc_set_offsets",
@@ -87,6 +87,7 @@ def load_library(path=None):
     L.tum_ocp_reset.argtypes = [vp]; L.tum_ocp_cold_start.argtypes = [vp]
     L.tum_ocp_set_stream.argtypes = [vp, vp]
     L.tum_ocp_set_schedule.argtypes = [vp, ci]
+    L.tum_ocp_set_kernel.argtypes = [vp, cs]
     L.tum_ocp_get_device.argtypes = [vp, cs, vp, ci, ci]
     L.tum_ocp_put_device.argtypes = [vp, cs, vp, ci, ci]
     L.tum_ocp_last_kernel_ms.restype = ctypes.c_double; L.tum_ocp_last_kernel_ms.argtypes = [vp]
@@ -243,9 +244,9 @@ class BatchedOcpSolver:
         return float(out[0]) if self.batch == 1 else out
 
     def get_stats(self, field):
-        if field == "time_tot":
+        if field in ("time_tot", "time_ipm"):
             o = ctypes.c_double(0.0)
-            self._chk(self._L.tum_ocp_get_stats(self._h, b"time_tot", ctypes.byref(o), 0, 1), "get_stats")
+            self._chk(self._L.tum_ocp_get_stats(self._h, field.encode(), ctypes.byref(o), 0, 1), "get_stats")
             return o.value
         if field in ("sqp_iter", "qp_iter", "status", "qp_status"):
             out = np.zeros(self.batch, dtype=np.int32)
@@ -327,6 +328,10 @@ class BatchedOcpSolver:
     def set_schedule(self, longest_first=True):
         """Dispatch instances longest-first by the previous solve's iteration counts (default) or in natural order."""
         self._chk(self._L.tum_ocp_set_schedule(self._h, int(bool(longest_first))), "set_schedule")
+
+    def set_kernel(self, name):
+        """'auto' | 'fused' | 'pipeline' (include/tum_nmpc.h, tum_ocp_set_kernel)"""
+        self._chk(self._L.tum_ocp_set_kernel(self._h, name.encode()), "set_kernel")
 
     def last_kernel_ms(self):
         return float(self._L.tum_ocp_last_kernel_ms(self._h))
