@@ -34,12 +34,19 @@ struct PArgs {
 };
 
 // ---------------------------------------------------------------------------------------------------------------- K1
+constexpr int L_PITCH = PREC + 1;               // LDS pitch of one item's record (odd: lane-strided writes hit distinct banks)
 __global__ void __launch_bounds__(64, 1) lin_kernel(const PArgs pa)
 {
+    // the 64 records of a wavefront are one contiguous 32 KiB block of the workspace: they are transposed through LDS so that
+    // every store instruction writes 512 contiguous bytes (a lane writing its own record would touch 64 segments per store)
+    __shared__ double sT[64 * L_PITCH];
     const KArgs &ka = pa.ka;
     const int N = ka.N, NB = N + 1;
-    const long long g = (long long)blockIdx.x * 64 + threadIdx.x;
-    if (g >= (long long)ka.batch * NB) return;
+    const long long total = (long long)ka.batch * NB;
+    const long long g0 = (long long)blockIdx.x * 64;
+    const long long gl = g0 + threadIdx.x;
+    const bool live = gl < total;
+    const long long g = live ? gl : total - 1;       // (lanes beyond the last item shadow it and store nothing)
     const int b = (int)(g / NB), k = (int)(g - (long long)b * NB);
     const double *gX = ka.X + ((size_t)b * NB + k) * NX;
     double xk[8];
@@ -71,7 +78,7 @@ __global__ void __launch_bounds__(64, 1) lin_kernel(const PArgs pa)
             for (int c = 0; c < 7; c++) r[2 + i * 7 + c] = S[i][c];
 #pragma unroll
         for (int i = 0; i < 8; i++) r[44 + i] = xn[i] - gX[NX + i];
-        if (ka.flags & 1) {   // full A (8x8), B (8x2), b (8) of this linearisation, row-major (get_from_qp_in)
+        if ((ka.flags & 1) && live) {   // full A (8x8), B (8x2), b (8) of this linearisation, row-major (get_from_qp_in)
             double *q = ka.qpin + ((size_t)b * N + k) * 88;
             for (int i = 0; i < 64; i++) q[i] = 0.0;
             q[0 * 8 + 0] = 1.0; q[1 * 8 + 1] = 1.0; q[2 * 8 + 2] = 1.0; q[6 * 8 + 6] = 1.0; q[7 * 8 + 7] = 1.0;
@@ -84,10 +91,13 @@ __global__ void __launch_bounds__(64, 1) lin_kernel(const PArgs pa)
             for (int i = 0; i < 8; i++) q[80 + i] = r[44 + i];
         }
     }
-    typedef double d2 __attribute__((ext_vector_type(2)));
-    d2 *dst = reinterpret_cast<d2 *>(pa.rec + (size_t)g * PREC);
 #pragma unroll
-    for (int i = 0; i < 31; i++) dst[i] = d2{r[2 * i], r[2 * i + 1]};
+    for (int i = 0; i <= PR_XD; i++) sT[threadIdx.x * L_PITCH + i] = r[i];
+    wsync();
+    double *dst = pa.rec + (size_t)g0 * PREC;
+    const int nitem = (int)((total - g0 < 64) ? (total - g0) : 64);
+    for (int it = 0; it < nitem; it++)
+        if ((int)threadIdx.x <= PR_XD) dst[(size_t)it * PREC + threadIdx.x] = sT[it * L_PITCH + threadIdx.x];
 }
 
 // ---------------------------------------------------------------------------------------------------------------- K2
