@@ -696,6 +696,7 @@ def test_gpu_instrumented_kernels_agree(kind):
             s = CoupledSnmpcSolver(N=40, batch=8, Apce=A, uph=5, x0_offsets=snm.x0_offsets(w, stds))
         else:
             s = BatchedOcpSolver(N=40, batch=8)
+        s.set_kernel("fused")          # (the debug dump always runs the fused kernel; the pipeline has its own test below)
         s.install_reference_ocp(); s.set_x0(x0); s.set_yref_all(yref); s.cold_start()
         if mode == "plain":
             s.solve()
@@ -707,3 +708,24 @@ def test_gpu_instrumented_kernels_agree(kind):
     for mode in ("phases", "dump"):
         np.testing.assert_array_equal(res[mode][1], res["plain"][1])
         np.testing.assert_array_equal(res[mode][0], res["plain"][0])
+
+
+@pytest.mark.gpu
+def test_gpu_pipeline_instrumented_kernel_agrees():
+    """the same for the two instantiations of the pipeline's interior point kernel (plain / phase timers)"""
+    from tum_control_amd.solver import BatchedOcpSolver
+    from tum_control_amd.workloads import nominal_batch
+    x0, yref = nominal_batch(24, N=40, seed=3)
+    res = {}
+    for mode in ("plain", "phases"):
+        s = BatchedOcpSolver(N=40, batch=24)
+        s.set_kernel("pipeline")
+        s.install_reference_ocp(); s.set_x0(x0); s.set_yref_all(yref); s.cold_start()
+        if mode == "plain":
+            s.solve()
+        else:
+            p = s.profile_phases()
+            assert (p[:, 1:10] > 0).all() and (p[:, 4] > p[:, 2]).all()          # the factorisation dominates the residual phase
+        res[mode] = (s.get_iterate()[1].copy(), s.get_stats("qp_iter").copy(), s.get_cost().copy())
+    for i in range(3):
+        np.testing.assert_array_equal(res["phases"][i], res["plain"][i])
