@@ -39,10 +39,13 @@ __global__ void pce_moments_kernel(const double *V, size_t rec, const double *A,
 //      lbx_k = delta_min + b_d, ubx_k = delta_max - b_d, uh_k = uh_nom - b_h; stages uph..N-1 reuse the last pair.
 //      One wavefront per instance, lane (i,j) owns entry (i,j) of the 8x8 covariance; the 8x8 blocks go
 //      through LDS (the "small-block LDS path" of BASELINE config 5).
+//      A_k comes from the full blocks the fused kernel keeps for get_from_qp_in (qpin: [b][N][88]) or, when the pipeline
+//      solved (rec != null: [b][N+1][rec_stride]), straight from the compact stage records: identity on (px, py, psi, delta,
+//      a), Sp[2] in the psi column of (px, py), S[6][5] in the (vl, vt, r, delta, a) columns of the first six rows.
 __global__ void __launch_bounds__(256) r2_backoff_kernel(const double *qpin, const double *X, double *bnd, const Model mp,
                                                          const double *Sigma0, const double *BWB, int N, int uph, int batch,
                                                          double dmin, double dmax, double uh_nom, double *backoff_out,
-                                                         const int *status)
+                                                         const int *status, const double *rec = nullptr, int rec_stride = 0)
 {
     __shared__ double sA[4][64], sS[4][64], sT[4][64];
     const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -77,7 +80,13 @@ __global__ void __launch_bounds__(256) r2_backoff_kernel(const double *qpin, con
             __syncthreads();
         }
         // Sigma <- A Sigma A' + B W B'
-        sA[w][lane] = on ? qpin[((size_t)b * N + k) * 88 + lane] : 0.0;     // A row-major 8x8
+        if (rec) {
+            const double *r = rec + ((size_t)b * (N + 1) + k) * rec_stride;
+            double a = (i == j && (i < 3 || i >= 6)) ? 1.0 : 0.0;
+            if (on && j == 2 && i < 2) a = r[i];
+            if (on && j >= 3 && i < 6) a = r[2 + i * 7 + (j - 3)];
+            sA[w][lane] = on ? a : 0.0;
+        } else sA[w][lane] = on ? qpin[((size_t)b * N + k) * 88 + lane] : 0.0;     // A row-major 8x8
         sS[w][lane] = sig;
         __syncthreads();
         double t = 0.0;

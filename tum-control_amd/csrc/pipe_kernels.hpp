@@ -78,18 +78,7 @@ __global__ void __launch_bounds__(64, 1) lin_kernel(const PArgs pa)
             for (int c = 0; c < 7; c++) r[2 + i * 7 + c] = S[i][c];
 #pragma unroll
         for (int i = 0; i < 8; i++) r[44 + i] = xn[i] - gX[NX + i];
-        if ((ka.flags & 1) && live) {   // full A (8x8), B (8x2), b (8) of this linearisation, row-major (get_from_qp_in)
-            double *q = ka.qpin + ((size_t)b * N + k) * 88;
-            for (int i = 0; i < 64; i++) q[i] = 0.0;
-            q[0 * 8 + 0] = 1.0; q[1 * 8 + 1] = 1.0; q[2 * 8 + 2] = 1.0; q[6 * 8 + 6] = 1.0; q[7 * 8 + 7] = 1.0;
-            q[0 * 8 + 2] = Sp[0]; q[1 * 8 + 2] = Sp[1];
-            for (int i = 0; i < 6; i++) {
-                for (int c = 0; c < 5; c++) q[i * 8 + 3 + c] = S[i][c];
-                q[64 + i * 2 + 0] = S[i][5]; q[64 + i * 2 + 1] = S[i][6];
-            }
-            q[64 + 6 * 2 + 0] = 0.0; q[64 + 6 * 2 + 1] = ka.dt; q[64 + 7 * 2 + 0] = ka.dt; q[64 + 7 * 2 + 1] = 0.0;
-            for (int i = 0; i < 8; i++) q[80 + i] = r[44 + i];
-        }
+        // (get_from_qp_in and the R2 back-off read A_k, B_k, b_k of a pipeline solve from these records: no separate copy)
     }
 #pragma unroll
     for (int i = 0; i <= PR_XD; i++) sT[threadIdx.x * L_PITCH + i] = r[i];

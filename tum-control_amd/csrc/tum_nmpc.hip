@@ -34,6 +34,7 @@ struct tum_ocp {
     double *dws, *dhws;
     int kmode;                     // 0 auto (pipeline for batches of more than one round of wavefronts), 1 fused, 2 pipeline
     bool pipe;                     // this solve runs the four-kernel pipeline (resolved from kmode at launch)
+    bool solved_pipe;              // the LAST solve ran the pipeline: its linearisation is in the stage records, not in qpin
     double *drec, *dcws, *dvec;    // pipeline workspace: stage records, gg rows in operand layout, q | d | dv
     hipEvent_t evi0, evi1;         // around the interior point kernel of the pipeline
     float last_ms;
@@ -126,7 +127,7 @@ extern "C" tum_ocp *tum_ocp_create(const tum_ocp_desc *desc)
     ok &= dalloc(&c->dprof, B * 12) == hipSuccess;
     ok &= dalloc(&c->dws, B * WS_DOUBLES) == hipSuccess;
     c->dhws = nullptr;
-    { const char *e = getenv("TUM_NMPC_KERNEL"); const std::string k(e ? e : "auto"); c->kmode = (k == "fused") ? 1 : (k == "pipeline") ? 2 : 0; c->pipe = false; }
+    { const char *e = getenv("TUM_NMPC_KERNEL"); const std::string k(e ? e : "auto"); c->kmode = (k == "fused") ? 1 : (k == "pipeline") ? 2 : 0; c->pipe = false; c->solved_pipe = false; }
     c->drec = c->dcws = c->dvec = nullptr; c->evi0 = c->evi1 = nullptr;
     ok &= hipEventCreate(&c->evi0) == hipSuccess && hipEventCreate(&c->evi1) == hipSuccess;
     if (!ok) { fail("device allocation failed"); tum_ocp_free(c); return nullptr; }
@@ -589,7 +590,8 @@ static int launch(tum_ocp *c, bool events = true)
     HIPCHK(hipGetLastError());
     if (c->r2) {   // constraint tightening for the NEXT solve from this one's linearisation (skipped per instance on failure)
         hipLaunchKernelGGL(r2_backoff_kernel, dim3((c->batch + 3) / 4), dim3(256), 0, c->stream, c->dqpin, c->dX, c->dbnd, c->ka.mp,
-                           c->dr2S, c->dr2B, c->N, c->r2_uph, c->batch, c->r2_dmin, c->r2_dmax, c->r2_uh, (double *)nullptr, c->dstatus);
+                           c->dr2S, c->dr2B, c->N, c->r2_uph, c->batch, c->r2_dmin, c->r2_dmax, c->r2_uh, (double *)nullptr, c->dstatus,
+                           c->pipe ? c->drec : (const double *)nullptr, PREC);
         HIPCHK(hipGetLastError());
     }
     if (events) HIPCHK(hipEventRecord(c->ev1, c->stream));
@@ -599,6 +601,7 @@ static int launch(tum_ocp *c, bool events = true)
         c->order_valid = true;
     }
     c->solved = true;
+    c->solved_pipe = c->pipe;
     return 0;
 }
 
@@ -712,6 +715,25 @@ extern "C" int tum_ocp_get_from_qp_in(tum_ocp *c, int stage, const char *field, 
     else if (f == "b") { off = 80; n = 8; rows = 8; cols = 1; }
     else return fail("get_from_qp_in: unknown field '" + f + "'");
     if (len != n || stride < n) return fail("get_from_qp_in: bad len/stride");
+    if (c->solved_pipe) {   // the pipeline keeps the linearisation as compact stage records (pipe_kernels.hpp): expand on the host
+        std::vector<double> r((size_t)nb * PREC);
+        if (fetch(c, c->drec, (size_t)(c->N + 1) * PREC, (size_t)stage * PREC, r.data(), PREC, b0, nb, PREC)) return 1;
+        const double dt = c->ka.dt;
+        for (int i = 0; i < nb; i++) {
+            const double *q = &r[(size_t)i * PREC];
+            double *o = out + (size_t)i * stride;
+            for (int e = 0; e < n; e++) o[e] = 0.0;
+            if (f == "A") {           // column-major 8 x 8
+                for (int d : {0, 1, 2, 6, 7}) o[d * 8 + d] = 1.0;
+                o[2 * 8 + 0] = q[0]; o[2 * 8 + 1] = q[1];
+                for (int ri = 0; ri < 6; ri++) for (int cc = 0; cc < 5; cc++) o[(3 + cc) * 8 + ri] = q[2 + ri * 7 + cc];
+            } else if (f == "B") {    // column-major 8 x 2
+                for (int ri = 0; ri < 6; ri++) { o[0 * 8 + ri] = q[2 + ri * 7 + 5]; o[1 * 8 + ri] = q[2 + ri * 7 + 6]; }
+                o[1 * 8 + 6] = dt; o[0 * 8 + 7] = dt;
+            } else for (int ri = 0; ri < 8; ri++) o[ri] = q[44 + ri];
+        }
+        return 0;
+    }
     std::vector<double> tmp((size_t)nb * n);
     if (fetch(c, c->dqpin, (size_t)c->N * 88, (size_t)stage * 88 + off, tmp.data(), n, b0, nb, n)) return 1;
     for (int i = 0; i < nb; i++)          // device keeps row-major, acados hands out column-major
@@ -914,7 +936,8 @@ extern "C" int tum_ocp_r2_backoff(tum_ocp *c, const double *Sigma0, const double
     HIPCHK(hipMemcpyAsync(dS, Sigma0, 64 * 8, hipMemcpyHostToDevice, c->stream));
     HIPCHK(hipMemcpyAsync(dB, BWB, 64 * 8, hipMemcpyHostToDevice, c->stream));
     hipLaunchKernelGGL(r2_backoff_kernel, dim3((c->batch + 3) / 4), dim3(256), 0, c->stream, c->dqpin, c->dX, c->dbnd, c->ka.mp,
-                       dS, dB, N, uph, c->batch, delta_min, delta_max, uh_nom, dbo, c->dstatus);
+                       dS, dB, N, uph, c->batch, delta_min, delta_max, uh_nom, dbo, c->dstatus,
+                       c->solved_pipe ? c->drec : (const double *)nullptr, PREC);
     HIPCHK(hipGetLastError());
     if (backoff) HIPCHK(hipMemcpyAsync(backoff, dbo, sizeof(double) * (size_t)c->batch * N * 2, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
