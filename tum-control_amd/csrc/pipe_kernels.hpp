@@ -771,6 +771,22 @@ __global__ void __launch_bounds__(64, IPM_WPS) ipm_kernel(const PArgs pa)
 #pragma unroll
                 for (int J = 0; J < 4; J++) bj[J] = lane_gather(b0, (16 * J + lc) << 2);
                 bj[4] = lane_gather(b1, lc << 2);
+                // (with the whole register file the entries of the factor this lane needs are fetched before the chain starts:
+                //  the chain itself then waits on row swaps and lane gathers only, not on LDS reads issued one tile at a time)
+                double Lo[NTT][4], Ld[NT][4], Lp[NT];
+                if (IPM_WPS == 1) {
+#pragma unroll
+                    for (int J = 0; J < NT; J++) {
+#pragma unroll
+                        for (int K = 0; K < J; K++)
+#pragma unroll
+                            for (int jj = 0; jj < 4; jj++) Lo[tidx(K, J)][jj] = sM[rb[J] + 16 * K + lq + 4 * jj];
+#pragma unroll
+                        for (int jj = 0; jj < 4; jj++) Ld[J][jj] = sM[rb[J] + 16 * J + lq + 4 * jj];
+                        Lp[J] = sM[rb[J] + 16 * J + lc];
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
 #pragma unroll
                 for (int J = 0; J < NT; J++) {
                     double t = bj[J];
@@ -780,7 +796,7 @@ __global__ void __launch_bounds__(64, IPM_WPS) ipm_kernel(const PArgs pa)
                         for (int K = 0; K < J; K++)
 #pragma unroll
                             for (int jj = 0; jj < 4; jj++) {
-                                const double lv = sM[rb[J] + 16 * K + lq + 4 * jj];
+                                const double lv = (IPM_WPS == 1) ? Lo[tidx(K, J)][jj] : sM[rb[J] + 16 * K + lq + 4 * jj];
                                 if (jj & 1) acc1 += lv * vs[K][jj]; else acc += lv * vs[K][jj];
                             }
                         t -= quad_sum(acc + acc1);
@@ -788,16 +804,28 @@ __global__ void __launch_bounds__(64, IPM_WPS) ipm_kernel(const PArgs pa)
                     double a2 = ondiag ? t : 0.0;
 #pragma unroll
                     for (int jj = 0; jj < 4; jj++) {
-                        const double lv = sM[rb[J] + 16 * J + lq + 4 * jj];
+                        const double lv = (IPM_WPS == 1) ? Ld[J][jj] : sM[rb[J] + 16 * J + lq + 4 * jj];
                         const double tv = lane_gather(t, ga[jj]);
                         a2 += ((lq + 4 * jj < lc) ? lv : 0.0) * tv;
                     }
                     const double y = quad_sum(a2);
-                    bj[J] = y * frcp(sM[rb[J] + 16 * J + lc]);
+                    bj[J] = y * frcp((IPM_WPS == 1) ? Lp[J] : sM[rb[J] + 16 * J + lc]);
                     if (J < NT - 1) {
 #pragma unroll
                         for (int jj = 0; jj < 4; jj++) vs[J][jj] = lane_gather(y, ga[jj]);
                     }
+                }
+                if (IPM_WPS == 1) {
+#pragma unroll
+                    for (int J = 0; J < NT; J++) {
+#pragma unroll
+                        for (int I = J + 1; I < NT; I++)
+#pragma unroll
+                            for (int jj = 0; jj < 4; jj++) Lo[tidx(J, I)][jj] = sM[lpk(16 * I + lq + 4 * jj, 0) + 16 * J + lc];
+#pragma unroll
+                        for (int jj = 0; jj < 4; jj++) Ld[J][jj] = sM[lpk(16 * J + lq + 4 * jj, 0) + 16 * J + lc];
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
                 }
 #pragma unroll
                 for (int J = NT - 1; J >= 0; J--) {
@@ -808,7 +836,7 @@ __global__ void __launch_bounds__(64, IPM_WPS) ipm_kernel(const PArgs pa)
                         for (int I = J + 1; I < NT; I++)
 #pragma unroll
                             for (int jj = 0; jj < 4; jj++) {
-                                const double lv = sM[lpk(16 * I + lq + 4 * jj, 0) + 16 * J + lc];
+                                const double lv = (IPM_WPS == 1) ? Lo[tidx(J, I)][jj] : sM[lpk(16 * I + lq + 4 * jj, 0) + 16 * J + lc];
                                 if (jj & 1) acc1 += lv * vs[I][jj]; else acc += lv * vs[I][jj];
                             }
                         t -= quad_sum(acc + acc1);
@@ -816,7 +844,7 @@ __global__ void __launch_bounds__(64, IPM_WPS) ipm_kernel(const PArgs pa)
                     double a2 = ondiag ? t : 0.0;
 #pragma unroll
                     for (int jj = 0; jj < 4; jj++) {
-                        const double lv = sM[lpk(16 * J + lq + 4 * jj, 0) + 16 * J + lc];
+                        const double lv = (IPM_WPS == 1) ? Ld[J][jj] : sM[lpk(16 * J + lq + 4 * jj, 0) + 16 * J + lc];
                         const double tv = lane_gather(t, ga[jj]);
                         a2 += ((lq + 4 * jj > lc) ? lv : 0.0) * tv;
                     }
