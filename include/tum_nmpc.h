@@ -27,7 +27,8 @@ extern "C" {
 #define TUM_NU 2          /* [jerk, steering_rate]                                                        :96-98   */
 #define TUM_NY 6          /* cost_y_expr = [x0,x1,wrap(yaw),vlong,u]        NMPC_STM_acados_settings.py:51 */
 #define TUM_NYE 4
-#define TUM_N_MAX 40      /* horizon limit of this build (2N <= 80 condensed variables, 5 MFMA tiles)     */
+#define TUM_N_MAX 48      /* horizon limit of this build: N <= 40 (five 16-wide MFMA tiles of condensed variables) on every kernel
+                             variant and for the coupled SNMPC OCP, 41..48 (six tiles) on the pipeline variant only */
 #define TUM_ALL_STAGES (-1)
 
 /* acados return codes the callers test (NMPC_class.py:183-206, main.py:59-61) */

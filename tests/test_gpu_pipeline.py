@@ -129,3 +129,47 @@ def test_pipeline_in_the_device_closed_loop(golden_dir):
         np.testing.assert_allclose(logs["pipeline"][f], logs["fused"][f], rtol=1e-7, atol=1e-7, err_msg=f)
     assert (logs["pipeline"]["simSolverDebug"][:, :, 4] == 0).all()
     assert np.array_equal(logs["pipeline"]["simSolverDebug"][:, :, 3], logs["fused"]["simSolverDebug"][:, :, 3])
+
+
+@pytest.mark.parametrize("N,B", [(41, 5), (44, 33), (48, 1500), (48, 1)])
+def test_long_horizons_vs_oracle(N, B):
+    """Horizons 41..48 (six 16-wide tiles of condensed variables; the reference derives N from its YAML, NMPC_class.py:49) exist
+    as a pipeline instantiation: cold start and a warm real-time iteration against the oracle, every instance; row mapping of
+    the interior point method with three rows per lane (box, steering angle, gg) instead of two."""
+    from tum_control_amd.solver import BatchedOcpSolver
+    from tum_control_amd.workloads import nominal_batch
+    x0, yref = nominal_batch(B, N=N, dt=0.08, seed=40 + N)
+    s = BatchedOcpSolver(N=N, dt=0.08, nsub=3, batch=B)
+    s.install_reference_ocp()
+    s.set_x0(x0); s.set_yref_all(yref); s.cold_start()
+    assert s.solve() == 0
+    X, U = s.get_iterate()
+    it = s.get_stats("qp_iter")
+    idx = np.unique(np.linspace(0, B - 1, min(B, 48)).astype(int))
+    o = _oracle(N)
+    u0, X1, st = o.solve_batch_cold(x0[idx], yref[idx], 8)
+    assert (st[:, 2] == 0).all()
+    same = it[idx] == st[:, 1]
+    assert same.mean() > 0.9 and np.abs(it[idx] - st[:, 1]).max() <= 1
+    assert np.abs(U[idx, 0] - u0)[same].max() < 1e-6 and np.abs(X[idx, 1] - X1)[same].max() < 1e-6
+    np.testing.assert_allclose(np.atleast_1d(s.get_cost())[idx][same], st[same, 0], rtol=1e-7)
+    # the whole iterate and a warm step with tightened bounds (slacks active) for a few instances
+    s.constraints_set(3, "uh", np.array([0.05])); s.constraints_set(N, "ubx", np.array([0.01]))
+    Xc, Uc = X.copy(), U.copy()
+    s.set_x0(X[:, 1]); assert s.solve() == 0
+    X2, U2 = s.get_iterate()
+    sl = s.get(3, "su")
+    for b in idx[:4]:
+        oo = _oracle(N); oo.cold_start(x0[b]); oo.yref[:] = yref[b]; assert oo.solve() == 0
+        assert np.abs(oo.U - Uc[b]).max() < 1e-6 and np.abs(oo.X - Xc[b]).max() < 1e-6
+        oo.uh[3] = 0.05; oo.ubx[N] = 0.01; oo.x0[:] = Xc[b, 1]; assert oo.solve() == 0
+        assert np.abs(oo.U - U2[b]).max() < 2e-6 and np.abs(oo.X - X2[b]).max() < 2e-6
+    assert np.isfinite(sl).all()
+    # what does not exist beyond 40
+    s.set_kernel("fused")
+    with pytest.raises(Exception, match="N <= 40"):
+        s.solve()
+    s.set_kernel("auto")
+    with pytest.raises(Exception, match="N <= 40"):
+        s.debug_dump(0)
+    assert s.solve() == 0

@@ -20,10 +20,45 @@ namespace tum {
 constexpr int PREC = 64;                        // doubles per stage record
 // record fields: [0,1] Sp | [2..43] S[6][7] | [44..51] defect b | [52..55] cost residuals | [56..59] g3 g5 g7 h | [60] delta_f
 constexpr int PR_RES = 52, PR_GH = 56, PR_XD = 60;
-constexpr int NCH = NCHV;                       // (chunk, tile column) pairs of the gg-row operands (nmpc_device.hpp)
-__host__ __device__ constexpr int cidx(int c, int T) { return chidx(c, T); }
-constexpr int PV_Q = 0, PV_D = NVP, PV_DV = 2 * NVP, PVEC = 3 * NVP + 16;      // per-instance vectors: q | d | dv | [slack cost, ...]
-constexpr int PV_SC = 3 * NVP;
+// Everything that depends on the horizon limit is a function of NT_, the number of 16-wide MFMA tiles of the condensed QP:
+// NT_ = 5 -> N <= 40 (what the fused kernel covers as well), NT_ = 6 -> N <= 48 (pipeline only).
+template <int NT_> struct PD {
+    static constexpr int NT = NT_, NVP = 16 * NT_, NMAX = 8 * NT_, NTT = NT_ * (NT_ + 1) / 2, LPK = NVP * (NVP + 1) / 2;
+    static constexpr int NC = 2 * NT_;              // chunks of 4 gg rows
+    static constexpr int NCH = NT_ * NT_ + NT_;     // (chunk c, tile column T) pairs with c >= 2T
+    static constexpr int NB1 = NVP - 64;            // condensed variables beyond the first 64: "bank 1", lanes 0..NB1-1
+    // rows of the interior point method per lane: NT_ = 5: two slots (box + steering on lanes 0..N-1, two gg rows on each of
+    // the lanes 40..59); more tiles: three slots on the lanes 0..N-1 (box of stage l, steering and gg row of stage l+1)
+    static constexpr int SLOTS = (NT_ == 5) ? 2 : 3;
+    static constexpr int PV_Q = 0, PV_D = NVP, PV_DV = 2 * NVP, PV_SC = 3 * NVP, PVEC = 3 * NVP + 16;   // q | d | dv | slack cost
+    static constexpr int C_REC = 0, C_STAGE = 2 * PREC, C_GS = C_STAGE + 4 * NVP, C_U0 = C_GS + 8, C_CH = C_U0 + NVP,
+                         C_LDS = C_CH + NMAX * (NMAX + 1);
+    static constexpr int E_REC = 0, E_X = 2 * PREC, E_U = E_X + (NMAX + 1) * NX, E_DV = E_U + NVP, E_LDS = E_DV + NVP;
+    // interior point kernel: the small vectors first (the diagonal-block substitution reads up to 15 doubles in front of a
+    // packed row with a zero multiplier: in front of row 0 that lands on them, finite data), then the KKT matrix
+    static constexpr int I_WH = 0;                  // NMAX     gamma / weights / C dv of the gg rows (index stage - 1)
+    static constexpr int I_WB = I_WH + NMAX;        // NMAX     box-row scalars
+    static constexpr int I_SFX = I_WB + NMAX;       // NMAX+2   suffix sums over the steering-angle rows
+    static constexpr int I_DV = I_WB;               //   (alias: a v-space vector lives here between a solve and the next publish)
+    static constexpr int I_DUMMY = I_SFX + NMAX + 2;
+    static constexpr int I_PZ = I_DUMMY + 1;        // 18       quadratic slack penalties Zl, Zu of the 9 (class, row type) pairs
+    static constexpr int I_M = I_PZ + 18;           // LPK      KKT matrix / L D L' factor
+    static constexpr int I_LDS = I_M + LPK, I_LDS_BYTES = I_LDS * 8;
+    static_assert(NVP <= 2 * NMAX + 2, "the v-space alias must fit in the box / suffix buffers");
+    static_assert(I_LDS_BYTES <= 40 * 1024, "four workgroups per CU");
+    static __host__ __device__ constexpr int tidx(int K, int I) { return K * NT_ - K * (K - 1) / 2 + (I - K); }   // K <= I
+    static __host__ __device__ constexpr int cidx(int c, int T) { return T * (NC - T - 1) + c; }              // c >= 2T
+};
+static_assert(PD<5>::cidx(9, 4) == chidx(9, 4) && PD<5>::cidx(2, 1) == chidx(2, 1) && PD<5>::NCH == NCHV, "operand layout of the fused kernel's tile count");
+// local names of the constants inside a kernel templated on NT_ (they hide the namespace-level ones of the fused kernel)
+#define PD_LOCALS \
+    using D = PD<NT_>; \
+    constexpr int NT = D::NT, NVP = D::NVP, NMAX = D::NMAX, NTT = D::NTT, LPK = D::LPK, NC = D::NC, NCH = D::NCH, NB1 = D::NB1; \
+    constexpr int SLOTS = D::SLOTS, PV_Q = D::PV_Q, PV_D = D::PV_D, PV_DV = D::PV_DV, PV_SC = D::PV_SC, PVEC = D::PVEC; \
+    auto tidx = [](int K, int I) { return D::tidx(K, I); }; \
+    auto cidx = [](int c, int T) { return D::cidx(c, T); }; \
+    (void)NT; (void)NVP; (void)NMAX; (void)NTT; (void)LPK; (void)NC; (void)NCH; (void)NB1; (void)SLOTS; \
+    (void)PV_Q; (void)PV_D; (void)PV_DV; (void)PV_SC; (void)PVEC; (void)tidx; (void)cidx;
 
 struct PArgs {
     KArgs ka;
@@ -90,17 +125,14 @@ __global__ void __launch_bounds__(64, 1) lin_kernel(const PArgs pa)
 }
 
 // ---------------------------------------------------------------------------------------------------------------- K2
-// LDS of the condensing kernel (doubles)
-constexpr int C_REC = 0;                        // 2 x PREC   stage record double buffer
-constexpr int C_STAGE = C_REC + 2 * PREC;       // 4 x NVP    staging rows of the SYRK
-constexpr int C_GS = C_STAGE + 4 * NVP;         // 8          g_s of the current stage
-constexpr int C_U0 = C_GS + 8;                  // NVP        iterate U
-constexpr int C_CH = C_U0 + NVP;                // NMAX*(NMAX+1) packed gg rows (staging for the operand layout)
-constexpr int C_LDS_DOUBLES = C_CH + NMAX * (NMAX + 1);
-
-__global__ void __launch_bounds__(64, 2) cond_kernel(const PArgs pa)
+// LDS of the condensing kernel (PD::C_*): stage record double buffer | 4 staging rows of the SYRK | g_s of the current stage |
+// iterate U | packed gg rows (staging for the operand layout)
+template <int NT_>
+__global__ void __launch_bounds__(64, (NT_ == 5) ? 2 : 1) cond_kernel(const PArgs pa)
 {
-    __shared__ __attribute__((aligned(16))) double lds[C_LDS_DOUBLES];
+    PD_LOCALS
+    constexpr int C_REC = D::C_REC, C_STAGE = D::C_STAGE, C_GS = D::C_GS, C_U0 = D::C_U0, C_CH = D::C_CH;
+    __shared__ __attribute__((aligned(16))) double lds[D::C_LDS];
     const KArgs &ka = pa.ka;
     const int lane = threadIdx.x, b = blockIdx.x;
     if (b >= ka.batch) return;
@@ -119,13 +151,13 @@ __global__ void __launch_bounds__(64, 2) cond_kernel(const PArgs pa)
     auto fetch = [&](int k) -> double { return (lane < PR_RES) ? grec[(size_t)k * PREC + lane] : ((lane <= PR_XD) ? grec[(size_t)(k + 1) * PREC + lane] : 0.0); };
     double pre = fetch(0);
     sU0[lane] = (lane < nv) ? gU[lane] : 0.0;
-    if (lane < 16) sU0[64 + lane] = (64 + lane < nv) ? gU[64 + lane] : 0.0;
+    if (lane < NB1) sU0[64 + lane] = (64 + lane < nv) ? gU[64 + lane] : 0.0;
     sRec[lane] = pre;
     if (N > 1) pre = fetch(1);
     wsync();
 
     const int j0 = lane >> 1, r0 = lane & 1, j1 = 32 + (lane >> 1);
-    const bool isg = (lane == 16);
+    const bool isg = (lane == NB1);              // bank 1: columns 64.. on the lanes 0..NB1-1, the constant column g on lane NB1
     const int lq = lane >> 4, lc = lane & 15;
     double q0 = 0.0, q1 = 0.0;
     d4 Ht[NTT];
@@ -149,7 +181,7 @@ __global__ void __launch_bounds__(64, 2) cond_kernel(const PArgs pa)
             const double *rec = sRec + (k & 1) * PREC;
             apply_A2(rec, w0, w1);
             {
-                const double sel0 = (j0 == k) ? 1.0 : 0.0, sel1 = (lane < 16 && j1 == k) ? 1.0 : 0.0, selg = isg ? 1.0 : 0.0;
+                const double sel0 = (j0 == k) ? 1.0 : 0.0, sel1 = (lane < NB1 && j1 == k) ? 1.0 : 0.0, selg = isg ? 1.0 : 0.0;
 #pragma unroll
                 for (int i = 0; i < 6; i++) {
                     const double bc = rec[2 + i * 7 + 5 + r0];
@@ -172,10 +204,10 @@ __global__ void __launch_bounds__(64, 2) cond_kernel(const PArgs pa)
                 gvec[PV_D + 2 * (s - 1) + 1] = hd + hr1;
             }
             if (lane < 2 * s) sCh[hoff(s) + lane] = hr0;
-            if (lane < 16 && 64 + lane < 2 * s) sCh[hoff(s) + 64 + lane] = hr1;
+            if (lane < NB1 && 64 + lane < 2 * s) sCh[hoff(s) + 64 + lane] = hr1;
 #pragma unroll
             for (int r = 0; r < 4; r++) sStage[r * NVP + lane] = w0[r];
-            if (lane < 16) {
+            if (lane < NB1) {
 #pragma unroll
                 for (int r = 0; r < 4; r++) sStage[r * NVP + 64 + lane] = w1[r];
             }
@@ -191,7 +223,7 @@ __global__ void __launch_bounds__(64, 2) cond_kernel(const PArgs pa)
                     a0 += e * w0[r]; a1 += e * w1[r];
                 }
                 q0 += a0;
-                q1 += (lane < 16) ? a1 : 0.0;
+                q1 += (lane < NB1) ? a1 : 0.0;
             }
             const double wl = (lq == 0) ? wr[0] : (lq == 1) ? wr[1] : (lq == 2) ? wr[2] : wr[3];
             double aop[Ts], bop[Ts];
@@ -209,11 +241,11 @@ __global__ void __launch_bounds__(64, 2) cond_kernel(const PArgs pa)
             if (k + 2 < N) pre = fetch(k + 2);
             wsync();
         };
-        for (int k = 0; k < N && k < 8; k++) stage_body(k, std::integral_constant<int, 1>());
-        for (int k = 8; k < N && k < 16; k++) stage_body(k, std::integral_constant<int, 2>());
-        for (int k = 16; k < N && k < 24; k++) stage_body(k, std::integral_constant<int, 3>());
-        for (int k = 24; k < N && k < 32; k++) stage_body(k, std::integral_constant<int, 4>());
-        for (int k = 32; k < N; k++) stage_body(k, std::integral_constant<int, 5>());
+        // stage s = k+1 touches columns < 2s, i.e. ceil(s/8) tiles: one instantiation of the stage per segment of 8 stages
+        static_for<1, NT>([&](auto tsc) {
+            constexpr int Ts = decltype(tsc)::value;
+            for (int k = 8 * (Ts - 1); k < N && k < 8 * Ts; k++) stage_body(k, tsc);
+        });
         for (int s = N + 1; s <= NMAX; s++)
             for (int c = lane; c < 2 * s; c += 64) sCh[hoff(s) + c] = 0.0;
     }
@@ -229,20 +261,20 @@ __global__ void __launch_bounds__(64, 2) cond_kernel(const PArgs pa)
             }
         }
     if (lane < nv) q0 += dt * Wd[4 + r0] * (sU0[lane] - gyref[j0 * 6 + 4 + r0]);
-    if (lane < 16 && 64 + lane < nv) q1 += dt * Wd[4 + r0] * (sU0[64 + lane] - gyref[j1 * 6 + 4 + r0]);
+    if (lane < NB1 && 64 + lane < nv) q1 += dt * Wd[4 + r0] * (sU0[64 + lane] - gyref[j1 * 6 + 4 + r0]);
     // ---- hand-over: H tiles, q, the gg rows in MFMA operand layout (masked: entries right of a row's end are zero)
     {
         d4 *gh = reinterpret_cast<d4 *>(pa.hws) + (size_t)b * NTT * 64 + lane;
 #pragma unroll
         for (int t = 0; t < NTT; t++) gh[t * 64] = Ht[t];
         gvec[PV_Q + lane] = q0;
-        if (lane < 16) gvec[PV_Q + 64 + lane] = q1;
+        if (lane < NB1) gvec[PV_Q + 64 + lane] = q1;
         wsync();
         double *gc = pa.cws + (size_t)b * NCH * 64 + lane;
 #pragma unroll
         for (int T = 0; T < NT; T++)
 #pragma unroll
-            for (int c = 2 * T; c < 10; c++) {
+            for (int c = 2 * T; c < NC; c++) {
                 const int s = 4 * c + lq + 1;
                 const double v = sCh[hoff(s) + 16 * T + lc];
                 gc[cidx(c, T) * 64] = (c >= 2 * T + 2) ? v : ((16 * T + lc < 2 * s) ? v : 0.0);
@@ -251,15 +283,12 @@ __global__ void __launch_bounds__(64, 2) cond_kernel(const PArgs pa)
 }
 
 // ---------------------------------------------------------------------------------------------------------------- K4
-constexpr int E_REC = 0;                          // 2 x PREC
-constexpr int E_X = E_REC + 2 * PREC;             // (NMAX+1)*8
-constexpr int E_U = E_X + (NMAX + 1) * NX;        // NVP
-constexpr int E_DV = E_U + NVP;                   // NVP
-constexpr int E_LDS_DOUBLES = E_DV + NVP;
-
+template <int NT_>
 __global__ void __launch_bounds__(64) expand_kernel(const PArgs pa)
 {
-    __shared__ __attribute__((aligned(16))) double lds[E_LDS_DOUBLES];
+    PD_LOCALS
+    constexpr int E_REC = D::E_REC, E_X = D::E_X, E_U = D::E_U, E_DV = D::E_DV;
+    __shared__ __attribute__((aligned(16))) double lds[D::E_LDS];
     const KArgs &ka = pa.ka;
     const int lane = threadIdx.x, b = blockIdx.x;
     if (b >= ka.batch) return;
@@ -309,7 +338,7 @@ __global__ void __launch_bounds__(64) expand_kernel(const PArgs pa)
             wsync();
         }
         sU1[lane] += sDv[lane];
-        if (lane < 16) sU1[64 + lane] += sDv[64 + lane];
+        if (lane < NB1) sU1[64 + lane] += sDv[64 + lane];
     }
     wsync();
     double cl = (lane == 0) ? gvec[PV_SC] : 0.0;      // slack part of the cost (interior point kernel)
@@ -339,77 +368,79 @@ __global__ void __launch_bounds__(64) expand_kernel(const PArgs pa)
 }
 
 // ---------------------------------------------------------------------------------------------------------------- K3
-// LDS of the interior point kernel (doubles): the small vectors first (the diagonal-block substitution reads up to 15 doubles
-// in front of a packed row with a zero multiplier: in front of row 0 that lands on them, finite data), then the KKT matrix.
-constexpr int I_WH = 0;                           // NMAX     gamma / weights / C dv of the gg rows (index stage - 1)
-constexpr int I_WB = I_WH + NMAX;                 // NMAX     box-row scalars
-constexpr int I_SFX = I_WB + NMAX;                // NMAX+2   suffix sums over the steering-angle rows
-constexpr int I_DV = I_WB;                        //   (alias: a v-space vector lives here between a solve and the next publish;
-                                                  //    the box scalars and suffix sums are dead in that window)
-constexpr int I_DUMMY = I_SFX + NMAX + 2;         // 1        target of masked-off stores
-constexpr int I_PZ = I_DUMMY + 1;                 // 18       quadratic slack penalties Zl, Zu of the 9 (class, row type) pairs
-constexpr int I_M = I_PZ + 18;                    // LPK      KKT matrix / L D L' factor
-constexpr int I_LDS_DOUBLES = I_M + LPK;
-constexpr int I_LDS_BYTES = I_LDS_DOUBLES * 8;
-static_assert(NVP <= 2 * NMAX + 2, "the v-space alias must fit in the box / suffix buffers");
-static_assert(((I_LDS_BYTES + 511) / 512 * 512) * 6 <= 160 * 1024, "six workgroups per CU");
-
 // lane-derived quantities of the interior point kernel (instantiated from an opaque copy of the lane id inside the loop, see
 // TUM_LANE_DEFS in nmpc_kernel.hpp). The gg rows are held in registers in MFMA operand layout: chv[cidx(c, T)] of lane
 // (lq, lc) is entry (row 4c+lq+1, column 16T+lc), zero right of the row's end.
 #define PIPE_LANE_DEFS \
     const bool boxlane = lane < N; \
-    const bool gglane = lane >= NMAX && lane < NMAX + 20; \
+    const bool gglane = (SLOTS == 2) && lane >= NMAX && lane < NMAX + 20; \
     const int gj = gglane ? lane - NMAX : 0; \
-    const int stg0 = gglane ? 2 * gj + 1 : lane, stg1 = gglane ? 2 * gj + 2 : lane + 1; \
-    const bool on0 = gglane ? (stg0 <= N) : boxlane, on1 = gglane ? (stg1 <= N) : boxlane; \
-    const int ty0 = gglane ? 2 : 0, ty1 = gglane ? 2 : 1; \
-    const int pc0 = gglane ? ((stg0 < N) ? 1 : 2) : ((lane == 0) ? 0 : 1), pc1 = (stg1 < N) ? 1 : 2; \
-    const double psc0 = (gglane && stg0 >= N) ? 1.0 : dt, psc1 = (stg1 < N) ? dt : 1.0; \
-    const int pix0 = (pc0 * 3 + ty0) * 4, pix1 = (pc1 * 3 + ty1) * 4; \
+    /* per row slot: is there a row, its stage, its type (0 steering-rate box, 1 steering angle, 2 gg), penalty class / scale */ \
+    bool on[SLOTS]; int stg[SLOTS], ty[SLOTS], pix[SLOTS]; double psc[SLOTS]; \
+    if constexpr (SLOTS == 2) { \
+        stg[0] = gglane ? 2 * gj + 1 : lane; stg[1] = gglane ? 2 * gj + 2 : lane + 1; \
+        on[0] = gglane ? (stg[0] <= N) : boxlane; on[1] = gglane ? (stg[1] <= N) : boxlane; \
+        ty[0] = gglane ? 2 : 0; ty[1] = gglane ? 2 : 1; \
+        const int pc0 = gglane ? ((stg[0] < N) ? 1 : 2) : ((lane == 0) ? 0 : 1), pc1 = (stg[1] < N) ? 1 : 2; \
+        psc[0] = (gglane && stg[0] >= N) ? 1.0 : dt; psc[1] = (stg[1] < N) ? dt : 1.0; \
+        pix[0] = (pc0 * 3 + ty[0]) * 4; pix[1] = (pc1 * 3 + ty[1]) * 4; \
+    } else { \
+        stg[0] = lane; stg[1] = lane + 1; stg[SLOTS - 1] = lane + 1; \
+        on[0] = boxlane; on[1] = boxlane; on[SLOTS - 1] = boxlane; \
+        ty[0] = 0; ty[1] = 1; ty[SLOTS - 1] = 2; \
+        const int pc0 = (lane == 0) ? 0 : 1, pc1 = (lane + 1 < N) ? 1 : 2; \
+        psc[0] = dt; psc[1] = (lane + 1 < N) ? dt : 1.0; psc[SLOTS - 1] = psc[1]; \
+        pix[0] = (pc0 * 3 + 0) * 4; pix[1] = (pc1 * 3 + 1) * 4; pix[SLOTS - 1] = (pc1 * 3 + 2) * 4; \
+    } \
     auto pen = [&](int slot, int sd, int quad) -> double {   /* z from the workspace (start / end of the solve), Z from LDS */ \
-        const int pix = (slot == 0 ? pix0 : pix1); \
-        return (slot == 0 ? psc0 : psc1) * (quad ? sPZ[(pix >> 1) + sd] : gpen[pix + sd]); \
+        return psc[slot] * (quad ? sPZ[(pix[slot] >> 1) + sd] : gpen[pix[slot] + sd]); \
     }; \
-    const bool v0on = lane < nv, v1on = (lane < 16) && (64 + lane < nv); \
+    const bool v0on = lane < nv, v1on = (lane < NB1) && (64 + lane < nv); \
     const bool odd = lane & 1; \
     auto ctw = [&](double &o0, double &o1) {   /* C' w for this lane's columns */ \
         double a0 = (odd && v0on) ? sWb[lane >> 1] + dt * sSfx[(lane >> 1) + 1] : 0.0; \
         double a1 = (odd && v1on) ? sWb[32 + (lane >> 1)] + dt * sSfx[32 + (lane >> 1) + 1] : 0.0; \
-        double wv[10]; \
+        double wv[NC]; \
     _Pragma("unroll") \
-        for (int c = 0; c < 10; c++) wv[c] = sWh[4 * c + lq]; \
+        for (int c = 0; c < NC; c++) wv[c] = sWh[4 * c + lq]; \
         double t[NT]; \
     _Pragma("unroll") \
         for (int T = 0; T < NT; T++) { \
             double e0 = 0.0, e1 = 0.0; \
     _Pragma("unroll") \
-            for (int c = 2 * T; c < 10; c++) { if (c & 1) e1 += chv[cidx(c, T)] * wv[c]; else e0 += chv[cidx(c, T)] * wv[c]; } \
+            for (int c = 2 * T; c < NC; c++) { if (c & 1) e1 += chv[cidx(c, T)] * wv[c]; else e0 += chv[cidx(c, T)] * wv[c]; } \
             t[T] = quad_sum(e0 + e1); \
         } \
         a0 += (lq == 0) ? t[0] : (lq == 1) ? t[1] : (lq == 2) ? t[2] : t[3]; \
-        a1 += t[4]; \
+        a1 += (NT > 5 && lq == 1) ? t[NT - 1] : t[4];          /* bank 1: tile 4 on its lanes 0..15, tile 5 on 16..31 */ \
         o0 = v0on ? a0 : 0.0; o1 = v1on ? a1 : 0.0; \
     }; \
-    auto publish = [&](double w0_, double w1_, double *dstH) { \
-        const double sfx = wave_suffix(boxlane ? w1_ : 0.0, lane); \
+    auto publish = [&](const double *w_, double *dstH) {   /* slot values of this lane -> box scalars, steering suffix sums, gg weights */ \
+        const double sfx = wave_suffix(boxlane ? w_[1] : 0.0, lane); \
         wsync(); \
-        if (lane < NMAX) sWb[lane] = boxlane ? w0_ : 0.0; \
+        if (lane < NMAX) sWb[lane] = boxlane ? w_[0] : 0.0; \
         if (lane < NMAX + 1) sSfx[lane + 1] = (lane < N) ? sfx : 0.0; \
-        if (gglane) { dstH[2 * gj] = on0 ? w0_ : 0.0; dstH[2 * gj + 1] = on1 ? w1_ : 0.0; } \
+        if constexpr (SLOTS == 2) { \
+            if (gglane) { dstH[2 * gj] = on[0] ? w_[0] : 0.0; dstH[2 * gj + 1] = on[1] ? w_[1] : 0.0; } \
+        } else { \
+            if (lane < NMAX) dstH[lane] = boxlane ? w_[SLOTS - 1] : 0.0; \
+        } \
         wsync(); \
     }; \
     int rb[NT]; \
     _Pragma("unroll") \
     for (int I = 0; I < NT; I++) rb[I] = lpk(16 * I + lc, 0); \
-    const int lane1 = 64 + lc;
+    const int lane1 = 64 + (lane & (NB1 - 1));
 
 #ifndef IPM_WPS
 #define IPM_WPS 1
 #endif
-template <bool PROF>
+template <bool PROF, int NT_>
 __global__ void __launch_bounds__(64, IPM_WPS) ipm_kernel(const PArgs pa)
 {
+    PD_LOCALS
+    constexpr int I_WH = D::I_WH, I_WB = D::I_WB, I_SFX = D::I_SFX, I_DV = D::I_DV, I_DUMMY = D::I_DUMMY, I_PZ = D::I_PZ, I_M = D::I_M;
+    constexpr int NS2 = 2 * SLOTS;                 // row sides of this lane
     extern __shared__ __attribute__((aligned(16))) double lds[];
     const KArgs &ka = pa.ka;
     const int lane = threadIdx.x;
@@ -440,12 +471,12 @@ __global__ void __launch_bounds__(64, IPM_WPS) ipm_kernel(const PArgs pa)
     const double *gcw = pa.cws + (size_t)b * NCH * 64 + lane;
 #pragma unroll
     for (int i = 0; i < NCH; i++) chv[i] = gcw[i * 64];
-    const double q0 = gvec[PV_Q + lane], q1 = (lane < 16) ? gvec[PV_Q + 64 + lane] : 0.0;
+    const double q0 = gvec[PV_Q + lane], q1 = (lane < NB1) ? gvec[PV_Q + 64 + lane] : 0.0;
     const int lq = lane >> 4, lc = lane & 15;
     wsync();
 
     double v0 = 0.0, v1 = 0.0, rv0, rv1, qn;
-    double rowst[6][4];      // IPM row state of this lane: [s, t, lam, mu, rs, rt][slot*2+side]
+    double rowst[6][NS2];    // IPM row state of this lane: [s, t, lam, mu, rs, rt][slot*2+side]
     const double npairs = 12.0 * N;
     const double inv_npairs = 1.0 / npairs;
     int it = 0, qp_status = 1;
@@ -454,20 +485,21 @@ __global__ void __launch_bounds__(64, IPM_WPS) ipm_kernel(const PArgs pa)
         PIPE_LANE_DEFS
         {
             const int NB = N + 1;
-            double dval[2], lo[2], hi[2];
-            {
-                const int i0 = on0 ? stg0 : (gglane ? 1 : 0), i1 = on1 ? stg1 : 1;
-                dval[0] = gglane ? gvec[PV_D + 2 * (i0 - 1) + 1] : gU[2 * i0 + 1];
-                lo[0] = gbnd[(gglane ? 4 : 0) * NB + i0]; hi[0] = gbnd[(gglane ? 5 : 1) * NB + i0];
-                dval[1] = gglane ? gvec[PV_D + 2 * (i1 - 1) + 1] : gvec[PV_D + 2 * (i1 - 1)];
-                lo[1] = gbnd[(gglane ? 4 : 2) * NB + i1]; hi[1] = gbnd[(gglane ? 5 : 3) * NB + i1];
+            double dval[SLOTS], lo[SLOTS], hi[SLOTS];
+#pragma unroll
+            for (int rr = 0; rr < SLOTS; rr++) {
+                // value of the row at dU = 0 and its bounds: steering rate of the iterate / steering angle / gg row (cond_kernel)
+                const int t_ = ty[rr];
+                const int i_ = on[rr] ? stg[rr] : ((t_ == 0) ? 0 : 1);
+                dval[rr] = (t_ == 0) ? gU[2 * i_ + 1] : gvec[PV_D + 2 * (i_ - 1) + ((t_ == 2) ? 1 : 0)];
+                lo[rr] = gbnd[(2 * t_) * NB + i_]; hi[rr] = gbnd[(2 * t_ + 1) * NB + i_];
             }
 #pragma unroll
-            for (int rr = 0; rr < 2; rr++)
+            for (int rr = 0; rr < SLOTS; rr++)
 #pragma unroll
                 for (int sd = 0; sd < 2; sd++) {
                     const int k = rr * 2 + sd;
-                    const bool on = rr ? on1 : on0;
+                    const bool on_ = on[rr];
                     const double eps = sd ? -1.0 : 1.0, bnd = sd ? hi[rr] : lo[rr];
                     const double r0v = eps * (dval[rr] - bnd);
                     const double z = pen(rr, sd, 0), Z = pen(rr, sd, 1);
@@ -478,19 +510,24 @@ __global__ void __launch_bounds__(64, IPM_WPS) ipm_kernel(const PArgs pa)
                     double ms = z + Z * s0 - lam;
                     const double msf = 1e-2 * p_mu0 / s0;
                     if (ms < msf) ms = msf;
-                    ROWF(0, k) = on ? s0 : 1.0; ROWF(1, k) = on ? t : 1.0; ROWF(2, k) = on ? lam : 1.0; ROWF(3, k) = on ? ms : 1.0;
-                    ROWF(4, k) = on ? z + Z * s0 - lam - ms : 0.0;
-                    ROWF(5, k) = on ? t - r0v - s0 : 0.0;
+                    ROWF(0, k) = on_ ? s0 : 1.0; ROWF(1, k) = on_ ? t : 1.0; ROWF(2, k) = on_ ? lam : 1.0; ROWF(3, k) = on_ ? ms : 1.0;
+                    ROWF(4, k) = on_ ? z + Z * s0 - lam - ms : 0.0;
+                    ROWF(5, k) = on_ ? t - r0v - s0 : 0.0;
                 }
         }
         wsync();
-        publish(ROWF(2, 0) - ROWF(2, 1), ROWF(2, 2) - ROWF(2, 3), sWh);
+        {
+            double w_[SLOTS];
+#pragma unroll
+            for (int rr = 0; rr < SLOTS; rr++) w_[rr] = ROWF(2, 2 * rr) - ROWF(2, 2 * rr + 1);
+            publish(w_, sWh);
+        }
         {
             double c0, c1;
             ctw(c0, c1);
             rv0 = v0on ? q0 - c0 : 0.0; rv1 = v1on ? q1 - c1 : 0.0;
         }
-        qn = wave_max(fmax(fabs(q0), (lane < 16) ? fabs(q1) : 0.0));
+        qn = wave_max(fmax(fabs(q0), (lane < NB1) ? fabs(q1) : 0.0));
         if (qn < 1.0) qn = 1.0;
     }
     TUM_TICK(1);
@@ -505,20 +542,20 @@ __global__ void __launch_bounds__(64, IPM_WPS) ipm_kernel(const PArgs pa)
         double gap;
         {
             double ls = fmax(fabs(rv0), fabs(rv1)), li = 0.0, lcmp = 0.0, lg = 0.0;
-            double gsum[2];
+            double gsum[SLOTS];
 #pragma unroll
-            for (int rr = 0; rr < 2; rr++) {
+            for (int rr = 0; rr < SLOTS; rr++) {
                 gsum[rr] = 0.0;
-                const bool on = rr ? on1 : on0;
+                const bool on_ = on[rr];
 #pragma unroll
                 for (int sd = 0; sd < 2; sd++) {
                     const int k = rr * 2 + sd;
                     const double s_ = ROWF(0, k), t_ = ROWF(1, k), l_ = ROWF(2, k), m_ = ROWF(3, k);
-                    ls = fmax(ls, on ? fabs(ROWF(4, k)) : 0.0);
-                    li = fmax(li, on ? fabs(ROWF(5, k)) : 0.0);
+                    ls = fmax(ls, on_ ? fabs(ROWF(4, k)) : 0.0);
+                    li = fmax(li, on_ ? fabs(ROWF(5, k)) : 0.0);
                     const double c1 = t_ * l_, c2 = s_ * m_;
-                    lcmp = fmax(lcmp, on ? fmax(c1, c2) : 0.0);
-                    lg += on ? c1 + c2 : 0.0;
+                    lcmp = fmax(lcmp, on_ ? fmax(c1, c2) : 0.0);
+                    lg += on_ ? c1 + c2 : 0.0;
                     // D = 1/(Z s + mu), G = 1/(t + lam s D): recomputed behind the factorisation rather than held across it
                     const double D_ = frcp(pen(rr, sd, 1) * s_ + m_);
                     gsum[rr] += l_ * frcp(t_ + l_ * s_ * D_);
@@ -532,13 +569,13 @@ __global__ void __launch_bounds__(64, IPM_WPS) ipm_kernel(const PArgs pa)
             if (!__any(lane_open)) { qp_status = 0; break; }
             if (it >= p_itmax) { qp_status = 1; break; }
             TUM_TICK(2);
-            publish(gsum[0], gsum[1], sGamH);
+            publish(gsum, sGamH);
         }
         // ---- M = H + C' Gamma C, tile columns outermost; H streamed from the workspace two tiles ahead
         {
-            double gch[10];
+            double gch[NC];
 #pragma unroll
-            for (int c = 0; c < 10; c++) gch[c] = sGamH[4 * c + lq];
+            for (int c = 0; c < NC; c++) gch[c] = sGamH[4 * c + lq];
             const double dt2 = dt * dt;
             // H comes back from the workspace HD tiles ahead of its use (tile order (0,0) (0,1) (1,1) (0,2) ...: tile n of that
             // order is (K, I) with n = I (I + 1) / 2 + K)
@@ -557,9 +594,9 @@ __global__ void __launch_bounds__(64, IPM_WPS) ipm_kernel(const PArgs pa)
                 const double sfxoI = ((lq & 1) && (lc & 1) && col < nv) ? dt2 * sSfx[(col >> 1) + 1] : 0.0;
                 // gamma-scaled operands of tile column I (at most 10, reused by every K <= I; scaling the column operand
                 // instead of the row operand keeps the number of live products at 10 instead of 30)
-                double bs[10];
+                double bs[NC];
 #pragma unroll
-                for (int c = 2 * I; c < 10; c++) bs[c] = chv[cidx(c, I)] * gch[c];
+                for (int c = 2 * I; c < NC; c++) bs[c] = chv[cidx(c, I)] * gch[c];
 #pragma unroll
                 for (int K = 0; K <= I; K++) {
                     const int n = I * (I + 1) / 2 + K;
@@ -581,7 +618,7 @@ __global__ void __launch_bounds__(64, IPM_WPS) ipm_kernel(const PArgs pa)
                         for (int jj = 0; jj < 4; jj++) acc[jj] += sfxoI;
                     }
 #pragma unroll
-                    for (int c = 2 * I; c < 10; c++) acc = mfma(chv[cidx(c, K)], bs[c], acc);
+                    for (int c = 2 * I; c < NC; c++) acc = mfma(chv[cidx(c, K)], bs[c], acc);
 #pragma unroll
                     for (int jj = 0; jj < 4; jj++) {
                         const int rg = 16 * K + lq + 4 * jj, cg = 16 * I + lc;
@@ -632,7 +669,7 @@ __global__ void __launch_bounds__(64, IPM_WPS) ipm_kernel(const PArgs pa)
                 const bool rin = row < NVP;
                 const int rbase = lpk(rin ? row : NVP - 1, c0);
                 double e0 = sM[rbase], e1 = sM[rbase + 1], e2 = sM[rbase + 2], e3 = sM[rbase + 3];
-                const bool two = (J == 0) && (m < 3);
+                const bool two = (c0 + 68 < NVP);                // rows c0+68.. exist (a compile-time fact per micro-panel)
                 const int row1 = c0 + 68 + lane;
                 const bool rin1 = two && (row1 < NVP);
                 const int rbase1 = lpk(rin1 ? row1 : NVP - 1, c0);
@@ -711,13 +748,13 @@ __global__ void __launch_bounds__(64, IPM_WPS) ipm_kernel(const PArgs pa)
                 wsync();
             };
             inv_diag(lane, true);
-            inv_diag(lane1, lane < 16);
+            inv_diag(lane1, lane < NB1);
         }
         TUM_TICK(4);
 
         if (!(dmin > 1e-300)) { qp_status = 3; break; }
         // ---- predictor / corrector
-        double rD[4], rG[4];       // D, G of every row side: fixed for both solves of this iteration
+        double rD[NS2], rG[NS2];   // D, G of every row side: fixed for both solves of this iteration
         {
             int lane_r = lane_outer;
             asm volatile("" : "+v"(lane_r));
@@ -725,12 +762,12 @@ __global__ void __launch_bounds__(64, IPM_WPS) ipm_kernel(const PArgs pa)
             const int lq = lane >> 4, lc = lane & 15;
             PIPE_LANE_DEFS
 #pragma unroll
-            for (int k = 0; k < 4; k++) {
+            for (int k = 0; k < NS2; k++) {
                 rD[k] = frcp(pen(k >> 1, k & 1, 1) * ROWF(0, k) + ROWF(3, k));
                 rG[k] = frcp(ROWF(1, k) + ROWF(2, k) * ROWF(0, k) * rD[k]);
             }
         }
-        double cross1[4], cross2[4];
+        double cross1[NS2], cross2[NS2];
         double dv0 = 0.0, dv1 = 0.0, alpha = 1.0, sigma = 0.0;
 #pragma unroll 1
         for (int pass = 0; pass < 2; pass++) {
@@ -741,9 +778,9 @@ __global__ void __launch_bounds__(64, IPM_WPS) ipm_kernel(const PArgs pa)
             PIPE_LANE_DEFS
             const double tau = (pass == 1) ? fmax(sigma * gap, 0.1 * p_tc) : 0.0;
             {
-                double w[2];
+                double w[SLOTS];
 #pragma unroll
-                for (int rr = 0; rr < 2; rr++) {
+                for (int rr = 0; rr < SLOTS; rr++) {
                     w[rr] = 0.0;
 #pragma unroll
                     for (int sd = 0; sd < 2; sd++) {
@@ -756,7 +793,7 @@ __global__ void __launch_bounds__(64, IPM_WPS) ipm_kernel(const PArgs pa)
                         w[rr] += sd ? -gr : gr;
                     }
                 }
-                publish(w[0], w[1], sWh);
+                publish(w, sWh);
             }
             double b0, b1;
             ctw(b0, b1);
@@ -770,11 +807,12 @@ __global__ void __launch_bounds__(64, IPM_WPS) ipm_kernel(const PArgs pa)
                 double bj[NT], vs[NT][4];
 #pragma unroll
                 for (int J = 0; J < 4; J++) bj[J] = lane_gather(b0, (16 * J + lc) << 2);
-                bj[4] = lane_gather(b1, lc << 2);
+#pragma unroll
+                for (int J = 4; J < NT; J++) bj[J] = lane_gather(b1, (16 * (J - 4) + lc) << 2);
                 // (with the whole register file the entries of the factor this lane needs are fetched before the chain starts:
                 //  the chain itself then waits on row swaps and lane gathers only, not on LDS reads issued one tile at a time)
-                double Lo[NTT][4], Ld[NT][4], Lp[NT];
-                if (IPM_WPS == 1) {
+                double Lo[NTT][4], Ld[NT][4], Lp[NT];       // (five-tile build with the whole register file only)
+                if (IPM_WPS == 1 && NT == 5) {
 #pragma unroll
                     for (int J = 0; J < NT; J++) {
 #pragma unroll
@@ -796,7 +834,7 @@ __global__ void __launch_bounds__(64, IPM_WPS) ipm_kernel(const PArgs pa)
                         for (int K = 0; K < J; K++)
 #pragma unroll
                             for (int jj = 0; jj < 4; jj++) {
-                                const double lv = (IPM_WPS == 1) ? Lo[tidx(K, J)][jj] : sM[rb[J] + 16 * K + lq + 4 * jj];
+                                const double lv = (IPM_WPS == 1 && NT == 5) ? Lo[tidx(K, J)][jj] : sM[rb[J] + 16 * K + lq + 4 * jj];
                                 if (jj & 1) acc1 += lv * vs[K][jj]; else acc += lv * vs[K][jj];
                             }
                         t -= quad_sum(acc + acc1);
@@ -804,18 +842,18 @@ __global__ void __launch_bounds__(64, IPM_WPS) ipm_kernel(const PArgs pa)
                     double a2 = ondiag ? t : 0.0;
 #pragma unroll
                     for (int jj = 0; jj < 4; jj++) {
-                        const double lv = (IPM_WPS == 1) ? Ld[J][jj] : sM[rb[J] + 16 * J + lq + 4 * jj];
+                        const double lv = (IPM_WPS == 1 && NT == 5) ? Ld[J][jj] : sM[rb[J] + 16 * J + lq + 4 * jj];
                         const double tv = lane_gather(t, ga[jj]);
                         a2 += ((lq + 4 * jj < lc) ? lv : 0.0) * tv;
                     }
                     const double y = quad_sum(a2);
-                    bj[J] = y * frcp((IPM_WPS == 1) ? Lp[J] : sM[rb[J] + 16 * J + lc]);
+                    bj[J] = y * frcp((IPM_WPS == 1 && NT == 5) ? Lp[J] : sM[rb[J] + 16 * J + lc]);
                     if (J < NT - 1) {
 #pragma unroll
                         for (int jj = 0; jj < 4; jj++) vs[J][jj] = lane_gather(y, ga[jj]);
                     }
                 }
-                if (IPM_WPS == 1) {
+                if (IPM_WPS == 1 && NT == 5) {
 #pragma unroll
                     for (int J = 0; J < NT; J++) {
 #pragma unroll
@@ -836,7 +874,7 @@ __global__ void __launch_bounds__(64, IPM_WPS) ipm_kernel(const PArgs pa)
                         for (int I = J + 1; I < NT; I++)
 #pragma unroll
                             for (int jj = 0; jj < 4; jj++) {
-                                const double lv = (IPM_WPS == 1) ? Lo[tidx(J, I)][jj] : sM[lpk(16 * I + lq + 4 * jj, 0) + 16 * J + lc];
+                                const double lv = (IPM_WPS == 1 && NT == 5) ? Lo[tidx(J, I)][jj] : sM[lpk(16 * I + lq + 4 * jj, 0) + 16 * J + lc];
                                 if (jj & 1) acc1 += lv * vs[I][jj]; else acc += lv * vs[I][jj];
                             }
                         t -= quad_sum(acc + acc1);
@@ -844,7 +882,7 @@ __global__ void __launch_bounds__(64, IPM_WPS) ipm_kernel(const PArgs pa)
                     double a2 = ondiag ? t : 0.0;
 #pragma unroll
                     for (int jj = 0; jj < 4; jj++) {
-                        const double lv = (IPM_WPS == 1) ? Ld[J][jj] : sM[lpk(16 * J + lq + 4 * jj, 0) + 16 * J + lc];
+                        const double lv = (IPM_WPS == 1 && NT == 5) ? Ld[J][jj] : sM[lpk(16 * J + lq + 4 * jj, 0) + 16 * J + lc];
                         const double tv = lane_gather(t, ga[jj]);
                         a2 += ((lq + 4 * jj > lc) ? lv : 0.0) * tv;
                     }
@@ -856,16 +894,16 @@ __global__ void __launch_bounds__(64, IPM_WPS) ipm_kernel(const PArgs pa)
                     }
                 }
                 b0 = (lq == 0) ? bj[0] : (lq == 1) ? bj[1] : (lq == 2) ? bj[2] : bj[3];
-                b1 = (lane < 16) ? bj[4] : 0.0;
+                b1 = (lane < NB1) ? ((NT > 5 && lq == 1) ? bj[NT - 1] : bj[4]) : 0.0;
             }
             dv0 = b0; dv1 = b1;
             TUM_TICK(6);
             wsync();
             sDv[lane] = dv0;
-            if (lane < 16) sDv[64 + lane] = dv1;
+            if (lane < NB1) sDv[64 + lane] = dv1;
             wsync();
             // row phase B2: C*dv for this lane's rows, step in (s,t,lam,mu), step length
-            double cdv[2];
+            double cdv[SLOTS];
             {
                 const double xo = boxlane ? sDv[2 * lane + 1] : 0.0;
                 const double pfx = dt * wave_prefix(xo, lane);
@@ -874,9 +912,9 @@ __global__ void __launch_bounds__(64, IPM_WPS) ipm_kernel(const PArgs pa)
                 double dvT[NT];
 #pragma unroll
                 for (int T = 0; T < NT; T++) dvT[T] = sDv[16 * T + lc];
-                double pr[10];
+                double pr[NC];
 #pragma unroll
-                for (int c = 0; c < 10; c++) {
+                for (int c = 0; c < NC; c++) {
                     double a = 0.0;
 #pragma unroll
                     for (int T = 0; 2 * T <= c; T++) a += chv[cidx(c, T)] * dvT[T];
@@ -886,20 +924,24 @@ __global__ void __launch_bounds__(64, IPM_WPS) ipm_kernel(const PArgs pa)
                 wsync();
                 if (lc == 15) {
 #pragma unroll
-                    for (int c = 0; c < 10; c++) sWh[4 * c + lq] = pr[c];
+                    for (int c = 0; c < NC; c++) sWh[4 * c + lq] = pr[c];
                 }
                 wsync();
-                cdv[0] = gglane ? sWh[2 * gj] : xo;
-                cdv[1] = gglane ? sWh[2 * gj + 1] : pfx;
+                if constexpr (SLOTS == 2) {
+                    cdv[0] = gglane ? sWh[2 * gj] : xo;
+                    cdv[1] = gglane ? sWh[2 * gj + 1] : pfx;
+                } else {
+                    cdv[0] = xo; cdv[1] = pfx; cdv[SLOTS - 1] = sWh[(lane < NMAX) ? lane : 0];
+                }
             }
             double amax = 1.0, lmu = 0.0;
-            double dcur[4][4];
+            double dcur[4][NS2];
 #pragma unroll
-            for (int rr = 0; rr < 2; rr++)
+            for (int rr = 0; rr < SLOTS; rr++)
 #pragma unroll
                 for (int sd = 0; sd < 2; sd++) {
                     const int k = rr * 2 + sd;
-                    const bool on = rr ? on1 : on0;
+                    const bool on_ = on[rr];
                     const double eps = sd ? -1.0 : 1.0;
                     const double s_ = ROWF(0, k), t_ = ROWF(1, k), l_ = ROWF(2, k), m_ = ROWF(3, k);
                     const double is_ = frcp(s_), il_ = frcp(l_), it_ = frcp(t_), im_ = frcp(m_);
@@ -913,33 +955,33 @@ __global__ void __launch_bounds__(64, IPM_WPS) ipm_kernel(const PArgs pa)
                     const double dsl = (dl - rsk - rc2 * is_) * iDs;
                     const double dm = (-rc2 - m_ * dsl) * is_;
                     const double dtt = (-rc1 - t_ * dl) * il_;
-                    dcur[0][k] = on ? dsl : 0.0; dcur[1][k] = on ? dtt : 0.0; dcur[2][k] = on ? dl : 0.0; dcur[3][k] = on ? dm : 0.0;
+                    dcur[0][k] = on_ ? dsl : 0.0; dcur[1][k] = on_ ? dtt : 0.0; dcur[2][k] = on_ ? dl : 0.0; dcur[3][k] = on_ ? dm : 0.0;
                     double q = fmax(fmax(-dsl * is_, -dtt * it_), fmax(-dl * il_, -dm * im_));
-                    q = on ? q : 0.0;
+                    q = on_ ? q : 0.0;
                     amax = fmax(amax, q);
-                    if (pass == 0) { cross1[k] = on ? dtt * dl : 0.0; cross2[k] = on ? dsl * dm : 0.0; }
+                    if (pass == 0) { cross1[k] = on_ ? dtt * dl : 0.0; cross2[k] = on_ ? dsl * dm : 0.0; }
                 }
             amax = frcp(wave_max(amax));
             if (pass == 0) {
 #pragma unroll
-                for (int k = 0; k < 4; k++) {
+                for (int k = 0; k < NS2; k++) {
                     const double pr_ = (ROWF(1, k) + amax * dcur[1][k]) * (ROWF(2, k) + amax * dcur[2][k])
                                      + (ROWF(0, k) + amax * dcur[0][k]) * (ROWF(3, k) + amax * dcur[3][k]);
-                    lmu += ((k < 2) ? on0 : on1) ? pr_ : 0.0;
+                    lmu += on[k >> 1] ? pr_ : 0.0;
                 }
                 const double mu_aff = wave_sum(lmu) * inv_npairs;
                 const double ratio = mu_aff * frcp(gap);
                 sigma = ratio * ratio * ratio;
                 if (amax < 0.1) {
 #pragma unroll
-                    for (int k = 0; k < 4; k++) { cross1[k] = 0.0; cross2[k] = 0.0; }
+                    for (int k = 0; k < NS2; k++) { cross1[k] = 0.0; cross2[k] = 0.0; }
                 }
             } else {
                 alpha = (amax >= 1.0) ? 1.0 : 0.995 * amax;
                 if (alpha >= 1e-12) {
                     const double om_ = 1.0 - alpha;
 #pragma unroll
-                    for (int k = 0; k < 4; k++) {
+                    for (int k = 0; k < NS2; k++) {
 #pragma unroll
                         for (int f = 0; f < 4; f++) ROWF(f, k) += alpha * dcur[f][k];
                         ROWF(4, k) *= om_; ROWF(5, k) *= om_;
@@ -962,29 +1004,29 @@ __global__ void __launch_bounds__(64, IPM_WPS) ipm_kernel(const PArgs pa)
     double cl = 0.0;
     {
 #pragma unroll
-        for (int rr = 0; rr < 2; rr++)
+        for (int rr = 0; rr < SLOTS; rr++)
 #pragma unroll
             for (int sd = 0; sd < 2; sd++) {
                 const double sv = ROWF(0, rr * 2 + sd);
                 const double c = pen(rr, sd, 0) * sv + 0.5 * pen(rr, sd, 1) * sv * sv;
-                cl += (rr ? on1 : on0) ? c : 0.0;
+                cl += on[rr] ? c : 0.0;
             }
         if (ka.slack) {
             double *sl = ka.slack + (size_t)b * 6 * N;
+            // order: [lower: box_k (N) | (bx_k, h_k) k=1..N] then the same for upper
 #pragma unroll
-            for (int sd = 0; sd < 2; sd++) {
-                if (boxlane) {
-                    sl[sd * 3 * N + lane] = ROWF(0, 0 + sd);
-                    sl[sd * 3 * N + N + 2 * lane] = ROWF(0, 2 + sd);
+            for (int sd = 0; sd < 2; sd++)
+#pragma unroll
+                for (int rr = 0; rr < SLOTS; rr++) {
+                    if (!on[rr]) continue;
+                    const int idx = (ty[rr] == 0) ? stg[rr] : N + 2 * (stg[rr] - 1) + ((ty[rr] == 2) ? 1 : 0);
+                    sl[sd * 3 * N + idx] = ROWF(0, 2 * rr + sd);
                 }
-                if (gglane && on0) sl[sd * 3 * N + N + 2 * (stg0 - 1) + 1] = ROWF(0, 0 + sd);
-                if (gglane && on1) sl[sd * 3 * N + N + 2 * (stg1 - 1) + 1] = ROWF(0, 2 + sd);
-            }
         }
     }
     const double scost = wave_sum(cl);
     gvec[PV_DV + lane] = v0;
-    if (lane < 16) gvec[PV_DV + 64 + lane] = v1;
+    if (lane < NB1) gvec[PV_DV + 64 + lane] = v1;
     TUM_TICK(9);
     if (PROF && lane == 0)
         for (int i = 0; i < 12; i++) ka.prof[(size_t)b * 12 + i] = pacc[i];

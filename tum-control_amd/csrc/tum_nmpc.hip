@@ -82,7 +82,7 @@ static hipError_t dalloc(T **p, size_t n) { hipError_t e = hipMalloc((void **)p,
 extern "C" tum_ocp *tum_ocp_create(const tum_ocp_desc *desc)
 {
     if (!desc) { fail("null desc"); return nullptr; }
-    if (desc->N < 1 || desc->N > TUM_N_MAX) { fail("N out of range (1..40)"); return nullptr; }
+    if (desc->N < 1 || desc->N > TUM_N_MAX) { fail("N out of range (1..48)"); return nullptr; }
     if (desc->batch < 1) { fail("batch < 1"); return nullptr; }
     if (desc->nsub < 1 || !(desc->dt > 0)) { fail("bad nsub/dt"); return nullptr; }
     if (desc->n_ggv < 2 || desc->n_ggv > 16) { fail("n_ggv out of range (2..16)"); return nullptr; }
@@ -160,8 +160,10 @@ extern "C" tum_ocp *tum_ocp_create(const tum_ocp_desc *desc)
     ka.status = c->dstatus; ka.qp_iter = c->dqpiter; ka.qp_status = c->dqpstatus;
     ka.qpin = c->dqpin; ka.dbg = c->ddbg; ka.dbg_stride = DBG_STRIDE; ka.prof = c->dprof; ka.ws = c->dws;
 
-    if (hipFuncSetAttribute((const void *)ipm_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024) != hipSuccess ||
-        hipFuncSetAttribute((const void *)ipm_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024) != hipSuccess ||
+    if (hipFuncSetAttribute((const void *)ipm_kernel<false, 5>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024) != hipSuccess ||
+        hipFuncSetAttribute((const void *)ipm_kernel<true, 5>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024) != hipSuccess ||
+        hipFuncSetAttribute((const void *)ipm_kernel<false, 6>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024) != hipSuccess ||
+        hipFuncSetAttribute((const void *)ipm_kernel<true, 6>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024) != hipSuccess ||
         hipFuncSetAttribute((const void *)nmpc_rti_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) != hipSuccess ||
         hipFuncSetAttribute((const void *)nmpc_rti_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) != hipSuccess ||
         hipFuncSetAttribute((const void *)nmpc_rti_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) != hipSuccess ||
@@ -196,6 +198,7 @@ extern "C" int tum_ocp_snmpc_attach(tum_ocp *c, int ns, int L, const double *Apc
 {
     if (!c || !Apce) return fail("null argument");
     if (c->sn) return fail("snmpc_attach: already attached");
+    if (c->N > NMAX) return fail("snmpc_attach: the coupled SNMPC OCP is built for N <= 40");
     if (ns < 1 || ns > SN_NSMAX) return fail("snmpc_attach: n_samples out of range (1..16)");
     if (L < 1 || L > SN_LMAX) return fail("snmpc_attach: number of PCE terms out of range (1..16)");
     if (uph < 0 || uph > c->N || uph > SN_UPHMAX) return fail("snmpc_attach: uncertainty propagation horizon out of range (0..min(N,31))");
@@ -517,12 +520,14 @@ extern "C" int tum_ocp_cost_set(tum_ocp *c, int stage, const char *field, const 
 static int ensure_workspace(tum_ocp *c)
 {
     const size_t B = c->batch;
+    const bool big = c->N > NMAX;          // horizons beyond 40: six MFMA tiles (PD<6>)
+    const size_t ntt = big ? PD<6>::NTT : PD<5>::NTT, nch = big ? PD<6>::NCH : PD<5>::NCH, pvec = big ? PD<6>::PVEC : PD<5>::PVEC;
     if (c->pipe && !c->dhws) {
-        if (dalloc(&c->dhws, B * (size_t)NTT * 256) != hipSuccess) return fail("workspace allocation failed (H tiles)");
+        if (dalloc(&c->dhws, B * ntt * 256) != hipSuccess) return fail("workspace allocation failed (H tiles)");
     }
     if (c->pipe && !c->drec) {
-        if (dalloc(&c->drec, B * (size_t)(c->N + 1) * PREC) != hipSuccess || dalloc(&c->dcws, B * (size_t)NCH * 64) != hipSuccess ||
-            dalloc(&c->dvec, B * (size_t)PVEC) != hipSuccess) return fail("workspace allocation failed (pipeline)");
+        if (dalloc(&c->drec, B * (size_t)(c->N + 1) * PREC) != hipSuccess || dalloc(&c->dcws, B * nch * 64) != hipSuccess ||
+            dalloc(&c->dvec, B * pvec) != hipSuccess) return fail("workspace allocation failed (pipeline)");
     }
     return 0;
 }
@@ -546,6 +551,12 @@ extern "C" int tum_ocp_set_kernel(tum_ocp *c, const char *name)
 static int resolve_kernel(tum_ocp *c)
 {
     c->pipe = !c->sn && !(c->ka.flags & 2) && (c->kmode == 2 || (c->kmode == 0 && c->batch > 1024));
+    if (c->N > NMAX) {      // the fused kernel covers N <= 40; longer horizons exist as a pipeline instantiation only
+        if (c->sn) return fail("solve: the coupled SNMPC OCP is built for N <= 40");
+        if (c->ka.flags & 2) return fail("debug_dump: the condensed-QP dump is built for N <= 40");
+        if (c->kmode == 1) return fail("solve: kernel 'fused' is built for N <= 40 (use 'auto' or 'pipeline')");
+        c->pipe = true;
+    }
     return ensure_workspace(c);
 }
 
@@ -556,14 +567,19 @@ static int launch_pipeline(tum_ocp *c, bool events)
     const bool prof = (c->ka.flags & 4) != 0;
     const long long items = (long long)c->batch * (c->N + 1);
     hipLaunchKernelGGL(lin_kernel, dim3((unsigned)((items + 63) / 64)), dim3(64), 0, c->stream, pa);
-    hipLaunchKernelGGL(cond_kernel, dim3(c->batch), dim3(64), 0, c->stream, pa);
-    if (events) HIPCHK(hipEventRecord(c->evi0, c->stream));
-    static const int ipm_lds = [] { const char *e = getenv("TUM_IPM_LDS"); const int v = e ? atoi(e) : 0; return (v > I_LDS_BYTES && v <= 64 * 1024) ? v : I_LDS_BYTES; }();
-    // (development aid: a larger request lowers the number of OCPs that share a CU)
-    if (prof) hipLaunchKernelGGL(ipm_kernel<true>, dim3(c->batch), dim3(64), ipm_lds, c->stream, pa);
-    else hipLaunchKernelGGL(ipm_kernel<false>, dim3(c->batch), dim3(64), ipm_lds, c->stream, pa);
-    if (events) HIPCHK(hipEventRecord(c->evi1, c->stream));
-    hipLaunchKernelGGL(expand_kernel, dim3(c->batch), dim3(64), 0, c->stream, pa);
+    // (development aid: a larger LDS request lowers the number of OCPs that share a CU)
+    static const int lds_req = [] { const char *e = getenv("TUM_IPM_LDS"); const int v = e ? atoi(e) : 0; return (v > 0 && v <= 64 * 1024) ? v : 0; }();
+    auto rest = [&](auto ntc) {
+        constexpr int NTv = decltype(ntc)::value;
+        const int ipm_lds = lds_req > PD<NTv>::I_LDS_BYTES ? lds_req : PD<NTv>::I_LDS_BYTES;
+        hipLaunchKernelGGL(cond_kernel<NTv>, dim3(c->batch), dim3(64), 0, c->stream, pa);
+        if (events) (void)hipEventRecord(c->evi0, c->stream);
+        if (prof) hipLaunchKernelGGL((ipm_kernel<true, NTv>), dim3(c->batch), dim3(64), ipm_lds, c->stream, pa);
+        else hipLaunchKernelGGL((ipm_kernel<false, NTv>), dim3(c->batch), dim3(64), ipm_lds, c->stream, pa);
+        if (events) (void)hipEventRecord(c->evi1, c->stream);
+        hipLaunchKernelGGL(expand_kernel<NTv>, dim3(c->batch), dim3(64), 0, c->stream, pa);
+    };
+    if (c->N > NMAX) rest(std::integral_constant<int, 6>()); else rest(std::integral_constant<int, 5>());
     return 0;
 }
 
@@ -799,9 +815,10 @@ extern "C" int tum_ocp_debug_dump(tum_ocp *c, int b, double *out, int len)
     DevGuard guard(c->d.device);
     if (len > DBG_STRIDE) len = DBG_STRIDE;
     c->ka.flags |= 2;
-    if (launch(c)) return 1;
-    HIPCHK(hipStreamSynchronize(c->stream));
+    const int rc = launch(c);
     c->ka.flags &= ~2;
+    if (rc) return 1;
+    HIPCHK(hipStreamSynchronize(c->stream));
     HIPCHK(hipMemcpy(out, c->ddbg + (size_t)b * DBG_STRIDE, sizeof(double) * len, hipMemcpyDeviceToHost));
     return 0;
 }
