@@ -1,0 +1,13 @@
+import sys, time, numpy as np
+sys.path.insert(0, ".")
+import torch
+from tum_control_amd.closed_loop import ClosedLoopBatch
+for k in ("fused", "pipeline"):
+    for B, steps in ((4096, 300), (26, 1000)):
+        cl = ClosedLoopBatch("monteblanco", batch=B, N=38, Tp=3.04, on_device=True, log_capacity=steps)
+        cl.solver.set_kernel(k)
+        cl.run(50)
+        t0 = time.perf_counter(); lg = cl.run(steps - 50); wall = time.perf_counter() - t0
+        dbg = lg["simSolverDebug"]
+        print(f"{k:9s} batch {B}: {1e3 * wall / (steps - 50):.3f} ms/step, {B * (steps - 50) / wall:,.0f} closed-loop solves/s, status0 {(dbg[:, :, 4] == 0).mean():.4f}, qp_iter {dbg[:, :, 3].mean():.2f}")
+        del cl

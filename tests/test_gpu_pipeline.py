@@ -173,3 +173,23 @@ def test_long_horizons_vs_oracle(N, B):
     with pytest.raises(Exception, match="N <= 40"):
         s.debug_dump(0)
     assert s.solve() == 0
+
+
+def test_long_horizon_closed_loops():
+    """N = 45 (Tp = 3.6 s) in closed loop: the loop on the host around the C-ABI against the all-device loop (planner, pipeline,
+    plant + estimator as kernels), and the robustified controller at N = 47 (covariance back-off from the pipeline's stage records)"""
+    from tum_control_amd.closed_loop import ClosedLoopBatch
+    logs = {}
+    for dev in (False, True):
+        cl = ClosedLoopBatch("lvms", batch=3, N=45, Tp=3.6, on_device=dev, log_capacity=40)
+        logs[dev] = cl.run(40)
+    for f in ("simU", "CiLX", "MPC_SimX"):
+        np.testing.assert_allclose(logs[True][f], logs[False][f], rtol=1e-8, atol=1e-8, err_msg=f)
+    assert (logs[True]["simSolverDebug"][:, :, 4] == 0).all()
+    cl = ClosedLoopBatch("modena", batch=5, N=47, Tp=3.76, on_device=True, log_capacity=30, controller="r2")
+    lg = cl.run(30)
+    assert (lg["simSolverDebug"][:, :, 4] == 0).all()
+    uh = cl.solver.constraints_get(3, "uh")
+    assert (uh < 1.0).all() and (uh > 0.5).all()
+    A = cl.solver.get_from_qp_in(46, "A")
+    assert A.shape == (5, 8, 8) and np.isfinite(A).all() and np.allclose(A[:, 6, 6], 1.0) and np.allclose(A[:, 7, 7], 1.0)
