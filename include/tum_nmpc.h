@@ -28,7 +28,7 @@ extern "C" {
 #define TUM_NY 6          /* cost_y_expr = [x0,x1,wrap(yaw),vlong,u]        NMPC_STM_acados_settings.py:51 */
 #define TUM_NYE 4
 #define TUM_N_MAX 48      /* horizon limit of this build: N <= 40 (five 16-wide MFMA tiles of condensed variables) on every kernel
-                             variant and for the coupled SNMPC OCP, 41..48 (six tiles) on the pipeline variant only */
+                             variant, 41..48 (six tiles) on the pipeline variant only (nominal and coupled SNMPC OCP) */
 #define TUM_ALL_STAGES (-1)
 
 /* acados return codes the callers test (NMPC_class.py:183-206, main.py:59-61) */
@@ -138,7 +138,8 @@ int tum_ocp_set_schedule(tum_ocp *c, int longest_first);
  * condense / interior point / expand as four kernels, each at its own occupancy, handing over through the L2-resident
  * workspace), "auto" (default: the pipeline for batches of more than 1024 instances, where it is 4-8 % faster, the fused kernel
  * below). Results agree to rounding (same arithmetic per phase). Environment override at create time: TUM_NMPC_KERNEL. The
- * coupled SNMPC OCP always runs the fused kernel. get_stats("time_ipm") reports the interior point kernel of the pipeline. */
+ * coupled SNMPC OCP follows the same rule (its prologue / epilogue kernels around either variant). get_stats("time_ipm") reports
+ * the interior point kernel of the pipeline. */
 int tum_ocp_set_kernel(tum_ocp *c, const char *name);
 /* last kernel launch time in milliseconds (HIP events on the launch stream) */
 double tum_ocp_last_kernel_ms(tum_ocp *c);

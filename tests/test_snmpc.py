@@ -232,12 +232,14 @@ def test_oracle_model_functions_against_exported_expressions(golden_dir):
 
 
 # ---------------------------------------------------------------------------------------------- GPU
-def _gpu_vs_oracle(golden_dir, N, uph, poses, nsolve=3, shift_ref=0):
+def _gpu_vs_oracle(golden_dir, N, uph, poses, nsolve=3, shift_ref=0, kernel=None):
     from tum_control_amd.solver import CoupledSnmpcSolver
     snm, stds, w, A = _pce()
     d = np.load(os.path.join(golden_dir, "kat0.npz"))
     B = len(poses)
     s = CoupledSnmpcSolver(N=N, dt=0.08, batch=B, Apce=A, uph=uph, gamma=0.8)
+    if kernel:
+        s.set_kernel(kernel)
     s.install_reference_ocp()
     X0 = np.zeros((B, 11, 8)); Y = np.zeros((B, N + 1, 6))
     rng = np.random.default_rng(11)
@@ -281,6 +283,14 @@ def test_gpu_coupled_snmpc_vs_oracle(golden_dir, N, uph):
     """cold start + two warm real-time iterations on logged poses (one with a perturbed state), every copy of the stacked
     iterate compared; tolerance 1e-7 relative (north_star: 1e-4)."""
     _gpu_vs_oracle(golden_dir, N, uph, poses=[0, 26, 30])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("N,uph", [(38, 5), (38, 15), (40, 5), (38, 0), (12, 12), (44, 5), (48, 12)])
+def test_gpu_coupled_snmpc_pipeline_vs_oracle(golden_dir, N, uph):
+    """the same through the pipeline variant (prologue, lin_kernel<SN>, cond_kernel<., SN>, ipm_kernel, expand_kernel<., SN>,
+    epilogue; what batches above 1024 instances run), including horizons beyond 40 (six-tile instantiation)"""
+    _gpu_vs_oracle(golden_dir, N, uph, poses=[0, 26, 30], kernel="pipeline")
 
 
 @pytest.mark.gpu

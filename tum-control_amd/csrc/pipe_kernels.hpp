@@ -20,6 +20,8 @@ namespace tum {
 constexpr int PREC = 64;                        // doubles per stage record
 // record fields: [0,1] Sp | [2..43] S[6][7] | [44..51] defect b | [52..55] cost residuals | [56..59] g3 g5 g7 h | [60] delta_f
 constexpr int PR_RES = 52, PR_GH = 56, PR_XD = 60;
+// coupled SNMPC OCP only: [61, 62] gradient (vl, vt)/|v| of the speed row of the cost, [63] d h / d vt of the gg row at |v|
+constexpr int PR_CV = 61, PR_G4 = 63;
 // Everything that depends on the horizon limit is a function of NT_, the number of 16-wide MFMA tiles of the condensed QP:
 // NT_ = 5 -> N <= 40 (what the fused kernel covers as well), NT_ = 6 -> N <= 48 (pipeline only).
 template <int NT_> struct PD {
@@ -70,6 +72,9 @@ struct PArgs {
 
 // ---------------------------------------------------------------------------------------------------------------- K1
 constexpr int L_PITCH = PREC + 1;               // LDS pitch of one item's record (odd: lane-strided writes hit distinct banks)
+// SN = true: the nominal copy of the coupled SNMPC OCP (speed row |v|, gg limits looked up at |v|; the stages below the
+// uncertainty propagation horizon are condensed by the prologue kernel and need no record here)
+template <bool SN>
 __global__ void __launch_bounds__(64, 1) lin_kernel(const PArgs pa)
 {
     // the 64 records of a wavefront are one contiguous 32 KiB block of the workspace: they are transposed through LDS so that
@@ -94,14 +99,22 @@ __global__ void __launch_bounds__(64, 1) lin_kernel(const PArgs pa)
     r[PR_RES + 0] = xk[0] - yr[0];
     r[PR_RES + 1] = xk[1] - yr[1];
     r[PR_RES + 2] = wrap_yaw(xk[2]) - yr[2];
-    r[PR_RES + 3] = xk[3] - yr[3];
+    if (SN) {
+        const double vabs = sqrt(xk[3] * xk[3] + xk[4] * xk[4]), iv = (vabs > 0.0) ? 1.0 / vabs : 0.0;
+        r[PR_RES + 3] = vabs - yr[3];
+        r[PR_CV] = xk[3] * iv; r[PR_CV + 1] = xk[4] * iv;
+    } else r[PR_RES + 3] = xk[3] - yr[3];
     r[PR_XD] = xk[6];
     if (k >= 1) {
         double h, g3, g5, g7;
-        h_con(ka.mp, xk[3], xk[5], xk[7], h, g3, g5, g7);
+        if (SN) {
+            double g4;
+            h_con_vabs(ka.mp, xk[3], xk[4], xk[5], xk[7], h, g3, g4, g5, g7);
+            r[PR_G4] = g4;
+        } else h_con(ka.mp, xk[3], xk[5], xk[7], h, g3, g5, g7);
         r[PR_GH + 0] = g3; r[PR_GH + 1] = g5; r[PR_GH + 2] = g7; r[PR_GH + 3] = h;
     }
-    if (k < N) {
+    if (k < N && (!SN || k >= ka.uph)) {
         const double *gU = ka.U + ((size_t)b * N + k) * NU;
         double uk[2] = {gU[0], gU[1]};
         double xn[8], Sp[2], S[6][7];
@@ -115,20 +128,21 @@ __global__ void __launch_bounds__(64, 1) lin_kernel(const PArgs pa)
         for (int i = 0; i < 8; i++) r[44 + i] = xn[i] - gX[NX + i];
         // (get_from_qp_in and the R2 back-off read A_k, B_k, b_k of a pipeline solve from these records: no separate copy)
     }
+    constexpr int NF = SN ? PREC : PR_XD + 1;          // fields in use
 #pragma unroll
-    for (int i = 0; i <= PR_XD; i++) sT[threadIdx.x * L_PITCH + i] = r[i];
+    for (int i = 0; i < NF; i++) sT[threadIdx.x * L_PITCH + i] = r[i];
     wsync();
     double *dst = pa.rec + (size_t)g0 * PREC;
     const int nitem = (int)((total - g0 < 64) ? (total - g0) : 64);
     for (int it = 0; it < nitem; it++)
-        if ((int)threadIdx.x <= PR_XD) dst[(size_t)it * PREC + threadIdx.x] = sT[it * L_PITCH + threadIdx.x];
+        if ((int)threadIdx.x < NF) dst[(size_t)it * PREC + threadIdx.x] = sT[it * L_PITCH + threadIdx.x];
 }
 
 // ---------------------------------------------------------------------------------------------------------------- K2
 // LDS of the condensing kernel (PD::C_*): stage record double buffer | 4 staging rows of the SYRK | g_s of the current stage |
 // iterate U | packed gg rows (staging for the operand layout)
-template <int NT_>
-__global__ void __launch_bounds__(64, (NT_ == 5) ? 2 : 1) cond_kernel(const PArgs pa)
+template <int NT_, bool SN>
+__global__ void __launch_bounds__(64, (NT_ == 5 && !SN) ? 2 : 1) cond_kernel(const PArgs pa)
 {
     PD_LOCALS
     constexpr int C_REC = D::C_REC, C_STAGE = D::C_STAGE, C_GS = D::C_GS, C_U0 = D::C_U0, C_CH = D::C_CH;
@@ -148,7 +162,9 @@ __global__ void __launch_bounds__(64, (NT_ == 5) ? 2 : 1) cond_kernel(const PArg
     double *gvec = pa.vec + (size_t)b * PVEC;
 
     // stage slot k & 1: fields 0..51 of record k (A_k, B_k, b_k), fields 52..60 of record k+1 (residuals, gg row, delta of stage k+1)
-    auto fetch = [&](int k) -> double { return (lane < PR_RES) ? grec[(size_t)k * PREC + lane] : ((lane <= PR_XD) ? grec[(size_t)(k + 1) * PREC + lane] : 0.0); };
+    auto fetch = [&](int k) -> double { return (lane < PR_RES) ? grec[(size_t)k * PREC + lane] : ((lane <= (SN ? PR_G4 : PR_XD)) ? grec[(size_t)(k + 1) * PREC + lane] : 0.0); };
+    const int uph = SN ? ka.uph : 0;
+    const double *gpro = SN ? ka.pro + (size_t)b * uph * SN_PRO_STAGE : nullptr;
     double pre = fetch(0);
     sU0[lane] = (lane < nv) ? gU[lane] : 0.0;
     if (lane < NB1) sU0[64 + lane] = (64 + lane < nv) ? gU[64 + lane] : 0.0;
@@ -179,6 +195,16 @@ __global__ void __launch_bounds__(64, (NT_ == 5) ? 2 : 1) cond_kernel(const PArg
         auto stage_body = [&](const int k, auto tsc) {
             constexpr int Ts = decltype(tsc)::value;
             const double *rec = sRec + (k & 1) * PREC;
+            if (SN && k < uph) {
+                // stage s = k+1 <= uph: G_nom,s and g_nom,s are PCE means of the sample recursions (prologue kernel)
+                const double *pg = gpro + (size_t)k * SN_PRO_STAGE;
+#pragma unroll
+                for (int i = 0; i < 8; i++) {
+                    const double gv = pg[i * 64 + lane], gg = pg[i * 64 + 2 * uph];
+                    w0[i] = (lane < 2 * uph) ? gv : 0.0;
+                    w1[i] = isg ? gg : 0.0;
+                }
+            } else {
             apply_A2(rec, w0, w1);
             {
                 const double sel0 = (j0 == k) ? 1.0 : 0.0, sel1 = (lane < NB1 && j1 == k) ? 1.0 : 0.0, selg = isg ? 1.0 : 0.0;
@@ -192,11 +218,23 @@ __global__ void __launch_bounds__(64, (NT_ == 5) ? 2 : 1) cond_kernel(const PArg
 #pragma unroll
                 for (int i = 0; i < 8; i++) w1[i] += selg * rec[44 + i];
             }
+            }
             const int s = k + 1;                         // stage whose G_s the lanes now hold
             const double sc = (s < N) ? dt : 1.0;
             const double g3 = rec[PR_GH + 0], g5 = rec[PR_GH + 1], g7 = rec[PR_GH + 2];
-            const double hr0 = g3 * w0[3] + g5 * w0[5] + g7 * w0[7], hr1 = g3 * w1[3] + g5 * w1[5] + g7 * w1[7];
-            const double hd = rec[PR_GH + 3];
+            const double g4 = SN ? rec[PR_G4] : 0.0, cvl = SN ? rec[PR_CV] : 1.0, cvt = SN ? rec[PR_CV + 1] : 0.0;
+            double hr0 = g3 * w0[3] + g5 * w0[5] + g7 * w0[7], hr1 = g3 * w1[3] + g5 * w1[5] + g7 * w1[7];
+            double hd = rec[PR_GH + 3];
+            if (SN) {
+                hr0 += g4 * w0[4]; hr1 += g4 * w1[4];
+                if (s < uph) {   // chance-constraint row E + kappa sqrt(Var) over the samples (prologue kernel)
+                    const double *pr = gpro + (size_t)k * SN_PRO_STAGE + SN_PRO_G;
+                    const double rv = pr[lane], rg = pr[2 * uph];
+                    hr0 = (lane < 2 * uph) ? rv : 0.0; hr1 = isg ? rg : 0.0; hd = 0.0;
+                }
+            }
+            // the speed row of the cost: vl (nominal OCP) or |v| (SNMPC: gradient (vl, vt)/|v|)
+            const double c30 = SN ? cvl * w0[3] + cvt * w0[4] : w0[3], c31 = SN ? cvl * w1[3] + cvt * w1[4] : w1[3];
             if (isg) {
 #pragma unroll
                 for (int i = 0; i < 8; i++) sGs[i] = w1[i];
@@ -206,10 +244,12 @@ __global__ void __launch_bounds__(64, (NT_ == 5) ? 2 : 1) cond_kernel(const PArg
             if (lane < 2 * s) sCh[hoff(s) + lane] = hr0;
             if (lane < NB1 && 64 + lane < 2 * s) sCh[hoff(s) + 64 + lane] = hr1;
 #pragma unroll
-            for (int r = 0; r < 4; r++) sStage[r * NVP + lane] = w0[r];
+            for (int r = 0; r < 3; r++) sStage[r * NVP + lane] = w0[r];
+            sStage[3 * NVP + lane] = c30;
             if (lane < NB1) {
 #pragma unroll
-                for (int r = 0; r < 4; r++) sStage[r * NVP + 64 + lane] = w1[r];
+                for (int r = 0; r < 3; r++) sStage[r * NVP + 64 + lane] = w1[r];
+                sStage[3 * NVP + 64 + lane] = c31;
             }
             wsync();
             double wr[4];
@@ -219,8 +259,9 @@ __global__ void __launch_bounds__(64, (NT_ == 5) ? 2 : 1) cond_kernel(const PArg
                 double a0 = 0.0, a1 = 0.0;
 #pragma unroll
                 for (int r = 0; r < 4; r++) {
-                    const double e = wr[r] * (rec[PR_RES + r] + sGs[r]);
-                    a0 += e * w0[r]; a1 += e * w1[r];
+                    const double gs = (SN && r == 3) ? cvl * sGs[3] + cvt * sGs[4] : sGs[r];
+                    const double e = wr[r] * (rec[PR_RES + r] + gs);
+                    a0 += e * ((r == 3) ? c30 : w0[r]); a1 += e * ((r == 3) ? c31 : w1[r]);
                 }
                 q0 += a0;
                 q1 += (lane < NB1) ? a1 : 0.0;
@@ -283,7 +324,7 @@ __global__ void __launch_bounds__(64, (NT_ == 5) ? 2 : 1) cond_kernel(const PArg
 }
 
 // ---------------------------------------------------------------------------------------------------------------- K4
-template <int NT_>
+template <int NT_, bool SN>
 __global__ void __launch_bounds__(64) expand_kernel(const PArgs pa)
 {
     PD_LOCALS
@@ -303,6 +344,8 @@ __global__ void __launch_bounds__(64) expand_kernel(const PArgs pa)
     const double *gW = ka.W + (size_t)b * 10;
     const double *gvec = pa.vec + (size_t)b * PVEC;
     const int status = ka.status[b];
+    const int uph = SN ? ka.uph : 0;
+    const double *gpro = SN ? ka.pro + (size_t)b * uph * SN_PRO_STAGE : nullptr;
     for (int i = lane; i < (N + 1) * NX; i += 64) sX[i] = gX[i];
     for (int i = lane; i < NVP; i += 64) { sU1[i] = (i < nv) ? gU[i] : 0.0; sDv[i] = gvec[PV_DV + i]; }
     double pre = (lane < PR_RES) ? grec[lane] : 0.0;
@@ -317,8 +360,19 @@ __global__ void __launch_bounds__(64) expand_kernel(const PArgs pa)
         double dxi = gx0r - sX[ri];
         wsync();
         if (lane < 8) sX[lane] += dxi;
+        if (SN) {
+            // stages 1..uph: dx_s = G_nom,s dU + g_nom,s straight from the prologue's matrices (2s columns each)
+            for (int s = 1; s <= uph; s++) {
+                const double *pg = gpro + (size_t)(s - 1) * SN_PRO_STAGE + ri * 64;
+                double acc = pg[2 * uph];
+                for (int j = 0; j < 2 * s; j++) acc += pg[j] * sDv[j];
+                dxi = acc;
+                if (lane < 8) sX[s * NX + lane] += dxi;
+            }
+        }
         for (int k = 0; k < N; k++) {
             const double *rec = sRec + (k & 1) * PREC;
+            if (k >= uph) {
             const double *Si = rec + 2 + (core ? ri : 0) * 7;
             const double du0 = sDv[2 * k], du1 = sDv[2 * k + 1];
             const double cpsi = (ri < 2) ? rec[ri] : 0.0;
@@ -333,6 +387,7 @@ __global__ void __launch_bounds__(64) expand_kernel(const PArgs pa)
             acc0 += c4 * x7;
             dxi = acc0 + acc1;
             if (lane < 8) sX[(k + 1) * NX + lane] += dxi;
+            }
             sRec[((k + 1) & 1) * PREC + lane] = pre;
             if (k + 2 < N) pre = (lane < PR_RES) ? grec[(size_t)(k + 2) * PREC + lane] : 0.0;
             wsync();
@@ -354,7 +409,8 @@ __global__ void __launch_bounds__(64) expand_kernel(const PArgs pa)
         e = sX[k * NX + 0] - yr[0]; acc += ((k < N) ? Wd[0] : We[0]) * e * e;
         e = sX[k * NX + 1] - yr[1]; acc += ((k < N) ? Wd[1] : We[1]) * e * e;
         e = wrap_yaw(sX[k * NX + 2]) - yr[2]; acc += ((k < N) ? Wd[2] : We[2]) * e * e;
-        e = sX[k * NX + 3] - yr[3]; acc += ((k < N) ? Wd[3] : We[3]) * e * e;
+        e = (SN ? sqrt(sX[k * NX + 3] * sX[k * NX + 3] + sX[k * NX + 4] * sX[k * NX + 4]) : sX[k * NX + 3]) - yr[3];
+        acc += ((k < N) ? Wd[3] : We[3]) * e * e;
         if (k < N) {
             e = sU1[2 * k] - yr[4]; acc += Wd[4] * e * e;
             e = sU1[2 * k + 1] - yr[5]; acc += Wd[5] * e * e;

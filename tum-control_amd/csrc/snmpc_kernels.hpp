@@ -42,7 +42,8 @@ struct SnArgs {
     const double *Apce;       // [L][ns]         PCE matrix (SNMPC_class.py:124), shared by the batch
     double *ws2;              // [b][uph*ns][ABS] sample linearisation records
     double *pro;              // [b][uph][SN_PRO_STAGE]
-    const double *dv;         // [b][NVP]        QP solution of the fused kernel (epilogue)
+    const double *dv;         // [b][dv_stride]  QP solution of the fused kernel / of the pipeline's interior point kernel (epilogue)
+    int dv_stride;
     const int *status;        // [b]
     double *dbg;              // development aid: phase cycle counters of instance 0 (or null)
 };
@@ -251,7 +252,7 @@ __global__ void __launch_bounds__(64) snmpc_epilogue_kernel(const SnArgs sa)
     if (i >= ns) return;
     double *gXS = sa.XS + (size_t)b * (N + 1) * ns * NX;
     const double *ws2 = sa.ws2 + (size_t)b * uph * ns * ABS;
-    const double *dv = sa.dv + (size_t)b * NVP;
+    const double *dv = sa.dv + (size_t)b * sa.dv_stride;
     double dx[8], xnew[8];
 #pragma unroll
     for (int r = 0; r < 8; r++) {

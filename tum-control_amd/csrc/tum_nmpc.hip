@@ -198,7 +198,6 @@ extern "C" int tum_ocp_snmpc_attach(tum_ocp *c, int ns, int L, const double *Apc
 {
     if (!c || !Apce) return fail("null argument");
     if (c->sn) return fail("snmpc_attach: already attached");
-    if (c->N > NMAX) return fail("snmpc_attach: the coupled SNMPC OCP is built for N <= 40");
     if (ns < 1 || ns > SN_NSMAX) return fail("snmpc_attach: n_samples out of range (1..16)");
     if (L < 1 || L > SN_LMAX) return fail("snmpc_attach: number of PCE terms out of range (1..16)");
     if (uph < 0 || uph > c->N || uph > SN_UPHMAX) return fail("snmpc_attach: uncertainty propagation horizon out of range (0..min(N,31))");
@@ -228,7 +227,7 @@ extern "C" int tum_ocp_snmpc_attach(tum_ocp *c, int ns, int L, const double *Apc
     sa.kappa = std::sqrt((1.0 - gamma) / gamma);      // SNMPC_acados_settings.py:187
     sa.mp = c->ka.mp;
     sa.X = c->dX; sa.U = c->dU; sa.XS = c->dXS; sa.xs0 = c->dxs0; sa.Apce = c->dApce; sa.ws2 = c->dws2; sa.pro = c->dpro;
-    sa.dv = c->ddv; sa.status = c->dstatus;
+    sa.dv = c->ddv; sa.dv_stride = NVP; sa.status = c->dstatus;
     sa.dbg = c->ddbg + 20000;                            // tail of instance 0's dump area (tum_ocp_debug_dump), unused by the fused kernel
     c->ka.uph = uph; c->ka.pro = c->dpro; c->ka.dv = c->ddv;
     c->sn = true;
@@ -535,7 +534,7 @@ static int ensure_workspace(tum_ocp *c)
 // "fused": one kernel per solve; "pipeline": linearise / condense / interior point / expand as four kernels, each at its own
 // occupancy (measured 4-8 % faster than the fused kernel from 4096 instances up, a few per cent slower below 1024: three
 // more launches and the hand-over through L2); "auto" (default): the pipeline when the batch is more than one round of
-// resident wavefronts (> 1024 instances). The coupled SNMPC OCP always runs the fused kernel.
+// resident wavefronts (> 1024 instances). The coupled SNMPC OCP follows the same rule (prologue / epilogue around either).
 extern "C" int tum_ocp_set_kernel(tum_ocp *c, const char *name)
 {
     if (!c || !name) return fail("null argument");
@@ -550,9 +549,8 @@ extern "C" int tum_ocp_set_kernel(tum_ocp *c, const char *name)
 // which kernel variant this solve runs, and its workspace (allocated on first use; never inside a stream capture)
 static int resolve_kernel(tum_ocp *c)
 {
-    c->pipe = !c->sn && !(c->ka.flags & 2) && (c->kmode == 2 || (c->kmode == 0 && c->batch > 1024));
+    c->pipe = !(c->ka.flags & 2) && (c->kmode == 2 || (c->kmode == 0 && c->batch > 1024));
     if (c->N > NMAX) {      // the fused kernel covers N <= 40; longer horizons exist as a pipeline instantiation only
-        if (c->sn) return fail("solve: the coupled SNMPC OCP is built for N <= 40");
         if (c->ka.flags & 2) return fail("debug_dump: the condensed-QP dump is built for N <= 40");
         if (c->kmode == 1) return fail("solve: kernel 'fused' is built for N <= 40 (use 'auto' or 'pipeline')");
         c->pipe = true;
@@ -566,18 +564,29 @@ static int launch_pipeline(tum_ocp *c, bool events)
     pa.ka = c->ka; pa.rec = c->drec; pa.hws = c->dhws; pa.cws = c->dcws; pa.vec = c->dvec;
     const bool prof = (c->ka.flags & 4) != 0;
     const long long items = (long long)c->batch * (c->N + 1);
-    hipLaunchKernelGGL(lin_kernel, dim3((unsigned)((items + 63) / 64)), dim3(64), 0, c->stream, pa);
+    if (c->sn) {   // coupled SNMPC OCP: sample fan-out and prologue first, the QP solution goes to the epilogue through the workspace
+        if (c->fanout && sn_fanout(c)) return 1;
+        hipLaunchKernelGGL(snmpc_prologue_kernel, dim3(c->batch), dim3(64), sizeof(double) * sn_prologue_lds_doubles(c->sa.uph, c->sa.ns),
+                           c->stream, c->sa);
+        hipLaunchKernelGGL(lin_kernel<true>, dim3((unsigned)((items + 63) / 64)), dim3(64), 0, c->stream, pa);
+    } else hipLaunchKernelGGL(lin_kernel<false>, dim3((unsigned)((items + 63) / 64)), dim3(64), 0, c->stream, pa);
     // (development aid: a larger LDS request lowers the number of OCPs that share a CU)
     static const int lds_req = [] { const char *e = getenv("TUM_IPM_LDS"); const int v = e ? atoi(e) : 0; return (v > 0 && v <= 64 * 1024) ? v : 0; }();
     auto rest = [&](auto ntc) {
         constexpr int NTv = decltype(ntc)::value;
         const int ipm_lds = lds_req > PD<NTv>::I_LDS_BYTES ? lds_req : PD<NTv>::I_LDS_BYTES;
-        hipLaunchKernelGGL(cond_kernel<NTv>, dim3(c->batch), dim3(64), 0, c->stream, pa);
+        if (c->sn) hipLaunchKernelGGL((cond_kernel<NTv, true>), dim3(c->batch), dim3(64), 0, c->stream, pa);
+        else hipLaunchKernelGGL((cond_kernel<NTv, false>), dim3(c->batch), dim3(64), 0, c->stream, pa);
         if (events) (void)hipEventRecord(c->evi0, c->stream);
         if (prof) hipLaunchKernelGGL((ipm_kernel<true, NTv>), dim3(c->batch), dim3(64), ipm_lds, c->stream, pa);
         else hipLaunchKernelGGL((ipm_kernel<false, NTv>), dim3(c->batch), dim3(64), ipm_lds, c->stream, pa);
         if (events) (void)hipEventRecord(c->evi1, c->stream);
-        hipLaunchKernelGGL(expand_kernel<NTv>, dim3(c->batch), dim3(64), 0, c->stream, pa);
+        if (c->sn) {
+            hipLaunchKernelGGL((expand_kernel<NTv, true>), dim3(c->batch), dim3(64), 0, c->stream, pa);
+            SnArgs sa = c->sa;
+            sa.dv = c->dvec + PD<NTv>::PV_DV; sa.dv_stride = PD<NTv>::PVEC;
+            hipLaunchKernelGGL(snmpc_epilogue_kernel, dim3(c->batch), dim3(64), 0, c->stream, sa);
+        } else hipLaunchKernelGGL((expand_kernel<NTv, false>), dim3(c->batch), dim3(64), 0, c->stream, pa);
     };
     if (c->N > NMAX) rest(std::integral_constant<int, 6>()); else rest(std::integral_constant<int, 5>());
     return 0;
@@ -594,14 +603,15 @@ static int launch(tum_ocp *c, bool events = true)
     // the instrumented instantiation carries the phase timers (flag 4) and the debug dump (flag 2)
     const bool prof = (c->ka.flags & 6) != 0;
     auto fused = [&](auto kern) { hipLaunchKernelGGL(kern, dim3(c->batch), dim3(64), LDS_BYTES, c->stream, c->ka); };
-    if (c->sn) {
-        if (sn_apply_p(c)) return 1;
+    if (c->sn && sn_apply_p(c)) return 1;
+    if (c->pipe) { if (launch_pipeline(c, events)) return 1; }
+    else if (c->sn) {
         if (c->fanout && sn_fanout(c)) return 1;
         hipLaunchKernelGGL(snmpc_prologue_kernel, dim3(c->batch), dim3(64), sizeof(double) * sn_prologue_lds_doubles(c->sa.uph, c->sa.ns),
                            c->stream, c->sa);
         if (prof) fused(nmpc_rti_kernel<true, true>); else fused(nmpc_rti_kernel<false, true>);
         hipLaunchKernelGGL(snmpc_epilogue_kernel, dim3(c->batch), dim3(64), 0, c->stream, c->sa);
-    } else if (c->pipe) { if (launch_pipeline(c, events)) return 1; }
+    }
     else { if (prof) fused(nmpc_rti_kernel<true>); else fused(nmpc_rti_kernel<false>); }
     HIPCHK(hipGetLastError());
     if (c->r2) {   // constraint tightening for the NEXT solve from this one's linearisation (skipped per instance on failure)
