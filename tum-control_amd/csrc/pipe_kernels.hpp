@@ -709,6 +709,7 @@ __global__ void __launch_bounds__(64, IPM_WPS) ipm_kernel(const PArgs pa)
 #pragma unroll
                     for (int I = J; I < NT; I++) T[I] = mfma(aJ, sM[rb[I] + kk], T[I]);
                 }
+            TUM_TICK(10);
 #pragma unroll
             for (int m = 0; m < 4; m++) {
                 const int c0 = 16 * J + 4 * m;
@@ -767,6 +768,7 @@ __global__ void __launch_bounds__(64, IPM_WPS) ipm_kernel(const PArgs pa)
                     }
                 }
             }
+            TUM_TICK(11);
         }
         // (a failed factorisation -- a pivot that is not positive -- is acted upon after the parked registers are back:
         //  leaving the loop here would keep all of them alive across the factorisation for the code behind the loop)
@@ -780,31 +782,35 @@ __global__ void __launch_bounds__(64, IPM_WPS) ipm_kernel(const PArgs pa)
         }
         // ---- inverses of the unit-lower 16x16 diagonal blocks, in place
         {
-            auto inv_diag = [&](const int g, const bool own) {
-                const int gb = g & ~15, cl = g & 15;
-                double X[16];
+            // lane = column: the columns 0..63 and (on the first NB1 lanes) 64.. are two independent substitution chains; they
+            // run interleaved (one pass over the rows, two accumulators each) instead of one after the other
+            const int gA = lane, gB = lane1;
+            const bool ownB = lane < NB1;
+            const int gbA = gA & ~15, clA = gA & 15, gbB = gB & ~15, clB = gB & 15;
+            double XA[16], XB[16];
 #pragma unroll
-                for (int k = 0; k < 16; k++) X[k] = (k == cl) ? 1.0 : 0.0;
-                int rowb = lpk(gb, gb);
-                int rows[16];
+            for (int k = 0; k < 16; k++) { XA[k] = (k == clA) ? 1.0 : 0.0; XB[k] = (k == clB) ? 1.0 : 0.0; }
+            int rowA = lpk(gbA, gbA), rowB = lpk(gbB, gbB);
+            int rowsA[16], rowsB[16];
 #pragma unroll
-                for (int r = 1; r < 16; r++) {
-                    rowb += gb + r;
-                    rows[r] = rowb;
-                    double a0 = 0.0, a1 = 0.0;
+            for (int r = 1; r < 16; r++) {
+                rowA += gbA + r; rowB += gbB + r;
+                rowsA[r] = rowA; rowsB[r] = rowB;
+                double a0 = 0.0, a1 = 0.0, b0_ = 0.0, b1_ = 0.0;
 #pragma unroll
-                    for (int k = 0; k < r; k++) {
-                        if (k & 1) a1 += sM[rowb + k] * X[k]; else a0 += sM[rowb + k] * X[k];
-                    }
-                    X[r] -= a0 + a1;
+                for (int k = 0; k < r; k++) {
+                    if (k & 1) { a1 += sM[rowA + k] * XA[k]; b1_ += sM[rowB + k] * XB[k]; }
+                    else { a0 += sM[rowA + k] * XA[k]; b0_ += sM[rowB + k] * XB[k]; }
                 }
-                wsync();
+                XA[r] -= a0 + a1; XB[r] -= b0_ + b1_;
+            }
+            wsync();
 #pragma unroll
-                for (int r = 1; r < 16; r++) sM[(own && r > cl) ? rows[r] + cl : (I_DUMMY - I_M)] = X[r];
-                wsync();
-            };
-            inv_diag(lane, true);
-            inv_diag(lane1, lane < NB1);
+            for (int r = 1; r < 16; r++) {
+                sM[(r > clA) ? rowsA[r] + clA : (I_DUMMY - I_M)] = XA[r];
+                sM[(ownB && r > clB) ? rowsB[r] + clB : (I_DUMMY - I_M)] = XB[r];
+            }
+            wsync();
         }
         TUM_TICK(4);
 
