@@ -203,6 +203,12 @@ __device__ __forceinline__ double frcp(double x)
     double r = __builtin_amdgcn_rcp(x);
     return fma(fma(-x, r, 1.0), r, r);
 }
+// value of lane l (a compile-time constant) as a wave-uniform scalar
+__device__ __forceinline__ double readlane_f64(double v, int l)
+{
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), l), hi = __builtin_amdgcn_readlane(__double2hiint(v), l);
+    return __hiloint2double(hi, lo);
+}
 __device__ __forceinline__ d4 mfma(double a, double b, d4 c) { return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0); }
 // LDS ordering point between the lanes of the ONE wavefront of a workgroup. The LDS executes a wave's DS
 // instructions in issue order, so a later ds_read already observes an earlier ds_write of another lane: no

@@ -688,6 +688,10 @@ __global__ void __launch_bounds__(64, IPM_WPS) ipm_kernel(const PArgs pa)
         TUM_TICK(3);
         // ---- blocked L D L' factorisation (as in the fused kernel: row-panel register tiles, 4-column micro-panels)
         double dmin = 1.0;
+        // lane predicates of the P operand (opaque to the optimiser: as plain compares of lc the select chains below become a
+        // switch with branches)
+        int ec0 = lc == 0, ec1 = lc == 1, ec2 = lc == 2, eq0 = lq == 0, eq1 = lq == 1, eq2 = lq == 2, epz = (lc < 4 && lq <= lc);
+        asm volatile("" : "+v"(ec0), "+v"(ec1), "+v"(ec2), "+v"(eq0), "+v"(eq1), "+v"(eq2), "+v"(epz));
 #pragma unroll
         for (int J = 0; J < NT; J++) {
             d4 T[NT];
@@ -710,64 +714,86 @@ __global__ void __launch_bounds__(64, IPM_WPS) ipm_kernel(const PArgs pa)
                     for (int I = J; I < NT; I++) T[I] = mfma(aJ, sM[rb[I] + kk], T[I]);
                 }
             TUM_TICK(10);
+            // four 4-column micro-panels. The 4x4 diagonal block sits in column m of the diagonal tile: entry (i, j) on lane
+            // 16 j + 4 m + i. It is read into scalars (v_readlane) and factorised uniformly; the panel below it is scaled by
+            // ONE MFMA per tile with the 4x4 upper triangular P = L^-T D^-1 as the A operand (new column block = E P, straight
+            // into the lanes that hold E), so there is no LDS round trip inside a micro-panel: finished columns are only
+            // stored. Software pipeline: only the diagonal tile is on the critical path (scale, rank-4 update, next
+            // readlane); the two MFMAs of every tile below it are issued under the scalar chain of the NEXT micro-panel.
+            double Lc[NT], bd = 0.0, pop = 0.0;
 #pragma unroll
             for (int m = 0; m < 4; m++) {
                 const int c0 = 16 * J + 4 * m;
-#pragma unroll
-                for (int I = J; I < NT; I++)
-                    sM[(I > J || lc >= 4 * m + lq) ? rb[I] + c0 + lq : (I_DUMMY - I_M)] = T[I][m];
-                wsync();
-                const int r1 = lpk(c0 + 1, c0), r2 = lpk(c0 + 2, c0), r3 = lpk(c0 + 3, c0);
-                const double a00 = sM[lpk(c0, c0)];
-                const double a10 = sM[r1], a11 = sM[r1 + 1];
-                const double a20 = sM[r2], a21 = sM[r2 + 1], a22 = sM[r2 + 2];
-                const double a30 = sM[r3], a31 = sM[r3 + 1], a32 = sM[r3 + 2], a33 = sM[r3 + 3];
-                const int row = c0 + 4 + lane;
-                const bool rin = row < NVP;
-                const int rbase = lpk(rin ? row : NVP - 1, c0);
-                double e0 = sM[rbase], e1 = sM[rbase + 1], e2 = sM[rbase + 2], e3 = sM[rbase + 3];
-                const bool two = (c0 + 68 < NVP);                // rows c0+68.. exist (a compile-time fact per micro-panel)
-                const int row1 = c0 + 68 + lane;
-                const bool rin1 = two && (row1 < NVP);
-                const int rbase1 = lpk(rin1 ? row1 : NVP - 1, c0);
-                double f0 = 0, f1 = 0, f2 = 0, f3 = 0;
-                if (two) { f0 = sM[rbase1]; f1 = sM[rbase1 + 1]; f2 = sM[rbase1 + 2]; f3 = sM[rbase1 + 3]; }
+                // k-th MFMA owed to the tiles below the diagonal one by the previous micro-panel: first their scaled columns,
+                // then their rank-4 updates; issued one at a time between the segments of the scalar chain below
+                auto owed = [&](int k) {
+                    const int nd = NT - J - 1;
+                    if (m > 0 && k < nd) {
+                        const int I = J + 1 + k;
+                        d4 z = {0.0, 0.0, 0.0, 0.0};
+                        z = mfma(pop, T[I][m - 1], z);
+                        Lc[I] = z[0];
+                    } else if (m > 0 && k < 2 * nd) {
+                        const int I = J + 1 + k - nd;
+                        sM[rb[I] + c0 - 4 + lq] = Lc[I];
+                        T[I] = mfma(bd, Lc[I], T[I]);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                };
+                const double a00 = readlane_f64(T[J][m], 4 * m);
+                const double a10 = readlane_f64(T[J][m], 4 * m + 1), a11 = readlane_f64(T[J][m], 16 + 4 * m + 1);
+                const double a20 = readlane_f64(T[J][m], 4 * m + 2), a21 = readlane_f64(T[J][m], 16 + 4 * m + 2),
+                             a22 = readlane_f64(T[J][m], 32 + 4 * m + 2);
+                owed(0);
+                const double a30 = readlane_f64(T[J][m], 4 * m + 3), a31 = readlane_f64(T[J][m], 16 + 4 * m + 3),
+                             a32 = readlane_f64(T[J][m], 32 + 4 * m + 3), a33 = readlane_f64(T[J][m], 48 + 4 * m + 3);
                 const double d0 = a00, i0 = frcp(d0);
                 const double l10 = a10 * i0, l20 = a20 * i0, l30 = a30 * i0;
+                owed(1);
                 const double d1 = a11 - l10 * a10, i1 = frcp(d1);
                 const double y21 = a21 - l20 * a10, y31 = a31 - l30 * a10;
                 const double l21 = y21 * i1, l31 = y31 * i1;
+                owed(2);
                 const double d2 = a22 - l20 * a20 - l21 * y21, i2 = frcp(d2);
                 const double y32 = a32 - l30 * a20 - l31 * y21;
                 const double l32 = y32 * i2;
+                const double w20 = l21 * l10 - l20;
+                owed(3);
                 const double d3 = a33 - l30 * a30 - l31 * y31 - l32 * y32, i3 = frcp(d3);
+                const double p01 = -l10 * i1, p02 = w20 * i2, p12 = -l21 * i2;
+                owed(4);
                 dmin = fmin(dmin, fmin(fmin(d0, d1), fmin(d2, d3)));
-                e1 -= l10 * e0; e2 -= l20 * e0 + l21 * e1; e3 -= l30 * e0 + l31 * e1 + l32 * e2;
-                if (rin) { sM[rbase] = e0 * i0; sM[rbase + 1] = e1 * i1; sM[rbase + 2] = e2 * i2; sM[rbase + 3] = e3 * i3; }
-                if (two) {
-                    f1 -= l10 * f0; f2 -= l20 * f0 + l21 * f1; f3 -= l30 * f0 + l31 * f1 + l32 * f2;
-                    if (rin1) { sM[rbase1] = f0 * i0; sM[rbase1 + 1] = f1 * i1; sM[rbase1 + 2] = f2 * i2; sM[rbase1 + 3] = f3 * i3; }
+                // P[k][x] on lane 16 k + x (k <= x < 4), zero elsewhere
+                const double p03 = (l31 * l10 - l30 - l32 * w20) * i3, p13 = (l32 * l21 - l31) * i3, p23 = -l32 * i3;
+                owed(5);
+                const double pr0 = ec0 ? i0 : ec1 ? p01 : ec2 ? p02 : p03;
+                const double pr1 = ec1 ? i1 : ec2 ? p12 : p13;
+                owed(6);
+                const double pr2 = ec2 ? i2 : p23;
+                const double prq = eq0 ? pr0 : eq1 ? pr1 : eq2 ? pr2 : i3;
+                const double popn = epz ? prq : 0.0;
+                owed(7);
+                const double dsel = eq0 ? d0 : eq1 ? d1 : eq2 ? d2 : d3;
+                const int rel = lc - (4 * m + lq);              // row - column inside the diagonal tile
+                if (NT > 5) { owed(8); owed(9); }
+                pop = popn;
+                {
+                    d4 z = {0.0, 0.0, 0.0, 0.0};
+                    z = mfma(pop, T[J][m], z);
+                    Lc[J] = z[0];
                 }
-                if (lane == 0) {
-                    sM[r1] = l10; sM[r2] = l20; sM[r2 + 1] = l21; sM[r3] = l30; sM[r3 + 1] = l31; sM[r3 + 2] = l32;
-                    sM[lpk(c0, c0)] = d0; sM[lpk(c0 + 1, c0 + 1)] = d1; sM[lpk(c0 + 2, c0 + 2)] = d2; sM[lpk(c0 + 3, c0 + 3)] = d3;
-                }
-                wsync();
-                if (m < 3) {
-                    const double dsel = (lq == 0) ? d0 : (lq == 1) ? d1 : (lq == 2) ? d2 : d3;
-                    const int kcol = c0 + lq;
-                    const int rowJ = 16 * J + lc;
-                    const double bl = sM[lpk(rowJ, kcol)];
-                    const double bval = (rowJ > kcol) ? bl : ((rowJ == kcol) ? 1.0 : 0.0);
-#pragma unroll
-                    for (int I = J; I < NT; I++) {
-                        double aval;
-                        if (I == J) aval = bval;
-                        else aval = sM[rb[I] + kcol];
-                        T[I] = mfma(-bval * dsel, aval, T[I]);
-                    }
-                }
+                sM[(rel >= 0) ? rb[J] + c0 + lq : (I_DUMMY - I_M)] = (rel == 0) ? dsel : Lc[J];
+                const double bval = (rel > 0) ? Lc[J] : ((rel == 0) ? 1.0 : 0.0);
+                bd = -bval * dsel;
+                if (m < 3) T[J] = mfma(bd, bval, T[J]);
             }
+#pragma unroll
+            for (int I = J + 1; I < NT; I++) {
+                d4 z = {0.0, 0.0, 0.0, 0.0};
+                z = mfma(pop, T[I][3], z);
+                sM[rb[I] + 16 * J + 12 + lq] = z[0];
+            }
+            wsync();
             TUM_TICK(11);
         }
         // (a failed factorisation -- a pivot that is not positive -- is acted upon after the parked registers are back:
