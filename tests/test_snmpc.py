@@ -735,7 +735,8 @@ def test_gpu_pipeline_instrumented_kernel_agrees():
             s.solve()
         else:
             p = s.profile_phases()
-            assert (p[:, 1:10] > 0).all() and (p[:, 4] > p[:, 2]).all()          # the factorisation dominates the residual phase
+            assert (p[:, [1, 2, 3, 5, 6, 7, 8, 9, 10, 11]] > 0).all()
+            assert (p[:, 10] + p[:, 11] > p[:, 2]).all()          # the factorisation (slots 10, 11) dominates the residual phase
         res[mode] = (s.get_iterate()[1].copy(), s.get_stats("qp_iter").copy(), s.get_cost().copy())
     for i in range(3):
         np.testing.assert_array_equal(res["phases"][i], res["plain"][i])

@@ -690,29 +690,35 @@ __global__ void __launch_bounds__(64, IPM_WPS) ipm_kernel(const PArgs pa)
         double dmin = 1.0;
         // lane predicates of the P operand (opaque to the optimiser: as plain compares of lc the select chains below become a
         // switch with branches)
-        int ec0 = lc == 0, ec1 = lc == 1, ec2 = lc == 2, eq0 = lq == 0, eq1 = lq == 1, eq2 = lq == 2, epz = (lc < 4 && lq <= lc);
+        int ec0 = lc == 0, ec1 = lc == 1, ec2 = lc == 2, eq0 = lq == 0, eq1 = lq == 1, eq2 = lq == 2, epz = lc < 4;
+        const double eu0 = (lq == 0) ? 1.0 : 0.0, eu1 = (lq == 1) ? 1.0 : 0.0, eu2 = (lq == 2) ? 1.0 : 0.0, eu3 = (lq == 3) ? 1.0 : 0.0;
         asm volatile("" : "+v"(ec0), "+v"(ec1), "+v"(ec2), "+v"(eq0), "+v"(eq1), "+v"(eq2), "+v"(epz));
+        static_for<0, NT - 1>([&](auto Jc) {      // (a template recursion: the body is far beyond the size up to which `#pragma unroll` is honoured)
+            constexpr int J = decltype(Jc)::value;
+            const int nd = NT - J;            // tiles below the diagonal one + the identity tile
+            d4 T[NT + 1];       // T[NT]: the identity, taken through the same steps as the tiles below the diagonal one
 #pragma unroll
-        for (int J = 0; J < NT; J++) {
-            d4 T[NT];
+            for (int jj = 0; jj < 4; jj++) T[NT][jj] = (lc == lq + 4 * jj) ? 1.0 : 0.0;
+            {
 #pragma unroll
-            for (int I = J; I < NT; I++) {
+                for (int I = J; I < NT; I++) {
 #pragma unroll
-                for (int jj = 0; jj < 4; jj++) {
-                    const int r = lq + 4 * jj;
-                    if (I > J) T[I][jj] = sM[rb[I] + 16 * J + r];
-                    else { const int hi = (r > lc) ? r : lc, lo = (r > lc) ? lc : r; T[I][jj] = sM[lpk(16 * J + hi, 16 * J + lo)]; }
+                    for (int jj = 0; jj < 4; jj++) {
+                        const int r = lq + 4 * jj;
+                        if (I > J) T[I][jj] = sM[rb[I] + 16 * J + r];
+                        else { const int hi = (r > lc) ? r : lc, lo = (r > lc) ? lc : r; T[I][jj] = sM[lpk(16 * J + hi, 16 * J + lo)]; }
+                    }
                 }
+#pragma unroll
+                for (int K = 0; K < J; K++)
+#pragma unroll
+                    for (int kc = 0; kc < 4; kc++) {
+                        const int kk = 16 * K + 4 * kc + lq;
+                        const double aJ = -sM[rb[J] + kk] * sM[lpk(kk, kk)];
+#pragma unroll
+                        for (int I = J; I < NT; I++) T[I] = mfma(aJ, sM[rb[I] + kk], T[I]);
+                    }
             }
-#pragma unroll
-            for (int K = 0; K < J; K++)
-#pragma unroll
-                for (int kc = 0; kc < 4; kc++) {
-                    const int kk = 16 * K + 4 * kc + lq;
-                    const double aJ = -sM[rb[J] + kk] * sM[lpk(kk, kk)];
-#pragma unroll
-                    for (int I = J; I < NT; I++) T[I] = mfma(aJ, sM[rb[I] + kk], T[I]);
-                }
             TUM_TICK(10);
             // four 4-column micro-panels. The 4x4 diagonal block sits in column m of the diagonal tile: entry (i, j) on lane
             // 16 j + 4 m + i. It is read into scalars (v_readlane) and factorised uniformly; the panel below it is scaled by
@@ -720,14 +726,16 @@ __global__ void __launch_bounds__(64, IPM_WPS) ipm_kernel(const PArgs pa)
             // into the lanes that hold E), so there is no LDS round trip inside a micro-panel: finished columns are only
             // stored. Software pipeline: only the diagonal tile is on the critical path (scale, rank-4 update, next
             // readlane); the two MFMAs of every tile below it are issued under the scalar chain of the NEXT micro-panel.
-            double Lc[NT], bd = 0.0, pop = 0.0;
+            // The identity tile T[NT] goes through the same two MFMAs: what comes out is W = L^-T D^-1 of the 16x16 diagonal
+            // block, and L^-1 = (W D)^T is stored into the strict lower triangle of the block (the solves use the inverse
+            // diagonal blocks; L of the diagonal block itself is never read again).
+            double Lc[NT + 1], bd = 0.0, pop = 0.0, dselp = 0.0;
 #pragma unroll
             for (int m = 0; m < 4; m++) {
                 const int c0 = 16 * J + 4 * m;
-                // k-th MFMA owed to the tiles below the diagonal one by the previous micro-panel: first their scaled columns,
-                // then their rank-4 updates; issued one at a time between the segments of the scalar chain below
+                // k-th MFMA slot between the segments of the scalar chain: what the previous micro-panel owes to the tiles
+                // below the diagonal one and to the identity tile (their scaled columns, then their rank-4 updates)
                 auto owed = [&](int k) {
-                    const int nd = NT - J - 1;
                     if (m > 0 && k < nd) {
                         const int I = J + 1 + k;
                         d4 z = {0.0, 0.0, 0.0, 0.0};
@@ -735,67 +743,77 @@ __global__ void __launch_bounds__(64, IPM_WPS) ipm_kernel(const PArgs pa)
                         Lc[I] = z[0];
                     } else if (m > 0 && k < 2 * nd) {
                         const int I = J + 1 + k - nd;
-                        sM[rb[I] + c0 - 4 + lq] = Lc[I];
+                        if (I < NT) sM[rb[I] + c0 - 4 + lq] = Lc[I];
+                        else sM[(4 * (m - 1) + lq > lc) ? lpk(c0 - 4 + lq, 16 * J + lc) : (I_DUMMY - I_M)] = Lc[NT] * dselp;
                         T[I] = mfma(bd, Lc[I], T[I]);
                     }
                     __builtin_amdgcn_sched_barrier(0);
                 };
                 const double a00 = readlane_f64(T[J][m], 4 * m);
                 const double a10 = readlane_f64(T[J][m], 4 * m + 1), a11 = readlane_f64(T[J][m], 16 + 4 * m + 1);
+                owed(0);
                 const double a20 = readlane_f64(T[J][m], 4 * m + 2), a21 = readlane_f64(T[J][m], 16 + 4 * m + 2),
                              a22 = readlane_f64(T[J][m], 32 + 4 * m + 2);
-                owed(0);
+                owed(1);
                 const double a30 = readlane_f64(T[J][m], 4 * m + 3), a31 = readlane_f64(T[J][m], 16 + 4 * m + 3),
                              a32 = readlane_f64(T[J][m], 32 + 4 * m + 3), a33 = readlane_f64(T[J][m], 48 + 4 * m + 3);
                 const double d0 = a00, i0 = frcp(d0);
+                owed(2);
                 const double l10 = a10 * i0, l20 = a20 * i0, l30 = a30 * i0;
-                owed(1);
                 const double d1 = a11 - l10 * a10, i1 = frcp(d1);
+                owed(3);
                 const double y21 = a21 - l20 * a10, y31 = a31 - l30 * a10;
                 const double l21 = y21 * i1, l31 = y31 * i1;
-                owed(2);
+                owed(4);
                 const double d2 = a22 - l20 * a20 - l21 * y21, i2 = frcp(d2);
+                owed(5);
                 const double y32 = a32 - l30 * a20 - l31 * y21;
                 const double l32 = y32 * i2;
-                const double w20 = l21 * l10 - l20;
-                owed(3);
-                const double d3 = a33 - l30 * a30 - l31 * y31 - l32 * y32, i3 = frcp(d3);
-                const double p01 = -l10 * i1, p02 = w20 * i2, p12 = -l21 * i2;
-                owed(4);
-                dmin = fmin(dmin, fmin(fmin(d0, d1), fmin(d2, d3)));
-                // P[k][x] on lane 16 k + x (k <= x < 4), zero elsewhere
-                const double p03 = (l31 * l10 - l30 - l32 * w20) * i3, p13 = (l32 * l21 - l31) * i3, p23 = -l32 * i3;
-                owed(5);
-                const double pr0 = ec0 ? i0 : ec1 ? p01 : ec2 ? p02 : p03;
-                const double pr1 = ec1 ? i1 : ec2 ? p12 : p13;
+                // P[k][x] = (L^-1)[x][k] / d_x on lane (k, x) = (lq, lc), x < 4: every lane runs the substitution for ITS column
+                // k of L^-1 (unit vector e_k as the start: one instruction stream, six FMAs), then picks row x
+                const double X1 = eu1 - l10 * eu0;
                 owed(6);
-                const double pr2 = ec2 ? i2 : p23;
-                const double prq = eq0 ? pr0 : eq1 ? pr1 : eq2 ? pr2 : i3;
-                const double popn = epz ? prq : 0.0;
+                const double d3 = a33 - l30 * a30 - l31 * y31 - l32 * y32, i3 = frcp(d3);
+                const double X2 = eu2 - l20 * eu0 - l21 * X1;
                 owed(7);
+                dmin = fmin(dmin, fmin(fmin(d0, d1), fmin(d2, d3)));
+                const double X3 = eu3 - l30 * eu0 - l31 * X1 - l32 * X2;
+                owed(8);
+                const double Xx = ec0 ? eu0 : ec1 ? X1 : ec2 ? X2 : X3;
+                owed(9);
+                const double ix = ec0 ? i0 : ec1 ? i1 : ec2 ? i2 : i3;
+                owed(10);
+                const double popn = epz ? Xx * ix : 0.0;
+                owed(11);
                 const double dsel = eq0 ? d0 : eq1 ? d1 : eq2 ? d2 : d3;
                 const int rel = lc - (4 * m + lq);              // row - column inside the diagonal tile
-                if (NT > 5) { owed(8); owed(9); }
                 pop = popn;
+                dselp = dsel;
                 {
                     d4 z = {0.0, 0.0, 0.0, 0.0};
                     z = mfma(pop, T[J][m], z);
                     Lc[J] = z[0];
                 }
-                sM[(rel >= 0) ? rb[J] + c0 + lq : (I_DUMMY - I_M)] = (rel == 0) ? dsel : Lc[J];
+                sM[(rel == 0) ? rb[J] + c0 + lq : (I_DUMMY - I_M)] = dsel;
                 const double bval = (rel > 0) ? Lc[J] : ((rel == 0) ? 1.0 : 0.0);
                 bd = -bval * dsel;
                 if (m < 3) T[J] = mfma(bd, bval, T[J]);
             }
+            // what the last micro-panel owes: scaled columns
 #pragma unroll
-            for (int I = J + 1; I < NT; I++) {
+            for (int I = J + 1; I <= NT; I++) {
                 d4 z = {0.0, 0.0, 0.0, 0.0};
                 z = mfma(pop, T[I][3], z);
-                sM[rb[I] + 16 * J + 12 + lq] = z[0];
+                Lc[I] = z[0];
+            }
+#pragma unroll
+            for (int I = J + 1; I <= NT; I++) {
+                if (I < NT) sM[rb[I] + 16 * J + 12 + lq] = Lc[I];
+                else sM[(12 + lq > lc) ? lpk(16 * J + 12 + lq, 16 * J + lc) : (I_DUMMY - I_M)] = Lc[NT] * dselp;
             }
             wsync();
             TUM_TICK(11);
-        }
+        });
         // (a failed factorisation -- a pivot that is not positive -- is acted upon after the parked registers are back:
         //  leaving the loop here would keep all of them alive across the factorisation for the code behind the loop)
         // bounded to two wavefronts per SIMD (IPM_WPS 2) the gg rows come back now, their latency running under the block
@@ -805,38 +823,6 @@ __global__ void __launch_bounds__(64, IPM_WPS) ipm_kernel(const PArgs pa)
             asm volatile("" : "+v"(gc2));          // (opaque: the reload must stay behind the micro-panels)
 #pragma unroll
             for (int i = 0; i < NCH; i++) chv[i] = gc2[i * 64];
-        }
-        // ---- inverses of the unit-lower 16x16 diagonal blocks, in place
-        {
-            // lane = column: the columns 0..63 and (on the first NB1 lanes) 64.. are two independent substitution chains; they
-            // run interleaved (one pass over the rows, two accumulators each) instead of one after the other
-            const int gA = lane, gB = lane1;
-            const bool ownB = lane < NB1;
-            const int gbA = gA & ~15, clA = gA & 15, gbB = gB & ~15, clB = gB & 15;
-            double XA[16], XB[16];
-#pragma unroll
-            for (int k = 0; k < 16; k++) { XA[k] = (k == clA) ? 1.0 : 0.0; XB[k] = (k == clB) ? 1.0 : 0.0; }
-            int rowA = lpk(gbA, gbA), rowB = lpk(gbB, gbB);
-            int rowsA[16], rowsB[16];
-#pragma unroll
-            for (int r = 1; r < 16; r++) {
-                rowA += gbA + r; rowB += gbB + r;
-                rowsA[r] = rowA; rowsB[r] = rowB;
-                double a0 = 0.0, a1 = 0.0, b0_ = 0.0, b1_ = 0.0;
-#pragma unroll
-                for (int k = 0; k < r; k++) {
-                    if (k & 1) { a1 += sM[rowA + k] * XA[k]; b1_ += sM[rowB + k] * XB[k]; }
-                    else { a0 += sM[rowA + k] * XA[k]; b0_ += sM[rowB + k] * XB[k]; }
-                }
-                XA[r] -= a0 + a1; XB[r] -= b0_ + b1_;
-            }
-            wsync();
-#pragma unroll
-            for (int r = 1; r < 16; r++) {
-                sM[(r > clA) ? rowsA[r] + clA : (I_DUMMY - I_M)] = XA[r];
-                sM[(ownB && r > clB) ? rowsB[r] + clB : (I_DUMMY - I_M)] = XB[r];
-            }
-            wsync();
         }
         TUM_TICK(4);
 
