@@ -686,7 +686,8 @@ __global__ void __launch_bounds__(64, IPM_WPS) ipm_kernel(const PArgs pa)
         }
         wsync();
         TUM_TICK(3);
-        // ---- blocked L D L' factorisation (as in the fused kernel: row-panel register tiles, 4-column micro-panels)
+        // ---- blocked L D L' factorisation (row-panel register tiles as in the fused kernel; the 4-column micro-panels differ:
+        //      no LDS round trips, see below)
         double dmin = 1.0;
         // lane predicates of the P operand (opaque to the optimiser: as plain compares of lc the select chains below become a
         // switch with branches)
@@ -699,33 +700,33 @@ __global__ void __launch_bounds__(64, IPM_WPS) ipm_kernel(const PArgs pa)
             d4 T[NT + 1];       // T[NT]: the identity, taken through the same steps as the tiles below the diagonal one
 #pragma unroll
             for (int jj = 0; jj < 4; jj++) T[NT][jj] = (lc == lq + 4 * jj) ? 1.0 : 0.0;
-            {
 #pragma unroll
-                for (int I = J; I < NT; I++) {
+            for (int I = J; I < NT; I++) {
 #pragma unroll
-                    for (int jj = 0; jj < 4; jj++) {
-                        const int r = lq + 4 * jj;
-                        if (I > J) T[I][jj] = sM[rb[I] + 16 * J + r];
-                        else { const int hi = (r > lc) ? r : lc, lo = (r > lc) ? lc : r; T[I][jj] = sM[lpk(16 * J + hi, 16 * J + lo)]; }
-                    }
+                for (int jj = 0; jj < 4; jj++) {
+                    const int r = lq + 4 * jj;
+                    if (I > J) T[I][jj] = sM[rb[I] + 16 * J + r];
+                    else { const int hi = (r > lc) ? r : lc, lo = (r > lc) ? lc : r; T[I][jj] = sM[lpk(16 * J + hi, 16 * J + lo)]; }
                 }
-#pragma unroll
-                for (int K = 0; K < J; K++)
-#pragma unroll
-                    for (int kc = 0; kc < 4; kc++) {
-                        const int kk = 16 * K + 4 * kc + lq;
-                        const double aJ = -sM[rb[J] + kk] * sM[lpk(kk, kk)];
-#pragma unroll
-                        for (int I = J; I < NT; I++) T[I] = mfma(aJ, sM[rb[I] + kk], T[I]);
-                    }
             }
+#pragma unroll
+            for (int K = 0; K < J; K++)
+#pragma unroll
+                for (int kc = 0; kc < 4; kc++) {
+                    const int kk = 16 * K + 4 * kc + lq;
+                    const double aJ = -sM[rb[J] + kk] * sM[lpk(kk, kk)];
+#pragma unroll
+                    for (int I = J; I < NT; I++) T[I] = mfma(aJ, sM[rb[I] + kk], T[I]);
+                }
             TUM_TICK(10);
             // four 4-column micro-panels. The 4x4 diagonal block sits in column m of the diagonal tile: entry (i, j) on lane
             // 16 j + 4 m + i. It is read into scalars (v_readlane) and factorised uniformly; the panel below it is scaled by
             // ONE MFMA per tile with the 4x4 upper triangular P = L^-T D^-1 as the A operand (new column block = E P, straight
             // into the lanes that hold E), so there is no LDS round trip inside a micro-panel: finished columns are only
-            // stored. Software pipeline: only the diagonal tile is on the critical path (scale, rank-4 update, next
-            // readlane); the two MFMAs of every tile below it are issued under the scalar chain of the NEXT micro-panel.
+            // stored. Only the diagonal tile is on the dependency path (scale, rank-4 update, next readlane); the two MFMAs
+            // of every tile below it are issued between the segments of the scalar chain of the NEXT micro-panel, where their
+            // 64-cycle result latency costs nothing. (An f64 MFMA occupies the same pipe as the f64 VALU instructions of its
+            // wavefront: measured, MFMA time and chain time add up -- the interleave hides latencies, not issue time.)
             // The identity tile T[NT] goes through the same two MFMAs: what comes out is W = L^-T D^-1 of the 16x16 diagonal
             // block, and L^-1 = (W D)^T is stored into the strict lower triangle of the block (the solves use the inverse
             // diagonal blocks; L of the diagonal block itself is never read again).
