@@ -688,7 +688,10 @@ __global__ void __launch_bounds__(64, IPM_WPS) ipm_kernel(const PArgs pa)
         TUM_TICK(3);
         // ---- blocked L D L' factorisation (row-panel register tiles as in the fused kernel; the 4-column micro-panels differ:
         //      no LDS round trips, see below)
-        double dmin = 1.0;
+        // smallest pivot, tracked through the HIGH WORDS of the (wave-uniform) pivots as signed integers: for positive doubles
+        // the order is the same, a negative pivot has a negative high word; integer minima instead of 4 v_min_f64 (+ 4
+        // canonicalising v_max_f64) per micro-panel
+        int dmin_hi = 0x3ff00000;
         // lane predicates of the P operand (opaque to the optimiser: as plain compares of lc the select chains below become a
         // switch with branches)
         int ec0 = lc == 0, ec1 = lc == 1, ec2 = lc == 2, eq0 = lq == 0, eq1 = lq == 1, eq2 = lq == 2, epz = lc < 4;
@@ -777,7 +780,7 @@ __global__ void __launch_bounds__(64, IPM_WPS) ipm_kernel(const PArgs pa)
                 const double d3 = a33 - l30 * a30 - l31 * y31 - l32 * y32, i3 = frcp(d3);
                 const double X2 = eu2 - l20 * eu0 - l21 * X1;
                 owed(7);
-                dmin = fmin(dmin, fmin(fmin(d0, d1), fmin(d2, d3)));
+                dmin_hi = min(min(min(dmin_hi, __double2hiint(d0)), min(__double2hiint(d1), __double2hiint(d2))), __double2hiint(d3));
                 const double X3 = eu3 - l30 * eu0 - l31 * X1 - l32 * X2;
                 owed(8);
                 const double Xx = ec0 ? eu0 : ec1 ? X1 : ec2 ? X2 : X3;
@@ -827,7 +830,7 @@ __global__ void __launch_bounds__(64, IPM_WPS) ipm_kernel(const PArgs pa)
         }
         TUM_TICK(4);
 
-        if (!(dmin > 1e-300)) { qp_status = 3; break; }
+        if (dmin_hi < 0x01a56e1f) { qp_status = 3; break; }          // a pivot below 1e-300 (or negative): the factorisation failed
         // ---- predictor / corrector
         double rD[NS2], rG[NS2];   // D, G of every row side: fixed for both solves of this iteration
         {
