@@ -227,7 +227,7 @@ def main():
     # correctness of what was timed: statuses, and a parity spot check against the oracle on rank 0
     st = s.get_stats("status"); it = s.get_stats("qp_iter")
     X, U = s.get_iterate()
-    # which kernels ran: the fused kernel, or (batches of more than 1024 instances) the four-kernel pipeline, whose dominant
+    # which kernels ran: the four-kernel pipeline (the default), whose dominant
     # kernel -- the interior point kernel -- is timed on its own (library events around it) over five more steps
     ipm_ms = None
     try:

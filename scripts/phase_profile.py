@@ -17,10 +17,10 @@ s.cold_start(); p = s.profile_phases(); ms1 = s.last_kernel_ms()
 it = s.get_stats("qp_iter")
 names = ["load+linearise", "condense", "ipm residuals", "M assembly (SYRK)", "Cholesky", "rhs (C'w)", "tri-solves", "C*dv + steps", "ipm exit", "expand+cost+store"]
 tot = p[:, :12].sum(axis=1)
-if KERNEL == "pipeline" or (KERNEL == "auto" and B > 1024):
+if KERNEL in ("pipeline", "auto"):
     names = ["(unused)", "load + initial point", "ipm residuals", "M assembly (SYRK)", "L D L' (rest)", "rhs (C'w)", "tri-solves", "C*dv + steps", "ipm exit", "outputs"]
 print(f"kernel variant {KERNEL}; batch {B}: kernel {ms0:.3f} ms plain, {ms1:.3f} ms with timers; mean qp_iter {it.mean():.2f}; mean cycles/OCP {tot.mean():.0f}")
-if KERNEL == "pipeline" or (KERNEL == "auto" and B > 1024):
+if KERNEL in ("pipeline", "auto"):
     names = names + ["L D L': tile loads + left-looking update", "L D L': micro-panels + block inverses"]
 for i, n in enumerate(names):
     print(f"  {n:22s} {p[:, i].mean():12.0f} cyc  {100*p[:, i].mean()/tot.mean():5.1f} %   per-iter {p[:, i].mean()/it.mean():9.0f}")

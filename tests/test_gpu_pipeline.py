@@ -2,8 +2,8 @@
 The two kernel variants of the nominal solve (include/tum_nmpc.h, tum_ocp_set_kernel) against each other and against the
 oracle: "fused" (one kernel per solve) and "pipeline" (linearise / condense / interior point / expand as four kernels,
 csrc/pipe_kernels.hpp). Same arithmetic per phase, so they agree to rounding (the order of a few sums differs) and
-take the same number of interior point iterations. With the default "auto" the large-batch tests of test_gpu_parity.py /
-test_gpu_configs.py already run the pipeline and the small-batch ones the fused kernel; here both are forced.
+take the same number of interior point iterations. With the default ("auto" = pipeline) every other GPU test already runs
+the pipeline; here both are forced.
 """
 import numpy as np
 import pytest

@@ -532,9 +532,11 @@ static int ensure_workspace(tum_ocp *c)
 }
 
 // "fused": one kernel per solve; "pipeline": linearise / condense / interior point / expand as four kernels, each at its own
-// occupancy (measured 4-8 % faster than the fused kernel from 4096 instances up, a few per cent slower below 1024: three
-// more launches and the hand-over through L2); "auto" (default): the pipeline when the batch is more than one round of
-// resident wavefronts (> 1024 instances). The coupled SNMPC OCP follows the same rule (prologue / epilogue around either).
+// occupancy, handing over through the L2-resident workspace. Since the pipeline's interior point kernel has the factorisation
+// without LDS round trips it is the faster one at every batch size (device time per solve 0.334 against 0.346 ms at one
+// instance, 1.51 against 1.71 ms at 4096; wall time of a solve() call likewise): "auto" (default) runs the pipeline; the fused
+// kernel stays selectable and is what the condensed-QP debug dump runs. The coupled SNMPC OCP follows the same rule
+// (prologue / epilogue around either).
 extern "C" int tum_ocp_set_kernel(tum_ocp *c, const char *name)
 {
     if (!c || !name) return fail("null argument");
@@ -549,7 +551,7 @@ extern "C" int tum_ocp_set_kernel(tum_ocp *c, const char *name)
 // which kernel variant this solve runs, and its workspace (allocated on first use; never inside a stream capture)
 static int resolve_kernel(tum_ocp *c)
 {
-    c->pipe = !(c->ka.flags & 2) && (c->kmode == 2 || (c->kmode == 0 && c->batch > 1024));
+    c->pipe = !(c->ka.flags & 2) && c->kmode != 1;
     if (c->N > NMAX) {      // the fused kernel covers N <= 40; longer horizons exist as a pipeline instantiation only
         if (c->ka.flags & 2) return fail("debug_dump: the condensed-QP dump is built for N <= 40");
         if (c->kmode == 1) return fail("solve: kernel 'fused' is built for N <= 40 (use 'auto' or 'pipeline')");
