@@ -627,65 +627,45 @@ __global__ void __launch_bounds__(64, IPM_WPS) ipm_kernel(const PArgs pa)
             TUM_TICK(2);
             publish(gsum, sGamH);
         }
-        // ---- M = H + C' Gamma C, tile columns outermost; H streamed from the workspace two tiles ahead
-        {
-            double gch[NC];
+        // ---- M = H + C' Gamma C is assembled block column by block column INSIDE the factorisation below, straight into the
+        // register tiles the factorisation works on (M itself never exists in LDS). H is streamed from the workspace HD tiles
+        // ahead of its use, in the order the block columns need it: (0,0) (1,0) .. (NT-1,0) (1,1) (2,1) ...
+        constexpr int HD = 4;
+        auto hpos = [](int J, int I) { return J * NT - J * (J - 1) / 2 + I - J; };       // position of tile (row I, column J)
+        auto hseq = [&](const int n) -> d4 {
+            int J2 = 0;
+            while (J2 + 1 < NT && (J2 + 1) * NT - (J2 + 1) * J2 / 2 <= n) J2++;
+            return ghws[tidx(J2, J2 + n - (J2 * NT - J2 * (J2 - 1) / 2)) * 64];
+        };
+        d4 hq[HD];
 #pragma unroll
-            for (int c = 0; c < NC; c++) gch[c] = sGamH[4 * c + lq];
-            const double dt2 = dt * dt;
-            // H comes back from the workspace HD tiles ahead of its use (tile order (0,0) (0,1) (1,1) (0,2) ...: tile n of that
-            // order is (K, I) with n = I (I + 1) / 2 + K)
-            constexpr int HD = 4;
-            auto hseq = [&](const int n) -> d4 {
-                int I2 = 0;
-                while ((I2 + 1) * (I2 + 2) / 2 <= n) I2++;
-                return ghws[tidx(n - I2 * (I2 + 1) / 2, I2) * 64];
-            };
-            d4 hq[HD];
+        for (int n = 0; n < HD; n++) hq[n] = hseq(n);
+        const double dt2 = dt * dt;
+        // everything the block columns take from the small LDS tables is fetched up front (the loads cannot be moved across the
+        // stores of the factorisation by the compiler, and at the start of a block column their latency would be exposed):
+        // gamma per chunk, the structured (steering-angle) rows' term of the off-diagonal tiles (depends on the row only) and
+        // the terms of the diagonal tiles
+        constexpr bool PRE_DIAG = (NT == 5);          // (the six-tile build has no registers for the diagonal tiles' terms)
+        double gch[NC], sfxo[NT], dadd[NT][4];
 #pragma unroll
-            for (int n = 0; n < HD; n++) hq[n] = hseq(n);
+        for (int c = 0; c < NC; c++) gch[c] = sGamH[4 * c + lq];
 #pragma unroll
-            for (int I = 0; I < NT; I++) {
-                const int col = 16 * I + lc;
-                const double sfxoI = ((lq & 1) && (lc & 1) && col < nv) ? dt2 * sSfx[(col >> 1) + 1] : 0.0;
-                // gamma-scaled operands of tile column I (at most 10, reused by every K <= I; scaling the column operand
-                // instead of the row operand keeps the number of live products at 10 instead of 30)
-                double bs[NC];
+        for (int I = 0; I < NT; I++) {
+            const int r_ = 16 * I + lc;
+            sfxo[I] = ((lq & 1) && (lc & 1) && r_ < nv) ? dt2 * sSfx[(r_ >> 1) + 1] : 0.0;
+            if constexpr (PRE_DIAG) {
 #pragma unroll
-                for (int c = 2 * I; c < NC; c++) bs[c] = chv[cidx(c, I)] * gch[c];
-#pragma unroll
-                for (int K = 0; K <= I; K++) {
-                    const int n = I * (I + 1) / 2 + K;
-                    d4 acc = hq[n % HD];
-                    if (n + HD < NTT) hq[n % HD] = hseq(n + HD);
-                    if (K == I) {
-#pragma unroll
-                        for (int jj = 0; jj < 4; jj++) {
-                            const int row = 16 * K + lq + 4 * jj;
-                            const int mx = (row > col) ? row : col;
-                            const double sf = sSfx[(mx >> 1) + 1];
-                            double add = ((row & 1) && (col & 1) && mx < nv) ? dt2 * sf : 0.0;
-                            const double wb = sWb[(row >> 1) < NMAX ? (row >> 1) : 0];
-                            if (row == col) add += p_reg + (((row & 1) && row < nv) ? wb : 0.0);
-                            acc[jj] += add;
-                        }
-                    } else {
-#pragma unroll
-                        for (int jj = 0; jj < 4; jj++) acc[jj] += sfxoI;
-                    }
-#pragma unroll
-                    for (int c = 2 * I; c < NC; c++) acc = mfma(chv[cidx(c, K)], bs[c], acc);
-#pragma unroll
-                    for (int jj = 0; jj < 4; jj++) {
-                        const int rg = 16 * K + lq + 4 * jj, cg = 16 * I + lc;
-                        if (K < I) sM[rb[I] + rg] = acc[jj];
-                        else sM[(cg >= rg) ? rb[I] + rg : (I_DUMMY - I_M)] = acc[jj];
-                    }
+                for (int jj = 0; jj < 4; jj++) {
+                    const int row = 16 * I + lq + 4 * jj, col = r_;
+                    const int mx = (row > col) ? row : col;
+                    const double sf = sSfx[(mx >> 1) + 1];
+                    double add = ((row & 1) && (col & 1) && mx < nv) ? dt2 * sf : 0.0;
+                    const double wb = sWb[(row >> 1) < NMAX ? (row >> 1) : 0];
+                    if (row == col) add += p_reg + (((row & 1) && row < nv) ? wb : 0.0);
+                    dadd[I][jj] = add;
                 }
             }
         }
-        wsync();
-        TUM_TICK(3);
         // ---- blocked L D L' factorisation (row-panel register tiles as in the fused kernel; the 4-column micro-panels differ:
         //      no LDS round trips, see below)
         // smallest pivot, tracked through the HIGH WORDS of the (wave-uniform) pivots as signed integers: for positive doubles
@@ -703,15 +683,37 @@ __global__ void __launch_bounds__(64, IPM_WPS) ipm_kernel(const PArgs pa)
             d4 T[NT + 1];       // T[NT]: the identity, taken through the same steps as the tiles below the diagonal one
 #pragma unroll
             for (int jj = 0; jj < 4; jj++) T[NT][jj] = (lc == lq + 4 * jj) ? 1.0 : 0.0;
+            {
+                // block column J of M: the column operand of the gg rows is scaled by gamma once (chunks 2J..NC-1) and reused by
+                // every tile below; tile (I, J) takes the chunks whose rows reach row tile I (c >= 2 I)
+                double as[NC];
 #pragma unroll
-            for (int I = J; I < NT; I++) {
+                for (int c = 2 * J; c < NC; c++) as[c] = chv[cidx(c, J)] * gch[c];
 #pragma unroll
-                for (int jj = 0; jj < 4; jj++) {
-                    const int r = lq + 4 * jj;
-                    if (I > J) T[I][jj] = sM[rb[I] + 16 * J + r];
-                    else { const int hi = (r > lc) ? r : lc, lo = (r > lc) ? lc : r; T[I][jj] = sM[lpk(16 * J + hi, 16 * J + lo)]; }
+                for (int I = J; I < NT; I++) {
+                    const int n = hpos(J, I);
+                    d4 acc = hq[n % HD];
+                    if (n + HD < NTT) hq[n % HD] = hseq(n + HD);
+#pragma unroll
+                    for (int jj = 0; jj < 4; jj++) {
+                        if constexpr (PRE_DIAG) acc[jj] += (I == J) ? dadd[J][jj] : sfxo[I];
+                        else if (I > J) acc[jj] += sfxo[I];
+                        else {
+                            const int row = 16 * J + lq + 4 * jj, col = 16 * J + lc;
+                            const int mx = (row > col) ? row : col;
+                            const double sf = sSfx[(mx >> 1) + 1];
+                            double add = ((row & 1) && (col & 1) && mx < nv) ? dt2 * sf : 0.0;
+                            const double wb = sWb[(row >> 1) < NMAX ? (row >> 1) : 0];
+                            if (row == col) add += p_reg + (((row & 1) && row < nv) ? wb : 0.0);
+                            acc[jj] += add;
+                        }
+                    }
+#pragma unroll
+                    for (int c = 2 * I; c < NC; c++) acc = mfma(as[c], chv[cidx(c, I)], acc);
+                    T[I] = acc;
                 }
             }
+            TUM_TICK(3);
 #pragma unroll
             for (int K = 0; K < J; K++)
 #pragma unroll
