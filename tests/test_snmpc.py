@@ -385,6 +385,31 @@ def test_gpu_coupled_snmpc_other_sample_counts(golden_dir, ns, L, N, uph):
 
 
 @pytest.mark.gpu
+def test_gpu_snmpc_frozen_sample_copies_are_deferred_not_lost():
+    """The epilogue does not write the sample copies of the stages > uph (they equal stage uph, pred_model_dynamic_disc.py:203);
+    they are brought up to date when asked for. Two solves without a read in between, then reads / a write beyond uph."""
+    from tum_control_amd.solver import CoupledSnmpcSolver
+    from tum_control_amd.workloads import nominal_batch
+    snm, stds, w, A = _pce()
+    N, uph, ns, B = 40, 5, 10, 6
+    x0, yref = nominal_batch(B, N=N, seed=11)
+    s = CoupledSnmpcSolver(N=N, batch=B, Apce=A, uph=uph, x0_offsets=snm.x0_offsets(w, stds))
+    s.install_reference_ocp(); s.set_x0(x0); s.set_yref_all(yref); s.cold_start()
+    assert s.solve() == 0 and s.solve() == 0
+    at = lambda k: np.atleast_2d(s.get(k, "x")).reshape(B, ns + 1, 8)
+    xu = at(uph)
+    for k in (uph + 1, 17, N):
+        np.testing.assert_array_equal(at(k)[:, 1:], xu[:, 1:], err_msg=f"stage {k}")
+    assert s.solve() == 0                       # a third solve, then a WRITE beyond uph before any read
+    xu3 = at(uph)
+    mine = np.arange(8.0 * (ns + 1)).reshape(1, -1) + 0.25
+    s.set(N - 1, "x", np.repeat(mine, B, axis=0))
+    np.testing.assert_array_equal(at(N - 1), np.repeat(mine, B, axis=0).reshape(B, ns + 1, 8))
+    np.testing.assert_array_equal(at(N)[:, 1:], xu3[:, 1:])          # the other stages got the third solve's copies
+    assert not np.array_equal(xu3[:, 1:], xu[:, 1:])
+
+
+@pytest.mark.gpu
 def test_gpu_snmpc_controller_mirror(golden_dir):
     """the SNMPC_class.py mirror drives the coupled solver like the reference's controller does"""
     from tum_control_amd.snmpc import Stochastic_Nonlinear_Model_Predictive_Controller as C

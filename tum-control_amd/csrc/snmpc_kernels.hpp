@@ -45,6 +45,7 @@ struct SnArgs {
     const double *dv;         // [b][dv_stride]  QP solution of the fused kernel / of the pipeline's interior point kernel (epilogue)
     int dv_stride;
     const int *status;        // [b]
+    int *xs_dirty;            // [b] 1: the sample copies of the stages > uph wait to be frozen at the value of stage uph (snmpc_freeze_kernel)
     double *dbg;              // development aid: phase cycle counters of instance 0 (or null)
 };
 
@@ -243,23 +244,27 @@ __global__ void __launch_bounds__(64) snmpc_prologue_kernel(const SnArgs sa)
 }
 
 // full step of the sample copies: dx^(i)_0 = xs0 - X^(i)_0, dx^(i)_{k+1} = A dx^(i)_k + B du_k + b for k < uph; frozen
-// afterwards (X^(i)_k = X^(i)_uph for k > uph, pred_model_dynamic_disc.py:203). One lane per sample.
+// afterwards (X^(i)_k = X^(i)_uph for k > uph, pred_model_dynamic_disc.py:203). One lane per sample. The frozen copies
+// are NOT written here: nothing on the solve path reads the sample copies of a stage > uph, and writing them is 22 KB per
+// instance and solve (N = 40, uph = 5, ten samples; 92 MB per 4096-instance solve). The instance is flagged instead and
+// snmpc_freeze_kernel brings the stages > uph up to date when somebody asks for them (get / set of a stacked state of
+// such a stage, a change of uph).
 __global__ void __launch_bounds__(64) snmpc_epilogue_kernel(const SnArgs sa)
 {
     const int lane = threadIdx.x, b = blockIdx.x;
     if (b >= sa.batch || sa.status[b] != 0) return;
     const int N = sa.N, ns = sa.ns, uph = sa.uph, i = lane;
+    if (lane == 0 && uph < N) sa.xs_dirty[b] = 1;
     if (i >= ns) return;
     double *gXS = sa.XS + (size_t)b * (N + 1) * ns * NX;
     const double *ws2 = sa.ws2 + (size_t)b * uph * ns * ABS;
     const double *dv = sa.dv + (size_t)b * sa.dv_stride;
-    double dx[8], xnew[8];
+    double dx[8];
 #pragma unroll
     for (int r = 0; r < 8; r++) {
         const double x = gXS[(size_t)i * NX + r];
         dx[r] = sa.xs0[((size_t)b * ns + i) * NX + r] - x;
-        xnew[r] = x + dx[r];
-        gXS[(size_t)i * NX + r] = xnew[r];
+        gXS[(size_t)i * NX + r] = x + dx[r];
     }
     for (int k = 0; k < uph; k++) {
         const double *rec = ws2 + (size_t)(k * ns + i) * ABS;
@@ -272,13 +277,20 @@ __global__ void __launch_bounds__(64) snmpc_epilogue_kernel(const SnArgs sa)
         for (int r = 0; r < 8; r++) dx[r] += rec[44 + r];
         double *xq = gXS + ((size_t)(k + 1) * ns + i) * NX;
 #pragma unroll
-        for (int r = 0; r < 8; r++) { xnew[r] = xq[r] + dx[r]; xq[r] = xnew[r]; }
+        for (int r = 0; r < 8; r++) xq[r] += dx[r];
     }
-    for (int k = uph + 1; k <= N; k++) {
-        double *xq = gXS + ((size_t)k * ns + i) * NX;
-#pragma unroll
-        for (int r = 0; r < 8; r++) xq[r] = xnew[r];
-    }
+}
+
+// the deferred part of the epilogue: X^(i)_k = X^(i)_uph for k > uph on the flagged instances (contiguous, coalesced)
+__global__ void __launch_bounds__(256) snmpc_freeze_kernel(double *XS, int *dirty, int N, int ns, int uph, int batch)
+{
+    const int b = blockIdx.x;
+    if (b >= batch || !dirty[b]) return;
+    const int per = ns * NX;
+    double *g = XS + (size_t)b * (N + 1) * per;
+    for (int o = threadIdx.x; o < (N - uph) * per; o += blockDim.x) g[(size_t)(uph + 1) * per + o] = g[(size_t)uph * per + o % per];
+    __syncthreads();
+    if (threadIdx.x == 0) dirty[b] = 0;
 }
 
 // sample initial conditions from the nominal one: xs0[b][i] = x0[b] + offs[i]  (compute_x0dist, stochastic_mpc_utils.py:78-91)

@@ -44,6 +44,7 @@ struct tum_ocp {
     bool sn;
     SnArgs sa;
     double *dXS, *dxs0, *dApce, *dws2, *dpro, *ddv, *doffs;
+    int *dxs_dirty; bool xs_lazy;          // sample copies of the stages > uph not yet frozen (snmpc_freeze_kernel)
     bool have_offs, fanout;        // sample initial conditions derived from the nominal x0 at every solve
     // R2NMPC tightening after every solve (tum_ocp_r2_attach)
     bool r2; int r2_uph; double r2_dmin, r2_dmax, r2_uh; double *dr2S, *dr2B;
@@ -92,7 +93,7 @@ extern "C" tum_ocp *tum_ocp_create(const tum_ocp_desc *desc)
     DevGuard guard(desc->device);
     tum_ocp *c = new tum_ocp();
     c->d = *desc; c->N = desc->N; c->batch = desc->batch; c->last_ms = 0; c->solved = false;
-    c->sn = false; c->dXS = c->dxs0 = c->dApce = c->dws2 = c->dpro = c->ddv = c->doffs = nullptr;
+    c->sn = false; c->dXS = c->dxs0 = c->dApce = c->dws2 = c->dpro = c->ddv = c->doffs = nullptr; c->dxs_dirty = nullptr; c->xs_lazy = false;
     c->have_offs = c->fanout = false;
     c->r2 = false; c->dr2S = c->dr2B = nullptr;
     c->p_dirty = false; c->uph_cap = 0; c->gamma = 0.0; c->dpceA = nullptr; c->pce_L = c->pce_S = 0; c->dbnd_snap = nullptr;
@@ -183,7 +184,7 @@ extern "C" void tum_ocp_free(tum_ocp *c)
     (void)hipFree(c->ddbg); (void)hipFree(c->dprof); (void)hipFree(c->dws); (void)hipFree(c->dhws); (void)hipFree(c->drec); (void)hipFree(c->dcws); (void)hipFree(c->dvec);
     if (c->evi0) (void)hipEventDestroy(c->evi0);
     if (c->evi1) (void)hipEventDestroy(c->evi1);
-    (void)hipFree(c->dXS); (void)hipFree(c->dxs0); (void)hipFree(c->dApce); (void)hipFree(c->dws2); (void)hipFree(c->dpro); (void)hipFree(c->ddv); (void)hipFree(c->doffs);
+    (void)hipFree(c->dXS); (void)hipFree(c->dxs0); (void)hipFree(c->dApce); (void)hipFree(c->dws2); (void)hipFree(c->dpro); (void)hipFree(c->ddv); (void)hipFree(c->doffs); (void)hipFree(c->dxs_dirty);
     (void)hipFree(c->dr2S); (void)hipFree(c->dr2B); (void)hipFree(c->dpceA); (void)hipFree(c->dbnd_snap);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
@@ -219,7 +220,9 @@ extern "C" int tum_ocp_snmpc_attach(tum_ocp *c, int ns, int L, const double *Apc
     ok &= dalloc(&c->dpro, B * (size_t)(uph > 0 ? uph : 1) * SN_PRO_STAGE) == hipSuccess;
     ok &= dalloc(&c->ddv, B * NVP) == hipSuccess;
     ok &= dalloc(&c->doffs, (size_t)ns * NX) == hipSuccess;
+    if (ok) { (void)hipFree(c->dxs_dirty); c->dxs_dirty = nullptr; ok &= hipMalloc((void **)&c->dxs_dirty, sizeof(int) * B) == hipSuccess; }
     if (!ok) return fail("snmpc_attach: device allocation failed");
+    HIPCHK(hipMemset(c->dxs_dirty, 0, sizeof(int) * B)); c->xs_lazy = false;
     HIPCHK(hipMemcpy(c->dApce, Apce, sizeof(double) * L * ns, hipMemcpyHostToDevice));
     SnArgs &sa = c->sa;
     memset(&sa, 0, sizeof(sa));
@@ -227,7 +230,7 @@ extern "C" int tum_ocp_snmpc_attach(tum_ocp *c, int ns, int L, const double *Apc
     sa.kappa = std::sqrt((1.0 - gamma) / gamma);      // SNMPC_acados_settings.py:187
     sa.mp = c->ka.mp;
     sa.X = c->dX; sa.U = c->dU; sa.XS = c->dXS; sa.xs0 = c->dxs0; sa.Apce = c->dApce; sa.ws2 = c->dws2; sa.pro = c->dpro;
-    sa.dv = c->ddv; sa.dv_stride = NVP; sa.status = c->dstatus;
+    sa.dv = c->ddv; sa.dv_stride = NVP; sa.status = c->dstatus; sa.xs_dirty = c->dxs_dirty;
     sa.dbg = c->ddbg + 20000;                            // tail of instance 0's dump area (tum_ocp_debug_dump), unused by the fused kernel
     c->ka.uph = uph; c->ka.pro = c->dpro; c->ka.dv = c->ddv;
     c->sn = true;
@@ -266,6 +269,17 @@ static int sn_set_p(tum_ocp *c, int stage, const double *v, int len, int nb, int
     c->p_dirty = true;
     return 0;
 }
+// the epilogue leaves the sample copies of the stages > uph for later (snmpc_epilogue_kernel); this brings them up to date
+static int sn_materialise(tum_ocp *c)
+{
+    if (!c->sn || !c->xs_lazy) return 0;
+    DevGuard guard(c->d.device);
+    hipLaunchKernelGGL(snmpc_freeze_kernel, dim3(c->batch), dim3(256), 0, c->stream, c->dXS, c->dxs_dirty, c->N, c->sa.ns, c->sa.uph, c->batch);
+    HIPCHK(hipGetLastError());
+    c->xs_lazy = false;
+    return 0;
+}
+
 // resolve the per-stage parameters into (uph, kappa) before a solve
 static int sn_apply_p(tum_ocp *c)
 {
@@ -290,6 +304,7 @@ static int sn_apply_p(tum_ocp *c)
         c->uph_cap = uph; c->sa.ws2 = c->dws2; c->sa.pro = c->dpro; c->ka.pro = c->dpro;
     }
     if (uph != c->sa.uph) {
+        if (sn_materialise(c)) return 1;          // (the frozen copies belong to the horizon they were solved with)
         // the prologue only writes the live columns of a stage (2k+3 of them) and relies on the rest of its hand-over
         // buffers being zero; the per-instance stride of both buffers depends on uph, so a new horizon starts from zeros
         DevGuard guard(c->d.device);
@@ -370,6 +385,7 @@ extern "C" int tum_ocp_set(tum_ocp *c, int stage, const char *field, const doubl
         if (c->sn && len == NX * (c->sa.ns + 1)) {   // stacked state: nominal copy, then the sample copies (SNMPC_class.py:126-127)
             if (stride != 0 && stride < len) return fail("stride < len");
             const int ns = c->sa.ns;
+            if (stage > c->sa.uph && sn_materialise(c)) return 1;
             if (put(c, c->dX, (N + 1) * NX, (size_t)stage * NX, v, NX, b0, nb, stride)) return 1;
             return put(c, c->dXS, (size_t)(N + 1) * ns * NX, (size_t)stage * ns * NX, v + NX, ns * NX, b0, nb, stride);
         }
@@ -407,6 +423,7 @@ extern "C" int tum_ocp_get(tum_ocp *c, int stage, const char *field, double *v, 
         if (c->sn && stage >= 0 && stage <= N && len == NX * (c->sa.ns + 1)) {
             const int ns = c->sa.ns;
             if (stride < len) return fail("stride < len");
+            if (stage > c->sa.uph && sn_materialise(c)) return 1;
             if (fetch(c, c->dX, (N + 1) * NX, (size_t)stage * NX, v, NX, b0, nb, stride)) return 1;
             return fetch(c, c->dXS, (size_t)(N + 1) * ns * NX, (size_t)stage * ns * NX, v + NX, ns * NX, b0, nb, stride);
         }
@@ -587,7 +604,7 @@ static int launch_pipeline(tum_ocp *c, bool events)
             hipLaunchKernelGGL((expand_kernel<NTv, true>), dim3(c->batch), dim3(64), 0, c->stream, pa);
             SnArgs sa = c->sa;
             sa.dv = c->dvec + PD<NTv>::PV_DV; sa.dv_stride = PD<NTv>::PVEC;
-            hipLaunchKernelGGL(snmpc_epilogue_kernel, dim3(c->batch), dim3(64), 0, c->stream, sa);
+            hipLaunchKernelGGL(snmpc_epilogue_kernel, dim3(c->batch), dim3(64), 0, c->stream, sa); c->xs_lazy = true;
         } else hipLaunchKernelGGL((expand_kernel<NTv, false>), dim3(c->batch), dim3(64), 0, c->stream, pa);
     };
     if (c->N > NMAX) rest(std::integral_constant<int, 6>()); else rest(std::integral_constant<int, 5>());
@@ -612,7 +629,7 @@ static int launch(tum_ocp *c, bool events = true)
         hipLaunchKernelGGL(snmpc_prologue_kernel, dim3(c->batch), dim3(64), sizeof(double) * sn_prologue_lds_doubles(c->sa.uph, c->sa.ns),
                            c->stream, c->sa);
         if (prof) fused(nmpc_rti_kernel<true, true>); else fused(nmpc_rti_kernel<false, true>);
-        hipLaunchKernelGGL(snmpc_epilogue_kernel, dim3(c->batch), dim3(64), 0, c->stream, c->sa);
+        hipLaunchKernelGGL(snmpc_epilogue_kernel, dim3(c->batch), dim3(64), 0, c->stream, c->sa); c->xs_lazy = true;
     }
     else { if (prof) fused(nmpc_rti_kernel<true>); else fused(nmpc_rti_kernel<false>); }
     HIPCHK(hipGetLastError());
@@ -715,6 +732,7 @@ extern "C" int tum_ocp_reset(tum_ocp *c)
     HIPCHK(hipMemsetAsync(c->dX, 0, sizeof(double) * (size_t)c->batch * (c->N + 1) * NX, c->stream));
     HIPCHK(hipMemsetAsync(c->dU, 0, sizeof(double) * (size_t)c->batch * c->N * NU, c->stream));
     if (c->sn) HIPCHK(hipMemsetAsync(c->dXS, 0, sizeof(double) * (size_t)c->batch * (c->N + 1) * c->sa.ns * NX, c->stream));
+    if (c->sn) { HIPCHK(hipMemsetAsync(c->dxs_dirty, 0, sizeof(int) * (size_t)c->batch, c->stream)); c->xs_lazy = false; }
     HIPCHK(hipStreamSynchronize(c->stream));
     return 0;
 }
@@ -726,6 +744,7 @@ extern "C" int tum_ocp_cold_start(tum_ocp *c)
     hipLaunchKernelGGL(cold_start_kernel, dim3(c->batch), dim3(64), 0, c->stream, c->dX, c->dU, c->dx0, c->N, c->batch);
     if (c->sn && c->fanout && sn_fanout(c)) return 1;
     if (c->sn) hipLaunchKernelGGL(snmpc_cold_start_kernel, dim3(c->batch), dim3(256), 0, c->stream, c->dXS, c->dxs0, c->N, c->sa.ns, c->batch);
+    if (c->sn) { HIPCHK(hipMemsetAsync(c->dxs_dirty, 0, sizeof(int) * (size_t)c->batch, c->stream)); c->xs_lazy = false; }
     HIPCHK(hipGetLastError());
     return 0;
 }
