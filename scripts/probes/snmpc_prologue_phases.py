@@ -16,4 +16,4 @@ for N, uph in ((40, 5), (40, 15)):
     s.constraints_set(0, "lbx", X0.reshape(B, -1)); s.constraints_set(0, "ubx", X0.reshape(B, -1))
     s.set_yref_all(yref); s.cold_start(); s.solve(); s.cold_start()
     d = s.debug_dump(0)
-    print(N, uph, "prologue cycles P1, P2+def, P3:", d[20000:20003])
+    print(N, uph, "prologue kernel cycles: load of the gg values (the linearisation is snmpc_lin_kernel), P2 + defect, P3:", d[20000:20003])

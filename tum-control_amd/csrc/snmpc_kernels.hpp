@@ -12,8 +12,10 @@
 //   * from stage uph on the samples are frozen and never read again: the nominal recursion of the fused kernel takes
 //     over from G_nom,uph;
 //   * at stage s the sample matrices G^(i)_s only have 2s <= 2 uph non-zero columns.
-// So the solve is three launches on one stream:
-//   snmpc_prologue_kernel   sample stages: linearise ns*uph RK4 steps (lane = (stage, sample)), PCE weights of the chance
+// So the solve is these launches on one stream:
+//   snmpc_lin_kernel        sample stages: one RK4 step with sensitivities and the gg value / gradient per (instance, stage,
+//                           sample) item, lane = item (full wavefronts; the register-heavy part, one wavefront per SIMD)
+//   snmpc_prologue_kernel   one wavefront per OCP, register-light (several wavefronts per SIMD): PCE weights of the chance
 //                           rows, column recursions of all samples (lane = (sample, column slot)), hands G_nom,s, g_nom,s
 //                           and the chance-constraint rows of the stages 1..uph to the fused kernel through `pro`
 //   nmpc_rti_kernel<.,true> the fused kernel: cost rows / gg rows / Hessian of stages <= uph from `pro`, nominal recursion
@@ -41,6 +43,7 @@ struct SnArgs {
     const double *xs0;        // [b][ns][8]      initial condition of the samples (lbx_0 = ubx_0)
     const double *Apce;       // [L][ns]         PCE matrix (SNMPC_class.py:124), shared by the batch
     double *ws2;              // [b][uph*ns][ABS] sample linearisation records
+    double *gh;               // [b][uph*ns][5]   gg value and its gradient (vl, vt, r, a) per (stage, sample) item
     double *pro;              // [b][uph][SN_PRO_STAGE]
     const double *dv;         // [b][dv_stride]  QP solution of the fused kernel / of the pipeline's interior point kernel (epilogue)
     int dv_stride;
@@ -78,6 +81,49 @@ __host__ __device__ inline int sn_prologue_lds_doubles(int uph, int ns)
            SN_LMAX * SN_NSMAX + uph * SN_LMAX;
 }
 
+// K-S1: linearisation of the sample stages. lane = (instance, stage k < uph, sample) item; the 64 records of a wavefront are
+// one contiguous block of ws2 and go out transposed through LDS (416 contiguous bytes per store instruction instead of 64
+// scattered 8-byte stores), like lin_kernel's.
+__global__ void __launch_bounds__(64, 1) snmpc_lin_kernel(const SnArgs sa)
+{
+    __shared__ double sT[64 * ABS];
+    const int N = sa.N, ns = sa.ns, nitem = sa.uph * ns;
+    const long long total = (long long)sa.batch * nitem;
+    const long long g0 = (long long)blockIdx.x * 64, gl = g0 + threadIdx.x;
+    const bool live = gl < total;
+    const long long g = live ? gl : total - 1;          // (lanes beyond the last item shadow it and store nothing)
+    const int b = (int)(g / nitem), item = (int)(g - (long long)b * nitem);
+    const int k = item / ns, i = item - k * ns;
+    const double *gXS = sa.XS + (size_t)b * (N + 1) * ns * NX;
+    const double *gU = sa.U + (size_t)b * N * NU;
+    const double *xp = gXS + ((size_t)k * ns + i) * NX;
+    double xk[8], uk[2] = {gU[2 * k], gU[2 * k + 1]};
+#pragma unroll
+    for (int r = 0; r < 8; r++) xk[r] = xp[r];
+    double xn[8], Sp[2], S[6][7];
+    rk4_sens(sa.mp, xk, uk, sa.dt, 1, xn, Sp, S);
+    double *rec = sT + threadIdx.x * ABS;
+    rec[0] = Sp[0]; rec[1] = Sp[1];
+#pragma unroll
+    for (int r = 0; r < 6; r++)
+#pragma unroll
+        for (int c = 0; c < 7; c++) rec[2 + r * 7 + c] = S[r][c];
+    const double *xq = gXS + ((size_t)(k + 1) * ns + i) * NX;
+#pragma unroll
+    for (int r = 0; r < 8; r++) rec[44 + r] = xn[r] - xq[r];
+    double h = 0.0, g3 = 0.0, g4 = 0.0, g5 = 0.0, g7 = 0.0;
+    if (k >= 1) h_con_vabs(sa.mp, xk[3], xk[4], xk[5], xk[7], h, g3, g4, g5, g7);
+    if (live) {
+        double *gh = sa.gh + (size_t)g * 5;
+        gh[0] = h; gh[1] = g3; gh[2] = g4; gh[3] = g5; gh[4] = g7;
+    }
+    wsync();
+    double *dst = sa.ws2 + (size_t)g0 * ABS;
+    const int nit = (int)((total - g0 < 64) ? (total - g0) : 64);
+    for (int it = 0; it < nit; it++)
+        if ((int)threadIdx.x < 52) dst[(size_t)it * ABS + threadIdx.x] = sT[it * ABS + threadIdx.x];
+}
+
 __global__ void __launch_bounds__(64) snmpc_prologue_kernel(const SnArgs sa)
 {
     extern __shared__ __attribute__((aligned(16))) double sn_lds[];
@@ -96,30 +142,15 @@ __global__ void __launch_bounds__(64) snmpc_prologue_kernel(const SnArgs sa)
     double *pro = sa.pro + (size_t)b * uph * SN_PRO_STAGE;
 
     const long long t0 = __builtin_readcyclecounter();
-    // ---- P1: one RK4 step with sensitivities per (stage, sample); chance-constraint terms of the sample
-    for (int item = lane; item < nitem; item += 64) {
-        const int k = item / ns, i = item - k * ns;
-        const double *xp = gXS + ((size_t)k * ns + i) * NX;
-        double xk[8], uk[2] = {gU[2 * k], gU[2 * k + 1]};
-#pragma unroll
-        for (int r = 0; r < 8; r++) xk[r] = xp[r];
-        double xn[8], Sp[2], S[6][7];
-        rk4_sens(sa.mp, xk, uk, dt, 1, xn, Sp, S);
-        double *rec = ws2 + (size_t)item * ABS;
-        rec[0] = Sp[0]; rec[1] = Sp[1];
-#pragma unroll
-        for (int r = 0; r < 6; r++)
-#pragma unroll
-            for (int c = 0; c < 7; c++) rec[2 + r * 7 + c] = S[r][c];
-        const double *xq = gXS + ((size_t)(k + 1) * ns + i) * NX;
-#pragma unroll
-        for (int r = 0; r < 8; r++) rec[44 + r] = xn[r] - xq[r];
-        double h = 0.0, g3 = 0.0, g4 = 0.0, g5 = 0.0, g7 = 0.0;
-        if (k >= 1) h_con_vabs(sa.mp, xk[3], xk[4], xk[5], xk[7], h, g3, g4, g5, g7);
-        sH[item] = h;
-        sGh[item * 4 + 0] = g3; sGh[item * 4 + 1] = g4; sGh[item * 4 + 2] = g5; sGh[item * 4 + 3] = g7;
+    // ---- P1 (snmpc_lin_kernel, launched before this kernel): records in ws2, gg values and gradients in gh
+    {
+        const double *gh = sa.gh + (size_t)b * nitem * 5;
+        for (int o = lane; o < nitem * 5; o += 64) {
+            const int item = o / 5, c = o - item * 5;
+            const double v = gh[o];
+            if (c == 0) sH[item] = v; else sGh[item * 4 + c - 1] = v;
+        }
     }
-    __threadfence_block();      // the records are read back by other lanes below
     __syncthreads();
     const long long t1 = __builtin_readcyclecounter();
 

@@ -216,7 +216,7 @@ extern "C" int tum_ocp_snmpc_attach(tum_ocp *c, int ns, int L, const double *Apc
     ok &= dalloc(&c->dXS, B * (N + 1) * ns * NX) == hipSuccess;
     ok &= dalloc(&c->dxs0, B * ns * NX) == hipSuccess;
     ok &= dalloc(&c->dApce, (size_t)L * ns) == hipSuccess;
-    ok &= dalloc(&c->dws2, B * (size_t)(uph > 0 ? uph : 1) * ns * ABS) == hipSuccess;
+    ok &= dalloc(&c->dws2, B * (size_t)(uph > 0 ? uph : 1) * ns * (ABS + 5)) == hipSuccess;      // records, then the gg values / gradients
     ok &= dalloc(&c->dpro, B * (size_t)(uph > 0 ? uph : 1) * SN_PRO_STAGE) == hipSuccess;
     ok &= dalloc(&c->ddv, B * NVP) == hipSuccess;
     ok &= dalloc(&c->doffs, (size_t)ns * NX) == hipSuccess;
@@ -230,6 +230,7 @@ extern "C" int tum_ocp_snmpc_attach(tum_ocp *c, int ns, int L, const double *Apc
     sa.kappa = std::sqrt((1.0 - gamma) / gamma);      // SNMPC_acados_settings.py:187
     sa.mp = c->ka.mp;
     sa.X = c->dX; sa.U = c->dU; sa.XS = c->dXS; sa.xs0 = c->dxs0; sa.Apce = c->dApce; sa.ws2 = c->dws2; sa.pro = c->dpro;
+    sa.gh = c->dws2 + B * (size_t)(uph > 0 ? uph : 1) * ns * ABS;
     sa.dv = c->ddv; sa.dv_stride = NVP; sa.status = c->dstatus; sa.xs_dirty = c->dxs_dirty;
     sa.dbg = c->ddbg + 20000;                            // tail of instance 0's dump area (tum_ocp_debug_dump), unused by the fused kernel
     c->ka.uph = uph; c->ka.pro = c->dpro; c->ka.dv = c->ddv;
@@ -269,6 +270,13 @@ static int sn_set_p(tum_ocp *c, int stage, const double *v, int len, int nb, int
     c->p_dirty = true;
     return 0;
 }
+// linearisation of the sample stages (K-S1), in front of the prologue kernel
+static void sn_launch_lin(tum_ocp *c)
+{
+    const long long items = (long long)c->batch * c->sa.uph * c->sa.ns;
+    if (items > 0) hipLaunchKernelGGL(snmpc_lin_kernel, dim3((unsigned)((items + 63) / 64)), dim3(64), 0, c->stream, c->sa);
+}
+
 // the epilogue leaves the sample copies of the stages > uph for later (snmpc_epilogue_kernel); this brings them up to date
 static int sn_materialise(tum_ocp *c)
 {
@@ -299,9 +307,9 @@ static int sn_apply_p(tum_ocp *c)
         HIPCHK(hipStreamSynchronize(c->stream));
         (void)hipFree(c->dws2); (void)hipFree(c->dpro); c->dws2 = c->dpro = nullptr;
         const size_t B = c->batch;
-        if (dalloc(&c->dws2, B * (size_t)uph * ns * ABS) != hipSuccess || dalloc(&c->dpro, B * (size_t)uph * SN_PRO_STAGE) != hipSuccess)
+        if (dalloc(&c->dws2, B * (size_t)uph * ns * (ABS + 5)) != hipSuccess || dalloc(&c->dpro, B * (size_t)uph * SN_PRO_STAGE) != hipSuccess)
             return fail("solve: device allocation failed for the longer uncertainty propagation horizon");
-        c->uph_cap = uph; c->sa.ws2 = c->dws2; c->sa.pro = c->dpro; c->ka.pro = c->dpro;
+        c->uph_cap = uph; c->sa.ws2 = c->dws2; c->sa.gh = c->dws2 + B * (size_t)uph * ns * ABS; c->sa.pro = c->dpro; c->ka.pro = c->dpro;
     }
     if (uph != c->sa.uph) {
         if (sn_materialise(c)) return 1;          // (the frozen copies belong to the horizon they were solved with)
@@ -585,6 +593,7 @@ static int launch_pipeline(tum_ocp *c, bool events)
     const long long items = (long long)c->batch * (c->N + 1);
     if (c->sn) {   // coupled SNMPC OCP: sample fan-out and prologue first, the QP solution goes to the epilogue through the workspace
         if (c->fanout && sn_fanout(c)) return 1;
+        sn_launch_lin(c);
         hipLaunchKernelGGL(snmpc_prologue_kernel, dim3(c->batch), dim3(64), sizeof(double) * sn_prologue_lds_doubles(c->sa.uph, c->sa.ns),
                            c->stream, c->sa);
         hipLaunchKernelGGL(lin_kernel<true>, dim3((unsigned)((items + 63) / 64)), dim3(64), 0, c->stream, pa);
@@ -626,6 +635,7 @@ static int launch(tum_ocp *c, bool events = true)
     if (c->pipe) { if (launch_pipeline(c, events)) return 1; }
     else if (c->sn) {
         if (c->fanout && sn_fanout(c)) return 1;
+        sn_launch_lin(c);
         hipLaunchKernelGGL(snmpc_prologue_kernel, dim3(c->batch), dim3(64), sizeof(double) * sn_prologue_lds_doubles(c->sa.uph, c->sa.ns),
                            c->stream, c->sa);
         if (prof) fused(nmpc_rti_kernel<true, true>); else fused(nmpc_rti_kernel<false, true>);
