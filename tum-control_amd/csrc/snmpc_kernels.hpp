@@ -282,23 +282,40 @@ __global__ void __launch_bounds__(64) snmpc_prologue_kernel(const SnArgs sa)
 // such a stage, a change of uph).
 __global__ void __launch_bounds__(64) snmpc_epilogue_kernel(const SnArgs sa)
 {
+    // the ns records of a stage are contiguous in ws2: all 64 lanes fetch them (coalesced, one stage ahead) and the sample
+    // lanes read theirs from LDS -- a lane reading its own 424-byte record field by field touches ns sectors per load
+    __shared__ double sRec[SN_NSMAX * ABS];
     const int lane = threadIdx.x, b = blockIdx.x;
     if (b >= sa.batch || sa.status[b] != 0) return;
-    const int N = sa.N, ns = sa.ns, uph = sa.uph, i = lane;
+    const int N = sa.N, ns = sa.ns, uph = sa.uph;
     if (lane == 0 && uph < N) sa.xs_dirty[b] = 1;
-    if (i >= ns) return;
+    const bool act = lane < ns;
+    const int i = act ? lane : 0;
     double *gXS = sa.XS + (size_t)b * (N + 1) * ns * NX;
     const double *ws2 = sa.ws2 + (size_t)b * uph * ns * ABS;
     const double *dv = sa.dv + (size_t)b * sa.dv_stride;
+    const int nrec = ns * ABS;
+    constexpr int NCH = (SN_NSMAX * ABS + 63) / 64;
+    double pre[NCH];
+#pragma unroll
+    for (int c = 0; c < NCH; c++) { const int idx = lane + 64 * c; pre[c] = (uph > 0 && idx < nrec) ? ws2[idx] : 0.0; }
     double dx[8];
 #pragma unroll
     for (int r = 0; r < 8; r++) {
         const double x = gXS[(size_t)i * NX + r];
         dx[r] = sa.xs0[((size_t)b * ns + i) * NX + r] - x;
-        gXS[(size_t)i * NX + r] = x + dx[r];
+        if (act) gXS[(size_t)i * NX + r] = x + dx[r];
     }
     for (int k = 0; k < uph; k++) {
-        const double *rec = ws2 + (size_t)(k * ns + i) * ABS;
+        wsync();
+#pragma unroll
+        for (int c = 0; c < NCH; c++) { const int idx = lane + 64 * c; if (idx < nrec) sRec[idx] = pre[c]; }
+        wsync();
+        if (k + 1 < uph) {
+#pragma unroll
+            for (int c = 0; c < NCH; c++) { const int idx = lane + 64 * c; pre[c] = (idx < nrec) ? ws2[(size_t)(k + 1) * nrec + idx] : 0.0; }
+        }
+        const double *rec = sRec + i * ABS;
         const double du0 = dv[2 * k], du1 = dv[2 * k + 1];
         apply_A(rec, dx);
 #pragma unroll
@@ -307,8 +324,10 @@ __global__ void __launch_bounds__(64) snmpc_epilogue_kernel(const SnArgs sa)
 #pragma unroll
         for (int r = 0; r < 8; r++) dx[r] += rec[44 + r];
         double *xq = gXS + ((size_t)(k + 1) * ns + i) * NX;
+        if (act) {
 #pragma unroll
-        for (int r = 0; r < 8; r++) xq[r] += dx[r];
+            for (int r = 0; r < 8; r++) xq[r] += dx[r];
+        }
     }
 }
 
