@@ -196,3 +196,23 @@ def test_long_horizon_closed_loops():
     assert (uh < 1.0).all() and (uh > 0.5).all()
     A = cl.solver.get_from_qp_in(46, "A")
     assert A.shape == (5, 8, 8) and np.isfinite(A).all() and np.allclose(A[:, 6, 6], 1.0) and np.allclose(A[:, 7, 7], 1.0)
+
+
+@pytest.mark.gpu
+def test_first_solve_after_a_large_allocation():
+    """65 536 instances: the FIRST solve after the workspaces were allocated and zero-filled. The fill runs on the NULL stream and
+    the solve on the capsule's non-blocking stream; without a wait in between the fill zeroed what the first instances had already
+    handed from kernel to kernel (found with scripts/stress_iters.py: wrong first solves for an eighth of the instances)."""
+    from tum_control_amd.solver import BatchedOcpSolver
+    from tum_control_amd.workloads import nominal_batch
+    B = 65536
+    x0, yref = nominal_batch(B, N=40, track_name="lvms", stride=7, seed=4321)
+    res = {}
+    for k in ("fused", "pipeline"):
+        s = BatchedOcpSolver(N=40, batch=B); s.set_kernel(k)
+        s.install_reference_ocp(); s.set_x0(x0); s.set_yref_all(yref); s.cold_start()
+        assert s.solve() == 0
+        res[k] = (s.get_stats("qp_iter").copy(), s.get_iterate()[1].copy())
+        del s
+    np.testing.assert_array_equal(res["pipeline"][0], res["fused"][0])
+    np.testing.assert_allclose(res["pipeline"][1], res["fused"][1], rtol=0, atol=1e-5)

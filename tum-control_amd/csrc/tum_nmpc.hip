@@ -78,7 +78,17 @@ struct DevTmp {
 };
 
 template <typename T>
-static hipError_t dalloc(T **p, size_t n) { hipError_t e = hipMalloc((void **)p, n * sizeof(T)); if (e == hipSuccess) e = hipMemset(*p, 0, n * sizeof(T)); return e; }
+static hipError_t dalloc(T **p, size_t n)
+{
+    hipError_t e = hipMalloc((void **)p, n * sizeof(T));
+    if (e == hipSuccess) e = hipMemset(*p, 0, n * sizeof(T));
+    // hipMemset on device memory returns before the fill has run, and the fill runs on the NULL stream -- which the capsule's
+    // non-blocking stream does not wait for. Without this wait the first solve after a large allocation races the fill: at
+    // 65 536 instances the fill of the pipeline's 4.4 GB of workspace was still zeroing what the first eighth of the instances
+    // had already handed from kernel to kernel (wrong first solves at batches >= 32 768; scripts/probes/large_batch_variants.py).
+    if (e == hipSuccess) e = hipDeviceSynchronize();
+    return e;
+}
 
 extern "C" tum_ocp *tum_ocp_create(const tum_ocp_desc *desc)
 {
@@ -222,7 +232,7 @@ extern "C" int tum_ocp_snmpc_attach(tum_ocp *c, int ns, int L, const double *Apc
     ok &= dalloc(&c->doffs, (size_t)ns * NX) == hipSuccess;
     if (ok) { (void)hipFree(c->dxs_dirty); c->dxs_dirty = nullptr; ok &= hipMalloc((void **)&c->dxs_dirty, sizeof(int) * B) == hipSuccess; }
     if (!ok) return fail("snmpc_attach: device allocation failed");
-    HIPCHK(hipMemset(c->dxs_dirty, 0, sizeof(int) * B)); c->xs_lazy = false;
+    HIPCHK(hipMemset(c->dxs_dirty, 0, sizeof(int) * B)); HIPCHK(hipDeviceSynchronize()); c->xs_lazy = false;
     HIPCHK(hipMemcpy(c->dApce, Apce, sizeof(double) * L * ns, hipMemcpyHostToDevice));
     SnArgs &sa = c->sa;
     memset(&sa, 0, sizeof(sa));
@@ -1128,6 +1138,7 @@ extern "C" int tum_sim_set_state(tum_sim *s, const double *x_sim, const double *
     HIPCHK(hipMemcpy2D(s->dpose, 2 * 8, x_mpc, 8 * 8, 2 * 8, B, hipMemcpyHostToDevice));
     HIPCHK(hipMemset(s->dhist, 0, sizeof(double) * B * 32));
     HIPCHK(hipMemset(s->dstep, 0, 2 * sizeof(int)));
+    HIPCHK(hipDeviceSynchronize());          // (the fills run on the NULL stream, the loop on the capsule's non-blocking one)
     s->step = 0;
     if (s->log_cap > 0) {
         HIPCHK(hipMemcpy(s->lCiLX, x_sim, sizeof(double) * B * 7, hipMemcpyHostToDevice));
