@@ -485,8 +485,7 @@ __global__ void __launch_bounds__(64) expand_kernel(const PArgs pa)
     }; \
     int rb[NT]; \
     _Pragma("unroll") \
-    for (int I = 0; I < NT; I++) rb[I] = lpk(16 * I + lc, 0); \
-    const int lane1 = 64 + (lane & (NB1 - 1));
+    for (int I = 0; I < NT; I++) rb[I] = lpk(16 * I + lc, 0);
 
 #ifndef IPM_WPS
 #define IPM_WPS 1

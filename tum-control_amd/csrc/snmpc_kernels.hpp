@@ -136,7 +136,6 @@ __global__ void __launch_bounds__(64) snmpc_prologue_kernel(const SnArgs sa)
     double *sA = sW + sn_prologue_passes(uph, ns) * 8 * 64, *sC = sA + SN_LMAX * SN_NSMAX;
     const double dt = sa.dt;
     const double *gX = sa.X + (size_t)b * (N + 1) * NX;
-    const double *gU = sa.U + (size_t)b * N * NU;
     const double *gXS = sa.XS + (size_t)b * (N + 1) * ns * NX;
     double *ws2 = sa.ws2 + (size_t)b * uph * ns * ABS;
     double *pro = sa.pro + (size_t)b * uph * SN_PRO_STAGE;
