@@ -719,6 +719,7 @@ extern "C" int tum_ocp_get_cost(tum_ocp *c, double *out, int b0, int nb)
 {
     if (chk_range(c, b0, nb)) return 1;
     DevGuard guard(c->d.device);
+    HIPCHK(hipStreamSynchronize(c->stream));        // (the copy below runs on the NULL stream, which the capsule's non-blocking stream is not ordered with)
     HIPCHK(hipMemcpy(out, c->dcost + b0, sizeof(double) * nb, hipMemcpyDeviceToHost));
     return 0;
 }
@@ -737,6 +738,7 @@ extern "C" int tum_ocp_get_stats(tum_ocp *c, const char *field, void *out, int b
     }
     if (chk_range(c, b0, nb)) return 1;
     DevGuard guard(c->d.device);
+    HIPCHK(hipStreamSynchronize(c->stream));        // (after tum_ocp_solve_async: the copies below are on the NULL stream)
     if (f == "sqp_iter") { int *o = (int *)out; for (int i = 0; i < nb; i++) o[i] = 1; return 0; }
     if (f == "qp_iter") { HIPCHK(hipMemcpy(out, c->dqpiter + b0, sizeof(int) * nb, hipMemcpyDeviceToHost)); return 0; }
     if (f == "status") { HIPCHK(hipMemcpy(out, c->dstatus + b0, sizeof(int) * nb, hipMemcpyDeviceToHost)); return 0; }
