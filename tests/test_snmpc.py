@@ -410,6 +410,44 @@ def test_gpu_snmpc_frozen_sample_copies_are_deferred_not_lost():
 
 
 @pytest.mark.gpu
+def test_gpu_snmpc_longer_horizon_after_deferred_freeze():
+    """A warm solve with a LONGER uncertainty propagation horizon reads sample copies of stages the previous solves left
+    to be frozen later: the change of uph must bring them up to date first. Reference: a second capsule, attached with the
+    longer horizon, that is handed the first one's complete iterate (every stage read back, i.e. frozen copies included)."""
+    from tum_control_amd.solver import CoupledSnmpcSolver
+    from tum_control_amd.workloads import nominal_batch
+    snm, stds, w, A = _pce()
+    N, ns, B = 38, 10, 4
+    x0, yref = nominal_batch(B, N=N, seed=21)
+    off = snm.x0_offsets(w, stds)
+
+    def warm(uph0):
+        s = CoupledSnmpcSolver(N=N, batch=B, Apce=A, uph=uph0, gamma=0.8, x0_offsets=off)
+        s.install_reference_ocp(); s.set_x0(x0); s.set_yref_all(yref); s.cold_start()
+        assert s.solve() == 0 and s.solve() == 0
+        return s
+
+    def setp(s, uph):
+        for k in range(N + 1):
+            s.set(k, "p", np.concatenate([A.flatten(), [0.8], [1.0 if k >= uph else 0.0]]))
+
+    a = warm(5); setp(a, 9)
+    assert a.solve() == 0                                   # stages 6..9 of the samples: frozen copies of the uph = 5 solves
+    b = warm(5)
+    stacked = [np.atleast_2d(b.get(k, "x")).copy() for k in range(N + 1)]
+    U = b.get_iterate()[1].copy()
+    c = CoupledSnmpcSolver(N=N, batch=B, Apce=A, uph=9, gamma=0.8, x0_offsets=off)
+    c.install_reference_ocp(); c.set_x0(x0); c.set_yref_all(yref); c.cold_start()
+    for k in range(N + 1):
+        c.set(k, "x", stacked[k])
+    c.set_iterate(U=U)
+    assert c.solve() == 0
+    np.testing.assert_array_equal(a.get_iterate()[1], c.get_iterate()[1])
+    for k in (0, 5, 9, N):
+        np.testing.assert_array_equal(np.atleast_2d(a.get(k, "x")), np.atleast_2d(c.get(k, "x")))
+
+
+@pytest.mark.gpu
 def test_gpu_snmpc_controller_mirror(golden_dir):
     """the SNMPC_class.py mirror drives the coupled solver like the reference's controller does"""
     from tum_control_amd.snmpc import Stochastic_Nonlinear_Model_Predictive_Controller as C
