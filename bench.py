@@ -2,7 +2,7 @@
 """
 bench.py -- SQP-RTI OCP solves/sec on synthetic batches (BASELINE.json metric).
 
-  python bench.py [--config {2,3,4,5}] --gpus N --steps K --warmup W
+  python bench.py [--config {2,3,4,5}] [--scaling {weak,strong}] --gpus N --steps K --warmup W
   (N > 1: launched by torch.distributed.run, one rank per GPU; the batch is sharded by scenario GROUP, every rank solves
    its own share, and the result slab is gathered to rank 0 over RCCL each step: one collective per step.)
 
@@ -14,8 +14,19 @@ A "step" = one pass of the hot path over one batch, inputs resident in HBM befor
   config 4 (configs[3]): 16384 Monte-Carlo scenarios per GPU (131072 over 8 GPUs), LVMS, cold start + SQP-RTI;
   config 5 (configs[4]): 4096 R2NMPC instances per GPU (32768 over 8), Modena: nominal bounds, cold start, SQP-RTI,
            covariance back-off (K7), SQP-RTI with the tightened bounds (2 solves per step).
-Prints ONE JSON line on rank 0. At N=1 the line also carries the natural-order and the fresh-batch figures of the schedule
- and the CPU baseline (the oracle on the host cores).
+
+`value` is the FRESH-BATCH throughput: NB differently seeded batches of the workload are resident in HBM and rotated, one per
+step, so no step sees a batch the solver has just solved (what a caller with new data every step gets). The repeated-batch
+figure (the same batch every step: the longest-first dispatch then has exact history) and the natural-order figure are
+reported next to it at N = 1 (`value_repeated_batch`, `config.kernel_ms_natural_order`).
+
+--scaling weak (default): every rank owns the config's per-GPU share (global batch = N x share).
+--scaling strong: a fixed global batch (--global-batch, default 8 x the per-GPU share = the BASELINE multi-GPU size of
+                  configs 4 / 5) is cut into N group-aligned shards.
+
+Prints ONE JSON line on rank 0. At N = 1 the line also carries the CPU baseline (the oracle on the host cores).
+The control flow below (`run`) is backend-agnostic: tests/test_host_logic.py drives it on CPU with gloo, world size 2 and a
+stand-in solver.
 """
 import argparse
 import json
@@ -31,6 +42,7 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBPS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 FP64_PEAK_TFLOPS = 78.6      # MI355X FP64 vector = matrix peak (spec); v_mfma_f64_16x16x4 probe: 70.2 measured
+NB_FRESH = 4                 # resident batches rotated by the timed loop
 
 
 def algorithmic_bytes(N, warm=False, per_instance_yref=True):
@@ -41,16 +53,19 @@ def algorithmic_bytes(N, warm=False, per_instance_yref=True):
     return 8 * (rd + wr)
 
 
+def ipm_flops_per_iter(N):
+    nv, ng = 2 * N, 2 * N
+    return ng * nv * nv + nv ** 3 / 3.0 + 6 * nv * nv + 4 * ng * nv
+
+
 def algorithmic_flops(N, nsub, qp_iter):
     """SURVEY.md 8(d) formulas (FMA = 2 FLOP)."""
     nx, nu = 8, 2
-    nv, ng = nu * N, 2 * N
     dyn = 4 * nsub * N * (250 + 350 + 2 * nx * nx * (nx + nu))
     condG = 128 * N * (N + 1)
     condH = 16 * N ** 3 / 3.0
     condC = 2 * 2 * nx * nu * N * (N + 1) / 2.0
-    ipm = ng * nv * nv + nv ** 3 / 3.0 + 6 * nv * nv + 4 * ng * nv
-    return dyn + condG + condH + condC + qp_iter * ipm
+    return dyn + condG + condH + condC + qp_iter * ipm_flops_per_iter(N)
 
 
 def usable_cores():
@@ -112,18 +127,286 @@ def cpu_baseline(N, x0, yref, cfg, budget_s=15.0):
                 single_thread=single), um[:ns1] if nsm >= ns1 else u1
 
 
-def main():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--config", type=int, default=2, choices=(2, 3, 4, 5), help="BASELINE.json configs[config-1]")
-    ap.add_argument("--batch", type=int, default=None, help="instances per GPU (default: the config's per-GPU share)")
+    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak")
+    ap.add_argument("--global-batch", type=int, default=None,
+                    help="--scaling strong: instances of the whole job (default: 8 x the config's per-GPU share)")
+    ap.add_argument("--batch", type=int, default=None, help="instances per GPU (weak scaling; default: the config's per-GPU share)")
     ap.add_argument("--horizon", type=int, default=40)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-schedule-legs", action="store_true", help="skip the natural-order and fresh-batch legs (N=1 only)")
-    args = ap.parse_args()
+    ap.add_argument("--no-schedule-legs", action="store_true",
+                    help="skip the repeated-batch, natural-order and N = 38 legs (N=1 only)")
+    return ap.parse_args(argv)
 
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Timing primitives: HIP events on the current torch stream on a GPU, the host clock on CPU (the gloo test).
+class _Clock:
+    def __init__(self, torch, cuda):
+        self.torch, self.cuda = torch, cuda
+
+    def mark(self):
+        if self.cuda:
+            e = self.torch.cuda.Event(enable_timing=True); e.record(); return e
+        return time.perf_counter()
+
+    def ms(self, a, b):
+        return a.elapsed_time(b) if self.cuda else 1e3 * (b - a)
+
+    def sync(self):
+        if self.cuda:
+            self.torch.cuda.synchronize()
+
+
+class Job:
+    """One rank's share of the benchmark job: solver, resident batches, the step (cold start, solve(s), reduction, gather) and
+    the timed loop with its barrier / max-over-ranks protocol. Nothing here depends on the backend: `solver_factory`, `dev`
+    and the process group decide whether this is RCCL on GPUs or the CPU stand-in of the tests."""
+
+    def __init__(self, args, torch, dist, dev, world, rank, local_rank, solver_factory, workload=None):
+        from tum_control_amd import sharding
+        from tum_control_amd.workloads import CONFIGS, config_groups
+        self.args, self.torch, self.dist, self.dev = args, torch, dist, dev
+        self.world, self.rank = world, rank
+        self.distributed = dist is not None and dist.is_initialized()
+        self.cuda = dev.type == "cuda"
+        self.clock = _Clock(torch, self.cuda)
+        N, cid = args.horizon, args.config
+        self.N, self.cid = N, cid
+        C = self.C = CONFIGS[cid]
+        gsz = self.gsz = C["group"]
+        share = C["groups_per_gpu"] if args.batch is None else max(1, args.batch // gsz)
+        if args.scaling == "strong":
+            gb = args.global_batch if args.global_batch is not None else 8 * C["groups_per_gpu"] * gsz
+            if gb % gsz:
+                raise SystemExit(f"--global-batch must be a multiple of the scenario group size {gsz}")
+            groups_total = gb // gsz
+            if groups_total < world:
+                raise SystemExit("--global-batch: fewer scenario groups than ranks")
+        else:
+            groups_total = world * share
+        self.groups_total = groups_total
+        # contiguous block of the global group range: a group never straddles two ranks
+        self.g_lo, self.g_hi, b_lo, b_hi = sharding.shard_groups(groups_total, gsz, world, rank)
+        B = self.B = b_hi - b_lo
+        P = self.P = self.g_hi - self.g_lo
+        self.global_batch = groups_total * gsz
+        gen = workload or (lambda k: config_groups(cid, self.g_lo, self.g_hi, groups_total, N=N, dt=0.08, variant=k))
+        # batch 0 = the configuration as BASELINE defines it, batches 1.. = fresh variants of it (other poses, other random streams)
+        self.host = [gen(k)[:2] for k in range(NB_FRESH + 1)]
+        x0, yref = self.host[0]
+        assert len(x0) == B
+        s = self.s = solver_factory(N=N, dt=0.08, nsub=3, batch=B, device=local_rank, store_qp_in=(cid == 5))
+        s.install_reference_ocp()
+        s.set_x0(x0); s.set_yref_all(yref)
+        if self.cuda:
+            s.set_stream(torch.cuda.current_stream().cuda_stream)
+        self.nmom = 0
+        if cid == 3:      # PCE matrix of the 15 Hammersley sigma points (10 terms): K6 runs inside the step
+            from tum_control_amd.snmpc import alpha_generation, hammersley_normal, pce_matrix
+            s.pce_attach(pce_matrix(hammersley_normal(15, 3), alpha_generation(3, 2)))
+            self.nmom = 16
+        if cid == 5:      # covariance back-off attached to every solve (K7), nominal bounds restored at the start of a step
+            from tum_control_amd.r2nmpc import r2_setup
+            m, veh = s.cfg["mpc"], s.cfg["veh"]
+            S0, BWB = r2_setup(m["stds"], 0.08)
+            s.r2_attach(S0, BWB, int(m["uncertainty_propagation_horizon"]), veh["delta_f_min"], veh["delta_f_max"], 1.0)
+            s.bounds_snapshot()
+        self.spp = C["solves_per_step"]
+        # result slab gathered to rank 0 each step: (u0[2], cost, status, qp_iter) as 5 doubles per instance, for config 3
+        # followed by the PCE mean / variance of x_1 of every scenario group (16 doubles per group): ONE flat buffer, packed
+        # on the device by the library, moved with ONE rooted gather. Shards of a strong-scaling job may differ by one group:
+        # every rank sends the size of the LARGEST shard (the tail is padding).
+        self.slab_len = B * 5 + P * self.nmom
+        mx = max((sharding.shard_range(groups_total, world, r)[1] - sharding.shard_range(groups_total, world, r)[0]) for r in range(world))
+        self.slab_pad = mx * gsz * 5 + mx * self.nmom
+        self.slab = torch.zeros(self.slab_pad, dtype=torch.float64, device=dev)
+        self.mom_ptr = self.slab.data_ptr() + 8 * B * 5
+        self.gather = sharding.ResultGatherer(world, rank, 1, dev, nf=self.slab_pad, ni=1) if self.distributed else None
+        # resident copies of the rotated batches
+        self.dx0 = [torch.from_numpy(np.ascontiguousarray(h[0])).to(dev) for h in self.host[1:]]
+        self.dyr = [torch.from_numpy(np.ascontiguousarray(h[1])).to(dev) for h in self.host[1:]]
+
+    # ---- one step; `marks`: list that receives (solve_begin, solve_end)* and (gather_begin, gather_end) clock marks
+    def step(self, marks=None, fresh=None):
+        s, cid = self.s, self.cid
+        if fresh is not None:
+            k = fresh % NB_FRESH
+            s.put_device("x0", self.dx0[k].data_ptr()); s.put_device("yref", self.dyr[k].data_ptr())
+        if cid == 5:
+            s.bounds_restore()
+        s.cold_start()
+        for _ in range(self.spp):
+            if marks is not None:
+                marks.append(self.clock.mark())
+            s.solve_async()
+            if marks is not None:
+                marks.append(self.clock.mark())
+        if cid == 3:
+            s.pce_moments_device("x", 1, self.mom_ptr, self.mom_ptr + 8 * self.P * 8)
+        if self.gather is not None:
+            if marks is not None:
+                marks.append(self.clock.mark())
+            s.get_device("summary", self.slab.data_ptr())
+            self.gather.gather(self.slab.view(1, -1))
+            if marks is not None:
+                marks.append(self.clock.mark())
+
+    def barrier(self):
+        if self.distributed:
+            self.dist.barrier()
+        self.clock.sync()
+
+    def timed(self, steps, fresh):
+        """EXACTLY `steps` steps between two barriers (+ device sync); returns (max-over-ranks seconds, per-step marks)."""
+        self.barrier()
+        marks = [[] for _ in range(steps)]
+        t0 = time.perf_counter()
+        for i in range(steps):
+            self.step(marks[i], fresh=(i if fresh else None))
+        self.barrier()
+        elapsed = time.perf_counter() - t0
+        if self.distributed:
+            tt = self.torch.tensor([elapsed], dtype=self.torch.float64, device=self.dev)
+            self.dist.all_reduce(tt, op=self.dist.ReduceOp.MAX)
+            elapsed = float(tt.item())
+        return elapsed, marks
+
+    def solve_ms(self, marks):
+        spp = self.spp
+        return float(np.mean([self.clock.ms(m[2 * j], m[2 * j + 1]) for m in marks for j in range(spp)]))
+
+    def gather_ms(self, marks):
+        if self.gather is None:
+            return None
+        return float(np.mean([self.clock.ms(m[2 * self.spp], m[2 * self.spp + 1]) for m in marks]))
+
+
+def run(args, torch, dist, dev, world, rank, local_rank, solver_factory, workload=None, extra_legs=True):
+    """The benchmark proper. Returns the result dict on rank 0 (None elsewhere)."""
+    job = Job(args, torch, dist, dev, world, rank, local_rank, solver_factory, workload)
+    s, N, cid, B, spp = job.s, job.N, job.cid, job.B, job.spp
+    for i in range(args.warmup):
+        job.step(fresh=i)
+    elapsed, marks = job.timed(args.steps, fresh=True)
+    kern_ms = job.solve_ms(marks)
+    gat_ms = job.gather_ms(marks)
+    # correctness of what was timed: statuses and iteration counts of the last batch
+    st = s.get_stats("status"); it = s.get_stats("qp_iter")
+    mean_it_fresh = float(it.mean())
+    ok_fresh = float((st == 0).mean())
+
+    rep_value = rep_ms = nat_ms = ipm_ms = n38 = None
+    mean_it = mean_it_fresh
+    U = None
+    if world == 1 and extra_legs and not args.no_schedule_legs:
+        # (a) the SAME batch every step (batch 0): the longest-first order has this batch's exact iteration counts
+        s.set_x0(job.host[0][0]); s.set_yref_all(job.host[0][1])
+        for _ in range(2):
+            job.step()
+        rep_elapsed, rmarks = job.timed(args.steps, fresh=False)
+        rep_ms = job.solve_ms(rmarks)
+        rep_value = B * spp * args.steps / rep_elapsed
+        st0 = s.get_stats("status"); it0 = s.get_stats("qp_iter"); mean_it = float(it0.mean())
+        _, U = s.get_iterate()
+        # the dominant kernel -- the interior point kernel -- timed on its own (library events around it) over five more steps
+        try:
+            tm = []
+            for _ in range(5):
+                job.step(); job.clock.sync(); tm.append(1e3 * s.get_stats("time_ipm"))
+            ipm_ms = float(np.median(tm))
+        except Exception:
+            pass
+        # (b) the same batch with the instances dispatched in natural order
+        s.set_schedule(False)
+        nat = [[] for _ in range(5)]
+        for m in nat:
+            job.step(m)
+        job.clock.sync()
+        nat_ms = float(np.median([job.clock.ms(m[2 * j], m[2 * j + 1]) for m in nat for j in range(spp)]))
+        s.set_schedule(True)
+    elif world == 1:
+        _, U = s.get_iterate()
+
+    if rank != 0:
+        return None
+    C, gsz, P = job.C, job.gsz, job.P
+    total = job.global_batch * spp * args.steps
+    value = total / elapsed
+    shared_yref = gsz > 1
+    abytes = algorithmic_bytes(N, warm=(cid == 5), per_instance_yref=not shared_yref)
+    # roofline of the fresh-batch loop (the timed region): algorithmic FLOPs of the batches it solved / device time of a solve
+    flops = algorithmic_flops(N, 3, mean_it_fresh) * B
+    ach_tf = flops / (kern_ms * 1e-3) / 1e12
+    ach_gb = abytes * B / (kern_ms * 1e-3) / 1e9
+    # HBM bytes per launch from the PMC counters cannot be collected from inside this process; they come from the committed
+    # rocprofv3 --pmc passes of this same command (profiles/*_traffic*.json), only when the workload matches what was profiled.
+    traffic, traffic_src = None, None
+    try:
+        for tj in sorted((f for f in os.listdir(os.path.join(ROOT, "profiles")) if "_traffic" in f and f.endswith(".json")), reverse=True):
+            tr = json.load(open(os.path.join(ROOT, "profiles", tj)))
+            if tr.get("batch") == B and tr.get("N") == N and tr.get("config", 2) == cid:
+                traffic, traffic_src = tr["traffic_bytes_per_launch"], "profiles/" + tj
+                break
+    except Exception:
+        pass
+    dominant = None
+    if ipm_ms:
+        ipm_flops = mean_it * ipm_flops_per_iter(N) * B
+        dominant = {"kernel": "ipm_kernel", "kernel_ms": ipm_ms, "flops_per_launch": ipm_flops, "mean_qp_iter": mean_it,
+                    "workload": "the repeated batch (exact longest-first history)",
+                    "achieved": ipm_flops / (ipm_ms * 1e-3) / 1e12, "frac": ipm_flops / (ipm_ms * 1e-3) / 1e12 / FP64_PEAK_TFLOPS}
+    out = {
+        "metric": "SQP-RTI OCP solves/sec (batch), N=40 single-track Pacejka",
+        "value": value, "unit": "OCP solves/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": args.scaling,
+        "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "config": {"workload": f"BASELINE configs[{cid - 1}]: {C['name']}, {C['track']} reftraj, cold-start SQP-RTI, one wavefront per OCP; "
+                               f"{NB_FRESH} differently seeded batches resident in HBM, rotated one per step (fresh batch every step)",
+                   "N": N, "nx": 8, "nu": 2, "nsub": 3, "batch_per_gpu": B, "global_batch": job.global_batch,
+                   "scenario_group": gsz, "groups_per_gpu": P, "solves_per_step": spp,
+                   "parallelism": f"scenario groups sharded x{world} (a group never straddles ranks), RCCL gather of "
+                                  f"{job.slab_pad * 8} B per rank (u0, cost, status, qp_iter"
+                                  + (", PCE mean/var of x_1 per group" if job.nmom else "") + "), one collective per step",
+                   "schedule": "workgroups take instances longest-first by the previous solve's IPM iteration count "
+                               "(tum_ocp_set_schedule): stale history when every step brings a new batch (`value`), exact when the "
+                               "same batch is solved again (`value_repeated_batch`)",
+                   "kernel_ms_natural_order": nat_ms,
+                   "solves_per_s_per_gpu_natural_order": (B / nat_ms * 1e3) if nat_ms else None,
+                   "kernel_ms_repeated_batch": rep_ms},
+        "value_repeated_batch": rep_value,
+        "solve_ms_per_step": kern_ms * spp, "gather_ms_per_step": gat_ms,
+        "roofline": {"bound": "mfma", "achieved": ach_tf, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
+                     "frac": ach_tf / FP64_PEAK_TFLOPS, "traffic": traffic, "traffic_source": traffic_src,
+                     "kernel": "pipeline of lin_kernel + cond_kernel + ipm_kernel + expand_kernel (kernel_ms = device time of one solve)",
+                     "kernel_ms": kern_ms, "dominant": dominant, "mean_qp_iter": mean_it_fresh,
+                     "flops_per_solve": flops / B,
+                     "hbm": {"achieved": ach_gb, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": ach_gb / HBM_PEAK_GBPS,
+                             "bytes_per_solve": abytes}},
+        "status_ok_frac": ok_fresh,
+    }
+    if rep_value is not None:
+        out["status_ok_frac_repeated_batch"] = float((st0 == 0).mean())
+    job.U_repeated = U
+    return out, job
+
+
+def n38_leg(args, torch, dev, solver_factory):
+    """"also report N = 38" (the reference's own horizon, Tp = 3.04 s): fresh-batch rate of config 2 at N = 38."""
+    a = argparse.Namespace(**vars(args)); a.horizon = 38; a.config = 2; a.batch = None; a.scaling = "weak"; a.no_schedule_legs = True
+    res = run(a, torch, None, dev, 1, 0, dev.index or 0, solver_factory, extra_legs=False)
+    out, _ = res
+    return {"N": 38, "value": out["value"], "ms_per_step": out["ms_per_step"], "kernel_ms": out["roofline"]["kernel_ms"],
+            "mean_qp_iter": out["roofline"]["mean_qp_iter"], "status_ok_frac": out["status_ok_frac"]}
+
+
+def main(argv=None):
+    args = parse_args(argv)
     import torch
     import torch.distributed as dist
 
@@ -133,207 +416,30 @@ def main():
     distributed = world > 1 or os.environ.get("RANK") is not None     # launched by torch.distributed.run
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the solver has no CPU fallback)")
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE is {world}: launch with `python -m torch.distributed.run --nnodes=1 "
+                         f"--nproc-per-node {args.gpus} ... bench.py --gpus {args.gpus}` (one rank per GPU)")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if distributed:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group(backend="nccl", device_id=dev)
-
-    from tum_control_amd import config as _cfg
-    from tum_control_amd import sharding
+        assert dist.get_world_size() == args.gpus, f"RCCL world size {dist.get_world_size()} != --gpus {args.gpus}"
     from tum_control_amd.solver import BatchedOcpSolver
-    from tum_control_amd.workloads import CONFIGS, config_groups
 
-    N, cid = args.horizon, args.config
-    C = CONFIGS[cid]
-    gsz = C["group"]
-    # weak scaling: every rank owns the config's per-GPU share, a whole number of scenario groups (contiguous block of the
-    # global group range: a group never straddles two ranks)
-    groups_per_gpu = C["groups_per_gpu"] if args.batch is None else max(1, args.batch // gsz)
-    groups_total = world * groups_per_gpu
-    g_lo, g_hi, b_lo, b_hi = sharding.shard_groups(groups_total, gsz, world, rank)
-    B = b_hi - b_lo
-    x0, yref, _ = config_groups(cid, g_lo, g_hi, groups_total, N=N, dt=0.08)
-    assert len(x0) == B
-    P = g_hi - g_lo
-
-    s = BatchedOcpSolver(N=N, dt=0.08, nsub=3, batch=B, device=local_rank, store_qp_in=(cid == 5))
-    s.install_reference_ocp()
-    s.set_x0(x0); s.set_yref_all(yref)
-    s.set_stream(torch.cuda.current_stream().cuda_stream)
-    nmom = 0
-    if cid == 3:      # PCE matrix of the 15 Hammersley sigma points (10 terms): K6 runs inside the step
-        from tum_control_amd.snmpc import alpha_generation, hammersley_normal, pce_matrix
-        s.pce_attach(pce_matrix(hammersley_normal(15, 3), alpha_generation(3, 2)))
-        nmom = 16
-    if cid == 5:      # covariance back-off attached to every solve (K7), nominal bounds restored at the start of a step
-        from tum_control_amd.r2nmpc import r2_setup
-        m, veh = s.cfg["mpc"], s.cfg["veh"]
-        S0, BWB = r2_setup(m["stds"], 0.08)
-        s.r2_attach(S0, BWB, int(m["uncertainty_propagation_horizon"]), veh["delta_f_min"], veh["delta_f_max"], 1.0)
-        s.bounds_snapshot()
-
-    # result slab gathered to rank 0 each step: (u0[2], cost, status, qp_iter) as 5 doubles per instance, for config 3
-    # followed by the PCE mean / variance of x_1 of every scenario group (16 doubles per group): ONE flat buffer, packed
-    # on the device by the library, moved with ONE rooted gather
-    slab = torch.zeros(B * 5 + P * nmom, dtype=torch.float64, device=dev)
-    mom_ptr = slab.data_ptr() + 8 * B * 5
-    gather = sharding.ResultGatherer(world, rank, 1, dev, nf=slab.numel(), ni=1) if distributed else None
-    spp = C["solves_per_step"]
-
-    def step(ev=None):
-        if cid == 5:
-            s.bounds_restore()
-        s.cold_start()
-        for j in range(spp):
-            if ev is not None:
-                ev[2 * j].record()
-            s.solve_async()
-            if ev is not None:
-                ev[2 * j + 1].record()
-        if cid == 3:
-            s.pce_moments_device("x", 1, mom_ptr, mom_ptr + 8 * P * 8)
-        if gather is not None:
-            s.get_device("summary", slab.data_ptr())
-            gather.gather(slab.view(1, -1))
-
-    def barrier():
-        if distributed:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    def new_events(n):
-        return [[torch.cuda.Event(enable_timing=True) for _ in range(2 * spp)] for _ in range(n)]
-
-    def kernel_ms(evs):
-        return float(np.mean([e[2 * j].elapsed_time(e[2 * j + 1]) for e in evs for j in range(spp)]))
-
-    for _ in range(args.warmup):
-        step()
-    barrier()
-    evs = new_events(args.steps)
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        step(evs[i])
-    barrier()
-    t1 = time.perf_counter()
-    elapsed = t1 - t0
-    if distributed:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
-    kern_ms = kernel_ms(evs)
-
-    # correctness of what was timed: statuses, and a parity spot check against the oracle on rank 0
-    st = s.get_stats("status"); it = s.get_stats("qp_iter")
-    X, U = s.get_iterate()
-    # which kernels ran: the four-kernel pipeline (the default), whose dominant
-    # kernel -- the interior point kernel -- is timed on its own (library events around it) over five more steps
-    ipm_ms = None
-    try:
-        tm = []
-        for _ in range(5):
-            step(); torch.cuda.synchronize(); tm.append(1e3 * s.get_stats("time_ipm"))
-        ipm_ms = float(np.median(tm))
-    except Exception:
-        pass
-
-    # The schedule legs (N = 1): (a) the same batch with the instances dispatched in natural order; (b) FRESH batches: four
-    # differently seeded batches of the same workload resident in HBM, rotated every step, so that the longest-first order
-    # comes from a DIFFERENT batch's iteration counts (stale history = what a caller with a new batch every step sees).
-    nat_ms = fresh_ms = fresh_value = None
-    if world == 1 and not args.no_schedule_legs:
-        s.set_schedule(False)
-        nat = new_events(5)
-        for e in nat:
-            step(e)
-        torch.cuda.synchronize()
-        nat_ms = float(np.median([e[2 * j].elapsed_time(e[2 * j + 1]) for e in nat for j in range(spp)]))
-        s.set_schedule(True)
-        nb = 4
-        shift = groups_per_gpu
-        dx0, dyr = [], []
-        for k in range(nb):      # batch k = the group range shifted by k * (groups per GPU): other poses, other random streams
-            gx, gy, _ = config_groups(cid, g_lo + (k + 1) * shift, g_hi + (k + 1) * shift, groups_total * (nb + 1), N=N, dt=0.08)
-            dx0.append(torch.from_numpy(np.ascontiguousarray(gx)).to(dev)); dyr.append(torch.from_numpy(np.ascontiguousarray(gy)).to(dev))
-
-        def fresh_step(k, ev=None):
-            s.put_device("x0", dx0[k % nb].data_ptr()); s.put_device("yref", dyr[k % nb].data_ptr())
-            step(ev)
-
-        for k in range(nb):
-            fresh_step(k)
-        torch.cuda.synchronize()
-        fev = new_events(args.steps)
-        t0 = time.perf_counter()
-        for k in range(args.steps):
-            fresh_step(k, fev[k])
-        torch.cuda.synchronize()
-        fresh_elapsed = time.perf_counter() - t0
-        fresh_ms = kernel_ms(fev)
-        fresh_value = B * spp * args.steps / fresh_elapsed
-        fresh_ok = float((s.get_stats("status") == 0).mean())
-
+    res = run(args, torch, dist if distributed else None, dev, world, rank, local_rank, BatchedOcpSolver)
     if rank == 0:
-        total = world * B * spp * args.steps
-        value = total / elapsed
-        mean_it = float(it.mean())
-        shared_yref = gsz > 1
-        flops = algorithmic_flops(N, 3, mean_it) * B
-        abytes = algorithmic_bytes(N, warm=(cid == 5), per_instance_yref=not shared_yref) * B
-        # HBM bytes per launch from the PMC counters cannot be collected from inside this process; they come
-        # from the committed rocprofv3 --pmc passes of this same command (profiles/*_traffic.json), only when
-        # the workload matches what was profiled.
-        traffic, traffic_src = None, None
-        try:
-            tj = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_traffic.json"))[-1]
-            tr = json.load(open(os.path.join(ROOT, "profiles", tj)))
-            if tr.get("batch") == B and tr.get("N") == N and tr.get("config", 2) == cid:
-                traffic, traffic_src = tr["traffic_bytes_per_launch"], "profiles/" + tj
-        except Exception:
-            pass
-        ach_tf = flops / (kern_ms * 1e-3) / 1e12
-        ach_gb = abytes / (kern_ms * 1e-3) / 1e9
-        nv_, ng_ = 2 * N, 2 * N
-        ipm_flops = mean_it * (ng_ * nv_ * nv_ + nv_ ** 3 / 3.0 + 6 * nv_ * nv_ + 4 * ng_ * nv_) * B
-        if ipm_ms:
-            kname = "pipeline of lin_kernel + cond_kernel + ipm_kernel + expand_kernel (kernel_ms = device time of one solve)"
-            dominant = {"kernel": "ipm_kernel", "kernel_ms": ipm_ms, "flops_per_launch": ipm_flops,
-                        "achieved": ipm_flops / (ipm_ms * 1e-3) / 1e12, "frac": ipm_flops / (ipm_ms * 1e-3) / 1e12 / FP64_PEAK_TFLOPS}
-        else:
-            kname, dominant = "nmpc_rti_kernel", None
-        out = {
-            "metric": "SQP-RTI OCP solves/sec (batch), N=40 single-track Pacejka",
-            "value": value, "unit": "OCP solves/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": f"BASELINE configs[{cid - 1}]: {C['name']}, {C['track']} reftraj, cold-start SQP-RTI, one wavefront per OCP",
-                       "N": N, "nx": 8, "nu": 2, "nsub": 3, "batch_per_gpu": B, "global_batch": world * B,
-                       "scenario_group": gsz, "groups_per_gpu": P, "solves_per_step": spp,
-                       "parallelism": f"scenario groups sharded x{world} (a group never straddles ranks), RCCL gather of "
-                                      f"{slab.numel() * 8} B per rank (u0, cost, status, qp_iter"
-                                      + (", PCE mean/var of x_1 per group" if nmom else "") + "), one collective per step",
-                       "schedule": "workgroups take instances longest-first by the previous solve's IPM iteration count "
-                                   "(tum_ocp_set_schedule): exact history when the same batch is solved again (`value`), "
-                                   "stale when every step brings a new batch (`value_fresh_batch`)",
-                       "kernel_ms_natural_order": nat_ms,
-                       "solves_per_s_per_gpu_natural_order": (B / nat_ms * 1e3) if nat_ms else None,
-                       "kernel_ms_fresh_batch": fresh_ms},
-            "value_fresh_batch": fresh_value,
-            "roofline": {"bound": "mfma", "achieved": ach_tf, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": ach_tf / FP64_PEAK_TFLOPS, "traffic": traffic, "traffic_source": traffic_src,
-                         "kernel": kname, "kernel_ms": kern_ms, "dominant": dominant, "mean_qp_iter": mean_it,
-                         "flops_per_solve": flops / B,
-                         "hbm": {"achieved": ach_gb, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": ach_gb / HBM_PEAK_GBPS,
-                                 "bytes_per_solve": abytes / B}},
-            "status_ok_frac": float((st == 0).mean()),
-        }
-        if fresh_value is not None:
-            out["status_ok_frac_fresh_batch"] = fresh_ok
+        out, job = res
+        if world == 1 and not args.no_schedule_legs and args.horizon != 38 and args.config == 2:
+            out["n38"] = n38_leg(args, torch, dev, BatchedOcpSolver)
         if not args.no_cpu_baseline and world == 1:
-            cb, u_ref = cpu_baseline(N, x0, yref, s.cfg)
+            x0, yref = job.host[0]
+            cb, u_ref = cpu_baseline(job.N, x0, yref, job.s.cfg)
             out["cpu_baseline"] = cb
-            if cid != 5:      # (config 5's iterate is the SECOND solve; the oracle sample is the cold-start solve)
+            U = job.U_repeated
+            if args.config != 5 and U is not None and not args.no_schedule_legs:
+                # (the iterate of the repeated-batch leg = batch 0 = what the oracle sample solved; config 5's iterate is
+                #  the SECOND solve of the step)
                 n = len(u_ref)
                 err = np.abs(U[:n, 0] - u_ref).max(axis=1)
                 out["parity_vs_oracle_max_abs_u0"] = float(err.max())

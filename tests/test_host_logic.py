@@ -278,3 +278,130 @@ def test_plant_restatement_reproduces_logged_closed_loops(golden_dir):
     xs = np.arange(40.0).reshape(5, 1, 8)
     outs = [est(x)[0] for x in xs]
     assert outs[4][0] == xs[4, 0, 0] and outs[4][2] == xs[1:5, 0, 2].mean() and outs[1][6] == xs[:2, 0, 6].mean()
+
+
+# ------------------------------------------------------------------------------------------------ bench.py, N > 1 control flow
+class _StandInSolver:
+    """CPU stand-in with the methods bench.py calls on BatchedOcpSolver: "solving" instance b yields
+    u0 = 2 x0[3:5], cost = sum(x0), status 0, qp_iter 5 + (b mod 3); device pointers are host pointers here."""
+
+    def __init__(self, N, dt, nsub, batch, device=0, store_qp_in=False):
+        from tum_control_amd import config
+        self.N, self.B = N, batch
+        self.cfg = config.default_config()
+        self.x0 = np.zeros((batch, 8)); self.yref = np.zeros((batch, N + 1, 6))
+        self.res = np.zeros((batch, 5)); self.calls = dict(cold=0, solve=0, put=0, summary=0)
+
+    @staticmethod
+    def _view(ptr, n):
+        import ctypes
+        return np.ctypeslib.as_array((ctypes.c_double * n).from_address(ptr))
+
+    def install_reference_ocp(self): pass
+    def set_x0(self, x0): self.x0[:] = x0
+    def set_yref_all(self, y): self.yref[:] = y
+    def set_schedule(self, on): pass
+    def cold_start(self): self.calls["cold"] += 1
+
+    def put_device(self, field, ptr):
+        self.calls["put"] += 1
+        if field == "x0":
+            self.x0[:] = self._view(ptr, self.B * 8).reshape(self.B, 8)
+        else:
+            self.yref[:] = self._view(ptr, self.yref.size).reshape(self.yref.shape)
+
+    def solve_async(self):
+        self.calls["solve"] += 1
+        self.res[:, 0:2] = 2.0 * self.x0[:, 3:5]; self.res[:, 2] = self.x0.sum(axis=1)
+        self.res[:, 3] = 0.0; self.res[:, 4] = 5 + (np.arange(self.B) % 3)
+
+    def get_device(self, field, ptr):
+        assert field == "summary"
+        self.calls["summary"] += 1
+        self._view(ptr, self.B * 5)[:] = self.res.reshape(-1)
+
+    def get_stats(self, f):
+        return self.res[:, 3].astype(int) if f == "status" else self.res[:, 4].astype(int)
+
+    def get_iterate(self):
+        return None, np.zeros((self.B, self.N, 2))
+
+
+def _gloo_bench_worker(rank, world, port, out, argv):
+    import torch
+    import torch.distributed as dist
+    sys.path.insert(0, ROOT)
+    import bench
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    args = bench.parse_args(argv)
+    assert dist.get_world_size() == args.gpus
+    res = bench.run(args, torch, dist, torch.device("cpu"), world, rank, rank, _StandInSolver)
+    if rank == 0:
+        o, job = res
+        out.put((o, job.gather.all_f.numpy().copy(), dict(job.s.calls), job.slab_pad, job.B))
+    else:
+        assert res is None
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("scaling", ["weak", "strong"])
+def test_bench_control_flow_world2_gloo(scaling):
+    """bench.py's own step / gather / timing control flow at world size 2 on CPU (gloo), with a stand-in solver: what the
+    driver's first real multi-GPU run executes, minus the kernels. Weak scaling: every rank its share; strong scaling: a fixed
+    global batch of 5 scenario groups cut 3 + 2 (unequal shards: the gathered slab is padded to the largest)."""
+    import json
+    import torch.multiprocessing as mp
+    from tum_control_amd.workloads import config_groups
+    steps, warm, N = 3, 1, 6
+    argv = ["--gpus", "2", "--steps", str(steps), "--warmup", str(warm), "--config", "4", "--horizon", str(N), "--no-cpu-baseline"]
+    argv += ["--batch", "48"] if scaling == "weak" else ["--scaling", "strong", "--global-batch", "80"]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 33500 + (os.getpid() % 2000) + (7 if scaling == "strong" else 0)
+    ps = [ctx.Process(target=_gloo_bench_worker, args=(r, 2, port, q, argv)) for r in range(2)]
+    for p in ps:
+        p.start()
+    o, allf, calls, pad, B0 = q.get(timeout=240)
+    for p in ps:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    G = 6 if scaling == "weak" else 5
+    sizes = [48, 48] if scaling == "weak" else [48, 32]
+    json.dumps(o)                                        # the line must serialise
+    assert o["n_gpus"] == 2 and o["scaling"] == scaling and o["steps"] == steps
+    assert o["config"]["global_batch"] == 16 * G and o["config"]["batch_per_gpu"] == sizes[0] == B0
+    assert o["value"] > 0 and abs(o["value"] * o["ms_per_step"] * 1e-3 - 16 * G) < 1e-6 * 16 * G
+    assert o["solve_ms_per_step"] >= 0 and o["gather_ms_per_step"] >= 0
+    assert o["status_ok_frac"] == 1.0
+    # every step: one cold start, one solve, one summary pack, one rotation of the inputs (x0 + yref)
+    n = steps + warm
+    assert calls == dict(cold=n, solve=n, put=2 * n, summary=n)
+    # what the root holds after the last step = the stand-in's results for the last rotated batch, in shard order
+    assert pad == 48 * 5 and allf.shape == (2, 1, pad)
+    variant = (steps - 1) % 4 + 1
+    x0, _, _ = config_groups(4, 0, G, G, N=N, variant=variant)
+    lo = 0
+    for r, sz in enumerate(sizes):
+        got = allf[r, 0, :sz * 5].reshape(sz, 5)
+        np.testing.assert_array_equal(got[:, 0:2], 2.0 * x0[lo:lo + sz, 3:5])
+        np.testing.assert_allclose(got[:, 2], x0[lo:lo + sz].sum(axis=1), rtol=1e-15)
+        assert (got[:, 3] == 0).all() and np.array_equal(got[:, 4], 5 + (np.arange(sz) % 3))
+        lo += sz
+
+
+def test_workload_variants_are_fresh_batches_of_the_same_workload():
+    """variant 0 is the BASELINE configuration; variants k > 0 (what bench.py rotates through) differ from it and from each
+    other in every instance but keep the group structure (one yref per scenario group)."""
+    from tum_control_amd.workloads import config_groups
+    for cid, G in ((2, 8), (3, 4), (4, 4), (5, 8)):
+        b = [config_groups(cid, 0, G, G, N=6, variant=k) for k in range(3)]
+        ref = config_groups(cid, 0, G, G, N=6)
+        assert np.array_equal(b[0][0], ref[0]) and np.array_equal(b[0][1], ref[1])
+        gsz = b[0][2]
+        for k in (1, 2):
+            assert b[k][0].shape == b[0][0].shape and not np.array_equal(b[k][0][:, :2], b[0][0][:, :2])
+            y = b[k][1].reshape(G, gsz, 7, 6)
+            assert (y == y[:, :1]).all()
+        assert not np.array_equal(b[1][0], b[2][0])

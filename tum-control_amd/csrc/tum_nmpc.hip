@@ -32,7 +32,9 @@ struct tum_ocp {
     bool lpt, order_valid;
     long long *dprof;
     double *dws, *dhws;
-    int kmode;                     // 0 auto (pipeline for batches of more than one round of wavefronts), 1 fused, 2 pipeline
+    int kmode;                     // 0 auto (= the pipeline), 1 fused, 2 pipeline
+    unsigned epoch;                // bumped by everything a captured launch bakes into its kernel arguments (kernel variant, schedule,
+                                   // SNMPC horizon / risk parameter / work buffers, R2 attachment): tum_sim_run re-captures its graph
     bool pipe;                     // this solve runs the four-kernel pipeline (resolved from kmode at launch)
     bool solved_pipe;              // the LAST solve ran the pipeline: its linearisation is in the stage records, not in qpin
     double *drec, *dcws, *dvec;    // pipeline workspace: stage records, gg rows in operand layout, q | d | dv
@@ -64,10 +66,16 @@ extern "C" int tum_ocp_horizon(const tum_ocp *c) { return c->N; }
 // Every entry point that touches the device runs under the capsule's device and leaves the caller's (torch's) current
 // device as it found it: two capsules on different GPUs may live in one process.
 struct DevGuard {
-    int prev = -1, dev; bool changed = false;
-    explicit DevGuard(int d) : dev(d) { if (hipGetDevice(&prev) == hipSuccess && prev != d) changed = hipSetDevice(d) == hipSuccess; }
+    int prev = -1, dev; bool changed = false, ok = true;
+    explicit DevGuard(int d) : dev(d)
+    {
+        if (hipGetDevice(&prev) != hipSuccess) { ok = false; return; }
+        if (prev != d) { changed = hipSetDevice(d) == hipSuccess; ok = changed; }
+    }
     ~DevGuard() { if (changed) (void)hipSetDevice(prev); }
 };
+// entry points that allocate or launch refuse to run on the caller's device when the switch failed
+#define GUARD_OK(g) do { if (!(g).ok) return fail("hipSetDevice failed"); } while (0)
 
 // temporary device buffer that cannot leak on an early error return
 struct DevTmp {
@@ -100,9 +108,9 @@ extern "C" tum_ocp *tum_ocp_create(const tum_ocp_desc *desc)
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) { fail("no HIP device: libtumnmpc has no CPU fallback"); return nullptr; }
     if (desc->device < 0 || desc->device >= ndev) { fail("device ordinal out of range"); return nullptr; }
-    DevGuard guard(desc->device);
+    DevGuard guard(desc->device); if (!guard.ok) { fail("hipSetDevice failed"); return nullptr; }
     tum_ocp *c = new tum_ocp();
-    c->d = *desc; c->N = desc->N; c->batch = desc->batch; c->last_ms = 0; c->solved = false;
+    c->d = *desc; c->N = desc->N; c->batch = desc->batch; c->last_ms = 0; c->solved = false; c->epoch = 0;
     c->sn = false; c->dXS = c->dxs0 = c->dApce = c->dws2 = c->dpro = c->ddv = c->doffs = nullptr; c->dxs_dirty = nullptr; c->xs_lazy = false;
     c->have_offs = c->fanout = false;
     c->r2 = false; c->dr2S = c->dr2B = nullptr;
@@ -215,7 +223,7 @@ extern "C" int tum_ocp_snmpc_attach(tum_ocp *c, int ns, int L, const double *Apc
     if (!(gamma > 0.0 && gamma <= 1.0)) return fail("snmpc_attach: gamma out of range (0,1]");
     if (c->d.nsub != 1) return fail("snmpc_attach: the SNMPC model is DISCRETE with one RK4 step per stage: create the capsule with nsub = 1");
     if (c->d.store_qp_in) return fail("snmpc_attach: store_qp_in is not available for the stacked state");
-    DevGuard guard(c->d.device);
+    DevGuard guard(c->d.device); GUARD_OK(guard);
     {
         const size_t lds = sizeof(double) * sn_prologue_lds_doubles(uph, ns);
         if (lds > 128 * 1024) return fail("snmpc_attach: n_samples x uph too large for the prologue kernel's LDS");
@@ -250,6 +258,7 @@ extern "C" int tum_ocp_snmpc_attach(tum_ocp *c, int ns, int L, const double *Apc
     c->p_gamma.assign(N + 1, gamma); c->p_stop.assign(N + 1, 0.0);
     for (int k = uph; k <= N; k++) c->p_stop[k] = 1.0;
     c->p_dirty = false;
+    c->epoch++;
     return 0;
 }
 
@@ -271,7 +280,7 @@ static int sn_set_p(tum_ocp *c, int stage, const double *v, int len, int nb, int
     if (!(g > 0.0 && g <= 1.0)) return fail("set p: risk parameter out of range (0,1]");
     if (sf != 0.0 && sf != 1.0) return fail("set p: stop_flag must be 0 or 1");
     if (memcmp(v, c->hApce.data(), sizeof(double) * L * ns) != 0) {
-        DevGuard guard(c->d.device);
+        DevGuard guard(c->d.device); GUARD_OK(guard);
         HIPCHK(hipStreamSynchronize(c->stream));
         HIPCHK(hipMemcpy(c->dApce, v, sizeof(double) * L * ns, hipMemcpyHostToDevice));
         c->hApce.assign(v, v + (size_t)L * ns);
@@ -291,7 +300,7 @@ static void sn_launch_lin(tum_ocp *c)
 static int sn_materialise(tum_ocp *c)
 {
     if (!c->sn || !c->xs_lazy) return 0;
-    DevGuard guard(c->d.device);
+    DevGuard guard(c->d.device); GUARD_OK(guard);
     hipLaunchKernelGGL(snmpc_freeze_kernel, dim3(c->batch), dim3(256), 0, c->stream, c->dXS, c->dxs_dirty, c->N, c->sa.ns, c->sa.uph, c->batch);
     HIPCHK(hipGetLastError());
     c->xs_lazy = false;
@@ -313,7 +322,7 @@ static int sn_apply_p(tum_ocp *c)
     if (uph > SN_UPHMAX) return fail("solve: uncertainty propagation horizon from the stop flags exceeds " + std::to_string(SN_UPHMAX));
     if (sizeof(double) * sn_prologue_lds_doubles(uph, ns) > 128 * 1024) return fail("solve: n_samples x uph too large for the prologue kernel's LDS");
     if (uph > c->uph_cap) {
-        DevGuard guard(c->d.device);
+        DevGuard guard(c->d.device); GUARD_OK(guard);
         HIPCHK(hipStreamSynchronize(c->stream));
         (void)hipFree(c->dws2); (void)hipFree(c->dpro); c->dws2 = c->dpro = nullptr;
         const size_t B = c->batch;
@@ -325,7 +334,7 @@ static int sn_apply_p(tum_ocp *c)
         if (sn_materialise(c)) return 1;          // (the frozen copies belong to the horizon they were solved with)
         // the prologue only writes the live columns of a stage (2k+3 of them) and relies on the rest of its hand-over
         // buffers being zero; the per-instance stride of both buffers depends on uph, so a new horizon starts from zeros
-        DevGuard guard(c->d.device);
+        DevGuard guard(c->d.device); GUARD_OK(guard);
         HIPCHK(hipMemsetAsync(c->dws2, 0, sizeof(double) * (size_t)c->batch * c->uph_cap * ns * ABS, c->stream));
         HIPCHK(hipMemsetAsync(c->dpro, 0, sizeof(double) * (size_t)c->batch * c->uph_cap * SN_PRO_STAGE, c->stream));
     }
@@ -333,6 +342,7 @@ static int sn_apply_p(tum_ocp *c)
     c->sa.kappa = std::sqrt((1.0 - c->gamma) / c->gamma);
     c->sa.uph = uph; c->ka.uph = uph;
     c->p_dirty = false;
+    c->epoch++;                                   // (uph, kappa and the work buffers are kernel arguments of a captured launch)
     return 0;
 }
 extern "C" int tum_ocp_snmpc_samples(const tum_ocp *c) { return (c && c->sn) ? c->sa.ns : 0; }
@@ -344,7 +354,7 @@ extern "C" int tum_ocp_snmpc_set_offsets(tum_ocp *c, const double *offs)
 {
     if (!c || !offs) return fail("null argument");
     if (!c->sn) return fail("snmpc_set_offsets: not an SNMPC capsule (tum_ocp_snmpc_attach)");
-    DevGuard guard(c->d.device);
+    DevGuard guard(c->d.device); GUARD_OK(guard);
     HIPCHK(hipMemcpy(c->doffs, offs, sizeof(double) * c->sa.ns * NX, hipMemcpyHostToDevice));
     c->have_offs = true;
     return 0;
@@ -368,7 +378,7 @@ static int chk_range(tum_ocp *c, int b0, int nb)
 static int put(tum_ocp *c, double *dbase, size_t rec, size_t off, const double *v, int len, int b0, int nb, int stride)
 {
     if (stride != 0 && stride < len) return fail("stride < len");
-    DevGuard guard(c->d.device);
+    DevGuard guard(c->d.device); GUARD_OK(guard);
     const double *src = v;
     size_t spitch = (size_t)stride * sizeof(double);
     if (stride == 0) {
@@ -384,7 +394,7 @@ static int put(tum_ocp *c, double *dbase, size_t rec, size_t off, const double *
 static int fetch(tum_ocp *c, const double *dbase, size_t rec, size_t off, double *v, int len, int b0, int nb, int stride)
 {
     if (stride < len) return fail("stride < len");
-    DevGuard guard(c->d.device);
+    DevGuard guard(c->d.device); GUARD_OK(guard);
     HIPCHK(hipMemcpy2DAsync(v, (size_t)stride * sizeof(double), dbase + (size_t)b0 * rec + off, rec * sizeof(double),
                             (size_t)len * sizeof(double), nb, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
@@ -403,7 +413,8 @@ extern "C" int tum_ocp_set(tum_ocp *c, int stage, const char *field, const doubl
         if (c->sn && len == NX * (c->sa.ns + 1)) {   // stacked state: nominal copy, then the sample copies (SNMPC_class.py:126-127)
             if (stride != 0 && stride < len) return fail("stride < len");
             const int ns = c->sa.ns;
-            if (stage > c->sa.uph && sn_materialise(c)) return 1;
+            // (a write to stage uph would change what the deferred freeze copies into the stages behind it: freeze first)
+            if (stage >= c->sa.uph && sn_materialise(c)) return 1;
             if (put(c, c->dX, (N + 1) * NX, (size_t)stage * NX, v, NX, b0, nb, stride)) return 1;
             return put(c, c->dXS, (size_t)(N + 1) * ns * NX, (size_t)stage * ns * NX, v + NX, ns * NX, b0, nb, stride);
         }
@@ -580,6 +591,7 @@ extern "C" int tum_ocp_set_kernel(tum_ocp *c, const char *name)
     else if (n == "fused") c->kmode = 1;
     else if (n == "pipeline") c->kmode = 2;
     else return fail("set_kernel: unknown kernel '" + n + "' (auto | fused | pipeline)");
+    c->epoch++;
     return 0;
 }
 
@@ -632,7 +644,7 @@ static int launch_pipeline(tum_ocp *c, bool events)
 
 static int launch(tum_ocp *c, bool events = true)
 {
-    DevGuard guard(c->d.device);
+    DevGuard guard(c->d.device); GUARD_OK(guard);
     if (resolve_kernel(c)) return 1;
     if (events) HIPCHK(hipEventRecord(c->ev0, c->stream));
     // longest-first schedule from the previous solve's iteration counts (only matters when the batch is more than one
@@ -674,6 +686,7 @@ static int launch(tum_ocp *c, bool events = true)
 extern "C" int tum_ocp_set_schedule(tum_ocp *c, int longest_first)
 {
     if (!c) return fail("null capsule");
+    if (c->lpt != (longest_first != 0)) c->epoch++;
     c->lpt = longest_first != 0;
     return 0;
 }
@@ -686,7 +699,7 @@ extern "C" int tum_ocp_solve_async(tum_ocp *c)
 extern "C" int tum_ocp_synchronize(tum_ocp *c)
 {
     if (!c) return fail("null capsule");
-    DevGuard guard(c->d.device);
+    DevGuard guard(c->d.device); GUARD_OK(guard);
     HIPCHK(hipStreamSynchronize(c->stream));
     return 0;
 }
@@ -694,7 +707,7 @@ extern "C" int tum_ocp_synchronize(tum_ocp *c)
 extern "C" int tum_ocp_solve(tum_ocp *c)
 {
     if (!c) { fail("null capsule"); return -1; }
-    DevGuard guard(c->d.device);
+    DevGuard guard(c->d.device); if (!guard.ok) { fail("hipSetDevice failed"); return -1; }
     if (launch(c)) return -1;
     if (hipStreamSynchronize(c->stream) != hipSuccess) { fail("kernel execution failed"); return -1; }
     std::vector<int> st(c->batch);
@@ -707,7 +720,7 @@ extern "C" int tum_ocp_solve(tum_ocp *c)
 extern "C" double tum_ocp_last_kernel_ms(tum_ocp *c)
 {
     if (!c || !c->solved) return 0.0;
-    DevGuard guard(c->d.device);
+    DevGuard guard(c->d.device); if (!guard.ok) return 0.0;
     if (hipEventSynchronize(c->ev1) != hipSuccess) return 0.0;
     float ms = 0;
     if (hipEventElapsedTime(&ms, c->ev0, c->ev1) != hipSuccess) return 0.0;
@@ -718,7 +731,7 @@ extern "C" double tum_ocp_last_kernel_ms(tum_ocp *c)
 extern "C" int tum_ocp_get_cost(tum_ocp *c, double *out, int b0, int nb)
 {
     if (chk_range(c, b0, nb)) return 1;
-    DevGuard guard(c->d.device);
+    DevGuard guard(c->d.device); GUARD_OK(guard);
     HIPCHK(hipStreamSynchronize(c->stream));        // (the copy below runs on the NULL stream, which the capsule's non-blocking stream is not ordered with)
     HIPCHK(hipMemcpy(out, c->dcost + b0, sizeof(double) * nb, hipMemcpyDeviceToHost));
     return 0;
@@ -730,14 +743,14 @@ extern "C" int tum_ocp_get_stats(tum_ocp *c, const char *field, void *out, int b
     const std::string f(field);
     if (f == "time_tot") { *(double *)out = tum_ocp_last_kernel_ms(c) * 1e-3; return 0; }
     if (f == "time_ipm") {    // pipeline only: device seconds of the interior point kernel of the last solve
-        if (!c->pipe || !c->solved) return fail("get_stats time_ipm: pipeline kernel only, after a solve");
-        DevGuard guard(c->d.device);
+        if (!c->solved || !c->solved_pipe) return fail("get_stats time_ipm: pipeline kernel only, after a solve");
+        DevGuard guard(c->d.device); GUARD_OK(guard);
         float ms = 0;
         if (hipEventSynchronize(c->evi1) != hipSuccess || hipEventElapsedTime(&ms, c->evi0, c->evi1) != hipSuccess) return fail("get_stats time_ipm: no timing");
         *(double *)out = ms * 1e-3; return 0;
     }
     if (chk_range(c, b0, nb)) return 1;
-    DevGuard guard(c->d.device);
+    DevGuard guard(c->d.device); GUARD_OK(guard);
     HIPCHK(hipStreamSynchronize(c->stream));        // (after tum_ocp_solve_async: the copies below are on the NULL stream)
     if (f == "sqp_iter") { int *o = (int *)out; for (int i = 0; i < nb; i++) o[i] = 1; return 0; }
     if (f == "qp_iter") { HIPCHK(hipMemcpy(out, c->dqpiter + b0, sizeof(int) * nb, hipMemcpyDeviceToHost)); return 0; }
@@ -750,7 +763,7 @@ extern "C" int tum_ocp_get_stats(tum_ocp *c, const char *field, void *out, int b
 extern "C" int tum_ocp_reset(tum_ocp *c)
 {
     if (!c) return fail("null capsule");
-    DevGuard guard(c->d.device);
+    DevGuard guard(c->d.device); GUARD_OK(guard);
     HIPCHK(hipMemsetAsync(c->dX, 0, sizeof(double) * (size_t)c->batch * (c->N + 1) * NX, c->stream));
     HIPCHK(hipMemsetAsync(c->dU, 0, sizeof(double) * (size_t)c->batch * c->N * NU, c->stream));
     if (c->sn) HIPCHK(hipMemsetAsync(c->dXS, 0, sizeof(double) * (size_t)c->batch * (c->N + 1) * c->sa.ns * NX, c->stream));
@@ -762,7 +775,7 @@ extern "C" int tum_ocp_reset(tum_ocp *c)
 extern "C" int tum_ocp_cold_start(tum_ocp *c)
 {
     if (!c) return fail("null capsule");
-    DevGuard guard(c->d.device);
+    DevGuard guard(c->d.device); GUARD_OK(guard);
     hipLaunchKernelGGL(cold_start_kernel, dim3(c->batch), dim3(64), 0, c->stream, c->dX, c->dU, c->dx0, c->N, c->batch);
     if (c->sn && c->fanout && sn_fanout(c)) return 1;
     if (c->sn) hipLaunchKernelGGL(snmpc_cold_start_kernel, dim3(c->batch), dim3(256), 0, c->stream, c->dXS, c->dxs0, c->N, c->sa.ns, c->batch);
@@ -825,7 +838,7 @@ extern "C" int tum_ocp_get_device(tum_ocp *c, const char *field, void *dst, int 
     if (!field || !dst) return fail("null argument");
     const int N = c->N;
     const std::string f(field);
-    DevGuard guard(c->d.device);
+    DevGuard guard(c->d.device); GUARD_OK(guard);
     hipStream_t s = c->stream;
     if (f == "summary") {
         hipLaunchKernelGGL(pack_summary_kernel, dim3((nb + 255) / 256), dim3(256), 0, s, c->dU, c->dcost, c->dstatus, c->dqpiter, N, b0, nb, (double *)dst);
@@ -849,7 +862,7 @@ extern "C" int tum_ocp_put_device(tum_ocp *c, const char *field, const void *src
     if (!field || !src) return fail("null argument");
     const int N = c->N;
     const std::string f(field);
-    DevGuard guard(c->d.device);
+    DevGuard guard(c->d.device); GUARD_OK(guard);
     hipStream_t s = c->stream;
     if (f == "x0") {
         if (c->sn) { if (!c->have_offs) return fail("put_device x0: an SNMPC capsule needs its sample offsets (tum_ocp_snmpc_set_offsets)"); c->fanout = true; }
@@ -865,7 +878,7 @@ extern "C" int tum_ocp_debug_dump(tum_ocp *c, int b, double *out, int len)
 {
     if (!c) return fail("null capsule");
     if (b < 0 || b >= DBG_INST || b >= c->batch) return fail("debug_dump: instance out of range");
-    DevGuard guard(c->d.device);
+    DevGuard guard(c->d.device); GUARD_OK(guard);
     if (len > DBG_STRIDE) len = DBG_STRIDE;
     c->ka.flags |= 2;
     const int rc = launch(c);
@@ -880,7 +893,7 @@ extern "C" int tum_ocp_debug_dump(tum_ocp *c, int b, double *out, int len)
 extern "C" int tum_ocp_profile_phases(tum_ocp *c, long long *out)
 {
     if (!c || !out) return fail("null argument");
-    DevGuard guard(c->d.device);
+    DevGuard guard(c->d.device); GUARD_OK(guard);
     c->ka.flags |= 4;
     int rc = launch(c);
     c->ka.flags &= ~4;
@@ -896,7 +909,7 @@ extern "C" int tum_ocp_set_x0_fanout(tum_ocp *c, const double *pose, const doubl
     if (!c || !pose || (S > 0 && !offs)) return fail("null argument");
     const int S1 = S + 1;
     if (P < 1 || S < 0 || (long long)P * S1 != c->batch) return fail("set_x0_fanout: P*(S+1) must equal the batch size");
-    DevGuard guard(c->d.device);
+    DevGuard guard(c->d.device); GUARD_OK(guard);
     DevTmp tp, to;
     HIPCHK(tp.alloc(sizeof(double) * P * NX));
     HIPCHK(to.alloc(sizeof(double) * (S > 0 ? S : 1) * NX));
@@ -915,7 +928,7 @@ extern "C" int tum_pce_attach(tum_ocp *c, const double *A, int L, int S)
 {
     if (!c || !A) return fail("null argument");
     if (S < 1 || L < 1 || c->batch % (S + 1) != 0) return fail("pce_attach: batch must be a multiple of S+1");
-    DevGuard guard(c->d.device);
+    DevGuard guard(c->d.device); GUARD_OK(guard);
     HIPCHK(hipStreamSynchronize(c->stream));
     (void)hipFree(c->dpceA); c->dpceA = nullptr;
     if (dalloc(&c->dpceA, (size_t)L * S) != hipSuccess) return fail("pce_attach: device allocation failed");
@@ -942,7 +955,7 @@ extern "C" int tum_pce_moments_device(tum_ocp *c, const char *field, int stage, 
 {
     if (!c || !field || !mean_dev || !var_dev) return fail("null argument");
     if (!c->dpceA) return fail("pce_moments_device: no PCE matrix registered (tum_pce_attach)");
-    DevGuard guard(c->d.device);
+    DevGuard guard(c->d.device); GUARD_OK(guard);
     return pce_launch(c, field, stage, c->dpceA, c->pce_L, c->pce_S, mean_dev, var_dev);
 }
 
@@ -953,7 +966,7 @@ extern "C" int tum_pce_moments(tum_ocp *c, const char *field, int stage, const d
     if (S < 1 || L < 1 || c->batch % S1 != 0) return fail("pce_moments: batch must be a multiple of S+1");
     const int P = c->batch / S1;
     const int m = (std::string(field) == "u") ? NU : NX;
-    DevGuard guard(c->d.device);
+    DevGuard guard(c->d.device); GUARD_OK(guard);
     DevTmp tA, tm, tv;
     HIPCHK(tA.alloc(sizeof(double) * L * S));
     HIPCHK(tm.alloc(sizeof(double) * P * m)); HIPCHK(tv.alloc(sizeof(double) * P * m));
@@ -971,7 +984,7 @@ extern "C" int tum_pce_moments(tum_ocp *c, const char *field, int stage, const d
 extern "C" int tum_ocp_bounds_snapshot(tum_ocp *c)
 {
     if (!c) return fail("null capsule");
-    DevGuard guard(c->d.device);
+    DevGuard guard(c->d.device); GUARD_OK(guard);
     const size_t n = (size_t)c->batch * 6 * (c->N + 1);
     if (!c->dbnd_snap && dalloc(&c->dbnd_snap, n) != hipSuccess) return fail("bounds_snapshot: device allocation failed");
     HIPCHK(hipMemcpyAsync(c->dbnd_snap, c->dbnd, sizeof(double) * n, hipMemcpyDeviceToDevice, c->stream));
@@ -982,7 +995,7 @@ extern "C" int tum_ocp_bounds_restore(tum_ocp *c)
 {
     if (!c) return fail("null capsule");
     if (!c->dbnd_snap) return fail("bounds_restore: no snapshot taken");
-    DevGuard guard(c->d.device);
+    DevGuard guard(c->d.device); GUARD_OK(guard);
     HIPCHK(hipMemcpyAsync(c->dbnd, c->dbnd_snap, sizeof(double) * (size_t)c->batch * 6 * (c->N + 1), hipMemcpyDeviceToDevice, c->stream));
     return 0;
 }
@@ -994,7 +1007,7 @@ extern "C" int tum_ocp_r2_backoff(tum_ocp *c, const double *Sigma0, const double
     if (!c->dqpin) return fail("r2_backoff: capsule created without store_qp_in");
     if (!c->solved) return fail("r2_backoff: no solve yet");
     if (uph < 1) return fail("r2_backoff: uncertainty propagation horizon < 1");
-    DevGuard guard(c->d.device);
+    DevGuard guard(c->d.device); GUARD_OK(guard);
     const int N = c->N;
     DevTmp tS, tB, tbo;
     HIPCHK(tS.alloc(64 * 8)); HIPCHK(tB.alloc(64 * 8));
@@ -1021,17 +1034,18 @@ extern "C" int tum_ocp_r2_attach(tum_ocp *c, const double *Sigma0, const double 
                                  double delta_min, double delta_max, double uh_nom)
 {
     if (!c) return fail("null capsule");
-    if (uph == 0) { c->r2 = false; return 0; }
+    if (uph == 0) { if (c->r2) c->epoch++; c->r2 = false; return 0; }
     if (!Sigma0 || !BWB) return fail("null argument");
     if (!c->dqpin) return fail("r2_attach: capsule created without store_qp_in");
     if (c->sn) return fail("r2_attach: not available for an SNMPC capsule");
     if (uph < 1) return fail("r2_attach: uncertainty propagation horizon < 1");
-    DevGuard guard(c->d.device);
+    DevGuard guard(c->d.device); GUARD_OK(guard);
     if (!c->dr2S && (dalloc(&c->dr2S, 64) != hipSuccess || dalloc(&c->dr2B, 64) != hipSuccess)) return fail("r2_attach: device allocation failed");
     HIPCHK(hipMemcpy(c->dr2S, Sigma0, 64 * 8, hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(c->dr2B, BWB, 64 * 8, hipMemcpyHostToDevice));
     c->r2_uph = uph; c->r2_dmin = delta_min; c->r2_dmax = delta_max; c->r2_uh = uh_nom;
     c->r2 = true;
+    c->epoch++;
     return 0;
 }
 
@@ -1057,6 +1071,7 @@ struct tum_sim {
     double *dtrack, *dxsim, *dpose, *dhist, *dref0;
     int *dclosest, *derr, *dstep;
     hipGraphExec_t graph; int graph_steps;            // captured chunk of control steps (tum_sim_run)
+    unsigned graph_epoch; bool graph_fanout;          // configuration of the capsule the chunk was captured with
     double *lCiLX, *lSimX, *lU, *lREF, *lDBG;
 };
 
@@ -1068,7 +1083,7 @@ extern "C" int tum_planner_emulate(const double *track, int n_track, const doubl
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return fail("no HIP device: libtumnmpc has no CPU fallback");
     if (device < 0 || device >= ndev) return fail("planner_emulate: device ordinal out of range");
-    DevGuard guard(device);
+    DevGuard guard(device); GUARD_OK(guard);
     DevTmp tt, tp, tout, tcl, terr;
     HIPCHK(tt.alloc(sizeof(double) * 4 * n_track)); HIPCHK(tp.alloc(sizeof(double) * 2 * P));
     HIPCHK(tout.alloc(sizeof(double) * 4 * (size_t)P * n_points)); HIPCHK(tcl.alloc(sizeof(int) * P)); HIPCHK(terr.alloc(sizeof(int)));
@@ -1105,7 +1120,7 @@ extern "C" tum_sim *tum_sim_create(tum_ocp *c, const double *track, int n_track,
     if (!c || !track || !windows) { fail("null argument"); return nullptr; }
     if (n_track < 2 || !(Tp > 0) || !(Ts > 0) || n_elem < 1 || log_capacity < 0) { fail("sim_create: bad arguments"); return nullptr; }
     for (int i = 0; i < 8; i++) if (windows[i] < 1 || windows[i] > 4) { fail("sim_create: estimator windows must be 1..4"); return nullptr; }
-    DevGuard guard(c->d.device);
+    DevGuard guard(c->d.device); if (!guard.ok) { fail("hipSetDevice failed"); return nullptr; }
     if (c->sn) {   // the state estimator writes the nominal x0 only: the samples follow by fan-out
         if (!c->have_offs) { fail("sim_create: an SNMPC capsule needs its sample offsets (tum_ocp_snmpc_set_offsets)"); return nullptr; }
         c->fanout = true;
@@ -1133,7 +1148,7 @@ extern "C" int tum_sim_set_state(tum_sim *s, const double *x_sim, const double *
 {
     if (!s || !x_sim || !x_mpc) return fail("null argument");
     tum_ocp *c = s->c; const size_t B = c->batch;
-    DevGuard guard(c->d.device);
+    DevGuard guard(c->d.device); GUARD_OK(guard);
     HIPCHK(hipStreamSynchronize(c->stream));
     HIPCHK(hipMemcpy(s->dxsim, x_sim, sizeof(double) * B * 7, hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(c->dx0, x_mpc, sizeof(double) * B * 8, hipMemcpyHostToDevice));
@@ -1154,7 +1169,7 @@ extern "C" int tum_sim_plan(tum_sim *s)
 {
     if (!s) return fail("null argument");
     tum_ocp *c = s->c;
-    DevGuard guard(c->d.device);
+    DevGuard guard(c->d.device); GUARD_OK(guard);
     hipLaunchKernelGGL(planner_kernel, dim3(c->batch), dim3(64), 0, c->stream, s->dtrack, s->n_track, s->dpose, 2, c->N + 1, s->Tp,
                        s->loop_circuit, c->dyref, 6, s->dref0, s->dclosest, s->derr, c->batch, (int *)nullptr);
     HIPCHK(hipGetLastError());
@@ -1166,7 +1181,7 @@ extern "C" int tum_sim_advance(tum_sim *s)
     if (!s) return fail("null argument");
     tum_ocp *c = s->c;
     if (!c->solved) return fail("sim_advance: no solve yet");
-    DevGuard guard(c->d.device);
+    DevGuard guard(c->d.device); GUARD_OK(guard);
     SimArgs sa;
     memset(&sa, 0, sizeof(sa));
     sa.N = c->N; sa.batch = c->batch; sa.n_elem = s->n_elem; sa.step_counter = s->dstep; sa.log_cap = s->log_cap; sa.Ts = s->Ts;
@@ -1206,11 +1221,17 @@ extern "C" int tum_sim_run(tum_sim *s, int nsteps)
 {
     if (!s || nsteps < 0) return fail("bad argument");
     tum_ocp *c = s->c;
-    DevGuard guard(c->d.device);
+    DevGuard guard(c->d.device); GUARD_OK(guard);
     if (resolve_kernel(c)) return 1;          // (workspace allocation must not happen inside the capture below)
+    // ... nor the reallocation / synchronisation a changed SNMPC parameter vector can trigger, nor the deferred freeze
+    if (c->sn && (sn_apply_p(c) || sn_materialise(c))) return 1;
     int done = 0;
     if (nsteps >= 2 * GRAPH_STEPS) {
+        // a captured chunk holds the kernel variant, the schedule flag, the SNMPC horizon / risk parameter / work-buffer
+        // pointers and the R2 attachment BY VALUE: after any of them changed the chunk is captured again
+        if (s->graph && (s->graph_epoch != c->epoch || s->graph_fanout != c->fanout)) { (void)hipGraphExecDestroy(s->graph); s->graph = nullptr; }
         if (!s->graph) {
+            s->graph_epoch = c->epoch; s->graph_fanout = c->fanout;
             hipGraph_t g = nullptr;
             const int step0 = s->step;
             bool ok = hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal) == hipSuccess;
@@ -1228,6 +1249,9 @@ extern "C" int tum_sim_run(tum_sim *s, int nsteps)
         while (s->graph && nsteps - done >= s->graph_steps) {
             HIPCHK(hipGraphLaunch(s->graph, c->stream));
             done += s->graph_steps; s->step += s->graph_steps;
+            // what launch() records on the host for every solve holds for the replayed solves as well
+            if (c->sn) c->xs_lazy = true;
+            c->solved = true; c->solved_pipe = c->pipe; if (c->lpt && c->batch > 1024) c->order_valid = true;
         }
     }
     for (; done < nsteps; done++)
@@ -1247,7 +1271,7 @@ extern "C" int tum_sim_get(tum_sim *s, const char *field, double *out, long long
     tum_ocp *c = s->c; const long long B = c->batch;
     const long long L = s->step < s->log_cap ? s->step : s->log_cap;
     const std::string f(field);
-    DevGuard guard(c->d.device);
+    DevGuard guard(c->d.device); GUARD_OK(guard);
     HIPCHK(hipStreamSynchronize(c->stream));
     const double *src = nullptr; long long want = 0;
     if (f == "x_sim") { src = s->dxsim; want = B * 7; }

@@ -75,7 +75,7 @@ def _pose_yref(tr, x, N, dt):
     return yref_from_ref(ref, N)
 
 
-def perturbed_pose_groups(g_lo, g_hi, N=40, dt=0.08, track_name="modena", stride=37, seed=777, noise=None):
+def perturbed_pose_groups(g_lo, g_hi, N=40, dt=0.08, track_name="modena", stride=37, seed=777, noise=None, shift=0):
     """Configs 2-style instances with shard-invariant random streams (used for config 5, SURVEY 8(d) row 5:
     "Modena poses + same noise"): instance b = pose (stride*b) mod n + N(0, diag(w)^2) from the stream (seed, b)."""
     tr = load_track(track_name)
@@ -84,14 +84,14 @@ def perturbed_pose_groups(g_lo, g_hi, N=40, dt=0.08, track_name="modena", stride
     B = g_hi - g_lo
     x0 = np.zeros((B, 8)); yref = np.zeros((B, N + 1, 6))
     for j, b in enumerate(range(g_lo, g_hi)):
-        x = _pose_state(tr, (stride * b) % n) + w * np.random.default_rng([seed, b]).standard_normal(8)
+        x = _pose_state(tr, (stride * b + shift) % n) + w * np.random.default_rng([seed, b]).standard_normal(8)
         x[3] = max(x[3], 1.0)
         x0[j] = x
         yref[j] = _pose_yref(tr, x, N, dt)
     return x0, yref
 
 
-def sigma_point_groups(g_lo, g_hi, groups_total, offsets, N=40, dt=0.08, track_name="monteblanco"):
+def sigma_point_groups(g_lo, g_hi, groups_total, offsets, N=40, dt=0.08, track_name="monteblanco", shift=0):
     """Config 3 (SURVEY 8(d) row 3): pose p = race-line point (p * n) // groups_total; its group is the nominal instance
     followed by pose + offsets[s] (the Hammersley sigma points scaled by the stds, snmpc.x0_offsets); one yref per group.
     Returns the POSE states (G, 8), the group yref (G, N+1, 6) and the expanded x0 (G*S1, 8), yref (G*S1, N+1, 6)."""
@@ -102,14 +102,14 @@ def sigma_point_groups(g_lo, g_hi, groups_total, offsets, N=40, dt=0.08, track_n
     G = g_hi - g_lo
     pose = np.zeros((G, 8)); yg = np.zeros((G, N + 1, 6))
     for j, p in enumerate(range(g_lo, g_hi)):
-        pose[j] = _pose_state(tr, (p * n) // groups_total)
+        pose[j] = _pose_state(tr, ((p * n) // groups_total + shift) % n)
         yg[j] = _pose_yref(tr, pose[j], N, dt)
     x0 = np.repeat(pose, S1, axis=0)
     x0.reshape(G, S1, 8)[:, 1:] += offsets[None]
     return pose, yg, x0, np.repeat(yg, S1, axis=0)
 
 
-def monte_carlo_groups(g_lo, g_hi, N=40, dt=0.08, track_name="lvms", pose_stride=7, draws=15, stds=None, seed=4321):
+def monte_carlo_groups(g_lo, g_hi, N=40, dt=0.08, track_name="lvms", pose_stride=7, draws=15, stds=None, seed=4321, shift=0):
     """Config 4: pose p = race-line point (7 p) mod n (LVMS), its group is the nominal instance followed
     by `draws` scenarios pose + N(0, diag(stds)^2), i.i.d. per scenario from the stream (seed, p); one yref per group.
     (The scenario generator is compute_x0dist, stochastic_mpc_utils.py:78-91, with random instead of Hammersley samples:
@@ -121,7 +121,7 @@ def monte_carlo_groups(g_lo, g_hi, N=40, dt=0.08, track_name="lvms", pose_stride
     G = g_hi - g_lo
     x0 = np.zeros((G * S1, 8)); yref = np.zeros((G * S1, N + 1, 6))
     for j, p in enumerate(range(g_lo, g_hi)):
-        x = _pose_state(tr, (pose_stride * p) % n)
+        x = _pose_state(tr, (pose_stride * p + shift) % n)
         y = _pose_yref(tr, x, N, dt)
         x0[j * S1] = x
         x0[j * S1 + 1:(j + 1) * S1] = x[None] + stds[None] * np.random.default_rng([seed, p]).standard_normal((draws, 8))
@@ -129,21 +129,25 @@ def monte_carlo_groups(g_lo, g_hi, N=40, dt=0.08, track_name="lvms", pose_stride
     return x0, yref
 
 
-def config_groups(config_id, g_lo, g_hi, groups_total, N=40, dt=0.08):
-    """x0 (n, 8), yref (n, N+1, 6) of the groups [g_lo, g_hi) of BASELINE configs[config_id - 1], group size."""
+def config_groups(config_id, g_lo, g_hi, groups_total, N=40, dt=0.08, variant=0):
+    """x0 (n, 8), yref (n, N+1, 6) of the groups [g_lo, g_hi) of BASELINE configs[config_id - 1], group size.
+    variant = 0 is the configuration as BASELINE / SURVEY 8(d) define it; variant k > 0 is a FRESH batch of the same
+    workload -- the poses moved along the race line by 3 k points and other random streams (seed + 1000 k) -- which
+    bench.py rotates through so that no step sees the batch of the step before."""
     c = CONFIGS[config_id]
+    shift, dseed = 3 * int(variant), 1000 * int(variant)
     if config_id == 2:
         # the round-1 benchmark batch (sequential stream): identical to nominal_batch(batch, offset=g_lo) for g_lo == 0
         x0, yref = nominal_batch(g_hi - g_lo, N=N, dt=dt, track_name=c["track"], stride=37,
-                                 seed=c["seed"] + (g_lo // max(g_hi - g_lo, 1)), offset=g_lo)
+                                 seed=c["seed"] + dseed + (g_lo // max(g_hi - g_lo, 1)), offset=g_lo + 5 * int(variant))
     elif config_id == 3:
         from .snmpc import hammersley_normal, x0_offsets
         off = x0_offsets(hammersley_normal(15, 3), _config.MPC["stds"])
-        _, _, x0, yref = sigma_point_groups(g_lo, g_hi, groups_total, off, N=N, dt=dt, track_name=c["track"])
+        _, _, x0, yref = sigma_point_groups(g_lo, g_hi, groups_total, off, N=N, dt=dt, track_name=c["track"], shift=shift)
     elif config_id == 4:
-        x0, yref = monte_carlo_groups(g_lo, g_hi, N=N, dt=dt, track_name=c["track"], seed=c["seed"])
+        x0, yref = monte_carlo_groups(g_lo, g_hi, N=N, dt=dt, track_name=c["track"], seed=c["seed"] + dseed, shift=shift)
     elif config_id == 5:
-        x0, yref = perturbed_pose_groups(g_lo, g_hi, N=N, dt=dt, track_name=c["track"], seed=c["seed"])
+        x0, yref = perturbed_pose_groups(g_lo, g_hi, N=N, dt=dt, track_name=c["track"], seed=c["seed"] + dseed, shift=shift)
     else:
         raise ValueError(f"no batch workload for config {config_id}")
     return x0, yref, c["group"]
