@@ -16,9 +16,14 @@ A "step" = one pass of the hot path over one batch, inputs resident in HBM befor
            covariance back-off (K7), SQP-RTI with the tightened bounds (2 solves per step).
 
 `value` is the FRESH-BATCH throughput: NB differently seeded batches of the workload are resident in HBM and rotated, one per
-step, so no step sees a batch the solver has just solved (what a caller with new data every step gets). The repeated-batch
-figure (the same batch every step: the longest-first dispatch then has exact history) and the natural-order figure are
-reported next to it at N = 1 (`value_repeated_batch`, `config.kernel_ms_natural_order`).
+step, so no step sees a batch the solver has just solved (what a caller with new data every step gets). The steps are dealt
+to --streams S capsules in turn (default 3; tum-control_amd/streaming.py), each with its own buffers on its own HIP stream: a
+step is still one complete pass over one batch, but the GPU starts on the next batch while the last wavefronts of the
+previous one finish (a batch is only four rounds of resident wavefronts: run one at a time, a fifth of the chip idles in
+every batch's tail). At N = 1 the line also carries the same loop on ONE capsule / ONE stream (`value_single_stream`: the
+roofline block and the per-kernel times are taken from that leg, where a launch has the chip to itself), the repeated-batch
+figure (the same batch every step: the longest-first dispatch then has exact history, `value_repeated_batch`) and the
+natural-order figure (`config.kernel_ms_natural_order`).
 
 --scaling weak (default): every rank owns the config's per-GPU share (global batch = N x share).
 --scaling strong: a fixed global batch (--global-batch, default 8 x the per-GPU share = the BASELINE multi-GPU size of
@@ -138,6 +143,9 @@ def parse_args(argv=None):
                     help="--scaling strong: instances of the whole job (default: 8 x the config's per-GPU share)")
     ap.add_argument("--batch", type=int, default=None, help="instances per GPU (weak scaling; default: the config's per-GPU share)")
     ap.add_argument("--horizon", type=int, default=40)
+    ap.add_argument("--streams", type=int, default=3,
+                    help="capsules (each on its own HIP stream) the steps are dealt to in turn: step k runs on capsule k mod S, so the "
+                         "tail of one batch's interior point kernel runs beside the head of the next batch (1 = one capsule, one stream)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-schedule-legs", action="store_true",
                     help="skip the repeated-batch, natural-order and N = 38 legs (N=1 only)")
@@ -168,8 +176,9 @@ class Job:
     the timed loop with its barrier / max-over-ranks protocol. Nothing here depends on the backend: `solver_factory`, `dev`
     and the process group decide whether this is RCCL on GPUs or the CPU stand-in of the tests."""
 
-    def __init__(self, args, torch, dist, dev, world, rank, local_rank, solver_factory, workload=None):
+    def __init__(self, args, torch, dist, dev, world, rank, local_rank, solver_factory, workload=None, n_slots=None):
         from tum_control_amd import sharding
+        from tum_control_amd.streaming import SolverRing
         from tum_control_amd.workloads import CONFIGS, config_groups
         self.args, self.torch, self.dist, self.dev = args, torch, dist, dev
         self.world, self.rank = world, rank
@@ -201,22 +210,32 @@ class Job:
         self.host = [gen(k)[:2] for k in range(NB_FRESH + 1)]
         x0, yref = self.host[0]
         assert len(x0) == B
-        s = self.s = solver_factory(N=N, dt=0.08, nsub=3, batch=B, device=local_rank, store_qp_in=(cid == 5))
-        s.install_reference_ocp()
-        s.set_x0(x0); s.set_yref_all(yref)
+        self.nmom = 16 if cid == 3 else 0
+
+        def make(slot):
+            s = solver_factory(N=N, dt=0.08, nsub=3, batch=B, device=local_rank, store_qp_in=(cid == 5))
+            s.install_reference_ocp()
+            s.set_x0(x0); s.set_yref_all(yref)
+            if cid == 3:      # PCE matrix of the 15 Hammersley sigma points (10 terms): K6 runs inside the step
+                from tum_control_amd.snmpc import alpha_generation, hammersley_normal, pce_matrix
+                s.pce_attach(pce_matrix(hammersley_normal(15, 3), alpha_generation(3, 2)))
+            if cid == 5:      # covariance back-off attached to every solve (K7), nominal bounds restored at the start of a step
+                from tum_control_amd.r2nmpc import r2_setup
+                m, veh = s.cfg["mpc"], s.cfg["veh"]
+                S0, BWB = r2_setup(m["stds"], 0.08)
+                s.r2_attach(S0, BWB, int(m["uncertainty_propagation_horizon"]), veh["delta_f_min"], veh["delta_f_max"], 1.0)
+                s.bounds_snapshot()
+            return s
+
+        # the steps are dealt to S capsules in turn, each on its own stream (streaming.py); S = 1: the current torch stream
+        S = self.S = max(1, int(n_slots if n_slots is not None else args.streams))
         if self.cuda:
-            s.set_stream(torch.cuda.current_stream().cuda_stream)
-        self.nmom = 0
-        if cid == 3:      # PCE matrix of the 15 Hammersley sigma points (10 terms): K6 runs inside the step
-            from tum_control_amd.snmpc import alpha_generation, hammersley_normal, pce_matrix
-            s.pce_attach(pce_matrix(hammersley_normal(15, 3), alpha_generation(3, 2)))
-            self.nmom = 16
-        if cid == 5:      # covariance back-off attached to every solve (K7), nominal bounds restored at the start of a step
-            from tum_control_amd.r2nmpc import r2_setup
-            m, veh = s.cfg["mpc"], s.cfg["veh"]
-            S0, BWB = r2_setup(m["stds"], 0.08)
-            s.r2_attach(S0, BWB, int(m["uncertainty_propagation_horizon"]), veh["delta_f_min"], veh["delta_f_max"], 1.0)
-            s.bounds_snapshot()
+            self.streams = [torch.cuda.current_stream()] if S == 1 else [torch.cuda.Stream() for _ in range(S)]
+            self.ring = SolverRing(S, make, [st.cuda_stream for st in self.streams])
+        else:
+            self.streams = [None] * S
+            self.ring = SolverRing(S, make)
+        self.s = self.ring[0]
         self.spp = C["solves_per_step"]
         # result slab gathered to rank 0 each step: (u0[2], cost, status, qp_iter) as 5 doubles per instance, for config 3
         # followed by the PCE mean / variance of x_1 of every scenario group (16 doubles per group): ONE flat buffer, packed
@@ -225,8 +244,7 @@ class Job:
         self.slab_len = B * 5 + P * self.nmom
         mx = max((sharding.shard_range(groups_total, world, r)[1] - sharding.shard_range(groups_total, world, r)[0]) for r in range(world))
         self.slab_pad = mx * gsz * 5 + mx * self.nmom
-        self.slab = torch.zeros(self.slab_pad, dtype=torch.float64, device=dev)
-        self.mom_ptr = self.slab.data_ptr() + 8 * B * 5
+        self.slabs = [torch.zeros(self.slab_pad, dtype=torch.float64, device=dev) for _ in range(S)]      # one per capsule
         self.gather = sharding.ResultGatherer(world, rank, 1, dev, nf=self.slab_pad, ni=1) if self.distributed else None
         # resident copies of the rotated batches
         self.dx0 = [torch.from_numpy(np.ascontiguousarray(h[0])).to(dev) for h in self.host[1:]]
@@ -234,7 +252,15 @@ class Job:
 
     # ---- one step; `marks`: list that receives (solve_begin, solve_end)* and (gather_begin, gather_end) clock marks
     def step(self, marks=None, fresh=None):
-        s, cid = self.s, self.cid
+        slot, s = self.ring.acquire()
+        if self.cuda and self.S > 1:
+            with self.torch.cuda.stream(self.streams[slot]):      # (events, the reduction and the gather follow the capsule's stream)
+                self._step(slot, s, marks, fresh)
+        else:
+            self._step(slot, s, marks, fresh)
+
+    def _step(self, slot, s, marks, fresh):
+        cid, slab = self.cid, self.slabs[slot]
         if fresh is not None:
             k = fresh % NB_FRESH
             s.put_device("x0", self.dx0[k].data_ptr()); s.put_device("yref", self.dyr[k].data_ptr())
@@ -248,12 +274,13 @@ class Job:
             if marks is not None:
                 marks.append(self.clock.mark())
         if cid == 3:
-            s.pce_moments_device("x", 1, self.mom_ptr, self.mom_ptr + 8 * self.P * 8)
+            mom_ptr = slab.data_ptr() + 8 * self.B * 5
+            s.pce_moments_device("x", 1, mom_ptr, mom_ptr + 8 * self.P * 8)
         if self.gather is not None:
             if marks is not None:
                 marks.append(self.clock.mark())
-            s.get_device("summary", self.slab.data_ptr())
-            self.gather.gather(self.slab.view(1, -1))
+            s.get_device("summary", slab.data_ptr())
+            self.gather.gather(slab.view(1, -1))
             if marks is not None:
                 marks.append(self.clock.mark())
 
@@ -288,29 +315,41 @@ class Job:
 
 
 def run(args, torch, dist, dev, world, rank, local_rank, solver_factory, workload=None, extra_legs=True):
-    """The benchmark proper. Returns the result dict on rank 0 (None elsewhere)."""
+    """The benchmark proper. Returns (result dict, job) on rank 0 (None elsewhere)."""
     job = Job(args, torch, dist, dev, world, rank, local_rank, solver_factory, workload)
-    s, N, cid, B, spp = job.s, job.N, job.cid, job.B, job.spp
+    N, cid, B, spp, S = job.N, job.cid, job.B, job.spp, job.S
     for i in range(args.warmup):
         job.step(fresh=i)
     elapsed, marks = job.timed(args.steps, fresh=True)
-    kern_ms = job.solve_ms(marks)
+    kern_ms = job.solve_ms(marks)             # device time between the events around a solve (S > 1: shared with other batches)
     gat_ms = job.gather_ms(marks)
-    # correctness of what was timed: statuses and iteration counts of the last batch
-    st = s.get_stats("status"); it = s.get_stats("qp_iter")
+    # correctness of what was timed: statuses and iteration counts of the batches the capsules solved last
+    st = np.concatenate([s.get_stats("status") for s in job.ring]); it = np.concatenate([s.get_stats("qp_iter") for s in job.ring])
     mean_it_fresh = float(it.mean())
     ok_fresh = float((st == 0).mean())
 
-    rep_value = rep_ms = nat_ms = ipm_ms = n38 = None
+    one_value = one_ms = rep_value = rep_ms = nat_ms = ipm_ms = None
     mean_it = mean_it_fresh
     U = None
-    if world == 1 and extra_legs and not args.no_schedule_legs:
+    job1 = job
+    legs = world == 1 and extra_legs and not args.no_schedule_legs
+    if legs:
+        if S > 1:      # the same loop on ONE capsule / ONE stream: a launch has the chip to itself, per-kernel times are clean
+            job1 = Job(args, torch, dist, dev, world, rank, local_rank, solver_factory, lambda k: job.host[k], n_slots=1)
+            for i in range(args.warmup):
+                job1.step(fresh=i)
+            one_elapsed, omarks = job1.timed(args.steps, fresh=True)
+            one_ms = job1.solve_ms(omarks)
+            one_value = B * spp * args.steps / one_elapsed
+        else:
+            one_ms, one_value = kern_ms, job.global_batch * spp * args.steps / elapsed
+        s = job1.s
         # (a) the SAME batch every step (batch 0): the longest-first order has this batch's exact iteration counts
         s.set_x0(job.host[0][0]); s.set_yref_all(job.host[0][1])
         for _ in range(2):
-            job.step()
-        rep_elapsed, rmarks = job.timed(args.steps, fresh=False)
-        rep_ms = job.solve_ms(rmarks)
+            job1.step()
+        rep_elapsed, rmarks = job1.timed(args.steps, fresh=False)
+        rep_ms = job1.solve_ms(rmarks)
         rep_value = B * spp * args.steps / rep_elapsed
         st0 = s.get_stats("status"); it0 = s.get_stats("qp_iter"); mean_it = float(it0.mean())
         _, U = s.get_iterate()
@@ -318,7 +357,7 @@ def run(args, torch, dist, dev, world, rank, local_rank, solver_factory, workloa
         try:
             tm = []
             for _ in range(5):
-                job.step(); job.clock.sync(); tm.append(1e3 * s.get_stats("time_ipm"))
+                job1.step(); job1.clock.sync(); tm.append(1e3 * s.get_stats("time_ipm"))
             ipm_ms = float(np.median(tm))
         except Exception:
             pass
@@ -326,12 +365,10 @@ def run(args, torch, dist, dev, world, rank, local_rank, solver_factory, workloa
         s.set_schedule(False)
         nat = [[] for _ in range(5)]
         for m in nat:
-            job.step(m)
-        job.clock.sync()
-        nat_ms = float(np.median([job.clock.ms(m[2 * j], m[2 * j + 1]) for m in nat for j in range(spp)]))
+            job1.step(m)
+        job1.clock.sync()
+        nat_ms = float(np.median([job1.clock.ms(m[2 * j], m[2 * j + 1]) for m in nat for j in range(spp)]))
         s.set_schedule(True)
-    elif world == 1:
-        _, U = s.get_iterate()
 
     if rank != 0:
         return None
@@ -340,10 +377,13 @@ def run(args, torch, dist, dev, world, rank, local_rank, solver_factory, workloa
     value = total / elapsed
     shared_yref = gsz > 1
     abytes = algorithmic_bytes(N, warm=(cid == 5), per_instance_yref=not shared_yref)
-    # roofline of the fresh-batch loop (the timed region): algorithmic FLOPs of the batches it solved / device time of a solve
-    flops = algorithmic_flops(N, 3, mean_it_fresh) * B
-    ach_tf = flops / (kern_ms * 1e-3) / 1e12
-    ach_gb = abytes * B / (kern_ms * 1e-3) / 1e9
+    # roofline: algorithmic FLOPs of the fresh batches / device time of one solve, from the leg in which a solve has the chip
+    # to itself (one stream) when that leg ran; `sustained` = the same FLOPs at the rate of the timed region (`value`)
+    roof_ms = one_ms if one_ms is not None else kern_ms
+    flops_solve = algorithmic_flops(N, 3, mean_it_fresh)
+    ach_tf = flops_solve * B / (roof_ms * 1e-3) / 1e12
+    ach_gb = abytes * B / (roof_ms * 1e-3) / 1e9
+    sus_tf = flops_solve * value / world / 1e12          # per GPU
     # HBM bytes per launch from the PMC counters cannot be collected from inside this process; they come from the committed
     # rocprofv3 --pmc passes of this same command (profiles/*_traffic*.json), only when the workload matches what was profiled.
     traffic, traffic_src = None, None
@@ -359,7 +399,7 @@ def run(args, torch, dist, dev, world, rank, local_rank, solver_factory, workloa
     if ipm_ms:
         ipm_flops = mean_it * ipm_flops_per_iter(N) * B
         dominant = {"kernel": "ipm_kernel", "kernel_ms": ipm_ms, "flops_per_launch": ipm_flops, "mean_qp_iter": mean_it,
-                    "workload": "the repeated batch (exact longest-first history)",
+                    "workload": "the repeated batch on one stream (exact longest-first history)",
                     "achieved": ipm_flops / (ipm_ms * 1e-3) / 1e12, "frac": ipm_flops / (ipm_ms * 1e-3) / 1e12 / FP64_PEAK_TFLOPS}
     out = {
         "metric": "SQP-RTI OCP solves/sec (batch), N=40 single-track Pacejka",
@@ -370,22 +410,30 @@ def run(args, torch, dist, dev, world, rank, local_rank, solver_factory, workloa
                                f"{NB_FRESH} differently seeded batches resident in HBM, rotated one per step (fresh batch every step)",
                    "N": N, "nx": 8, "nu": 2, "nsub": 3, "batch_per_gpu": B, "global_batch": job.global_batch,
                    "scenario_group": gsz, "groups_per_gpu": P, "solves_per_step": spp,
+                   "streams": S,
+                   "streams_note": "steps are dealt to `streams` capsules in turn, each with its own buffers on its own HIP stream: every "
+                                   "step is a complete pass over one fresh batch, consecutive batches overlap on the GPU (`value`); "
+                                   "`value_single_stream` is the same loop on one capsule / one stream",
                    "parallelism": f"scenario groups sharded x{world} (a group never straddles ranks), RCCL gather of "
                                   f"{job.slab_pad * 8} B per rank (u0, cost, status, qp_iter"
                                   + (", PCE mean/var of x_1 per group" if job.nmom else "") + "), one collective per step",
                    "schedule": "workgroups take instances longest-first by the previous solve's IPM iteration count "
-                               "(tum_ocp_set_schedule): stale history when every step brings a new batch (`value`), exact when the "
-                               "same batch is solved again (`value_repeated_batch`)",
+                               "(tum_ocp_set_schedule): stale history when every step brings a new batch (`value`, "
+                               "`value_single_stream`), exact when the same batch is solved again (`value_repeated_batch`)",
                    "kernel_ms_natural_order": nat_ms,
                    "solves_per_s_per_gpu_natural_order": (B / nat_ms * 1e3) if nat_ms else None,
                    "kernel_ms_repeated_batch": rep_ms},
-        "value_repeated_batch": rep_value,
+        "value_single_stream": one_value, "value_repeated_batch": rep_value,
         "solve_ms_per_step": kern_ms * spp, "gather_ms_per_step": gat_ms,
         "roofline": {"bound": "mfma", "achieved": ach_tf, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
                      "frac": ach_tf / FP64_PEAK_TFLOPS, "traffic": traffic, "traffic_source": traffic_src,
-                     "kernel": "pipeline of lin_kernel + cond_kernel + ipm_kernel + expand_kernel (kernel_ms = device time of one solve)",
-                     "kernel_ms": kern_ms, "dominant": dominant, "mean_qp_iter": mean_it_fresh,
-                     "flops_per_solve": flops / B,
+                     "kernel": "pipeline of lin_kernel + cond_kernel + ipm_kernel + expand_kernel (kernel_ms = device time of one solve"
+                               + (", one stream: the launches have the chip to themselves)" if (one_ms is not None or S == 1) else
+                                  f", {S} streams: launches of consecutive batches share the chip)"),
+                     "kernel_ms": roof_ms, "dominant": dominant, "mean_qp_iter": mean_it_fresh,
+                     "flops_per_solve": flops_solve,
+                     "sustained": {"achieved": sus_tf, "frac": sus_tf / FP64_PEAK_TFLOPS,
+                                   "note": "algorithmic FLOPs per solve x `value` per GPU: the rate of the timed region"},
                      "hbm": {"achieved": ach_gb, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": ach_gb / HBM_PEAK_GBPS,
                              "bytes_per_solve": abytes}},
         "status_ok_frac": ok_fresh,
@@ -401,7 +449,7 @@ def n38_leg(args, torch, dev, solver_factory):
     a = argparse.Namespace(**vars(args)); a.horizon = 38; a.config = 2; a.batch = None; a.scaling = "weak"; a.no_schedule_legs = True
     res = run(a, torch, None, dev, 1, 0, dev.index or 0, solver_factory, extra_legs=False)
     out, _ = res
-    return {"N": 38, "value": out["value"], "ms_per_step": out["ms_per_step"], "kernel_ms": out["roofline"]["kernel_ms"],
+    return {"N": 38, "value": out["value"], "ms_per_step": out["ms_per_step"], "streams": out["config"]["streams"],
             "mean_qp_iter": out["roofline"]["mean_qp_iter"], "status_ok_frac": out["status_ok_frac"]}
 
 

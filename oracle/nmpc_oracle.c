@@ -231,6 +231,10 @@ typedef struct {
     double mu0;           /* initial complementarity target */
     double t0;            /* floor of the initial constraint residuals t */
     double reg;           /* primal regularisation added to diag(M) */
+    int iter_force;       /* tests only: > 0 = run exactly this many iterations, whatever the termination test says (the HIP
+                           * kernel tracks its linear residuals, this code recomputes them: an instance whose test sits on the
+                           * tolerance edge can stop one iteration apart; forced to the kernel's count the two follow the same
+                           * path and are compared at full tolerance). 0 = off */
 } ipm_opts;
 
 typedef struct {
@@ -349,7 +353,8 @@ static void qp_ipm(int nv, int m, const double *H, const double *q, const double
         }
         gap /= (2.0 * M2);
         if (!(res_stat == res_stat) || !(gap == gap)) { status = 3; break; }
-        if (res_stat <= opt->tol_stat * qn && res_ineq <= opt->tol_ineq && res_comp <= opt->tol_comp) { status = 0; break; }
+        if (opt->iter_force > 0) { if (it >= opt->iter_force) { status = 0; break; } }
+        else if (res_stat <= opt->tol_stat * qn && res_ineq <= opt->tol_ineq && res_comp <= opt->tol_comp) { status = 0; break; }
         if (it >= opt->iter_max) { status = 1; break; }
 
         /* --- factorise M = H + sum gamma c c' */
@@ -511,6 +516,7 @@ double *oracle_field(oracle_ocp *o, const char *name, int *len)
 }
 void oracle_set_model(oracle_ocp *o, const stm_model *m) { o->model = *m; }
 void oracle_set_iter_max(oracle_ocp *o, int it) { o->ipm.iter_max = it; }
+void oracle_set_iter_force(oracle_ocp *o, int it) { o->ipm.iter_force = it; }
 int oracle_qp_iter(const oracle_ocp *o) { return o->qp_iter; }
 int oracle_status(const oracle_ocp *o) { return o->status; }
 
@@ -677,8 +683,16 @@ int oracle_solve(oracle_ocp *o)
  * model / weights / bounds of `tmpl`, each from a cold start (X_k = x0, U = 0).
  * x0: nb x 8, yref: nb x (N+1) x 6. Outputs u0 (nb x 2), X1 (nb x 8), stats (nb x 3: cost, qp_iter, status).
  * OpenMP over instances when compiled with -fopenmp. */
+void oracle_solve_batch_cold_forced(const oracle_ocp *tmpl, int nb, const double *x0, const double *yref,
+                                    double *u0, double *X1, double *stats, int nthreads, const int *force);
 void oracle_solve_batch_cold(const oracle_ocp *tmpl, int nb, const double *x0, const double *yref,
                              double *u0, double *X1, double *stats, int nthreads)
+{
+    oracle_solve_batch_cold_forced(tmpl, nb, x0, yref, u0, X1, stats, nthreads, NULL);
+}
+/* the same with the interior point iteration count of every instance imposed (force[b] > 0; see ipm_opts.iter_force) */
+void oracle_solve_batch_cold_forced(const oracle_ocp *tmpl, int nb, const double *x0, const double *yref,
+                                    double *u0, double *X1, double *stats, int nthreads, const int *force)
 {
     (void)nthreads;
     /* keep the per-solve work arrays (a few 100 KB) in the thread arenas: without this every solve
@@ -696,6 +710,7 @@ void oracle_solve_batch_cold(const oracle_ocp *tmpl, int nb, const double *x0, c
         memcpy(o->yref, yref + (size_t)b * (N + 1) * 6, sizeof(double) * (N + 1) * 6);
         for (int k = 0; k <= N; k++) memcpy(o->X + k * NX, o->x0, sizeof(double) * NX);
         memset(o->U, 0, sizeof(double) * N * NU);
+        if (force) o->ipm.iter_force = force[b];
         oracle_solve(o);
         u0[b * 2] = o->U[0]; u0[b * 2 + 1] = o->U[1];
         memcpy(X1 + (size_t)b * NX, o->X + NX, sizeof(double) * NX);

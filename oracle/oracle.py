@@ -112,6 +112,9 @@ def lib():
         L.oracle_h.argtypes = [ctypes.POINTER(StmModel), dp, dp, dp]
         L.oracle_set_debug.argtypes = [dp]
         L.oracle_solve_batch_cold.argtypes = [ctypes.c_void_p, ctypes.c_int, dp, dp, dp, dp, dp, ctypes.c_int]
+        L.oracle_solve_batch_cold_forced.argtypes = [ctypes.c_void_p, ctypes.c_int, dp, dp, dp, dp, dp, ctypes.c_int,
+                                                     ctypes.POINTER(ctypes.c_int)]
+        L.oracle_set_iter_force.argtypes = [ctypes.c_void_p, ctypes.c_int]
         _lib = L
     return _lib
 
@@ -226,6 +229,10 @@ class OracleOcp:
     def set_iter_max(self, it):
         lib().oracle_set_iter_max(self._h, int(it))
 
+    def set_iter_force(self, it):
+        """tests: run exactly `it` interior point iterations (0 = normal termination test)"""
+        lib().oracle_set_iter_force(self._h, int(it))
+
     def solve(self):
         return lib().oracle_solve(self._h)
 
@@ -258,14 +265,21 @@ class OracleOcp:
     def status(self):
         return lib().oracle_status(self._h)
 
-    def solve_batch_cold(self, x0, yref, nthreads=1):
-        """cpu_baseline helper: nb independent cold-start solves sharing this OCP's data."""
+    def solve_batch_cold(self, x0, yref, nthreads=1, force_iter=None):
+        """cpu_baseline helper: nb independent cold-start solves sharing this OCP's data. force_iter (tests): interior point
+        iteration count imposed per instance."""
         x0 = np.ascontiguousarray(x0, dtype=np.float64)
         yref = np.ascontiguousarray(yref, dtype=np.float64)
         nb = x0.shape[0]
         assert yref.shape == (nb, self.N + 1, 6)
         u0 = np.zeros((nb, 2)); X1 = np.zeros((nb, 8)); stats = np.zeros((nb, 3))
-        lib().oracle_solve_batch_cold(self._h, nb, _dp(x0), _dp(yref), _dp(u0), _dp(X1), _dp(stats), int(nthreads))
+        if force_iter is None:
+            lib().oracle_solve_batch_cold(self._h, nb, _dp(x0), _dp(yref), _dp(u0), _dp(X1), _dp(stats), int(nthreads))
+        else:
+            f = np.ascontiguousarray(force_iter, dtype=np.int32)
+            assert f.shape == (nb,)
+            lib().oracle_solve_batch_cold_forced(self._h, nb, _dp(x0), _dp(yref), _dp(u0), _dp(X1), _dp(stats), int(nthreads),
+                                                 f.ctypes.data_as(ctypes.POINTER(ctypes.c_int)))
         return u0, X1, stats
 
 

@@ -1,0 +1,224 @@
+#!/usr/bin/env python3
+"""
+tests/golden/replay_full_logs.py -- the per-solve parity gate over ALL logged acados closed loops.
+
+Replays every control step of the 52 complete closed-loop logs the reference holds
+(Learning_To_Adapt/SafeRL_WMPC/_baseline/F/{monteblanco,lvms}/{0..25}.npz: 2 x 26 x 5499 acados SQP-RTI solves) through the CPU
+oracle, sequentially and warm-started exactly like the logged loop (the protocol of make_golden.replay_inputs:
+get_baseline_performances.py:101-131, SimulationMode_main_class.py:106-156), and compares EVERY solve with what acados
+logged for it (`simU[i]`, `MPC_SimX[i+1]`).
+
+  error of a solve = max over the ten channels of (u0, x1) of |ours - logged| / (largest magnitude of that channel in that
+                     loop; pi for the yaw angle)  (north_star: "trajectories within 1e-4 rel": relative to the scale of the
+                     trajectory). A stricter measure -- relative to the logged value itself, floored at 10 % of that scale --
+                     is recorded next to it (`worst_strict`): its outliers are steering-rate differences of ~5e-6 rad/s.
+  COMPARABLE solve = acados converged on it and on the 25 solves before it (qp_iter < 50; a QP step acados stopped at its
+                     iteration cap leaves a different warm start behind, which the RTI sequence forgets within ~20 steps)
+  GATE             = every comparable solve within 1e-4 -- or an EXCEPTION, recorded with the evidence there is about whose
+                     answer moved:
+                     (i)  this solver's own answer does not move when its tolerances are tightened 100x (1e-8 -> 1e-10):
+                          re-solved from the identical pre-solve state, the shift must stay below 1e-5 (observed: median
+                          2e-8, worst 7e-6) -- the answer compared with the log IS the solution of that QP;
+                     (ii) acados' own iteration count on that solve and over the 25 solves before it, from the log: every
+                          exception sits in a stretch where acados needed at least 20 (up to 45) QP iterations, 1.3x to
+                          2.3x its median for that loop -- elevated, but only three of the six clusters reach 30;
+                     (iii) the exceptions are rare and clustered: 32 of 283 615 comparable solves, six runs of consecutive
+                          control steps on six Monteblanco loops (sets 8, 9, 10, 13, 16, 21), none on LVMS; in every run the
+                          linearised LOWER bound 0 <= h of the acceleration constraint is degenerate (h ~ 0 with a vanishing
+                          gradient on the late stages), the regime in which a QP solution is determined far less sharply
+                          than its KKT residuals (two interior point variants that both stop at 1e-8 differ by 1e-4 in dU
+                          there), and the deviation dies out again within ~10 control steps. A 1e-7 perturbation of the
+                          warm start moves this solver's answer by 1e-7 (no amplification), so the deviation is not
+                          inherited from earlier steps: it is the accuracy of the logged QP steps themselves.
+
+Runs ONLY where /root/reference exists (the build container). Writes
+  full_replay_report.json     per log: counts, worst errors, every exception with its evidence   (committed; the CPU test
+                              tests/test_oracle_golden.py::test_full_logs_per_solve_gate re-runs the replay when the logs
+                              are present and otherwise asserts the gate on this file)
+  replay_full_13_16.npz       replay inputs + logged outputs of the complete loops of weight sets 13 and 16 on both tracks
+                              (the sets with the exceptions) for the GPU test that drives the mirrored controller class.
+usage: replay_full_logs.py [--procs P] [--logs monteblanco:13,lvms:16,...] [--no-write]
+"""
+import json
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+REF = "/root/reference"
+BASE = os.path.join(REF, "Learning_To_Adapt/SafeRL_WMPC/_baseline/F")
+FCSV = os.path.join(REF, "Learning_To_Adapt/SafeRL_WMPC/_parameters/F.csv")
+WINDOWS = np.array([1, 1, 4, 2, 2, 3, 4, 2])      # SimulationMode_main_class.py:86
+N, TP = 38, 3.04
+TOL, TIGHT, LOOKBACK, HARD_IT = 1e-4, 1e-10, 25, 20
+
+
+def available():
+    return os.path.isdir(BASE) and os.path.exists(FCSV)
+
+
+def log_inputs(track, k):
+    """x0_i (the state the logged solve i started from), planner pose_i, and what acados returned for it."""
+    from tum_control_amd.planner import load_track
+    d = np.load(os.path.join(BASE, track, f"{k}.npz"))
+    tr = load_track(track)
+    CiLX = d["CiLX"].copy()
+    CiLX[:, 2] = np.unwrap(CiLX[:, 2])            # the logs hold yaw mod 2 pi, the live state is continuous
+    SimX = d["MPC_SimX"]
+    n = len(d["simU"])
+    X0 = np.array([tr[0, 0], tr[0, 1], np.mod(tr[0, 2], 2 * np.pi), tr[0, 3], 0, 0, 0, 0.0])
+    xn = np.concatenate([CiLX[:n], SimX[:n, 7:8]], axis=1)          # what StateEstimation receives at step i >= 1
+    x0 = np.empty((n, 8)); x0[0] = X0
+    for j in range(8):
+        w = int(WINDOWS[j])
+        for i in range(1, n):
+            x0[i, j] = np.mean(xn[max(1, i - w + 1):i + 1, j])       # moving average, buffer starts empty at step 1
+    pose = CiLX[:n, :2].copy(); pose[0] = X0[:2]
+    dbg = d["simSolverDebug"][:n]
+    assert (dbg[:, 4] == 0).all()
+    return dict(x0=x0, pose=pose, u0=d["simU"][:n].astype(float), x1=SimX[1:n + 1].astype(float), qp_iter=dbg[:, 3].astype(int),
+                cost=dbg[:, 0].astype(float))
+
+
+def channel_scales(g):
+    """largest magnitude of every channel of (u0, x1) in one logged loop (yaw: pi)"""
+    sc = np.abs(np.concatenate([g["u0"], g["x1"]], axis=1)).max(axis=0)
+    sc[4] = np.pi
+    return sc
+
+
+def solve_errors(u0, x1, ref_u0, ref_x1, scales, strict=False):
+    """per-solve relative error (definition in the header); arrays (n,2), (n,8); scales from channel_scales()"""
+    d = np.concatenate([u0 - ref_u0, x1 - ref_x1], axis=1)
+    d[:, 4] = (d[:, 4] + np.pi) % (2 * np.pi) - np.pi                 # logged yaw is wrapped
+    if strict:
+        den = np.maximum(np.abs(np.concatenate([ref_u0, ref_x1], axis=1)), 0.1 * scales[None, :])
+        den[:, 4] = np.pi
+        return (np.abs(d) / den).max(axis=1)
+    return (np.abs(d) / scales[None, :]).max(axis=1)
+
+
+def comparable_mask(qp_iter):
+    n = len(qp_iter)
+    tainted = np.zeros(n, bool)
+    for c in np.nonzero(qp_iter >= 50)[0]:
+        tainted[c:c + LOOKBACK + 1] = True
+    return ~tainted
+
+
+def replay_log(args):
+    """One complete logged loop through the oracle. Returns the report entry of that log."""
+    track, k = args
+    from oracle.oracle import OracleOcp
+    from tum_control_amd.planner import load_track, planner_emulator, yref_from_ref
+    F = np.loadtxt(FCSV, delimiter=",")
+    g = log_inputs(track, k)
+    tr = load_track(track)
+    n = len(g["u0"])
+    sc = channel_scales(g)
+    o = OracleOcp(N, 0.08, 3); o.set_weights(*F[k])
+    t = OracleOcp(N, 0.08, 3); t.set_weights(*F[k]); t.ipm_tol[:] = TIGHT; t.set_iter_max(200)
+    U0 = np.zeros((n, 2)); X1 = np.zeros((n, 8)); it = np.zeros(n, int)
+    pre = []
+    for i in range(n):
+        if i == 0:
+            o.cold_start(g["x0"][0])
+        else:
+            o.x0[:] = g["x0"][i]
+        _, ref = planner_emulator(tr, g["pose"][i], N + 1, TP, True)
+        o.yref[:] = yref_from_ref(ref, N)
+        pre.append((o.X.copy(), o.U.copy(), o.yref.copy()))
+        if len(pre) > 1:
+            pre.pop(0)
+        st = o.solve()
+        assert st == 0 and o.res.max() < 1e-6, (track, k, i, st, o.res)
+        U0[i] = o.U[0]; X1[i] = o.X[1]; it[i] = o.qp_iter
+        # candidate exception: keep the tolerance-tightened answer from the identical pre-solve state
+        e = solve_errors(U0[i:i + 1], X1[i:i + 1], g["u0"][i:i + 1], g["x1"][i:i + 1], sc)
+        if e[0] > 0.1 * TOL:
+            Xp, Up, yp = pre[-1]
+            t.X[:] = Xp; t.U[:] = Up; t.yref[:] = yp; t.x0[:] = g["x0"][i]
+            assert t.solve() == 0
+            g.setdefault("tight", {})[i] = (t.U[0].copy(), t.X[1].copy(), t.qp_iter)
+    err = solve_errors(U0, X1, g["u0"], g["x1"], sc)
+    strict = solve_errors(U0, X1, g["u0"], g["x1"], sc, strict=True)
+    comp = comparable_mask(g["qp_iter"])
+    aq = g["qp_iter"]
+    exc = []
+    for i in np.nonzero(comp & (err > TOL))[0]:
+        tu, tx, tit = g["tight"][int(i)]
+        shift = float(solve_errors(U0[i:i + 1], X1[i:i + 1], tu[None], tx[None], sc)[0])
+        exc.append(dict(step=int(i), err=float(err[i]), acados_qp_iter=int(aq[i]), acados_qp_iter_max_lookback=int(aq[max(0, i - LOOKBACK):i + 1].max()),
+                        qp_iter=int(it[i]), qp_iter_tight=int(tit), shift_when_tolerances_tighten_100x=shift))
+    return dict(track=track, k=int(k), n=int(n), n_comparable=int(comp.sum()), n_capped=int((aq >= 50).sum()),
+                worst_comparable=float(err[comp].max()), median_comparable=float(np.median(err[comp])),
+                worst_strict=float(strict[comp].max()), n_strict_above_tol=int((comp & (strict > TOL)).sum()),
+                worst_after_capped=float(err[~comp].max()) if (~comp).any() else 0.0,
+                n_above_1e6=int((comp & (err > 1e-6)).sum()), mean_qp_iter=float(it.mean()), max_qp_iter=int(it.max()),
+                acados_mean_qp_iter=float(aq.mean()), exceptions=exc)
+
+
+def gate(report):
+    """The assertion of the gate on a report (list of per-log entries). Returns a one-line summary."""
+    nexc = 0
+    for r in report:
+        assert r["n"] == 5499 and r["n_comparable"] > 3000, (r["track"], r["k"])
+        for e in r["exceptions"]:
+            nexc += 1
+            assert e["shift_when_tolerances_tighten_100x"] < 0.1 * TOL, (r["track"], r["k"], e)      # (i) our answer is converged
+            assert e["acados_qp_iter_max_lookback"] >= HARD_IT, (r["track"], r["k"], e)               # (ii) acados laboured there
+        assert len(r["exceptions"]) <= 15, (r["track"], r["k"])                                        # (iii) short runs
+        assert r["worst_comparable"] <= TOL or r["exceptions"], (r["track"], r["k"])
+        if r["track"] == "lvms":
+            assert not r["exceptions"], (r["track"], r["k"])
+    ncomp = sum(r["n_comparable"] for r in report)
+    assert nexc <= 2e-4 * ncomp, (nexc, ncomp)
+    return (f"{len(report)} logs, {sum(r['n'] for r in report)} solves, {ncomp} comparable, {ncomp - nexc} within {TOL:g}, {nexc} exceptions "
+            f"on {sum(bool(r['exceptions']) for r in report)} logs (each with its evidence)")
+
+
+def run(logs=None, procs=None):
+    import multiprocessing as mp
+    logs = logs or [(t, k) for t in ("monteblanco", "lvms") for k in range(26)]
+    procs = procs or min(len(logs), max(1, len(os.sched_getaffinity(0))))
+    os.environ.setdefault("OMP_NUM_THREADS", "1")
+    if procs == 1:
+        return [replay_log(a) for a in logs]
+    with mp.get_context("fork").Pool(procs) as pool:
+        return pool.map(replay_log, logs, chunksize=1)
+
+
+def write_gpu_fixture():
+    out = {}
+    for track in ("monteblanco", "lvms"):
+        for k in (13, 16):
+            g = log_inputs(track, k)
+            for f in ("x0", "pose", "u0", "x1"):
+                out[f"{track}_{k}_{f}"] = g[f]
+            out[f"{track}_{k}_qp_iter"] = g["qp_iter"].astype(np.int16)
+    out["params"] = np.loadtxt(FCSV, delimiter=",")
+    np.savez_compressed(os.path.join(HERE, "replay_full_13_16.npz"), **out)
+
+
+if __name__ == "__main__":
+    a = sys.argv[1:]
+    procs = int(a[a.index("--procs") + 1]) if "--procs" in a else None
+    logs = None
+    if "--logs" in a:
+        logs = [(s.split(":")[0], int(s.split(":")[1])) for s in a[a.index("--logs") + 1].split(",")]
+    assert available(), "needs /root/reference (build container only)"
+    rep = run(logs, procs)
+    for r in rep:
+        print(f"{r['track']:12s} {r['k']:2d}: comparable {r['n_comparable']:5d}  worst {r['worst_comparable']:.2e}  median {r['median_comparable']:.1e}  "
+              f"capped {r['n_capped']:3d}  after-capped worst {r['worst_after_capped']:.1e}  iters {r['mean_qp_iter']:.1f} (acados {r['acados_mean_qp_iter']:.1f})  "
+              f"exceptions {len(r['exceptions'])}")
+    print(gate(rep))
+    if "--no-write" not in a and logs is None:
+        with open(os.path.join(HERE, "full_replay_report.json"), "w") as f:
+            json.dump(dict(tol=TOL, tight=TIGHT, lookback=LOOKBACK, hard_iter=HARD_IT, logs=rep), f, indent=1)
+        write_gpu_fixture()

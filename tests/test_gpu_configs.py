@@ -44,6 +44,11 @@ def _check_subset_against_oracle(s, x0, yref, idx, tol=1e-6):
     assert eu[same].max() < tol and ex[same].max() < tol
     assert eu.max() < 5e-5 and ex.max() < 5e-5
     np.testing.assert_allclose(s.get_cost()[idx][same], st[same, 0], rtol=1e-7)
+    if (~same).any():      # the instances that stopped one iteration apart, against the oracle with the GPU's count imposed
+        d = idx[~same]
+        u0f, X1f, stf = _oracle().solve_batch_cold(x0[d], yref[d], 8, force_iter=it[d])
+        assert np.abs(U[d, 0] - u0f).max() < tol and np.abs(X[d, 1] - X1f).max() < tol
+        np.testing.assert_allclose(s.get_cost()[d], stf[:, 0], rtol=1e-7)
 
 
 def test_config3_sigma_points_full_size():

@@ -57,8 +57,12 @@ def test_pipeline_matches_fused_and_oracle(N, B):
     X, U = s.get_iterate()
     idx = np.unique(np.linspace(0, B - 1, min(B, 40)).astype(int))
     u0, X1, st = _oracle(N).solve_batch_cold(x0[idx], yref[idx], 8)
-    same = s.get_stats("qp_iter")[idx] == st[:, 1]
+    itg = s.get_stats("qp_iter")[idx]
+    same = itg == st[:, 1]
     assert same.mean() > 0.9
+    if (~same).any():      # (one iteration apart on the tolerance edge: the oracle with the kernel's count imposed)
+        u0f, X1f, stf = _oracle(N).solve_batch_cold(x0[idx][~same], yref[idx][~same], 8, force_iter=itg[~same])
+        u0[~same] = u0f; X1[~same] = X1f; st[~same] = stf; same[:] = True
     assert np.abs(U[idx, 0] - u0)[same].max() < 1e-6 and np.abs(X[idx, 1] - X1)[same].max() < 1e-6
     np.testing.assert_allclose(s.get_cost()[idx][same] if B > 1 else np.atleast_1d(s.get_cost())[same], st[same, 0], rtol=1e-7)
 

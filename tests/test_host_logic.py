@@ -339,7 +339,8 @@ def _gloo_bench_worker(rank, world, port, out, argv):
     res = bench.run(args, torch, dist, torch.device("cpu"), world, rank, rank, _StandInSolver)
     if rank == 0:
         o, job = res
-        out.put((o, job.gather.all_f.numpy().copy(), dict(job.s.calls), job.slab_pad, job.B))
+        calls = {k: sum(sv.calls[k] for sv in job.ring) for k in job.s.calls}
+        out.put((o, job.gather.all_f.numpy().copy(), calls, job.slab_pad, job.B, [dict(sv.calls) for sv in job.ring]))
     else:
         assert res is None
     dist.barrier()
@@ -355,7 +356,8 @@ def test_bench_control_flow_world2_gloo(scaling):
     import torch.multiprocessing as mp
     from tum_control_amd.workloads import config_groups
     steps, warm, N = 3, 1, 6
-    argv = ["--gpus", "2", "--steps", str(steps), "--warmup", str(warm), "--config", "4", "--horizon", str(N), "--no-cpu-baseline"]
+    argv = ["--gpus", "2", "--steps", str(steps), "--warmup", str(warm), "--config", "4", "--horizon", str(N), "--no-cpu-baseline",
+            "--streams", "2"]
     argv += ["--batch", "48"] if scaling == "weak" else ["--scaling", "strong", "--global-batch", "80"]
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
@@ -363,7 +365,7 @@ def test_bench_control_flow_world2_gloo(scaling):
     ps = [ctx.Process(target=_gloo_bench_worker, args=(r, 2, port, q, argv)) for r in range(2)]
     for p in ps:
         p.start()
-    o, allf, calls, pad, B0 = q.get(timeout=240)
+    o, allf, calls, pad, B0, per_slot = q.get(timeout=240)
     for p in ps:
         p.join(timeout=120)
         assert p.exitcode == 0
@@ -375,9 +377,11 @@ def test_bench_control_flow_world2_gloo(scaling):
     assert o["value"] > 0 and abs(o["value"] * o["ms_per_step"] * 1e-3 - 16 * G) < 1e-6 * 16 * G
     assert o["solve_ms_per_step"] >= 0 and o["gather_ms_per_step"] >= 0
     assert o["status_ok_frac"] == 1.0
-    # every step: one cold start, one solve, one summary pack, one rotation of the inputs (x0 + yref)
+    # every step: one cold start, one solve, one summary pack, one rotation of the inputs (x0 + yref), dealt to the two
+    # capsules of the ring in turn
     n = steps + warm
-    assert calls == dict(cold=n, solve=n, put=2 * n, summary=n)
+    assert calls == dict(cold=n, solve=n, put=2 * n, summary=n) and o["config"]["streams"] == 2
+    assert [c["solve"] for c in per_slot] == [n - n // 2, n // 2]
     # what the root holds after the last step = the stand-in's results for the last rotated batch, in shard order
     assert pad == 48 * 5 and allf.shape == (2, 1, pad)
     variant = (steps - 1) % 4 + 1
