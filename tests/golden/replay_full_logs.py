@@ -123,6 +123,9 @@ def replay_log(args):
     sc = channel_scales(g)
     o = OracleOcp(N, 0.08, 3); o.set_weights(*F[k])
     t = OracleOcp(N, 0.08, 3); t.set_weights(*F[k]); t.ipm_tol[:] = TIGHT; t.set_iter_max(200)
+    if os.environ.get("REPLAY_MU0"):          # (experiments with the interior point start; not used by the tests)
+        for q in (o, t):
+            q.ipm_mu0[:] = float(os.environ["REPLAY_MU0"]); q.ipm_t0[:] = float(os.environ.get("REPLAY_T0", os.environ["REPLAY_MU0"]))
     U0 = np.zeros((n, 2)); X1 = np.zeros((n, 8)); it = np.zeros(n, int)
     pre = []
     for i in range(n):

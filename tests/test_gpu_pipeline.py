@@ -220,3 +220,27 @@ def test_first_solve_after_a_large_allocation():
         del s
     np.testing.assert_array_equal(res["pipeline"][0], res["fused"][0])
     np.testing.assert_allclose(res["pipeline"][1], res["fused"][1], rtol=0, atol=1e-5)
+
+
+def test_four_wavefront_interior_point_kernel_agrees():
+    """ipm4_kernel (four wavefronts per OCP, kernel variant "pipeline4": built to measure the multi-wavefront design, DESIGN.md
+    section 7) computes what ipm_kernel computes: same iteration counts, same iterate after a cold start and two warm
+    real-time iterations, slacks and costs included."""
+    from tum_control_amd.workloads import nominal_batch
+    N, B = 40, 512
+    x0, yref = nominal_batch(B, N=N, seed=5)
+    out = {}
+    for k in ("pipeline", "pipeline4"):
+        s = _mk(N, B, k)
+        s.set_x0(x0); s.set_yref_all(yref); s.cold_start(); assert s.solve() == 0
+        X, U = s.get_iterate()
+        for _ in range(2):
+            s.set_x0(X[:, 1]); assert s.solve() == 0
+            X, U = s.get_iterate()
+        out[k] = (X, U, s.get_stats("qp_iter"), s.get_cost(), s.get_stats("res"), s.get(3, "sl"), s.get(N, "su"))
+    a, b = out["pipeline"], out["pipeline4"]
+    assert np.array_equal(a[2], b[2])
+    assert np.abs(a[1] - b[1]).max() < 2e-6 and np.abs(a[0] - b[0]).max() < 2e-6
+    np.testing.assert_allclose(a[3], b[3], rtol=1e-7)
+    np.testing.assert_allclose(a[5], b[5], atol=1e-7); np.testing.assert_allclose(a[6], b[6], atol=1e-7)
+    assert b[4].max() < 1e-6

@@ -2,12 +2,15 @@
 // (the fused kernel of nmpc_kernel.hpp runs every phase at the occupancy of its most demanding one: one wavefront per SIMD).
 //
 //   K1  lin_kernel      lane = (instance, stage): ERK4 x nsub with forward sensitivities, cost residuals, gg constraint.
-//                       Full lanes (the fused kernel has 41 of 64 busy), no LDS, two wavefronts per SIMD.
+//                       Full lanes (the fused kernel has 41 of 64 busy), LDS only for the transposed store of the records;
+//                       390 registers: one wavefront per SIMD.
 //   K2  cond_kernel     one wavefront per OCP: column recursion G_{k+1} = A_k G_k, Gauss-Newton SYRK on the matrix cores
 //                       (15 register tiles), gg rows; hands H (tiles), C (MFMA operand layout), q, d to the workspace.
-//   K3  ipm_kernel      one wavefront per OCP, <= 256 registers and <= 27 KiB of LDS so that SIX OCPs share a CU (two
-//                       wavefronts on half of the SIMDs): the KKT matrix is the only large LDS resident, the gg rows live
-//                       in registers in MFMA operand layout, H is streamed tile by tile from the workspace (L2).
+//   K3  ipm_kernel      one wavefront per OCP with the whole register file (493 of 512 registers, four OCPs per CU): the KKT
+//                       matrix is the only large LDS resident (26.9 KiB), the gg rows live in registers in MFMA operand
+//                       layout, H is streamed tile by tile from the workspace (L2). (Built with -DIPM_WPS=2 the same source is
+//                       bounded to 256 registers, two wavefronts per SIMD: measured slower)
+//   K3' ipm4_kernel     (ipm4_kernel.hpp) the same method with FOUR wavefronts per OCP, each below 128 registers.
 //   K4  expand_kernel   one wavefront per OCP: dx recursion, full step, cost at the new iterate.
 //
 // Workspace per instance (HBM/L2): stage records 41 x 64 doubles, H 15 x 64 x 4, C 30 x 64, q | d | dv 3 x 80.
@@ -519,9 +522,9 @@ __global__ void __launch_bounds__(64, IPM_WPS) ipm_kernel(const PArgs pa)
     long long tprev = __builtin_readcyclecounter();
     for (int i = lane; i < I_PZ; i += 64) lds[i] = 0.0;
     if (lane < 18) sPZ[lane] = gpen[(lane >> 1) * 4 + 2 + (lane & 1)];
-    // the gg rows, MFMA operand layout (30 coalesced loads). They are needed by the KKT assembly and by the row phases, not by
-    // the factorisation: every iteration re-reads them from the workspace (L2) after the factorisation instead of holding 60
-    // registers across it (the register file is the resource that decides whether two wavefronts share a SIMD).
+    // the gg rows, MFMA operand layout (30 coalesced loads), resident in registers for the whole solve: the KKT assembly and the
+    // row phases take their operands from them. (Only the IPM_WPS = 2 build re-reads them from the workspace behind every
+    // factorisation instead of holding 60 registers across it.)
     double chv[NCH];
     const double *gcw = pa.cws + (size_t)b * NCH * 64 + lane;
 #pragma unroll

@@ -12,6 +12,7 @@
 #include "../../include/tum_nmpc.h"
 #include "nmpc_kernel.hpp"
 #include "pipe_kernels.hpp"
+#include "ipm4_kernel.hpp"
 #include "aux_kernels.hpp"
 #include "loop_kernels.hpp"
 
@@ -32,7 +33,7 @@ struct tum_ocp {
     bool lpt, order_valid;
     long long *dprof;
     double *dws, *dhws;
-    int kmode;                     // 0 auto (= the pipeline), 1 fused, 2 pipeline
+    int kmode;                     // 0 auto (= the pipeline), 1 fused, 2 pipeline, 3 pipeline with the four-wavefront interior point kernel
     unsigned epoch;                // bumped by everything a captured launch bakes into its kernel arguments (kernel variant, schedule,
                                    // SNMPC horizon / risk parameter / work buffers, R2 attachment): tum_sim_run re-captures its graph
     bool pipe;                     // this solve runs the four-kernel pipeline (resolved from kmode at launch)
@@ -146,7 +147,7 @@ extern "C" tum_ocp *tum_ocp_create(const tum_ocp_desc *desc)
     ok &= dalloc(&c->dprof, B * 12) == hipSuccess;
     ok &= dalloc(&c->dws, B * WS_DOUBLES) == hipSuccess;
     c->dhws = nullptr;
-    { const char *e = getenv("TUM_NMPC_KERNEL"); const std::string k(e ? e : "auto"); c->kmode = (k == "fused") ? 1 : (k == "pipeline") ? 2 : 0; c->pipe = false; c->solved_pipe = false; }
+    { const char *e = getenv("TUM_NMPC_KERNEL"); const std::string k(e ? e : "auto"); c->kmode = (k == "fused") ? 1 : (k == "pipeline") ? 2 : (k == "pipeline4") ? 3 : 0; c->pipe = false; c->solved_pipe = false; }
     c->drec = c->dcws = c->dvec = nullptr; c->evi0 = c->evi1 = nullptr;
     ok &= hipEventCreate(&c->evi0) == hipSuccess && hipEventCreate(&c->evi1) == hipSuccess;
     if (!ok) { fail("device allocation failed"); tum_ocp_free(c); return nullptr; }
@@ -183,6 +184,8 @@ extern "C" tum_ocp *tum_ocp_create(const tum_ocp_desc *desc)
         hipFuncSetAttribute((const void *)ipm_kernel<true, 5>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024) != hipSuccess ||
         hipFuncSetAttribute((const void *)ipm_kernel<false, 6>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024) != hipSuccess ||
         hipFuncSetAttribute((const void *)ipm_kernel<true, 6>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024) != hipSuccess ||
+        hipFuncSetAttribute((const void *)ipm4_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024) != hipSuccess ||
+        hipFuncSetAttribute((const void *)ipm4_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024) != hipSuccess ||
         hipFuncSetAttribute((const void *)nmpc_rti_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) != hipSuccess ||
         hipFuncSetAttribute((const void *)nmpc_rti_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) != hipSuccess ||
         hipFuncSetAttribute((const void *)nmpc_rti_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) != hipSuccess ||
@@ -590,7 +593,8 @@ extern "C" int tum_ocp_set_kernel(tum_ocp *c, const char *name)
     if (n == "auto") c->kmode = 0;
     else if (n == "fused") c->kmode = 1;
     else if (n == "pipeline") c->kmode = 2;
-    else return fail("set_kernel: unknown kernel '" + n + "' (auto | fused | pipeline)");
+    else if (n == "pipeline4") c->kmode = 3;
+    else return fail("set_kernel: unknown kernel '" + n + "' (auto | fused | pipeline | pipeline4)");
     c->epoch++;
     return 0;
 }
@@ -628,7 +632,9 @@ static int launch_pipeline(tum_ocp *c, bool events)
         if (c->sn) hipLaunchKernelGGL((cond_kernel<NTv, true>), dim3(c->batch), dim3(64), 0, c->stream, pa);
         else hipLaunchKernelGGL((cond_kernel<NTv, false>), dim3(c->batch), dim3(64), 0, c->stream, pa);
         if (events) (void)hipEventRecord(c->evi0, c->stream);
-        if (prof) hipLaunchKernelGGL((ipm_kernel<true, NTv>), dim3(c->batch), dim3(64), ipm_lds, c->stream, pa);
+        if (prof && c->kmode == 3 && NTv == 5) hipLaunchKernelGGL((ipm4_kernel<true>), dim3(c->batch), dim3(256), I4::BYTES, c->stream, pa);
+        else if (prof) hipLaunchKernelGGL((ipm_kernel<true, NTv>), dim3(c->batch), dim3(64), ipm_lds, c->stream, pa);
+        else if (c->kmode == 3 && NTv == 5) hipLaunchKernelGGL((ipm4_kernel<false>), dim3(c->batch), dim3(256), I4::BYTES, c->stream, pa);
         else hipLaunchKernelGGL((ipm_kernel<false, NTv>), dim3(c->batch), dim3(64), ipm_lds, c->stream, pa);
         if (events) (void)hipEventRecord(c->evi1, c->stream);
         if (c->sn) {
