@@ -168,7 +168,8 @@ int tum_pce_moments_device(tum_ocp *c, const char *field, int stage, double *mea
  * stage uph on); gamma is the chance-constraint level (kappa = sqrt((1-gamma)/gamma), SNMPC_acados_settings.py:187).
  * Afterwards set/get "x" and constraints_set "lbx"/"ubx" at stage 0 also accept 8 (ns+1) values, cold_start copies the
  * stacked x0 to every stage (SNMPC_class.py:126-127), and solve runs prologue + fused kernel + epilogue. The cost acts
- * on the nominal copy with |v| as the speed row; the gg limits are looked up at |v|. 0 <= uph <= min(N, 31). */
+ * on the nominal copy with |v| as the speed row; the gg limits are looked up at |v|. 0 <= uph <= N (the reference ran
+ * uph = N; beyond 31 stages the sample columns no longer fit one wavefront: pipeline kernels only). */
 int tum_ocp_snmpc_attach(tum_ocp *c, int ns, int L, const double *Apce, int uph, double gamma);
 int tum_ocp_snmpc_samples(const tum_ocp *c);   /* ns, or 0 for a nominal capsule */
 /* Offsets of the sample initial conditions from the nominal one (compute_x0dist, Stochastic_NMPC/stochastic_mpc_utils.py:78-91;

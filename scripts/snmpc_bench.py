@@ -19,7 +19,7 @@ def main():
     w = snm.hammersley_normal(10, 3)
     A = snm.pce_matrix(w, snm.alpha_generation(3, 2))
     offs = snm.x0_offsets(w, stds)
-    for N, uph in ((38, 5), (40, 5), (40, 15)):
+    for N, uph in ((38, 5), (40, 5), (40, 15), (38, 38)):      # (38, 38): UPH = Tp as in the ACC24 campaign of the reference
         x0, yref = nominal_batch(B, N=N)
         X0 = np.concatenate([x0[:, None, :], x0[:, None, :] + offs[None]], axis=1)          # (B, 11, 8)
         s = CoupledSnmpcSolver(N=N, dt=0.08, batch=B, Apce=A, uph=uph, gamma=config.MPC["gamma"])

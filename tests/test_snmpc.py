@@ -266,14 +266,19 @@ def _gpu_vs_oracle(golden_dir, N, uph, poses, nsolve=3, shift_ref=0, kernel=None
         assert s.solve() == 0
         Xn, U = s.get_iterate()
         cost = np.atleast_1d(s.get_cost())
+        # Propagating the samples over more than ~30 stages makes the real-time iteration itself ill-conditioned: in the oracle
+        # alone a 1e-9 perturbation of the iterate moves the NEXT solve by 2e-7 (uph = 33) / 2e-6 (uph = 38) against 1e-8 at
+        # uph = 5 (measured). The cold start is held to 1e-7 for every uph; the warm iterations of the long
+        # propagation horizons to the amplified level.
+        rt, at = (1e-7, 2e-8) if (uph <= 31 or it == 0) else (2e-4, 2e-5)
         for j, o in enumerate(orcs):
             assert o.solve() == 0
-            np.testing.assert_allclose(U[j], o.U, rtol=1e-7, atol=2e-8, err_msg=f"U solve {it} inst {j}")
-            np.testing.assert_allclose(Xn[j], o.X[:, 0], rtol=1e-7, atol=2e-8, err_msg=f"X nominal solve {it} inst {j}")
-            np.testing.assert_allclose(cost[j], o.cost, rtol=1e-7)
+            np.testing.assert_allclose(U[j], o.U, rtol=rt, atol=at, err_msg=f"U solve {it} inst {j}")
+            np.testing.assert_allclose(Xn[j], o.X[:, 0], rtol=rt, atol=at, err_msg=f"X nominal solve {it} inst {j}")
+            np.testing.assert_allclose(cost[j], o.cost, rtol=max(rt, 1e-7) * (1 if rt < 1e-6 else 0.05))
             for k in (0, 1, max(uph, 1), N):
                 xf = np.atleast_2d(s.get(k, "x"))[j].reshape(11, 8)
-                np.testing.assert_allclose(xf, o.X[k], rtol=1e-7, atol=2e-8, err_msg=f"stacked x stage {k} solve {it} inst {j}")
+                np.testing.assert_allclose(xf, o.X[k], rtol=rt, atol=at, err_msg=f"stacked x stage {k} solve {it} inst {j}")
     return s
 
 
@@ -286,10 +291,12 @@ def test_gpu_coupled_snmpc_vs_oracle(golden_dir, N, uph):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("N,uph", [(38, 5), (38, 15), (40, 5), (38, 0), (12, 12), (44, 5), (48, 12)])
+@pytest.mark.parametrize("N,uph", [(38, 5), (38, 15), (40, 5), (38, 0), (12, 12), (44, 5), (48, 12), (40, 33), (38, 38), (48, 48)])
 def test_gpu_coupled_snmpc_pipeline_vs_oracle(golden_dir, N, uph):
     """the same through the pipeline variant (prologue, lin_kernel<SN>, cond_kernel<., SN>, ipm_kernel, expand_kernel<., SN>,
-    epilogue; what batches above 1024 instances run), including horizons beyond 40 (six-tile instantiation)"""
+    epilogue; what batches above 1024 instances run), including horizons beyond 40 (six-tile instantiation) and uncertainty
+    propagation horizons up to the whole horizon (the reference ran UPH = Tp = 38 stages, SNMPC_class.py:103-104: the sample
+    columns then no longer fit one wavefront and the prologue's hand-over buffer switches to the 128-column pitch)"""
     _gpu_vs_oracle(golden_dir, N, uph, poses=[0, 26, 30], kernel="pipeline")
 
 
@@ -524,7 +531,11 @@ def test_gpu_snmpc_errors():
     from tum_control_amd.solver import CoupledSnmpcSolver, BatchedOcpSolver, _dp
     snm, stds, w, A = _pce()
     with pytest.raises(Exception, match="propagation horizon"):
-        CoupledSnmpcSolver(N=40, batch=1, Apce=A, uph=32)
+        CoupledSnmpcSolver(N=40, batch=1, Apce=A, uph=41)
+    f = CoupledSnmpcSolver(N=40, batch=1, Apce=A, uph=32)           # beyond 31 stages: pipeline only
+    f.install_reference_ocp(); f.set_kernel("fused")
+    with pytest.raises(Exception, match="fused"):
+        f.solve()
     with pytest.raises(Exception, match="n_samples"):
         CoupledSnmpcSolver(N=10, batch=1, Apce=np.zeros((3, 17)), uph=2)
     n = BatchedOcpSolver(N=10, nsub=3, batch=1)

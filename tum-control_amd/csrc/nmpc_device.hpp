@@ -110,7 +110,7 @@ struct KArgs {
     const int *order;                                 // [batch] workgroup -> instance map (longest-first schedule) or null
     // coupled SNMPC OCP only (nmpc_rti_kernel<., true>, snmpc_kernels.hpp)
     int uph;                                          // uncertainty propagation horizon: stages 1..uph come from `pro`
-    const double *pro;                                // [b][uph][SN_PRO_STAGE] G_nom,s | chance-constraint row of stage s
+    const double *pro;                                // [b][uph][sn_pro_stage(uph)] G_nom,s | chance-constraint row of stage s
     double *dv;                                       // [b][NVP] QP solution for the epilogue kernel
 };
 
@@ -210,6 +210,9 @@ __device__ __forceinline__ double readlane_f64(double v, int l)
     return __hiloint2double(hi, lo);
 }
 __device__ __forceinline__ d4 mfma(double a, double b, d4 c) { return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0); }
+// four independent 4x4x4 products, one per 4-lane block of a DPP row: D_blk[i][j] = sum_k A_blk[i][k] B_blk[k][j] with
+// A[i][k] on lane 16 k + 4 blk + i, B[k][j] on lane 16 k + 4 blk + j, D[i][j] on lane 16 i + 4 blk + j (one double per lane)
+__device__ __forceinline__ double mfma4(double a, double b) { return __builtin_amdgcn_mfma_f64_4x4x4f64(a, b, 0.0, 0, 0, 0); }
 // LDS ordering point between the lanes of the ONE wavefront of a workgroup. The LDS executes a wave's DS
 // instructions in issue order, so a later ds_read already observes an earlier ds_write of another lane: no
 // s_barrier and no counter drain are needed, only a fence that stops the compiler from reordering across it.

@@ -105,6 +105,7 @@ __global__ void __launch_bounds__(64, 1) nmpc_rti_kernel(const KArgs ka)
     const double *gpen = ka.pen + (size_t)b * 36;
     const double *gbnd = ka.bnd + (size_t)b * 6 * (N + 1);
     const int uph = SN ? ka.uph : 0;
+    constexpr int SN_PRO_G = 8 * 64, SN_PRO_STAGE = 9 * 64;        // (uph <= SN_UPHMAX_FUSED: pitch 64, sn_pro_pitch)
     const double *gpro = SN ? ka.pro + (size_t)b * uph * SN_PRO_STAGE : nullptr;
 
     long long pacc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};

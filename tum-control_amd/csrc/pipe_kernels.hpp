@@ -167,7 +167,8 @@ __global__ void __launch_bounds__(64, (NT_ == 5 && !SN) ? 2 : 1) cond_kernel(con
     // stage slot k & 1: fields 0..51 of record k (A_k, B_k, b_k), fields 52..60 of record k+1 (residuals, gg row, delta of stage k+1)
     auto fetch = [&](int k) -> double { return (lane < PR_RES) ? grec[(size_t)k * PREC + lane] : ((lane <= (SN ? PR_G4 : PR_XD)) ? grec[(size_t)(k + 1) * PREC + lane] : 0.0); };
     const int uph = SN ? ka.uph : 0;
-    const double *gpro = SN ? ka.pro + (size_t)b * uph * SN_PRO_STAGE : nullptr;
+    const int PP = SN ? sn_pro_pitch(uph) : 64, PSTAGE = 9 * PP;
+    const double *gpro = SN ? ka.pro + (size_t)b * uph * PSTAGE : nullptr;
     double pre = fetch(0);
     sU0[lane] = (lane < nv) ? gU[lane] : 0.0;
     if (lane < NB1) sU0[64 + lane] = (64 + lane < nv) ? gU[64 + lane] : 0.0;
@@ -200,12 +201,15 @@ __global__ void __launch_bounds__(64, (NT_ == 5 && !SN) ? 2 : 1) cond_kernel(con
             const double *rec = sRec + (k & 1) * PREC;
             if (SN && k < uph) {
                 // stage s = k+1 <= uph: G_nom,s and g_nom,s are PCE means of the sample recursions (prologue kernel)
-                const double *pg = gpro + (size_t)k * SN_PRO_STAGE;
+                // (columns 0..63 in bank 0, 64..2 uph-1 on the lanes of bank 1, the constant column on the g lane)
+                const double *pg = gpro + (size_t)k * PSTAGE;
+                const bool b1 = lane < NB1 && 64 + lane < 2 * uph;
 #pragma unroll
                 for (int i = 0; i < 8; i++) {
-                    const double gv = pg[i * 64 + lane], gg = pg[i * 64 + 2 * uph];
+                    const double gv = pg[i * PP + lane], gg = pg[i * PP + 2 * uph];
+                    const double g1 = b1 ? pg[i * PP + 64 + lane] : 0.0;
                     w0[i] = (lane < 2 * uph) ? gv : 0.0;
-                    w1[i] = isg ? gg : 0.0;
+                    w1[i] = isg ? gg : g1;
                 }
             } else {
             apply_A2(rec, w0, w1);
@@ -231,9 +235,10 @@ __global__ void __launch_bounds__(64, (NT_ == 5 && !SN) ? 2 : 1) cond_kernel(con
             if (SN) {
                 hr0 += g4 * w0[4]; hr1 += g4 * w1[4];
                 if (s < uph) {   // chance-constraint row E + kappa sqrt(Var) over the samples (prologue kernel)
-                    const double *pr = gpro + (size_t)k * SN_PRO_STAGE + SN_PRO_G;
+                    const double *pr = gpro + (size_t)k * PSTAGE + 8 * PP;
                     const double rv = pr[lane], rg = pr[2 * uph];
-                    hr0 = (lane < 2 * uph) ? rv : 0.0; hr1 = isg ? rg : 0.0; hd = 0.0;
+                    const double r1 = (lane < NB1 && 64 + lane < 2 * uph) ? pr[64 + lane] : 0.0;
+                    hr0 = (lane < 2 * uph) ? rv : 0.0; hr1 = isg ? rg : r1; hd = 0.0;
                 }
             }
             // the speed row of the cost: vl (nominal OCP) or |v| (SNMPC: gradient (vl, vt)/|v|)
@@ -348,7 +353,8 @@ __global__ void __launch_bounds__(64) expand_kernel(const PArgs pa)
     const double *gvec = pa.vec + (size_t)b * PVEC;
     const int status = ka.status[b];
     const int uph = SN ? ka.uph : 0;
-    const double *gpro = SN ? ka.pro + (size_t)b * uph * SN_PRO_STAGE : nullptr;
+    const int PP = SN ? sn_pro_pitch(uph) : 64, PSTAGE = 9 * PP;
+    const double *gpro = SN ? ka.pro + (size_t)b * uph * PSTAGE : nullptr;
     for (int i = lane; i < (N + 1) * NX; i += 64) sX[i] = gX[i];
     for (int i = lane; i < NVP; i += 64) { sU1[i] = (i < nv) ? gU[i] : 0.0; sDv[i] = gvec[PV_DV + i]; }
     double pre = (lane < PR_RES) ? grec[lane] : 0.0;
@@ -366,7 +372,7 @@ __global__ void __launch_bounds__(64) expand_kernel(const PArgs pa)
         if (SN) {
             // stages 1..uph: dx_s = G_nom,s dU + g_nom,s straight from the prologue's matrices (2s columns each)
             for (int s = 1; s <= uph; s++) {
-                const double *pg = gpro + (size_t)(s - 1) * SN_PRO_STAGE + ri * 64;
+                const double *pg = gpro + (size_t)(s - 1) * PSTAGE + ri * PP;
                 double acc = pg[2 * uph];
                 for (int j = 0; j < 2 * s; j++) acc += pg[j] * sDv[j];
                 dxi = acc;
@@ -676,9 +682,11 @@ __global__ void __launch_bounds__(64, IPM_WPS) ipm_kernel(const PArgs pa)
         int dmin_hi = 0x3ff00000;
         // lane predicates of the P operand (opaque to the optimiser: as plain compares of lc the select chains below become a
         // switch with branches)
-        int ec0 = lc == 0, ec1 = lc == 1, ec2 = lc == 2, eq0 = lq == 0, eq1 = lq == 1, eq2 = lq == 2, epz = lc < 4;
+        // (P is replicated over the four 4-lane blocks of a DPP row: lane (k, 4 blk + x) holds P[k][x] for every blk, the A
+        //  operand layout of v_mfma_f64_4x4x4_4b below)
+        int ec0 = (lc & 3) == 0, ec1 = (lc & 3) == 1, ec2 = (lc & 3) == 2, eq0 = lq == 0, eq1 = lq == 1, eq2 = lq == 2;
         const double eu0 = (lq == 0) ? 1.0 : 0.0, eu1 = (lq == 1) ? 1.0 : 0.0, eu2 = (lq == 2) ? 1.0 : 0.0, eu3 = (lq == 3) ? 1.0 : 0.0;
-        asm volatile("" : "+v"(ec0), "+v"(ec1), "+v"(ec2), "+v"(eq0), "+v"(eq1), "+v"(eq2), "+v"(epz));
+        asm volatile("" : "+v"(ec0), "+v"(ec1), "+v"(ec2), "+v"(eq0), "+v"(eq1), "+v"(eq2));
         static_for<0, NT - 1>([&](auto Jc) {      // (a template recursion: the body is far beyond the size up to which `#pragma unroll` is honoured)
             constexpr int J = decltype(Jc)::value;
             const int nd = NT - J;            // tiles below the diagonal one + the identity tile
@@ -730,7 +738,11 @@ __global__ void __launch_bounds__(64, IPM_WPS) ipm_kernel(const PArgs pa)
             // 16 j + 4 m + i. It is read into scalars (v_readlane) and factorised uniformly; the panel below it is scaled by
             // ONE MFMA per tile with the 4x4 upper triangular P = L^-T D^-1 as the A operand (new column block = E P, straight
             // into the lanes that hold E), so there is no LDS round trip inside a micro-panel: finished columns are only
-            // stored. Only the diagonal tile is on the dependency path (scale, rank-4 update, next readlane); the two MFMAs
+            // stored. The scaling is FOUR independent 4x4x4 products (16 rows x 4 columns, K = 4): one v_mfma_f64_4x4x4_4b
+            // (measured 21 cycles; lane layout A[i][k] on lane 16 k + 4 blk + i, B[k][j] on 16 k + 4 blk + j, D[i][j] on
+            // 16 i + 4 blk + j, scripts/probes/probe_mfma_4x4x4.cpp) instead of a quarter-used 16x16x4 (64 cycles): E sits in
+            // the B layout as it is, the result lands where the 16x16x4 form put it.
+            // Only the diagonal tile is on the dependency path (scale, rank-4 update, next readlane); the two MFMAs
             // of every tile below it are issued between the segments of the scalar chain of the NEXT micro-panel, where their
             // 64-cycle result latency costs nothing. (An f64 MFMA occupies the same pipe as the f64 VALU instructions of its
             // wavefront: measured, MFMA time and chain time add up -- the interleave hides latencies, not issue time.)
@@ -746,9 +758,7 @@ __global__ void __launch_bounds__(64, IPM_WPS) ipm_kernel(const PArgs pa)
                 auto owed = [&](int k) {
                     if (m > 0 && k < nd) {
                         const int I = J + 1 + k;
-                        d4 z = {0.0, 0.0, 0.0, 0.0};
-                        z = mfma(pop, T[I][m - 1], z);
-                        Lc[I] = z[0];
+                        Lc[I] = mfma4(pop, T[I][m - 1]);
                     } else if (m > 0 && k < 2 * nd) {
                         const int I = J + 1 + k - nd;
                         if (I < NT) sM[rb[I] + c0 - 4 + lq] = Lc[I];
@@ -791,17 +801,13 @@ __global__ void __launch_bounds__(64, IPM_WPS) ipm_kernel(const PArgs pa)
                 owed(9);
                 const double ix = ec0 ? i0 : ec1 ? i1 : ec2 ? i2 : i3;
                 owed(10);
-                const double popn = epz ? Xx * ix : 0.0;
+                const double popn = Xx * ix;
                 owed(11);
                 const double dsel = eq0 ? d0 : eq1 ? d1 : eq2 ? d2 : d3;
                 const int rel = lc - (4 * m + lq);              // row - column inside the diagonal tile
                 pop = popn;
                 dselp = dsel;
-                {
-                    d4 z = {0.0, 0.0, 0.0, 0.0};
-                    z = mfma(pop, T[J][m], z);
-                    Lc[J] = z[0];
-                }
+                Lc[J] = mfma4(pop, T[J][m]);
                 sM[(rel == 0) ? rb[J] + c0 + lq : (I_DUMMY - I_M)] = dsel;
                 const double bval = (rel > 0) ? Lc[J] : ((rel == 0) ? 1.0 : 0.0);
                 bd = -bval * dsel;
@@ -809,11 +815,7 @@ __global__ void __launch_bounds__(64, IPM_WPS) ipm_kernel(const PArgs pa)
             }
             // what the last micro-panel owes: scaled columns
 #pragma unroll
-            for (int I = J + 1; I <= NT; I++) {
-                d4 z = {0.0, 0.0, 0.0, 0.0};
-                z = mfma(pop, T[I][3], z);
-                Lc[I] = z[0];
-            }
+            for (int I = J + 1; I <= NT; I++) Lc[I] = mfma4(pop, T[I][3]);
 #pragma unroll
             for (int I = J + 1; I <= NT; I++) {
                 if (I < NT) sM[rb[I] + 16 * J + 12 + lq] = Lc[I];

@@ -28,10 +28,13 @@ namespace tum {
 
 constexpr int SN_NSMAX = 16;                 // max samples
 constexpr int SN_LMAX = 16;                  // max PCE terms
-constexpr int SN_UPHMAX = 31;                // sample columns 0..2 uph-1 and the g column 2 uph share one wavefront
-constexpr int SN_PRO_G = 8 * 64;             // doubles per stage of G_nom in `pro`: [row][lane]
-constexpr int SN_PRO_STAGE = SN_PRO_G + 64;  // + one chance-constraint row [lane]
-constexpr int SN_ITEMS = SN_UPHMAX * SN_NSMAX;
+constexpr int SN_UPHMAX = 48;                // up to the whole horizon (the reference ran UPH = Tp, SNMPC_class.py:103-104)
+constexpr int SN_UPHMAX_FUSED = 31;          // the fused kernel reads `pro` with a fixed pitch of 64 columns
+// `pro` holds, per stage s <= uph, nine rows (8 rows of G_nom,s | the chance-constraint row) of 2 uph + 1 columns (the sample
+// columns 0..2 uph-1 and the constant column g at index 2 uph). Row pitch: 64 doubles while the columns fit one wavefront
+// (uph <= 31), 128 beyond (the consumers then fill their second register bank from the columns 64..).
+__host__ __device__ inline int sn_pro_pitch(int uph) { return (2 * uph + 1 <= 64) ? 64 : 128; }
+__host__ __device__ inline int sn_pro_stage(int uph) { return 9 * sn_pro_pitch(uph); }
 
 struct SnArgs {
     int N, batch, ns, L, uph;
@@ -44,7 +47,7 @@ struct SnArgs {
     const double *Apce;       // [L][ns]         PCE matrix (SNMPC_class.py:124), shared by the batch
     double *ws2;              // [b][uph*ns][ABS] sample linearisation records
     double *gh;               // [b][uph*ns][5]   gg value and its gradient (vl, vt, r, a) per (stage, sample) item
-    double *pro;              // [b][uph][SN_PRO_STAGE]
+    double *pro;              // [b][uph][sn_pro_stage(uph)]
     const double *dv;         // [b][dv_stride]  QP solution of the fused kernel / of the pipeline's interior point kernel (epilogue)
     int dv_stride;
     const int *status;        // [b]
@@ -138,7 +141,8 @@ __global__ void __launch_bounds__(64) snmpc_prologue_kernel(const SnArgs sa)
     const double *gX = sa.X + (size_t)b * (N + 1) * NX;
     const double *gXS = sa.XS + (size_t)b * (N + 1) * ns * NX;
     double *ws2 = sa.ws2 + (size_t)b * uph * ns * ABS;
-    double *pro = sa.pro + (size_t)b * uph * SN_PRO_STAGE;
+    const int PP = sn_pro_pitch(uph), PSTAGE = 9 * PP;
+    double *pro = sa.pro + (size_t)b * uph * PSTAGE;
 
     const long long t0 = __builtin_readcyclecounter();
     // ---- P1 (snmpc_lin_kernel, launched before this kernel): records in ws2, gg values and gradients in gh
@@ -227,7 +231,7 @@ __global__ void __launch_bounds__(64) snmpc_prologue_kernel(const SnArgs sa)
             for (int c = 0; c < NCH; c++) { const int idx = lane + 64 * c; pre[c] = (idx < nrec) ? ws2[(size_t)(k + 1) * nrec + idx] : 0.0; }
         }
         const double *rec = sRec + i * ABS;
-        double *pg = pro + (size_t)k * SN_PRO_STAGE;
+        double *pg = pro + (size_t)k * PSTAGE;
         const int np_k = (2 * k + 3 + CS - 1) / CS;
         for (int pass = 0; pass < np_k; pass++) {
             const int q = pass * CS + sc;
@@ -260,8 +264,8 @@ __global__ void __launch_bounds__(64) snmpc_prologue_kernel(const SnArgs sa)
                 if (qo <= 2 * uph) {
                     const bool og = (qo == 0);
                     const int colo = og ? 2 * uph : qo - 1;
-                    if (r < 8) pg[r * 64 + colo] = acc + (og ? sDef[k * 8 + r] : 0.0);
-                    else pg[SN_PRO_G + colo] = acc + ((og && s < uph) ? sHval[s] : 0.0);
+                    if (r < 8) pg[r * PP + colo] = acc + (og ? sDef[k * 8 + r] : 0.0);
+                    else pg[8 * PP + colo] = acc + ((og && s < uph) ? sHval[s] : 0.0);
                 }
             }
             wsync();

@@ -52,7 +52,7 @@ struct tum_ocp {
     // R2NMPC tightening after every solve (tum_ocp_r2_attach)
     bool r2; int r2_uph; double r2_dmin, r2_dmax, r2_uh; double *dr2S, *dr2B;
     // per-stage parameter vector of the SNMPC OCP as the caller last set it (tum_ocp_set "p")
-    std::vector<double> hApce, p_gamma, p_stop; bool p_dirty; int uph_cap; double gamma;
+    std::vector<double> hApce, p_gamma, p_stop; bool p_dirty; int uph_cap; size_t pro_cap; double gamma;
     // PCE matrix of the scenario fan-out (tum_pce_attach), snapshot of the bounds (tum_ocp_bounds_snapshot)
     double *dpceA; int pce_L, pce_S; double *dbnd_snap;
 };
@@ -222,7 +222,7 @@ extern "C" int tum_ocp_snmpc_attach(tum_ocp *c, int ns, int L, const double *Apc
     if (c->sn) return fail("snmpc_attach: already attached");
     if (ns < 1 || ns > SN_NSMAX) return fail("snmpc_attach: n_samples out of range (1..16)");
     if (L < 1 || L > SN_LMAX) return fail("snmpc_attach: number of PCE terms out of range (1..16)");
-    if (uph < 0 || uph > c->N || uph > SN_UPHMAX) return fail("snmpc_attach: uncertainty propagation horizon out of range (0..min(N,31))");
+    if (uph < 0 || uph > c->N || uph > SN_UPHMAX) return fail("snmpc_attach: uncertainty propagation horizon out of range (0..N)");
     if (!(gamma > 0.0 && gamma <= 1.0)) return fail("snmpc_attach: gamma out of range (0,1]");
     if (c->d.nsub != 1) return fail("snmpc_attach: the SNMPC model is DISCRETE with one RK4 step per stage: create the capsule with nsub = 1");
     if (c->d.store_qp_in) return fail("snmpc_attach: store_qp_in is not available for the stacked state");
@@ -238,7 +238,7 @@ extern "C" int tum_ocp_snmpc_attach(tum_ocp *c, int ns, int L, const double *Apc
     ok &= dalloc(&c->dxs0, B * ns * NX) == hipSuccess;
     ok &= dalloc(&c->dApce, (size_t)L * ns) == hipSuccess;
     ok &= dalloc(&c->dws2, B * (size_t)(uph > 0 ? uph : 1) * ns * (ABS + 5)) == hipSuccess;      // records, then the gg values / gradients
-    ok &= dalloc(&c->dpro, B * (size_t)(uph > 0 ? uph : 1) * SN_PRO_STAGE) == hipSuccess;
+    ok &= dalloc(&c->dpro, B * (size_t)(uph > 0 ? uph : 1) * sn_pro_stage(uph)) == hipSuccess;
     ok &= dalloc(&c->ddv, B * NVP) == hipSuccess;
     ok &= dalloc(&c->doffs, (size_t)ns * NX) == hipSuccess;
     if (ok) { (void)hipFree(c->dxs_dirty); c->dxs_dirty = nullptr; ok &= hipMalloc((void **)&c->dxs_dirty, sizeof(int) * B) == hipSuccess; }
@@ -257,7 +257,7 @@ extern "C" int tum_ocp_snmpc_attach(tum_ocp *c, int ns, int L, const double *Apc
     c->ka.uph = uph; c->ka.pro = c->dpro; c->ka.dv = c->ddv;
     c->sn = true;
     c->hApce.assign(Apce, Apce + (size_t)L * ns);
-    c->gamma = gamma; c->uph_cap = uph > 0 ? uph : 1;
+    c->gamma = gamma; c->uph_cap = uph > 0 ? uph : 1; c->pro_cap = (size_t)(uph > 0 ? uph : 1) * sn_pro_stage(uph);
     c->p_gamma.assign(N + 1, gamma); c->p_stop.assign(N + 1, 0.0);
     for (int k = uph; k <= N; k++) c->p_stop[k] = 1.0;
     c->p_dirty = false;
@@ -324,12 +324,14 @@ static int sn_apply_p(tum_ocp *c)
     if (uph > N) uph = N;                      // no stop flag at all: the samples are propagated over the whole horizon
     if (uph > SN_UPHMAX) return fail("solve: uncertainty propagation horizon from the stop flags exceeds " + std::to_string(SN_UPHMAX));
     if (sizeof(double) * sn_prologue_lds_doubles(uph, ns) > 128 * 1024) return fail("solve: n_samples x uph too large for the prologue kernel's LDS");
-    if (uph > c->uph_cap) {
+    // (the hand-over buffer of the prologue is sized uph x sn_pro_stage(uph): its row pitch doubles beyond uph = 31)
+    if (uph > c->uph_cap || (size_t)uph * sn_pro_stage(uph) > c->pro_cap) {
         DevGuard guard(c->d.device); GUARD_OK(guard);
         HIPCHK(hipStreamSynchronize(c->stream));
         (void)hipFree(c->dws2); (void)hipFree(c->dpro); c->dws2 = c->dpro = nullptr;
         const size_t B = c->batch;
-        if (dalloc(&c->dws2, B * (size_t)uph * ns * (ABS + 5)) != hipSuccess || dalloc(&c->dpro, B * (size_t)uph * SN_PRO_STAGE) != hipSuccess)
+        c->pro_cap = (size_t)uph * sn_pro_stage(uph);
+        if (dalloc(&c->dws2, B * (size_t)uph * ns * (ABS + 5)) != hipSuccess || dalloc(&c->dpro, B * c->pro_cap) != hipSuccess)
             return fail("solve: device allocation failed for the longer uncertainty propagation horizon");
         c->uph_cap = uph; c->sa.ws2 = c->dws2; c->sa.gh = c->dws2 + B * (size_t)uph * ns * ABS; c->sa.pro = c->dpro; c->ka.pro = c->dpro;
     }
@@ -339,7 +341,7 @@ static int sn_apply_p(tum_ocp *c)
         // buffers being zero; the per-instance stride of both buffers depends on uph, so a new horizon starts from zeros
         DevGuard guard(c->d.device); GUARD_OK(guard);
         HIPCHK(hipMemsetAsync(c->dws2, 0, sizeof(double) * (size_t)c->batch * c->uph_cap * ns * ABS, c->stream));
-        HIPCHK(hipMemsetAsync(c->dpro, 0, sizeof(double) * (size_t)c->batch * c->uph_cap * SN_PRO_STAGE, c->stream));
+        HIPCHK(hipMemsetAsync(c->dpro, 0, sizeof(double) * (size_t)c->batch * c->pro_cap, c->stream));
     }
     c->gamma = c->p_gamma[0];
     c->sa.kappa = std::sqrt((1.0 - c->gamma) / c->gamma);
@@ -660,6 +662,8 @@ static int launch(tum_ocp *c, bool events = true)
     const bool prof = (c->ka.flags & 6) != 0;
     auto fused = [&](auto kern) { hipLaunchKernelGGL(kern, dim3(c->batch), dim3(64), LDS_BYTES, c->stream, c->ka); };
     if (c->sn && sn_apply_p(c)) return 1;
+    if (c->sn && !c->pipe && c->sa.uph > SN_UPHMAX_FUSED)
+        return fail("solve: kernel 'fused' reads the sample columns of one wavefront: uncertainty propagation horizon <= 31 (use 'auto' or 'pipeline')");
     if (c->pipe) { if (launch_pipeline(c, events)) return 1; }
     else if (c->sn) {
         if (c->fanout && sn_fanout(c)) return 1;
