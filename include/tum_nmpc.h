@@ -56,8 +56,8 @@ typedef struct tum_ocp_desc {
     /* QP solver options (acados: qp_solver_iter_max :232, HPIPM tolerances json:904-950) */
     int qp_iter_max;
     double qp_tol_stat, qp_tol_ineq, qp_tol_comp;
-    double qp_mu0;         /* initial complementarity target of the interior point method (default 0.1) */
-    double qp_t0;          /* floor of the initial constraint residuals (default 0.1) */
+    double qp_mu0;         /* initial complementarity target of the interior point method (default 0.05) */
+    double qp_t0;          /* floor of the initial constraint residuals (default 0.05) */
     int store_qp_in;       /* keep A_k,B_k,b_k of the last linearisation for tum_ocp_get_from_qp_in */
 } tum_ocp_desc;
 

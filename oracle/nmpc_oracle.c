@@ -491,7 +491,7 @@ oracle_ocp *oracle_create(int N, double dt, int nsub)
     oracle_ocp *o = calloc(1, sizeof(oracle_ocp));
     o->N = N; o->dt = dt; o->nsub = nsub;
     o->ipm.iter_max = 50; o->ipm.tol_stat = 1e-8; o->ipm.tol_ineq = 1e-8; o->ipm.tol_comp = 1e-8;
-    o->ipm.mu0 = 0.1; o->ipm.t0 = 0.1; o->ipm.reg = 0.0;
+    o->ipm.mu0 = 0.05; o->ipm.t0 = 0.05; o->ipm.reg = 0.0;
     return o;
 }
 void oracle_free(oracle_ocp *o) { free(o); }
@@ -774,7 +774,7 @@ snmpc_ocp *snmpc_create(int N, double dt, int ns, int L, double gamma)
     o->N = N; o->dt = dt; o->ns = ns; o->L = L;
     o->kappa = sqrt((1.0 - gamma) / gamma);          /* SNMPC_acados_settings.py:187 */
     o->ipm.iter_max = 50; o->ipm.tol_stat = 1e-8; o->ipm.tol_ineq = 1e-8; o->ipm.tol_comp = 1e-8;
-    o->ipm.mu0 = 0.1; o->ipm.t0 = 0.1; o->ipm.reg = 0.0;
+    o->ipm.mu0 = 0.05; o->ipm.t0 = 0.05; o->ipm.reg = 0.0;
     return o;
 }
 void snmpc_free(snmpc_ocp *o) { free(o); }

@@ -22,7 +22,7 @@ logged for it (`simU[i]`, `MPC_SimX[i+1]`).
                      (ii) acados' own iteration count on that solve and over the 25 solves before it, from the log: every
                           exception sits in a stretch where acados needed at least 20 (up to 45) QP iterations, 1.3x to
                           2.3x its median for that loop -- elevated, but only three of the six clusters reach 30;
-                     (iii) the exceptions are rare and clustered: 32 of 283 615 comparable solves, six runs of consecutive
+                     (iii) the exceptions are rare and clustered: 30 of 283 615 comparable solves, six runs of consecutive
                           control steps on six Monteblanco loops (sets 8, 9, 10, 13, 16, 21), none on LVMS; in every run the
                           linearised LOWER bound 0 <= h of the acceleration constraint is degenerate (h ~ 0 with a vanishing
                           gradient on the late stages), the regime in which a QP solution is determined far less sharply

@@ -159,8 +159,8 @@ extern "C" tum_ocp *tum_ocp_create(const tum_ocp_desc *desc)
     ka.tol_stat = desc->qp_tol_stat > 0 ? desc->qp_tol_stat : 1e-8;
     ka.tol_ineq = desc->qp_tol_ineq > 0 ? desc->qp_tol_ineq : 1e-8;
     ka.tol_comp = desc->qp_tol_comp > 0 ? desc->qp_tol_comp : 1e-8;
-    ka.mu0 = desc->qp_mu0 > 0 ? desc->qp_mu0 : 0.1;
-    ka.t0 = desc->qp_t0 > 0 ? desc->qp_t0 : 0.1;
+    ka.mu0 = desc->qp_mu0 > 0 ? desc->qp_mu0 : 0.05;
+    ka.t0 = desc->qp_t0 > 0 ? desc->qp_t0 : 0.05;
     ka.reg = 0.0;
     Model &m = ka.mp;
     m.lf = desc->lf; m.lr = desc->lr; m.m = desc->m; m.inv_m = 1.0 / desc->m; m.inv_Iz = 1.0 / desc->Iz;

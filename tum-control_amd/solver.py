@@ -118,7 +118,7 @@ def load_library(path=None):
 
 
 def make_desc(N, dt, nsub, batch, device=0, cfg=None, store_qp_in=False, qp_iter_max=50,
-              qp_tol=(1e-8, 1e-8, 1e-8), qp_mu0=0.1, qp_t0=0.1):
+              qp_tol=(1e-8, 1e-8, 1e-8), qp_mu0=0.05, qp_t0=0.05):
     cfg = cfg or _config.default_config()
     d = TumOcpDesc()
     d.N, d.nsub, d.dt, d.batch, d.device = int(N), int(nsub), float(dt), int(batch), int(device)
@@ -150,7 +150,7 @@ class BatchedOcpSolver:
     """`batch` independent copies of the nominal NMPC OCP on one MI355X; acados method names."""
 
     def __init__(self, N=38, dt=0.08, nsub=3, batch=1, device=0, cfg=None, store_qp_in=False,
-                 qp_iter_max=50, qp_tol=(1e-8, 1e-8, 1e-8), qp_mu0=0.1, qp_t0=0.1):
+                 qp_iter_max=50, qp_tol=(1e-8, 1e-8, 1e-8), qp_mu0=0.05, qp_t0=0.05):
         self._L = load_library()
         self.N, self.dt, self.nsub, self.batch = int(N), float(dt), int(nsub), int(batch)
         self.cfg = cfg or _config.default_config()
@@ -442,7 +442,7 @@ class CoupledSnmpcSolver(BatchedOcpSolver):
     """
 
     def __init__(self, N=38, dt=0.08, batch=1, Apce=None, uph=5, gamma=0.8, device=0, cfg=None,
-                 qp_iter_max=50, qp_tol=(1e-8, 1e-8, 1e-8), qp_mu0=0.1, qp_t0=0.1, x0_offsets=None):
+                 qp_iter_max=50, qp_tol=(1e-8, 1e-8, 1e-8), qp_mu0=0.05, qp_t0=0.05, x0_offsets=None):
         super().__init__(N=N, dt=dt, nsub=1, batch=batch, device=device, cfg=cfg, qp_iter_max=qp_iter_max,
                          qp_tol=qp_tol, qp_mu0=qp_mu0, qp_t0=qp_t0)
         self.Apce = np.ascontiguousarray(Apce, dtype=np.float64)
