@@ -883,6 +883,115 @@ __global__ void __launch_bounds__(64, IPM_WPS) ipm_kernel(const PArgs pa)
             ctw(b0, b1);
             b0 = v0on ? -rv0 - b0 : 0.0; b1 = v1on ? -rv1 - b1 : 0.0;
             TUM_TICK(5);
+#ifndef IPM_OLD_SOLVES
+            {
+                // The two substitutions on v_mfma_f64_4x4x4_4b (four independent 4x4x4 products per instruction, 21 cycles). A
+                // vector block lives in "D form": lane (lq, lc) holds entry 4 (lc >> 2) + lq of the 16 -- what the instruction
+                // returns (D[i][j] on lane 16 i + 4 blk + j, the same for every j when B does not depend on j) and what it
+                // takes as the B operand (B[k][j] on lane 16 k + 4 blk + j) for the DIAGONAL 4x4 blocks of a 16x16 tile. The
+                // other 4x4 blocks see the vector rotated by one, two, three quads inside a DPP row (row_ror: 4, 8, 12): a
+                // 16x16 tile times a vector block is four accumulating 4x4x4 instructions, no row swaps, no lane gathers:
+                // per block row the dependent chain is rotate -> 4 MFMAs -> rotate -> 4 MFMAs.
+                const int blk = lc >> 2;
+                double bj[NT], vr[NT][4];
+#pragma unroll
+                for (int J = 0; J < 4; J++) bj[J] = lane_gather(b0, (16 * J + 4 * blk + lq) << 2);
+#pragma unroll
+                for (int J = 4; J < NT; J++) bj[J] = lane_gather(b1, (16 * (J - 4) + 4 * blk + lq) << 2);
+                int co[4];                                   // column (forward) / row (backward) offset of the block met at rotation d
+#pragma unroll
+                for (int d = 0; d < 4; d++) co[d] = 4 * ((blk - d) & 3) + lq;
+                constexpr bool PRE = (IPM_WPS == 1 && NT == 5);          // (the five-tile build fetches the factor up front)
+                double Lo[NTT][4], Ld[NT][4], Lp[NT];
+                auto lo_f = [&](int J, int K, int d) { return sM[rb[J] + 16 * K + co[d]]; };
+                auto ld_f = [&](int J, int d) {
+                    const double lv = sM[rb[J] + 16 * J + co[d]];
+                    return (co[d] < lc) ? lv : ((co[d] == lc) ? 1.0 : 0.0);
+                };
+                auto lo_b = [&](int I, int J, int d) { return sM[lpk(16 * I + co[d], 0) + 16 * J + lc]; };
+                auto ld_b = [&](int J, int d) {
+                    const double lv = sM[lpk(16 * J + co[d], 0) + 16 * J + lc];
+                    return (co[d] > lc) ? lv : ((co[d] == lc) ? 1.0 : 0.0);
+                };
+                if (PRE) {
+#pragma unroll
+                    for (int J = 0; J < NT; J++) {
+#pragma unroll
+                        for (int K = 0; K < J; K++)
+#pragma unroll
+                            for (int d = 0; d < 4; d++) Lo[tidx(K, J)][d] = lo_f(J, K, d);
+#pragma unroll
+                        for (int d = 0; d < 4; d++) Ld[J][d] = ld_f(J, d);
+                        Lp[J] = sM[lpk(16 * J + 4 * blk + lq, 16 * J + 4 * blk + lq)];
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+#pragma unroll
+                for (int J = 0; J < NT; J++) {
+                    double t = bj[J];
+                    if (J > 0) {
+                        double acc = 0.0, acc1 = 0.0;
+#pragma unroll
+                        for (int K = 0; K < J; K++)
+#pragma unroll
+                            for (int d = 0; d < 4; d++) {
+                                const double lv = PRE ? Lo[tidx(K, J)][d] : lo_f(J, K, d);
+                                if (d & 1) acc1 = mfma4a(lv, vr[K][d], acc1); else acc = mfma4a(lv, vr[K][d], acc);
+                            }
+                        t -= acc + acc1;
+                    }
+                    const double t1 = row_ror<4>(t), t2 = row_ror<8>(t), t3 = row_ror<12>(t);
+                    double y = mfma4a(PRE ? Ld[J][0] : ld_f(J, 0), t, 0.0), y1 = mfma4a(PRE ? Ld[J][1] : ld_f(J, 1), t1, 0.0);
+                    y = mfma4a(PRE ? Ld[J][2] : ld_f(J, 2), t2, y); y1 = mfma4a(PRE ? Ld[J][3] : ld_f(J, 3), t3, y1);
+                    y += y1;
+                    bj[J] = y * frcp(PRE ? Lp[J] : sM[lpk(16 * J + 4 * blk + lq, 16 * J + 4 * blk + lq)]);
+                    if (J < NT - 1) { vr[J][0] = y; vr[J][1] = row_ror<4>(y); vr[J][2] = row_ror<8>(y); vr[J][3] = row_ror<12>(y); }
+                }
+                if (PRE) {
+#pragma unroll
+                    for (int J = 0; J < NT; J++) {
+#pragma unroll
+                        for (int I = J + 1; I < NT; I++)
+#pragma unroll
+                            for (int d = 0; d < 4; d++) Lo[tidx(J, I)][d] = lo_b(I, J, d);
+#pragma unroll
+                        for (int d = 0; d < 4; d++) Ld[J][d] = ld_b(J, d);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+#pragma unroll
+                for (int J = NT - 1; J >= 0; J--) {
+                    double t = bj[J];
+                    if (J < NT - 1) {
+                        double acc = 0.0, acc1 = 0.0;
+#pragma unroll
+                        for (int I = J + 1; I < NT; I++)
+#pragma unroll
+                            for (int d = 0; d < 4; d++) {
+                                const double lv = PRE ? Lo[tidx(J, I)][d] : lo_b(I, J, d);
+                                if (d & 1) acc1 = mfma4a(lv, vr[I][d], acc1); else acc = mfma4a(lv, vr[I][d], acc);
+                            }
+                        t -= acc + acc1;
+                    }
+                    const double t1 = row_ror<4>(t), t2 = row_ror<8>(t), t3 = row_ror<12>(t);
+                    double x = mfma4a(PRE ? Ld[J][0] : ld_b(J, 0), t, 0.0), x1 = mfma4a(PRE ? Ld[J][1] : ld_b(J, 1), t1, 0.0);
+                    x = mfma4a(PRE ? Ld[J][2] : ld_b(J, 2), t2, x); x1 = mfma4a(PRE ? Ld[J][3] : ld_b(J, 3), t3, x1);
+                    x += x1;
+                    bj[J] = x;
+                    if (J > 0) { vr[J][0] = x; vr[J][1] = row_ror<4>(x); vr[J][2] = row_ror<8>(x); vr[J][3] = row_ror<12>(x); }
+                }
+                TUM_TICK(6);
+                // back to lane = variable through the v-space buffer of the row phase (one representative lane per entry)
+                wsync();
+                if ((lc & 3) == 0) {
+#pragma unroll
+                    for (int J = 0; J < NT; J++) sDv[16 * J + 4 * blk + lq] = bj[J];
+                }
+                wsync();
+                dv0 = sDv[lane]; dv1 = (lane < NB1) ? sDv[64 + lane] : 0.0;
+                dv0 = v0on ? dv0 : 0.0; dv1 = v1on ? dv1 : 0.0;
+            }
+#else
             {
                 int ga[4];
 #pragma unroll
@@ -986,6 +1095,7 @@ __global__ void __launch_bounds__(64, IPM_WPS) ipm_kernel(const PArgs pa)
             sDv[lane] = dv0;
             if (lane < NB1) sDv[64 + lane] = dv1;
             wsync();
+#endif
             // row phase B2: C*dv for this lane's rows, step in (s,t,lam,mu), step length
             double cdv[SLOTS];
             {
