@@ -1,3 +1,4 @@
+import os; os.environ.setdefault("TUM_NMPC_DEV", "1")      # (the fused kernel lives in the development build)
 import sys, time, numpy as np
 sys.path.insert(0, ".")
 import torch

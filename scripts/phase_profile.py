@@ -9,8 +9,11 @@ from tum_control_amd.solver import BatchedOcpSolver
 from tum_control_amd.workloads import nominal_batch
 N, B = 40, int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 KERNEL = sys.argv[2] if len(sys.argv) > 2 else os.environ.get("TUM_NMPC_KERNEL", "auto")
+import contextlib
+from tum_control_amd import solver as _sv
 x0, yref = nominal_batch(B, N=N)
-s = BatchedOcpSolver(N=N, dt=0.08, nsub=3, batch=B)
+with (_sv.dev_library() if KERNEL in ("fused", "pipeline4") else contextlib.nullcontext()):      # (development build)
+    s = BatchedOcpSolver(N=N, dt=0.08, nsub=3, batch=B)
 s.install_reference_ocp(); s.set_x0(x0); s.set_yref_all(yref); s.set_kernel(KERNEL)
 s.cold_start(); s.solve(); ms0 = s.last_kernel_ms()
 s.cold_start(); p = s.profile_phases(); ms1 = s.last_kernel_ms()

@@ -12,7 +12,10 @@ N, B = 40, int(os.environ.get("B", "4096"))
 x0, yref = nominal_batch(B, N=N)
 ref = None
 for name in sys.argv[1:] or ["fused", "pipeline"]:
-    s = BatchedOcpSolver(N=N, batch=B, store_qp_in=False)
+    import contextlib
+    from tum_control_amd import solver as _sv
+    with (_sv.dev_library() if name in ("fused", "pipeline4") and "TUM_NMPC_LIB" not in os.environ else contextlib.nullcontext()):
+        s = BatchedOcpSolver(N=N, batch=B, store_qp_in=False)      # (fused / pipeline4: development build)
     s.install_reference_ocp(); s.set_kernel(name)
     s.set_x0(x0); s.set_yref_all(yref)
     ms, ipm = [], []

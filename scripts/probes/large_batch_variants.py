@@ -1,5 +1,6 @@
 """fused kernel against pipeline at large batches: iteration counts and iterates instance by instance (cold start)"""
 import os, sys
+os.environ.setdefault("TUM_NMPC_DEV", "1")      # (the fused kernel lives in the development build)
 import numpy as np
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
 from tum_control_amd.solver import BatchedOcpSolver

@@ -1,3 +1,4 @@
+import os; os.environ.setdefault("TUM_NMPC_DEV", "1")      # (the fused kernel lives in the development build)
 import time, numpy as np, sys
 sys.path.insert(0, __import__("os").path.join(__import__("os").path.dirname(__import__("os").path.abspath(__file__)), "..", ".."))
 from tum_control_amd.solver import BatchedOcpSolver

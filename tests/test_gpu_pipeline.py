@@ -11,9 +11,18 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
+def _lib_for(kernel):
+    """the kernel variants "fused" and "pipeline4" exist in the development build only (libtumnmpc_dev.so); everything else
+    runs on the shipped library"""
+    import contextlib
+    from tum_control_amd import solver
+    return solver.dev_library() if kernel in ("fused", "pipeline4") else contextlib.nullcontext()
+
+
 def _mk(N, B, kernel, **kw):
     from tum_control_amd.solver import BatchedOcpSolver
-    s = BatchedOcpSolver(N=N, dt=0.08, nsub=3, batch=B, **kw)
+    with _lib_for(kernel):
+        s = BatchedOcpSolver(N=N, dt=0.08, nsub=3, batch=B, **kw)
     s.install_reference_ocp()
     s.set_kernel(kernel)
     return s
@@ -125,7 +134,8 @@ def test_pipeline_in_the_device_closed_loop(golden_dir):
     from tum_control_amd.closed_loop import ClosedLoopBatch
     logs = {}
     for k in ("fused", "pipeline"):
-        cl = ClosedLoopBatch("lvms", batch=4, N=38, Tp=3.04, on_device=True, log_capacity=80)
+        with _lib_for(k):
+            cl = ClosedLoopBatch("lvms", batch=4, N=38, Tp=3.04, on_device=True, log_capacity=80)
         cl.solver.set_kernel(k)
         logs[k] = cl.run(80)
         assert cl.dev.graph_steps == 25
@@ -170,14 +180,16 @@ def test_long_horizons_vs_oracle(N, B):
         oo.uh[3] = 0.05; oo.ubx[N] = 0.01; oo.x0[:] = Xc[b, 1]; assert oo.solve() == 0
         assert np.abs(oo.U - U2[b]).max() < 2e-6 and np.abs(oo.X - X2[b]).max() < 2e-6
     assert np.isfinite(sl).all()
-    # what does not exist beyond 40
-    s.set_kernel("fused")
-    with pytest.raises(Exception, match="N <= 40"):
-        s.solve()
-    s.set_kernel("auto")
+    # what does not exist beyond 40 / in the shipped library
+    with pytest.raises(Exception, match="development build"):
+        s.set_kernel("fused")
     with pytest.raises(Exception, match="N <= 40"):
         s.debug_dump(0)
     assert s.solve() == 0
+    if B == 1:
+        f = _mk(N, 1, "fused")
+        with pytest.raises(Exception, match="N <= 40"):
+            f.solve()
 
 
 def test_long_horizon_closed_loops():
@@ -213,7 +225,9 @@ def test_first_solve_after_a_large_allocation():
     x0, yref = nominal_batch(B, N=40, track_name="lvms", stride=7, seed=4321)
     res = {}
     for k in ("fused", "pipeline"):
-        s = BatchedOcpSolver(N=40, batch=B); s.set_kernel(k)
+        with _lib_for(k):
+            s = BatchedOcpSolver(N=40, batch=B)
+        s.set_kernel(k)
         s.install_reference_ocp(); s.set_x0(x0); s.set_yref_all(yref); s.cold_start()
         assert s.solve() == 0
         res[k] = (s.get_stats("qp_iter").copy(), s.get_iterate()[1].copy())

@@ -237,7 +237,10 @@ def _gpu_vs_oracle(golden_dir, N, uph, poses, nsolve=3, shift_ref=0, kernel=None
     snm, stds, w, A = _pce()
     d = np.load(os.path.join(golden_dir, "kat0.npz"))
     B = len(poses)
-    s = CoupledSnmpcSolver(N=N, dt=0.08, batch=B, Apce=A, uph=uph, gamma=0.8)
+    import contextlib
+    from tum_control_amd import solver as _sv
+    with (_sv.dev_library() if kernel == "fused" else contextlib.nullcontext()):      # (the fused kernel: development build)
+        s = CoupledSnmpcSolver(N=N, dt=0.08, batch=B, Apce=A, uph=uph, gamma=0.8)
     if kernel:
         s.set_kernel(kernel)
     s.install_reference_ocp()
@@ -287,7 +290,7 @@ def _gpu_vs_oracle(golden_dir, N, uph, poses, nsolve=3, shift_ref=0, kernel=None
 def test_gpu_coupled_snmpc_vs_oracle(golden_dir, N, uph):
     """cold start + two warm real-time iterations on logged poses (one with a perturbed state), every copy of the stacked
     iterate compared; tolerance 1e-7 relative (north_star: 1e-4)."""
-    _gpu_vs_oracle(golden_dir, N, uph, poses=[0, 26, 30])
+    _gpu_vs_oracle(golden_dir, N, uph, poses=[0, 26, 30], kernel="fused")
 
 
 @pytest.mark.gpu
@@ -301,10 +304,15 @@ def test_gpu_coupled_snmpc_pipeline_vs_oracle(golden_dir, N, uph):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("N,uph", [(12, 5), (12, 12), (40, 9), (40, 31)])
-def test_gpu_coupled_snmpc_condensed_qp(golden_dir, N, uph):
-    """The condensed QP (H, q, chance / gg rows, constants) the prologue + fused kernel build, against the oracle's
-    dense 88-state condensing, at a strongly excited iterate with non-zero defects on every copy."""
+@pytest.mark.parametrize("N,uph,lib", [(12, 5, "shipped"), (12, 12, "shipped"), (40, 9, "shipped"), (40, 31, "shipped"), (40, 36, "shipped"),
+                                       (38, 38, "shipped"), (12, 5, "dev"), (40, 9, "dev"), (40, 31, "dev")])
+def test_gpu_coupled_snmpc_condensed_qp(golden_dir, N, uph, lib):
+    """The condensed QP (H, q, chance / gg rows, constants) against the oracle's dense 88-state condensing, at a strongly
+    excited iterate with non-zero defects on every copy: what the prologue + condensing kernel hand to the interior point
+    kernel (shipped library: the dump is read back from the pipeline's hand-over buffers), and what the prologue + fused
+    kernel build (development build)."""
+    import contextlib
+    from tum_control_amd import solver as _sv
     from tum_control_amd.solver import CoupledSnmpcSolver
     from tum_control_amd import config
     snm, stds, w, A = _pce()
@@ -323,7 +331,8 @@ def test_gpu_coupled_snmpc_condensed_qp(golden_dir, N, uph):
     o.set_weights(m["q_lon"], m["q_yaw"], m["q_vel"], m["r_jerk"], m["r_steering_rate"], m["L1_pen"], m["L2_pen"], scale=0.01)
     o.yref[:] = Y; o.x0[:] = xs + 1e-3; o.X[:] = X; o.U[:] = U
     _, qp = o.solve_debug()
-    s = CoupledSnmpcSolver(N=N, dt=0.08, batch=1, Apce=A, uph=uph, gamma=0.8)
+    with (_sv.dev_library() if lib == "dev" else contextlib.nullcontext()):
+        s = CoupledSnmpcSolver(N=N, dt=0.08, batch=1, Apce=A, uph=uph, gamma=0.8)
     s.install_reference_ocp()
     s.constraints_set(0, "lbx", (xs + 1e-3).flatten()); s.constraints_set(0, "ubx", (xs + 1e-3).flatten())
     s.set_yref_all(Y)
@@ -532,7 +541,9 @@ def test_gpu_snmpc_errors():
     snm, stds, w, A = _pce()
     with pytest.raises(Exception, match="propagation horizon"):
         CoupledSnmpcSolver(N=40, batch=1, Apce=A, uph=41)
-    f = CoupledSnmpcSolver(N=40, batch=1, Apce=A, uph=32)           # beyond 31 stages: pipeline only
+    from tum_control_amd import solver as _sv
+    with _sv.dev_library():
+        f = CoupledSnmpcSolver(N=40, batch=1, Apce=A, uph=32)       # beyond 31 stages: pipeline only
     f.install_reference_ocp(); f.set_kernel("fused")
     with pytest.raises(Exception, match="fused"):
         f.solve()
@@ -775,12 +786,14 @@ def test_gpu_instrumented_kernels_agree(kind):
     snm, stds, w, A = _pce()
     x0, yref = nominal_batch(8, N=40)
     res = {}
+    from tum_control_amd import solver as _sv
     for mode in ("plain", "phases", "dump"):
-        if kind == "snmpc":
-            s = CoupledSnmpcSolver(N=40, batch=8, Apce=A, uph=5, x0_offsets=snm.x0_offsets(w, stds))
-        else:
-            s = BatchedOcpSolver(N=40, batch=8)
-        s.set_kernel("fused")          # (the debug dump always runs the fused kernel; the pipeline has its own test below)
+        with _sv.dev_library():        # (the fused kernel lives in the development build; the pipeline has its own test below)
+            if kind == "snmpc":
+                s = CoupledSnmpcSolver(N=40, batch=8, Apce=A, uph=5, x0_offsets=snm.x0_offsets(w, stds))
+            else:
+                s = BatchedOcpSolver(N=40, batch=8)
+        s.set_kernel("fused")
         s.install_reference_ocp(); s.set_x0(x0); s.set_yref_all(yref); s.cold_start()
         if mode == "plain":
             s.solve()

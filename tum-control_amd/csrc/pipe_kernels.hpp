@@ -16,7 +16,8 @@
 // Workspace per instance (HBM/L2): stage records 41 x 64 doubles, H 15 x 64 x 4, C 30 x 64, q | d | dv 3 x 80.
 // Reference semantics as in nmpc_kernel.hpp; the arithmetic of every phase is the fused kernel's.
 #pragma once
-#include "nmpc_device.hpp"
+#include "common_kernels.hpp"
+#include "snmpc_kernels.hpp"
 
 namespace tum {
 
@@ -145,7 +146,7 @@ __global__ void __launch_bounds__(64, 1) lin_kernel(const PArgs pa)
 // LDS of the condensing kernel (PD::C_*): stage record double buffer | 4 staging rows of the SYRK | g_s of the current stage |
 // iterate U | packed gg rows (staging for the operand layout)
 template <int NT_, bool SN>
-__global__ void __launch_bounds__(64, (NT_ == 5 && !SN) ? 2 : 1) cond_kernel(const PArgs pa)
+__global__ void __launch_bounds__(64, (NT_ == 5) ? 2 : 1) cond_kernel(const PArgs pa)
 {
     PD_LOCALS
     constexpr int C_REC = D::C_REC, C_STAGE = D::C_STAGE, C_GS = D::C_GS, C_U0 = D::C_U0, C_CH = D::C_CH;

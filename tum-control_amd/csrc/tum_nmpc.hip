@@ -1,5 +1,7 @@
 // tum_nmpc.hip -- host side of libtumnmpc.so: the C-ABI declared in include/tum_nmpc.h.
-// Owns device memory for `batch` OCP instances and launches the fused SQP-RTI kernel.
+// Owns device memory for `batch` OCP instances and launches the SQP-RTI pipeline (lin / cond / ipm / expand kernels).
+// -DTUM_DEV_KERNELS (libtumnmpc_dev.so, tests and experiments only) adds the two other implementations of the solve the
+// pipeline is held against: round 1's fused kernel and the four-wavefront interior point kernel.
 #include <hip/hip_runtime.h>
 
 #include <cmath>
@@ -10,9 +12,11 @@
 #include <vector>
 
 #include "../../include/tum_nmpc.h"
-#include "nmpc_kernel.hpp"
 #include "pipe_kernels.hpp"
+#ifdef TUM_DEV_KERNELS
+#include "nmpc_kernel.hpp"
 #include "ipm4_kernel.hpp"
+#endif
 #include "aux_kernels.hpp"
 #include "loop_kernels.hpp"
 
@@ -142,12 +146,21 @@ extern "C" tum_ocp *tum_ocp_create(const tum_ocp_desc *desc)
         c->order_valid = true;
     }
     c->dqpin = nullptr;
+#ifdef TUM_DEV_KERNELS      // (only the fused kernel writes A | B | b per stage; the pipeline's stage records hold them)
     if (desc->store_qp_in) ok &= dalloc(&c->dqpin, B * N * 88) == hipSuccess;
+#endif
     ok &= dalloc(&c->ddbg, (size_t)DBG_STRIDE * DBG_INST) == hipSuccess;
     ok &= dalloc(&c->dprof, B * 12) == hipSuccess;
+    c->dws = nullptr;
+#ifdef TUM_DEV_KERNELS      // (linearisation records parked by the fused kernel during its interior point loop)
     ok &= dalloc(&c->dws, B * WS_DOUBLES) == hipSuccess;
+#endif
     c->dhws = nullptr;
-    { const char *e = getenv("TUM_NMPC_KERNEL"); const std::string k(e ? e : "auto"); c->kmode = (k == "fused") ? 1 : (k == "pipeline") ? 2 : (k == "pipeline4") ? 3 : 0; c->pipe = false; c->solved_pipe = false; }
+    { const char *e = getenv("TUM_NMPC_KERNEL"); const std::string k(e ? e : "auto"); c->kmode = (k == "pipeline") ? 2 : 0;
+#ifdef TUM_DEV_KERNELS
+      if (k == "fused") c->kmode = 1; else if (k == "pipeline4") c->kmode = 3;
+#endif
+      c->pipe = false; c->solved_pipe = false; }
     c->drec = c->dcws = c->dvec = nullptr; c->evi0 = c->evi1 = nullptr;
     ok &= hipEventCreate(&c->evi0) == hipSuccess && hipEventCreate(&c->evi1) == hipSuccess;
     if (!ok) { fail("device allocation failed"); tum_ocp_free(c); return nullptr; }
@@ -182,14 +195,16 @@ extern "C" tum_ocp *tum_ocp_create(const tum_ocp_desc *desc)
 
     if (hipFuncSetAttribute((const void *)ipm_kernel<false, 5>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024) != hipSuccess ||
         hipFuncSetAttribute((const void *)ipm_kernel<true, 5>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024) != hipSuccess ||
-        hipFuncSetAttribute((const void *)ipm_kernel<false, 6>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024) != hipSuccess ||
-        hipFuncSetAttribute((const void *)ipm_kernel<true, 6>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024) != hipSuccess ||
-        hipFuncSetAttribute((const void *)ipm4_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024) != hipSuccess ||
+        hipFuncSetAttribute((const void *)ipm_kernel<false, 6>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024) != hipSuccess
+#ifdef TUM_DEV_KERNELS
+        || hipFuncSetAttribute((const void *)ipm4_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024) != hipSuccess ||
         hipFuncSetAttribute((const void *)ipm4_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024) != hipSuccess ||
         hipFuncSetAttribute((const void *)nmpc_rti_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) != hipSuccess ||
         hipFuncSetAttribute((const void *)nmpc_rti_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) != hipSuccess ||
         hipFuncSetAttribute((const void *)nmpc_rti_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) != hipSuccess ||
-        hipFuncSetAttribute((const void *)nmpc_rti_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) != hipSuccess) {
+        hipFuncSetAttribute((const void *)nmpc_rti_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) != hipSuccess
+#endif
+        ) {
         fail("hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed"); tum_ocp_free(c); return nullptr;
     }
     return c;
@@ -593,10 +608,15 @@ extern "C" int tum_ocp_set_kernel(tum_ocp *c, const char *name)
     if (!c || !name) return fail("null argument");
     const std::string n(name);
     if (n == "auto") c->kmode = 0;
-    else if (n == "fused") c->kmode = 1;
     else if (n == "pipeline") c->kmode = 2;
+#ifdef TUM_DEV_KERNELS
+    else if (n == "fused") c->kmode = 1;
     else if (n == "pipeline4") c->kmode = 3;
-    else return fail("set_kernel: unknown kernel '" + n + "' (auto | fused | pipeline | pipeline4)");
+#else
+    else if (n == "fused" || n == "pipeline4")
+        return fail("set_kernel: kernel '" + n + "' exists in the development build only (libtumnmpc_dev.so); this library is the pipeline");
+#endif
+    else return fail("set_kernel: unknown kernel '" + n + "' (auto | pipeline; development build: fused | pipeline4)");
     c->epoch++;
     return 0;
 }
@@ -604,12 +624,16 @@ extern "C" int tum_ocp_set_kernel(tum_ocp *c, const char *name)
 // which kernel variant this solve runs, and its workspace (allocated on first use; never inside a stream capture)
 static int resolve_kernel(tum_ocp *c)
 {
+#ifdef TUM_DEV_KERNELS
     c->pipe = !(c->ka.flags & 2) && c->kmode != 1;
     if (c->N > NMAX) {      // the fused kernel covers N <= 40; longer horizons exist as a pipeline instantiation only
         if (c->ka.flags & 2) return fail("debug_dump: the condensed-QP dump is built for N <= 40");
         if (c->kmode == 1) return fail("solve: kernel 'fused' is built for N <= 40 (use 'auto' or 'pipeline')");
         c->pipe = true;
     }
+#else
+    c->pipe = true;
+#endif
     return ensure_workspace(c);
 }
 
@@ -634,10 +658,15 @@ static int launch_pipeline(tum_ocp *c, bool events)
         if (c->sn) hipLaunchKernelGGL((cond_kernel<NTv, true>), dim3(c->batch), dim3(64), 0, c->stream, pa);
         else hipLaunchKernelGGL((cond_kernel<NTv, false>), dim3(c->batch), dim3(64), 0, c->stream, pa);
         if (events) (void)hipEventRecord(c->evi0, c->stream);
+#ifdef TUM_DEV_KERNELS
         if (prof && c->kmode == 3 && NTv == 5) hipLaunchKernelGGL((ipm4_kernel<true>), dim3(c->batch), dim3(256), I4::BYTES, c->stream, pa);
-        else if (prof) hipLaunchKernelGGL((ipm_kernel<true, NTv>), dim3(c->batch), dim3(64), ipm_lds, c->stream, pa);
-        else if (c->kmode == 3 && NTv == 5) hipLaunchKernelGGL((ipm4_kernel<false>), dim3(c->batch), dim3(256), I4::BYTES, c->stream, pa);
-        else hipLaunchKernelGGL((ipm_kernel<false, NTv>), dim3(c->batch), dim3(64), ipm_lds, c->stream, pa);
+        else if (!prof && c->kmode == 3 && NTv == 5) hipLaunchKernelGGL((ipm4_kernel<false>), dim3(c->batch), dim3(256), I4::BYTES, c->stream, pa);
+        else
+#endif
+        if constexpr (NTv == 5) {      // (the instrumented instantiation exists for the five-tile build only)
+            if (prof) hipLaunchKernelGGL((ipm_kernel<true, 5>), dim3(c->batch), dim3(64), ipm_lds, c->stream, pa);
+            else hipLaunchKernelGGL((ipm_kernel<false, 5>), dim3(c->batch), dim3(64), ipm_lds, c->stream, pa);
+        } else hipLaunchKernelGGL((ipm_kernel<false, NTv>), dim3(c->batch), dim3(64), ipm_lds, c->stream, pa);
         if (events) (void)hipEventRecord(c->evi1, c->stream);
         if (c->sn) {
             hipLaunchKernelGGL((expand_kernel<NTv, true>), dim3(c->batch), dim3(64), 0, c->stream, pa);
@@ -659,9 +688,10 @@ static int launch(tum_ocp *c, bool events = true)
     // round of resident wavefronts)
     c->ka.order = (c->lpt && c->order_valid && c->batch > 1024) ? c->dorder : nullptr;
     // the instrumented instantiation carries the phase timers (flag 4) and the debug dump (flag 2)
+    if (c->sn && sn_apply_p(c)) return 1;
+#ifdef TUM_DEV_KERNELS
     const bool prof = (c->ka.flags & 6) != 0;
     auto fused = [&](auto kern) { hipLaunchKernelGGL(kern, dim3(c->batch), dim3(64), LDS_BYTES, c->stream, c->ka); };
-    if (c->sn && sn_apply_p(c)) return 1;
     if (c->sn && !c->pipe && c->sa.uph > SN_UPHMAX_FUSED)
         return fail("solve: kernel 'fused' reads the sample columns of one wavefront: uncertainty propagation horizon <= 31 (use 'auto' or 'pipeline')");
     if (c->pipe) { if (launch_pipeline(c, events)) return 1; }
@@ -674,6 +704,9 @@ static int launch(tum_ocp *c, bool events = true)
         hipLaunchKernelGGL(snmpc_epilogue_kernel, dim3(c->batch), dim3(64), 0, c->stream, c->sa); c->xs_lazy = true;
     }
     else { if (prof) fused(nmpc_rti_kernel<true>); else fused(nmpc_rti_kernel<false>); }
+#else
+    if (launch_pipeline(c, events)) return 1;
+#endif
     HIPCHK(hipGetLastError());
     if (c->r2) {   // constraint tightening for the NEXT solve from this one's linearisation (skipped per instance on failure)
         hipLaunchKernelGGL(r2_backoff_kernel, dim3((c->batch + 3) / 4), dim3(256), 0, c->stream, c->dqpin, c->dX, c->dbnd, c->ka.mp,
@@ -797,7 +830,7 @@ extern "C" int tum_ocp_cold_start(tum_ocp *c)
 extern "C" int tum_ocp_get_from_qp_in(tum_ocp *c, int stage, const char *field, double *out, int len, int b0, int nb, int stride)
 {
     if (chk_range(c, b0, nb)) return 1;
-    if (!c->dqpin) return fail("get_from_qp_in: capsule created without store_qp_in");
+    if (!c->d.store_qp_in) return fail("get_from_qp_in: capsule created without store_qp_in");
     if (!c->solved) return fail("get_from_qp_in: no solve yet");
     if (stage < 0 || stage >= c->N) return fail("get_from_qp_in: stage out of range");
     const std::string f(field ? field : "");
@@ -884,18 +917,55 @@ extern "C" int tum_ocp_put_device(tum_ocp *c, const char *field, const void *src
     return fail("put_device: unknown field '" + f + "'");
 }
 
+// One solve, then the condensed QP of instance b as the solve built it. Layout of `out` (doubles, N <= 40):
+//   [0, 6400) H (80 x 80, symmetric, incl. the input cost and the unit padding) | [6400, 6480) q |
+//   [6480, 6480 + 2 N 80) the steering-angle row and the gg row of every stage 1..N | [12880, 12880 + 2 N) their constants.
+// The shipped library reads it back from the hand-over buffers of the pipeline (H tiles, gg rows in MFMA operand layout,
+// q | d) -- so the dump shows what the interior point kernel is given; the development build keeps the fused kernel's own
+// dump, which continues with g, the KKT matrix and the first right-hand side / step of the first iteration.
 extern "C" int tum_ocp_debug_dump(tum_ocp *c, int b, double *out, int len)
 {
     if (!c) return fail("null capsule");
     if (b < 0 || b >= DBG_INST || b >= c->batch) return fail("debug_dump: instance out of range");
     DevGuard guard(c->d.device); GUARD_OK(guard);
     if (len > DBG_STRIDE) len = DBG_STRIDE;
-    c->ka.flags |= 2;
-    const int rc = launch(c);
-    c->ka.flags &= ~2;
-    if (rc) return 1;
+#ifdef TUM_DEV_KERNELS
+    if (c->kmode != 2 && c->kmode != 3) {
+        c->ka.flags |= 2;
+        const int rc = launch(c);
+        c->ka.flags &= ~2;
+        if (rc) return 1;
+        HIPCHK(hipStreamSynchronize(c->stream));
+        HIPCHK(hipMemcpy(out, c->ddbg + (size_t)b * DBG_STRIDE, sizeof(double) * len, hipMemcpyDeviceToHost));
+        return 0;
+    }
+#endif
+    if (c->N > NMAX) return fail("debug_dump: the condensed-QP dump is built for N <= 40");
+    if (launch(c)) return 1;
     HIPCHK(hipStreamSynchronize(c->stream));
-    HIPCHK(hipMemcpy(out, c->ddbg + (size_t)b * DBG_STRIDE, sizeof(double) * len, hipMemcpyDeviceToHost));
+    using D = PD<5>;
+    const int N = c->N;
+    std::vector<double> hw((size_t)D::NTT * 256), cw((size_t)D::NCH * 64), vv(D::PVEC), o(DBG_STRIDE, 0.0);
+    HIPCHK(hipMemcpy(hw.data(), c->dhws + (size_t)b * D::NTT * 256, sizeof(double) * hw.size(), hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(cw.data(), c->dcws + (size_t)b * D::NCH * 64, sizeof(double) * cw.size(), hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(vv.data(), c->dvec + (size_t)b * D::PVEC, sizeof(double) * vv.size(), hipMemcpyDeviceToHost));
+    for (int K = 0; K < D::NT; K++)
+        for (int I = K; I < D::NT; I++)
+            for (int l = 0; l < 64; l++)
+                for (int jj = 0; jj < 4; jj++) {         // accumulator layout: row (l >> 4) + 4 jj, column l & 15
+                    const int row = 16 * K + (l >> 4) + 4 * jj, col = 16 * I + (l & 15);
+                    const double v = hw[((size_t)D::tidx(K, I) * 64 + l) * 4 + jj];
+                    o[row * 80 + col] = v; o[col * 80 + row] = v;
+                }
+    for (int i = 0; i < 80; i++) o[6400 + i] = vv[D::PV_Q + i];
+    for (int s = 1; s <= N; s++)
+        for (int col = 0; col < 80; col++) {
+            o[6480 + (2 * (s - 1)) * 80 + col] = ((col & 1) && col < 2 * s) ? c->ka.dt : 0.0;
+            const int cc = (s - 1) >> 2, lq = (s - 1) & 3, T = col >> 4;       // operand layout: chunk cc, DPP row lq, tile column T
+            o[6480 + (2 * (s - 1) + 1) * 80 + col] = (cc >= 2 * T) ? cw[(size_t)D::cidx(cc, T) * 64 + 16 * lq + (col & 15)] : 0.0;
+        }
+    for (int i = 0; i < 2 * N; i++) o[12880 + i] = vv[D::PV_D + i];
+    memcpy(out, o.data(), sizeof(double) * len);
     return 0;
 }
 
@@ -903,6 +973,7 @@ extern "C" int tum_ocp_debug_dump(tum_ocp *c, int b, double *out, int len)
 extern "C" int tum_ocp_profile_phases(tum_ocp *c, long long *out)
 {
     if (!c || !out) return fail("null argument");
+    if (c->N > NMAX) return fail("profile_phases: the instrumented kernels are built for N <= 40");
     DevGuard guard(c->d.device); GUARD_OK(guard);
     c->ka.flags |= 4;
     int rc = launch(c);
@@ -1014,7 +1085,7 @@ extern "C" int tum_ocp_r2_backoff(tum_ocp *c, const double *Sigma0, const double
                                   double delta_min, double delta_max, double uh_nom, double *backoff)
 {
     if (!c || !Sigma0 || !BWB) return fail("null argument");
-    if (!c->dqpin) return fail("r2_backoff: capsule created without store_qp_in");
+    if (!c->d.store_qp_in) return fail("r2_backoff: capsule created without store_qp_in");
     if (!c->solved) return fail("r2_backoff: no solve yet");
     if (uph < 1) return fail("r2_backoff: uncertainty propagation horizon < 1");
     DevGuard guard(c->d.device); GUARD_OK(guard);
@@ -1046,7 +1117,7 @@ extern "C" int tum_ocp_r2_attach(tum_ocp *c, const double *Sigma0, const double 
     if (!c) return fail("null capsule");
     if (uph == 0) { if (c->r2) c->epoch++; c->r2 = false; return 0; }
     if (!Sigma0 || !BWB) return fail("null argument");
-    if (!c->dqpin) return fail("r2_attach: capsule created without store_qp_in");
+    if (!c->d.store_qp_in) return fail("r2_attach: capsule created without store_qp_in");
     if (c->sn) return fail("r2_attach: not available for an SNMPC capsule");
     if (uph < 1) return fail("r2_attach: uncertainty propagation horizon < 1");
     DevGuard guard(c->d.device); GUARD_OK(guard);

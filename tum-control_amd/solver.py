@@ -13,6 +13,7 @@ without it is broadcast to all instances.
 
 There is NO CPU fallback: if the HIP library or a GPU is missing, construction raises.
 """
+import contextlib
 import ctypes
 import os
 
@@ -21,7 +22,10 @@ import numpy as np
 from . import config as _config
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.environ.get("TUM_NMPC_LIB", os.path.join(_HERE, "libtumnmpc.so"))   # override: A/B testing of builds
+# development build (tests / experiments): the same C-ABI plus the kernel variants "fused" and "pipeline4" (tum_ocp_set_kernel)
+DEV_LIB_PATH = os.path.join(_HERE, "libtumnmpc_dev.so")
+# overrides: TUM_NMPC_LIB=<path> (A/B testing of builds), TUM_NMPC_DEV=1 (a whole script on the development build)
+LIB_PATH = os.environ.get("TUM_NMPC_LIB", DEV_LIB_PATH if os.environ.get("TUM_NMPC_DEV") == "1" else os.path.join(_HERE, "libtumnmpc.so"))
 ALL_STAGES = -1
 
 
@@ -41,6 +45,23 @@ class TumOcpDesc(ctypes.Structure):
 
 
 _lib = None
+_libs = {}              # path -> loaded library
+_default_path = None    # None: LIB_PATH
+
+
+@contextlib.contextmanager
+def dev_library():
+    """Solvers created inside this context bind to the development build (libtumnmpc_dev.so: the shipped pipeline plus the
+    kernel variants "fused" and "pipeline4"). Tests and experiments only."""
+    global _default_path
+    old = _default_path
+    _default_path = DEV_LIB_PATH
+    try:
+        yield
+    finally:
+        _default_path = old
+
+
 # every symbol include/tum_nmpc.h declares (tests/test_cabi.py checks the .so exports them all)
 C_SYMBOLS = ["tum_ocp_create", "tum_ocp_free", "tum_ocp_last_error", "tum_ocp_batch", "tum_ocp_horizon",
              "tum_ocp_set", "tum_ocp_get", "tum_ocp_constraints_set", "tum_ocp_cost_set",
@@ -58,9 +79,9 @@ C_SYMBOLS = ["tum_ocp_create", "tum_ocp_free", "tum_ocp_last_error", "tum_ocp_ba
 def load_library(path=None):
     """dlopen libtumnmpc.so (built by __graft_entry__.build()); raises if it is missing."""
     global _lib
-    if _lib is not None and path is None:
-        return _lib
-    p = path or LIB_PATH
+    p = path or _default_path or LIB_PATH
+    if p in _libs:
+        return _libs[p]
     try:
         # torch ships its own HIP runtime: let it load first so that libtumnmpc.so binds to the same
         # libamdhip64 (two runtimes in one process lose the device)
@@ -112,7 +133,8 @@ def load_library(path=None):
     L.tum_sim_plan.argtypes = [vp]; L.tum_sim_advance.argtypes = [vp]; L.tum_sim_run.argtypes = [vp, ci]
     L.tum_sim_steps.argtypes = [vp]
     L.tum_sim_get.argtypes = [vp, cs, dp, ctypes.c_longlong]
-    if path is None:
+    _libs[p] = L
+    if p == LIB_PATH:
         _lib = L
     return L
 
