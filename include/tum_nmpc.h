@@ -134,16 +134,19 @@ int tum_ocp_cold_start(tum_ocp *c);
  * first instead of leaving the GPU idle at the end (a batch is only a few rounds of resident wavefronts); 0: natural order.
  * Results do not depend on the schedule. Environment override at create time: TUM_NMPC_SCHEDULE=natural. */
 int tum_ocp_set_schedule(tum_ocp *c, int longest_first);
-/* Kernel variant of the nominal solve (no reference counterpart): "fused" (one kernel per solve), "pipeline" (linearise /
- * condense / interior point / expand as four kernels, each at its own occupancy, handing over through the L2-resident
- * workspace), "auto" (default: the pipeline -- the faster variant at every batch size, 3 % at one instance, 13 % at 4096; the
- * fused kernel covers N <= 40 only and is what tum_ocp_debug_dump runs). Results agree to rounding (same arithmetic per phase). Environment override at create time: TUM_NMPC_KERNEL. The
- * coupled SNMPC OCP follows the same rule (its prologue / epilogue kernels around either variant). get_stats("time_ipm") reports
- * the interior point kernel of the pipeline. */
+/* Kernel variant of the solve (no reference counterpart). The shipped library has ONE: "pipeline" (= "auto", the default):
+ * linearise / condense / interior point / expand as four kernels, each at its own occupancy, handing over through an
+ * L2-resident workspace; the coupled SNMPC OCP runs its prologue / epilogue kernels around it. get_stats("time_ipm") reports
+ * the interior point kernel. The development build (libtumnmpc_dev.so, tests and experiments only) adds the two other
+ * implementations the pipeline is held against: "fused" (round 1's single kernel, N <= 40, uph <= 31) and "pipeline4" (the
+ * pipeline with the four-wavefront interior point kernel); the shipped library refuses these names. Environment override at
+ * create time: TUM_NMPC_KERNEL. */
 int tum_ocp_set_kernel(tum_ocp *c, const char *name);
 /* last kernel launch time in milliseconds (HIP events on the launch stream) */
 double tum_ocp_last_kernel_ms(tum_ocp *c);
-/* debug: dump of condensed-QP intermediates of instance b (see csrc/nmpc_kernel.hip) */
+/* debug: one solve, then the condensed QP of instance b as the condensing kernel handed it to the interior point kernel
+ * (N <= 40): out = [H 80x80 | q 80 | steering-angle row and gg row of every stage, 2N x 80 | their constants 2N]; see
+ * csrc/tum_nmpc.hip */
 int tum_ocp_debug_dump(tum_ocp *c, int b, double *out, int len);
 
 /* ---- the small kernels either side of the solve ---------------------------------

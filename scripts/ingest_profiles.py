@@ -3,12 +3,39 @@
 import collections, csv, json, os, shutil, sys
 tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
 src, dst = "gpurun_out/final", "profiles"
-shutil.copy(f"{src}/stats/s_kernel_stats.csv", f"{dst}/{tag}_kernel_stats.csv")
-for f in ("phase_cycles.txt", "configs.jsonl", "kernel_variants.txt", "ipm_occupancy.txt", "snmpc_bench.txt", "pcie.txt"):
+shutil.copy(f"{src}/stats/s_kernel_stats.csv", f"{dst}/{tag}_kernel_stats.csv")          # bench.py --streams 1 (one stream)
+if os.path.exists(f"{src}/stats3/s_kernel_stats.csv"):
+    shutil.copy(f"{src}/stats3/s_kernel_stats.csv", f"{dst}/{tag}_kernel_stats_3streams.csv")      # the default command
+for f in ("phase_cycles.txt", "configs.jsonl", "kernel_variants.txt", "ipm_occupancy.txt", "snmpc_bench.txt", "pcie.txt", "streams.txt",
+          "closed_loops.txt", "ipm4_phases.txt"):
     if os.path.exists(f"{src}/{f}"):
         shutil.copy(f"{src}/{f}", f"{dst}/{tag}_{f}")
 KERNELS = ("lin_kernel", "cond_kernel", "ipm_kernel", "expand_kernel", "nmpc_rti_kernel")
+BATCH = {2: 4096, 3: 16384, 4: 16384, 5: 4096}
+
+
+def traffic(cfg, suffix):
+    out = {"kernels": "one solve = lin_kernel + cond_kernel + ipm_kernel + expand_kernel (the pipeline)", "config": cfg, "batch": BATCH[cfg], "N": 40,
+           "command": "bench.py --streams 1" + (f" --config {cfg}" if cfg != 2 else ""),
+           "units": "KB per launch (rocprofv3 --pmc, separate passes for FETCH_SIZE and WRITE_SIZE)"}
+    tot = 0.0
+    for d, name in (("pmc_fetch" + suffix, "FETCH_SIZE"), ("pmc_write" + suffix, "WRITE_SIZE")):
+        rows = list(csv.DictReader(open(f"{src}/{d}/p_counter_collection.csv")))
+        for k in KERNELS:
+            v = [float(r["Counter_Value"]) for r in rows if k in r["Kernel_Name"] and r["Counter_Name"] == name]
+            if v:
+                out[f"{name}_KB_{k}"] = sum(v) / len(v)
+                tot += sum(v) / len(v) * (2 if cfg == 5 else 1)      # (config 5: two solves per step, both counted)
+    out["traffic_bytes_per_launch"] = tot * 1024 / (2 if cfg == 5 else 1)
+    out["traffic_bytes_per_solve"] = out["traffic_bytes_per_launch"] / BATCH[cfg]
+    return out
+
+
+for cfg in (3, 4, 5):
+    if os.path.exists(f"{src}/pmc_fetch_c{cfg}/p_counter_collection.csv"):
+        json.dump(traffic(cfg, f"_c{cfg}"), open(f"{dst}/{tag}_traffic_c{cfg}.json", "w"), indent=1)
 out = {"kernels": "one solve = lin_kernel + cond_kernel + ipm_kernel + expand_kernel (the pipeline; batch > 1024)", "config": 2, "batch": 4096, "N": 40,
+       "command": "bench.py --streams 1",
        "units": "KB per launch (rocprofv3 --pmc, separate passes for FETCH_SIZE and WRITE_SIZE)",
        "calibration": "cold_start_kernel in the same runs reads 262 KB (x0) and writes 13 369 344 B (X,U): FETCH_SIZE / WRITE_SIZE "
                       "report these 1:1 for this kernel family's 8-byte-per-lane accesses (the 2x FETCH_SIZE correction of "
@@ -42,5 +69,5 @@ json.dump(sq, open(f"{dst}/{tag}_sq_counters.json", "w"), indent=1)
 b = json.load(open(f"{src}/bench.json"))
 b["roofline"]["traffic"] = out["traffic_bytes_per_launch"]; b["roofline"]["traffic_source"] = f"profiles/{tag}_traffic.json"
 json.dump(b, open(f"{dst}/{tag}_bench.json", "w"))
-print(tag, "value", b["value"], "fresh", b.get("value_fresh_batch"), "ms", b["ms_per_step"], "frac", b["roofline"]["frac"],
+print(tag, "value", b["value"], "one stream", b.get("value_single_stream"), "repeated", b.get("value_repeated_batch"), "ms", b["ms_per_step"], "frac", b["roofline"]["frac"],
       "traffic/solve", out["traffic_bytes_per_solve"], "cpu", b["cpu_baseline"]["value"])

@@ -18,12 +18,12 @@ logged for it (`simU[i]`, `MPC_SimX[i+1]`).
                      answer moved:
                      (i)  this solver's own answer does not move when its tolerances are tightened 100x (1e-8 -> 1e-10):
                           re-solved from the identical pre-solve state, the shift must stay below 1e-5 (observed: median
-                          2e-8, worst 7e-6) -- the answer compared with the log IS the solution of that QP;
+                          1.5e-8, worst 4e-6) -- the answer compared with the log IS the solution of that QP;
                      (ii) acados' own iteration count on that solve and over the 25 solves before it, from the log: every
-                          exception sits in a stretch where acados needed at least 20 (up to 45) QP iterations, 1.3x to
-                          2.3x its median for that loop -- elevated, but only three of the six clusters reach 30;
+                          exception sits in a stretch where acados needed at least 20 (up to 45) QP iterations, 1.2x to
+                          2.2x its mean for that loop -- elevated, but only three of the six clusters reach 30;
                      (iii) the exceptions are rare and clustered: 30 of 283 615 comparable solves, six runs of consecutive
-                          control steps on six Monteblanco loops (sets 8, 9, 10, 13, 16, 21), none on LVMS; in every run the
+                          control steps on six Monteblanco loops (sets 8, 10, 12, 13, 16, 21), none on LVMS; in every run the
                           linearised LOWER bound 0 <= h of the acceleration constraint is degenerate (h ~ 0 with a vanishing
                           gradient on the late stages), the regime in which a QP solution is determined far less sharply
                           than its KKT residuals (two interior point variants that both stop at 1e-8 differ by 1e-4 in dU
