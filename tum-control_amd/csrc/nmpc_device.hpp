@@ -130,11 +130,20 @@ __device__ __forceinline__ double dpp_f64(double ident, double v)
     const int hi = __builtin_amdgcn_update_dpp(__double2hiint(ident), __double2hiint(v), CTRL, ROWMASK, 0xf, false);
     return __hiloint2double(hi, lo);
 }
+// (row_shr steps with bound_ctrl: a lane whose source is outside its row of 16 receives 0 -- the identity of both scans used
+//  here, sums and maxima of non-negative values -- without a v_mov that pre-loads the identity into the destination)
+template <int CTRL>
+__device__ __forceinline__ double dpp0_f64(double v)
+{
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xf, 0xf, true);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xf, 0xf, true);
+    return __hiloint2double(hi, lo);
+}
 #define TUM_DPP_SCAN(OP, IDENT)                                   \
-    v = OP(v, dpp_f64<0x111, 0xf>(IDENT, v));                     \
-    v = OP(v, dpp_f64<0x112, 0xf>(IDENT, v));                     \
-    v = OP(v, dpp_f64<0x114, 0xf>(IDENT, v));                     \
-    v = OP(v, dpp_f64<0x118, 0xf>(IDENT, v));                     \
+    v = OP(v, dpp0_f64<0x111>(v));                                \
+    v = OP(v, dpp0_f64<0x112>(v));                                \
+    v = OP(v, dpp0_f64<0x114>(v));                                \
+    v = OP(v, dpp0_f64<0x118>(v));                                \
     v = OP(v, dpp_f64<0x142, 0xa>(IDENT, v));                     \
     v = OP(v, dpp_f64<0x143, 0xc>(IDENT, v));
 __device__ __forceinline__ double op_add(double a, double b) { return a + b; }
@@ -158,8 +167,8 @@ __device__ __forceinline__ double wave_sum(double v)
     return rl(v, 63);
 }
 // value of lane l-K (row_shr) / l+K (row_shl) inside each row of 16 lanes, 0.0 where that lane is outside the row
-template <int K> __device__ __forceinline__ double row_shr(double v) { return dpp_f64<0x110 + K, 0xf>(0.0, v); }
-template <int K> __device__ __forceinline__ double row_shl(double v) { return dpp_f64<0x100 + K, 0xf>(0.0, v); }
+template <int K> __device__ __forceinline__ double row_shr(double v) { return dpp0_f64<0x110 + K>(v); }
+template <int K> __device__ __forceinline__ double row_shl(double v) { return dpp0_f64<0x100 + K>(v); }
 // compile-time loop: f(integral_constant<int, K>) for K = LO..HI
 template <int LO, int HI, typename F>
 __device__ __forceinline__ void static_for(F &&f)

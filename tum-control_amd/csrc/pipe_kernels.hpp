@@ -905,13 +905,17 @@ __global__ void __launch_bounds__(64, IPM_WPS) ipm_kernel(const PArgs pa)
                 constexpr bool PRE = (IPM_WPS == 1 && NT == 5);          // (the five-tile build fetches the factor up front)
                 double Lo[NTT][4], Ld[NT][4], Lp[NT];
                 auto lo_f = [&](int J, int K, int d) { return sM[rb[J] + 16 * K + co[d]]; };
+                // (the loaded value is made opaque before the select: otherwise the compiler turns "select of an LDS read" into an
+                //  exec-masked read per element -- a branch, two exec saves and a wait of its own for each of the 40 operands)
                 auto ld_f = [&](int J, int d) {
-                    const double lv = sM[rb[J] + 16 * J + co[d]];
+                    double lv = sM[rb[J] + 16 * J + co[d]];
+                    asm("" : "+v"(lv));
                     return (co[d] < lc) ? lv : ((co[d] == lc) ? 1.0 : 0.0);
                 };
                 auto lo_b = [&](int I, int J, int d) { return sM[lpk(16 * I + co[d], 0) + 16 * J + lc]; };
                 auto ld_b = [&](int J, int d) {
-                    const double lv = sM[lpk(16 * J + co[d], 0) + 16 * J + lc];
+                    double lv = sM[lpk(16 * J + co[d], 0) + 16 * J + lc];
+                    asm("" : "+v"(lv));
                     return (co[d] > lc) ? lv : ((co[d] == lc) ? 1.0 : 0.0);
                 };
                 if (PRE) {
