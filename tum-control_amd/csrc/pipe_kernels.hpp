@@ -810,9 +810,11 @@ __global__ void __launch_bounds__(64, IPM_WPS) ipm_kernel(const PArgs pa)
                 dselp = dsel;
                 Lc[J] = mfma4(pop, T[J][m]);
                 sM[(rel == 0) ? rb[J] + c0 + lq : (I_DUMMY - I_M)] = dsel;
-                const double bval = (rel > 0) ? Lc[J] : ((rel == 0) ? 1.0 : 0.0);
-                bd = -bval * dsel;
-                if (m < 3) T[J] = mfma(bd, bval, T[J]);
+                // (the rank-4 update takes the scaled columns as they are: their rows on and above the 4x4 diagonal block --
+                //  1 and 0 up to rounding -- only reach entries of the diagonal tile in rows or columns that are finished and
+                //  never read again)
+                bd = -Lc[J] * dsel;
+                if (m < 3) T[J] = mfma(bd, Lc[J], T[J]);
             }
             // what the last micro-panel owes: scaled columns
 #pragma unroll
