@@ -155,12 +155,7 @@ __device__ __forceinline__ double wave_prefix(double v, int /*lane*/)
     return v;
 }
 // inclusive suffix sum: reverse, prefix, reverse
-__device__ __forceinline__ double wave_suffix(double v, int lane)
-{
-    v = __shfl(v, 63 - lane, 64);
-    TUM_DPP_SCAN(op_add, 0.0)
-    return __shfl(v, 63 - lane, 64);
-}
+
 __device__ __forceinline__ double wave_sum(double v)
 {
     TUM_DPP_SCAN(op_add, 0.0)
@@ -169,6 +164,19 @@ __device__ __forceinline__ double wave_sum(double v)
 // value of lane l-K (row_shr) / l+K (row_shl) inside each row of 16 lanes, 0.0 where that lane is outside the row
 template <int K> __device__ __forceinline__ double row_shr(double v) { return dpp0_f64<0x110 + K>(v); }
 template <int K> __device__ __forceinline__ double row_shl(double v) { return dpp0_f64<0x100 + K>(v); }
+// inclusive suffix sum over the wavefront: a suffix scan inside each row of 16 lanes (row_shl 1, 2, 4, 8), then the totals of the
+// later rows (lanes 16, 32, 48 hold them) through scalar registers. (DPP has no backward counterpart of row_bcast 15 / 31, and
+// reversing the lanes around the forward scan costs two trips through the LDS crossbar on the critical path.)
+__device__ __forceinline__ double wave_suffix(double v, int lane)
+{
+    v += row_shl<1>(v); v += row_shl<2>(v); v += row_shl<4>(v); v += row_shl<8>(v);
+    const double r1 = rl(v, 16), r2 = rl(v, 32), r3 = rl(v, 48);
+    const int q = lane >> 4;
+    double c = (q < 3) ? r3 : 0.0;
+    c += (q < 2) ? r2 : 0.0;
+    c += (q < 1) ? r1 : 0.0;
+    return v + c;
+}
 // compile-time loop: f(integral_constant<int, K>) for K = LO..HI
 template <int LO, int HI, typename F>
 __device__ __forceinline__ void static_for(F &&f)
