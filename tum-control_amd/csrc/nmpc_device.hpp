@@ -39,6 +39,9 @@ constexpr int LPK = NVP * (NVP + 1) / 2;    // 3240 packed lower-triangular entr
 
 __host__ __device__ constexpr int tidx(int K, int I) { return K * NT - K * (K - 1) / 2 + (I - K); }   // K <= I
 __host__ __device__ constexpr int lpk(int i, int j) { return i * (i + 1) / 2 + j; }                    // i >= j
+// packed start of row R0 + r for a compile-time R0 and a small lane value r whose r (r + 1) / 2 is at hand: one 24-bit multiply-add
+// (lpk on a lane value costs a full-width integer multiply -- quarter rate -- and a signed halving)
+__device__ __forceinline__ int lpk_row(int R0, int r, int tri_r) { return R0 * (R0 + 1) / 2 + (int)__umul24(R0, r) + tri_r; }
 // packed gg-constraint rows: stage s (1..N) owns one row (grad h' G_s) of 2s entries.
 // (The steering-angle rows need no storage: delta is a pure integrator of the steering rate, so
 //  row s of that block is dt on the odd (steering-rate) columns < 2s and 0 elsewhere.)

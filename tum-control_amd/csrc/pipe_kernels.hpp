@@ -602,6 +602,7 @@ __global__ void __launch_bounds__(64, IPM_WPS) ipm_kernel(const PArgs pa)
         asm volatile("" : "+v"(lane_v));
         const int lane = lane_v;
         const int lq = lane >> 4, lc = lane & 15;
+        const int trilq = (lq * (lq + 1)) >> 1;
         PIPE_LANE_DEFS
         // ---- row phase A: residual norms, gamma
         double gap;
@@ -763,7 +764,7 @@ __global__ void __launch_bounds__(64, IPM_WPS) ipm_kernel(const PArgs pa)
                     } else if (m > 0 && k < 2 * nd) {
                         const int I = J + 1 + k - nd;
                         if (I < NT) sM[rb[I] + c0 - 4 + lq] = Lc[I];
-                        else sM[(4 * (m - 1) + lq > lc) ? lpk(c0 - 4 + lq, 16 * J + lc) : (I_DUMMY - I_M)] = Lc[NT] * dselp;
+                        else sM[(4 * (m - 1) + lq > lc) ? lpk_row(c0 - 4, lq, trilq) + 16 * J + lc : (I_DUMMY - I_M)] = Lc[NT] * dselp;
                         T[I] = mfma(bd, Lc[I], T[I]);
                     }
                     __builtin_amdgcn_sched_barrier(0);
@@ -822,7 +823,7 @@ __global__ void __launch_bounds__(64, IPM_WPS) ipm_kernel(const PArgs pa)
 #pragma unroll
             for (int I = J + 1; I <= NT; I++) {
                 if (I < NT) sM[rb[I] + 16 * J + 12 + lq] = Lc[I];
-                else sM[(12 + lq > lc) ? lpk(16 * J + 12 + lq, 16 * J + lc) : (I_DUMMY - I_M)] = Lc[NT] * dselp;
+                else sM[(12 + lq > lc) ? lpk_row(16 * J + 12, lq, trilq) + 16 * J + lc : (I_DUMMY - I_M)] = Lc[NT] * dselp;
             }
             wsync();
             TUM_TICK(11);
@@ -906,20 +907,30 @@ __global__ void __launch_bounds__(64, IPM_WPS) ipm_kernel(const PArgs pa)
                 for (int d = 0; d < 4; d++) co[d] = 4 * ((blk - d) & 3) + lq;
                 constexpr bool PRE = (IPM_WPS == 1 && NT == 5);          // (the five-tile build fetches the factor up front)
                 double Lo[NTT][4], Ld[NT][4], Lp[NT];
+                int tco[4];                                  // co (co + 1) / 2: the lane part of a packed row start (lpk_row)
+#pragma unroll
+                for (int d = 0; d < 4; d++) tco[d] = (int)(__umul24(co[d], co[d] + 1) >> 1);
+                const int edg = 4 * blk + lq, tedg = (int)(__umul24(edg, edg + 1) >> 1) + edg;
                 auto lo_f = [&](int J, int K, int d) { return sM[rb[J] + 16 * K + co[d]]; };
-                // (the loaded value is made opaque before the select: otherwise the compiler turns "select of an LDS read" into an
-                //  exec-masked read per element -- a branch, two exec saves and a wait of its own for each of the 40 operands)
-                auto ld_f = [&](int J, int d) {
-                    double lv = sM[rb[J] + 16 * J + co[d]];
-                    asm("" : "+v"(lv));
-                    return (co[d] < lc) ? lv : ((co[d] == lc) ? 1.0 : 0.0);
+                // (the four loaded values of a tile are made opaque TOGETHER before the selects: otherwise the compiler turns
+                //  "select of an LDS read" into an exec-masked read per element -- a branch, two exec saves and a wait of its own
+                //  for each of the 40 operands; one opaque point per element would still wait for every read on its own)
+                auto ld_f = [&](int J, double *o) {
+                    double l0 = sM[rb[J] + 16 * J + co[0]], l1 = sM[rb[J] + 16 * J + co[1]], l2 = sM[rb[J] + 16 * J + co[2]],
+                           l3 = sM[rb[J] + 16 * J + co[3]];
+                    asm("" : "+v"(l0), "+v"(l1), "+v"(l2), "+v"(l3));
+                    o[0] = (co[0] < lc) ? l0 : ((co[0] == lc) ? 1.0 : 0.0); o[1] = (co[1] < lc) ? l1 : ((co[1] == lc) ? 1.0 : 0.0);
+                    o[2] = (co[2] < lc) ? l2 : ((co[2] == lc) ? 1.0 : 0.0); o[3] = (co[3] < lc) ? l3 : ((co[3] == lc) ? 1.0 : 0.0);
                 };
-                auto lo_b = [&](int I, int J, int d) { return sM[lpk(16 * I + co[d], 0) + 16 * J + lc]; };
-                auto ld_b = [&](int J, int d) {
-                    double lv = sM[lpk(16 * J + co[d], 0) + 16 * J + lc];
-                    asm("" : "+v"(lv));
-                    return (co[d] > lc) ? lv : ((co[d] == lc) ? 1.0 : 0.0);
+                auto lo_b = [&](int I, int J, int d) { return sM[lpk_row(16 * I, co[d], tco[d]) + 16 * J + lc]; };
+                auto ld_b = [&](int J, double *o) {
+                    double l0 = sM[lpk_row(16 * J, co[0], tco[0]) + 16 * J + lc], l1 = sM[lpk_row(16 * J, co[1], tco[1]) + 16 * J + lc],
+                           l2 = sM[lpk_row(16 * J, co[2], tco[2]) + 16 * J + lc], l3 = sM[lpk_row(16 * J, co[3], tco[3]) + 16 * J + lc];
+                    asm("" : "+v"(l0), "+v"(l1), "+v"(l2), "+v"(l3));
+                    o[0] = (co[0] > lc) ? l0 : ((co[0] == lc) ? 1.0 : 0.0); o[1] = (co[1] > lc) ? l1 : ((co[1] == lc) ? 1.0 : 0.0);
+                    o[2] = (co[2] > lc) ? l2 : ((co[2] == lc) ? 1.0 : 0.0); o[3] = (co[3] > lc) ? l3 : ((co[3] == lc) ? 1.0 : 0.0);
                 };
+                auto l_piv = [&](int J) { return sM[lpk_row(16 * J, edg, tedg) + 16 * J]; };       // D of entry 4 blk + lq of block J
                 if (PRE) {
 #pragma unroll
                     for (int J = 0; J < NT; J++) {
@@ -927,9 +938,8 @@ __global__ void __launch_bounds__(64, IPM_WPS) ipm_kernel(const PArgs pa)
                         for (int K = 0; K < J; K++)
 #pragma unroll
                             for (int d = 0; d < 4; d++) Lo[tidx(K, J)][d] = lo_f(J, K, d);
-#pragma unroll
-                        for (int d = 0; d < 4; d++) Ld[J][d] = ld_f(J, d);
-                        Lp[J] = sM[lpk(16 * J + 4 * blk + lq, 16 * J + 4 * blk + lq)];
+                        ld_f(J, Ld[J]);
+                        Lp[J] = l_piv(J);
                     }
                     __builtin_amdgcn_sched_barrier(0);
                 }
@@ -948,10 +958,11 @@ __global__ void __launch_bounds__(64, IPM_WPS) ipm_kernel(const PArgs pa)
                         t -= acc + acc1;
                     }
                     const double t1 = row_ror<4>(t), t2 = row_ror<8>(t), t3 = row_ror<12>(t);
-                    double y = mfma4a(PRE ? Ld[J][0] : ld_f(J, 0), t, 0.0), y1 = mfma4a(PRE ? Ld[J][1] : ld_f(J, 1), t1, 0.0);
-                    y = mfma4a(PRE ? Ld[J][2] : ld_f(J, 2), t2, y); y1 = mfma4a(PRE ? Ld[J][3] : ld_f(J, 3), t3, y1);
+                    if (!PRE) ld_f(J, Ld[J]);
+                    double y = mfma4a(Ld[J][0], t, 0.0), y1 = mfma4a(Ld[J][1], t1, 0.0);
+                    y = mfma4a(Ld[J][2], t2, y); y1 = mfma4a(Ld[J][3], t3, y1);
                     y += y1;
-                    bj[J] = y * frcp(PRE ? Lp[J] : sM[lpk(16 * J + 4 * blk + lq, 16 * J + 4 * blk + lq)]);
+                    bj[J] = y * frcp(PRE ? Lp[J] : l_piv(J));
                     if (J < NT - 1) { vr[J][0] = y; vr[J][1] = row_ror<4>(y); vr[J][2] = row_ror<8>(y); vr[J][3] = row_ror<12>(y); }
                 }
                 if (PRE) {
@@ -961,8 +972,7 @@ __global__ void __launch_bounds__(64, IPM_WPS) ipm_kernel(const PArgs pa)
                         for (int I = J + 1; I < NT; I++)
 #pragma unroll
                             for (int d = 0; d < 4; d++) Lo[tidx(J, I)][d] = lo_b(I, J, d);
-#pragma unroll
-                        for (int d = 0; d < 4; d++) Ld[J][d] = ld_b(J, d);
+                        ld_b(J, Ld[J]);
                     }
                     __builtin_amdgcn_sched_barrier(0);
                 }
@@ -981,8 +991,9 @@ __global__ void __launch_bounds__(64, IPM_WPS) ipm_kernel(const PArgs pa)
                         t -= acc + acc1;
                     }
                     const double t1 = row_ror<4>(t), t2 = row_ror<8>(t), t3 = row_ror<12>(t);
-                    double x = mfma4a(PRE ? Ld[J][0] : ld_b(J, 0), t, 0.0), x1 = mfma4a(PRE ? Ld[J][1] : ld_b(J, 1), t1, 0.0);
-                    x = mfma4a(PRE ? Ld[J][2] : ld_b(J, 2), t2, x); x1 = mfma4a(PRE ? Ld[J][3] : ld_b(J, 3), t3, x1);
+                    if (!PRE) ld_b(J, Ld[J]);
+                    double x = mfma4a(Ld[J][0], t, 0.0), x1 = mfma4a(Ld[J][1], t1, 0.0);
+                    x = mfma4a(Ld[J][2], t2, x); x1 = mfma4a(Ld[J][3], t3, x1);
                     x += x1;
                     bj[J] = x;
                     if (J > 0) { vr[J][0] = x; vr[J][1] = row_ror<4>(x); vr[J][2] = row_ror<8>(x); vr[J][3] = row_ror<12>(x); }
