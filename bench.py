@@ -414,6 +414,9 @@ def run(args, torch, dist, dev, world, rank, local_rank, solver_factory, workloa
                     "workload": "fresh batches on one stream (stale longest-first history), five steps behind that leg",
                     "kernel_ms_repeated_batch": rep_ipm_ms,
                     "achieved": ipm_flops / (ipm_ms * 1e-3) / 1e12, "frac": ipm_flops / (ipm_ms * 1e-3) / 1e12 / FP64_PEAK_TFLOPS}
+        if rep_ipm_ms:           # the same kernel on the repeated batch (exact longest-first order: no tail of late long instances)
+            rep_flops = float(it0.mean()) * ipm_flops_per_iter(N) * B
+            dominant["frac_repeated_batch"] = rep_flops / (rep_ipm_ms * 1e-3) / 1e12 / FP64_PEAK_TFLOPS
     out = {
         "metric": "SQP-RTI OCP solves/sec (batch), N=40 single-track Pacejka",
         "value": value, "unit": "OCP solves/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,

@@ -662,16 +662,19 @@ __global__ void __launch_bounds__(64, IPM_WPS) ipm_kernel(const PArgs pa)
 #pragma unroll
         for (int I = 0; I < NT; I++) {
             const int r_ = 16 * I + lc;
-            sfxo[I] = ((lq & 1) && (lc & 1) && r_ < nv) ? dt2 * sSfx[(r_ >> 1) + 1] : 0.0;
+            const double sfc = dt2 * sSfx[(r_ >> 1) + 1];
+            sfxo[I] = ((lq & 1) && (lc & 1) && r_ < nv) ? sfc : 0.0;
             if constexpr (PRE_DIAG) {
+                // entry (row, col) of a diagonal tile takes the suffix sum at max(row, col): the suffix sums of the (positive)
+                // weights do not increase with the index, so that is the smaller of the row's and the column's; the box term
+                // sits on the diagonal only and is read for the lane's column
+                const double wbc = sWb[(r_ >> 1) < NMAX ? (r_ >> 1) : 0];
 #pragma unroll
                 for (int jj = 0; jj < 4; jj++) {
                     const int row = 16 * I + lq + 4 * jj, col = r_;
-                    const int mx = (row > col) ? row : col;
-                    const double sf = sSfx[(mx >> 1) + 1];
-                    double add = ((row & 1) && (col & 1) && mx < nv) ? dt2 * sf : 0.0;
-                    const double wb = sWb[(row >> 1) < NMAX ? (row >> 1) : 0];
-                    if (row == col) add += p_reg + (((row & 1) && row < nv) ? wb : 0.0);
+                    const double sfr = dt2 * sSfx[((16 * I + 4 * jj + lq) >> 1) + 1];
+                    double add = ((row & 1) && (col & 1) && row < nv && col < nv) ? fmin(sfr, sfc) : 0.0;
+                    if (row == col) add += p_reg + (((row & 1) && row < nv) ? wbc : 0.0);
                     dadd[I][jj] = add;
                 }
             }
@@ -1124,20 +1127,38 @@ __global__ void __launch_bounds__(64, IPM_WPS) ipm_kernel(const PArgs pa)
                 double dvT[NT];
 #pragma unroll
                 for (int T = 0; T < NT; T++) dvT[T] = sDv[16 * T + lc];
+                // (a butterfly that folds the chunks into each other on the way down: at distance 8 a register keeps one chunk in
+                //  the lower and another in the upper half of every DPP row, at distance 4 two such registers are folded again ...
+                //  the last register holds a different row total in (almost) every lane: 9 merges of 7 instructions and 2 plain
+                //  steps of 3 instead of 40 steps of 3, and ONE store instead of one masked store per chunk)
+                static_assert(NC == 10 || NC == 12, "the reduction tree below is written for 10 or 12 row chunks");
                 double pr[NC];
 #pragma unroll
                 for (int c = 0; c < NC; c++) {
                     double a = 0.0;
 #pragma unroll
                     for (int T = 0; 2 * T <= c; T++) a += chv[cidx(c, T)] * dvT[T];
-                    a += row_shr<8>(a); a += row_shr<4>(a); a += row_shr<2>(a); a += row_shr<1>(a);
                     pr[c] = a;
                 }
-                wsync();
-                if (lc == 15) {
+                const bool h8 = lc & 8, h4 = lc & 4, h2 = lc & 2, h1 = lc & 1;
+                // merge<CTRL>: lanes whose bit is clear keep `lo`'s partial sums, the others `hi`'s; the DPP pattern (mirror of
+                // the row / the half row / the quad, swap of neighbours) brings the partner lane's share of the same chunk
+#define TUM_MERGE(CTRL, BIT, lo, hi) (((BIT) ? (hi) : (lo)) + dpp0_f64<CTRL>((BIT) ? (lo) : (hi)))
+#define TUM_FOLD(CTRL, v) ((v) + dpp0_f64<CTRL>(v))
+                double R[NC / 2];
 #pragma unroll
-                    for (int c = 0; c < NC; c++) sWh[4 * c + lq] = pr[c];
-                }
+                for (int q = 0; q < NC / 2; q++) R[q] = TUM_MERGE(0x140, h8, pr[2 * q], pr[2 * q + 1]);
+                const double S0 = TUM_MERGE(0x141, h4, R[0], R[1]), S1 = TUM_MERGE(0x141, h4, R[2], R[3]);
+                double S2;
+                if constexpr (NC == 12) S2 = TUM_MERGE(0x141, h4, R[4], R[NC / 2 - 1]); else S2 = TUM_FOLD(0x141, R[4]);
+                const double U0 = TUM_MERGE(0x1b, h2, S0, S1), U1 = TUM_FOLD(0x1b, S2);
+                const double V = TUM_MERGE(0xb1, h1, U0, U1);
+#undef TUM_MERGE
+#undef TUM_FOLD
+                // chunk whose row total this lane holds
+                const int cl = h1 ? 8 + ((NC == 12 && h4) ? 2 : 0) + (h8 ? 1 : 0) : (h2 ? 4 : 0) + (h4 ? 2 : 0) + (h8 ? 1 : 0);
+                wsync();
+                sWh[4 * cl + lq] = V;
                 wsync();
                 if constexpr (SLOTS == 2) {
                     cdv[0] = gglane ? sWh[2 * gj] : xo;
@@ -1156,10 +1177,13 @@ __global__ void __launch_bounds__(64, IPM_WPS) ipm_kernel(const PArgs pa)
                     const bool on_ = on[rr];
                     const double eps = sd ? -1.0 : 1.0;
                     const double s_ = ROWF(0, k), t_ = ROWF(1, k), l_ = ROWF(2, k), m_ = ROWF(3, k);
-                    const double is_ = frcp(s_), il_ = frcp(l_), it_ = frcp(t_), im_ = frcp(m_);
+                    double rc1 = t_ * l_, rc2 = s_ * m_;
+                    // 1/s, 1/mu and 1/t, 1/lam from the reciprocals of the two complementarity products (two quarter-rate
+                    // v_rcp_f64 per row side instead of four)
+                    const double i1_ = frcp(rc1), i2_ = frcp(rc2);
+                    const double is_ = m_ * i2_, im_ = s_ * i2_, il_ = t_ * i1_, it_ = l_ * i1_;
                     const double iDs = s_ * rD[k];
                     const double gam = l_ * rG[k];
-                    double rc1 = t_ * l_, rc2 = s_ * m_;
                     if (pass == 1) { rc1 += cross1[k] - tau; rc2 += cross2[k] - tau; }
                     const double rsk = ROWF(4, k);
                     const double rho = -ROWF(5, k) + rc1 * il_ - (rsk + rc2 * is_) * iDs;
