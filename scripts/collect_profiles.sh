@@ -13,6 +13,7 @@ P="python bench.py --streams 1 --no-cpu-baseline --no-schedule-legs"
 $T python bench.py --steps 20 --warmup 3 2>/dev/null < /dev/null | grep metric > $OUT/bench.json
 $T rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o s -- $P --steps 20 --warmup 3 > $OUT/stats_bench.log 2>&1 < /dev/null
 $T rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats3 -o s -- python bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-schedule-legs > /dev/null 2>&1 < /dev/null
+$T rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_rep -o s -- $P --same-batch --steps 20 --warmup 3 > /dev/null 2>&1 < /dev/null
 $T rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -o p -- $P --steps 4 --warmup 1 > /dev/null 2>&1 < /dev/null
 $T rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -o p -- $P --steps 4 --warmup 1 > /dev/null 2>&1 < /dev/null
 $T rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_INSTS_VALU SQ_INSTS_LDS --output-format csv -d $OUT/pmc_sq1 -o p -- $P --steps 2 --warmup 1 > /dev/null 2>&1 < /dev/null
@@ -28,5 +29,8 @@ for S in 1 2 3 4 6; do $T python bench.py --steps 20 --warmup 3 --streams $S --n
 $T python scripts/snmpc_bench.py 2>&1 < /dev/null | grep -v amdgpu.ids > $OUT/snmpc_bench.txt
 $T python scripts/pcie_inclusive.py 2>&1 < /dev/null | grep PCIe > $OUT/pcie.txt
 $T python scripts/closed_loop_variants.py 2>&1 < /dev/null | grep -v amdgpu.ids > $OUT/closed_loops.txt
+$T python scripts/dev/ab2.py exp_libs/lib_3bc4d34.so shipped 2>&1 < /dev/null | grep -v amdgpu.ids > $OUT/ab_round3_instruction_work.txt
+W=$(ls exp_libs/lib_*_wps2.so 2>/dev/null | head -1)      # TAG=wps2 scripts/dev/build_exp_lib.sh HEAD -DIPM_WPS=2
+[ -n "$W" ] && $T python scripts/dev/ab2.py shipped $W 2>&1 < /dev/null | grep -v amdgpu.ids > $OUT/ipm_occupancy.txt
 $T python scripts/dev/ipm4_prof.py 4096 2>&1 < /dev/null | grep -v amdgpu.ids > $OUT/ipm4_phases.txt
 head -8 $OUT/stats/s_kernel_stats.csv | cut -c1-150; cut -c1-300 $OUT/bench.json

@@ -6,7 +6,9 @@ src, dst = "gpurun_out/final", "profiles"
 shutil.copy(f"{src}/stats/s_kernel_stats.csv", f"{dst}/{tag}_kernel_stats.csv")          # bench.py --streams 1 (one stream)
 if os.path.exists(f"{src}/stats3/s_kernel_stats.csv"):
     shutil.copy(f"{src}/stats3/s_kernel_stats.csv", f"{dst}/{tag}_kernel_stats_3streams.csv")      # the default command
-for f in ("phase_cycles.txt", "configs.jsonl", "kernel_variants.txt", "ipm_occupancy.txt", "snmpc_bench.txt", "pcie.txt", "streams.txt",
+if os.path.exists(f"{src}/stats_rep/s_kernel_stats.csv"):
+    shutil.copy(f"{src}/stats_rep/s_kernel_stats.csv", f"{dst}/{tag}_kernel_stats_repeated.csv")      # bench.py --streams 1 --same-batch
+for f in ("ab_round3_instruction_work.txt", "phase_cycles.txt", "configs.jsonl", "kernel_variants.txt", "ipm_occupancy.txt", "snmpc_bench.txt", "pcie.txt", "streams.txt",
           "closed_loops.txt", "ipm4_phases.txt"):
     if os.path.exists(f"{src}/{f}"):
         shutil.copy(f"{src}/{f}", f"{dst}/{tag}_{f}")
