@@ -934,16 +934,35 @@ __global__ void __launch_bounds__(64, IPM_WPS) ipm_kernel(const PArgs pa)
                     o[2] = (co[2] > lc) ? l2 : ((co[2] == lc) ? 1.0 : 0.0); o[3] = (co[3] > lc) ? l3 : ((co[3] == lc) ? 1.0 : 0.0);
                 };
                 auto l_piv = [&](int J) { return sM[lpk_row(16 * J, edg, tedg) + 16 * J]; };       // D of entry 4 blk + lq of block J
-                if (PRE) {
+                // The off-diagonal tile operands are only ever read by the matrix instructions, which take their A operand from an
+                // ACCUMULATOR register as well: the reads are issued by hand with an accumulator register as the destination
+                // (`ds_read_b64 a[..]`), so that the 80 registers they occupy during a substitution do not push the row state
+                // (48 + 48 registers of s, t, lambda, mu, residuals, D, G, cross terms) out of the vector registers and back --
+                // which the register allocator did with 200 v_accvgpr moves per pass. The compiler does not know these reads:
+                // TUM_LDS_WAIT4 (s_waitcnt lgkmcnt(0), tied to the four values of a tile) stands between them and their use.
+#define TUM_LDS_A64(dst, addr, off) asm volatile("ds_read_b64 %0, %1 offset:%2" : "=a"(dst) : "v"(addr), "i"(off))
+#define TUM_LDS_WAIT4(a) asm("s_waitcnt lgkmcnt(0)" : "+a"((a)[0]), "+a"((a)[1]), "+a"((a)[2]), "+a"((a)[3]))
+                const unsigned sMb = (unsigned)(size_t)sM;         // LDS byte address of the factor
+                if constexpr (PRE) {
 #pragma unroll
-                    for (int J = 0; J < NT; J++) {
+                    for (int J = 1; J < NT; J++) {
+                        unsigned a[4];
+#pragma unroll
+                        for (int d = 0; d < 4; d++) a[d] = sMb + 8u * (unsigned)(rb[J] + co[d]);
 #pragma unroll
                         for (int K = 0; K < J; K++)
 #pragma unroll
-                            for (int d = 0; d < 4; d++) Lo[tidx(K, J)][d] = lo_f(J, K, d);
+                            for (int d = 0; d < 4; d++) TUM_LDS_A64(Lo[D::tidx(K, J)][d], a[d], 128 * K);
+                    }
+#pragma unroll
+                    for (int J = 0; J < NT; J++) {
                         ld_f(J, Ld[J]);
                         Lp[J] = l_piv(J);
                     }
+#pragma unroll
+                    for (int J = 1; J < NT; J++)
+#pragma unroll
+                        for (int K = 0; K < J; K++) TUM_LDS_WAIT4(Lo[D::tidx(K, J)]);
                     __builtin_amdgcn_sched_barrier(0);
                 }
 #pragma unroll
@@ -968,17 +987,27 @@ __global__ void __launch_bounds__(64, IPM_WPS) ipm_kernel(const PArgs pa)
                     bj[J] = y * frcp(PRE ? Lp[J] : l_piv(J));
                     if (J < NT - 1) { vr[J][0] = y; vr[J][1] = row_ror<4>(y); vr[J][2] = row_ror<8>(y); vr[J][3] = row_ror<12>(y); }
                 }
-                if (PRE) {
+                if constexpr (PRE) {
 #pragma unroll
-                    for (int J = 0; J < NT; J++) {
+                    for (int I = 1; I < NT; I++) {
+                        unsigned a[4];
 #pragma unroll
-                        for (int I = J + 1; I < NT; I++)
+                        for (int d = 0; d < 4; d++) a[d] = sMb + 8u * (unsigned)((int)__umul24(16 * I, co[d]) + tco[d] + lc);
 #pragma unroll
-                            for (int d = 0; d < 4; d++) Lo[tidx(J, I)][d] = lo_b(I, J, d);
-                        ld_b(J, Ld[J]);
+                        for (int J = 0; J < I; J++)
+#pragma unroll
+                            for (int d = 0; d < 4; d++) TUM_LDS_A64(Lo[D::tidx(J, I)][d], a[d], 8 * (lpk(16 * I, 0) + 16 * J));
                     }
+#pragma unroll
+                    for (int J = 0; J < NT; J++) ld_b(J, Ld[J]);
+#pragma unroll
+                    for (int I = 1; I < NT; I++)
+#pragma unroll
+                        for (int J = 0; J < I; J++) TUM_LDS_WAIT4(Lo[D::tidx(J, I)]);
                     __builtin_amdgcn_sched_barrier(0);
                 }
+#undef TUM_LDS_A64
+#undef TUM_LDS_WAIT4
 #pragma unroll
                 for (int J = NT - 1; J >= 0; J--) {
                     double t = bj[J];
