@@ -19,6 +19,11 @@
 #include "common_kernels.hpp"
 #include "snmpc_kernels.hpp"
 
+// wavefronts per SIMD the interior point kernel is bounded to (1: the whole register file; 2: an experiment build)
+#ifndef IPM_WPS
+#define IPM_WPS 1
+#endif
+
 namespace tum {
 
 constexpr int PREC = 64;                        // doubles per stage record
@@ -49,7 +54,13 @@ template <int NT_> struct PD {
     static constexpr int I_DUMMY = I_SFX + NMAX + 2;
     static constexpr int I_PZ = I_DUMMY + 1;        // 18       quadratic slack penalties Zl, Zu of the 9 (class, row type) pairs
     static constexpr int I_M = I_PZ + 18;           // LPK      KKT matrix / L D L' factor
-    static constexpr int I_LDS = I_M + LPK, I_LDS_BYTES = I_LDS * 8;
+    // five-tile build: the inverse diagonal blocks of the factor as DENSE 16x16 tiles (pitch 17, unit diagonal, zeros above it,
+    // both written once): the substitutions read them without masks, straight into accumulator registers. (Six tiles: no room --
+    // they stay in the strict lower triangle of the packed diagonal tiles and are read with masks.)
+    static constexpr bool DENSE_W = (NT_ == 5 && IPM_WPS == 1);
+    static constexpr int W_PITCH = 17, W_TILE = 16 * W_PITCH;
+    static constexpr int I_W = I_M + LPK;
+    static constexpr int I_LDS = I_W + (DENSE_W ? NT_ * W_TILE : 0), I_LDS_BYTES = I_LDS * 8;
     static_assert(NVP <= 2 * NMAX + 2, "the v-space alias must fit in the box / suffix buffers");
     static_assert(I_LDS_BYTES <= 40 * 1024, "four workgroups per CU");
     static __host__ __device__ constexpr int tidx(int K, int I) { return K * NT_ - K * (K - 1) / 2 + (I - K); }   // K <= I
@@ -497,9 +508,6 @@ __global__ void __launch_bounds__(64) expand_kernel(const PArgs pa)
     _Pragma("unroll") \
     for (int I = 0; I < NT; I++) rb[I] = lpk(16 * I + lc, 0);
 
-#ifndef IPM_WPS
-#define IPM_WPS 1
-#endif
 template <bool PROF, int NT_>
 __global__ void __launch_bounds__(64, IPM_WPS) ipm_kernel(const PArgs pa)
 {
@@ -528,6 +536,8 @@ __global__ void __launch_bounds__(64, IPM_WPS) ipm_kernel(const PArgs pa)
     long long pacc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     long long tprev = __builtin_readcyclecounter();
     for (int i = lane; i < I_PZ; i += 64) lds[i] = 0.0;
+    if constexpr (D::DENSE_W)
+        for (int i = lane; i < NT * D::W_TILE; i += 64) lds[D::I_W + i] = ((i % D::W_TILE) / D::W_PITCH == (i % D::W_TILE) % D::W_PITCH) ? 1.0 : 0.0;
     if (lane < 18) sPZ[lane] = gpen[(lane >> 1) * 4 + 2 + (lane & 1)];
     // the gg rows, MFMA operand layout (30 coalesced loads), resident in registers for the whole solve: the KKT assembly and the
     // row phases take their operands from them. (Only the IPM_WPS = 2 build re-reads them from the workspace behind every
@@ -603,6 +613,7 @@ __global__ void __launch_bounds__(64, IPM_WPS) ipm_kernel(const PArgs pa)
         const int lane = lane_v;
         const int lq = lane >> 4, lc = lane & 15;
         const int trilq = (lq * (lq + 1)) >> 1;
+        const int wl = lq * D::W_PITCH + lc;          // (row lq, column lc) of a dense inverse diagonal block
         PIPE_LANE_DEFS
         // ---- row phase A: residual norms, gamma
         double gap;
@@ -767,6 +778,7 @@ __global__ void __launch_bounds__(64, IPM_WPS) ipm_kernel(const PArgs pa)
                     } else if (m > 0 && k < 2 * nd) {
                         const int I = J + 1 + k - nd;
                         if (I < NT) sM[rb[I] + c0 - 4 + lq] = Lc[I];
+                        else if constexpr (D::DENSE_W) lds[(4 * (m - 1) + lq > lc) ? D::I_W + J * D::W_TILE + 4 * (m - 1) * D::W_PITCH + wl : I_DUMMY] = Lc[NT] * dselp;
                         else sM[(4 * (m - 1) + lq > lc) ? lpk_row(c0 - 4, lq, trilq) + 16 * J + lc : (I_DUMMY - I_M)] = Lc[NT] * dselp;
                         T[I] = mfma(bd, Lc[I], T[I]);
                     }
@@ -826,6 +838,7 @@ __global__ void __launch_bounds__(64, IPM_WPS) ipm_kernel(const PArgs pa)
 #pragma unroll
             for (int I = J + 1; I <= NT; I++) {
                 if (I < NT) sM[rb[I] + 16 * J + 12 + lq] = Lc[I];
+                else if constexpr (D::DENSE_W) lds[(12 + lq > lc) ? D::I_W + J * D::W_TILE + 12 * D::W_PITCH + wl : I_DUMMY] = Lc[NT] * dselp;
                 else sM[(12 + lq > lc) ? lpk_row(16 * J + 12, lq, trilq) + 16 * J + lc : (I_DUMMY - I_M)] = Lc[NT] * dselp;
             }
             wsync();
@@ -890,7 +903,6 @@ __global__ void __launch_bounds__(64, IPM_WPS) ipm_kernel(const PArgs pa)
             ctw(b0, b1);
             b0 = v0on ? -rv0 - b0 : 0.0; b1 = v1on ? -rv1 - b1 : 0.0;
             TUM_TICK(5);
-#ifndef IPM_OLD_SOLVES
             {
                 // The two substitutions on v_mfma_f64_4x4x4_4b (four independent 4x4x4 products per instruction, 21 cycles). A
                 // vector block lives in "D form": lane (lq, lc) holds entry 4 (lc >> 2) + lq of the 16 -- what the instruction
@@ -908,7 +920,7 @@ __global__ void __launch_bounds__(64, IPM_WPS) ipm_kernel(const PArgs pa)
                 int co[4];                                   // column (forward) / row (backward) offset of the block met at rotation d
 #pragma unroll
                 for (int d = 0; d < 4; d++) co[d] = 4 * ((blk - d) & 3) + lq;
-                constexpr bool PRE = (IPM_WPS == 1 && NT == 5);          // (the five-tile build fetches the factor up front)
+                constexpr bool PRE = D::DENSE_W;          // (the five-tile build fetches the factor up front)
                 double Lo[NTT][4], Ld[NT][4], Lp[NT];
                 int tco[4];                                  // co (co + 1) / 2: the lane part of a packed row start (lpk_row)
 #pragma unroll
@@ -943,6 +955,7 @@ __global__ void __launch_bounds__(64, IPM_WPS) ipm_kernel(const PArgs pa)
 #define TUM_LDS_A64(dst, addr, off) asm volatile("ds_read_b64 %0, %1 offset:%2" : "=a"(dst) : "v"(addr), "i"(off))
 #define TUM_LDS_WAIT4(a) asm("s_waitcnt lgkmcnt(0)" : "+a"((a)[0]), "+a"((a)[1]), "+a"((a)[2]), "+a"((a)[3]))
                 const unsigned sMb = (unsigned)(size_t)sM;         // LDS byte address of the factor
+                const unsigned sWb_ = (unsigned)(size_t)(lds + D::I_W);      // ... of the dense inverse diagonal blocks (five tiles)
                 if constexpr (PRE) {
 #pragma unroll
                     for (int J = 1; J < NT; J++) {
@@ -954,15 +967,23 @@ __global__ void __launch_bounds__(64, IPM_WPS) ipm_kernel(const PArgs pa)
 #pragma unroll
                             for (int d = 0; d < 4; d++) TUM_LDS_A64(Lo[D::tidx(K, J)][d], a[d], 128 * K);
                     }
+                    {   // inverse diagonal blocks, dense: entry (row lc, column co[d]) of block J
+                        unsigned a[4];
 #pragma unroll
-                    for (int J = 0; J < NT; J++) {
-                        ld_f(J, Ld[J]);
-                        Lp[J] = l_piv(J);
+                        for (int d = 0; d < 4; d++) a[d] = sWb_ + 8u * (unsigned)(lc * D::W_PITCH + co[d]);
+#pragma unroll
+                        for (int J = 0; J < NT; J++)
+#pragma unroll
+                            for (int d = 0; d < 4; d++) TUM_LDS_A64(Ld[J][d], a[d], 8 * D::W_TILE * J);
                     }
+#pragma unroll
+                    for (int J = 0; J < NT; J++) Lp[J] = l_piv(J);
 #pragma unroll
                     for (int J = 1; J < NT; J++)
 #pragma unroll
                         for (int K = 0; K < J; K++) TUM_LDS_WAIT4(Lo[D::tidx(K, J)]);
+#pragma unroll
+                    for (int J = 0; J < NT; J++) TUM_LDS_WAIT4(Ld[J]);
                     __builtin_amdgcn_sched_barrier(0);
                 }
 #pragma unroll
@@ -998,12 +1019,21 @@ __global__ void __launch_bounds__(64, IPM_WPS) ipm_kernel(const PArgs pa)
 #pragma unroll
                             for (int d = 0; d < 4; d++) TUM_LDS_A64(Lo[D::tidx(J, I)][d], a[d], 8 * (lpk(16 * I, 0) + 16 * J));
                     }
+                    {   // the transposes of the inverse diagonal blocks: entry (row co[d], column lc) of block J
+                        unsigned a[4];
 #pragma unroll
-                    for (int J = 0; J < NT; J++) ld_b(J, Ld[J]);
+                        for (int d = 0; d < 4; d++) a[d] = sWb_ + 8u * (unsigned)(co[d] * D::W_PITCH + lc);
+#pragma unroll
+                        for (int J = 0; J < NT; J++)
+#pragma unroll
+                            for (int d = 0; d < 4; d++) TUM_LDS_A64(Ld[J][d], a[d], 8 * D::W_TILE * J);
+                    }
 #pragma unroll
                     for (int I = 1; I < NT; I++)
 #pragma unroll
                         for (int J = 0; J < I; J++) TUM_LDS_WAIT4(Lo[D::tidx(J, I)]);
+#pragma unroll
+                    for (int J = 0; J < NT; J++) TUM_LDS_WAIT4(Ld[J]);
                     __builtin_amdgcn_sched_barrier(0);
                 }
 #undef TUM_LDS_A64
@@ -1041,111 +1071,6 @@ __global__ void __launch_bounds__(64, IPM_WPS) ipm_kernel(const PArgs pa)
                 dv0 = sDv[lane]; dv1 = (lane < NB1) ? sDv[64 + lane] : 0.0;
                 dv0 = v0on ? dv0 : 0.0; dv1 = v1on ? dv1 : 0.0;
             }
-#else
-            {
-                int ga[4];
-#pragma unroll
-                for (int jj = 0; jj < 4; jj++) ga[jj] = ((lane & 48) | ((lq + 4 * jj) & 15)) << 2;
-                const bool ondiag = (lc >= lq) && (((lc - lq) & 3) == 0);
-                double bj[NT], vs[NT][4];
-#pragma unroll
-                for (int J = 0; J < 4; J++) bj[J] = lane_gather(b0, (16 * J + lc) << 2);
-#pragma unroll
-                for (int J = 4; J < NT; J++) bj[J] = lane_gather(b1, (16 * (J - 4) + lc) << 2);
-                // (with the whole register file the entries of the factor this lane needs are fetched before the chain starts:
-                //  the chain itself then waits on row swaps and lane gathers only, not on LDS reads issued one tile at a time)
-                double Lo[NTT][4], Ld[NT][4], Lp[NT];       // (five-tile build with the whole register file only)
-                if (IPM_WPS == 1 && NT == 5) {
-#pragma unroll
-                    for (int J = 0; J < NT; J++) {
-#pragma unroll
-                        for (int K = 0; K < J; K++)
-#pragma unroll
-                            for (int jj = 0; jj < 4; jj++) Lo[tidx(K, J)][jj] = sM[rb[J] + 16 * K + lq + 4 * jj];
-#pragma unroll
-                        for (int jj = 0; jj < 4; jj++) Ld[J][jj] = sM[rb[J] + 16 * J + lq + 4 * jj];
-                        Lp[J] = sM[rb[J] + 16 * J + lc];
-                    }
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-#pragma unroll
-                for (int J = 0; J < NT; J++) {
-                    double t = bj[J];
-                    if (J > 0) {
-                        double acc = 0.0, acc1 = 0.0;
-#pragma unroll
-                        for (int K = 0; K < J; K++)
-#pragma unroll
-                            for (int jj = 0; jj < 4; jj++) {
-                                const double lv = (IPM_WPS == 1 && NT == 5) ? Lo[tidx(K, J)][jj] : sM[rb[J] + 16 * K + lq + 4 * jj];
-                                if (jj & 1) acc1 += lv * vs[K][jj]; else acc += lv * vs[K][jj];
-                            }
-                        t -= quad_sum(acc + acc1);
-                    }
-                    double a2 = ondiag ? t : 0.0;
-#pragma unroll
-                    for (int jj = 0; jj < 4; jj++) {
-                        const double lv = (IPM_WPS == 1 && NT == 5) ? Ld[J][jj] : sM[rb[J] + 16 * J + lq + 4 * jj];
-                        const double tv = lane_gather(t, ga[jj]);
-                        a2 += ((lq + 4 * jj < lc) ? lv : 0.0) * tv;
-                    }
-                    const double y = quad_sum(a2);
-                    bj[J] = y * frcp((IPM_WPS == 1 && NT == 5) ? Lp[J] : sM[rb[J] + 16 * J + lc]);
-                    if (J < NT - 1) {
-#pragma unroll
-                        for (int jj = 0; jj < 4; jj++) vs[J][jj] = lane_gather(y, ga[jj]);
-                    }
-                }
-                if (IPM_WPS == 1 && NT == 5) {
-#pragma unroll
-                    for (int J = 0; J < NT; J++) {
-#pragma unroll
-                        for (int I = J + 1; I < NT; I++)
-#pragma unroll
-                            for (int jj = 0; jj < 4; jj++) Lo[tidx(J, I)][jj] = sM[lpk(16 * I + lq + 4 * jj, 0) + 16 * J + lc];
-#pragma unroll
-                        for (int jj = 0; jj < 4; jj++) Ld[J][jj] = sM[lpk(16 * J + lq + 4 * jj, 0) + 16 * J + lc];
-                    }
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-#pragma unroll
-                for (int J = NT - 1; J >= 0; J--) {
-                    double t = bj[J];
-                    if (J < NT - 1) {
-                        double acc = 0.0, acc1 = 0.0;
-#pragma unroll
-                        for (int I = J + 1; I < NT; I++)
-#pragma unroll
-                            for (int jj = 0; jj < 4; jj++) {
-                                const double lv = (IPM_WPS == 1 && NT == 5) ? Lo[tidx(J, I)][jj] : sM[lpk(16 * I + lq + 4 * jj, 0) + 16 * J + lc];
-                                if (jj & 1) acc1 += lv * vs[I][jj]; else acc += lv * vs[I][jj];
-                            }
-                        t -= quad_sum(acc + acc1);
-                    }
-                    double a2 = ondiag ? t : 0.0;
-#pragma unroll
-                    for (int jj = 0; jj < 4; jj++) {
-                        const double lv = (IPM_WPS == 1 && NT == 5) ? Ld[J][jj] : sM[lpk(16 * J + lq + 4 * jj, 0) + 16 * J + lc];
-                        const double tv = lane_gather(t, ga[jj]);
-                        a2 += ((lq + 4 * jj > lc) ? lv : 0.0) * tv;
-                    }
-                    const double x = quad_sum(a2);
-                    bj[J] = x;
-                    if (J > 0) {
-#pragma unroll
-                        for (int jj = 0; jj < 4; jj++) vs[J][jj] = lane_gather(x, ga[jj]);
-                    }
-                }
-                b0 = (lq == 0) ? bj[0] : (lq == 1) ? bj[1] : (lq == 2) ? bj[2] : bj[3];
-                b1 = (lane < NB1) ? ((NT > 5 && lq == 1) ? bj[NT - 1] : bj[4]) : 0.0;
-            }
-            dv0 = b0; dv1 = b1;
-            TUM_TICK(6);
-            wsync();
-            sDv[lane] = dv0;
-            if (lane < NB1) sDv[64 + lane] = dv1;
-            wsync();
-#endif
             // row phase B2: C*dv for this lane's rows, step in (s,t,lam,mu), step length
             double cdv[SLOTS];
             {
