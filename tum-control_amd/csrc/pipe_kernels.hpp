@@ -60,7 +60,8 @@ template <int NT_> struct PD {
     static constexpr bool DENSE_W = (NT_ == 5 && IPM_WPS == 1);
     static constexpr int W_PITCH = 17, W_TILE = 16 * W_PITCH;
     static constexpr int I_W = I_M + LPK;
-    static constexpr int I_LDS = I_W + (DENSE_W ? NT_ * W_TILE : 0), I_LDS_BYTES = I_LDS * 8;
+    static constexpr int I_BK = (I_W + (DENSE_W ? NT_ * W_TILE : 0) + 1) & ~1;      // 64 (16-byte aligned): the strip of a micro-panel
+    static constexpr int I_LDS = I_BK + 64, I_LDS_BYTES = I_LDS * 8;
     static_assert(NVP <= 2 * NMAX + 2, "the v-space alias must fit in the box / suffix buffers");
     static_assert(I_LDS_BYTES <= 40 * 1024, "four workgroups per CU");
     static __host__ __device__ constexpr int tidx(int K, int I) { return K * NT_ - K * (K - 1) / 2 + (I - K); }   // K <= I
@@ -526,6 +527,7 @@ __global__ void __launch_bounds__(64, IPM_WPS) ipm_kernel(const PArgs pa)
     asm volatile("" : "+v"(p_mu0), "+v"(p_t0), "+v"(p_reg), "+v"(p_ts), "+v"(p_ti), "+v"(p_tc), "+v"(p_itmax));
 
     double *sPZ = lds + I_PZ;
+    double *sBk = lds + D::I_BK;
     double *sM = lds + I_M, *sWh = lds + I_WH, *sGamH = lds + I_WH, *sWb = lds + I_WB, *sSfx = lds + I_SFX, *sDv = lds + I_DV;
     const double *gU = ka.U + (size_t)b * N * NU;
     const double *gpen = ka.pen + (size_t)b * 36;
@@ -784,42 +786,48 @@ __global__ void __launch_bounds__(64, IPM_WPS) ipm_kernel(const PArgs pa)
                     }
                     __builtin_amdgcn_sched_barrier(0);
                 };
-                const double a00 = readlane_f64(T[J][m], 4 * m);
-                const double a10 = readlane_f64(T[J][m], 4 * m + 1), a11 = readlane_f64(T[J][m], 16 + 4 * m + 1);
+                // The ten entries of the block reach every lane through LDS: the strip is stored as it is and read back at
+                // wave-uniform addresses (broadcasts: 4 x 16 bytes + 2 x 8). Twenty v_readlane into scalar registers cost as
+                // many issue slots as the whole pivot arithmetic, and a dozen moves back on top (a VALU instruction of this
+                // part takes ONE scalar operand); the round trip runs under the matrix instructions the previous micro-panel owes.
+                typedef double dpair __attribute__((ext_vector_type(2)));
+                sBk[lane] = T[J][m];
+                const dpair c01 = *reinterpret_cast<const dpair *>(sBk + 4 * m), c23 = *reinterpret_cast<const dpair *>(sBk + 4 * m + 2);
+                const double a11 = sBk[16 + 4 * m + 1];
+                const dpair e23 = *reinterpret_cast<const dpair *>(sBk + 16 + 4 * m + 2), f23 = *reinterpret_cast<const dpair *>(sBk + 32 + 4 * m + 2);
+                const double a33 = sBk[48 + 4 * m + 3];
                 owed(0);
-                const double a20 = readlane_f64(T[J][m], 4 * m + 2), a21 = readlane_f64(T[J][m], 16 + 4 * m + 2),
-                             a22 = readlane_f64(T[J][m], 32 + 4 * m + 2);
                 owed(1);
-                const double a30 = readlane_f64(T[J][m], 4 * m + 3), a31 = readlane_f64(T[J][m], 16 + 4 * m + 3),
-                             a32 = readlane_f64(T[J][m], 32 + 4 * m + 3), a33 = readlane_f64(T[J][m], 48 + 4 * m + 3);
-                const double d0 = a00, i0 = frcp(d0);
                 owed(2);
+                const double a00 = c01[0], a10 = c01[1], a20 = c23[0], a30 = c23[1], a21 = e23[0], a31 = e23[1], a22 = f23[0], a32 = f23[1];
+                const double d0 = a00, i0 = frcp(d0);
+                owed(3);
                 const double l10 = a10 * i0, l20 = a20 * i0, l30 = a30 * i0;
                 const double d1 = a11 - l10 * a10, i1 = frcp(d1);
-                owed(3);
+                owed(4);
                 const double y21 = a21 - l20 * a10, y31 = a31 - l30 * a10;
                 const double l21 = y21 * i1, l31 = y31 * i1;
-                owed(4);
-                const double d2 = a22 - l20 * a20 - l21 * y21, i2 = frcp(d2);
                 owed(5);
+                const double d2 = a22 - l20 * a20 - l21 * y21, i2 = frcp(d2);
+                owed(6);
                 const double y32 = a32 - l30 * a20 - l31 * y21;
                 const double l32 = y32 * i2;
                 // P[k][x] = (L^-1)[x][k] / d_x on lane (k, x) = (lq, lc), x < 4: every lane runs the substitution for ITS column
                 // k of L^-1 (unit vector e_k as the start: one instruction stream, six FMAs), then picks row x
                 const double X1 = eu1 - l10 * eu0;
-                owed(6);
+                owed(7);
                 const double d3 = a33 - l30 * a30 - l31 * y31 - l32 * y32, i3 = frcp(d3);
                 const double X2 = eu2 - l20 * eu0 - l21 * X1;
-                owed(7);
+                owed(8);
                 dmin_hi = min(min(min(dmin_hi, __double2hiint(d0)), min(__double2hiint(d1), __double2hiint(d2))), __double2hiint(d3));
                 const double X3 = eu3 - l30 * eu0 - l31 * X1 - l32 * X2;
-                owed(8);
-                const double Xx = ec0 ? eu0 : ec1 ? X1 : ec2 ? X2 : X3;
                 owed(9);
-                const double ix = ec0 ? i0 : ec1 ? i1 : ec2 ? i2 : i3;
+                const double Xx = ec0 ? eu0 : ec1 ? X1 : ec2 ? X2 : X3;
                 owed(10);
-                const double popn = Xx * ix;
+                const double ix = ec0 ? i0 : ec1 ? i1 : ec2 ? i2 : i3;
                 owed(11);
+                const double popn = Xx * ix;
+                owed(12);
                 const double dsel = eq0 ? d0 : eq1 ? d1 : eq2 ? d2 : d3;
                 const int rel = lc - (4 * m + lq);              // row - column inside the diagonal tile
                 pop = popn;
