@@ -61,7 +61,8 @@ template <int NT_> struct PD {
     static constexpr int W_PITCH = 17, W_TILE = 16 * W_PITCH;
     static constexpr int I_W = I_M + LPK;
     static constexpr int I_BK = (I_W + (DENSE_W ? NT_ * W_TILE : 0) + 1) & ~1;      // 64 (16-byte aligned): the strip of a micro-panel
-    static constexpr int I_LDS = I_BK + 64, I_LDS_BYTES = I_LDS * 8;
+    static constexpr int I_ZERO = I_BK + 64;        // 1        0.0, written once
+    static constexpr int I_LDS = I_ZERO + 2, I_LDS_BYTES = I_LDS * 8;
     static_assert(NVP <= 2 * NMAX + 2, "the v-space alias must fit in the box / suffix buffers");
     static_assert(I_LDS_BYTES <= 40 * 1024, "four workgroups per CU");
     static __host__ __device__ constexpr int tidx(int K, int I) { return K * NT_ - K * (K - 1) / 2 + (I - K); }   // K <= I
@@ -538,6 +539,7 @@ __global__ void __launch_bounds__(64, IPM_WPS) ipm_kernel(const PArgs pa)
     long long pacc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     long long tprev = __builtin_readcyclecounter();
     for (int i = lane; i < I_PZ; i += 64) lds[i] = 0.0;
+    if (lane == 0) lds[D::I_ZERO] = 0.0;
     if constexpr (D::DENSE_W)
         for (int i = lane; i < NT * D::W_TILE; i += 64) lds[D::I_W + i] = ((i % D::W_TILE) / D::W_PITCH == (i % D::W_TILE) % D::W_PITCH) ? 1.0 : 0.0;
     if (lane < 18) sPZ[lane] = gpen[(lane >> 1) * 4 + 2 + (lane & 1)];
@@ -675,20 +677,20 @@ __global__ void __launch_bounds__(64, IPM_WPS) ipm_kernel(const PArgs pa)
 #pragma unroll
         for (int I = 0; I < NT; I++) {
             const int r_ = 16 * I + lc;
-            const double sfc = dt2 * sSfx[(r_ >> 1) + 1];
-            sfxo[I] = ((lq & 1) && (lc & 1) && r_ < nv) ? sfc : 0.0;
+            // (a column / row that carries no steering term -- even, or beyond nv -- is pointed at a zero, and the smaller of two such
+            //  values is the term of the entry)
+            const double sfc = dt2 * lds[((lc & 1) && r_ < nv) ? I_SFX + (r_ >> 1) + 1 : D::I_ZERO];
+            sfxo[I] = (lq & 1) ? sfc : 0.0;
             if constexpr (PRE_DIAG) {
                 // entry (row, col) of a diagonal tile takes the suffix sum at max(row, col): the suffix sums of the (positive)
                 // weights do not increase with the index, so that is the smaller of the row's and the column's; the box term
                 // sits on the diagonal only and is read for the lane's column
-                const double wbc = sWb[(r_ >> 1) < NMAX ? (r_ >> 1) : 0];
+                const double dterm = p_reg + (((lc & 1) && r_ < nv) ? sWb[(r_ >> 1) < NMAX ? (r_ >> 1) : 0] : 0.0);
 #pragma unroll
                 for (int jj = 0; jj < 4; jj++) {
-                    const int row = 16 * I + lq + 4 * jj, col = r_;
-                    const double sfr = dt2 * sSfx[((16 * I + 4 * jj + lq) >> 1) + 1];
-                    double add = ((row & 1) && (col & 1) && row < nv && col < nv) ? fmin(sfr, sfc) : 0.0;
-                    if (row == col) add += p_reg + (((row & 1) && row < nv) ? wbc : 0.0);
-                    dadd[I][jj] = add;
+                    const int row = 16 * I + lq + 4 * jj;
+                    const double sfr = dt2 * lds[((lq & 1) && row < nv) ? I_SFX + (row >> 1) + 1 : D::I_ZERO];
+                    dadd[I][jj] = fmin(sfr, sfc) + ((lq + 4 * jj == lc) ? dterm : 0.0);
                 }
             }
         }
