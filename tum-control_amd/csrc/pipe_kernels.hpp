@@ -62,7 +62,11 @@ template <int NT_> struct PD {
     static constexpr int I_W = I_M + LPK;
     static constexpr int I_BK = (I_W + (DENSE_W ? NT_ * W_TILE : 0) + 1) & ~1;      // 64 (16-byte aligned): the strip of a micro-panel
     static constexpr int I_ZERO = I_BK + 64;        // 1        0.0, written once
-    static constexpr int I_LDS = I_ZERO + 2, I_LDS_BYTES = I_LDS * 8;
+    // five-tile build: the steering and the box term of every v-space index, expanded per iteration (0 where an index has none):
+    // the diagonal tiles gather their terms with one address register and instruction offsets
+    static constexpr bool PRE_DIAG = (NT_ == 5);    // (the six-tile build has neither the registers nor the LDS for it)
+    static constexpr int I_XS = I_ZERO + 2, I_XB = I_XS + (PRE_DIAG ? NVP : 0);
+    static constexpr int I_LDS = I_XB + (PRE_DIAG ? NVP : 0), I_LDS_BYTES = I_LDS * 8;
     static_assert(NVP <= 2 * NMAX + 2, "the v-space alias must fit in the box / suffix buffers");
     static_assert(I_LDS_BYTES <= 40 * 1024, "four workgroups per CU");
     static __host__ __device__ constexpr int tidx(int K, int I) { return K * NT_ - K * (K - 1) / 2 + (I - K); }   // K <= I
@@ -651,6 +655,19 @@ __global__ void __launch_bounds__(64, IPM_WPS) ipm_kernel(const PArgs pa)
             if (it >= p_itmax) { qp_status = 1; break; }
             TUM_TICK(2);
             publish(gsum, sGamH);
+            if constexpr (D::PRE_DIAG) {
+                const double dt2_ = dt * dt;
+#pragma unroll
+                for (int h = 0; h < 2; h++) {
+                    const int r = 64 * h + lane;
+                    if (h == 0 || lane < NVP - 64) {
+                        const bool has = (r & 1) && r < nv;
+                        lds[D::I_XS + r] = dt2_ * lds[has ? I_SFX + (r >> 1) + 1 : D::I_ZERO];
+                        lds[D::I_XB + r] = lds[has ? I_WB + (r >> 1) : D::I_ZERO];
+                    }
+                }
+                wsync();
+            }
         }
         // ---- M = H + C' Gamma C is assembled block column by block column INSIDE the factorisation below, straight into the
         // register tiles the factorisation works on (M itself never exists in LDS). H is streamed from the workspace HD tiles
@@ -670,28 +687,26 @@ __global__ void __launch_bounds__(64, IPM_WPS) ipm_kernel(const PArgs pa)
         // stores of the factorisation by the compiler, and at the start of a block column their latency would be exposed):
         // gamma per chunk, the structured (steering-angle) rows' term of the off-diagonal tiles (depends on the row only) and
         // the terms of the diagonal tiles
-        constexpr bool PRE_DIAG = (NT == 5);          // (the six-tile build has no registers for the diagonal tiles' terms)
+        constexpr bool PRE_DIAG = D::PRE_DIAG;
         double gch[NC], sfxo[NT], dadd[NT][4];
 #pragma unroll
         for (int c = 0; c < NC; c++) gch[c] = sGamH[4 * c + lq];
 #pragma unroll
         for (int I = 0; I < NT; I++) {
             const int r_ = 16 * I + lc;
-            // (a column / row that carries no steering term -- even, or beyond nv -- is pointed at a zero, and the smaller of two such
-            //  values is the term of the entry)
-            const double sfc = dt2 * lds[((lc & 1) && r_ < nv) ? I_SFX + (r_ >> 1) + 1 : D::I_ZERO];
+            // (a column / row that carries no steering term -- even, or beyond nv -- reads a zero, and the smaller of two such values
+            //  is the term of the entry)
+            double sfc;
+            if constexpr (PRE_DIAG) sfc = lds[D::I_XS + r_];
+            else sfc = dt2 * lds[((lc & 1) && r_ < nv) ? I_SFX + (r_ >> 1) + 1 : D::I_ZERO];
             sfxo[I] = (lq & 1) ? sfc : 0.0;
             if constexpr (PRE_DIAG) {
                 // entry (row, col) of a diagonal tile takes the suffix sum at max(row, col): the suffix sums of the (positive)
                 // weights do not increase with the index, so that is the smaller of the row's and the column's; the box term
                 // sits on the diagonal only and is read for the lane's column
-                const double dterm = p_reg + (((lc & 1) && r_ < nv) ? sWb[(r_ >> 1) < NMAX ? (r_ >> 1) : 0] : 0.0);
+                const double dterm = p_reg + lds[D::I_XB + r_];
 #pragma unroll
-                for (int jj = 0; jj < 4; jj++) {
-                    const int row = 16 * I + lq + 4 * jj;
-                    const double sfr = dt2 * lds[((lq & 1) && row < nv) ? I_SFX + (row >> 1) + 1 : D::I_ZERO];
-                    dadd[I][jj] = fmin(sfr, sfc) + ((lq + 4 * jj == lc) ? dterm : 0.0);
-                }
+                for (int jj = 0; jj < 4; jj++) dadd[I][jj] = fmin(lds[D::I_XS + 16 * I + 4 * jj + lq], sfc) + ((lq + 4 * jj == lc) ? dterm : 0.0);
             }
         }
         // ---- blocked L D L' factorisation (row-panel register tiles as in the fused kernel; the 4-column micro-panels differ:
