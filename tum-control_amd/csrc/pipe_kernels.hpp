@@ -6,10 +6,12 @@
 //                       390 registers: one wavefront per SIMD.
 //   K2  cond_kernel     one wavefront per OCP: column recursion G_{k+1} = A_k G_k, Gauss-Newton SYRK on the matrix cores
 //                       (15 register tiles), gg rows; hands H (tiles), C (MFMA operand layout), q, d to the workspace.
-//   K3  ipm_kernel      one wavefront per OCP with the whole register file (493 of 512 registers, four OCPs per CU): the KKT
-//                       matrix is the only large LDS resident (26.9 KiB), the gg rows live in registers in MFMA operand
-//                       layout, H is streamed tile by tile from the workspace (L2). (Built with -DIPM_WPS=2 the same source is
-//                       bounded to 256 registers, two wavefronts per SIMD: measured slower)
+//   K3  ipm_kernel      one wavefront per OCP with the whole register file (450 of 512 registers, four OCPs per CU): LDS holds
+//                       the factor of the KKT matrix (26 KiB) and, in the five-tile build, its inverse diagonal blocks as dense
+//                       tiles (38.8 KiB in all); the gg rows live in registers in MFMA operand layout, H is streamed tile by
+//                       tile from the workspace (L2); the tile operands of the substitutions are read from LDS straight into
+//                       accumulator registers. (Built with -DIPM_WPS=2 the same source is bounded to 256 registers, two
+//                       wavefronts per SIMD: measured slower)
 //   K3' ipm4_kernel     (ipm4_kernel.hpp) the same method with FOUR wavefronts per OCP, each below 128 registers.
 //   K4  expand_kernel   one wavefront per OCP: dx recursion, full step, cost at the new iterate.
 //
