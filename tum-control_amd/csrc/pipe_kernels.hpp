@@ -900,7 +900,7 @@ __global__ void __launch_bounds__(64, IPM_WPS) ipm_kernel(const PArgs pa)
         }
         double cross1[NS2], cross2[NS2];
         double dv0 = 0.0, dv1 = 0.0, alpha = 1.0, sigma = 0.0;
-#pragma unroll 1
+#pragma unroll
         for (int pass = 0; pass < 2; pass++) {
             int lane_p = lane_outer;
             asm volatile("" : "+v"(lane_p));
