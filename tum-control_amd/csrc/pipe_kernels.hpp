@@ -514,7 +514,7 @@ __global__ void __launch_bounds__(64) expand_kernel(const PArgs pa)
     }; \
     int rb[NT]; \
     _Pragma("unroll") \
-    for (int I = 0; I < NT; I++) rb[I] = lpk(16 * I + lc, 0);
+    for (int I = 0; I < NT; I++) rb[I] = lpk_row(16 * I, lc, (int)(__umul24(lc, lc + 1) >> 1));
 
 template <bool PROF, int NT_>
 __global__ void __launch_bounds__(64, IPM_WPS) ipm_kernel(const PArgs pa)
@@ -766,7 +766,7 @@ __global__ void __launch_bounds__(64, IPM_WPS) ipm_kernel(const PArgs pa)
 #pragma unroll
                 for (int kc = 0; kc < 4; kc++) {
                     const int kk = 16 * K + 4 * kc + lq;
-                    const double aJ = -sM[rb[J] + kk] * sM[lpk(kk, kk)];
+                    const double aJ = -sM[rb[J] + kk] * sM[lpk_row(16 * K + 4 * kc, lq, trilq) + kk];          // (D of column kk: entry (kk, kk))
 #pragma unroll
                     for (int I = J; I < NT; I++) T[I] = mfma(aJ, sM[rb[I] + kk], T[I]);
                 }
