@@ -295,16 +295,15 @@ __global__ void __launch_bounds__(64, (NT_ == 5) ? 2 : 1) cond_kernel(const PArg
                 q1 += (lane < NB1) ? a1 : 0.0;
             }
             const double wl = (lq == 0) ? wr[0] : (lq == 1) ? wr[1] : (lq == 2) ? wr[2] : wr[3];
-            double aop[Ts], bop[Ts];
+            double bop[Ts];
 #pragma unroll
-            for (int T = 0; T < Ts; T++) {
-                bop[T] = sStage[lq * NVP + 16 * T + lc];
-                aop[T] = bop[T] * wl;
+            for (int T = 0; T < Ts; T++) bop[T] = sStage[lq * NVP + 16 * T + lc];
+#pragma unroll
+            for (int K = 0; K < Ts; K++) {
+                const double aop = bop[K] * wl;          // (one weighted operand at a time: five of them held were the registers the last segment lacked)
+#pragma unroll
+                for (int I = K; I < Ts; I++) Ht[tidx(K, I)] = mfma(aop, bop[I], Ht[tidx(K, I)]);
             }
-#pragma unroll
-            for (int K = 0; K < Ts; K++)
-#pragma unroll
-                for (int I = K; I < Ts; I++) Ht[tidx(K, I)] = mfma(aop[K], bop[I], Ht[tidx(K, I)]);
             // next stage's record into the other slot (its global load has been in flight for a whole stage)
             sRec[((k + 1) & 1) * PREC + lane] = pre;
             if (k + 2 < N) pre = fetch(k + 2);
@@ -330,7 +329,13 @@ __global__ void __launch_bounds__(64, (NT_ == 5) ? 2 : 1) cond_kernel(const PArg
             }
         }
     if (lane < nv) q0 += dt * Wd[4 + r0] * (sU0[lane] - gyref[j0 * 6 + 4 + r0]);
-    if (lane < NB1 && 64 + lane < nv) q1 += dt * Wd[4 + r0] * (sU0[64 + lane] - gyref[j1 * 6 + 4 + r0]);
+    {   // (the stage of a bank-1 column is recomputed from an opaque copy of the lane id: held since the top of the kernel it was the
+        //  one value the register allocator sent to scratch)
+        int lane_e = lane;
+        asm volatile("" : "+v"(lane_e));
+        const int j1e = 32 + (lane_e >> 1);
+        if (lane < NB1 && 64 + lane < nv) q1 += dt * Wd[4 + r0] * (sU0[64 + lane] - gyref[j1e * 6 + 4 + r0]);
+    }
     // ---- hand-over: H tiles, q, the gg rows in MFMA operand layout (masked: entries right of a row's end are zero)
     {
         d4 *gh = reinterpret_cast<d4 *>(pa.hws) + (size_t)b * NTT * 64 + lane;
@@ -339,15 +344,18 @@ __global__ void __launch_bounds__(64, (NT_ == 5) ? 2 : 1) cond_kernel(const PArg
         gvec[PV_Q + lane] = q0;
         if (lane < NB1) gvec[PV_Q + 64 + lane] = q1;
         wsync();
+        __builtin_amdgcn_sched_barrier(0);       // (the reads below are not to be requested while the 15 tiles are still waiting to go out)
         double *gc = pa.cws + (size_t)b * NCH * 64 + lane;
 #pragma unroll
-        for (int T = 0; T < NT; T++)
+        for (int T = 0; T < NT; T++) {
 #pragma unroll
             for (int c = 2 * T; c < NC; c++) {
                 const int s = 4 * c + lq + 1;
                 const double v = sCh[hoff(s) + 16 * T + lc];
                 gc[cidx(c, T) * 64] = (c >= 2 * T + 2) ? v : ((16 * T + lc < 2 * s) ? v : 0.0);
             }
+            __builtin_amdgcn_sched_barrier(0);
+        }
     }
 }
 
