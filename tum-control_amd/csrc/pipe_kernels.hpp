@@ -216,8 +216,17 @@ __global__ void __launch_bounds__(64, (NT_ == 5) ? 2 : 1) cond_kernel(const PArg
 #pragma unroll
             for (int i = 0; i < 8; i++) w1[i] = gx0[i] - gX[i];
         }
+        const int lane_cond = lane;
         auto stage_body = [&](const int k, auto tsc) {
             constexpr int Ts = decltype(tsc)::value;
+            // (everything derived from the lane id is derived again in every stage, from a copy the optimiser cannot see through:
+            //  held across the stage loop these values cost the registers the last segment lacks)
+            int lane_s = lane_cond;
+            asm volatile("" : "+v"(lane_s));
+            const int lane = lane_s;
+            const int j0 = lane >> 1, r0 = lane & 1, j1 = 32 + (lane >> 1);
+            const bool isg = (lane == NB1);
+            const int lq = lane >> 4, lc = lane & 15;
             const double *rec = sRec + (k & 1) * PREC;
             if (SN && k < uph) {
                 // stage s = k+1 <= uph: G_nom,s and g_nom,s are PCE means of the sample recursions (prologue kernel)
