@@ -78,10 +78,24 @@ __device__ __forceinline__ void h_con_vabs(const Model &p, double vl, double vt,
 // the constraint value per stage; the records of one stage; the reduction buffer of P3; the nominal copy's own defect per
 // stage; the column state of P3 (8 doubles per lane and pass); A_pce and the PCE coefficients per stage
 __host__ __device__ inline int sn_prologue_passes(int uph, int ns) { const int cs = 64 / ns; return (2 * uph + 1 + cs - 1) / cs; }
-__host__ __device__ inline int sn_prologue_lds_doubles(int uph, int ns)
+// (NPM = 0: the column state of P3 waits in LDS between the stages -- 4 KiB per pass; NPM > 0: it lives in registers, see below)
+__host__ __device__ inline int sn_prologue_lds_doubles(int uph, int ns, int npm = 0)
 {
-    return 6 * uph * ns + (uph + 1) + ns * ABS + 9 * 64 + uph * 8 + sn_prologue_passes(uph, ns) * 8 * 64 +
+    return 6 * uph * ns + (uph + 1) + ns * ABS + 9 * 64 + uph * 8 + (npm > 0 ? 0 : sn_prologue_passes(uph, ns) * 8 * 64) +
            SN_LMAX * SN_NSMAX + uph * SN_LMAX;
+}
+// register-resident variants of the prologue: the number of passes NPM a lane's column state is held for (8 doubles each).
+// Chosen on the host: the smallest instantiation that covers the passes of the last stage; 0 (column state in LDS) for short
+// propagation horizons, where the LDS variant's five wavefronts per SIMD win, and beyond the largest instantiation.
+__host__ inline int sn_prologue_variant(int uph, int ns)
+{
+    const int np = sn_prologue_passes(uph, ns);
+    static const int forced = [] { const char *e = getenv("TUM_SN_PROLOGUE"); return e ? atoi(e) : -1; }();     // development aid
+    if (forced == 0 || ((forced == 6 || forced == 9 || forced == 13) && np <= forced)) return forced;
+    if (np <= 3) return 0;
+    for (int v : {6, 9, 13}) if (np <= v) return v;          // (a 17-pass instantiation -- 478 registers -- compiles and gives wrong results, like the fused
+                                                                     //  kernel at its register limit, DESIGN.md section 7: not shipped; beyond 13 passes the LDS variant runs)
+    return 0;
 }
 
 // K-S1: linearisation of the sample stages. lane = (instance, stage k < uph, sample) item; the 64 records of a wavefront are
@@ -127,6 +141,7 @@ __global__ void __launch_bounds__(64, 1) snmpc_lin_kernel(const SnArgs sa)
         if ((int)threadIdx.x < 52) dst[(size_t)it * ABS + threadIdx.x] = sT[it * ABS + threadIdx.x];
 }
 
+template <int NPM>
 __global__ void __launch_bounds__(64) snmpc_prologue_kernel(const SnArgs sa)
 {
     extern __shared__ __attribute__((aligned(16))) double sn_lds[];
@@ -136,7 +151,7 @@ __global__ void __launch_bounds__(64) snmpc_prologue_kernel(const SnArgs sa)
     const int nitem = uph * ns;
     double *sH = sn_lds, *sGh = sH + nitem, *sCoef = sGh + 4 * nitem, *sHval = sCoef + nitem;
     double *sRec = sHval + (uph + 1), *sRed = sRec + ns * ABS, *sDef = sRed + 9 * 64, *sW = sDef + uph * 8;
-    double *sA = sW + sn_prologue_passes(uph, ns) * 8 * 64, *sC = sA + SN_LMAX * SN_NSMAX;
+    double *sA = sW + (NPM > 0 ? 0 : sn_prologue_passes(uph, ns) * 8 * 64), *sC = sA + SN_LMAX * SN_NSMAX;
     const double dt = sa.dt;
     const double *gX = sa.X + (size_t)b * (N + 1) * NX;
     const double *gXS = sa.XS + (size_t)b * (N + 1) * ns * NX;
@@ -211,11 +226,25 @@ __global__ void __launch_bounds__(64) snmpc_prologue_kernel(const SnArgs sa)
     constexpr int NCH = (SN_NSMAX * ABS + 63) / 64;
     const double ai = sA[i];
     const int npass = sn_prologue_passes(uph, ns);
+    // NPM > 0: the column state of this lane's slot in every pass stays in registers (8 NPM doubles) and the record of the lane's
+    // sample is read from LDS once per STAGE instead of once per pass (52 of the ~90 LDS instructions of a pass), the reduction
+    // over the samples reads its operands together (compile-time bound). The LDS variant needs 4 KiB per pass -- 65 KiB at
+    // uph = 38, two wavefronts per CU -- and was 6.2 of the 8.2 ms of a 4096-instance solve there.
+    double W[NPM > 0 ? NPM : 1][8];
+    if constexpr (NPM > 0) {
+#pragma unroll
+        for (int pass = 0; pass < NPM; pass++) {
+            const bool isg = act && pass == 0 && sc == 0;
+#pragma unroll
+            for (int r = 0; r < 8; r++) W[pass][r] = isg ? sa.xs0[((size_t)b * ns + i) * NX + r] - gXS[(size_t)i * NX + r] : 0.0;
+        }
+    } else {
     for (int pass = 0; pass < npass; pass++) {
         const bool isg = act && pass == 0 && sc == 0;
 #pragma unroll
         for (int r = 0; r < 8; r++)
             sW[(pass * 8 + r) * 64 + lane] = isg ? sa.xs0[((size_t)b * ns + i) * NX + r] - gXS[(size_t)i * NX + r] : 0.0;
+    }
     }
     double pre[NCH];
 #pragma unroll
@@ -230,9 +259,63 @@ __global__ void __launch_bounds__(64) snmpc_prologue_kernel(const SnArgs sa)
 #pragma unroll
             for (int c = 0; c < NCH; c++) { const int idx = lane + 64 * c; pre[c] = (idx < nrec) ? ws2[(size_t)(k + 1) * nrec + idx] : 0.0; }
         }
-        const double *rec = sRec + i * ABS;
         double *pg = pro + (size_t)k * PSTAGE;
         const int np_k = (2 * k + 3 + CS - 1) / CS;
+        if constexpr (NPM > 0) {
+            // (the slot of the lane is derived again in every stage from a copy the optimiser cannot see through: the per-pass lane
+            //  predicates would otherwise all be hoisted out of the stage loop and held in scalar registers -- 137 of them spilled)
+            int lane_k = lane;
+            asm volatile("" : "+v"(lane_k));
+            const int si = lane_k / CS, sc = lane_k - si * CS;
+            const bool act = si < ns;
+            const int i = act ? si : 0;
+            double rec[52];
+#pragma unroll
+            for (int f = 0; f < 52; f++) rec[f] = sRec[i * ABS + f];
+            double gh4[4], coefk = 0.0;                        // chance row of this stage's item (sample i): weight and gradient
+            if (s < uph) {
+                const int it = s * ns + i;
+                coefk = sCoef[it];
+#pragma unroll
+                for (int e = 0; e < 4; e++) gh4[e] = sGh[it * 4 + e];
+            } else { gh4[0] = gh4[1] = gh4[2] = gh4[3] = 0.0; }
+#pragma unroll
+            for (int pass = 0; pass < NPM; pass++) {
+                if (pass < np_k) {
+                    const int q = pass * CS + sc;
+                    const bool isg = act && q == 0, valid = act && q <= 2 * uph;
+                    const int col = q - 1, jst = col >> 1, r0 = col & 1;
+                    double *w = W[pass];
+                    const double sel = (valid && !isg && jst == k) ? 1.0 : 0.0, selg = isg ? 1.0 : 0.0;
+                    apply_A(rec, w);
+#pragma unroll
+                    for (int r = 0; r < 6; r++) w[r] += sel * (r0 ? rec[2 + r * 7 + 6] : rec[2 + r * 7 + 5]);      // (a lane-dependent index would send the record to scratch)
+                    w[6] += sel * (r0 ? dt : 0.0);
+                    w[7] += sel * (r0 ? 0.0 : dt);
+#pragma unroll
+                    for (int r = 0; r < 8; r++) w[r] += selg * rec[44 + r];
+#pragma unroll
+                    for (int r = 0; r < 8; r++) sRed[r * 64 + lane] = valid ? ai * w[r] : 0.0;
+                    const double rowv = coefk * (gh4[0] * w[3] + gh4[1] * w[4] + gh4[2] * w[5] + gh4[3] * w[7]);
+                    sRed[8 * 64 + lane] = (valid && s < uph) ? rowv : 0.0;
+                    wsync();
+                    for (int o = lane; o < 9 * CS; o += 64) {
+                        const int r = o / CS, cc = o - r * CS, qo = pass * CS + cc;
+                        double acc = 0.0;
+#pragma unroll
+                        for (int ii = 0; ii < SN_NSMAX; ii++) acc += (ii < ns) ? sRed[r * 64 + (ii < ns ? ii : 0) * CS + cc] : 0.0;
+                        if (qo <= 2 * uph) {
+                            const bool og = (qo == 0);
+                            const int colo = og ? 2 * uph : qo - 1;
+                            if (r < 8) pg[r * PP + colo] = acc + (og ? sDef[k * 8 + r] : 0.0);
+                            else pg[8 * PP + colo] = acc + ((og && s < uph) ? sHval[s] : 0.0);
+                        }
+                    }
+                    wsync();
+                }
+            }
+        } else {
+        const double *rec = sRec + i * ABS;
         for (int pass = 0; pass < np_k; pass++) {
             const int q = pass * CS + sc;
             const bool isg = act && q == 0, valid = act && q <= 2 * uph;
@@ -269,6 +352,7 @@ __global__ void __launch_bounds__(64) snmpc_prologue_kernel(const SnArgs sa)
                 }
             }
             wsync();
+        }
         }
     }
     if (sa.dbg && b == 0 && lane == 0) {

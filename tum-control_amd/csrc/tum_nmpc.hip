@@ -243,9 +243,12 @@ extern "C" int tum_ocp_snmpc_attach(tum_ocp *c, int ns, int L, const double *Apc
     if (c->d.store_qp_in) return fail("snmpc_attach: store_qp_in is not available for the stacked state");
     DevGuard guard(c->d.device); GUARD_OK(guard);
     {
-        const size_t lds = sizeof(double) * sn_prologue_lds_doubles(uph, ns);
+        const size_t lds = sizeof(double) * sn_prologue_lds_doubles(uph, ns, sn_prologue_variant(uph, ns));
         if (lds > 128 * 1024) return fail("snmpc_attach: n_samples x uph too large for the prologue kernel's LDS");
-        HIPCHK(hipFuncSetAttribute((const void *)snmpc_prologue_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+        HIPCHK(hipFuncSetAttribute((const void *)snmpc_prologue_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+        HIPCHK(hipFuncSetAttribute((const void *)snmpc_prologue_kernel<6>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+        HIPCHK(hipFuncSetAttribute((const void *)snmpc_prologue_kernel<9>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+        HIPCHK(hipFuncSetAttribute((const void *)snmpc_prologue_kernel<13>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
     }
     const size_t B = c->batch; const int N = c->N;
     bool ok = true;
@@ -637,6 +640,21 @@ static int resolve_kernel(tum_ocp *c)
     return ensure_workspace(c);
 }
 
+// the prologue of the coupled SNMPC OCP: column state of its recursions in registers (instantiation by the number of passes of the
+// last stage) or, for short propagation horizons and beyond the largest instantiation, in LDS
+static void sn_launch_prologue(tum_ocp *c)
+{
+    const int v = sn_prologue_variant(c->sa.uph, c->sa.ns);
+    const size_t lds = sizeof(double) * sn_prologue_lds_doubles(c->sa.uph, c->sa.ns, v);
+    const dim3 g(c->batch), blk(64);
+    switch (v) {
+    case 6: hipLaunchKernelGGL(snmpc_prologue_kernel<6>, g, blk, lds, c->stream, c->sa); break;
+    case 9: hipLaunchKernelGGL(snmpc_prologue_kernel<9>, g, blk, lds, c->stream, c->sa); break;
+    case 13: hipLaunchKernelGGL(snmpc_prologue_kernel<13>, g, blk, lds, c->stream, c->sa); break;
+    default: hipLaunchKernelGGL(snmpc_prologue_kernel<0>, g, blk, lds, c->stream, c->sa); break;
+    }
+}
+
 static int launch_pipeline(tum_ocp *c, bool events)
 {
     PArgs pa;
@@ -646,8 +664,7 @@ static int launch_pipeline(tum_ocp *c, bool events)
     if (c->sn) {   // coupled SNMPC OCP: sample fan-out and prologue first, the QP solution goes to the epilogue through the workspace
         if (c->fanout && sn_fanout(c)) return 1;
         sn_launch_lin(c);
-        hipLaunchKernelGGL(snmpc_prologue_kernel, dim3(c->batch), dim3(64), sizeof(double) * sn_prologue_lds_doubles(c->sa.uph, c->sa.ns),
-                           c->stream, c->sa);
+        sn_launch_prologue(c);
         hipLaunchKernelGGL(lin_kernel<true>, dim3((unsigned)((items + 63) / 64)), dim3(64), 0, c->stream, pa);
     } else hipLaunchKernelGGL(lin_kernel<false>, dim3((unsigned)((items + 63) / 64)), dim3(64), 0, c->stream, pa);
     // (development aid: a larger LDS request lowers the number of OCPs that share a CU)
@@ -698,8 +715,7 @@ static int launch(tum_ocp *c, bool events = true)
     else if (c->sn) {
         if (c->fanout && sn_fanout(c)) return 1;
         sn_launch_lin(c);
-        hipLaunchKernelGGL(snmpc_prologue_kernel, dim3(c->batch), dim3(64), sizeof(double) * sn_prologue_lds_doubles(c->sa.uph, c->sa.ns),
-                           c->stream, c->sa);
+        sn_launch_prologue(c);
         if (prof) fused(nmpc_rti_kernel<true, true>); else fused(nmpc_rti_kernel<false, true>);
         hipLaunchKernelGGL(snmpc_epilogue_kernel, dim3(c->batch), dim3(64), 0, c->stream, c->sa); c->xs_lazy = true;
     }
