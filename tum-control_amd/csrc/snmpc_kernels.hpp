@@ -81,7 +81,8 @@ __host__ __device__ inline int sn_prologue_passes(int uph, int ns) { const int c
 // (NPM = 0: the column state of P3 waits in LDS between the stages -- 4 KiB per pass; NPM > 0: it lives in registers, see below)
 __host__ __device__ inline int sn_prologue_lds_doubles(int uph, int ns, int npm = 0)
 {
-    return 6 * uph * ns + (uph + 1) + ns * ABS + 9 * 64 + uph * 8 + (npm > 0 ? 0 : sn_prologue_passes(uph, ns) * 8 * 64) +
+    // (NPM > 0: reduction rows of pitch 128 whose upper halves stay zero: the sum over the samples reads 16 cells of a row without a mask)
+    return (npm > 0 ? 2 : 6) * uph * ns + (uph + 1) + ns * ABS + (npm > 0 ? 9 * 130 : 9 * 64) + uph * 8 + (npm > 0 ? 0 : sn_prologue_passes(uph, ns) * 8 * 64) +
            SN_LMAX * SN_NSMAX + uph * SN_LMAX;
 }
 // register-resident variants of the prologue: the number of passes NPM a lane's column state is held for (8 doubles each).
@@ -91,8 +92,8 @@ __host__ inline int sn_prologue_variant(int uph, int ns)
 {
     const int np = sn_prologue_passes(uph, ns);
     static const int forced = [] { const char *e = getenv("TUM_SN_PROLOGUE"); return e ? atoi(e) : -1; }();     // development aid
-    if (forced == 0 || ((forced == 6 || forced == 9 || forced == 13) && np <= forced)) return forced;
-    if (np <= 3) return 0;
+    if (forced == 0 || ((forced == 6 || forced == 9 || forced == 13) && np <= forced && ns >= 8)) return forced;
+    if (np <= 3 || ns < 8) return 0;         // (fewer than 8 samples: more than 8 column slots per pass, the LDS variant's general reduction)
     for (int v : {6, 9, 13}) if (np <= v) return v;          // (a 17-pass instantiation -- 478 registers -- compiles and gives wrong results, like the fused
                                                                      //  kernel at its register limit, DESIGN.md section 7: not shipped; beyond 13 passes the LDS variant runs)
     return 0;
@@ -149,8 +150,11 @@ __global__ void __launch_bounds__(64) snmpc_prologue_kernel(const SnArgs sa)
     if (b >= sa.batch) return;
     const int N = sa.N, ns = sa.ns, L = sa.L, uph = sa.uph;
     const int nitem = uph * ns;
-    double *sH = sn_lds, *sGh = sH + nitem, *sCoef = sGh + 4 * nitem, *sHval = sCoef + nitem;
-    double *sRec = sHval + (uph + 1), *sRed = sRec + ns * ABS, *sDef = sRed + 9 * 64, *sW = sDef + uph * 8;
+    // (NPM > 0: the gradients of the gg value are read from the workspace where P3 needs them -- four doubles per lane and stage --
+    //  instead of waiting in LDS: with them the kernel needs 41.5 KiB at uph = 38 and only three instances share a CU)
+    double *sH = sn_lds, *sGh = sH + nitem, *sCoef = sGh + (NPM > 0 ? 0 : 4 * nitem), *sHval = sCoef + nitem;
+    constexpr int RP = (NPM > 0) ? 130 : 64;          // pitch of a reduction row (130: 128 cells, and the nine rows a reducing instruction reads do not start in the same bank)
+    double *sRec = sHval + (uph + 1), *sRed = sRec + ns * ABS, *sDef = sRed + 9 * RP, *sW = sDef + uph * 8;
     double *sA = sW + (NPM > 0 ? 0 : sn_prologue_passes(uph, ns) * 8 * 64), *sC = sA + SN_LMAX * SN_NSMAX;
     const double dt = sa.dt;
     const double *gX = sa.X + (size_t)b * (N + 1) * NX;
@@ -166,8 +170,12 @@ __global__ void __launch_bounds__(64) snmpc_prologue_kernel(const SnArgs sa)
         for (int o = lane; o < nitem * 5; o += 64) {
             const int item = o / 5, c = o - item * 5;
             const double v = gh[o];
-            if (c == 0) sH[item] = v; else sGh[item * 4 + c - 1] = v;
+            if (c == 0) sH[item] = v; else if (NPM == 0) sGh[item * 4 + c - 1] = v;
         }
+    }
+    if constexpr (NPM > 0) {
+#pragma unroll
+        for (int r = 0; r < 9; r++) sRed[r * RP + 64 + lane] = 0.0;
     }
     __syncthreads();
     const long long t1 = __builtin_readcyclecounter();
@@ -277,11 +285,13 @@ __global__ void __launch_bounds__(64) snmpc_prologue_kernel(const SnArgs sa)
                 const int it = s * ns + i;
                 coefk = sCoef[it];
 #pragma unroll
-                for (int e = 0; e < 4; e++) gh4[e] = sGh[it * 4 + e];
+                for (int e = 0; e < 4; e++) gh4[e] = sa.gh[((size_t)b * nitem + it) * 5 + 1 + e];
             } else { gh4[0] = gh4[1] = gh4[2] = gh4[3] = 0.0; }
 #pragma unroll
             for (int pass = 0; pass < NPM; pass++) {
                 if (pass < np_k) {
+                    asm volatile("" ::: "memory");          // (keeps this a BRANCH: without it the compiler predicates all NPM passes into one block and
+                                                             //  every stage pays for the passes its columns do not reach yet)
                     const int q = pass * CS + sc;
                     const bool isg = act && q == 0, valid = act && q <= 2 * uph;
                     const int col = q - 1, jst = col >> 1, r0 = col & 1;
@@ -295,19 +305,23 @@ __global__ void __launch_bounds__(64) snmpc_prologue_kernel(const SnArgs sa)
 #pragma unroll
                     for (int r = 0; r < 8; r++) w[r] += selg * rec[44 + r];
 #pragma unroll
-                    for (int r = 0; r < 8; r++) sRed[r * 64 + lane] = valid ? ai * w[r] : 0.0;
+                    for (int r = 0; r < 8; r++) sRed[r * RP + lane] = valid ? ai * w[r] : 0.0;
                     const double rowv = coefk * (gh4[0] * w[3] + gh4[1] * w[4] + gh4[2] * w[5] + gh4[3] * w[7]);
-                    sRed[8 * 64 + lane] = (valid && s < uph) ? rowv : 0.0;
+                    sRed[8 * RP + lane] = (valid && s < uph) ? rowv : 0.0;
                     wsync();
-                    for (int o = lane; o < 9 * CS; o += 64) {
-                        const int r = o / CS, cc = o - r * CS, qo = pass * CS + cc;
-                        double acc = 0.0;
+                    // lane (si, sc) with si < 9 sums row si, column slot sc over the samples: cells sc, CS + sc, ... (CS <= 8 here: 16 cells
+                    // stay inside the 128-wide row; those of lanes without a sample and the upper half hold zeros)
+                    if (si < 9) {
+                        const double *rp = sRed + si * RP + sc;
+                        double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
 #pragma unroll
-                        for (int ii = 0; ii < SN_NSMAX; ii++) acc += (ii < ns) ? sRed[r * 64 + (ii < ns ? ii : 0) * CS + cc] : 0.0;
+                        for (int ii = 0; ii < SN_NSMAX; ii += 4) { a0 += rp[ii * CS]; a1 += rp[(ii + 1) * CS]; a2 += rp[(ii + 2) * CS]; a3 += rp[(ii + 3) * CS]; }
+                        const double acc = (a0 + a1) + (a2 + a3);
+                        const int qo = pass * CS + sc;
                         if (qo <= 2 * uph) {
                             const bool og = (qo == 0);
                             const int colo = og ? 2 * uph : qo - 1;
-                            if (r < 8) pg[r * PP + colo] = acc + (og ? sDef[k * 8 + r] : 0.0);
+                            if (si < 8) pg[si * PP + colo] = acc + (og ? sDef[k * 8 + si] : 0.0);
                             else pg[8 * PP + colo] = acc + ((og && s < uph) ? sHval[s] : 0.0);
                         }
                     }
