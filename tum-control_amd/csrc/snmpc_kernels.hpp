@@ -92,10 +92,9 @@ __host__ inline int sn_prologue_variant(int uph, int ns)
 {
     const int np = sn_prologue_passes(uph, ns);
     static const int forced = [] { const char *e = getenv("TUM_SN_PROLOGUE"); return e ? atoi(e) : -1; }();     // development aid
-    if (forced == 0 || ((forced == 6 || forced == 9 || forced == 13) && np <= forced && ns >= 8)) return forced;
+    if (forced == 0 || ((forced == 6 || forced == 9 || forced == 13 || forced == 17) && np <= forced && ns >= 8)) return forced;
     if (np <= 3 || ns < 8) return 0;         // (fewer than 8 samples: more than 8 column slots per pass, the LDS variant's general reduction)
-    for (int v : {6, 9, 13}) if (np <= v) return v;          // (a 17-pass instantiation -- 478 registers -- compiles and gives wrong results, like the fused
-                                                                     //  kernel at its register limit, DESIGN.md section 7: not shipped; beyond 13 passes the LDS variant runs)
+    for (int v : {6, 9, 13, 17}) if (np <= v) return v;          // (beyond 17 passes the LDS variant runs)
     return 0;
 }
 

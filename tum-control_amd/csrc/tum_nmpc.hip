@@ -249,6 +249,7 @@ extern "C" int tum_ocp_snmpc_attach(tum_ocp *c, int ns, int L, const double *Apc
         HIPCHK(hipFuncSetAttribute((const void *)snmpc_prologue_kernel<6>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
         HIPCHK(hipFuncSetAttribute((const void *)snmpc_prologue_kernel<9>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
         HIPCHK(hipFuncSetAttribute((const void *)snmpc_prologue_kernel<13>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+        HIPCHK(hipFuncSetAttribute((const void *)snmpc_prologue_kernel<17>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
     }
     const size_t B = c->batch; const int N = c->N;
     bool ok = true;
@@ -651,6 +652,7 @@ static void sn_launch_prologue(tum_ocp *c)
     case 6: hipLaunchKernelGGL(snmpc_prologue_kernel<6>, g, blk, lds, c->stream, c->sa); break;
     case 9: hipLaunchKernelGGL(snmpc_prologue_kernel<9>, g, blk, lds, c->stream, c->sa); break;
     case 13: hipLaunchKernelGGL(snmpc_prologue_kernel<13>, g, blk, lds, c->stream, c->sa); break;
+    case 17: hipLaunchKernelGGL(snmpc_prologue_kernel<17>, g, blk, lds, c->stream, c->sa); break;
     default: hipLaunchKernelGGL(snmpc_prologue_kernel<0>, g, blk, lds, c->stream, c->sa); break;
     }
 }
