@@ -256,6 +256,14 @@ __global__ void __launch_bounds__(64) snmpc_prologue_kernel(const SnArgs sa)
     double pre[NCH];
 #pragma unroll
     for (int c = 0; c < NCH; c++) { const int idx = lane + 64 * c; pre[c] = (uph > 0 && idx < nrec) ? ws2[idx] : 0.0; }
+    // (NPM > 0: the gg gradients of the lane's sample at stage s, requested one stage ahead like the records)
+    double ghn[4] = {0.0, 0.0, 0.0, 0.0};
+    if constexpr (NPM > 0) {
+        if (1 < uph) {
+#pragma unroll
+            for (int e = 0; e < 4; e++) ghn[e] = sa.gh[((size_t)b * nitem + 1 * ns + i) * 5 + 1 + e];
+        }
+    }
     for (int k = 0; k < uph; k++) {
         const int s = k + 1;
         wsync();
@@ -280,12 +288,13 @@ __global__ void __launch_bounds__(64) snmpc_prologue_kernel(const SnArgs sa)
 #pragma unroll
             for (int f = 0; f < 52; f++) rec[f] = sRec[i * ABS + f];
             double gh4[4], coefk = 0.0;                        // chance row of this stage's item (sample i): weight and gradient
-            if (s < uph) {
-                const int it = s * ns + i;
-                coefk = sCoef[it];
 #pragma unroll
-                for (int e = 0; e < 4; e++) gh4[e] = sa.gh[((size_t)b * nitem + it) * 5 + 1 + e];
-            } else { gh4[0] = gh4[1] = gh4[2] = gh4[3] = 0.0; }
+            for (int e = 0; e < 4; e++) gh4[e] = ghn[e];
+            if (s < uph) coefk = sCoef[s * ns + i];
+            if (s + 1 < uph) {
+#pragma unroll
+                for (int e = 0; e < 4; e++) ghn[e] = sa.gh[((size_t)b * nitem + (s + 1) * ns + i) * 5 + 1 + e];
+            }
 #pragma unroll
             for (int pass = 0; pass < NPM; pass++) {
                 if (pass < np_k) {
