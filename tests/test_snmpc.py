@@ -294,17 +294,19 @@ def test_gpu_coupled_snmpc_vs_oracle(golden_dir, N, uph):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("N,uph", [(38, 5), (38, 15), (40, 5), (38, 0), (12, 12), (44, 5), (48, 12), (40, 33), (38, 38), (48, 48)])
+@pytest.mark.parametrize("N,uph", [(38, 5), (38, 15), (40, 5), (38, 0), (12, 12), (44, 5), (48, 12), (40, 24), (40, 33), (38, 38), (48, 48)])
 def test_gpu_coupled_snmpc_pipeline_vs_oracle(golden_dir, N, uph):
     """the same through the pipeline variant (prologue, lin_kernel<SN>, cond_kernel<., SN>, ipm_kernel, expand_kernel<., SN>,
     epilogue; what batches above 1024 instances run), including horizons beyond 40 (six-tile instantiation) and uncertainty
     propagation horizons up to the whole horizon (the reference ran UPH = Tp = 38 stages, SNMPC_class.py:103-104: the sample
-    columns then no longer fit one wavefront and the prologue's hand-over buffer switches to the 128-column pitch)"""
+    columns then no longer fit one wavefront and the prologue's hand-over buffer switches to the 128-column pitch). The
+    propagation horizons also walk through the prologue's instantiations: column state in LDS (uph <= 8 at ten samples) and in
+    registers for 6 / 9 / 13 / 17 passes (uph 15 / 24 / 33, 38 / 48)"""
     _gpu_vs_oracle(golden_dir, N, uph, poses=[0, 26, 30], kernel="pipeline")
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("N,uph,lib", [(12, 5, "shipped"), (12, 12, "shipped"), (40, 9, "shipped"), (40, 31, "shipped"), (40, 36, "shipped"),
+@pytest.mark.parametrize("N,uph,lib", [(12, 5, "shipped"), (12, 12, "shipped"), (40, 9, "shipped"), (40, 15, "shipped"), (40, 24, "shipped"), (40, 31, "shipped"), (40, 36, "shipped"),
                                        (38, 38, "shipped"), (12, 5, "dev"), (40, 9, "dev"), (40, 31, "dev")])
 def test_gpu_coupled_snmpc_condensed_qp(golden_dir, N, uph, lib):
     """The condensed QP (H, q, chance / gg rows, constants) against the oracle's dense 88-state condensing, at a strongly
