@@ -212,21 +212,35 @@ def test_shipped_kernels_resource_budget():
     libtumnmpc.so.resources): no kernel spills more than 64 SGPRs (the fused kernel's 129-158 went with an unexplained
     miscompile, DESIGN §7 -- it lives in the development build only), scratch stays small everywhere, and the headline
     instantiation of the interior point kernel has no spills, no scratch and one wavefront per SIMD."""
+    import shutil
+    import subprocess
     import __graft_entry__ as g
+    if not (os.path.exists(g.HIPCC) or shutil.which("hipcc")) and not os.path.exists(g.LIB + ".resources"):
+        pytest.skip("no hipcc and no resource table of a previous build on this host")
     g.build()
     rows = {}
     for line in open(g.LIB + ".resources"):
         parts = line.split()
         rows[parts[0]] = [int(x) for x in parts[1:]]
     assert len(rows) >= 20
+    # kernels are looked up by their demangled names (the mangling is the compiler's business)
+    filt = shutil.which("c++filt") or "/opt/rocm/lib/llvm/bin/llvm-cxxfilt"
+    names = list(rows)
+    dem = subprocess.run([filt], input="\n".join(names), capture_output=True, text=True).stdout.split("\n")
+    rows = {d.strip(): rows[n] for n, d in zip(names, dem)}
+
+    def kernel(sub):
+        hit = [v for n, v in rows.items() if sub in n]
+        assert len(hit) == 1, (sub, [n for n in rows if sub in n])
+        return hit[0]
     assert not any("nmpc_rti_kernel" in n or "ipm4_kernel" in n for n in rows), "development kernels in the shipped library"
     for name, (vgpr, agpr, sgpr_spill, vgpr_spill, scratch, lds, occ) in rows.items():
         assert sgpr_spill <= 64, (name, sgpr_spill)
         assert scratch <= 128, (name, scratch)
         assert vgpr + agpr <= 512 and lds <= 40 * 1024, name
-    ipm = rows["_ZN3tum10ipm_kernelILb0ELi5EEEvNS_5PArgsE"]
+    ipm = kernel("ipm_kernel<false, 5>")
     assert ipm[2:5] == [0, 0, 0] and ipm[6] == 1, ipm
-    assert rows["_ZN3tum11cond_kernelILi5ELb0EEEvNS_5PArgsE"][6] == 2          # two wavefronts per SIMD
+    assert kernel("cond_kernel<5, false>")[6] == 2          # two wavefronts per SIMD
 
 
 def test_no_cpu_fallback():

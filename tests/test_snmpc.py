@@ -271,17 +271,23 @@ def _gpu_vs_oracle(golden_dir, N, uph, poses, nsolve=3, shift_ref=0, kernel=None
         cost = np.atleast_1d(s.get_cost())
         # Propagating the samples over more than ~30 stages makes the real-time iteration itself ill-conditioned: in the oracle
         # alone a 1e-9 perturbation of the iterate moves the NEXT solve by 2e-7 (uph = 33) / 2e-6 (uph = 38) against 1e-8 at
-        # uph = 5 (measured). The cold start is held to 1e-7 for every uph; the warm iterations of the long
-        # propagation horizons to the amplified level.
-        rt, at = (1e-7, 2e-8) if (uph <= 31 or it == 0) else (2e-4, 2e-5)
+        # uph = 5 (measured). So that EVERY solve is held to 1e-7 whatever the horizon, the oracle starts
+        # each warm iteration of a long propagation horizon from the GPU's iterate (below): the comparison is then one solve on
+        # identical inputs, with nothing accumulated from the solves before.
+        rt, at = 1e-7, 2e-8
         for j, o in enumerate(orcs):
             assert o.solve() == 0
             np.testing.assert_allclose(U[j], o.U, rtol=rt, atol=at, err_msg=f"U solve {it} inst {j}")
             np.testing.assert_allclose(Xn[j], o.X[:, 0], rtol=rt, atol=at, err_msg=f"X nominal solve {it} inst {j}")
-            np.testing.assert_allclose(cost[j], o.cost, rtol=max(rt, 1e-7) * (1 if rt < 1e-6 else 0.05))
+            np.testing.assert_allclose(cost[j], o.cost, rtol=1e-7)
             for k in (0, 1, max(uph, 1), N):
                 xf = np.atleast_2d(s.get(k, "x"))[j].reshape(11, 8)
                 np.testing.assert_allclose(xf, o.X[k], rtol=rt, atol=at, err_msg=f"stacked x stage {k} solve {it} inst {j}")
+        if uph > 31 and it + 1 < nsolve:
+            XS = np.stack([np.atleast_2d(s.get(k, "x")).reshape(B, 11, 8) for k in range(N + 1)], axis=1)      # (B, N+1, 11, 8)
+            for j, o in enumerate(orcs):
+                assert np.abs(XS[j] - o.X).max() < 1e-6 * (1.0 + np.abs(o.X).max())
+                o.X[:] = XS[j]; o.U[:] = U[j]
     return s
 
 
@@ -358,10 +364,13 @@ def test_gpu_coupled_snmpc_condensed_qp(golden_dir, N, uph, lib):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("ns,L,N,uph", [(15, 10, 20, 6), (16, 16, 14, 14), (7, 4, 40, 11), (1, 1, 10, 3), (3, 2, 40, 31)])
+@pytest.mark.parametrize("ns,L,N,uph", [(15, 10, 20, 6), (16, 16, 14, 14), (7, 4, 40, 11), (1, 1, 10, 3), (3, 2, 40, 31),
+                                        (8, 6, 40, 12), (8, 6, 40, 24), (8, 6, 38, 38), (9, 6, 40, 24)])
 def test_gpu_coupled_snmpc_other_sample_counts(golden_dir, ns, L, N, uph):
     """sample counts / PCE sizes other than the shipped 10 x 10 (any L x n_s matrix defines a valid OCP): condensed QP and
-    one full step of every copy against the oracle"""
+    one full step of every copy against the oracle. Eight samples with a propagation horizon of 12 / 24 / 38 stages run the
+    register-resident prologue instantiations (6 / 9 / 13 passes) with EIGHT column slots per sample: the 64 lanes then only
+    reach eight of the nine reduction rows, and the chance-constraint row takes a second round (round 3 dropped it)."""
     from tum_control_amd.solver import CoupledSnmpcSolver
     from tum_control_amd import config
     x0, yref, p = _kat(golden_dir)

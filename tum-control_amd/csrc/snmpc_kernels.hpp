@@ -318,21 +318,24 @@ __global__ void __launch_bounds__(64) snmpc_prologue_kernel(const SnArgs sa)
                     sRed[8 * RP + lane] = (valid && s < uph) ? rowv : 0.0;
                     wsync();
                     // lane (si, sc) with si < 9 sums row si, column slot sc over the samples: cells sc, CS + sc, ... (CS <= 8 here: 16 cells
-                    // stay inside the 128-wide row; those of lanes without a sample and the upper half hold zeros)
-                    if (si < 9) {
-                        const double *rp = sRed + si * RP + sc;
+                    // stay inside the 128-wide row; those of lanes without a sample and the upper half hold zeros). With eight samples
+                    // (CS = 8) the lanes only reach the rows 0..7: the lanes of row 0 then sum the chance row (row 8) in a second round.
+                    auto reduce_row = [&](const int row, const int cc) {
+                        const double *rp = sRed + row * RP + cc;
                         double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
 #pragma unroll
                         for (int ii = 0; ii < SN_NSMAX; ii += 4) { a0 += rp[ii * CS]; a1 += rp[(ii + 1) * CS]; a2 += rp[(ii + 2) * CS]; a3 += rp[(ii + 3) * CS]; }
                         const double acc = (a0 + a1) + (a2 + a3);
-                        const int qo = pass * CS + sc;
+                        const int qo = pass * CS + cc;
                         if (qo <= 2 * uph) {
                             const bool og = (qo == 0);
                             const int colo = og ? 2 * uph : qo - 1;
-                            if (si < 8) pg[si * PP + colo] = acc + (og ? sDef[k * 8 + si] : 0.0);
+                            if (row < 8) pg[row * PP + colo] = acc + (og ? sDef[k * 8 + row] : 0.0);
                             else pg[8 * PP + colo] = acc + ((og && s < uph) ? sHval[s] : 0.0);
                         }
-                    }
+                    };
+                    if (si < 9) reduce_row(si, sc);
+                    if (9 * CS > 64 && si == 0) reduce_row(8, sc);
                     wsync();
                 }
             }

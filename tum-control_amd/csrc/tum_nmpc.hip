@@ -342,7 +342,8 @@ static int sn_apply_p(tum_ocp *c)
         if (c->p_stop[k] != 1.0) return fail("solve: stop_flag pattern not supported: it must be 0 on the stages < uph and 1 from stage uph on (stage " + std::to_string(k) + " is 0 after a 1)");
     if (uph > N) uph = N;                      // no stop flag at all: the samples are propagated over the whole horizon
     if (uph > SN_UPHMAX) return fail("solve: uncertainty propagation horizon from the stop flags exceeds " + std::to_string(SN_UPHMAX));
-    if (sizeof(double) * sn_prologue_lds_doubles(uph, ns) > 128 * 1024) return fail("solve: n_samples x uph too large for the prologue kernel's LDS");
+    if (sizeof(double) * sn_prologue_lds_doubles(uph, ns, sn_prologue_variant(uph, ns)) > 128 * 1024)      // (the variant sn_launch_prologue will pick)
+        return fail("solve: n_samples x uph too large for the prologue kernel's LDS");
     // (the hand-over buffer of the prologue is sized uph x sn_pro_stage(uph): its row pitch doubles beyond uph = 31)
     if (uph > c->uph_cap || (size_t)uph * sn_pro_stage(uph) > c->pro_cap) {
         DevGuard guard(c->d.device); GUARD_OK(guard);
@@ -888,6 +889,10 @@ extern "C" int tum_ocp_get_from_qp_in(tum_ocp *c, int stage, const char *field, 
 extern "C" int tum_ocp_set_stream(tum_ocp *c, void *hip_stream)
 {
     if (!c) return fail("null capsule");
+    DevGuard guard(c->d.device); GUARD_OK(guard);
+    // whatever is still pending on the old stream (asynchronous uploads, a bounds snapshot, a solve) must not be overtaken
+    // by work enqueued on the new one
+    if (c->stream) HIPCHK(hipStreamSynchronize(c->stream));
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
     c->stream = (hipStream_t)hip_stream; c->own_stream = false;
     return 0;
