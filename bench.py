@@ -252,6 +252,11 @@ class Job:
         # resident copies of the rotated batches
         self.dx0 = [torch.from_numpy(np.ascontiguousarray(h[0])).to(dev) for h in self.host[1:]]
         self.dyr = [torch.from_numpy(np.ascontiguousarray(h[1])).to(dev) for h in self.host[1:]]
+        # host-visible legs: every step's results (u0, cost, status, qp_iter -- optionally the whole iterate) land in the capsule's
+        # pinned host slab behind an event (tum_ocp_results_async); the host reads them when the capsule's turn comes round again
+        self.host_results = None          # None | "summary" | "iterate"
+        self.host_ok = self.host_seen = 0
+        self.host_checksum = 0.0
 
     # ---- one step; `marks`: list that receives (solve_begin, solve_end)* and (gather_begin, gather_end) clock marks
     def step(self, marks=None, fresh=None):
@@ -262,8 +267,22 @@ class Job:
         else:
             self._step(slot, s, marks, fresh)
 
+    def _read(self, res):
+        """the host side of a step: read the pinned slab of a finished batch"""
+        if res is None:
+            return
+        summ, X, U = res
+        self.host_seen += len(summ); self.host_ok += int((summ[:, 3] == 0).sum())
+        self.host_checksum += float(summ[:, 0].sum()) + (float(X[:, 1, 3].sum()) if X is not None else 0.0)
+
+    def drain(self):
+        for _, res in self.ring.drain():
+            self._read(res)
+
     def _step(self, slot, s, marks, fresh):
         cid, slab = self.cid, self.slabs[slot]
+        if self.host_results:
+            self._read(self.ring.take_results(slot))      # (the batch this capsule solved S steps ago)
         if fresh is not None:
             k = fresh % NB_FRESH
             s.put_device("x0", self.dx0[k].data_ptr()); s.put_device("yref", self.dyr[k].data_ptr())
@@ -279,6 +298,8 @@ class Job:
         if cid == 3:
             mom_ptr = slab.data_ptr() + 8 * self.B * 5
             s.pce_moments_device("x", 1, mom_ptr, mom_ptr + 8 * self.P * 8)
+        if self.host_results:
+            self.ring.request_results(slot, self.host_results == "iterate")
         if self.gather is not None:
             if marks is not None:
                 marks.append(self.clock.mark())
@@ -299,6 +320,8 @@ class Job:
         t0 = time.perf_counter()
         for i in range(steps):
             self.step(marks[i], fresh=(i if fresh else None))
+        if self.host_results:
+            self.drain()                      # (the last results have been READ on the host when the clock stops)
         self.barrier()
         elapsed = time.perf_counter() - t0
         if self.distributed:
@@ -330,6 +353,25 @@ def run(args, torch, dist, dev, world, rank, local_rank, solver_factory, workloa
     st = np.concatenate([s.get_stats("status") for s in job.ring]); it = np.concatenate([s.get_stats("qp_iter") for s in job.ring])
     mean_it_fresh = float(it.mean())
     ok_fresh = float((st == 0).mean())
+
+    # ---- the same loop with the results of EVERY step on the host (what a Python caller sees: NMPC_class.py:193-206 reads u0 /
+    # cost / status after every solve): results_async behind each solve, the pinned slab read when the capsule comes round
+    # again, the last ones inside the timed region. Same capsules, same streams, same fresh batches as `value`.
+    hv_value = hv_iter_value = hv_ok = None
+    if world == 1 and extra_legs and not args.no_schedule_legs and hasattr(job.s, "results_async"):
+        for mode in ("summary", "iterate"):
+            job.host_results = mode; job.host_seen = job.host_ok = 0
+            for i in range(max(2, S)):
+                job.step(fresh=i)
+            job.drain(); job.host_seen = job.host_ok = 0
+            hv_elapsed, _ = job.timed(args.steps, fresh=not args.same_batch)
+            assert job.host_seen == B * args.steps, (job.host_seen, B, args.steps)
+            v = B * spp * args.steps / hv_elapsed
+            if mode == "summary":
+                hv_value, hv_ok = v, job.host_ok / max(1, job.host_seen)
+            else:
+                hv_iter_value = v
+        job.host_results = None
 
     one_value = one_ms = rep_value = rep_ms = nat_ms = ipm_ms = rep_ipm_ms = None
     mean_it = mean_it_fresh
@@ -428,6 +470,7 @@ def run(args, torch, dist, dev, world, rank, local_rank, solver_factory, workloa
                    "N": N, "nx": 8, "nu": 2, "nsub": 3, "batch_per_gpu": B, "global_batch": job.global_batch,
                    "scenario_group": gsz, "groups_per_gpu": P, "solves_per_step": spp,
                    "streams": S,
+                   "collective_backend": (dist.get_backend() if job.distributed else None),
                    "streams_note": "steps are dealt to `streams` capsules in turn, each with its own buffers on its own HIP stream: every "
                                    "step is a complete pass over one fresh batch, consecutive batches overlap on the GPU (`value`); "
                                    "`value_single_stream` is the same loop on one capsule / one stream",
@@ -441,6 +484,11 @@ def run(args, torch, dist, dev, world, rank, local_rank, solver_factory, workloa
                    "solves_per_s_per_gpu_natural_order": (B / nat_ms * 1e3) if nat_ms else None,
                    "kernel_ms_repeated_batch": rep_ms},
         "value_single_stream": one_value, "value_repeated_batch": rep_value,
+        "value_host_visible": hv_value, "value_host_visible_with_iterate": hv_iter_value, "host_visible_status_ok_frac": hv_ok,
+        "host_visible_note": "the loop of `value` with every step's results READ ON THE HOST inside the timed region: u0, cost, status, "
+                             "qp_iter of every instance (`value_host_visible`), plus the whole iterate X, U "
+                             "(`value_host_visible_with_iterate`), through pinned slabs and an event per capsule (tum_ocp_results_async / "
+                             "_wait): the copy of one batch crosses PCIe while the next batches run",
         "solve_ms_per_step": kern_ms * spp, "gather_ms_per_step": gat_ms,
         "roofline": {"bound": "mfma", "achieved": ach_tf, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
                      "frac": ach_tf / FP64_PEAK_TFLOPS, "traffic": traffic, "traffic_source": traffic_src,

@@ -123,6 +123,16 @@ int tum_ocp_set_stream(tum_ocp *c, void *hip_stream);
 /* field: "u0" (nb x 2), "x1" (nb x 8), "cost" (nb), "X" (nb x (N+1)*8), "U" (nb x N*2),
  * "status" / "qp_iter" (nb int32), "summary" (nb x 5 doubles: u0[2], cost, status, qp_iter -- the slab of the rooted gather) */
 int tum_ocp_get_device(tum_ocp *c, const char *field, void *dev_dst, int b0, int nb);
+/* Results on the HOST without stalling the stream (no reference counterpart; the caller it serves reads u0 / pred_X / cost /
+ * status after every solve, NMPC_class.py:193-206). tum_ocp_results_async enqueues, on the capsule's stream and behind the
+ * solve already enqueued there: the result summary packed on the device (5 doubles per instance: u0[2], cost, status,
+ * qp_iter) and its copy into a PINNED host slab the capsule owns -- with_iterate != 0: also the whole iterate X ((N+1)*8
+ * doubles per instance) and U (N*2) -- then records an event. It returns at once: a caller that keeps several capsules in
+ * flight (streaming.SolverRing) enqueues the next batches while this one's results cross PCIe.
+ * tum_ocp_results_wait blocks until that event has passed and hands out the pinned slabs (valid until the next
+ * tum_ocp_results_async on this capsule; X / U are null when the last request was made without the iterate). */
+int tum_ocp_results_async(tum_ocp *c, int with_iterate);
+int tum_ocp_results_wait(tum_ocp *c, const double **summary, const double **X, const double **U);
 /* The other direction: per-instance inputs from caller-owned DEVICE memory (asynchronous D2D on the capsule's stream).
  * field: "x0" (nb x 8, = constraints_set(0,"lbx")), "yref" (nb x (N+1)*6), "X" (nb x (N+1)*8), "U" (nb x N*2). */
 int tum_ocp_put_device(tum_ocp *c, const char *field, const void *dev_src, int b0, int nb);

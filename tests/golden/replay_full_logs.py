@@ -37,7 +37,9 @@ Runs ONLY where /root/reference exists (the build container). Writes
                               are present and otherwise asserts the gate on this file)
   replay_full_13_16.npz       replay inputs + logged outputs of the complete loops of weight sets 13 and 16 on both tracks
                               (the sets with the exceptions) for the GPU test that drives the mirrored controller class.
-usage: replay_full_logs.py [--procs P] [--logs monteblanco:13,lvms:16,...] [--no-write]
+  replay_full_exceptions.npz  the same for the Monteblanco loops of the sets 8, 10, 12, 21: with 13 and 16 these are the six
+                              loops that hold all 30 exceptions; the GPU test replays the six as one batch, per solve.
+usage: replay_full_logs.py [--procs P] [--logs monteblanco:13,lvms:16,...] [--no-write] [--fixtures-only]
 """
 import json
 import os
@@ -196,6 +198,9 @@ def run(logs=None, procs=None):
         return pool.map(replay_log, logs, chunksize=1)
 
 
+EXCEPTION_LOOPS = (8, 10, 12, 13, 16, 21)          # the Monteblanco loops that hold every exception of the gate
+
+
 def write_gpu_fixture():
     out = {}
     for track in ("monteblanco", "lvms"):
@@ -206,6 +211,17 @@ def write_gpu_fixture():
             out[f"{track}_{k}_qp_iter"] = g["qp_iter"].astype(np.int16)
     out["params"] = np.loadtxt(FCSV, delimiter=",")
     np.savez_compressed(os.path.join(HERE, "replay_full_13_16.npz"), **out)
+    # sibling fixture: the other four Monteblanco loops with exceptions (sets 13 and 16 are in the file above), so that the GPU
+    # test replays ALL six exception loops per solve (tests/test_gpu_parity.py::test_exception_loops_per_solve_gpu)
+    out = {}
+    for k in EXCEPTION_LOOPS:
+        if k in (13, 16):
+            continue
+        g = log_inputs("monteblanco", k)
+        for f in ("x0", "pose", "u0", "x1"):
+            out[f"monteblanco_{k}_{f}"] = g[f]
+        out[f"monteblanco_{k}_qp_iter"] = g["qp_iter"].astype(np.int16)
+    np.savez_compressed(os.path.join(HERE, "replay_full_exceptions.npz"), **out)
 
 
 if __name__ == "__main__":
@@ -215,6 +231,9 @@ if __name__ == "__main__":
     if "--logs" in a:
         logs = [(s.split(":")[0], int(s.split(":")[1])) for s in a[a.index("--logs") + 1].split(",")]
     assert available(), "needs /root/reference (build container only)"
+    if "--fixtures-only" in a:
+        write_gpu_fixture()
+        sys.exit(0)
     rep = run(logs, procs)
     for r in rep:
         print(f"{r['track']:12s} {r['k']:2d}: comparable {r['n_comparable']:5d}  worst {r['worst_comparable']:.2e}  median {r['median_comparable']:.1e}  "

@@ -612,17 +612,27 @@ def test_r2_closed_loop_attached(golden_dir):
     assert 0.0 < float(np.atleast_1d(uh)[0]) < 1.0             # the bounds really are tightened
 
 
-def _full_log_errors(golden_dir, key, U0, X1):
+def _full_log_fixture(golden_dir, key):
+    """the committed replay inputs / logged outputs of one complete loop (sets 13, 16: replay_full_13_16.npz; the other exception
+    loops: replay_full_exceptions.npz)"""
+    for f in ("replay_full_13_16.npz", "replay_full_exceptions.npz"):
+        g = np.load(os.path.join(golden_dir, f))
+        if key + "_u0" in g.files:
+            return g
+    raise KeyError(key)
+
+
+def _full_log_errors(golden_dir, key, U0, X1, strict=False):
     import sys
     sys.path.insert(0, golden_dir)
     import replay_full_logs as R
-    g = np.load(os.path.join(golden_dir, "replay_full_13_16.npz"))
+    g = _full_log_fixture(golden_dir, key)
     ref = dict(u0=g[key + "_u0"], x1=g[key + "_x1"])
     sc = R.channel_scales(ref)
-    return R.solve_errors(U0, X1, ref["u0"], ref["x1"], sc), R.comparable_mask(g[key + "_qp_iter"].astype(int))
+    return R.solve_errors(U0, X1, ref["u0"], ref["x1"], sc, strict=strict), R.comparable_mask(g[key + "_qp_iter"].astype(int))
 
 
-def _assert_full_log_gate(golden_dir, track, k, err, comp):
+def _assert_full_log_gate(golden_dir, track, k, err, comp, strict=None):
     """every comparable solve within 1e-4 of the log, except the control steps the committed CPU report lists as exceptions
     for this loop (tests/golden/full_replay_report.json, with their evidence) and their immediate neighbours"""
     import json
@@ -632,12 +642,17 @@ def _assert_full_log_gate(golden_dir, track, k, err, comp):
     for e in entry["exceptions"]:
         allowed.update(range(e["step"] - 2, e["step"] + 3))
     bad = [int(i) for i in np.nonzero(comp & (err > 1e-4))[0]]
-    assert set(bad) <= allowed, (track, k, [b for b in bad if b not in allowed][:10])
-    assert len(bad) <= len(entry["exceptions"]) + 2
+    # (the message carries the loop's worst error in BOTH metrics: scale-relative -- the gate -- and `worst_strict`, relative to
+    #  the logged value itself floored at 10 % of the channel's scale)
+    ws = f"worst {err[comp].max():.2e} (scale-relative), worst_strict {strict[comp].max():.2e}" if strict is not None else ""
+    assert set(bad) <= allowed, (track, k, [b for b in bad if b not in allowed][:10], ws)
+    assert len(bad) <= len(entry["exceptions"]) + 2, (track, k, ws)
     assert comp.sum() == entry["n_comparable"]
     # and the GPU follows the oracle's replay of the same loop closely on everything comparable
-    assert abs(err[comp].max() - entry["worst_comparable"]) <= 1e-5 + 0.2 * entry["worst_comparable"]
+    assert abs(err[comp].max() - entry["worst_comparable"]) <= 1e-5 + 0.2 * entry["worst_comparable"], (track, k, ws)
     assert np.median(err[comp]) < 5e-8
+    if strict is not None:
+        assert abs(strict[comp].max() - entry["worst_strict"]) <= 1e-5 + 0.2 * entry["worst_strict"], (track, k, ws)
 
 
 @pytest.mark.parametrize("k", [13, 16])
@@ -695,3 +710,76 @@ def test_full_logged_loops_sets_13_16_batch_gpu(golden_dir):
     for b, (t, k) in enumerate(keys):
         err, comp = _full_log_errors(golden_dir, f"{t}_{k}", U0[:, b], X1[:, b])
         _assert_full_log_gate(golden_dir, t, k, err, comp)
+
+
+def test_exception_loops_per_solve_gpu(golden_dir):
+    """ALL six logged loops that hold the gate's exceptions (Monteblanco, weight sets 8, 10, 12, 13, 16, 21: every one of the
+    30 solves of the 283 615 comparable ones that deviates from its log by more than 1e-4, worst 8.2e-3 at set 21 step 3852)
+    through the HIP path PER SOLVE: one batch of six instances with per-instance weights, 5499 sequential warm-started
+    real-time iterations. Held (a) to the logs with the gate of tests/golden/replay_full_logs.py -- 1e-4 scale-relative on
+    every comparable solve outside the recorded exception steps -- and (b) to the CPU oracle replaying the same six loops
+    beside it: on EVERY step, the exception steps included, the GPU's (u0, x1) equals the oracle's to 1e-6 scale-relative --
+    so what the waiver covers is the distance between this solver and acados' logged answer on those steps, not a
+    difference between the kernel and its checker."""
+    import json
+    import sys
+    from tum_control_amd.planner import load_track, planner_emulator, yref_from_ref
+    from oracle.oracle import OracleOcp
+    sys.path.insert(0, golden_dir)
+    import replay_full_logs as R
+    sets = list(R.EXCEPTION_LOOPS)
+    params = np.load(os.path.join(golden_dir, "replay_full_13_16.npz"))["params"]
+    G = {k: _full_log_fixture(golden_dir, f"monteblanco_{k}") for k in sets}
+    tr = load_track("monteblanco")
+    B, n = len(sets), 5499
+    s = _mk(38, B)
+    _set_params(s, np.array([params[k] for k in sets]))
+    orcs = []
+    for k in sets:
+        o = OracleOcp(38, 0.08, 3); o.set_weights(*params[k]); orcs.append(o)
+    x0 = np.stack([G[k][f"monteblanco_{k}_x0"] for k in sets], axis=1)
+    pose = np.stack([G[k][f"monteblanco_{k}_pose"] for k in sets], axis=1)
+    U0 = np.zeros((n, B, 2)); X1 = np.zeros((n, B, 8)); OU = np.zeros((n, B, 2)); OX = np.zeros((n, B, 8))
+    yref = np.zeros((B, 39, 6))
+    for i in range(n):
+        s.set_x0(x0[i])
+        for b in range(B):
+            _, ref = planner_emulator(tr, pose[i, b], 39, 3.04, True)
+            yref[b] = yref_from_ref(ref, 38)
+        s.set_yref_all(yref)
+        if i == 0:
+            s.cold_start()
+        assert s.solve() == 0, i
+        U0[i] = s.get(0, "u"); X1[i] = s.get(1, "x")
+        for b, o in enumerate(orcs):
+            if i == 0:
+                o.cold_start(x0[0, b])
+            else:
+                o.x0[:] = x0[i, b]
+            o.yref[:] = yref[b]
+            assert o.solve() == 0, (i, b)
+            OU[i, b] = o.U[0]; OX[i, b] = o.X[1]
+    rep = json.load(open(os.path.join(golden_dir, "full_replay_report.json")))
+    nexc = 0
+    for b, k in enumerate(sets):
+        key = f"monteblanco_{k}"
+        err, comp = _full_log_errors(golden_dir, key, U0[:, b], X1[:, b])
+        strict, _ = _full_log_errors(golden_dir, key, U0[:, b], X1[:, b], strict=True)
+        _assert_full_log_gate(golden_dir, "monteblanco", k, err, comp, strict)
+        # (b) GPU against the oracle, every step, in the metric of the gate (scales of the logged loop)
+        g = G[k]
+        sc = R.channel_scales(dict(u0=g[key + "_u0"], x1=g[key + "_x1"]))
+        dev = R.solve_errors(U0[:, b], X1[:, b], OU[:, b], OX[:, b], sc)
+        assert dev.max() < 1e-6, (k, int(dev.argmax()), float(dev.max()))
+        entry = [r for r in rep["logs"] if r["track"] == "monteblanco" and r["k"] == k][0]
+        assert entry["exceptions"], k
+        for e in entry["exceptions"]:
+            nexc += 1
+            assert dev[e["step"]] < 1e-6, (k, e["step"], float(dev[e["step"]]))
+            # the oracle of THIS run reproduces the committed report's deviation from the log on that step
+            oerr = R.solve_errors(OU[e["step"]:e["step"] + 1, b], OX[e["step"]:e["step"] + 1, b], g[key + "_u0"][e["step"]:e["step"] + 1],
+                                  g[key + "_x1"][e["step"]:e["step"] + 1], sc)[0]
+            assert abs(oerr - e["err"]) <= 1e-6 + 0.05 * e["err"], (k, e["step"], oerr, e["err"])
+    assert nexc == 30
+    worst = [r for r in rep["logs"] if r["track"] == "monteblanco" and r["k"] == 21][0]
+    assert any(e["step"] == 3852 for e in worst["exceptions"])

@@ -445,3 +445,31 @@ def test_workload_variants_are_fresh_batches_of_the_same_workload():
             y = b[k][1].reshape(G, gsz, 7, 6)
             assert (y == y[:, :1]).all()
         assert not np.array_equal(b[1][0], b[2][0])
+
+
+def test_solver_ring_results_bookkeeping():
+    """streaming.SolverRing: capsules handed out in turn; a results request is remembered per slot, taken once, and `drain`
+    walks the outstanding ones oldest capsule first (host logic only: stand-in capsules)."""
+    from tum_control_amd.streaming import SolverRing
+
+    class Fake:
+        def __init__(self, i):
+            self.i, self.calls = i, []
+
+        def results_async(self, with_iterate):
+            self.calls.append(("async", with_iterate))
+
+        def results_wait(self):
+            self.calls.append(("wait",))
+            return ("summary", self.i), None, None
+
+    ring = SolverRing(3, Fake)
+    assert [ring.acquire()[0] for _ in range(4)] == [0, 1, 2, 0]          # next turn: capsule 1
+    assert ring.take_results(1) is None and list(ring.drain()) == []
+    ring.request_results(2, with_iterate=True); ring.request_results(0); ring.request_results(1)
+    assert ring[2].calls == [("async", True)] and ring[0].calls == [("async", False)]
+    assert ring.take_results(2)[0] == ("summary", 2) and ring.take_results(2) is None
+    assert [i for i, _ in ring.drain()] == [1, 0]                          # from the capsule whose turn is next
+    assert list(ring.drain()) == []
+    with pytest.raises(ValueError):
+        SolverRing(0, Fake)

@@ -59,6 +59,9 @@ struct tum_ocp {
     std::vector<double> hApce, p_gamma, p_stop; bool p_dirty; int uph_cap; size_t pro_cap; double gamma;
     // PCE matrix of the scenario fan-out (tum_pce_attach), snapshot of the bounds (tum_ocp_bounds_snapshot)
     double *dpceA; int pce_L, pce_S; double *dbnd_snap;
+    // results on the host without a stream stall (tum_ocp_results_async / _wait): device slab of the packed summary, pinned
+    // host slabs, the event behind the copies
+    double *dsum, *hsum, *hX, *hU; hipEvent_t evres; bool res_pending, res_iter;
 };
 
 static const int DBG_STRIDE = 20480;
@@ -120,6 +123,7 @@ extern "C" tum_ocp *tum_ocp_create(const tum_ocp_desc *desc)
     c->have_offs = c->fanout = false;
     c->r2 = false; c->dr2S = c->dr2B = nullptr;
     c->p_dirty = false; c->uph_cap = 0; c->gamma = 0.0; c->dpceA = nullptr; c->pce_L = c->pce_S = 0; c->dbnd_snap = nullptr;
+    c->dsum = c->hsum = c->hX = c->hU = nullptr; c->evres = nullptr; c->res_pending = c->res_iter = false;
     const int N = c->N; const size_t B = c->batch;
     bool ok = true;
     ok &= hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) == hipSuccess; c->own_stream = true;
@@ -222,6 +226,11 @@ extern "C" void tum_ocp_free(tum_ocp *c)
     if (c->evi1) (void)hipEventDestroy(c->evi1);
     (void)hipFree(c->dXS); (void)hipFree(c->dxs0); (void)hipFree(c->dApce); (void)hipFree(c->dws2); (void)hipFree(c->dpro); (void)hipFree(c->ddv); (void)hipFree(c->doffs); (void)hipFree(c->dxs_dirty);
     (void)hipFree(c->dr2S); (void)hipFree(c->dr2B); (void)hipFree(c->dpceA); (void)hipFree(c->dbnd_snap);
+    (void)hipFree(c->dsum);
+    if (c->hsum) (void)hipHostFree(c->hsum);
+    if (c->hX) (void)hipHostFree(c->hX);
+    if (c->hU) (void)hipHostFree(c->hU);
+    if (c->evres) (void)hipEventDestroy(c->evres);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
@@ -919,6 +928,45 @@ extern "C" int tum_ocp_get_device(tum_ocp *c, const char *field, void *dst, int 
     if (f == "status") { HIPCHK(hipMemcpyAsync(dst, c->dstatus + b0, 4 * (size_t)nb, hipMemcpyDeviceToDevice, s)); return 0; }
     if (f == "qp_iter") { HIPCHK(hipMemcpyAsync(dst, c->dqpiter + b0, 4 * (size_t)nb, hipMemcpyDeviceToDevice, s)); return 0; }
     return fail("get_device: unknown field '" + f + "'");
+}
+
+// Results on the host behind an event instead of a stream synchronisation (include/tum_nmpc.h). The slabs are allocated on first
+// use: pinned memory is a scarce host resource and most capsules (closed loops on the device, the RCCL gather) never ask.
+extern "C" int tum_ocp_results_async(tum_ocp *c, int with_iterate)
+{
+    if (!c) return fail("null capsule");
+    DevGuard guard(c->d.device); GUARD_OK(guard);
+    const size_t B = c->batch; const int N = c->N;
+    if (!c->evres) HIPCHK(hipEventCreateWithFlags(&c->evres, hipEventDisableTiming));
+    if (!c->dsum) { if (dalloc(&c->dsum, B * 5) != hipSuccess) return fail("results_async: device allocation failed"); }
+    if (!c->hsum) HIPCHK(hipHostMalloc((void **)&c->hsum, sizeof(double) * B * 5, hipHostMallocDefault));
+    if (with_iterate && !c->hX) {
+        HIPCHK(hipHostMalloc((void **)&c->hX, sizeof(double) * B * (N + 1) * NX, hipHostMallocDefault));
+        HIPCHK(hipHostMalloc((void **)&c->hU, sizeof(double) * B * N * NU, hipHostMallocDefault));
+    }
+    hipStream_t s = c->stream;
+    hipLaunchKernelGGL(pack_summary_kernel, dim3((unsigned)((B + 255) / 256)), dim3(256), 0, s, c->dU, c->dcost, c->dstatus, c->dqpiter, N, 0, (int)B, c->dsum);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(c->hsum, c->dsum, sizeof(double) * B * 5, hipMemcpyDeviceToHost, s));
+    if (with_iterate) {
+        HIPCHK(hipMemcpyAsync(c->hX, c->dX, sizeof(double) * B * (N + 1) * NX, hipMemcpyDeviceToHost, s));
+        HIPCHK(hipMemcpyAsync(c->hU, c->dU, sizeof(double) * B * N * NU, hipMemcpyDeviceToHost, s));
+    }
+    HIPCHK(hipEventRecord(c->evres, s));
+    c->res_pending = true; c->res_iter = with_iterate != 0;
+    return 0;
+}
+
+extern "C" int tum_ocp_results_wait(tum_ocp *c, const double **summary, const double **X, const double **U)
+{
+    if (!c) return fail("null capsule");
+    if (!c->res_pending) return fail("results_wait: no tum_ocp_results_async before it");
+    DevGuard guard(c->d.device); GUARD_OK(guard);
+    HIPCHK(hipEventSynchronize(c->evres));
+    if (summary) *summary = c->hsum;
+    if (X) *X = c->res_iter ? c->hX : nullptr;
+    if (U) *U = c->res_iter ? c->hU : nullptr;
+    return 0;
 }
 
 // device-to-device upload of per-instance inputs from caller-owned HBM (asynchronous, on the capsule's stream)

@@ -67,7 +67,7 @@ C_SYMBOLS = ["tum_ocp_create", "tum_ocp_free", "tum_ocp_last_error", "tum_ocp_ba
              "tum_ocp_set", "tum_ocp_get", "tum_ocp_constraints_set", "tum_ocp_cost_set",
              "tum_ocp_solve", "tum_ocp_solve_async", "tum_ocp_synchronize",
              "tum_ocp_get_cost", "tum_ocp_get_stats", "tum_ocp_reset", "tum_ocp_get_from_qp_in",
-             "tum_ocp_set_stream", "tum_ocp_get_device", "tum_ocp_put_device", "tum_ocp_cold_start", "tum_ocp_last_kernel_ms",
+             "tum_ocp_set_stream", "tum_ocp_get_device", "tum_ocp_put_device", "tum_ocp_results_async", "tum_ocp_results_wait", "tum_ocp_cold_start", "tum_ocp_last_kernel_ms",
              "tum_ocp_debug_dump", "tum_ocp_profile_phases", "tum_ocp_set_schedule", "tum_ocp_set_kernel",
              "tum_ocp_set_x0_fanout", "tum_pce_moments", "tum_pce_attach", "tum_pce_moments_device",
              "tum_ocp_bounds_snapshot", "tum_ocp_bounds_restore", "tum_ocp_r2_backoff", "tum_ocp_r2_attach", "tum_ocp_constraints_get",
@@ -111,6 +111,8 @@ def load_library(path=None):
     L.tum_ocp_set_kernel.argtypes = [vp, cs]
     L.tum_ocp_get_device.argtypes = [vp, cs, vp, ci, ci]
     L.tum_ocp_put_device.argtypes = [vp, cs, vp, ci, ci]
+    L.tum_ocp_results_async.argtypes = [vp, ci]
+    L.tum_ocp_results_wait.argtypes = [vp, ctypes.POINTER(dp), ctypes.POINTER(dp), ctypes.POINTER(dp)]
     L.tum_ocp_last_kernel_ms.restype = ctypes.c_double; L.tum_ocp_last_kernel_ms.argtypes = [vp]
     L.tum_ocp_debug_dump.argtypes = [vp, ci, dp, ci]
     L.tum_ocp_profile_phases.argtypes = [vp, ctypes.POINTER(ctypes.c_longlong)]
@@ -346,6 +348,23 @@ class BatchedOcpSolver:
         """'x0' | 'yref' | 'X' | 'U' from caller-owned device memory (asynchronous D2D on the capsule's stream)"""
         nb = self.batch - b0 if nb is None else nb
         self._chk(self._L.tum_ocp_put_device(self._h, field.encode(), ctypes.c_void_p(dev_ptr), b0, nb), "put_device")
+
+    def results_async(self, with_iterate=False):
+        """Enqueue, behind the solve on this capsule's stream, the copy of the results into the capsule's pinned host slabs
+        (summary: u0[2], cost, status, qp_iter per instance; with_iterate: also X and U). Returns at once."""
+        self._chk(self._L.tum_ocp_results_async(self._h, int(bool(with_iterate))), "results_async")
+
+    def results_wait(self):
+        """Block until the copies of the last results_async have landed. Returns numpy VIEWS of the pinned slabs (valid until
+        the next results_async on this capsule): (summary (batch, 5), X (batch, N+1, 8) or None, U (batch, N, 2) or None)."""
+        dp = ctypes.POINTER(ctypes.c_double)
+        ps, px, pu = dp(), dp(), dp()
+        self._chk(self._L.tum_ocp_results_wait(self._h, ctypes.byref(ps), ctypes.byref(px), ctypes.byref(pu)), "results_wait")
+        B, N = self.batch, self.N
+        summ = np.ctypeslib.as_array(ps, shape=(B, 5))
+        X = np.ctypeslib.as_array(px, shape=(B, N + 1, 8)) if px else None
+        U = np.ctypeslib.as_array(pu, shape=(B, N, 2)) if pu else None
+        return summ, X, U
 
     def set_schedule(self, longest_first=True):
         """Dispatch instances longest-first by the previous solve's iteration counts (default) or in natural order."""

@@ -11,7 +11,14 @@ cold start, solve, result packing) runs on that capsule's stream, so consecutive
 still gets a complete, independent solve. Measured on config 2 (4096 x N = 40, fresh batch every step): 2.49 M solves/s on one
 capsule, 2.91 / 3.04 / 3.1 M on two / three / four (scripts/dev/overlap_probe.py).
 
-This is host logic above the C-ABI (which already allows any number of capsules per process); no new entry point is needed.
+Results on the host ride the same ring: `request_results(slot)` enqueues, behind the solve on that capsule's stream, the copy
+of the batch's results into the capsule's pinned host slab and an event (C-ABI: tum_ocp_results_async); `take_results(slot)`
+waits for THAT event only and returns views of the slab (tum_ocp_results_wait). A caller that asks for the results of batch k
+when capsule k mod S comes round again has S - 1 batches of GPU work between the request and the wait: the PCIe copy and the
+host's own work on the results hide behind them (measured on config 2, three capsules: host-visible rate = device rate,
+bench.py `value_host_visible`; with a synchronous read after every solve it was 25 % below).
+
+This is host logic above the C-ABI (which already allows any number of capsules per process).
 A closed loop -- where solve k + 1 needs the result of solve k -- has nothing to overlap and keeps using one capsule.
 """
 
@@ -29,6 +36,7 @@ class SolverRing:
             for s, st in zip(self.solvers, streams):
                 s.set_stream(st)
         self._next = 0
+        self._pending = [False] * n_slots
 
     def __len__(self):
         return len(self.solvers)
@@ -45,6 +53,29 @@ class SolverRing:
         i = self._next
         self._next = (i + 1) % len(self.solvers)
         return i, self.solvers[i]
+
+    def request_results(self, slot, with_iterate=False):
+        """Behind everything enqueued on capsule `slot` so far: copy its batch's results (summary; with_iterate: X and U too)
+        into the capsule's pinned host slab, asynchronously."""
+        self.solvers[slot].results_async(with_iterate)
+        self._pending[slot] = True
+
+    def take_results(self, slot):
+        """(summary, X, U) views of capsule `slot`'s pinned slab once the copies requested last have landed -- None when no
+        request is outstanding. The views stay valid until the next request_results on this slot."""
+        if not self._pending[slot]:
+            return None
+        self._pending[slot] = False
+        return self.solvers[slot].results_wait()
+
+    def drain(self):
+        """(slot, results) of every outstanding request, oldest capsule first"""
+        n = len(self.solvers)
+        for d in range(n):
+            i = (self._next + d) % n
+            r = self.take_results(i)
+            if r is not None:
+                yield i, r
 
     def synchronize(self):
         for s in self.solvers:
