@@ -150,6 +150,7 @@ def parse_args(argv=None):
                     help="solve the SAME batch every step (batch 0; the longest-first dispatch then has exact history) instead of "
                          "rotating fresh batches: round 2's headline, kept for profiling the repeated-batch leg on its own")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-host-legs", action="store_true", help="skip the host-visible legs (N=1 only)")
     ap.add_argument("--no-schedule-legs", action="store_true",
                     help="skip the repeated-batch, natural-order and N = 38 legs (N=1 only)")
     return ap.parse_args(argv)
@@ -281,8 +282,6 @@ class Job:
 
     def _step(self, slot, s, marks, fresh):
         cid, slab = self.cid, self.slabs[slot]
-        if self.host_results:
-            self._read(self.ring.take_results(slot))      # (the batch this capsule solved S steps ago)
         if fresh is not None:
             k = fresh % NB_FRESH
             s.put_device("x0", self.dx0[k].data_ptr()); s.put_device("yref", self.dyr[k].data_ptr())
@@ -300,6 +299,8 @@ class Job:
             s.pce_moments_device("x", 1, mom_ptr, mom_ptr + 8 * self.P * 8)
         if self.host_results:
             self.ring.request_results(slot, self.host_results == "iterate")
+            if self.ring.outstanding(slot) == 2:                # the batch this capsule solved S steps ago: read AFTER the new batch and
+                self._read(self.ring.take_results(slot))        # its request are on the stream, so the stream never waits for the host
         if self.gather is not None:
             if marks is not None:
                 marks.append(self.clock.mark())
@@ -358,14 +359,19 @@ def run(args, torch, dist, dev, world, rank, local_rank, solver_factory, workloa
     # cost / status after every solve): results_async behind each solve, the pinned slab read when the capsule comes round
     # again, the last ones inside the timed region. Same capsules, same streams, same fresh batches as `value`.
     hv_value = hv_iter_value = hv_ok = None
-    if world == 1 and extra_legs and not args.no_schedule_legs and hasattr(job.s, "results_async"):
+    if world == 1 and extra_legs and not args.no_host_legs and hasattr(job.s, "results_async"):
         for mode in ("summary", "iterate"):
             job.host_results = mode; job.host_seen = job.host_ok = 0
-            for i in range(max(2, S)):
+            # (first uses are slow and must stay outside the timed region: pinned slabs are allocated when a capsule is first asked
+            #  for its results, and the first device-to-host copies of a stream set up its copy path -- several ms each)
+            for i in range(int(os.environ.get("BENCH_HOST_WARM", 4 * S))):
                 job.step(fresh=i)
             job.drain(); job.host_seen = job.host_ok = 0
-            hv_elapsed, _ = job.timed(args.steps, fresh=not args.same_batch)
+            hv_elapsed, hmarks = job.timed(args.steps, fresh=not args.same_batch)
             assert job.host_seen == B * args.steps, (job.host_seen, B, args.steps)
+            if os.environ.get("BENCH_DEBUG"):
+                print(f"[host leg {mode}] {1e3 * hv_elapsed / args.steps:.3f} ms/step; device ms between the events around each solve: "
+                      + " ".join(f"{job.clock.ms(m[0], m[1]):.2f}" for m in hmarks), file=sys.stderr)
             v = B * spp * args.steps / hv_elapsed
             if mode == "summary":
                 hv_value, hv_ok = v, job.host_ok / max(1, job.host_seen)

@@ -129,8 +129,11 @@ int tum_ocp_get_device(tum_ocp *c, const char *field, void *dev_dst, int b0, int
  * qp_iter) and its copy into a PINNED host slab the capsule owns -- with_iterate != 0: also the whole iterate X ((N+1)*8
  * doubles per instance) and U (N*2) -- then records an event. It returns at once: a caller that keeps several capsules in
  * flight (streaming.SolverRing) enqueues the next batches while this one's results cross PCIe.
- * tum_ocp_results_wait blocks until that event has passed and hands out the pinned slabs (valid until the next
- * tum_ocp_results_async on this capsule; X / U are null when the last request was made without the iterate). */
+ * A capsule owns TWO sets of slabs and events, used in turn: up to two requests may be outstanding, so a caller can enqueue the
+ * next batch and its request BEFORE it reads the previous batch's results (the stream then never runs dry waiting for the host).
+ * tum_ocp_results_wait blocks until the event of the OLDEST outstanding request has passed and hands out its pinned slabs
+ * (valid until the second-next tum_ocp_results_async on this capsule; X / U are null when that request was made without the
+ * iterate). A third request without a wait in between is an error. */
 int tum_ocp_results_async(tum_ocp *c, int with_iterate);
 int tum_ocp_results_wait(tum_ocp *c, const double **summary, const double **X, const double **U);
 /* The other direction: per-instance inputs from caller-owned DEVICE memory (asynchronous D2D on the capsule's stream).

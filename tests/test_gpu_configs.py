@@ -354,6 +354,16 @@ def test_results_on_the_host_through_pinned_slabs():
     s.cold_start(); s.solve_async(); ring.request_results(slot)
     summ, X, U = ring.take_results(slot)
     assert X is None and U is None and np.array_equal(summ, got[slot][0])
+    # two requests may be outstanding on a capsule (two sets of slabs, used in turn), taken oldest first; a third is refused
     s2 = _mk(4)
     with pytest.raises(Exception, match="results_wait"):
         s2.results_wait()
+    x0, yr = nominal_batch(4, N=N, seed=7)
+    s2.set_x0(x0); s2.set_yref_all(yr); s2.cold_start(); s2.solve_async(); s2.results_async(True)
+    s2.solve_async(); s2.results_async(True)                        # a second real-time iteration behind the first
+    with pytest.raises(Exception, match="two requests outstanding"):
+        s2.results_async()
+    (a, Xa, Ua), (b, Xb, Ub) = s2.results_wait(), s2.results_wait()
+    Xr, Ur = s2.get_iterate()
+    assert np.array_equal(Xb, Xr) and np.array_equal(Ub, Ur) and not np.array_equal(Ua, Ub)
+    assert a.ctypes.data != b.ctypes.data and np.array_equal(b[:, :2], Ur[:, 0])

@@ -448,28 +448,31 @@ def test_workload_variants_are_fresh_batches_of_the_same_workload():
 
 
 def test_solver_ring_results_bookkeeping():
-    """streaming.SolverRing: capsules handed out in turn; a results request is remembered per slot, taken once, and `drain`
-    walks the outstanding ones oldest capsule first (host logic only: stand-in capsules)."""
+    """streaming.SolverRing: capsules handed out in turn; up to two result requests are remembered per slot and taken oldest
+    first, `drain` walks the outstanding ones in the order the batches were enqueued (host logic only: stand-in capsules)."""
     from tum_control_amd.streaming import SolverRing
 
     class Fake:
         def __init__(self, i):
-            self.i, self.calls = i, []
+            self.i, self.calls, self.n_req, self.n_wait = i, [], 0, 0
 
         def results_async(self, with_iterate):
-            self.calls.append(("async", with_iterate))
+            self.calls.append(("async", with_iterate)); self.n_req += 1
 
         def results_wait(self):
-            self.calls.append(("wait",))
-            return ("summary", self.i), None, None
+            self.n_wait += 1
+            return ("summary", self.i, self.n_wait), None, None
 
     ring = SolverRing(3, Fake)
     assert [ring.acquire()[0] for _ in range(4)] == [0, 1, 2, 0]          # next turn: capsule 1
     assert ring.take_results(1) is None and list(ring.drain()) == []
-    ring.request_results(2, with_iterate=True); ring.request_results(0); ring.request_results(1)
-    assert ring[2].calls == [("async", True)] and ring[0].calls == [("async", False)]
-    assert ring.take_results(2)[0] == ("summary", 2) and ring.take_results(2) is None
-    assert [i for i, _ in ring.drain()] == [1, 0]                          # from the capsule whose turn is next
-    assert list(ring.drain()) == []
+    ring.request_results(2, with_iterate=True); ring.request_results(0); ring.request_results(1); ring.request_results(2)
+    assert ring[2].calls == [("async", True), ("async", False)] and ring[0].calls == [("async", False)]
+    assert [ring.outstanding(i) for i in range(3)] == [1, 1, 2]
+    assert ring.take_results(2)[0] == ("summary", 2, 1) and ring.outstanding(2) == 1
+    ring.request_results(2)
+    # drain: capsule 2 holds an older batch (two outstanding) -> first; then from the capsule whose turn is next
+    assert [(i, r[0][2]) for i, r in ring.drain()] == [(2, 2), (1, 1), (2, 3), (0, 1)]
+    assert list(ring.drain()) == [] and ring.take_results(2) is None
     with pytest.raises(ValueError):
         SolverRing(0, Fake)

@@ -61,7 +61,8 @@ struct tum_ocp {
     double *dpceA; int pce_L, pce_S; double *dbnd_snap;
     // results on the host without a stream stall (tum_ocp_results_async / _wait): device slab of the packed summary, pinned
     // host slabs, the event behind the copies
-    double *dsum, *hsum, *hX, *hU; hipEvent_t evres; bool res_pending, res_iter;
+    // two sets, used in turn: the request for the NEXT batch can be enqueued before the previous batch's results have been read
+    double *dsum, *hsum[2], *hX[2], *hU[2]; hipEvent_t evres[2]; bool res_iter[2]; int res_head, res_count;
 };
 
 static const int DBG_STRIDE = 20480;
@@ -123,7 +124,8 @@ extern "C" tum_ocp *tum_ocp_create(const tum_ocp_desc *desc)
     c->have_offs = c->fanout = false;
     c->r2 = false; c->dr2S = c->dr2B = nullptr;
     c->p_dirty = false; c->uph_cap = 0; c->gamma = 0.0; c->dpceA = nullptr; c->pce_L = c->pce_S = 0; c->dbnd_snap = nullptr;
-    c->dsum = c->hsum = c->hX = c->hU = nullptr; c->evres = nullptr; c->res_pending = c->res_iter = false;
+    c->dsum = nullptr; c->res_head = c->res_count = 0;
+    for (int i = 0; i < 2; i++) { c->hsum[i] = c->hX[i] = c->hU[i] = nullptr; c->evres[i] = nullptr; c->res_iter[i] = false; }
     const int N = c->N; const size_t B = c->batch;
     bool ok = true;
     ok &= hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) == hipSuccess; c->own_stream = true;
@@ -227,10 +229,12 @@ extern "C" void tum_ocp_free(tum_ocp *c)
     (void)hipFree(c->dXS); (void)hipFree(c->dxs0); (void)hipFree(c->dApce); (void)hipFree(c->dws2); (void)hipFree(c->dpro); (void)hipFree(c->ddv); (void)hipFree(c->doffs); (void)hipFree(c->dxs_dirty);
     (void)hipFree(c->dr2S); (void)hipFree(c->dr2B); (void)hipFree(c->dpceA); (void)hipFree(c->dbnd_snap);
     (void)hipFree(c->dsum);
-    if (c->hsum) (void)hipHostFree(c->hsum);
-    if (c->hX) (void)hipHostFree(c->hX);
-    if (c->hU) (void)hipHostFree(c->hU);
-    if (c->evres) (void)hipEventDestroy(c->evres);
+    for (int i = 0; i < 2; i++) {
+        if (c->hsum[i]) (void)hipHostFree(c->hsum[i]);
+        if (c->hX[i]) (void)hipHostFree(c->hX[i]);
+        if (c->hU[i]) (void)hipHostFree(c->hU[i]);
+        if (c->evres[i]) (void)hipEventDestroy(c->evres[i]);
+    }
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
@@ -937,35 +941,49 @@ extern "C" int tum_ocp_results_async(tum_ocp *c, int with_iterate)
     if (!c) return fail("null capsule");
     DevGuard guard(c->d.device); GUARD_OK(guard);
     const size_t B = c->batch; const int N = c->N;
-    if (!c->evres) HIPCHK(hipEventCreateWithFlags(&c->evres, hipEventDisableTiming));
+    // Two sets of slabs / events used in turn: a caller keeps one request outstanding per capsule while it enqueues the next batch
+    // and its request, and only then reads the older one -- the stream never runs dry between two batches waiting for the host.
+    if (c->res_count == 2) return fail("results_async: two requests outstanding on this capsule (call tum_ocp_results_wait first)");
+    const int w = (c->res_head + c->res_count) & 1;
+    if (!c->evres[w]) HIPCHK(hipEventCreateWithFlags(&c->evres[w], hipEventDisableTiming));
     if (!c->dsum) { if (dalloc(&c->dsum, B * 5) != hipSuccess) return fail("results_async: device allocation failed"); }
-    if (!c->hsum) HIPCHK(hipHostMalloc((void **)&c->hsum, sizeof(double) * B * 5, hipHostMallocDefault));
-    if (with_iterate && !c->hX) {
-        HIPCHK(hipHostMalloc((void **)&c->hX, sizeof(double) * B * (N + 1) * NX, hipHostMallocDefault));
-        HIPCHK(hipHostMalloc((void **)&c->hU, sizeof(double) * B * N * NU, hipHostMallocDefault));
+    if (!c->hsum[w]) HIPCHK(hipHostMalloc((void **)&c->hsum[w], sizeof(double) * B * 5, hipHostMallocDefault));
+    if (with_iterate && !c->hX[w]) {
+        HIPCHK(hipHostMalloc((void **)&c->hX[w], sizeof(double) * B * (N + 1) * NX, hipHostMallocDefault));
+        HIPCHK(hipHostMalloc((void **)&c->hU[w], sizeof(double) * B * N * NU, hipHostMallocDefault));
     }
+    // The copies stay on the capsule's own stream. (Tried: a copy stream per capsule behind an event of the solve. Three capsules
+    // then own six streams, more than the four hardware queues the runtime multiplexes streams onto: the capsules' compute
+    // streams start to share queues and their batches no longer overlap -- 2.6 instead of 3.8 M solves/s on config 2.)
     hipStream_t s = c->stream;
-    hipLaunchKernelGGL(pack_summary_kernel, dim3((unsigned)((B + 255) / 256)), dim3(256), 0, s, c->dU, c->dcost, c->dstatus, c->dqpiter, N, 0, (int)B, c->dsum);
+    // the summary (40 B per instance) is written by the packing kernel STRAIGHT into the pinned slab (host memory mapped into the
+    // device's address space): no copy command, no DMA engine and no signal round trip between the kernels of two batches
+    static const bool zero_copy = [] { const char *e = getenv("TUM_RESULTS_ZERO_COPY"); return !(e && e[0] == '0'); }();
+    hipLaunchKernelGGL(pack_summary_kernel, dim3((unsigned)((B + 255) / 256)), dim3(256), 0, s, c->dU, c->dcost, c->dstatus, c->dqpiter, N, 0, (int)B,
+                       zero_copy ? c->hsum[w] : c->dsum);
     HIPCHK(hipGetLastError());
-    HIPCHK(hipMemcpyAsync(c->hsum, c->dsum, sizeof(double) * B * 5, hipMemcpyDeviceToHost, s));
+    if (!zero_copy) HIPCHK(hipMemcpyAsync(c->hsum[w], c->dsum, sizeof(double) * B * 5, hipMemcpyDeviceToHost, s));
     if (with_iterate) {
-        HIPCHK(hipMemcpyAsync(c->hX, c->dX, sizeof(double) * B * (N + 1) * NX, hipMemcpyDeviceToHost, s));
-        HIPCHK(hipMemcpyAsync(c->hU, c->dU, sizeof(double) * B * N * NU, hipMemcpyDeviceToHost, s));
+        HIPCHK(hipMemcpyAsync(c->hX[w], c->dX, sizeof(double) * B * (N + 1) * NX, hipMemcpyDeviceToHost, s));
+        HIPCHK(hipMemcpyAsync(c->hU[w], c->dU, sizeof(double) * B * N * NU, hipMemcpyDeviceToHost, s));
     }
-    HIPCHK(hipEventRecord(c->evres, s));
-    c->res_pending = true; c->res_iter = with_iterate != 0;
+    HIPCHK(hipEventRecord(c->evres[w], s));
+    c->res_iter[w] = with_iterate != 0;
+    c->res_count++;
     return 0;
 }
 
 extern "C" int tum_ocp_results_wait(tum_ocp *c, const double **summary, const double **X, const double **U)
 {
     if (!c) return fail("null capsule");
-    if (!c->res_pending) return fail("results_wait: no tum_ocp_results_async before it");
+    if (c->res_count == 0) return fail("results_wait: no tum_ocp_results_async before it");
     DevGuard guard(c->d.device); GUARD_OK(guard);
-    HIPCHK(hipEventSynchronize(c->evres));
-    if (summary) *summary = c->hsum;
-    if (X) *X = c->res_iter ? c->hX : nullptr;
-    if (U) *U = c->res_iter ? c->hU : nullptr;
+    const int r = c->res_head;          // the OLDEST outstanding request
+    HIPCHK(hipEventSynchronize(c->evres[r]));
+    if (summary) *summary = c->hsum[r];
+    if (X) *X = c->res_iter[r] ? c->hX[r] : nullptr;
+    if (U) *U = c->res_iter[r] ? c->hU[r] : nullptr;
+    c->res_head ^= 1; c->res_count--;
     return 0;
 }
 

@@ -12,11 +12,13 @@ still gets a complete, independent solve. Measured on config 2 (4096 x N = 40, f
 capsule, 2.91 / 3.04 / 3.1 M on two / three / four (scripts/dev/overlap_probe.py).
 
 Results on the host ride the same ring: `request_results(slot)` enqueues, behind the solve on that capsule's stream, the copy
-of the batch's results into the capsule's pinned host slab and an event (C-ABI: tum_ocp_results_async); `take_results(slot)`
-waits for THAT event only and returns views of the slab (tum_ocp_results_wait). A caller that asks for the results of batch k
-when capsule k mod S comes round again has S - 1 batches of GPU work between the request and the wait: the PCIe copy and the
-host's own work on the results hide behind them (measured on config 2, three capsules: host-visible rate = device rate,
-bench.py `value_host_visible`; with a synchronous read after every solve it was 25 % below).
+of the batch's results into one of the capsule's two pinned host slabs and an event (C-ABI: tum_ocp_results_async);
+`take_results(slot)` waits for the event of the capsule's OLDEST request only and returns views of its slab
+(tum_ocp_results_wait). The pattern that keeps the GPU busy: when capsule k mod S comes round again, enqueue batch k and its
+request FIRST, then take the results of batch k - S -- the capsule's stream already holds the next batch while the host reads
+the previous one, and S batches of GPU work lie between a request and its wait (measured on config 2, three capsules:
+host-visible rate = device rate, bench.py `value_host_visible`; reading BEFORE enqueuing leaves the stream dry for the host's
+reaction time once per batch, 3.06 against 3.8 M solves/s; a synchronous read after every solve: 2.9 M).
 
 This is host logic above the C-ABI (which already allows any number of capsules per process).
 A closed loop -- where solve k + 1 needs the result of solve k -- has nothing to overlap and keeps using one capsule.
@@ -36,7 +38,7 @@ class SolverRing:
             for s, st in zip(self.solvers, streams):
                 s.set_stream(st)
         self._next = 0
-        self._pending = [False] * n_slots
+        self._pending = [0] * n_slots          # outstanding result requests per capsule (the C-ABI allows two)
 
     def __len__(self):
         return len(self.solvers)
@@ -58,24 +60,29 @@ class SolverRing:
         """Behind everything enqueued on capsule `slot` so far: copy its batch's results (summary; with_iterate: X and U too)
         into the capsule's pinned host slab, asynchronously."""
         self.solvers[slot].results_async(with_iterate)
-        self._pending[slot] = True
+        self._pending[slot] += 1
+
+    def outstanding(self, slot):
+        return self._pending[slot]
 
     def take_results(self, slot):
-        """(summary, X, U) views of capsule `slot`'s pinned slab once the copies requested last have landed -- None when no
-        request is outstanding. The views stay valid until the next request_results on this slot."""
+        """(summary, X, U) views of the pinned slabs of capsule `slot`'s OLDEST outstanding request once its copies have landed --
+        None when no request is outstanding. A capsule has two sets of slabs: the views stay valid until the second-next
+        request_results on this slot. To keep a capsule's stream busy, enqueue the next batch and its request first and take
+        the older results afterwards (`outstanding(slot) == 2`)."""
         if not self._pending[slot]:
             return None
-        self._pending[slot] = False
+        self._pending[slot] -= 1
         return self.solvers[slot].results_wait()
 
     def drain(self):
-        """(slot, results) of every outstanding request, oldest capsule first"""
+        """(slot, results) of every outstanding request, in the order the batches were enqueued"""
         n = len(self.solvers)
-        for d in range(n):
-            i = (self._next + d) % n
-            r = self.take_results(i)
-            if r is not None:
-                yield i, r
+        for want in (2, 1):          # capsules with two requests hold the older batches
+            for d in range(n):
+                i = (self._next + d) % n
+                if self._pending[i] == want:
+                    yield i, self.take_results(i)
 
     def synchronize(self):
         for s in self.solvers:
