@@ -153,7 +153,11 @@ int tum_ocp_set_schedule(tum_ocp *c, int longest_first);
  * the interior point kernel. The development build (libtumnmpc_dev.so, tests and experiments only) adds the two other
  * implementations the pipeline is held against: "fused" (round 1's single kernel, N <= 40, uph <= 31) and "pipeline4" (the
  * pipeline with the four-wavefront interior point kernel); the shipped library refuses these names. Environment override at
- * create time: TUM_NMPC_KERNEL. */
+ * create time: TUM_NMPC_KERNEL.
+ * Two further names choose the PROLOGUE of a coupled SNMPC capsule without touching the rest: "prologue-cols" (one column of
+ * every sample's sensitivity matrix per lane; n_samples <= 10; the library's own choice from 20 propagation stages on) and
+ * "prologue-passes" (the column-slot / pass kernels of rounds 1-3; the choice for shorter horizons and the only one for
+ * n_samples > 10): two implementations of the same hand-over the tests hold against each other. */
 int tum_ocp_set_kernel(tum_ocp *c, const char *name);
 /* last kernel launch time in milliseconds (HIP events on the launch stream) */
 double tum_ocp_last_kernel_ms(tum_ocp *c);

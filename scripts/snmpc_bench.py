@@ -19,11 +19,13 @@ def main():
     w = snm.hammersley_normal(10, 3)
     A = snm.pce_matrix(w, snm.alpha_generation(3, 2))
     offs = snm.x0_offsets(w, stds)
-    for N, uph in ((38, 5), (40, 5), (40, 15), (38, 38)):      # (38, 38): UPH = Tp as in the ACC24 campaign of the reference
+    for N, uph in ((38, 5), (40, 5), (38, 9), (40, 15), (40, 24), (38, 38)):      # (38, 38): UPH = Tp as in the ACC24 campaign of the reference
         x0, yref = nominal_batch(B, N=N)
         X0 = np.concatenate([x0[:, None, :], x0[:, None, :] + offs[None]], axis=1)          # (B, 11, 8)
         s = CoupledSnmpcSolver(N=N, dt=0.08, batch=B, Apce=A, uph=uph, gamma=config.MPC["gamma"])
         s.install_reference_ocp()
+        if os.environ.get("SN_PROLOGUE"):          # prologue-cols | prologue-passes (default: the library's choice)
+            s.set_kernel(os.environ["SN_PROLOGUE"])
         s.constraints_set(0, "lbx", X0.reshape(B, -1)); s.constraints_set(0, "ubx", X0.reshape(B, -1))
         s.set_yref_all(yref)
         cold = []

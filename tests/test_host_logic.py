@@ -476,3 +476,21 @@ def test_solver_ring_results_bookkeeping():
     assert list(ring.drain()) == [] and ring.take_results(2) is None
     with pytest.raises(ValueError):
         SolverRing(0, Fake)
+
+
+def test_external_cost_type_is_refused_loudly(monkeypatch):
+    """NMPC_class.py:90-94 builds a different OCP for costfunction_type != 'NONLINEAR_LS' (the EXTERNAL-cost development
+    variant): the mirrors refuse that configuration before anything touches the GPU instead of solving the NONLINEAR_LS problem
+    under another name."""
+    from tum_control_amd import config, nmpc, snmpc
+    cfg = config.default_config(); cfg["mpc"]["costfunction_type"] = "EXTERNAL"
+    monkeypatch.setattr(nmpc._config, "default_config", lambda: cfg)
+    monkeypatch.setattr(snmpc._config, "default_config", lambda: cfg)
+    sim = dict(Tp=3.04, Ts=0.02, Ts_MPC=0.08)
+    for C in (nmpc.Nonlinear_Model_Predictive_Controller, snmpc.Stochastic_Nonlinear_Model_Predictive_Controller):
+        with pytest.raises(NotImplementedError, match="EXTERNAL"):
+            C(sim_main_params=sim, X0_MPC=np.zeros(8))
+    from tum_control_amd.r2nmpc import Reduced_Robustified_Nonlinear_Model_Predictive_Controller as R2
+    with pytest.raises(NotImplementedError, match="EXTERNAL"):
+        R2(sim_main_params=sim, X0_MPC=np.zeros(8))
+    nmpc.check_costfunction_type({"costfunction_type": "NONLINEAR_LS"}); nmpc.check_costfunction_type({})

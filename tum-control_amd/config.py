@@ -50,6 +50,9 @@ def load_reference_config(config_path, sim_main_params=None, mpc_params_file="ED
     with open(os.path.join(config_path, mpc_params_file)) as f:
         mp = yaml.safe_load(f)
     cfg["mpc"].update({k: v for k, v in mp.items() if k in cfg["mpc"]})
+    # which OCP the controller classes build (NMPC_class.py:90-94): the NONLINEAR_LS formulation is the one that exists here;
+    # the value is carried so that the controller mirrors can refuse anything else instead of silently assuming it
+    cfg["mpc"]["costfunction_type"] = mp.get("costfunction_type", "NONLINEAR_LS")
     with open(os.path.join(config_path, mp["lookuptable_gg_limits"])) as f:
         rows = list(csv.DictReader(f))
     cfg["ggv"] = dict(v=[float(r["vel_max_mps"]) for r in rows], ax=[float(r["ax_max_mps2"]) for r in rows],

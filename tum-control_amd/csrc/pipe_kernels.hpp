@@ -231,13 +231,15 @@ __global__ void __launch_bounds__(64, (NT_ == 5) ? 2 : 1) cond_kernel(const PArg
             if (SN && k < uph) {
                 // stage s = k+1 <= uph: G_nom,s and g_nom,s are PCE means of the sample recursions (prologue kernel)
                 // (columns 0..63 in bank 0, 64..2 uph-1 on the lanes of bank 1, the constant column on the g lane)
+                // (only the 2 (k + 1) live columns of the stage are fetched: the rest of a row is zero, and at UPH = Tp the full rows
+                //  were 200 KB of the 350 KB this kernel read per instance)
                 const double *pg = gpro + (size_t)k * PSTAGE;
-                const bool b1 = lane < NB1 && 64 + lane < 2 * uph;
+                const bool b0 = lane < 2 * (k + 1), b1 = lane < NB1 && 64 + lane < 2 * (k + 1);
 #pragma unroll
                 for (int i = 0; i < 8; i++) {
-                    const double gv = pg[i * PP + lane], gg = pg[i * PP + 2 * uph];
+                    const double gv = b0 ? pg[i * PP + lane] : 0.0, gg = pg[i * PP + 2 * uph];
                     const double g1 = b1 ? pg[i * PP + 64 + lane] : 0.0;
-                    w0[i] = (lane < 2 * uph) ? gv : 0.0;
+                    w0[i] = gv;
                     w1[i] = isg ? gg : g1;
                 }
             } else {
@@ -265,9 +267,9 @@ __global__ void __launch_bounds__(64, (NT_ == 5) ? 2 : 1) cond_kernel(const PArg
                 hr0 += g4 * w0[4]; hr1 += g4 * w1[4];
                 if (s < uph) {   // chance-constraint row E + kappa sqrt(Var) over the samples (prologue kernel)
                     const double *pr = gpro + (size_t)k * PSTAGE + 8 * PP;
-                    const double rv = pr[lane], rg = pr[2 * uph];
-                    const double r1 = (lane < NB1 && 64 + lane < 2 * uph) ? pr[64 + lane] : 0.0;
-                    hr0 = (lane < 2 * uph) ? rv : 0.0; hr1 = isg ? rg : r1; hd = 0.0;
+                    const double rv = (lane < 2 * s) ? pr[lane] : 0.0, rg = pr[2 * uph];
+                    const double r1 = (lane < NB1 && 64 + lane < 2 * s) ? pr[64 + lane] : 0.0;
+                    hr0 = rv; hr1 = isg ? rg : r1; hd = 0.0;
                 }
             }
             // the speed row of the cost: vl (nominal OCP) or |v| (SNMPC: gradient (vl, vt)/|v|)

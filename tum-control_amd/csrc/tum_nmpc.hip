@@ -53,6 +53,7 @@ struct tum_ocp {
     double *dXS, *dxs0, *dApce, *dws2, *dpro, *ddv, *doffs;
     int *dxs_dirty; bool xs_lazy;          // sample copies of the stages > uph not yet frozen (snmpc_freeze_kernel)
     bool have_offs, fanout;        // sample initial conditions derived from the nominal x0 at every solve
+    int sn_cols;                   // prologue of the SNMPC OCP: -1 the library's choice, 1 column-per-lane, 0 column slots and passes (tum_ocp_set_kernel)
     // R2NMPC tightening after every solve (tum_ocp_r2_attach)
     bool r2; int r2_uph; double r2_dmin, r2_dmax, r2_uh; double *dr2S, *dr2B;
     // per-stage parameter vector of the SNMPC OCP as the caller last set it (tum_ocp_set "p")
@@ -121,7 +122,7 @@ extern "C" tum_ocp *tum_ocp_create(const tum_ocp_desc *desc)
     tum_ocp *c = new tum_ocp();
     c->d = *desc; c->N = desc->N; c->batch = desc->batch; c->last_ms = 0; c->solved = false; c->epoch = 0;
     c->sn = false; c->dXS = c->dxs0 = c->dApce = c->dws2 = c->dpro = c->ddv = c->doffs = nullptr; c->dxs_dirty = nullptr; c->xs_lazy = false;
-    c->have_offs = c->fanout = false;
+    c->have_offs = c->fanout = false; c->sn_cols = -1;
     c->r2 = false; c->dr2S = c->dr2B = nullptr;
     c->p_dirty = false; c->uph_cap = 0; c->gamma = 0.0; c->dpceA = nullptr; c->pce_L = c->pce_S = 0; c->dbnd_snap = nullptr;
     c->dsum = nullptr; c->res_head = c->res_count = 0;
@@ -256,8 +257,9 @@ extern "C" int tum_ocp_snmpc_attach(tum_ocp *c, int ns, int L, const double *Apc
     if (c->d.store_qp_in) return fail("snmpc_attach: store_qp_in is not available for the stacked state");
     DevGuard guard(c->d.device); GUARD_OK(guard);
     {
-        const size_t lds = sizeof(double) * sn_prologue_lds_doubles(uph, ns, sn_prologue_variant(uph, ns));
+        const size_t lds = sizeof(double) * (sn_prologue_cols(uph, ns, c->sn_cols) ? sn_cols_lds_doubles(uph, ns) : sn_prologue_lds_doubles(uph, ns, sn_prologue_variant(uph, ns)));
         if (lds > 128 * 1024) return fail("snmpc_attach: n_samples x uph too large for the prologue kernel's LDS");
+        HIPCHK(hipFuncSetAttribute((const void *)snmpc_prologue_cols_kernel<SN_COLS_NSW>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
         HIPCHK(hipFuncSetAttribute((const void *)snmpc_prologue_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
         HIPCHK(hipFuncSetAttribute((const void *)snmpc_prologue_kernel<6>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
         HIPCHK(hipFuncSetAttribute((const void *)snmpc_prologue_kernel<9>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
@@ -355,7 +357,7 @@ static int sn_apply_p(tum_ocp *c)
         if (c->p_stop[k] != 1.0) return fail("solve: stop_flag pattern not supported: it must be 0 on the stages < uph and 1 from stage uph on (stage " + std::to_string(k) + " is 0 after a 1)");
     if (uph > N) uph = N;                      // no stop flag at all: the samples are propagated over the whole horizon
     if (uph > SN_UPHMAX) return fail("solve: uncertainty propagation horizon from the stop flags exceeds " + std::to_string(SN_UPHMAX));
-    if (sizeof(double) * sn_prologue_lds_doubles(uph, ns, sn_prologue_variant(uph, ns)) > 128 * 1024)      // (the variant sn_launch_prologue will pick)
+    if (sizeof(double) * (sn_prologue_cols(uph, ns, c->sn_cols) ? sn_cols_lds_doubles(uph, ns) : sn_prologue_lds_doubles(uph, ns, sn_prologue_variant(uph, ns))) > 128 * 1024)      // (the variant sn_launch_prologue will pick)
         return fail("solve: n_samples x uph too large for the prologue kernel's LDS");
     // (the hand-over buffer of the prologue is sized uph x sn_pro_stage(uph): its row pitch doubles beyond uph = 31)
     if (uph > c->uph_cap || (size_t)uph * sn_pro_stage(uph) > c->pro_cap) {
@@ -627,6 +629,16 @@ extern "C" int tum_ocp_set_kernel(tum_ocp *c, const char *name)
     const std::string n(name);
     if (n == "auto") c->kmode = 0;
     else if (n == "pipeline") c->kmode = 2;
+    // the prologue of the coupled SNMPC OCP: one column per lane (default where n_samples <= 10) or the column-slot / pass variants
+    else if (n == "prologue-cols" || n == "prologue-passes") {
+        if (c->sn) {
+            const int want = (n == "prologue-passes") ? 0 : 1;
+            const size_t lds = sizeof(double) * (sn_prologue_cols(c->sa.uph, c->sa.ns, want) ? sn_cols_lds_doubles(c->sa.uph, c->sa.ns)
+                                                 : sn_prologue_lds_doubles(c->sa.uph, c->sa.ns, sn_prologue_variant(c->sa.uph, c->sa.ns)));
+            if (lds > 128 * 1024) return fail("set_kernel: n_samples x uph too large for that prologue kernel's LDS");
+        }
+        c->sn_cols = (n == "prologue-passes") ? 0 : 1;
+    }
 #ifdef TUM_DEV_KERNELS
     else if (n == "fused") c->kmode = 1;
     else if (n == "pipeline4") c->kmode = 3;
@@ -634,7 +646,7 @@ extern "C" int tum_ocp_set_kernel(tum_ocp *c, const char *name)
     else if (n == "fused" || n == "pipeline4")
         return fail("set_kernel: kernel '" + n + "' exists in the development build only (libtumnmpc_dev.so); this library is the pipeline");
 #endif
-    else return fail("set_kernel: unknown kernel '" + n + "' (auto | pipeline; development build: fused | pipeline4)");
+    else return fail("set_kernel: unknown kernel '" + n + "' (auto | pipeline | prologue-cols | prologue-passes; development build: fused | pipeline4)");
     c->epoch++;
     return 0;
 }
@@ -659,6 +671,11 @@ static int resolve_kernel(tum_ocp *c)
 // last stage) or, for short propagation horizons and beyond the largest instantiation, in LDS
 static void sn_launch_prologue(tum_ocp *c)
 {
+    if (sn_prologue_cols(c->sa.uph, c->sa.ns, c->sn_cols)) {      // one column per lane, the samples split over the two wavefronts of a workgroup
+        const size_t lds = sizeof(double) * sn_cols_lds_doubles(c->sa.uph, c->sa.ns);
+        hipLaunchKernelGGL((snmpc_prologue_cols_kernel<SN_COLS_NSW>), dim3(c->batch), dim3(128), lds, c->stream, c->sa);
+        return;
+    }
     const int v = sn_prologue_variant(c->sa.uph, c->sa.ns);
     const size_t lds = sizeof(double) * sn_prologue_lds_doubles(c->sa.uph, c->sa.ns, v);
     const dim3 g(c->batch), blk(64);

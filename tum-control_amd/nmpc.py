@@ -46,6 +46,17 @@ def model_namespaces(cfg, nx=8, name="pred_dynamic_bicycle_model"):
     return constraints, model
 
 
+def check_costfunction_type(mpc_params):
+    """NMPC_class.py:90-94 picks the OCP by MPC_params['costfunction_type']: 'NONLINEAR_LS' (the shipped YAML,
+    Config/EDGAR/MPC_params.yaml:1) builds NMPC_STM_acados_settings.py -- the formulation this library solves -- anything else
+    the EXTERNAL-cost development variant (NMPC_STM_acados_settings_dev_lonlat.py:90-91, yref fed through set(j, "p", ...),
+    NMPC_class.py:173-180), which is not built. Refuse it loudly rather than solve a different problem than configured."""
+    t = mpc_params.get("costfunction_type", "NONLINEAR_LS")
+    if t != "NONLINEAR_LS":
+        raise NotImplementedError(f"costfunction_type '{t}': only 'NONLINEAR_LS' (NMPC_STM_acados_settings.py) is built; the EXTERNAL-cost "
+                                  "variant (NMPC_STM_acados_settings_dev_lonlat.py) is out of scope")
+
+
 def acados_settings(Tf, N, x0, Q, R, Qe, L1_pen, L2_pen, ax_max_interpolant=None, ay_max_interpolant=None,
                     combined_acc_limits=2, veh_params_file=None, tire_params_file=None,
                     solver_generate_C_code=True, solver_build=True, cfg=None, batch=1, device=0,
@@ -86,6 +97,7 @@ class Nonlinear_Model_Predictive_Controller:
         if sim_main_params:
             sim.update({k: sim_main_params[k] for k in ("Tp", "Ts", "Ts_MPC") if k in sim_main_params})
         self.MPC_params = self.cfg["mpc"]
+        check_costfunction_type(self.MPC_params)
         self.Tp, self.Ts, self.Ts_MPC = sim["Tp"], sim["Ts"], sim["Ts_MPC"]
         self.N = int(self.Tp / self.Ts_MPC)
         m = self.MPC_params

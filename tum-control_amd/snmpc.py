@@ -142,6 +142,8 @@ class Stochastic_Nonlinear_Model_Predictive_Controller:
         if sim_main_params:
             sim.update({k: sim_main_params[k] for k in ("Tp", "Ts", "Ts_MPC") if k in sim_main_params})
         m = self.MPC_params = self.cfg["mpc"]
+        from .nmpc import check_costfunction_type
+        check_costfunction_type(m)
         self.Tp, self.Ts, self.Ts_MPC = sim["Tp"], sim["Ts"], sim["Ts_MPC"]
         self.N = int(self.Tp / self.Ts_MPC)
         self.L1_pen, self.L2_pen = m["L1_pen"], m["L2_pen"]
