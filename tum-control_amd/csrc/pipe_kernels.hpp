@@ -55,14 +55,23 @@ template <int NT_> struct PD {
     static constexpr int I_DV = I_WB;               //   (alias: a v-space vector lives here between a solve and the next publish)
     static constexpr int I_DUMMY = I_SFX + NMAX + 2;
     static constexpr int I_PZ = I_DUMMY + 1;        // 18       quadratic slack penalties Zl, Zu of the 9 (class, row type) pairs
-    static constexpr int I_M = I_PZ + 18;           // LPK      KKT matrix / L D L' factor
-    // five-tile build: the inverse diagonal blocks of the factor as DENSE 16x16 tiles (pitch 17, unit diagonal, zeros above it,
-    // both written once): the substitutions read them without masks, straight into accumulator registers. (Six tiles: no room --
-    // they stay in the strict lower triangle of the packed diagonal tiles and are read with masks.)
+    // five-tile build: the factor is stored as TILES -- the NT (NT - 1) / 2 blocks below the diagonal and the NT inverse diagonal
+    // blocks (unit diagonal, zeros above it, both written once) as 16 x 16 tiles of pitch 16 with the column index XOR-swizzled by
+    // a bit permutation of the row (tile_swz below), the pivots as a vector of their own; L of a diagonal block itself is never
+    // read again and is not stored. Every access pattern of the kernel then hits each LDS bank once: the column stores of a
+    // micro-panel, the operand reads of the left-looking update and the tile operands of the forward substitution (row = lane
+    // column) are conflict-free, the transposed reads of the backward substitution 2-way for two of their four rotations.
+    // (Rounds 2-3 kept the factor packed-triangular by rows: 3-way conflicts on the substitutions' operands, 2-way on the
+    // update's and on the pitch-17 inverse blocks, 850 conflict cycles per iteration; and every row start was a multiply.)
+    // Six tiles (N = 41..48): no room for the inverse blocks as tiles of their own -- the factor stays packed, the inverse blocks
+    // in the strict lower triangle of its diagonal tiles, read with masks.
     static constexpr bool DENSE_W = (NT_ == 5 && IPM_WPS == 1);
-    static constexpr int W_PITCH = 17, W_TILE = 16 * W_PITCH;
-    static constexpr int I_W = I_M + LPK;
-    static constexpr int I_BK = (I_W + (DENSE_W ? NT_ * W_TILE : 0) + 1) & ~1;      // 64 (16-byte aligned): the strip of a micro-panel
+    static constexpr bool TILED = DENSE_W;
+    static constexpr int NOT = NT_ * (NT_ - 1) / 2, W_TILE = 256;
+    static constexpr int I_M = TILED ? ((I_PZ + 18 + 31) & ~31) : I_PZ + 18;      // LPK (packed) | NOT tiles, on a 256-byte boundary
+    static constexpr int I_W = I_M + (TILED ? NOT * 256 : LPK);                    // NT tiles: the inverse diagonal blocks
+    static constexpr int I_D = I_W + (TILED ? NT_ * W_TILE : 0);                   // NVP: the pivots
+    static constexpr int I_BK = (I_D + (TILED ? NVP : 0) + 1) & ~1;      // 64 (16-byte aligned): the strip of a micro-panel
     static constexpr int I_ZERO = I_BK + 64;        // 1        0.0, written once
     // five-tile build: the steering and the box term of every v-space index, expanded per iteration (0 where an index has none):
     // the diagonal tiles gather their terms with one address register and instruction offsets
@@ -72,6 +81,9 @@ template <int NT_> struct PD {
     static_assert(NVP <= 2 * NMAX + 2, "the v-space alias must fit in the box / suffix buffers");
     static_assert(I_LDS_BYTES <= 40 * 1024, "four workgroups per CU");
     static __host__ __device__ constexpr int tidx(int K, int I) { return K * NT_ - K * (K - 1) / 2 + (I - K); }   // K <= I
+    static __host__ __device__ constexpr int offt(int I, int K) { return I * (I - 1) / 2 + K; }                 // tile (I, K), I > K
+    // physical column of (row, col) inside a tile: col ^ tile_swz(row); bits of the row: [3 2 1 0] -> [1 3 2 0]
+    static __host__ __device__ constexpr int tile_swz(int row) { return ((row & 2) << 2) | ((row & 12) >> 1) | (row & 1); }
     static __host__ __device__ constexpr int cidx(int c, int T) { return T * (NC - T - 1) + c; }              // c >= 2T
 };
 static_assert(PD<5>::cidx(9, 4) == chidx(9, 4) && PD<5>::cidx(2, 1) == chidx(2, 1) && PD<5>::NCH == NCHV, "operand layout of the fused kernel's tile count");
@@ -566,7 +578,7 @@ __global__ void __launch_bounds__(64, IPM_WPS) ipm_kernel(const PArgs pa)
     for (int i = lane; i < I_PZ; i += 64) lds[i] = 0.0;
     if (lane == 0) lds[D::I_ZERO] = 0.0;
     if constexpr (D::DENSE_W)
-        for (int i = lane; i < NT * D::W_TILE; i += 64) lds[D::I_W + i] = ((i % D::W_TILE) / D::W_PITCH == (i % D::W_TILE) % D::W_PITCH) ? 1.0 : 0.0;
+        for (int i = lane; i < NT * D::W_TILE; i += 64) { const int row = (i >> 4) & 15; lds[D::I_W + i] = (((i & 15) ^ D::tile_swz(row)) == row) ? 1.0 : 0.0; }
     if (lane < 18) sPZ[lane] = gpen[(lane >> 1) * 4 + 2 + (lane & 1)];
     // the gg rows, MFMA operand layout (30 coalesced loads), resident in registers for the whole solve: the KKT assembly and the
     // row phases take their operands from them. (Only the IPM_WPS = 2 build re-reads them from the workspace behind every
@@ -642,7 +654,7 @@ __global__ void __launch_bounds__(64, IPM_WPS) ipm_kernel(const PArgs pa)
         const int lane = lane_v;
         const int lq = lane >> 4, lc = lane & 15;
         const int trilq = (lq * (lq + 1)) >> 1;
-        const int wl = lq * D::W_PITCH + lc;          // (row lq, column lc) of a dense inverse diagonal block
+
         PIPE_LANE_DEFS
         // ---- row phase A: residual norms, gamma
         double gap;
@@ -743,6 +755,14 @@ __global__ void __launch_bounds__(64, IPM_WPS) ipm_kernel(const PArgs pa)
         int ec0 = (lc & 3) == 0, ec1 = (lc & 3) == 1, ec2 = (lc & 3) == 2, eq0 = lq == 0, eq1 = lq == 1, eq2 = lq == 2;
         const double eu0 = (lq == 0) ? 1.0 : 0.0, eu1 = (lq == 1) ? 1.0 : 0.0, eu2 = (lq == 2) ? 1.0 : 0.0, eu3 = (lq == 3) ? 1.0 : 0.0;
         asm volatile("" : "+v"(ec0), "+v"(ec1), "+v"(ec2), "+v"(eq0), "+v"(eq1), "+v"(eq2));
+        // tiled factor: element (row lc, column 4 q + lq) of a tile, q = 0..3 (operands of the left-looking update, column stores of
+        // the micro-panels), and (row 4 q + lq, column lc) (stores of the inverse diagonal blocks)
+        const int slc = D::tile_swz(lc);
+        int e4[4], w4[4];
+#pragma unroll
+        for (int q4 = 0; q4 < 4; q4++) { e4[q4] = 16 * lc + ((4 * q4 + lq) ^ slc); w4[q4] = 16 * (4 * q4 + lq) + (lc ^ D::tile_swz(4 * q4 + lq)); }
+        double *sT = lds + I_M;
+        (void)e4; (void)w4; (void)sT;
         static_for<0, NT - 1>([&](auto Jc) {      // (a template recursion: the body is far beyond the size up to which `#pragma unroll` is honoured)
             constexpr int J = decltype(Jc)::value;
             const int nd = NT - J;            // tiles below the diagonal one + the identity tile
@@ -785,9 +805,15 @@ __global__ void __launch_bounds__(64, IPM_WPS) ipm_kernel(const PArgs pa)
 #pragma unroll
                 for (int kc = 0; kc < 4; kc++) {
                     const int kk = 16 * K + 4 * kc + lq;
+                    if constexpr (D::TILED) {
+                        const double aJ = -sT[D::offt(J, K) * 256 + e4[kc]] * lds[D::I_D + kk];
+#pragma unroll
+                        for (int I = J; I < NT; I++) T[I] = mfma(aJ, sT[D::offt(I, K) * 256 + e4[kc]], T[I]);
+                    } else {
                     const double aJ = -sM[rb[J] + kk] * sM[lpk_row(16 * K + 4 * kc, lq, trilq) + kk];          // (D of column kk: entry (kk, kk))
 #pragma unroll
                     for (int I = J; I < NT; I++) T[I] = mfma(aJ, sM[rb[I] + kk], T[I]);
+                    }
                 }
             TUM_TICK(10);
             // four 4-column micro-panels. The 4x4 diagonal block sits in column m of the diagonal tile: entry (i, j) on lane
@@ -817,8 +843,8 @@ __global__ void __launch_bounds__(64, IPM_WPS) ipm_kernel(const PArgs pa)
                         Lc[I] = mfma4(pop, T[I][m - 1]);
                     } else if (m > 0 && k < 2 * nd) {
                         const int I = J + 1 + k - nd;
-                        if (I < NT) sM[rb[I] + c0 - 4 + lq] = Lc[I];
-                        else if constexpr (D::DENSE_W) lds[(4 * (m - 1) + lq > lc) ? D::I_W + J * D::W_TILE + 4 * (m - 1) * D::W_PITCH + wl : I_DUMMY] = Lc[NT] * dselp;
+                        if (I < NT) { if constexpr (D::TILED) sT[D::offt(I, J) * 256 + e4[m > 0 ? m - 1 : 0]] = Lc[I]; else sM[rb[I] + c0 - 4 + lq] = Lc[I]; }
+                        else if constexpr (D::DENSE_W) lds[(4 * (m - 1) + lq > lc) ? D::I_W + J * D::W_TILE + w4[m > 0 ? m - 1 : 0] : I_DUMMY] = Lc[NT] * dselp;
                         else sM[(4 * (m - 1) + lq > lc) ? lpk_row(c0 - 4, lq, trilq) + 16 * J + lc : (I_DUMMY - I_M)] = Lc[NT] * dselp;
                         T[I] = mfma(bd, Lc[I], T[I]);
                     }
@@ -838,6 +864,30 @@ __global__ void __launch_bounds__(64, IPM_WPS) ipm_kernel(const PArgs pa)
                 owed(1);
                 owed(2);
                 const double a00 = c01[0], a10 = c01[1], a20 = c23[0], a30 = c23[1], a21 = e23[0], a31 = e23[1], a22 = f23[0], a32 = f23[1];
+#ifdef TUM_EXP_PIV2
+                // (experiment, DESIGN section 7: the four pivots in TWO reciprocal levels instead of four -- 1/d1 = a00 / det(A[0:2,0:2])
+                //  beside 1/d0, 1/d3 = d2 / det of the 2x2 Schur block beside 1/d2)
+                const double d0 = a00, i0 = frcp(d0);
+                const double det2 = fma(a00, a11, -(a10 * a10)), r2 = frcp(det2);
+                owed(3);
+                const double l10 = a10 * i0, l20 = a20 * i0, l30 = a30 * i0;
+                const double i1 = a00 * r2, d1 = det2 * i0;
+                owed(4);
+                const double y21 = a21 - l20 * a10, y31 = a31 - l30 * a10;
+                const double l21 = y21 * i1, l31 = y31 * i1;
+                owed(5);
+                const double d2 = a22 - l20 * a20 - l21 * y21, i2 = frcp(d2);
+                const double y32 = a32 - l30 * a20 - l31 * y21;
+                const double s33 = a33 - l30 * a30 - l31 * y31;
+                owed(6);
+                const double det2b = fma(d2, s33, -(y32 * y32)), r2b = frcp(det2b);
+                const double l32 = y32 * i2;
+                const double X1 = eu1 - l10 * eu0;
+                owed(7);
+                const double i3 = d2 * r2b, d3 = det2b * i2;
+                const double X2 = eu2 - l20 * eu0 - l21 * X1;
+                owed(8);
+#else
                 const double d0 = a00, i0 = frcp(d0);
                 owed(3);
                 const double l10 = a10 * i0, l20 = a20 * i0, l30 = a30 * i0;
@@ -857,6 +907,7 @@ __global__ void __launch_bounds__(64, IPM_WPS) ipm_kernel(const PArgs pa)
                 const double d3 = a33 - l30 * a30 - l31 * y31 - l32 * y32, i3 = frcp(d3);
                 const double X2 = eu2 - l20 * eu0 - l21 * X1;
                 owed(8);
+#endif
                 dmin_hi = min(min(min(dmin_hi, __double2hiint(d0)), min(__double2hiint(d1), __double2hiint(d2))), __double2hiint(d3));
                 const double X3 = eu3 - l30 * eu0 - l31 * X1 - l32 * X2;
                 owed(9);
@@ -871,7 +922,8 @@ __global__ void __launch_bounds__(64, IPM_WPS) ipm_kernel(const PArgs pa)
                 pop = popn;
                 dselp = dsel;
                 Lc[J] = mfma4(pop, T[J][m]);
-                sM[(rel == 0) ? rb[J] + c0 + lq : (I_DUMMY - I_M)] = dsel;
+                if constexpr (D::TILED) lds[(rel == 0) ? D::I_D + c0 + lq : I_DUMMY] = dsel;
+                else sM[(rel == 0) ? rb[J] + c0 + lq : (I_DUMMY - I_M)] = dsel;
                 // (the rank-4 update takes the scaled columns as they are: their rows on and above the 4x4 diagonal block --
                 //  1 and 0 up to rounding -- only reach entries of the diagonal tile in rows or columns that are finished and
                 //  never read again)
@@ -883,8 +935,8 @@ __global__ void __launch_bounds__(64, IPM_WPS) ipm_kernel(const PArgs pa)
             for (int I = J + 1; I <= NT; I++) Lc[I] = mfma4(pop, T[I][3]);
 #pragma unroll
             for (int I = J + 1; I <= NT; I++) {
-                if (I < NT) sM[rb[I] + 16 * J + 12 + lq] = Lc[I];
-                else if constexpr (D::DENSE_W) lds[(12 + lq > lc) ? D::I_W + J * D::W_TILE + 12 * D::W_PITCH + wl : I_DUMMY] = Lc[NT] * dselp;
+                if (I < NT) { if constexpr (D::TILED) sT[D::offt(I, J) * 256 + e4[3]] = Lc[I]; else sM[rb[I] + 16 * J + 12 + lq] = Lc[I]; }
+                else if constexpr (D::DENSE_W) lds[(12 + lq > lc) ? D::I_W + J * D::W_TILE + w4[3] : I_DUMMY] = Lc[NT] * dselp;
                 else sM[(12 + lq > lc) ? lpk_row(16 * J + 12, lq, trilq) + 16 * J + lc : (I_DUMMY - I_M)] = Lc[NT] * dselp;
             }
             wsync();
@@ -991,7 +1043,10 @@ __global__ void __launch_bounds__(64, IPM_WPS) ipm_kernel(const PArgs pa)
                     o[0] = (co[0] > lc) ? l0 : ((co[0] == lc) ? 1.0 : 0.0); o[1] = (co[1] > lc) ? l1 : ((co[1] == lc) ? 1.0 : 0.0);
                     o[2] = (co[2] > lc) ? l2 : ((co[2] == lc) ? 1.0 : 0.0); o[3] = (co[3] > lc) ? l3 : ((co[3] == lc) ? 1.0 : 0.0);
                 };
-                auto l_piv = [&](int J) { return sM[lpk_row(16 * J, edg, tedg) + 16 * J]; };       // D of entry 4 blk + lq of block J
+                auto l_piv = [&](int J) {       // D of entry 4 blk + lq of block J
+                    if constexpr (D::TILED) return lds[D::I_D + 16 * J + edg];
+                    else return sM[lpk_row(16 * J, edg, tedg) + 16 * J];
+                };
                 // The off-diagonal tile operands are only ever read by the matrix instructions, which take their A operand from an
                 // ACCUMULATOR register as well: the reads are issued by hand with an accumulator register as the destination
                 // (`ds_read_b64 a[..]`), so that the 80 registers they occupy during a substitution do not push the row state
@@ -1001,27 +1056,23 @@ __global__ void __launch_bounds__(64, IPM_WPS) ipm_kernel(const PArgs pa)
 #define TUM_LDS_A64(dst, addr, off) asm volatile("ds_read_b64 %0, %1 offset:%2" : "=a"(dst) : "v"(addr), "i"(off))
 #define TUM_LDS_WAIT4(a) asm("s_waitcnt lgkmcnt(0)" : "+a"((a)[0]), "+a"((a)[1]), "+a"((a)[2]), "+a"((a)[3]))
                 const unsigned sMb = (unsigned)(size_t)sM;         // LDS byte address of the factor
-                const unsigned sWb_ = (unsigned)(size_t)(lds + D::I_W);      // ... of the dense inverse diagonal blocks (five tiles)
+                const int slc = D::tile_swz(lc);
                 if constexpr (PRE) {
+                    // tile operands of the forward substitution: entry (row lc, column co[d]) of the tile -- one address per rotation
+                    // for ALL tiles (the tile is an instruction offset), inverse diagonal blocks included
+                    unsigned a[4];
 #pragma unroll
-                    for (int J = 1; J < NT; J++) {
-                        unsigned a[4];
+                    for (int d = 0; d < 4; d++) a[d] = sMb + 8u * (unsigned)(16 * lc + (co[d] ^ slc));
 #pragma unroll
-                        for (int d = 0; d < 4; d++) a[d] = sMb + 8u * (unsigned)(rb[J] + co[d]);
+                    for (int J = 1; J < NT; J++)
 #pragma unroll
                         for (int K = 0; K < J; K++)
 #pragma unroll
-                            for (int d = 0; d < 4; d++) TUM_LDS_A64(Lo[D::tidx(K, J)][d], a[d], 128 * K);
-                    }
-                    {   // inverse diagonal blocks, dense: entry (row lc, column co[d]) of block J
-                        unsigned a[4];
+                            for (int d = 0; d < 4; d++) TUM_LDS_A64(Lo[D::tidx(K, J)][d], a[d], 2048 * D::offt(J, K));
 #pragma unroll
-                        for (int d = 0; d < 4; d++) a[d] = sWb_ + 8u * (unsigned)(lc * D::W_PITCH + co[d]);
+                    for (int J = 0; J < NT; J++)
 #pragma unroll
-                        for (int J = 0; J < NT; J++)
-#pragma unroll
-                            for (int d = 0; d < 4; d++) TUM_LDS_A64(Ld[J][d], a[d], 8 * D::W_TILE * J);
-                    }
+                        for (int d = 0; d < 4; d++) TUM_LDS_A64(Ld[J][d], a[d], 8 * (D::I_W - D::I_M) + 8 * D::W_TILE * J);
 #pragma unroll
                     for (int J = 0; J < NT; J++) Lp[J] = l_piv(J);
 #pragma unroll
@@ -1055,25 +1106,20 @@ __global__ void __launch_bounds__(64, IPM_WPS) ipm_kernel(const PArgs pa)
                     if (J < NT - 1) { vr[J][0] = y; vr[J][1] = row_ror<4>(y); vr[J][2] = row_ror<8>(y); vr[J][3] = row_ror<12>(y); }
                 }
                 if constexpr (PRE) {
+                    // ... of the backward substitution: the transposes, entry (row co[d], column lc)
+                    unsigned a[4];
 #pragma unroll
-                    for (int I = 1; I < NT; I++) {
-                        unsigned a[4];
+                    for (int d = 0; d < 4; d++) a[d] = sMb + 8u * (unsigned)(16 * co[d] + (lc ^ D::tile_swz(co[d])));
 #pragma unroll
-                        for (int d = 0; d < 4; d++) a[d] = sMb + 8u * (unsigned)((int)__umul24(16 * I, co[d]) + tco[d] + lc);
+                    for (int I = 1; I < NT; I++)
 #pragma unroll
                         for (int J = 0; J < I; J++)
 #pragma unroll
-                            for (int d = 0; d < 4; d++) TUM_LDS_A64(Lo[D::tidx(J, I)][d], a[d], 8 * (lpk(16 * I, 0) + 16 * J));
-                    }
-                    {   // the transposes of the inverse diagonal blocks: entry (row co[d], column lc) of block J
-                        unsigned a[4];
+                            for (int d = 0; d < 4; d++) TUM_LDS_A64(Lo[D::tidx(J, I)][d], a[d], 2048 * D::offt(I, J));
 #pragma unroll
-                        for (int d = 0; d < 4; d++) a[d] = sWb_ + 8u * (unsigned)(co[d] * D::W_PITCH + lc);
+                    for (int J = 0; J < NT; J++)
 #pragma unroll
-                        for (int J = 0; J < NT; J++)
-#pragma unroll
-                            for (int d = 0; d < 4; d++) TUM_LDS_A64(Ld[J][d], a[d], 8 * D::W_TILE * J);
-                    }
+                        for (int d = 0; d < 4; d++) TUM_LDS_A64(Ld[J][d], a[d], 8 * (D::I_W - D::I_M) + 8 * D::W_TILE * J);
 #pragma unroll
                     for (int I = 1; I < NT; I++)
 #pragma unroll

@@ -111,8 +111,9 @@ def load_library(path=None):
     L.tum_ocp_set_kernel.argtypes = [vp, cs]
     L.tum_ocp_get_device.argtypes = [vp, cs, vp, ci, ci]
     L.tum_ocp_put_device.argtypes = [vp, cs, vp, ci, ci]
-    L.tum_ocp_results_async.argtypes = [vp, ci]
-    L.tum_ocp_results_wait.argtypes = [vp, ctypes.POINTER(dp), ctypes.POINTER(dp), ctypes.POINTER(dp)]
+    if hasattr(L, "tum_ocp_results_async"):          # (absent from the libraries of earlier revisions that scripts/dev/ab2.py loads beside this one)
+        L.tum_ocp_results_async.argtypes = [vp, ci]
+        L.tum_ocp_results_wait.argtypes = [vp, ctypes.POINTER(dp), ctypes.POINTER(dp), ctypes.POINTER(dp)]
     L.tum_ocp_last_kernel_ms.restype = ctypes.c_double; L.tum_ocp_last_kernel_ms.argtypes = [vp]
     L.tum_ocp_debug_dump.argtypes = [vp, ci, dp, ci]
     L.tum_ocp_profile_phases.argtypes = [vp, ctypes.POINTER(ctypes.c_longlong)]
