@@ -238,8 +238,9 @@ def test_shipped_kernels_resource_budget():
         assert sgpr_spill <= 64, (name, sgpr_spill)
         assert scratch <= 128, (name, scratch)
         assert vgpr + agpr <= 512 and lds <= 40 * 1024, name
-    ipm = kernel("ipm_kernel<false, 5>")
-    assert ipm[2:5] == [0, 0, 0] and ipm[6] == 1, ipm
+    for name in ("ipm_kernel<false, 5, true>", "ipm_kernel<false, 5, false>"):      # headline: the expansion fused into its tail; SNMPC: without
+        ipm = kernel(name)
+        assert ipm[2:5] == [0, 0, 0] and ipm[6] == 1, (name, ipm)
     assert kernel("cond_kernel<5, false>")[6] == 2          # two wavefronts per SIMD
 
 

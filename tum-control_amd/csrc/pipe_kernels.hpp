@@ -383,15 +383,16 @@ __global__ void __launch_bounds__(64, (NT_ == 5) ? 2 : 1) cond_kernel(const PArg
 }
 
 // ---------------------------------------------------------------------------------------------------------------- K4
-template <int NT_, bool SN>
-__global__ void __launch_bounds__(64) expand_kernel(const PArgs pa)
+// The expansion of ONE instance by one wavefront: dx recursion, full step, cost at the new iterate. `lds` holds PD::E_LDS doubles;
+// FUSED: the caller (the tail of ipm_kernel) has put the step of the inputs into lds[E_DV ..] and passes status / slack cost in
+// registers; otherwise both come from the workspace the interior point kernel wrote.
+template <int NT_, bool SN, bool FUSED>
+__device__ __forceinline__ void expand_instance(const PArgs &pa, const int b, double *lds, int status, double slack_cost)
 {
     PD_LOCALS
     constexpr int E_REC = D::E_REC, E_X = D::E_X, E_U = D::E_U, E_DV = D::E_DV;
-    __shared__ __attribute__((aligned(16))) double lds[D::E_LDS];
     const KArgs &ka = pa.ka;
-    const int lane = threadIdx.x, b = blockIdx.x;
-    if (b >= ka.batch) return;
+    const int lane = threadIdx.x;
     const int N = ka.N, nv = 2 * N;
     const double dt = ka.dt;
     double *sRec = lds + E_REC, *sX = lds + E_X, *sU1 = lds + E_U, *sDv = lds + E_DV;
@@ -402,12 +403,12 @@ __global__ void __launch_bounds__(64) expand_kernel(const PArgs pa)
     const double *gyref = ka.yref + (size_t)b * (N + 1) * 6;
     const double *gW = ka.W + (size_t)b * 10;
     const double *gvec = pa.vec + (size_t)b * PVEC;
-    const int status = ka.status[b];
+    if (!FUSED) status = ka.status[b];
     const int uph = SN ? ka.uph : 0;
     const int PP = SN ? sn_pro_pitch(uph) : 64, PSTAGE = 9 * PP;
     const double *gpro = SN ? ka.pro + (size_t)b * uph * PSTAGE : nullptr;
     for (int i = lane; i < (N + 1) * NX; i += 64) sX[i] = gX[i];
-    for (int i = lane; i < NVP; i += 64) { sU1[i] = (i < nv) ? gU[i] : 0.0; sDv[i] = gvec[PV_DV + i]; }
+    for (int i = lane; i < NVP; i += 64) { sU1[i] = (i < nv) ? gU[i] : 0.0; if (!FUSED) sDv[i] = gvec[PV_DV + i]; }
     double pre = (lane < PR_RES) ? grec[lane] : 0.0;
     sRec[lane] = pre;
     if (N > 1) pre = (lane < PR_RES) ? grec[PREC + lane] : 0.0;
@@ -456,7 +457,7 @@ __global__ void __launch_bounds__(64) expand_kernel(const PArgs pa)
         if (lane < NB1) sU1[64 + lane] += sDv[64 + lane];
     }
     wsync();
-    double cl = (lane == 0) ? gvec[PV_SC] : 0.0;      // slack part of the cost (interior point kernel)
+    double cl = (lane == 0) ? (FUSED ? slack_cost : gvec[PV_SC]) : 0.0;      // slack part of the cost (interior point kernel)
     if (lane <= N) {
         double Wd[6], We[4], yr[6];
 #pragma unroll
@@ -481,6 +482,16 @@ __global__ void __launch_bounds__(64) expand_kernel(const PArgs pa)
     for (int i = lane; i < (N + 1) * NX; i += 64) gX[i] = sX[i];
     for (int i = lane; i < nv; i += 64) gU[i] = sU1[i];
     if (lane == 0) ka.cost[b] = cost;
+}
+
+template <int NT_, bool SN>
+__global__ void __launch_bounds__(64) expand_kernel(const PArgs pa)
+{
+    using D = PD<NT_>;
+    __shared__ __attribute__((aligned(16))) double lds[D::E_LDS];
+    const int b = blockIdx.x;
+    if (b >= pa.ka.batch) return;
+    expand_instance<NT_, SN, false>(pa, b, lds, 0, 0.0);
 }
 
 // ---------------------------------------------------------------------------------------------------------------- K3
@@ -547,7 +558,12 @@ __global__ void __launch_bounds__(64) expand_kernel(const PArgs pa)
     _Pragma("unroll") \
     for (int I = 0; I < NT; I++) rb[I] = lpk_row(16 * I, lc, (int)(__umul24(lc, lc + 1) >> 1));
 
-template <bool PROF, int NT_>
+// FUSE: the expansion of the instance (K4) runs as the tail of this kernel, in the LDS the factor no longer needs: one launch
+// less per solve, and neither the step of the inputs nor the status / slack cost make a round trip through the workspace. Used
+// for batches of at most one round of resident wavefronts (the host decides, tum_nmpc.hip: larger batches lose 5 % to the
+// expansion's loads running at this kernel's occupancy); the nominal OCP only -- the coupled SNMPC OCP keeps its own expansion
+// kernel between this kernel and its epilogue
+template <bool PROF, int NT_, bool FUSE = false>
 __global__ void __launch_bounds__(64, IPM_WPS) ipm_kernel(const PArgs pa)
 {
     PD_LOCALS
@@ -1307,17 +1323,27 @@ __global__ void __launch_bounds__(64, IPM_WPS) ipm_kernel(const PArgs pa)
         }
     }
     const double scost = wave_sum(cl);
-    gvec[PV_DV + lane] = v0;
-    if (lane < NB1) gvec[PV_DV + 64 + lane] = v1;
+    if (!FUSE) {
+        gvec[PV_DV + lane] = v0;
+        if (lane < NB1) gvec[PV_DV + 64 + lane] = v1;
+    }
     TUM_TICK(9);
     if (PROF && lane == 0)
         for (int i = 0; i < 12; i++) ka.prof[(size_t)b * 12 + i] = pacc[i];
     if (lane == 0) {
-        gvec[PV_SC] = scost;
+        if (!FUSE) gvec[PV_SC] = scost;
         ka.status[b] = status;
         ka.qp_iter[b] = it;
         ka.qp_status[b] = qp_status;
         ka.res[b * 3 + 0] = res_stat; ka.res[b * 3 + 1] = res_ineq; ka.res[b * 3 + 2] = res_comp;
+    }
+    if constexpr (FUSE) {
+        static_assert(D::E_LDS <= D::I_LDS - D::I_M, "the expansion works in the LDS of the factor");
+        double *el = lds + D::I_M;
+        wsync();
+        el[D::E_DV + lane] = v0;
+        if (lane < NB1) el[D::E_DV + 64 + lane] = v1;
+        expand_instance<NT_, false, true>(pa, b, el, status, scost);
     }
 }
 

@@ -202,7 +202,9 @@ extern "C" tum_ocp *tum_ocp_create(const tum_ocp_desc *desc)
 
     if (hipFuncSetAttribute((const void *)ipm_kernel<false, 5>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024) != hipSuccess ||
         hipFuncSetAttribute((const void *)ipm_kernel<true, 5>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024) != hipSuccess ||
-        hipFuncSetAttribute((const void *)ipm_kernel<false, 6>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024) != hipSuccess
+        hipFuncSetAttribute((const void *)ipm_kernel<false, 6>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024) != hipSuccess ||
+        hipFuncSetAttribute((const void *)ipm_kernel<false, 5, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024) != hipSuccess ||
+        hipFuncSetAttribute((const void *)ipm_kernel<false, 6, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024) != hipSuccess
 #ifdef TUM_DEV_KERNELS
         || hipFuncSetAttribute((const void *)ipm4_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024) != hipSuccess ||
         hipFuncSetAttribute((const void *)ipm4_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024) != hipSuccess ||
@@ -701,6 +703,12 @@ static int launch_pipeline(tum_ocp *c, bool events)
         hipLaunchKernelGGL(lin_kernel<true>, dim3((unsigned)((items + 63) / 64)), dim3(64), 0, c->stream, pa);
     } else hipLaunchKernelGGL(lin_kernel<false>, dim3((unsigned)((items + 63) / 64)), dim3(64), 0, c->stream, pa);
     // (development aid: a larger LDS request lowers the number of OCPs that share a CU)
+    // The expansion as the tail of the interior point kernel pays where a batch is at most one round of resident wavefronts (one
+    // launch less: 0.424 against 0.432 ms per solve() call at 26 instances, 0.457 against 0.469 at 1024); beyond that its
+    // loads run at the interior point kernel's occupancy -- one wavefront per SIMD, four OCPs per CU -- and hold that slot:
+    // 3.72 against 3.96 M solves/s on config 2 (three streams). TUM_FUSED_EXPAND=0 / 1 forces it off / on (development aid).
+    static const int fuse_env = [] { const char *e = getenv("TUM_FUSED_EXPAND"); return e ? atoi(e) : -1; }();
+    const bool no_fuse = fuse_env == 0 || (fuse_env < 0 && c->batch > 1024);
     static const int lds_req = [] { const char *e = getenv("TUM_IPM_LDS"); const int v = e ? atoi(e) : 0; return (v > 0 && v <= 64 * 1024) ? v : 0; }();
     auto rest = [&](auto ntc) {
         constexpr int NTv = decltype(ntc)::value;
@@ -708,22 +716,29 @@ static int launch_pipeline(tum_ocp *c, bool events)
         if (c->sn) hipLaunchKernelGGL((cond_kernel<NTv, true>), dim3(c->batch), dim3(64), 0, c->stream, pa);
         else hipLaunchKernelGGL((cond_kernel<NTv, false>), dim3(c->batch), dim3(64), 0, c->stream, pa);
         if (events) (void)hipEventRecord(c->evi0, c->stream);
+        bool expanded = false;
 #ifdef TUM_DEV_KERNELS
         if (prof && c->kmode == 3 && NTv == 5) hipLaunchKernelGGL((ipm4_kernel<true>), dim3(c->batch), dim3(256), I4::BYTES, c->stream, pa);
         else if (!prof && c->kmode == 3 && NTv == 5) hipLaunchKernelGGL((ipm4_kernel<false>), dim3(c->batch), dim3(256), I4::BYTES, c->stream, pa);
         else
 #endif
+        // the nominal OCP: the expansion runs as the tail of the interior point kernel (ipm_kernel<., ., true>); the instrumented
+        // instantiation and the coupled SNMPC OCP keep the expansion kernel
         if constexpr (NTv == 5) {      // (the instrumented instantiation exists for the five-tile build only)
             if (prof) hipLaunchKernelGGL((ipm_kernel<true, 5>), dim3(c->batch), dim3(64), ipm_lds, c->stream, pa);
-            else hipLaunchKernelGGL((ipm_kernel<false, 5>), dim3(c->batch), dim3(64), ipm_lds, c->stream, pa);
-        } else hipLaunchKernelGGL((ipm_kernel<false, NTv>), dim3(c->batch), dim3(64), ipm_lds, c->stream, pa);
+            else if (c->sn || no_fuse) hipLaunchKernelGGL((ipm_kernel<false, 5>), dim3(c->batch), dim3(64), ipm_lds, c->stream, pa);
+            else { hipLaunchKernelGGL((ipm_kernel<false, 5, true>), dim3(c->batch), dim3(64), ipm_lds, c->stream, pa); expanded = true; }
+        } else {
+            if (c->sn || no_fuse) hipLaunchKernelGGL((ipm_kernel<false, NTv>), dim3(c->batch), dim3(64), ipm_lds, c->stream, pa);
+            else { hipLaunchKernelGGL((ipm_kernel<false, NTv, true>), dim3(c->batch), dim3(64), ipm_lds, c->stream, pa); expanded = true; }
+        }
         if (events) (void)hipEventRecord(c->evi1, c->stream);
         if (c->sn) {
             hipLaunchKernelGGL((expand_kernel<NTv, true>), dim3(c->batch), dim3(64), 0, c->stream, pa);
             SnArgs sa = c->sa;
             sa.dv = c->dvec + PD<NTv>::PV_DV; sa.dv_stride = PD<NTv>::PVEC;
             hipLaunchKernelGGL(snmpc_epilogue_kernel, dim3(c->batch), dim3(64), 0, c->stream, sa); c->xs_lazy = true;
-        } else hipLaunchKernelGGL((expand_kernel<NTv, false>), dim3(c->batch), dim3(64), 0, c->stream, pa);
+        } else if (!expanded) hipLaunchKernelGGL((expand_kernel<NTv, false>), dim3(c->batch), dim3(64), 0, c->stream, pa);
     };
     if (c->N > NMAX) rest(std::integral_constant<int, 6>()); else rest(std::integral_constant<int, 5>());
     return 0;
