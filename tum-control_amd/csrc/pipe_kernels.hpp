@@ -421,15 +421,10 @@ __device__ __forceinline__ void expand_instance(const PArgs &pa, const int b, do
         double dxi = gx0r - sX[ri];
         wsync();
         if (lane < 8) sX[lane] += dxi;
-        if (SN) {
-            // stages 1..uph: dx_s = G_nom,s dU + g_nom,s straight from the prologue's matrices (2s columns each)
-            for (int s = 1; s <= uph; s++) {
-                const double *pg = gpro + (size_t)(s - 1) * PSTAGE + ri * PP;
-                double acc = pg[2 * uph];
-                for (int j = 0; j < 2 * s; j++) acc += pg[j] * sDv[j];
-                dxi = acc;
-                if (lane < 8) sX[s * NX + lane] += dxi;
-            }
+        if (SN && uph > 0) {
+            // stages 1..uph of the nominal copy have been stepped by the epilogue kernel (PCE mean of the stepped sample copies),
+            // which runs in front of this one; the recursion continues from its step of stage uph
+            dxi = gvec[PV_SC + 8 + ri];
         }
         for (int k = 0; k < N; k++) {
             const double *rec = sRec + (k & 1) * PREC;

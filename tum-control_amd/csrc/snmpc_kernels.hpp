@@ -52,6 +52,8 @@ struct SnArgs {
     int dv_stride;
     const int *status;        // [b]
     int *xs_dirty;            // [b] 1: the sample copies of the stages > uph wait to be frozen at the value of stage uph (snmpc_freeze_kernel)
+    double *Xn;               // pipeline only (else null): the epilogue also writes the NOMINAL copy of the stages 1..uph, [b][(N+1)*8]
+    double *dxu;              // ... and the nominal step of stage uph, 8 doubles per instance at stride dv_stride (the expansion kernel starts from it)
     double *dbg;              // development aid: phase cycle counters of instance 0 (or null)
 };
 
@@ -595,6 +597,11 @@ __global__ void __launch_bounds__(128, 2) snmpc_prologue_cols_kernel(const SnArg
 // instance and solve (N = 40, uph = 5, ten samples; 92 MB per 4096-instance solve). The instance is flagged instead and
 // snmpc_freeze_kernel brings the stages > uph up to date when somebody asks for them (get / set of a stacked state of
 // such a stage, a change of uph).
+// Pipeline (sa.Xn set): the NOMINAL copy of the stages 1..uph is written here as well. In the stacked model it is the PCE mean of
+// the sample copies (x0+ = sum_i A[0, i] x_i+, pred_model_dynamic_disc.py:208-210), and the linearised step keeps that:
+// X_nom,s + dx_nom,s = sum_i a_i (X^(i)_s + dx^(i)_s) -- a 16-lane sum of what the lanes have just computed. Round 3's expansion
+// kernel formed the same step as G_nom,s dU + g_nom,s from the prologue's matrices: 2 s products per row and stage on eight
+// lanes and 200 KB of hand-over buffer read again per instance at UPH = Tp (0.21 ms per 4096 instances, now gone).
 __global__ void __launch_bounds__(64) snmpc_epilogue_kernel(const SnArgs sa)
 {
     // the ns records of a stage are contiguous in ws2: all 64 lanes fetch them (coalesced, one stage ahead) and the sample
@@ -607,6 +614,8 @@ __global__ void __launch_bounds__(64) snmpc_epilogue_kernel(const SnArgs sa)
     const bool act = lane < ns;
     const int i = act ? lane : 0;
     double *gXS = sa.XS + (size_t)b * (N + 1) * ns * NX;
+    double *gXn = sa.Xn ? sa.Xn + (size_t)b * (N + 1) * NX : nullptr;
+    const double ai = (sa.Xn && act) ? sa.Apce[i] : 0.0;                 // row 0 of A_pce: the PCE mean
     const double *ws2 = sa.ws2 + (size_t)b * uph * ns * ABS;
     const double *dv = sa.dv + (size_t)b * sa.dv_stride;
     const int nrec = ns * ABS;
@@ -621,6 +630,10 @@ __global__ void __launch_bounds__(64) snmpc_epilogue_kernel(const SnArgs sa)
         dx[r] = sa.xs0[((size_t)b * ns + i) * NX + r] - x;
         if (act) gXS[(size_t)i * NX + r] = x + dx[r];
     }
+    // the old sample copies of the next stage, requested one stage ahead like the records
+    double xo[8];
+#pragma unroll
+    for (int r = 0; r < 8; r++) xo[r] = (uph > 0) ? gXS[((size_t)1 * ns + i) * NX + r] : 0.0;
     for (int k = 0; k < uph; k++) {
         wsync();
 #pragma unroll
@@ -639,9 +652,36 @@ __global__ void __launch_bounds__(64) snmpc_epilogue_kernel(const SnArgs sa)
 #pragma unroll
         for (int r = 0; r < 8; r++) dx[r] += rec[44 + r];
         double *xq = gXS + ((size_t)(k + 1) * ns + i) * NX;
+        double xn[8];
+#pragma unroll
+        for (int r = 0; r < 8; r++) xn[r] = xo[r] + dx[r];
+        if (k + 2 <= uph) {
+#pragma unroll
+            for (int r = 0; r < 8; r++) xo[r] = gXS[((size_t)(k + 2) * ns + i) * NX + r];
+        }
         if (act) {
 #pragma unroll
-            for (int r = 0; r < 8; r++) xq[r] += dx[r];
+            for (int r = 0; r < 8; r++) xq[r] = xn[r];
+        }
+        if (gXn) {
+            // PCE mean of the new sample copies: sum over the (at most 16) sample lanes of DPP row 0, total on lane 15
+            double m[8];
+#pragma unroll
+            for (int r = 0; r < 8; r++) {
+                double v = ai * xn[r];
+                v += row_shr<1>(v); v += row_shr<2>(v); v += row_shr<4>(v); v += row_shr<8>(v);
+                m[r] = v;
+            }
+            if (lane == 15) {
+                double *xd = gXn + (size_t)(k + 1) * NX;
+                if (k + 1 == uph) {
+                    double *du = sa.dxu + (size_t)b * sa.dv_stride;
+#pragma unroll
+                    for (int r = 0; r < 8; r++) du[r] = m[r] - xd[r];
+                }
+#pragma unroll
+                for (int r = 0; r < 8; r++) xd[r] = m[r];
+            }
         }
     }
 }

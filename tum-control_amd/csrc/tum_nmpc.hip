@@ -734,10 +734,13 @@ static int launch_pipeline(tum_ocp *c, bool events)
         }
         if (events) (void)hipEventRecord(c->evi1, c->stream);
         if (c->sn) {
-            hipLaunchKernelGGL((expand_kernel<NTv, true>), dim3(c->batch), dim3(64), 0, c->stream, pa);
+            // the epilogue steps the sample copies AND the nominal copy of the stages 1..uph (their PCE mean); the expansion
+            // kernel behind it takes the nominal recursion from stage uph to the end of the horizon and evaluates the cost
             SnArgs sa = c->sa;
             sa.dv = c->dvec + PD<NTv>::PV_DV; sa.dv_stride = PD<NTv>::PVEC;
+            sa.Xn = c->dX; sa.dxu = c->dvec + PD<NTv>::PV_SC + 8;
             hipLaunchKernelGGL(snmpc_epilogue_kernel, dim3(c->batch), dim3(64), 0, c->stream, sa); c->xs_lazy = true;
+            hipLaunchKernelGGL((expand_kernel<NTv, true>), dim3(c->batch), dim3(64), 0, c->stream, pa);
         } else if (!expanded) hipLaunchKernelGGL((expand_kernel<NTv, false>), dim3(c->batch), dim3(64), 0, c->stream, pa);
     };
     if (c->N > NMAX) rest(std::integral_constant<int, 6>()); else rest(std::integral_constant<int, 5>());
