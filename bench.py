@@ -47,7 +47,7 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBPS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 FP64_PEAK_TFLOPS = 78.6      # MI355X FP64 vector = matrix peak (spec); v_mfma_f64_16x16x4 probe: 70.2 measured
-NB_FRESH = 4                 # resident batches rotated by the timed loop
+NB_FRESH = 4                 # resident batches rotated by the timed loop (one more when that shares a factor with the stream count)
 
 
 def algorithmic_bytes(N, warm=False, per_instance_yref=True):
@@ -211,7 +211,14 @@ class Job:
         self.global_batch = groups_total * gsz
         gen = workload or (lambda k: config_groups(cid, self.g_lo, self.g_hi, groups_total, N=N, dt=0.08, variant=k))
         # batch 0 = the configuration as BASELINE defines it, batches 1.. = fresh variants of it (other poses, other random streams)
-        self.host = [gen(k)[:2] for k in range(NB_FRESH + 1)]
+        # step k runs batch k mod nb on capsule k mod S: the two periods must be coprime, or a capsule would meet the same batch
+        # again and again (four batches over four -- or two -- capsules: every solve would be a REPEATED batch with exact
+        # longest-first history, not a fresh one)
+        S_ = max(1, int(n_slots if n_slots is not None else args.streams))
+        self.nb = NB_FRESH
+        while np.gcd(self.nb, S_) != 1:
+            self.nb += 1
+        self.host = [gen(k)[:2] for k in range(self.nb + 1)]
         x0, yref = self.host[0]
         assert len(x0) == B
         self.nmom = 16 if cid == 3 else 0
@@ -283,7 +290,7 @@ class Job:
     def _step(self, slot, s, marks, fresh):
         cid, slab = self.cid, self.slabs[slot]
         if fresh is not None:
-            k = fresh % NB_FRESH
+            k = fresh % self.nb
             s.put_device("x0", self.dx0[k].data_ptr()); s.put_device("yref", self.dyr[k].data_ptr())
         if cid == 5:
             s.bounds_restore()
@@ -472,7 +479,7 @@ def run(args, torch, dist, dev, world, rank, local_rank, solver_factory, workloa
         "vs_baseline": None, "dtype": "f64", "data": "synthetic",
         "config": {"workload": f"BASELINE configs[{cid - 1}]: {C['name']}, {C['track']} reftraj, cold-start SQP-RTI, one wavefront per OCP; "
                                + ("the same batch every step (--same-batch)" if args.same_batch else
-                                  f"{NB_FRESH} differently seeded batches resident in HBM, rotated one per step (fresh batch every step)"),
+                                  f"{job.nb} differently seeded batches resident in HBM, rotated one per step over {S} capsules (coprime periods: a capsule never meets the batch it solved last)"),
                    "N": N, "nx": 8, "nu": 2, "nsub": 3, "batch_per_gpu": B, "global_batch": job.global_batch,
                    "scenario_group": gsz, "groups_per_gpu": P, "solves_per_step": spp,
                    "streams": S,

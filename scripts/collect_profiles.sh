@@ -27,10 +27,13 @@ for c in 3 4 5; do $T python bench.py --config $c --steps 10 2>/dev/null < /dev/
 for b in 1 512 4096 16384; do B=$b $T python scripts/pipe_check.py fused pipeline pipeline4 2>&1 < /dev/null | grep -E "^fused|^pipeline" | sed "s/^/batch $b: /" >> $OUT/kernel_variants.txt; done
 for S in 1 2 3 4 6; do $T python bench.py --steps 20 --warmup 3 --streams $S --no-cpu-baseline --no-schedule-legs 2>/dev/null < /dev/null | grep metric | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('streams',d['config']['streams'],'value %.3f M solves/s'%(d['value']/1e6),'ms/step %.3f'%d['ms_per_step'])" >> $OUT/streams.txt; done
 $T python scripts/snmpc_bench.py 2>&1 < /dev/null | grep -v amdgpu.ids > $OUT/snmpc_bench.txt
-$T python scripts/pcie_inclusive.py 2>&1 < /dev/null | grep PCIe > $OUT/pcie.txt
+for v in prologue-cols prologue-passes; do echo "== set_kernel(\"$v\") on every capsule (default: passes below 20 propagation stages, cols from there on)" >> $OUT/snmpc_prologue_variants.txt; SN_PROLOGUE=$v $T python scripts/snmpc_bench.py 2>&1 < /dev/null | grep "^coupled" >> $OUT/snmpc_prologue_variants.txt; done
+$T rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/sn38 -o s -- python scripts/dev/sn_uph_profile.py 38 38 > /dev/null 2>&1 < /dev/null
+$T rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/sn05 -o s -- python scripts/dev/sn_uph_profile.py 38 5 > /dev/null 2>&1 < /dev/null
+$T python scripts/pcie_inclusive.py 1 3 2>&1 < /dev/null | grep -v amdgpu.ids > $OUT/pcie.txt
 $T python scripts/closed_loop_variants.py 2>&1 < /dev/null | grep -v amdgpu.ids > $OUT/closed_loops.txt
-$T python scripts/dev/ab2.py exp_libs/lib_3bc4d34.so shipped 2>&1 < /dev/null | grep -v amdgpu.ids > $OUT/ab_round3_instruction_work.txt
-W=$(ls exp_libs/lib_*_wps2.so 2>/dev/null | head -1)      # TAG=wps2 scripts/dev/build_exp_lib.sh HEAD -DIPM_WPS=2
-[ -n "$W" ] && $T python scripts/dev/ab2.py shipped $W 2>&1 < /dev/null | grep -v amdgpu.ids > $OUT/ipm_occupancy.txt
+# round 4: the library of commit f5e2d65 (packed-triangular factor; scripts/dev/build_exp_lib.sh f5e2d65) against the shipped one (tiled factor)
+[ -f exp_libs/lib_f5e2d65.so ] && $T python scripts/dev/ab2.py exp_libs/lib_f5e2d65.so shipped 2>&1 < /dev/null | grep -v amdgpu.ids > $OUT/ab_tiled_factor_final.txt
+for f in 0 1; do echo "TUM_FUSED_EXPAND=$f" >> $OUT/fused_expand.txt; TUM_FUSED_EXPAND=$f $T python scripts/probes/solve_wall_time.py 2>&1 < /dev/null | grep pipeline >> $OUT/fused_expand.txt; TUM_FUSED_EXPAND=$f $T python bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-schedule-legs --no-host-legs 2>/dev/null < /dev/null | grep metric | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('  config 2, three streams: value %.3f M solves/s'%(d['value']/1e6))" >> $OUT/fused_expand.txt; done
 $T python scripts/dev/ipm4_prof.py 4096 2>&1 < /dev/null | grep -v amdgpu.ids > $OUT/ipm4_phases.txt
 head -8 $OUT/stats/s_kernel_stats.csv | cut -c1-150; cut -c1-300 $OUT/bench.json

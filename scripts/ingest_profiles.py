@@ -8,7 +8,10 @@ if os.path.exists(f"{src}/stats3/s_kernel_stats.csv"):
     shutil.copy(f"{src}/stats3/s_kernel_stats.csv", f"{dst}/{tag}_kernel_stats_3streams.csv")      # the default command
 if os.path.exists(f"{src}/stats_rep/s_kernel_stats.csv"):
     shutil.copy(f"{src}/stats_rep/s_kernel_stats.csv", f"{dst}/{tag}_kernel_stats_repeated.csv")      # bench.py --streams 1 --same-batch
-for f in ("ab_round3_instruction_work.txt", "phase_cycles.txt", "configs.jsonl", "kernel_variants.txt", "ipm_occupancy.txt", "snmpc_bench.txt", "pcie.txt", "streams.txt",
+for d, n in (("sn38", "snmpc_uph38_kernel_stats.csv"), ("sn05", "snmpc_uph5_kernel_stats.csv")):
+    if os.path.exists(f"{src}/{d}/s_kernel_stats.csv"):
+        shutil.copy(f"{src}/{d}/s_kernel_stats.csv", f"{dst}/{tag}_{n}")
+for f in ("ab_round3_instruction_work.txt", "ab_tiled_factor_final.txt", "fused_expand.txt", "snmpc_prologue_variants.txt", "phase_cycles.txt", "configs.jsonl", "kernel_variants.txt", "ipm_occupancy.txt", "snmpc_bench.txt", "pcie.txt", "streams.txt",
           "closed_loops.txt", "ipm4_phases.txt"):
     if os.path.exists(f"{src}/{f}"):
         shutil.copy(f"{src}/{f}", f"{dst}/{tag}_{f}")

@@ -7,13 +7,15 @@
 //   K2  cond_kernel     one wavefront per OCP: column recursion G_{k+1} = A_k G_k, Gauss-Newton SYRK on the matrix cores
 //                       (15 register tiles), gg rows; hands H (tiles), C (MFMA operand layout), q, d to the workspace.
 //   K3  ipm_kernel      one wavefront per OCP with the whole register file (450 of 512 registers, four OCPs per CU): LDS holds
-//                       the factor of the KKT matrix (26 KiB) and, in the five-tile build, its inverse diagonal blocks as dense
-//                       tiles (38.8 KiB in all); the gg rows live in registers in MFMA operand layout, H is streamed tile by
-//                       tile from the workspace (L2); the tile operands of the substitutions are read from LDS straight into
-//                       accumulator registers. (Built with -DIPM_WPS=2 the same source is bounded to 256 registers, two
-//                       wavefronts per SIMD: measured slower)
+//                       the factor of the KKT matrix -- five-tile build: as XOR-swizzled 16 x 16 tiles, the blocks below the
+//                       diagonal, the inverse diagonal blocks and the pivot vector, 31 KiB (34 KiB in all); six tiles: packed by
+//                       rows, 26 KiB -- the gg rows live in registers in MFMA operand layout, H is streamed tile by tile from
+//                       the workspace (L2); the tile operands of the substitutions are read from LDS straight into accumulator
+//                       registers. (Built with -DIPM_WPS=2 the same source is bounded to 256 registers, two wavefronts per
+//                       SIMD: measured slower)
 //   K3' ipm4_kernel     (ipm4_kernel.hpp) the same method with FOUR wavefronts per OCP, each below 128 registers.
-//   K4  expand_kernel   one wavefront per OCP: dx recursion, full step, cost at the new iterate.
+//   K4  expand_kernel   one wavefront per OCP: dx recursion, full step, cost at the new iterate. For batches of at most one
+//                       round of resident wavefronts the nominal OCP runs it as the tail of K3 instead (ipm_kernel<., ., true>).
 //
 // Workspace per instance (HBM/L2): stage records 41 x 64 doubles, H 15 x 64 x 4, C 30 x 64, q | d | dv 3 x 80.
 // Reference semantics as in nmpc_kernel.hpp; the arithmetic of every phase is the fused kernel's.

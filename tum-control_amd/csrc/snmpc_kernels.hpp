@@ -1,4 +1,4 @@
-// snmpc_kernels.hpp -- the coupled SNMPC OCP around the fused SQP-RTI kernel.
+// snmpc_kernels.hpp -- the coupled SNMPC OCP around the SQP-RTI pipeline of pipe_kernels.hpp.
 //
 // Reference: Stochastic_NMPC/pred_model_dynamic_disc.py:121-220 (DISCRETE dynamics of the stacked state: nominal copy +
 // n_s sample copies under ONE input), Stochastic_NMPC/SNMPC_acados_settings.py:57-194 (cost on the nominal copy, chance
@@ -9,18 +9,21 @@
 //   * the stage matrix is block diagonal over the sample copies; the nominal copy of stage s <= uph is the PCE mean of
 //     the sample copies (row 0 of A_pce), so  G_nom,s = sum_i a_i G^(i)_s  and the full-condensed QP keeps the shape
 //     of the nominal one (2N variables, the same 3 soft rows per stage);
-//   * from stage uph on the samples are frozen and never read again: the nominal recursion of the fused kernel takes
+//   * from stage uph on the samples are frozen and never read again: the nominal recursion of the condensing kernel takes
 //     over from G_nom,uph;
 //   * at stage s the sample matrices G^(i)_s only have 2s <= 2 uph non-zero columns.
-// So the solve is these launches on one stream:
-//   snmpc_lin_kernel        sample stages: one RK4 step with sensitivities and the gg value / gradient per (instance, stage,
-//                           sample) item, lane = item (full wavefronts; the register-heavy part, one wavefront per SIMD)
-//   snmpc_prologue_kernel   one wavefront per OCP, register-light (several wavefronts per SIMD): PCE weights of the chance
-//                           rows, column recursions of all samples (lane = (sample, column slot)), hands G_nom,s, g_nom,s
-//                           and the chance-constraint rows of the stages 1..uph to the fused kernel through `pro`
-//   nmpc_rti_kernel<.,true> the fused kernel: cost rows / gg rows / Hessian of stages <= uph from `pro`, nominal recursion
-//                           from stage uph, interior point, expansion of the nominal copy
-//   snmpc_epilogue_kernel   full step of the sample copies (lane = sample)
+// So the solve is these launches on one stream (shipped library: the pipeline; the development build can put round 1's fused
+// kernel nmpc_rti_kernel<., true> in the place of the four pipeline kernels):
+//   snmpc_lin_kernel             sample stages: one RK4 step with sensitivities and the gg value / gradient per (instance, stage,
+//                                sample) item, lane = item (full wavefronts; the register-heavy part, one wavefront per SIMD)
+//   snmpc_prologue_kernel<NPM>   one wavefront per OCP: PCE weights of the chance rows, column recursions of all samples
+//   / snmpc_prologue_cols_kernel (lane = (sample, column slot) with passes / lane = column, round 4); hands G_nom,s, g_nom,s and the
+//                                chance-constraint rows of the stages 1..uph to the condensing kernel through `pro`
+//   lin_kernel<true>, cond_kernel<., true>, ipm_kernel   cost rows / gg rows / Hessian of stages <= uph from `pro`, nominal recursion
+//                                from stage uph, interior point
+//   snmpc_epilogue_kernel        full step of the sample copies (lane = sample) and, as their PCE mean, of the nominal copy of the
+//                                stages 1..uph
+//   expand_kernel<., true>       the nominal recursion from stage uph to the end of the horizon, cost at the new iterate
 #pragma once
 #include "nmpc_device.hpp"
 
