@@ -336,6 +336,15 @@ def test_gpu_coupled_snmpc_pipeline_cols_prologue_vs_oracle(golden_dir, N, uph):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("N,uph", [(38, 5), (38, 15), (12, 12), (40, 1), (44, 5), (40, 24), (40, 33), (38, 38), (48, 48), (48, 32)])
+def test_gpu_coupled_snmpc_pipeline_mfma_prologue_vs_oracle(golden_dir, N, uph):
+    """... and the matrix-core prologue (column recursions as v_mfma_f64_4x4x4_4b products over the live column groups) on
+    every propagation horizon: one and several column groups, the second phase for the columns beyond 63 (uph 32 is its first
+    stage, 33 / 38 / 48 run it for 2 / 7 / 17 stages)"""
+    _gpu_vs_oracle(golden_dir, N, uph, poses=[0, 26, 30], kernel="pipeline", prologue="prologue-mfma")
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("N,uph,lib", [(12, 5, "shipped"), (12, 12, "shipped"), (40, 9, "shipped"), (40, 15, "shipped"), (40, 24, "shipped"), (40, 31, "shipped"), (40, 36, "shipped"),
                                        (38, 38, "shipped"), (12, 5, "dev"), (40, 9, "dev"), (40, 31, "dev")])
 def test_gpu_coupled_snmpc_condensed_qp(golden_dir, N, uph, lib):
@@ -392,7 +401,10 @@ def test_gpu_coupled_snmpc_condensed_qp(golden_dir, N, uph, lib):
                                                  (8, 6, 40, 12, "prologue-passes"), (8, 6, 40, 24, "prologue-passes"), (8, 6, 38, 38, "prologue-passes"),
                                                  (9, 6, 40, 24, "prologue-passes"), (7, 4, 40, 11, "prologue-passes"), (3, 2, 40, 31, "prologue-passes"),
                                                  (8, 6, 38, 38, None), (9, 6, 40, 24, None), (6, 3, 40, 36, None), (2, 2, 40, 40, None),
-                                                 (7, 4, 40, 11, "prologue-cols"), (1, 1, 10, 3, "prologue-cols"), (10, 10, 40, 9, "prologue-cols")])
+                                                 (7, 4, 40, 11, "prologue-cols"), (1, 1, 10, 3, "prologue-cols"), (10, 10, 40, 9, "prologue-cols"),
+                                                 (7, 4, 40, 11, "prologue-mfma"), (1, 1, 10, 3, "prologue-mfma"), (10, 10, 40, 9, "prologue-mfma"), (8, 6, 38, 38, "prologue-mfma"),
+                                                 (9, 6, 40, 24, "prologue-mfma"), (6, 3, 40, 36, "prologue-mfma"), (2, 2, 40, 40, "prologue-mfma"), (3, 2, 40, 31, "prologue-mfma"),
+                                                 (5, 4, 40, 17, "prologue-mfma")])
 def test_gpu_coupled_snmpc_other_sample_counts(golden_dir, ns, L, N, uph, prologue):
     """sample counts / PCE sizes other than the shipped 10 x 10 (any L x n_s matrix defines a valid OCP): condensed QP and
     one full step of every copy against the oracle. Up to ten samples with 20 propagation stages or more -- or

@@ -109,15 +109,21 @@ __host__ inline int sn_prologue_variant(int uph, int ns)
 // kernels waste less); the variants above serve everything else and are the second implementation the tests hold the new one
 // against (TUM_SN_PROLOGUE = 0 | 6 | 9 | 13 | 17 forces them, "cols" forces the new one wherever the sample count allows;
 // per capsule: tum_ocp_set_kernel "prologue-passes" / "prologue-cols")
+#ifndef SN_PROLOGUE_DEFAULT
+#define SN_PROLOGUE_DEFAULT(uph) (((uph) >= SN_COLS_UPH) ? 1 : 0)
+#endif
 constexpr int SN_COLS_NS = 10;          // = 2 SN_COLS_NSW: five samples per wavefront
 constexpr int SN_COLS_UPH = 20;
-__host__ inline bool sn_prologue_cols(int uph, int ns, int want = -1)
+// which prologue runs: 0 column slots and passes, 1 one column per lane, 2 the matrix-core kernel. `want` < 0: the library's choice.
+__host__ inline int sn_prologue_kind(int uph, int ns, int want = -1)
 {
-    static const int forced = [] { const char *e = getenv("TUM_SN_PROLOGUE"); return !e ? -1 : (e[0] == 'c' ? 1 : 0); }();
+    static const int forced = [] { const char *e = getenv("TUM_SN_PROLOGUE"); return !e ? -1 : (e[0] == 'c' ? 1 : e[0] == 'm' ? 2 : 0); }();
     const int f = want >= 0 ? want : forced;
-    if (ns > SN_COLS_NS || f == 0) return false;
-    return f == 1 || uph >= SN_COLS_UPH;
+    if (ns > SN_COLS_NS || f == 0) return 0;
+    if (f > 0) return f;
+    return SN_PROLOGUE_DEFAULT(uph);
 }
+__host__ inline bool sn_prologue_cols(int uph, int ns, int want = -1) { return sn_prologue_kind(uph, ns, want) == 1; }
 
 // K-S1: linearisation of the sample stages. lane = (instance, stage k < uph, sample) item; the 64 records of a wavefront are
 // one contiguous block of ws2 and go out transposed through LDS (416 contiguous bytes per store instruction instead of 64
@@ -590,6 +596,233 @@ __global__ void __launch_bounds__(128, 2) snmpc_prologue_cols_kernel(const SnArg
                 pg[8 * PP + colo] = M[8] + sX[8 * 64 + lane] + ((isg && s < uph) ? sHval[s] : 0.0);
             }
             if (k + 1 < uph) stash(k + 1);
+        }
+    }
+}
+
+// ---- the prologue on the matrix cores (round 4): the column recursions G^(i) <- A^(i) G^(i) as v_mfma_f64_4x4x4_4b products.
+// The instruction computes four independent 4 x 4 x 4 products, one per 4-lane block of a DPP row: lane = 16 q + 4 blk + x,
+// A_blk[i][k] on lane (q = k, x = i), B_blk[k][j] and D_blk[i][j] on lane (q = row, x = j) (pipe_kernels.hpp, probe_mfma_4x4x4.cpp).
+// A sample's G (8 rows x 64 columns) lives in that B / D layout: register W[rb][cg] of lane (q, blk, x) is row 4 rb + q of column
+// 16 cg + 4 blk + x (column 0: the constant column g, column c >= 1: input column c - 1) -- eight doubles per sample, as before;
+// the output of a product is the input of the next stage's. The A operand of block (rb, kb) is the SAME for all columns: lane
+// (q, x) reads entry (4 rb + x, 4 kb + q) of the sample's 8 x 8 stage matrix straight out of the compact record in LDS (the
+// structural zeros, ones and dt are three constants appended to the record's image, so it is a plain load at a lane-constant
+// offset): FOUR LDS reads per (stage, sample) where the column-per-lane kernel needs 45 broadcasts -- that kernel is bound by its
+// LDS instructions, this one is not. And the matrix instructions only run over the column groups that hold a live column
+// (stage k has 2 k + 3: one group of 16 for the first seven stages, two for the next eight, ...), which a lane mapping cannot
+// do. Per (stage, sample, group): 4 products (2 x 2 blocks of the 8 x 8 matrix), the input column, the PCE mean and the chance row
+// as 6 FMAs. Two wavefronts per OCP share the samples as in the column-per-lane kernel and meet through LDS once per stage; the
+// chance row is reduced over the four row lanes (q) of a column once per stage (quad_sum).
+constexpr int SN_MREC = 56;                  // LDS image of a record: ABS doubles | 0.0 | 1.0 | dt
+__host__ __device__ inline int sn_mfma_lds_doubles(int uph, int ns)
+{
+    return 2 * uph * ns + (uph + 1) + uph * 8 + SN_LMAX * SN_NSMAX + uph * SN_LMAX + 2 * ns * SN_MREC + 2 * ns * 5 + 12 * 64;
+}
+template <int NSW>
+__global__ void __launch_bounds__(128, 2) snmpc_prologue_mfma_kernel(const SnArgs sa)
+{
+    extern __shared__ __attribute__((aligned(16))) double sn_lds[];
+    const int tid = threadIdx.x, b = blockIdx.x;
+    constexpr int NT = 128;
+    if (b >= sa.batch) return;
+    const int N = sa.N, ns = sa.ns, L = sa.L, uph = sa.uph;
+    const int nitem = uph * ns;
+    double *sH = sn_lds, *sCoef = sH + nitem, *sHval = sCoef + nitem, *sDef = sHval + (uph + 1), *sA = sDef + uph * 8;
+    double *sC = sA + SN_LMAX * SN_NSMAX, *sRec = sC + uph * SN_LMAX, *sG4 = sRec + 2 * ns * SN_MREC, *sX = sG4 + 2 * ns * 5;
+    const double dt = sa.dt;
+    const double *gX = sa.X + (size_t)b * (N + 1) * NX;
+    const double *gXS = sa.XS + (size_t)b * (N + 1) * ns * NX;
+    const double *ws2 = sa.ws2 + (size_t)b * uph * ns * ABS;
+    const double *ggh = sa.gh + (size_t)b * nitem * 5;
+    const int PP = sn_pro_pitch(uph), PSTAGE = 9 * PP;
+    double *pro = sa.pro + (size_t)b * uph * PSTAGE;
+
+    // ---- gg values of the items; PCE coefficients c = A h, weights d(E + kappa sqrt(Var)) / d h_i; the nominal copy's own defect
+    //      (the arithmetic of snmpc_prologue_kernel's P1 / P2, term by term)
+    for (int o = tid; o < nitem; o += NT) sH[o] = ggh[o * 5];
+    for (int o = tid; o < L * ns; o += NT) sA[o] = sa.Apce[o];
+    // the constants behind every record image and gradient table (both buffers), written once
+    for (int o = tid; o < 2 * ns; o += NT) {
+        sRec[o * SN_MREC + ABS] = 0.0; sRec[o * SN_MREC + ABS + 1] = 1.0; sRec[o * SN_MREC + ABS + 2] = dt;
+        sG4[o * 5 + 4] = 0.0;
+    }
+    __syncthreads();
+    for (int o = tid; o < uph * L; o += NT) {
+        const int k = o / L, l = o - k * L;
+        double cl = 0.0;
+#pragma unroll
+        for (int j = 0; j < SN_NSMAX; j++) cl += (j < ns) ? sA[l * ns + j] * sH[k * ns + j] : 0.0;
+        sC[o] = cl;
+    }
+    __syncthreads();
+    for (int item = tid; item < nitem; item += NT) {
+        const int k = item / ns, i = item - k * ns;
+        double w = 0.0;
+        if (k >= 1) {
+            double var = 0.0, acc = 0.0;
+#pragma unroll
+            for (int l = 1; l < SN_LMAX; l++) {
+                const double cl = (l < L) ? sC[k * L + l] : 0.0;
+                var += cl * cl; acc += (l < L) ? cl * sA[l * ns + i] : 0.0;
+            }
+            const double sd = sqrt(var);
+            w = sA[i] + ((sd > 0.0) ? sa.kappa * acc / sd : 0.0);
+            if (i == 0) sHval[k] = sC[k * L] + sa.kappa * sd;
+        }
+        sCoef[item] = w;
+    }
+    for (int o = tid; o < uph * 8; o += NT) {
+        const int s = (o >> 3) + 1, r = o & 7;
+        double acc = -gX[s * NX + r];
+#pragma unroll
+        for (int ii = 0; ii < SN_NSMAX; ii++) acc += (ii < ns) ? sA[ii] * gXS[((size_t)s * ns + ii) * NX + r] : 0.0;
+        sDef[o] = acc;
+    }
+
+    // ---- lane roles
+    const int lane = tid & 63, grp = tid >> 6;
+    const int q = lane >> 4, blk = (lane >> 2) & 3, x = lane & 3;
+    const int i0 = grp * NSW;                          // first sample of this wavefront
+    const int nrec = ns * ABS, ngh = ns * 4;
+    // entry (r, c) of a stage matrix as an index into the record image: Sp / S entries, or the constants 0.0 / 1.0 behind the record
+    auto aidx = [](int r, int c) -> int {
+        if (c < 2) return (r == c) ? ABS + 1 : ABS;
+        if (c == 2) return (r < 2) ? r : ((r == 2) ? ABS + 1 : ABS);
+        if (r < 6) return 2 + 7 * r + (c - 3);
+        return (r == c) ? ABS + 1 : ABS;
+    };
+    int oA[2][2];
+#pragma unroll
+    for (int rb = 0; rb < 2; rb++)
+#pragma unroll
+        for (int kb = 0; kb < 2; kb++) oA[rb][kb] = aidx(4 * rb + x, 4 * kb + q);
+    // the input column B[:, r0] (rows 6, 7: dt on the row the input integrates into) and the defect b, rows 4 rb + q
+    const int r0 = (x + 1) & 1;                        // parity of the input column c - 1 of column c = 16 cg + 4 blk + x
+    int oB[2], oG[2], oV[2];
+#pragma unroll
+    for (int rb = 0; rb < 2; rb++) {
+        const int row = 4 * rb + q;
+        oB[rb] = (row < 6) ? 2 + 7 * row + 5 + r0 : ((row == 6) ? (r0 ? ABS + 2 : ABS) : (r0 ? ABS : ABS + 2));
+        oG[rb] = 44 + row;
+    }
+    // gradient of the gg value w.r.t. (vl, vt, r, a) = rows 3, 4, 5, 7: index into the sample's table [g3, g4, g5, g7, 0.0]
+    oV[0] = (q == 3) ? 0 : 4;
+    oV[1] = (q == 0) ? 1 : (q == 1) ? 2 : (q == 3) ? 3 : 4;
+    constexpr int NCH = (2 * NSW * ABS + NT - 1) / NT;
+
+    for (int phase = 0; phase < 2; phase++) {
+        if (phase == 1 && 2 * uph < 64) break;         // (no column beyond 63)
+        const int kbeg = phase ? 31 : 0;               // input column 63 belongs to stage 31
+        const int cbase = 64 * phase + 4 * blk + x;    // column of this lane in group 0
+        const bool isg0 = (phase == 0) && blk == 0 && x == 0;      // (group 0 only) the constant column
+        double W[NSW][2][4];
+#pragma unroll
+        for (int i = 0; i < NSW; i++) {
+            const int ii = (i0 + i < ns) ? i0 + i : ns - 1;
+#pragma unroll
+            for (int rb = 0; rb < 2; rb++) {
+                const int row = 4 * rb + q;
+                const double d0 = sa.xs0[((size_t)b * ns + ii) * NX + row] - gXS[(size_t)ii * NX + row];
+                W[i][rb][0] = (isg0 && i0 + i < ns) ? d0 : 0.0;
+#pragma unroll
+                for (int cg = 1; cg < 4; cg++) W[i][rb][cg] = 0.0;
+            }
+        }
+        // the records of a stage are requested TWO stages ahead (with this kernel's short stages one stage of arithmetic no longer
+        // covers a global load under load: requested one stage ahead, the kernel spent more time waiting for records than computing)
+        double preA[NCH], preB[NCH], pregA = 0.0, pregB = 0.0;
+        auto fetch = [&](int k, double *pre, double &preg) {
+#pragma unroll
+            for (int c = 0; c < NCH; c++) { const int idx = tid + NT * c; pre[c] = (idx < nrec) ? ws2[(size_t)k * nrec + idx] : 0.0; }
+            if (tid < ngh && k + 1 < uph) { const int i = tid >> 2, e = tid & 3; preg = ggh[((size_t)(k + 1) * ns + i) * 5 + 1 + e]; }
+        };
+        auto stash = [&](int k, const double *pre, double preg) {
+            double *dr = sRec + (k & 1) * ns * SN_MREC, *dg = sG4 + (k & 1) * ns * 5;
+#pragma unroll
+            for (int c = 0; c < NCH; c++) {
+                const int idx = tid + NT * c, smp = idx / ABS, f = idx - smp * ABS;
+                if (idx < nrec) dr[smp * SN_MREC + f] = pre[c];
+            }
+            if (tid < ngh) dg[(tid >> 2) * 5 + (tid & 3)] = preg;
+        };
+        __syncthreads();                               // (phase 1: everybody is through with the buffers of phase 0)
+        if (kbeg < uph) { fetch(kbeg, preA, pregA); stash(kbeg, preA, pregA); }
+        if (kbeg + 1 < uph) fetch(kbeg + 1, preA, pregA);          // (stage kbeg + 1 waits in A, stage kbeg + 2 goes to B, ...)
+        for (int k = kbeg; k < uph; k++) {
+            const int s = k + 1;
+            const bool useA = ((k - kbeg) & 1) == 0;     // the registers that hold stage k + 1
+            __syncthreads();
+            if (k + 2 < uph) { if (useA) fetch(k + 2, preB, pregB); else fetch(k + 2, preA, pregA); }
+            const double *recs = sRec + (k & 1) * ns * SN_MREC, *g4s = sG4 + (k & 1) * ns * 5;
+            // column groups with a live column in this stage (live columns: 0 .. 2 k + 2)
+            const int nlive = 2 * k + 3 - 64 * phase;
+            const int ncg = (nlive >= 49) ? 4 : (nlive >= 33) ? 3 : (nlive >= 17) ? 2 : 1;
+            double sel[4];
+#pragma unroll
+            for (int cg = 0; cg < 4; cg++) {
+                const int c = cbase + 16 * cg;
+                sel[cg] = ((cg == 0 && isg0) || (c >= 1 && c <= 2 * uph && ((c - 1) >> 1) == k)) ? 1.0 : 0.0;
+            }
+            double M[2][4], Mc[4];
+#pragma unroll
+            for (int cg = 0; cg < 4; cg++) { M[0][cg] = 0.0; M[1][cg] = 0.0; Mc[cg] = 0.0; }
+#pragma unroll
+            for (int i = 0; i < NSW; i++) {
+                if (i0 + i < ns) {
+                    asm volatile("" ::: "memory");      // (the operand reads of a sample stay behind the arithmetic of the one before)
+                    const int gi = i0 + i;
+                    const double *rec = recs + gi * SN_MREC;
+                    const double a00 = rec[oA[0][0]], a01 = rec[oA[0][1]], a10 = rec[oA[1][0]], a11 = rec[oA[1][1]];
+                    const double bn0 = rec[oB[0]], bn1 = rec[oB[1]];
+                    const double bg0 = isg0 ? rec[oG[0]] : bn0, bg1 = isg0 ? rec[oG[1]] : bn1;      // (group 0: the g lanes take the defect)
+                    const double ai = sA[gi];
+                    const double cf = (s < uph) ? sCoef[s * ns + gi] : 0.0;
+                    const double gv0 = cf * g4s[gi * 5 + oV[0]], gv1 = cf * g4s[gi * 5 + oV[1]];
+#pragma unroll
+                    for (int cg = 0; cg < 4; cg++) {
+                        if (cg < ncg) {
+                            double d0 = __builtin_amdgcn_mfma_f64_4x4x4f64(a00, W[i][0][cg], 0.0, 0, 0, 0);
+                            double d1 = __builtin_amdgcn_mfma_f64_4x4x4f64(a10, W[i][0][cg], 0.0, 0, 0, 0);
+                            d0 = __builtin_amdgcn_mfma_f64_4x4x4f64(a01, W[i][1][cg], d0, 0, 0, 0);
+                            d1 = __builtin_amdgcn_mfma_f64_4x4x4f64(a11, W[i][1][cg], d1, 0, 0, 0);
+                            d0 += sel[cg] * (cg == 0 ? bg0 : bn0);
+                            d1 += sel[cg] * (cg == 0 ? bg1 : bn1);
+                            W[i][0][cg] = d0; W[i][1][cg] = d1;
+                            M[0][cg] += ai * d0; M[1][cg] += ai * d1;
+                            Mc[cg] += gv0 * d0 + gv1 * d1;
+                        }
+                    }
+                }
+            }
+            // the chance row: sum over the four row lanes of a column
+#pragma unroll
+            for (int cg = 0; cg < 4; cg++)
+                if (cg < ncg) Mc[cg] = quad_sum(Mc[cg]);
+            // the two sample halves meet: wavefront 1 hands its partial sums over, wavefront 0 adds and stores the stage
+            if (grp == 1) {
+#pragma unroll
+                for (int cg = 0; cg < 4; cg++) { sX[(3 * cg + 0) * 64 + lane] = M[0][cg]; sX[(3 * cg + 1) * 64 + lane] = M[1][cg]; sX[(3 * cg + 2) * 64 + lane] = Mc[cg]; }
+            }
+            __syncthreads();
+            if (grp == 0) {
+                double *pg = pro + (size_t)k * PSTAGE;
+#pragma unroll
+                for (int cg = 0; cg < 4; cg++) {
+                    const int c = cbase + 16 * cg;
+                    const bool isg = (cg == 0) && isg0;
+                    if (cg < ncg && c <= 2 * k + 2 && c <= 2 * uph) {      // (the live columns only: the rest of the buffer is zero and stays zero)
+                        const int colo = isg ? 2 * uph : c - 1;
+#pragma unroll
+                        for (int rb = 0; rb < 2; rb++) {
+                            const int row = 4 * rb + q;
+                            pg[row * PP + colo] = M[rb][cg] + sX[(3 * cg + rb) * 64 + lane] + (isg ? sDef[k * 8 + row] : 0.0);
+                        }
+                        if (q == 0) pg[8 * PP + colo] = Mc[cg] + sX[(3 * cg + 2) * 64 + lane] + ((isg && s < uph) ? sHval[s] : 0.0);
+                    }
+                }
+            }
+            if (k + 1 < uph) { if (useA) stash(k + 1, preA, pregA); else stash(k + 1, preB, pregB); }
         }
     }
 }

@@ -244,6 +244,13 @@ extern "C" void tum_ocp_free(tum_ocp *c)
     delete c;
 }
 
+// dynamic LDS (doubles) of the prologue kernel that `want` (a capsule's choice, < 0: the library's) selects for (uph, ns)
+static size_t sn_prologue_lds(int uph, int ns, int want)
+{
+    const int kind = sn_prologue_kind(uph, ns, want);
+    return kind == 2 ? sn_mfma_lds_doubles(uph, ns) : kind == 1 ? sn_cols_lds_doubles(uph, ns) : sn_prologue_lds_doubles(uph, ns, sn_prologue_variant(uph, ns));
+}
+
 // Turn the capsule into the coupled SNMPC OCP: the stacked state is the nominal copy followed by `ns`
 // sample copies; A_pce (L x ns, row-major) and the uncertainty propagation horizon replace the per-stage parameter
 // vector p = [A_pce.flatten(), risk_parameter, stop_flag] of the reference (SNMPC_class.py:103-104,124).
@@ -259,9 +266,10 @@ extern "C" int tum_ocp_snmpc_attach(tum_ocp *c, int ns, int L, const double *Apc
     if (c->d.store_qp_in) return fail("snmpc_attach: store_qp_in is not available for the stacked state");
     DevGuard guard(c->d.device); GUARD_OK(guard);
     {
-        const size_t lds = sizeof(double) * (sn_prologue_cols(uph, ns, c->sn_cols) ? sn_cols_lds_doubles(uph, ns) : sn_prologue_lds_doubles(uph, ns, sn_prologue_variant(uph, ns)));
+        const size_t lds = sizeof(double) * (sn_prologue_lds(uph, ns, c->sn_cols));
         if (lds > 128 * 1024) return fail("snmpc_attach: n_samples x uph too large for the prologue kernel's LDS");
         HIPCHK(hipFuncSetAttribute((const void *)snmpc_prologue_cols_kernel<SN_COLS_NSW>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
+        HIPCHK(hipFuncSetAttribute((const void *)snmpc_prologue_mfma_kernel<SN_COLS_NSW>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
         HIPCHK(hipFuncSetAttribute((const void *)snmpc_prologue_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
         HIPCHK(hipFuncSetAttribute((const void *)snmpc_prologue_kernel<6>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
         HIPCHK(hipFuncSetAttribute((const void *)snmpc_prologue_kernel<9>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
@@ -359,7 +367,7 @@ static int sn_apply_p(tum_ocp *c)
         if (c->p_stop[k] != 1.0) return fail("solve: stop_flag pattern not supported: it must be 0 on the stages < uph and 1 from stage uph on (stage " + std::to_string(k) + " is 0 after a 1)");
     if (uph > N) uph = N;                      // no stop flag at all: the samples are propagated over the whole horizon
     if (uph > SN_UPHMAX) return fail("solve: uncertainty propagation horizon from the stop flags exceeds " + std::to_string(SN_UPHMAX));
-    if (sizeof(double) * (sn_prologue_cols(uph, ns, c->sn_cols) ? sn_cols_lds_doubles(uph, ns) : sn_prologue_lds_doubles(uph, ns, sn_prologue_variant(uph, ns))) > 128 * 1024)      // (the variant sn_launch_prologue will pick)
+    if (sizeof(double) * (sn_prologue_lds(uph, ns, c->sn_cols)) > 128 * 1024)      // (the variant sn_launch_prologue will pick)
         return fail("solve: n_samples x uph too large for the prologue kernel's LDS");
     // (the hand-over buffer of the prologue is sized uph x sn_pro_stage(uph): its row pitch doubles beyond uph = 31)
     if (uph > c->uph_cap || (size_t)uph * sn_pro_stage(uph) > c->pro_cap) {
@@ -632,14 +640,13 @@ extern "C" int tum_ocp_set_kernel(tum_ocp *c, const char *name)
     if (n == "auto") c->kmode = 0;
     else if (n == "pipeline") c->kmode = 2;
     // the prologue of the coupled SNMPC OCP: one column per lane (default where n_samples <= 10) or the column-slot / pass variants
-    else if (n == "prologue-cols" || n == "prologue-passes") {
+    else if (n == "prologue-cols" || n == "prologue-passes" || n == "prologue-mfma") {
         if (c->sn) {
-            const int want = (n == "prologue-passes") ? 0 : 1;
-            const size_t lds = sizeof(double) * (sn_prologue_cols(c->sa.uph, c->sa.ns, want) ? sn_cols_lds_doubles(c->sa.uph, c->sa.ns)
-                                                 : sn_prologue_lds_doubles(c->sa.uph, c->sa.ns, sn_prologue_variant(c->sa.uph, c->sa.ns)));
+            const int want = (n == "prologue-passes") ? 0 : (n == "prologue-cols") ? 1 : 2;
+            const size_t lds = sizeof(double) * sn_prologue_lds(c->sa.uph, c->sa.ns, want);
             if (lds > 128 * 1024) return fail("set_kernel: n_samples x uph too large for that prologue kernel's LDS");
         }
-        c->sn_cols = (n == "prologue-passes") ? 0 : 1;
+        c->sn_cols = (n == "prologue-passes") ? 0 : (n == "prologue-cols") ? 1 : 2;
     }
 #ifdef TUM_DEV_KERNELS
     else if (n == "fused") c->kmode = 1;
@@ -648,7 +655,7 @@ extern "C" int tum_ocp_set_kernel(tum_ocp *c, const char *name)
     else if (n == "fused" || n == "pipeline4")
         return fail("set_kernel: kernel '" + n + "' exists in the development build only (libtumnmpc_dev.so); this library is the pipeline");
 #endif
-    else return fail("set_kernel: unknown kernel '" + n + "' (auto | pipeline | prologue-cols | prologue-passes; development build: fused | pipeline4)");
+    else return fail("set_kernel: unknown kernel '" + n + "' (auto | pipeline | prologue-mfma | prologue-cols | prologue-passes; development build: fused | pipeline4)");
     c->epoch++;
     return 0;
 }
@@ -673,7 +680,13 @@ static int resolve_kernel(tum_ocp *c)
 // last stage) or, for short propagation horizons and beyond the largest instantiation, in LDS
 static void sn_launch_prologue(tum_ocp *c)
 {
-    if (sn_prologue_cols(c->sa.uph, c->sa.ns, c->sn_cols)) {      // one column per lane, the samples split over the two wavefronts of a workgroup
+    const int kind = sn_prologue_kind(c->sa.uph, c->sa.ns, c->sn_cols);
+    if (kind == 2) {      // the column recursions on the matrix cores, the samples split over the two wavefronts of a workgroup
+        const size_t lds = sizeof(double) * sn_mfma_lds_doubles(c->sa.uph, c->sa.ns);
+        hipLaunchKernelGGL((snmpc_prologue_mfma_kernel<SN_COLS_NSW>), dim3(c->batch), dim3(128), lds, c->stream, c->sa);
+        return;
+    }
+    if (kind == 1) {      // one column per lane, the samples split over the two wavefronts of a workgroup
         const size_t lds = sizeof(double) * sn_cols_lds_doubles(c->sa.uph, c->sa.ns);
         hipLaunchKernelGGL((snmpc_prologue_cols_kernel<SN_COLS_NSW>), dim3(c->batch), dim3(128), lds, c->stream, c->sa);
         return;
