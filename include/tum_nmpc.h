@@ -154,10 +154,10 @@ int tum_ocp_set_schedule(tum_ocp *c, int longest_first);
  * implementations the pipeline is held against: "fused" (round 1's single kernel, N <= 40, uph <= 31) and "pipeline4" (the
  * pipeline with the four-wavefront interior point kernel); the shipped library refuses these names. Environment override at
  * create time: TUM_NMPC_KERNEL.
- * Two further names choose the PROLOGUE of a coupled SNMPC capsule without touching the rest: "prologue-cols" (one column of
- * every sample's sensitivity matrix per lane; n_samples <= 10; the library's own choice from 20 propagation stages on) and
- * "prologue-passes" (the column-slot / pass kernels of rounds 1-3; the choice for shorter horizons and the only one for
- * n_samples > 10): two implementations of the same hand-over the tests hold against each other. */
+ * Two further names choose the PROLOGUE of a coupled SNMPC capsule without touching the rest: "prologue-mfma" (the column
+ * recursions of the samples as v_mfma_f64_4x4x4_4b products; n_samples <= 10, where it is the library's own choice) and
+ * "prologue-passes" (the column-slot / pass kernels of rounds 1-3, the only ones for n_samples > 10): two implementations of
+ * the same hand-over the tests hold against each other. */
 int tum_ocp_set_kernel(tum_ocp *c, const char *name);
 /* last kernel launch time in milliseconds (HIP events on the launch stream) */
 double tum_ocp_last_kernel_ms(tum_ocp *c);

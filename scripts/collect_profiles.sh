@@ -27,7 +27,7 @@ for c in 3 4 5; do $T python bench.py --config $c --steps 10 2>/dev/null < /dev/
 for b in 1 512 4096 16384; do B=$b $T python scripts/pipe_check.py fused pipeline pipeline4 2>&1 < /dev/null | grep -E "^fused|^pipeline" | sed "s/^/batch $b: /" >> $OUT/kernel_variants.txt; done
 for S in 1 2 3 4 6; do $T python bench.py --steps 20 --warmup 3 --streams $S --no-cpu-baseline --no-schedule-legs 2>/dev/null < /dev/null | grep metric | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('streams',d['config']['streams'],'value %.3f M solves/s'%(d['value']/1e6),'ms/step %.3f'%d['ms_per_step'])" >> $OUT/streams.txt; done
 $T python scripts/snmpc_bench.py 2>&1 < /dev/null | grep -v amdgpu.ids > $OUT/snmpc_bench.txt
-for v in prologue-cols prologue-passes; do echo "== set_kernel(\"$v\") on every capsule (default: passes below 20 propagation stages, cols from there on)" >> $OUT/snmpc_prologue_variants.txt; SN_PROLOGUE=$v $T python scripts/snmpc_bench.py 2>&1 < /dev/null | grep "^coupled" >> $OUT/snmpc_prologue_variants.txt; done
+for v in prologue-mfma prologue-passes; do echo "== set_kernel(\"$v\") on every capsule (default at ten samples: prologue-mfma)" >> $OUT/snmpc_prologue_variants.txt; SN_PROLOGUE=$v $T python scripts/snmpc_bench.py 2>&1 < /dev/null | grep "^coupled" >> $OUT/snmpc_prologue_variants.txt; done
 $T rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/sn38 -o s -- python scripts/dev/sn_uph_profile.py 38 38 > /dev/null 2>&1 < /dev/null
 $T rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/sn05 -o s -- python scripts/dev/sn_uph_profile.py 38 5 > /dev/null 2>&1 < /dev/null
 $T python scripts/pcie_inclusive.py 1 3 2>&1 < /dev/null | grep -v amdgpu.ids > $OUT/pcie.txt

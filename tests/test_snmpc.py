@@ -322,24 +322,17 @@ def test_gpu_coupled_snmpc_pipeline_vs_oracle(golden_dir, N, uph):
 @pytest.mark.parametrize("N,uph", [(38, 5), (38, 15), (40, 24), (40, 33), (38, 38), (48, 48)])
 def test_gpu_coupled_snmpc_pipeline_passes_prologue_vs_oracle(golden_dir, N, uph):
     """the pipeline with the prologue of rounds 1-3 (set_kernel("prologue-passes"): column slots and passes; column state in LDS
-    at uph = 5, in registers for 6 / 9 / 13 / 17 passes beyond) instead of the column-per-lane prologue that is the default at
+    at uph = 5, in registers for 6 / 9 / 13 / 17 passes beyond) instead of the matrix-core prologue that is the default at
     ten samples: the second implementation of the same hand-over, held to the oracle like the first"""
     _gpu_vs_oracle(golden_dir, N, uph, poses=[0, 26, 30], kernel="pipeline", prologue="prologue-passes")
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("N,uph", [(38, 5), (38, 15), (12, 12), (40, 1), (44, 5)])
-def test_gpu_coupled_snmpc_pipeline_cols_prologue_vs_oracle(golden_dir, N, uph):
-    """... and the column-per-lane prologue forced onto the short propagation horizons the library would give to the pass kernels
-    (its own choice from 20 stages on, which the default runs above cover at uph = 24 / 33 / 38 / 48)"""
-    _gpu_vs_oracle(golden_dir, N, uph, poses=[0, 26, 30], kernel="pipeline", prologue="prologue-cols")
-
-
-@pytest.mark.gpu
 @pytest.mark.parametrize("N,uph", [(38, 5), (38, 15), (12, 12), (40, 1), (44, 5), (40, 24), (40, 33), (38, 38), (48, 48), (48, 32)])
 def test_gpu_coupled_snmpc_pipeline_mfma_prologue_vs_oracle(golden_dir, N, uph):
-    """... and the matrix-core prologue (column recursions as v_mfma_f64_4x4x4_4b products over the live column groups) on
-    every propagation horizon: one and several column groups, the second phase for the columns beyond 63 (uph 32 is its first
+    """the matrix-core prologue (column recursions as v_mfma_f64_4x4x4_4b products over the live column groups), named
+    explicitly (it is also the library's own choice at ten samples, i.e. what the pipeline test above runs) on every
+    propagation horizon: one and several column groups, the second phase for the columns beyond 63 (uph 32 is its first
     stage, 33 / 38 / 48 run it for 2 / 7 / 17 stages)"""
     _gpu_vs_oracle(golden_dir, N, uph, poses=[0, 26, 30], kernel="pipeline", prologue="prologue-mfma")
 
@@ -401,16 +394,14 @@ def test_gpu_coupled_snmpc_condensed_qp(golden_dir, N, uph, lib):
                                                  (8, 6, 40, 12, "prologue-passes"), (8, 6, 40, 24, "prologue-passes"), (8, 6, 38, 38, "prologue-passes"),
                                                  (9, 6, 40, 24, "prologue-passes"), (7, 4, 40, 11, "prologue-passes"), (3, 2, 40, 31, "prologue-passes"),
                                                  (8, 6, 38, 38, None), (9, 6, 40, 24, None), (6, 3, 40, 36, None), (2, 2, 40, 40, None),
-                                                 (7, 4, 40, 11, "prologue-cols"), (1, 1, 10, 3, "prologue-cols"), (10, 10, 40, 9, "prologue-cols"),
-                                                 (7, 4, 40, 11, "prologue-mfma"), (1, 1, 10, 3, "prologue-mfma"), (10, 10, 40, 9, "prologue-mfma"), (8, 6, 38, 38, "prologue-mfma"),
+                                                                                                  (7, 4, 40, 11, "prologue-mfma"), (1, 1, 10, 3, "prologue-mfma"), (10, 10, 40, 9, "prologue-mfma"), (8, 6, 38, 38, "prologue-mfma"),
                                                  (9, 6, 40, 24, "prologue-mfma"), (6, 3, 40, 36, "prologue-mfma"), (2, 2, 40, 40, "prologue-mfma"), (3, 2, 40, 31, "prologue-mfma"),
                                                  (5, 4, 40, 17, "prologue-mfma")])
 def test_gpu_coupled_snmpc_other_sample_counts(golden_dir, ns, L, N, uph, prologue):
     """sample counts / PCE sizes other than the shipped 10 x 10 (any L x n_s matrix defines a valid OCP): condensed QP and
-    one full step of every copy against the oracle. Up to ten samples with 20 propagation stages or more -- or
-    set_kernel("prologue-cols") -- run the column-per-lane prologue (five samples per wavefront; fewer than six leave the
-    second wavefront of the workgroup without a sample), everything else -- or set_kernel("prologue-passes") -- the column-slot
-    / pass kernels. Of those, eight samples with a propagation horizon of
+    one full step of every copy against the oracle. Up to ten samples run the matrix-core prologue (five samples per
+    wavefront; fewer than six leave the second wavefront of the workgroup without a sample), more than ten -- or
+    set_kernel("prologue-passes") -- the column-slot / pass kernels. Of those, eight samples with a propagation horizon of
     12 / 24 / 38 stages run the register-resident instantiations (6 / 9 / 13 passes) with EIGHT column slots per sample: the 64
     lanes then only reach eight of the nine reduction rows, and the chance-constraint row takes a second round (round 3 dropped
     it)."""

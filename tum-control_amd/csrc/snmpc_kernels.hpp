@@ -103,27 +103,21 @@ __host__ inline int sn_prologue_variant(int uph, int ns)
     return 0;
 }
 
-// the column-per-lane prologue (snmpc_prologue_cols_kernel below) runs the configurations with at most SN_COLS_NS samples and a
-// propagation horizon of SN_COLS_UPH stages or more (measured on 4096 instances, whole solve, cols against passes: uph = 5: 1.40 /
-// 1.33 ms, 9: 1.56 / 1.52, 15: 1.87 / 1.82, 24: 2.19 / 2.24, 38: 2.85 / 3.03 -- with few live columns per stage the column-slot
-// kernels waste less); the variants above serve everything else and are the second implementation the tests hold the new one
-// against (TUM_SN_PROLOGUE = 0 | 6 | 9 | 13 | 17 forces them, "cols" forces the new one wherever the sample count allows;
-// per capsule: tum_ocp_set_kernel "prologue-passes" / "prologue-cols")
-#ifndef SN_PROLOGUE_DEFAULT
-#define SN_PROLOGUE_DEFAULT(uph) (((uph) >= SN_COLS_UPH) ? 1 : 0)
-#endif
-constexpr int SN_COLS_NS = 10;          // = 2 SN_COLS_NSW: five samples per wavefront
-constexpr int SN_COLS_UPH = 20;
-// which prologue runs: 0 column slots and passes, 1 one column per lane, 2 the matrix-core kernel. `want` < 0: the library's choice.
+// Which prologue runs: the matrix-core kernel (snmpc_prologue_mfma_kernel below) wherever the sample count allows (two wavefronts
+// with SN_MFMA_NSW samples each: n_samples <= 10), the column-slot / pass variants above for more samples -- and as the second
+// implementation the tests hold the new one against (per capsule: tum_ocp_set_kernel "prologue-passes" / "prologue-mfma";
+// TUM_SN_PROLOGUE = 0 | 6 | 9 | 13 | 17 forces a pass variant, "mfma" the matrix-core kernel). Measured on 4096 instances, whole
+// solve, matrix cores against passes: uph = 5: 1.31 / 1.31 ms, 9: 1.46 / 1.48, 15: 1.70 / 1.77, 24: 1.99 / 2.16, 38: 2.54 / 2.88.
+constexpr int SN_MFMA_NSW = 5, SN_MFMA_NS = 2 * SN_MFMA_NSW;
+// 0: column slots and passes, 2: the matrix-core kernel. `want` < 0: the library's choice.
 __host__ inline int sn_prologue_kind(int uph, int ns, int want = -1)
 {
-    static const int forced = [] { const char *e = getenv("TUM_SN_PROLOGUE"); return !e ? -1 : (e[0] == 'c' ? 1 : e[0] == 'm' ? 2 : 0); }();
+    static const int forced = [] { const char *e = getenv("TUM_SN_PROLOGUE"); return !e ? -1 : (e[0] == 'm' ? 2 : 0); }();
     const int f = want >= 0 ? want : forced;
-    if (ns > SN_COLS_NS || f == 0) return 0;
-    if (f > 0) return f;
-    return SN_PROLOGUE_DEFAULT(uph);
+    (void)uph;
+    if (ns > SN_MFMA_NS || f == 0) return 0;
+    return 2;
 }
-__host__ inline bool sn_prologue_cols(int uph, int ns, int want = -1) { return sn_prologue_kind(uph, ns, want) == 1; }
 
 // K-S1: linearisation of the sample stages. lane = (instance, stage k < uph, sample) item; the 64 records of a wavefront are
 // one contiguous block of ws2 and go out transposed through LDS (416 contiguous bytes per store instruction instead of 64
@@ -413,193 +407,6 @@ __global__ void __launch_bounds__(64) snmpc_prologue_kernel(const SnArgs sa)
     }
 }
 
-// ---- the prologue with one COLUMN per lane (round 4). A workgroup of TWO wavefronts per OCP; lane l of both owns column q of
-// every sample's G^(i) (q = 0: the constant column g, q >= 1: input column q - 1); wavefront 0 keeps that column for the samples
-// 0..NSW-1 in registers, wavefront 1 for the samples NSW..2 NSW-1: W[NSW][8]. Per stage a wavefront walks its samples one after
-// the other: the record of (stage, sample) is read from LDS at wave-uniform addresses (broadcasts), A^(i) w is 32 FMAs, and the
-// PCE mean over the samples and the weighted chance row accumulate IN THE LANE; the two halves meet through one LDS exchange per
-// stage (nine doubles per lane). No reduction across lanes, no passes, no column state in LDS, and the stores of a stage are
-// nine rows of consecutive columns. (The variants above spend most of their time in the per-pass reduction through LDS -- nine
-// row stores and sixteen reads per pass for ~60 FMAs -- and in passes over slots that hold no column yet.) Propagation horizons
-// above 31 stages have more than 64 columns: the columns 63.. only exist from stage 31 on, and are run as a second, short phase
-// over the stages 31..uph-1 by the same two wavefronts (their records come from L2 again).
-// What made round 3's attempt at this mapping fail -- ten samples per lane: the compiler hoisted the uniform record reads of all
-// samples above the first one, 500+ live registers -- is avoided by halving the samples per lane and by a compiler-level memory
-// fence between the samples (LDS reads do not move across it; the latency exposed at the start of a sample is what the other
-// wavefronts of the SIMD are for).
-constexpr int SN_COLS_NSW = 5;
-// LDS image of a sample's record in this kernel: rows of S on 16-byte boundaries, so that the uniform reads are ds_read_b128 (a
-// quarter of the LDS cycles of the ds_read2_b64 the packed record gives: 4 against 8 per 16 bytes and lane): [0, 1] Sp |
-// [2 + 8 r .. 8 + 8 r] S[r][0..6], r = 0..5 | [50..57] b; stride 58
-constexpr int SN_CREC = 58;
-__host__ __device__ inline int sn_cols_rec_pos(int f) { return (f < 2) ? f : (f < 44) ? 2 + 8 * ((f - 2) / 7) + (f - 2) % 7 : 50 + (f - 44); }
-__host__ __device__ inline int sn_cols_lds_doubles(int uph, int ns)
-{
-    const int head = 2 * uph * ns + (uph + 1) + uph * 8 + SN_LMAX * SN_NSMAX + uph * SN_LMAX;
-    return ((head + 1) & ~1) + 2 * ns * SN_CREC + 2 * ns * 4 + 9 * 64;
-}
-template <int NSW>
-__global__ void __launch_bounds__(128, 2) snmpc_prologue_cols_kernel(const SnArgs sa)
-{
-    extern __shared__ __attribute__((aligned(16))) double sn_lds[];
-    const int tid = threadIdx.x, b = blockIdx.x;
-    constexpr int NT = 128;
-    if (b >= sa.batch) return;
-    const int N = sa.N, ns = sa.ns, L = sa.L, uph = sa.uph;
-    const int nitem = uph * ns;
-    double *sH = sn_lds, *sCoef = sH + nitem, *sHval = sCoef + nitem, *sDef = sHval + (uph + 1), *sA = sDef + uph * 8;
-    double *sC = sA + SN_LMAX * SN_NSMAX;
-    double *sRec = sn_lds + (((int)(sC + uph * SN_LMAX - sn_lds) + 1) & ~1), *sG4 = sRec + 2 * ns * SN_CREC, *sX = sG4 + 2 * ns * 4;
-    const double dt = sa.dt;
-    const double *gX = sa.X + (size_t)b * (N + 1) * NX;
-    const double *gXS = sa.XS + (size_t)b * (N + 1) * ns * NX;
-    const double *ws2 = sa.ws2 + (size_t)b * uph * ns * ABS;
-    const double *ggh = sa.gh + (size_t)b * nitem * 5;
-    const int PP = sn_pro_pitch(uph), PSTAGE = 9 * PP;
-    double *pro = sa.pro + (size_t)b * uph * PSTAGE;
-
-    // ---- gg values of the items; PCE coefficients c = A h, weights d(E + kappa sqrt(Var)) / d h_i; the nominal copy's own defect
-    //      (the arithmetic of snmpc_prologue_kernel's P1 / P2, term by term)
-    for (int o = tid; o < nitem; o += NT) sH[o] = ggh[o * 5];
-    for (int o = tid; o < L * ns; o += NT) sA[o] = sa.Apce[o];
-    __syncthreads();
-    for (int o = tid; o < uph * L; o += NT) {
-        const int k = o / L, l = o - k * L;
-        double cl = 0.0;
-#pragma unroll
-        for (int j = 0; j < SN_NSMAX; j++) cl += (j < ns) ? sA[l * ns + j] * sH[k * ns + j] : 0.0;
-        sC[o] = cl;
-    }
-    __syncthreads();
-    for (int item = tid; item < nitem; item += NT) {
-        const int k = item / ns, i = item - k * ns;
-        double w = 0.0;
-        if (k >= 1) {
-            double var = 0.0, acc = 0.0;
-#pragma unroll
-            for (int l = 1; l < SN_LMAX; l++) {
-                const double cl = (l < L) ? sC[k * L + l] : 0.0;
-                var += cl * cl; acc += (l < L) ? cl * sA[l * ns + i] : 0.0;
-            }
-            const double sd = sqrt(var);
-            w = sA[i] + ((sd > 0.0) ? sa.kappa * acc / sd : 0.0);
-            if (i == 0) sHval[k] = sC[k * L] + sa.kappa * sd;
-        }
-        sCoef[item] = w;
-    }
-    for (int o = tid; o < uph * 8; o += NT) {
-        const int s = (o >> 3) + 1, r = o & 7;
-        double acc = -gX[s * NX + r];
-#pragma unroll
-        for (int ii = 0; ii < SN_NSMAX; ii++) acc += (ii < ns) ? sA[ii] * gXS[((size_t)s * ns + ii) * NX + r] : 0.0;
-        sDef[o] = acc;
-    }
-
-    // ---- the column recursions: phase 0 = the columns 0..63 over all stages, phase 1 = the columns 64.. over the stages they exist in
-    const int lane = tid & 63, grp = tid >> 6;
-    const int i0 = grp * NSW;                          // first sample of this wavefront
-    const int nrec = ns * ABS, ngh = ns * 4;
-    constexpr int NCH = (2 * NSW * ABS + NT - 1) / NT;
-    for (int phase = 0; phase < 2; phase++) {
-        const int q = 64 * phase + lane;
-        if (phase == 1 && 2 * uph < 64) break;         // (no column beyond 63)
-        const int kbeg = phase ? 31 : 0;               // input column 63 belongs to stage 31
-        const bool isg = q == 0, valid = q <= 2 * uph;
-        const int col = q - 1, jst = col >> 1, r0 = col & 1;
-        double W[NSW][8];
-        // (every lane reads the initial defect of every sample at a clamped index and the g lane keeps it: as a select of a guarded
-        //  load this was forty branches with a load and a full wait each)
-#pragma unroll
-        for (int i = 0; i < NSW; i++) {
-            const int ii = (i0 + i < ns) ? i0 + i : ns - 1;
-#pragma unroll
-            for (int r = 0; r < 8; r++) {
-                const double d0 = sa.xs0[((size_t)b * ns + ii) * NX + r] - gXS[(size_t)ii * NX + r];
-                W[i][r] = (isg && i0 + i < ns) ? d0 : 0.0;
-            }
-        }
-        // stage buffers: the ns records of stage k | the gg gradients (4 doubles per sample) of the items of stage k + 1
-        double pre[NCH], preg = 0.0;
-        auto fetch = [&](int k) {
-#pragma unroll
-            for (int c = 0; c < NCH; c++) { const int idx = tid + NT * c; pre[c] = (idx < nrec) ? ws2[(size_t)k * nrec + idx] : 0.0; }
-            if (tid < ngh && k + 1 < uph) { const int i = tid >> 2, e = tid & 3; preg = ggh[((size_t)(k + 1) * ns + i) * 5 + 1 + e]; }
-        };
-        auto stash = [&](int k) {
-            double *dr = sRec + (k & 1) * ns * SN_CREC, *dg = sG4 + (k & 1) * ngh;
-#pragma unroll
-            for (int c = 0; c < NCH; c++) {
-                const int idx = tid + NT * c, smp = idx / ABS, f = idx - smp * ABS;
-                if (idx < nrec && f < 52) dr[smp * SN_CREC + sn_cols_rec_pos(f)] = pre[c];
-            }
-            if (tid < ngh) dg[tid] = preg;
-        };
-        __syncthreads();                               // (phase 1: everybody is through with the buffers of phase 0)
-        if (kbeg < uph) { fetch(kbeg); stash(kbeg); }
-        // per lane: where the input / constant part of this lane's column sits in a record (B column r0 of rows 0..5, or the defect b)
-        const int offB = isg ? 50 : 7 + r0, strB = isg ? 1 : 8;
-        const double d6 = (!isg && r0) ? dt : 0.0, d7 = (!isg && !r0) ? dt : 0.0;
-        for (int k = kbeg; k < uph; k++) {
-            const int s = k + 1;
-            __syncthreads();
-            if (k + 1 < uph) fetch(k + 1);
-            const double *recs = sRec + (k & 1) * ns * SN_CREC, *g4s = sG4 + (k & 1) * ngh;
-            const double sel = (isg || (valid && jst == k)) ? 1.0 : 0.0;
-            const double *recB = recs + offB;
-            double M[9];
-#pragma unroll
-            for (int r = 0; r < 9; r++) M[r] = 0.0;
-#pragma unroll
-            for (int i = 0; i < NSW; i++) {
-                if (i0 + i < ns) {
-                    asm volatile("" ::: "memory");      // (the record reads of a sample stay behind the arithmetic of the one before)
-                    const int gi = i0 + i;
-                    const double *rec = (const double *)__builtin_assume_aligned(recs + gi * SN_CREC, 16);
-                    double *w = W[i];
-                    {   // w <- A w (apply_A on the 16-byte-aligned image of the record)
-                        double n[6];
-                        n[0] = w[0] + rec[0] * w[2]; n[1] = w[1] + rec[1] * w[2]; n[2] = w[2];
-                        n[3] = 0.0; n[4] = 0.0; n[5] = 0.0;
-#pragma unroll
-                        for (int r = 0; r < 6; r++) {
-                            const double *Sr = rec + 2 + 8 * r;
-#pragma unroll
-                            for (int c = 0; c < 5; c++) n[r] += Sr[c] * w[3 + c];
-                        }
-#pragma unroll
-                        for (int r = 0; r < 6; r++) w[r] = n[r];
-                    }
-#pragma unroll
-                    for (int r = 0; r < 6; r++) w[r] += sel * recB[gi * SN_CREC + r * strB];
-                    w[6] += isg ? rec[56] : sel * d6;
-                    w[7] += isg ? rec[57] : sel * d7;
-                    const double ai = sA[gi];
-#pragma unroll
-                    for (int r = 0; r < 8; r++) M[r] += ai * w[r];
-                    if (s < uph) {
-                        const double cf = sCoef[s * ns + gi];
-                        M[8] += cf * (g4s[gi * 4 + 0] * w[3] + g4s[gi * 4 + 1] * w[4] + g4s[gi * 4 + 2] * w[5] + g4s[gi * 4 + 3] * w[7]);
-                    }
-                }
-            }
-            // the two sample halves meet: wavefront 1 hands its nine partial sums over, wavefront 0 adds and stores the stage
-            if (grp == 1) {
-#pragma unroll
-                for (int r = 0; r < 9; r++) sX[r * 64 + lane] = M[r];
-            }
-            __syncthreads();
-            if (grp == 0 && valid && q <= 2 * k + 2) {      // (the live columns only: the rest of the buffer is zero and stays zero)
-                double *pg = pro + (size_t)k * PSTAGE;
-                const int colo = isg ? 2 * uph : col;
-#pragma unroll
-                for (int r = 0; r < 8; r++) pg[r * PP + colo] = M[r] + sX[r * 64 + lane] + (isg ? sDef[k * 8 + r] : 0.0);
-                pg[8 * PP + colo] = M[8] + sX[8 * 64 + lane] + ((isg && s < uph) ? sHval[s] : 0.0);
-            }
-            if (k + 1 < uph) stash(k + 1);
-        }
-    }
-}
-
 // ---- the prologue on the matrix cores (round 4): the column recursions G^(i) <- A^(i) G^(i) as v_mfma_f64_4x4x4_4b products.
 // The instruction computes four independent 4 x 4 x 4 products, one per 4-lane block of a DPP row: lane = 16 q + 4 blk + x,
 // A_blk[i][k] on lane (q = k, x = i), B_blk[k][j] and D_blk[i][j] on lane (q = row, x = j) (pipe_kernels.hpp, probe_mfma_4x4x4.cpp).
@@ -608,23 +415,25 @@ __global__ void __launch_bounds__(128, 2) snmpc_prologue_cols_kernel(const SnArg
 // the output of a product is the input of the next stage's. The A operand of block (rb, kb) is the SAME for all columns: lane
 // (q, x) reads entry (4 rb + x, 4 kb + q) of the sample's 8 x 8 stage matrix straight out of the compact record in LDS (the
 // structural zeros, ones and dt are three constants appended to the record's image, so it is a plain load at a lane-constant
-// offset): FOUR LDS reads per (stage, sample) where the column-per-lane kernel needs 45 broadcasts -- that kernel is bound by its
-// LDS instructions, this one is not. And the matrix instructions only run over the column groups that hold a live column
+// offset): FOUR LDS reads per (stage, sample) where a lane-per-column kernel (built first in this round) needs 45
+// broadcasts and is bound by its LDS instructions. And the matrix instructions only run over the column groups that hold a live column
 // (stage k has 2 k + 3: one group of 16 for the first seven stages, two for the next eight, ...), which a lane mapping cannot
 // do. Per (stage, sample, group): 4 products (2 x 2 blocks of the 8 x 8 matrix), the input column, the PCE mean and the chance row
-// as 6 FMAs. Two wavefronts per OCP share the samples as in the column-per-lane kernel and meet through LDS once per stage; the
+// as 6 FMAs. Two wavefronts per OCP share the samples (five each: 80 registers of column state) and meet through LDS once per stage; the
 // chance row is reduced over the four row lanes (q) of a column once per stage (quad_sum).
 constexpr int SN_MREC = 56;                  // LDS image of a record: ABS doubles | 0.0 | 1.0 | dt
 __host__ __device__ inline int sn_mfma_lds_doubles(int uph, int ns)
 {
     return 2 * uph * ns + (uph + 1) + uph * 8 + SN_LMAX * SN_NSMAX + uph * SN_LMAX + 2 * ns * SN_MREC + 2 * ns * 5 + 12 * 64;
 }
-template <int NSW>
-__global__ void __launch_bounds__(128, 2) snmpc_prologue_mfma_kernel(const SnArgs sa)
+// NWV wavefronts per OCP, NSW samples per wavefront (NWV x NSW >= n_samples)
+template <int NSW, int NWV>
+__global__ void __launch_bounds__(64 * NWV, 2) snmpc_prologue_mfma_kernel(const SnArgs sa)
 {
     extern __shared__ __attribute__((aligned(16))) double sn_lds[];
     const int tid = threadIdx.x, b = blockIdx.x;
-    constexpr int NT = 128;
+    constexpr int NT = 64 * NWV;
+    auto sync = [] { if (NWV > 1) __syncthreads(); else wsync(); };
     if (b >= sa.batch) return;
     const int N = sa.N, ns = sa.ns, L = sa.L, uph = sa.uph;
     const int nitem = uph * ns;
@@ -709,8 +518,10 @@ __global__ void __launch_bounds__(128, 2) snmpc_prologue_mfma_kernel(const SnArg
     // gradient of the gg value w.r.t. (vl, vt, r, a) = rows 3, 4, 5, 7: index into the sample's table [g3, g4, g5, g7, 0.0]
     oV[0] = (q == 3) ? 0 : 4;
     oV[1] = (q == 0) ? 1 : (q == 1) ? 2 : (q == 3) ? 3 : 4;
-    constexpr int NCH = (2 * NSW * ABS + NT - 1) / NT;
+    constexpr int NCH = (NWV * NSW * ABS + NT - 1) / NT;
 
+    long long tacc[6] = {0, 0, 0, 0, 0, 0}, tprev = __builtin_readcyclecounter();
+#define SN_TICK(j) do { if (sa.dbg && b == 256) { const long long t_ = __builtin_readcyclecounter(); tacc[j] += t_ - tprev; tprev = t_; } } while (0)
     for (int phase = 0; phase < 2; phase++) {
         if (phase == 1 && 2 * uph < 64) break;         // (no column beyond 63)
         const int kbeg = phase ? 31 : 0;               // input column 63 belongs to stage 31
@@ -729,15 +540,13 @@ __global__ void __launch_bounds__(128, 2) snmpc_prologue_mfma_kernel(const SnArg
                 for (int cg = 1; cg < 4; cg++) W[i][rb][cg] = 0.0;
             }
         }
-        // the records of a stage are requested TWO stages ahead (with this kernel's short stages one stage of arithmetic no longer
-        // covers a global load under load: requested one stage ahead, the kernel spent more time waiting for records than computing)
-        double preA[NCH], preB[NCH], pregA = 0.0, pregB = 0.0;
-        auto fetch = [&](int k, double *pre, double &preg) {
+        double pre[NCH], preg = 0.0;
+        auto fetch = [&](int k) {
 #pragma unroll
             for (int c = 0; c < NCH; c++) { const int idx = tid + NT * c; pre[c] = (idx < nrec) ? ws2[(size_t)k * nrec + idx] : 0.0; }
             if (tid < ngh && k + 1 < uph) { const int i = tid >> 2, e = tid & 3; preg = ggh[((size_t)(k + 1) * ns + i) * 5 + 1 + e]; }
         };
-        auto stash = [&](int k, const double *pre, double preg) {
+        auto stash = [&](int k) {
             double *dr = sRec + (k & 1) * ns * SN_MREC, *dg = sG4 + (k & 1) * ns * 5;
 #pragma unroll
             for (int c = 0; c < NCH; c++) {
@@ -746,14 +555,14 @@ __global__ void __launch_bounds__(128, 2) snmpc_prologue_mfma_kernel(const SnArg
             }
             if (tid < ngh) dg[(tid >> 2) * 5 + (tid & 3)] = preg;
         };
-        __syncthreads();                               // (phase 1: everybody is through with the buffers of phase 0)
-        if (kbeg < uph) { fetch(kbeg, preA, pregA); stash(kbeg, preA, pregA); }
-        if (kbeg + 1 < uph) fetch(kbeg + 1, preA, pregA);          // (stage kbeg + 1 waits in A, stage kbeg + 2 goes to B, ...)
+        sync();                                        // (phase 1: everybody is through with the buffers of phase 0)
+        if (kbeg < uph) { fetch(kbeg); stash(kbeg); }
         for (int k = kbeg; k < uph; k++) {
             const int s = k + 1;
-            const bool useA = ((k - kbeg) & 1) == 0;     // the registers that hold stage k + 1
-            __syncthreads();
-            if (k + 2 < uph) { if (useA) fetch(k + 2, preB, pregB); else fetch(k + 2, preA, pregA); }
+            SN_TICK(5);
+            sync();
+            SN_TICK(0);
+            if (k + 1 < uph) fetch(k + 1);
             const double *recs = sRec + (k & 1) * ns * SN_MREC, *g4s = sG4 + (k & 1) * ns * 5;
             // column groups with a live column in this stage (live columns: 0 .. 2 k + 2)
             const int nlive = 2 * k + 3 - 64 * phase;
@@ -795,16 +604,22 @@ __global__ void __launch_bounds__(128, 2) snmpc_prologue_mfma_kernel(const SnArg
                     }
                 }
             }
+            SN_TICK(1);
             // the chance row: sum over the four row lanes of a column
 #pragma unroll
             for (int cg = 0; cg < 4; cg++)
                 if (cg < ncg) Mc[cg] = quad_sum(Mc[cg]);
             // the two sample halves meet: wavefront 1 hands its partial sums over, wavefront 0 adds and stores the stage
-            if (grp == 1) {
+            if (NWV > 1 && grp == 1) {
 #pragma unroll
                 for (int cg = 0; cg < 4; cg++) { sX[(3 * cg + 0) * 64 + lane] = M[0][cg]; sX[(3 * cg + 1) * 64 + lane] = M[1][cg]; sX[(3 * cg + 2) * 64 + lane] = Mc[cg]; }
             }
-            __syncthreads();
+            if (NWV > 1) __syncthreads();
+            SN_TICK(2);
+            // the next stage's records go to LDS BEFORE this stage's results go out: stores count in the same counter as loads on
+            // this part, and a wait for the records behind the stores would wait for the stores' round trip to L2 as well
+            if (k + 1 < uph) stash(k + 1);
+            SN_TICK(3);
             if (grp == 0) {
                 double *pg = pro + (size_t)k * PSTAGE;
 #pragma unroll
@@ -816,15 +631,18 @@ __global__ void __launch_bounds__(128, 2) snmpc_prologue_mfma_kernel(const SnArg
 #pragma unroll
                         for (int rb = 0; rb < 2; rb++) {
                             const int row = 4 * rb + q;
-                            pg[row * PP + colo] = M[rb][cg] + sX[(3 * cg + rb) * 64 + lane] + (isg ? sDef[k * 8 + row] : 0.0);
+                            pg[row * PP + colo] = M[rb][cg] + (NWV > 1 ? sX[(3 * cg + rb) * 64 + lane] : 0.0) + (isg ? sDef[k * 8 + row] : 0.0);
                         }
-                        if (q == 0) pg[8 * PP + colo] = Mc[cg] + sX[(3 * cg + 2) * 64 + lane] + ((isg && s < uph) ? sHval[s] : 0.0);
+                        if (q == 0) pg[8 * PP + colo] = Mc[cg] + (NWV > 1 ? sX[(3 * cg + 2) * 64 + lane] : 0.0) + ((isg && s < uph) ? sHval[s] : 0.0);
                     }
                 }
             }
-            if (k + 1 < uph) { if (useA) stash(k + 1, preA, pregA); else stash(k + 1, preB, pregB); }
+            SN_TICK(4);
         }
     }
+    if (sa.dbg && b == 256 && lane == 0)
+        for (int j = 0; j < 6; j++) sa.dbg[10 * grp + j] = (double)tacc[j];
+#undef SN_TICK
 }
 
 // full step of the sample copies: dx^(i)_0 = xs0 - X^(i)_0, dx^(i)_{k+1} = A dx^(i)_k + B du_k + b for k < uph; frozen

@@ -53,7 +53,7 @@ struct tum_ocp {
     double *dXS, *dxs0, *dApce, *dws2, *dpro, *ddv, *doffs;
     int *dxs_dirty; bool xs_lazy;          // sample copies of the stages > uph not yet frozen (snmpc_freeze_kernel)
     bool have_offs, fanout;        // sample initial conditions derived from the nominal x0 at every solve
-    int sn_cols;                   // prologue of the SNMPC OCP: -1 the library's choice, 1 column-per-lane, 0 column slots and passes (tum_ocp_set_kernel)
+    int sn_prologue;                   // prologue of the SNMPC OCP: -1 the library's choice, 2 the matrix-core kernel, 0 column slots and passes (tum_ocp_set_kernel)
     // R2NMPC tightening after every solve (tum_ocp_r2_attach)
     bool r2; int r2_uph; double r2_dmin, r2_dmax, r2_uh; double *dr2S, *dr2B;
     // per-stage parameter vector of the SNMPC OCP as the caller last set it (tum_ocp_set "p")
@@ -122,7 +122,7 @@ extern "C" tum_ocp *tum_ocp_create(const tum_ocp_desc *desc)
     tum_ocp *c = new tum_ocp();
     c->d = *desc; c->N = desc->N; c->batch = desc->batch; c->last_ms = 0; c->solved = false; c->epoch = 0;
     c->sn = false; c->dXS = c->dxs0 = c->dApce = c->dws2 = c->dpro = c->ddv = c->doffs = nullptr; c->dxs_dirty = nullptr; c->xs_lazy = false;
-    c->have_offs = c->fanout = false; c->sn_cols = -1;
+    c->have_offs = c->fanout = false; c->sn_prologue = -1;
     c->r2 = false; c->dr2S = c->dr2B = nullptr;
     c->p_dirty = false; c->uph_cap = 0; c->gamma = 0.0; c->dpceA = nullptr; c->pce_L = c->pce_S = 0; c->dbnd_snap = nullptr;
     c->dsum = nullptr; c->res_head = c->res_count = 0;
@@ -248,7 +248,7 @@ extern "C" void tum_ocp_free(tum_ocp *c)
 static size_t sn_prologue_lds(int uph, int ns, int want)
 {
     const int kind = sn_prologue_kind(uph, ns, want);
-    return kind == 2 ? sn_mfma_lds_doubles(uph, ns) : kind == 1 ? sn_cols_lds_doubles(uph, ns) : sn_prologue_lds_doubles(uph, ns, sn_prologue_variant(uph, ns));
+    return kind == 2 ? sn_mfma_lds_doubles(uph, ns) : sn_prologue_lds_doubles(uph, ns, sn_prologue_variant(uph, ns));
 }
 
 // Turn the capsule into the coupled SNMPC OCP: the stacked state is the nominal copy followed by `ns`
@@ -266,10 +266,9 @@ extern "C" int tum_ocp_snmpc_attach(tum_ocp *c, int ns, int L, const double *Apc
     if (c->d.store_qp_in) return fail("snmpc_attach: store_qp_in is not available for the stacked state");
     DevGuard guard(c->d.device); GUARD_OK(guard);
     {
-        const size_t lds = sizeof(double) * (sn_prologue_lds(uph, ns, c->sn_cols));
+        const size_t lds = sizeof(double) * (sn_prologue_lds(uph, ns, c->sn_prologue));
         if (lds > 128 * 1024) return fail("snmpc_attach: n_samples x uph too large for the prologue kernel's LDS");
-        HIPCHK(hipFuncSetAttribute((const void *)snmpc_prologue_cols_kernel<SN_COLS_NSW>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
-        HIPCHK(hipFuncSetAttribute((const void *)snmpc_prologue_mfma_kernel<SN_COLS_NSW>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
+        HIPCHK(hipFuncSetAttribute((const void *)snmpc_prologue_mfma_kernel<SN_MFMA_NSW, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
         HIPCHK(hipFuncSetAttribute((const void *)snmpc_prologue_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
         HIPCHK(hipFuncSetAttribute((const void *)snmpc_prologue_kernel<6>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
         HIPCHK(hipFuncSetAttribute((const void *)snmpc_prologue_kernel<9>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
@@ -367,7 +366,7 @@ static int sn_apply_p(tum_ocp *c)
         if (c->p_stop[k] != 1.0) return fail("solve: stop_flag pattern not supported: it must be 0 on the stages < uph and 1 from stage uph on (stage " + std::to_string(k) + " is 0 after a 1)");
     if (uph > N) uph = N;                      // no stop flag at all: the samples are propagated over the whole horizon
     if (uph > SN_UPHMAX) return fail("solve: uncertainty propagation horizon from the stop flags exceeds " + std::to_string(SN_UPHMAX));
-    if (sizeof(double) * (sn_prologue_lds(uph, ns, c->sn_cols)) > 128 * 1024)      // (the variant sn_launch_prologue will pick)
+    if (sizeof(double) * (sn_prologue_lds(uph, ns, c->sn_prologue)) > 128 * 1024)      // (the variant sn_launch_prologue will pick)
         return fail("solve: n_samples x uph too large for the prologue kernel's LDS");
     // (the hand-over buffer of the prologue is sized uph x sn_pro_stage(uph): its row pitch doubles beyond uph = 31)
     if (uph > c->uph_cap || (size_t)uph * sn_pro_stage(uph) > c->pro_cap) {
@@ -639,14 +638,14 @@ extern "C" int tum_ocp_set_kernel(tum_ocp *c, const char *name)
     const std::string n(name);
     if (n == "auto") c->kmode = 0;
     else if (n == "pipeline") c->kmode = 2;
-    // the prologue of the coupled SNMPC OCP: one column per lane (default where n_samples <= 10) or the column-slot / pass variants
-    else if (n == "prologue-cols" || n == "prologue-passes" || n == "prologue-mfma") {
+    // the prologue of the coupled SNMPC OCP: the matrix-core kernel (default where n_samples <= 10) or the column-slot / pass variants
+    else if (n == "prologue-passes" || n == "prologue-mfma") {
         if (c->sn) {
-            const int want = (n == "prologue-passes") ? 0 : (n == "prologue-cols") ? 1 : 2;
+            const int want = (n == "prologue-passes") ? 0 : 2;
             const size_t lds = sizeof(double) * sn_prologue_lds(c->sa.uph, c->sa.ns, want);
             if (lds > 128 * 1024) return fail("set_kernel: n_samples x uph too large for that prologue kernel's LDS");
         }
-        c->sn_cols = (n == "prologue-passes") ? 0 : (n == "prologue-cols") ? 1 : 2;
+        c->sn_prologue = (n == "prologue-passes") ? 0 : 2;
     }
 #ifdef TUM_DEV_KERNELS
     else if (n == "fused") c->kmode = 1;
@@ -655,7 +654,7 @@ extern "C" int tum_ocp_set_kernel(tum_ocp *c, const char *name)
     else if (n == "fused" || n == "pipeline4")
         return fail("set_kernel: kernel '" + n + "' exists in the development build only (libtumnmpc_dev.so); this library is the pipeline");
 #endif
-    else return fail("set_kernel: unknown kernel '" + n + "' (auto | pipeline | prologue-mfma | prologue-cols | prologue-passes; development build: fused | pipeline4)");
+    else return fail("set_kernel: unknown kernel '" + n + "' (auto | pipeline | prologue-mfma | prologue-passes; development build: fused | pipeline4)");
     c->epoch++;
     return 0;
 }
@@ -680,15 +679,11 @@ static int resolve_kernel(tum_ocp *c)
 // last stage) or, for short propagation horizons and beyond the largest instantiation, in LDS
 static void sn_launch_prologue(tum_ocp *c)
 {
-    const int kind = sn_prologue_kind(c->sa.uph, c->sa.ns, c->sn_cols);
+    const int kind = sn_prologue_kind(c->sa.uph, c->sa.ns, c->sn_prologue);
     if (kind == 2) {      // the column recursions on the matrix cores, the samples split over the two wavefronts of a workgroup
         const size_t lds = sizeof(double) * sn_mfma_lds_doubles(c->sa.uph, c->sa.ns);
-        hipLaunchKernelGGL((snmpc_prologue_mfma_kernel<SN_COLS_NSW>), dim3(c->batch), dim3(128), lds, c->stream, c->sa);
-        return;
-    }
-    if (kind == 1) {      // one column per lane, the samples split over the two wavefronts of a workgroup
-        const size_t lds = sizeof(double) * sn_cols_lds_doubles(c->sa.uph, c->sa.ns);
-        hipLaunchKernelGGL((snmpc_prologue_cols_kernel<SN_COLS_NSW>), dim3(c->batch), dim3(128), lds, c->stream, c->sa);
+        // (one wavefront with all ten samples instead: 178 spilled registers, 3.6 against 2.55 ms per solve at UPH = Tp)
+        hipLaunchKernelGGL((snmpc_prologue_mfma_kernel<SN_MFMA_NSW, 2>), dim3(c->batch), dim3(128), lds, c->stream, c->sa);
         return;
     }
     const int v = sn_prologue_variant(c->sa.uph, c->sa.ns);
@@ -1102,6 +1097,8 @@ extern "C" int tum_ocp_debug_dump(tum_ocp *c, int b, double *out, int len)
             o[6480 + (2 * (s - 1) + 1) * 80 + col] = (cc >= 2 * T) ? cw[(size_t)D::cidx(cc, T) * 64 + 16 * lq + (col & 15)] : 0.0;
         }
     for (int i = 0; i < 2 * N; i++) o[12880 + i] = vv[D::PV_D + i];
+    // (development aid: the tail of the dump area carries the phase cycle counters of the SNMPC prologue kernels, SnArgs::dbg)
+    HIPCHK(hipMemcpy(o.data() + 20000, c->ddbg + (size_t)b * DBG_STRIDE + 20000, sizeof(double) * (DBG_STRIDE - 20000), hipMemcpyDeviceToHost));
     memcpy(out, o.data(), sizeof(double) * len);
     return 0;
 }
