@@ -682,8 +682,10 @@ __global__ void __launch_bounds__(64, IPM_WPS) ipm_kernel(const PArgs pa)
                 for (int sd = 0; sd < 2; sd++) {
                     const int k = rr * 2 + sd;
                     const double s_ = ROWF(0, k), t_ = ROWF(1, k), l_ = ROWF(2, k), m_ = ROWF(3, k);
-                    ls = fmax(ls, on_ ? fabs(ROWF(4, k)) : 0.0);
-                    li = fmax(li, on_ ? fabs(ROWF(5, k)) : 0.0);
+                    // (a row side that does not exist keeps s = t = lam = mu = 1 and zero residuals from the initial point on -- its
+                    //  steps are masked through the step length below --, so its residuals need no mask here)
+                    ls = fmax(ls, fabs(ROWF(4, k)));
+                    li = fmax(li, fabs(ROWF(5, k)));
                     const double c1 = t_ * l_, c2 = s_ * m_;
                     lcmp = fmax(lcmp, on_ ? fmax(c1, c2) : 0.0);
                     lg += on_ ? c1 + c2 : 0.0;
@@ -1250,7 +1252,9 @@ __global__ void __launch_bounds__(64, IPM_WPS) ipm_kernel(const PArgs pa)
                     const double dsl = (dl - rsk - rc2 * is_) * iDs;
                     const double dm = (-rc2 - m_ * dsl) * is_;
                     const double dtt = (-rc1 - t_ * dl) * il_;
-                    dcur[0][k] = on_ ? dsl : 0.0; dcur[1][k] = on_ ? dtt : 0.0; dcur[2][k] = on_ ? dl : 0.0; dcur[3][k] = on_ ? dm : 0.0;
+                    // (the steps of a row side that does not exist are finite -- its state is all ones -- and never applied: its
+                    //  step length is zero below; only what enters a wave reduction or the corrector is masked)
+                    dcur[0][k] = dsl; dcur[1][k] = dtt; dcur[2][k] = dl; dcur[3][k] = dm;
                     double q = fmax(fmax(-dsl * is_, -dtt * it_), fmax(-dl * il_, -dm * im_));
                     q = on_ ? q : 0.0;
                     amax = fmax(amax, q);
@@ -1277,8 +1281,9 @@ __global__ void __launch_bounds__(64, IPM_WPS) ipm_kernel(const PArgs pa)
                     const double om_ = 1.0 - alpha;
 #pragma unroll
                     for (int k = 0; k < NS2; k++) {
+                        const double ak = on[k >> 1] ? alpha : 0.0;
 #pragma unroll
-                        for (int f = 0; f < 4; f++) ROWF(f, k) += alpha * dcur[f][k];
+                        for (int f = 0; f < 4; f++) ROWF(f, k) += ak * dcur[f][k];
                         ROWF(4, k) *= om_; ROWF(5, k) *= om_;
                     }
                 }
