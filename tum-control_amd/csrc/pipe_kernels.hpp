@@ -671,6 +671,10 @@ __global__ void __launch_bounds__(64, IPM_WPS) ipm_kernel(const PArgs pa)
         PIPE_LANE_DEFS
         // ---- row phase A: residual norms, gamma
         double gap;
+        // D, G of every row side, fixed for both solves of an iteration: the five-tile build computes them with gamma and HOLDS them
+        // across the factorisation (16 registers); the six-tile build, at the top of the register file, recomputes them behind it
+        constexpr bool HOLD_DG = (NT_ == 5) && (IPM_WPS == 1);
+        double rD[NS2], rG[NS2];
         {
             double ls = fmax(fabs(rv0), fabs(rv1)), li = 0.0, lcmp = 0.0, lg = 0.0;
             double gsum[SLOTS];
@@ -689,9 +693,11 @@ __global__ void __launch_bounds__(64, IPM_WPS) ipm_kernel(const PArgs pa)
                     const double c1 = t_ * l_, c2 = s_ * m_;
                     lcmp = fmax(lcmp, on_ ? fmax(c1, c2) : 0.0);
                     lg += on_ ? c1 + c2 : 0.0;
-                    // D = 1/(Z s + mu), G = 1/(t + lam s D): recomputed behind the factorisation rather than held across it
-                    const double D_ = frcp(pen(rr, sd, 1) * s_ + m_);
-                    gsum[rr] += l_ * frcp(t_ + l_ * s_ * D_);
+                    // D = 1/(Z s + mu), G = 1/(t + lam s D)  (rounds 2-3 recomputed them behind the factorisation everywhere -- eight
+                    // quarter-rate reciprocals with their Newton steps -- when the register file had no room)
+                    const double D_ = frcp(pen(rr, sd, 1) * s_ + m_), G_ = frcp(t_ + l_ * s_ * D_);
+                    if constexpr (HOLD_DG) { rD[k] = D_; rG[k] = G_; }
+                    gsum[rr] += l_ * G_;
                 }
             }
             res_stat = ls; res_ineq = li; res_comp = lcmp;
@@ -971,8 +977,7 @@ __global__ void __launch_bounds__(64, IPM_WPS) ipm_kernel(const PArgs pa)
 
         if (dmin_hi < 0x01a56e1f) { qp_status = 3; break; }          // a pivot below 1e-300 (or negative): the factorisation failed
         // ---- predictor / corrector
-        double rD[NS2], rG[NS2];   // D, G of every row side: fixed for both solves of this iteration
-        {
+        if constexpr (!HOLD_DG) {
             int lane_r = lane_outer;
             asm volatile("" : "+v"(lane_r));
             const int lane = lane_r;
