@@ -90,9 +90,10 @@ int tum_ocp_get(tum_ocp *c, int stage, const char *field, double *v, int len, in
 int tum_ocp_constraints_set(tum_ocp *c, int stage, const char *field, const double *v, int len, int b0, int nb, int stride);
 
 /* acados_solver.cost_set(stage, field, value)   NMPC_class.py:295-317
- * "W": ny*ny (stage<N: 36, stage N: 16) column-major, must be diagonal (the reference only installs
- * blockdiag(Q,R)). RESTRICTION: all stages < N share ONE W per instance (the reference sets them identically,
- * NMPC_class.py:295-296): cost_set at any stage < N overwrites the weight of all of them; stage-dependent W is not built.
+ * "W": ny*ny (stage<N: 36, stage N: 16) column-major, must be diagonal (the reference only installs blockdiag(Q,R) with
+ * diagonal Q, R). Per STAGE, as in acados: the reference sets every stage in a loop (NMPC_class.py:294-296), and a caller may
+ * give every stage its own weights. stage == TUM_ALL_STAGES with a 6 x 6 W: all the stages 0..N-1 in one call. (The development
+ * build's fused kernel reads stage 0's W for all stages < N; the shipped pipeline honours every stage.)
  * "zl","zu","Zl","Zu": 1 value at stage 0 [sbu], 3 at stages 1..N-1 [sbu,sbx,sh], 2 at stage N [sbx,sh]. */
 int tum_ocp_cost_set(tum_ocp *c, int stage, const char *field, const double *v, int len, int b0, int nb, int stride);
 

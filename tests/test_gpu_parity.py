@@ -38,7 +38,7 @@ def _set_params(s, p):
     W = np.zeros((B, 6, 6)); We = np.zeros((B, 4, 4))
     for j in range(B):
         W[j] = np.diag([p[j, 0], p[j, 0], p[j, 1], p[j, 2], p[j, 3], p[j, 4]]); We[j] = W[j][:4, :4]
-    s.cost_set(0, "W", W); s.cost_set(N, "W", We)
+    s.cost_set(-1, "W", W); s.cost_set(N, "W", We)          # (-1 = ALL_STAGES)
     for st, n in ((0, 1), (1, 3), (N, 2)):
         for f, col in (("zl", 5), ("zu", 5), ("Zl", 6), ("Zu", 6)):
             s.cost_set(st, f, np.repeat(p[:, col:col + 1], n, axis=1))
@@ -783,3 +783,64 @@ def test_exception_loops_per_solve_gpu(golden_dir):
     assert nexc == 30
     worst = [r for r in rep["logs"] if r["track"] == "monteblanco" and r["k"] == 21][0]
     assert any(e["step"] == 3852 for e in worst["exceptions"])
+
+
+@pytest.mark.parametrize("N", [38, 40, 45])
+def test_stage_dependent_weights_vs_oracle(golden_dir, N):
+    """acados honours cost_set(i, 'W', ...) per stage (the reference sets every stage in a loop, NMPC_class.py:294-296, always
+    with the same matrix). Here every stage gets its OWN diagonal weights, per instance: state weights growing along the horizon,
+    input weights alternating, a different pattern per instance -- cold start and two warm real-time iterations against the
+    oracle (whose W is per stage as well), N = 45 on the six-tile instantiation; then one W for all stages through
+    TUM_ALL_STAGES gives what the per-stage loop gives."""
+    from oracle.oracle import OracleOcp
+    from tum_control_amd import config
+    d = np.load(os.path.join(golden_dir, "kat0.npz"))
+    m = config.MPC
+    B = 3
+    s = _mk(N, B)
+    base = 0.01 * np.array([m["q_lon"], m["q_lon"], m["q_yaw"], m["q_vel"], m["r_jerk"], m["r_steering_rate"]])
+    Wst = np.zeros((B, N + 1, 6))
+    for j in range(B):
+        for k in range(N + 1):
+            f = np.array([1.0 + 0.03 * k * (j + 1), 1.0 + 0.02 * k, 1.0 + 0.5 * np.sin(0.3 * k + j), 1.0 + 0.04 * k,
+                          1.5 if (k + j) % 2 else 0.7, 1.0 + 0.25 * np.cos(0.5 * k)])
+            Wst[j, k] = base * f
+    for k in range(N):
+        s.cost_set(k, "W", np.stack([np.diag(Wst[j, k]) for j in range(B)]))
+    s.cost_set(N, "W", np.stack([np.diag(Wst[j, N, :4]) for j in range(B)]))
+    x0 = d["x0"][[0, 26, 30]].copy(); x0[1, 3:6] += [0.6, 0.1, 0.02]
+    yref = np.zeros((B, N + 1, 6))
+    for j, i in enumerate([0, 26, 30]):
+        yr = d["yref"][i]
+        yref[j, :min(N, 38) + 1, :4] = yr[:min(N, 38) + 1]
+        for k in range(39, N + 1):
+            yref[j, k, :4] = 2 * yref[j, k - 1, :4] - yref[j, k - 2, :4]
+    s.set_x0(x0); s.set_yref_all(yref); s.cold_start()
+    orcs = []
+    for j in range(B):
+        o = OracleOcp(N, 0.08, 3)
+        o.set_weights(m["q_lon"], m["q_yaw"], m["q_vel"], m["r_jerk"], m["r_steering_rate"], m["L1_pen"], m["L2_pen"], scale=0.01)
+        o.W[:] = Wst[j]; o.cold_start(x0[j]); o.yref[:] = yref[j]
+        orcs.append(o)
+    for it in range(3):
+        assert s.solve() == 0
+        X, U = s.get_iterate(); cost = s.get_cost()
+        for j, o in enumerate(orcs):
+            assert o.solve() == 0
+            np.testing.assert_allclose(U[j], o.U, rtol=1e-6, atol=1e-7, err_msg=f"U solve {it} inst {j}")
+            np.testing.assert_allclose(X[j], o.X, rtol=1e-6, atol=1e-7, err_msg=f"X solve {it} inst {j}")
+            np.testing.assert_allclose(cost[j], o.cost, rtol=1e-7)
+    # the weights really are stage dependent: with stage 0's weights on every stage the answer differs
+    s2 = _mk(N, B)
+    s2.cost_set(-1, "W", np.stack([np.diag(Wst[j, 0]) for j in range(B)]))
+    s2.cost_set(N, "W", np.stack([np.diag(Wst[j, N, :4]) for j in range(B)]))
+    s3 = _mk(N, B)
+    for k in range(N):
+        s3.cost_set(k, "W", np.stack([np.diag(Wst[j, 0]) for j in range(B)]))
+    s3.cost_set(N, "W", np.stack([np.diag(Wst[j, N, :4]) for j in range(B)]))
+    for q in (s2, s3):
+        q.set_x0(x0); q.set_yref_all(yref); q.cold_start(); assert q.solve() == 0
+    U2, U3 = s2.get_iterate()[1], s3.get_iterate()[1]
+    assert np.array_equal(U2, U3)
+    s.cold_start(); assert s.solve() == 0
+    assert np.abs(s.get_iterate()[1] - U2).max() > 1e-3

@@ -661,7 +661,7 @@ def test_gpu_coupled_snmpc_randomised(golden_dir, seed):
     s.install_reference_ocp()
     q = np.array([2.8, 0.4, 0.2, 38.1, 101.4]) * 0.01 * rng.uniform(0.3, 3.0, 5)
     W = np.diag([q[0], q[0], q[1], q[2], q[3], q[4]])
-    s.cost_set(0, "W", W); s.cost_set(N, "W", W[:4, :4])
+    s.cost_set(-1, "W", W); s.cost_set(N, "W", W[:4, :4])
     L1, L2 = float(rng.uniform(20, 200)), float(rng.uniform(2, 50))
     for st, n in ((0, 1), (1, 3), (N, 2)) if N > 1 else ((0, 1), (N, 2)):
         for f, v in (("zl", L1), ("zu", L1), ("Zl", L2), ("Zu", L2)):

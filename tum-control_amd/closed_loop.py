@@ -137,7 +137,7 @@ class ClosedLoopBatch:
         W = np.zeros((B, 6, 6))
         for j in range(B):
             W[j] = np.diag([p[j, 0], p[j, 0], p[j, 1], p[j, 2], p[j, 3], p[j, 4]])
-        s.cost_set(0, "W", W if B > 1 else W[0])
+        s.cost_set(-1, "W", W if B > 1 else W[0])          # (-1 = ALL_STAGES: the stages 0..N-1)
         s.cost_set(N, "W", W[:, :4, :4] if B > 1 else W[0, :4, :4])
         for st, n in ((0, 1), (1, 3), (N, 2)):
             for f, col in (("zl", 5), ("zu", 5), ("Zl", 6), ("Zu", 6)):

@@ -99,7 +99,8 @@ __global__ void __launch_bounds__(64, 1) nmpc_rti_kernel(const KArgs ka)
     double *gU = ka.U + (size_t)b * N * NU;
     const double *gx0 = ka.x0 + (size_t)b * NX;
     const double *gyref = ka.yref + (size_t)b * (N + 1) * 6;
-    const double *gW = ka.W + (size_t)b * 10;
+    // (the fused kernel takes ONE W for the stages < N: stage 0's; per-stage weights are a feature of the pipeline)
+    const double *gW = ka.W + (size_t)b * (N + 1) * 6;
     const double *gpen = ka.pen + (size_t)b * 36;
     const double *gbnd = ka.bnd + (size_t)b * 6 * (N + 1);
     const int uph = SN ? ka.uph : 0;
@@ -195,7 +196,7 @@ __global__ void __launch_bounds__(64, 1) nmpc_rti_kernel(const KArgs ka)
 #pragma unroll
     for (int i = 0; i < 6; i++) Wd[i] = gW[i];
 #pragma unroll
-    for (int i = 0; i < 4; i++) We[i] = gW[6 + i];
+    for (int i = 0; i < 4; i++) We[i] = gW[N * 6 + i];
 #pragma unroll
     for (int i = 0; i < NTT; i++) Ht[i] = d4{0.0, 0.0, 0.0, 0.0};
     {
@@ -936,7 +937,7 @@ __global__ void __launch_bounds__(64, 1) nmpc_rti_kernel(const KArgs ka)
         double tx[NXI], tw[NWI];
         gx0r = gx0[(lane < 8) ? lane : 0];                   // (used by the expansion and the cost below)
 #pragma unroll
-        for (int i = 0; i < 10; i++) Wc[i] = gW[i];
+        for (int i = 0; i < 10; i++) Wc[i] = (i < 6) ? gW[i] : gW[N * 6 + i - 6];
 #pragma unroll
         for (int i = 0; i < 6; i++) yrc[i] = gyref[((lane <= N) ? lane : 0) * 6 + i];
 #pragma unroll

@@ -47,7 +47,7 @@ template <int NT_> struct PD {
     static constexpr int SLOTS = (NT_ == 5) ? 2 : 3;
     static constexpr int PV_Q = 0, PV_D = NVP, PV_DV = 2 * NVP, PV_SC = 3 * NVP, PVEC = 3 * NVP + 16;   // q | d | dv | slack cost
     static constexpr int C_REC = 0, C_STAGE = 2 * PREC, C_GS = C_STAGE + 4 * NVP, C_U0 = C_GS + 8, C_CH = C_U0 + NVP,
-                         C_LDS = C_CH + NMAX * (NMAX + 1);
+                         C_WT = C_CH + NMAX * (NMAX + 1), C_LDS = C_WT + (NMAX + 1) * 6;      // (C_WT: the weights of every stage)
     static constexpr int E_REC = 0, E_X = 2 * PREC, E_U = E_X + (NMAX + 1) * NX, E_DV = E_U + NVP, E_LDS = E_DV + NVP;
     // interior point kernel: the small vectors first (the diagonal-block substitution reads up to 15 doubles in front of a
     // packed row with a zero multiplier: in front of row 0 that lands on them, finite data), then the KKT matrix
@@ -182,21 +182,22 @@ template <int NT_, bool SN>
 __global__ void __launch_bounds__(64, (NT_ == 5) ? 2 : 1) cond_kernel(const PArgs pa)
 {
     PD_LOCALS
-    constexpr int C_REC = D::C_REC, C_STAGE = D::C_STAGE, C_GS = D::C_GS, C_U0 = D::C_U0, C_CH = D::C_CH;
+    constexpr int C_REC = D::C_REC, C_STAGE = D::C_STAGE, C_GS = D::C_GS, C_U0 = D::C_U0, C_CH = D::C_CH, C_WT = D::C_WT;
     __shared__ __attribute__((aligned(16))) double lds[D::C_LDS];
     const KArgs &ka = pa.ka;
     const int lane = threadIdx.x, b = blockIdx.x;
     if (b >= ka.batch) return;
     const int N = ka.N, nv = 2 * N;
     const double dt = ka.dt;
-    double *sRec = lds + C_REC, *sStage = lds + C_STAGE, *sGs = lds + C_GS, *sU0 = lds + C_U0, *sCh = lds + C_CH;
+    double *sRec = lds + C_REC, *sStage = lds + C_STAGE, *sGs = lds + C_GS, *sU0 = lds + C_U0, *sCh = lds + C_CH, *sWt = lds + C_WT;
     const double *grec = pa.rec + (size_t)b * (N + 1) * PREC;
     const double *gx0 = ka.x0 + (size_t)b * NX;
     const double *gX = ka.X + (size_t)b * (N + 1) * NX;
     const double *gU = ka.U + (size_t)b * N * NU;
     const double *gyref = ka.yref + (size_t)b * (N + 1) * 6;
-    const double *gW = ka.W + (size_t)b * 10;
+    const double *gW = ka.W + (size_t)b * (N + 1) * 6;      // diagonal of W per stage (cost_set(i, 'W', ...), NMPC_class.py:294-296)
     double *gvec = pa.vec + (size_t)b * PVEC;
+    for (int i = lane; i < (N + 1) * 6; i += 64) sWt[i] = gW[i];
 
     // stage slot k & 1: fields 0..51 of record k (A_k, B_k, b_k), fields 52..60 of record k+1 (residuals, gg row, delta of stage k+1)
     auto fetch = [&](int k) -> double { return (lane < PR_RES) ? grec[(size_t)k * PREC + lane] : ((lane <= (SN ? PR_G4 : PR_XD)) ? grec[(size_t)(k + 1) * PREC + lane] : 0.0); };
@@ -215,11 +216,6 @@ __global__ void __launch_bounds__(64, (NT_ == 5) ? 2 : 1) cond_kernel(const PArg
     const int lq = lane >> 4, lc = lane & 15;
     double q0 = 0.0, q1 = 0.0;
     d4 Ht[NTT];
-    double Wd[6], We[4];
-#pragma unroll
-    for (int i = 0; i < 6; i++) Wd[i] = gW[i];
-#pragma unroll
-    for (int i = 0; i < 4; i++) We[i] = gW[6 + i];
 #pragma unroll
     for (int i = 0; i < NTT; i++) Ht[i] = d4{0.0, 0.0, 0.0, 0.0};
     {
@@ -307,7 +303,7 @@ __global__ void __launch_bounds__(64, (NT_ == 5) ? 2 : 1) cond_kernel(const PArg
             wsync();
             double wr[4];
 #pragma unroll
-            for (int r = 0; r < 4; r++) wr[r] = sc * ((s < N) ? Wd[r] : We[r]);
+            for (int r = 0; r < 4; r++) wr[r] = sc * sWt[s * 6 + r];          // (the stage's own weights; stage N: W_e)
             {
                 double a0 = 0.0, a1 = 0.0;
 #pragma unroll
@@ -350,16 +346,16 @@ __global__ void __launch_bounds__(64, (NT_ == 5) ? 2 : 1) cond_kernel(const PArg
             const int row = lq + 4 * jj;
             if (row == lc) {
                 const int idx = 16 * K + row;
-                Ht[tidx(K, K)][jj] += (idx < nv) ? dt * Wd[4 + (idx & 1)] : 1.0;
+                Ht[tidx(K, K)][jj] += (idx < nv) ? dt * sWt[(idx >> 1) * 6 + 4 + (idx & 1)] : 1.0;
             }
         }
-    if (lane < nv) q0 += dt * Wd[4 + r0] * (sU0[lane] - gyref[j0 * 6 + 4 + r0]);
+    if (lane < nv) q0 += dt * sWt[j0 * 6 + 4 + r0] * (sU0[lane] - gyref[j0 * 6 + 4 + r0]);
     {   // (the stage of a bank-1 column is recomputed from an opaque copy of the lane id: held since the top of the kernel it was the
         //  one value the register allocator sent to scratch)
         int lane_e = lane;
         asm volatile("" : "+v"(lane_e));
         const int j1e = 32 + (lane_e >> 1);
-        if (lane < NB1 && 64 + lane < nv) q1 += dt * Wd[4 + r0] * (sU0[64 + lane] - gyref[j1e * 6 + 4 + r0]);
+        if (lane < NB1 && 64 + lane < nv) q1 += dt * sWt[j1e * 6 + 4 + r0] * (sU0[64 + lane] - gyref[j1e * 6 + 4 + r0]);
     }
     // ---- hand-over: H tiles, q, the gg rows in MFMA operand layout (masked: entries right of a row's end are zero)
     {
@@ -403,7 +399,7 @@ __device__ __forceinline__ void expand_instance(const PArgs &pa, const int b, do
     double *gU = ka.U + (size_t)b * N * NU;
     const double *gx0 = ka.x0 + (size_t)b * NX;
     const double *gyref = ka.yref + (size_t)b * (N + 1) * 6;
-    const double *gW = ka.W + (size_t)b * 10;
+    const double *gW = ka.W + (size_t)b * (N + 1) * 6;
     const double *gvec = pa.vec + (size_t)b * PVEC;
     if (!FUSED) status = ka.status[b];
     const int uph = SN ? ka.uph : 0;
@@ -456,11 +452,11 @@ __device__ __forceinline__ void expand_instance(const PArgs &pa, const int b, do
     wsync();
     double cl = (lane == 0) ? (FUSED ? slack_cost : gvec[PV_SC]) : 0.0;      // slack part of the cost (interior point kernel)
     if (lane <= N) {
-        double Wd[6], We[4], yr[6];
+        double Wd[6], We[4], yr[6];          // the weights of this lane's stage
 #pragma unroll
-        for (int i = 0; i < 6; i++) { Wd[i] = gW[i]; yr[i] = gyref[lane * 6 + i]; }
+        for (int i = 0; i < 6; i++) { Wd[i] = gW[lane * 6 + i]; yr[i] = gyref[lane * 6 + i]; }
 #pragma unroll
-        for (int i = 0; i < 4; i++) We[i] = gW[6 + i];
+        for (int i = 0; i < 4; i++) We[i] = Wd[i];
         const int k = lane;
         const double sc = (k < N) ? dt : 1.0;
         double acc = 0.0, e;

@@ -135,7 +135,7 @@ extern "C" tum_ocp *tum_ocp_create(const tum_ocp_desc *desc)
     ok &= dalloc(&c->dU, B * N * NU) == hipSuccess;
     ok &= dalloc(&c->dx0, B * NX) == hipSuccess;
     ok &= dalloc(&c->dyref, B * (N + 1) * 6) == hipSuccess;
-    ok &= dalloc(&c->dW, B * 10) == hipSuccess;
+    ok &= dalloc(&c->dW, B * (size_t)(N + 1) * 6) == hipSuccess;          // diagonal of W per stage (stage N: the first 4 = W_e)
     ok &= dalloc(&c->dpen, B * 36) == hipSuccess;
     ok &= dalloc(&c->dbnd, B * 6 * (N + 1)) == hipSuccess;
     ok &= dalloc(&c->dcost, B) == hipSuccess;
@@ -575,21 +575,25 @@ extern "C" int tum_ocp_cost_set(tum_ocp *c, int stage, const char *field, const 
     if (!field || !v) return fail("null argument");
     const int N = c->N;
     const std::string f(field);
-    if (stage < 0 || stage > N) return fail("cost_set: stage out of range");
+    if ((stage < 0 || stage > N) && !(stage == TUM_ALL_STAGES && f == "W")) return fail("cost_set: stage out of range");
     if (f == "W") {
-        const int ny = (stage < N) ? TUM_NY : TUM_NYE;
+        // per stage, like acados (NMPC_class.py:294-296 sets every stage in a loop); stage == TUM_ALL_STAGES: one 6 x 6 W for all
+        // the stages 0..N-1 in one call
+        const bool all = stage == TUM_ALL_STAGES;
+        const int ny = (all || stage < N) ? TUM_NY : TUM_NYE;
         if (len != ny * ny) return fail("cost_set W: mismatching dimension");
         const int cnt = stride == 0 ? 1 : nb;
-        std::vector<double> diag((size_t)cnt * ny);
+        const int rep = all ? N : 1;
+        std::vector<double> diag((size_t)cnt * rep * ny);
         for (int i = 0; i < cnt; i++) {
             const double *Wm = v + (size_t)i * stride;
             for (int r = 0; r < ny; r++)
                 for (int q = 0; q < ny; q++) {
-                    if (r == q) diag[(size_t)i * ny + r] = Wm[r * ny + r];
+                    if (r == q) { for (int k = 0; k < rep; k++) diag[((size_t)i * rep + k) * ny + r] = Wm[r * ny + r]; }
                     else if (Wm[q * ny + r] != 0.0) return fail("cost_set W: only diagonal W supported");
                 }
         }
-        return put(c, c->dW, 10, stage < N ? 0 : 6, diag.data(), ny, b0, nb, stride == 0 ? 0 : ny);
+        return put(c, c->dW, (size_t)(N + 1) * 6, all ? 0 : (size_t)stage * 6, diag.data(), rep * ny, b0, nb, stride == 0 ? 0 : rep * ny);
     }
     int which = -1;
     if (f == "zl") which = 0; else if (f == "zu") which = 1; else if (f == "Zl") which = 2; else if (f == "Zu") which = 3;

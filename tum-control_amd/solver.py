@@ -249,7 +249,7 @@ class BatchedOcpSolver:
         replaces the weight of all of them."""
         v = np.asarray(value, dtype=np.float64)
         if field == "W":
-            ny = 6 if stage < self.N else 4
+            ny = 6 if (stage < self.N) else 4          # (stage == ALL_STAGES = -1: one 6 x 6 W for all the stages 0..N-1)
             if v.ndim == 3:     # (batch, ny, ny): column-major per instance (diagonal => same either way)
                 v = np.ascontiguousarray(v.transpose(0, 2, 1)).reshape(v.shape[0], ny * ny)
             else:
@@ -458,7 +458,7 @@ class BatchedOcpSolver:
         L2 = mpc["L2_pen"] if L2 is None else L2
         N = self.N
         W = np.zeros((6, 6)); W[:4, :4] = Q; W[4:, 4:] = R
-        self.cost_set(0, "W", w_scale * W)          # shared by all stages < N
+        self.cost_set(ALL_STAGES, "W", w_scale * W)          # the same W on every stage < N (per-stage: cost_set(i, "W", ...))
         self.cost_set(N, "W", w_scale * np.asarray(Qe))
         classes = ((0, 1), (1, 3), (N, 2)) if N > 1 else ((0, 1), (N, 2))
         for st, n in classes:                        # one representative stage per penalty class
