@@ -22,7 +22,15 @@ for n in names:
         s = sv.BatchedOcpSolver(N=N, batch=B, store_qp_in=False)
     finally:
         sv._default_path = old
-    s.install_reference_ocp(); s.set_x0(x0); s.set_yref_all(yref)
+    try:
+        s.install_reference_ocp()
+    except Exception:          # a library from before per-stage W (round 4): cost_set at stage 0 sets all stages there
+        sv.ALL_STAGES = 0
+        try:
+            s.install_reference_ocp()
+        finally:
+            sv.ALL_STAGES = -1
+    s.set_x0(x0); s.set_yref_all(yref)
     for _ in range(3):
         s.cold_start(); s.solve()
     sol.append(s)
