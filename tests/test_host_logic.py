@@ -236,12 +236,15 @@ def test_shipped_kernels_resource_budget():
     assert not any("nmpc_rti_kernel" in n or "ipm4_kernel" in n for n in rows), "development kernels in the shipped library"
     for name, (vgpr, agpr, sgpr_spill, vgpr_spill, scratch, lds, occ) in rows.items():
         assert sgpr_spill <= 64, (name, sgpr_spill)
-        assert scratch <= 128, (name, scratch)
+        # no scratch anywhere in the five-tile (N <= 40) build -- the condensing kernel's 52 B of rounds 2-3 are gone --; the
+        # six-tile interior point kernel (N = 41..48, the whole register file and then some) keeps a few dozen bytes
+        assert scratch == 0 or ("ipm_kernel<false, 6" in name and scratch <= 64), (name, scratch)
         assert vgpr + agpr <= 512 and lds <= 40 * 1024, name
     for name in ("ipm_kernel<false, 5, true>", "ipm_kernel<false, 5, false>"):      # headline: the expansion fused into its tail; SNMPC: without
         ipm = kernel(name)
         assert ipm[2:5] == [0, 0, 0] and ipm[6] == 1, (name, ipm)
-    assert kernel("cond_kernel<5, false>")[6] == 2          # two wavefronts per SIMD
+    cond = kernel("cond_kernel<5, false>")
+    assert cond[2:5] == [0, 0, 0] and cond[6] == 2          # no spills, two wavefronts per SIMD
 
 
 def test_no_cpu_fallback():

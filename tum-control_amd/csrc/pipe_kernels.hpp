@@ -46,8 +46,11 @@ template <int NT_> struct PD {
     // the lanes 40..59); more tiles: three slots on the lanes 0..N-1 (box of stage l, steering and gg row of stage l+1)
     static constexpr int SLOTS = (NT_ == 5) ? 2 : 3;
     static constexpr int PV_Q = 0, PV_D = NVP, PV_DV = 2 * NVP, PV_SC = 3 * NVP, PVEC = 3 * NVP + 16;   // q | d | dv | slack cost
-    static constexpr int C_REC = 0, C_STAGE = 2 * PREC, C_GS = C_STAGE + 4 * NVP, C_U0 = C_GS + 8, C_CH = C_U0 + NVP,
-                         C_WT = C_CH + NMAX * (NMAX + 1), C_LDS = C_WT + (NMAX + 1) * 6;      // (C_WT: the weights of every stage)
+    // (C_WT: the weights of every stage; C_PARK: the Hessian tiles of the last block column wait here between the stages of the
+    //  last segment -- d4 per lane and tile)
+    static constexpr int C_NPARK = 3;
+    static constexpr int C_REC = 0, C_STAGE = 2 * PREC, C_GS = C_STAGE + 4 * NVP, C_U0 = C_GS + 8,
+                         C_WT = C_U0 + NVP, C_PARK = (C_WT + (NMAX + 1) * 6 + 1) & ~1, C_LDS = C_PARK + C_NPARK * 256;
     static constexpr int E_REC = 0, E_X = 2 * PREC, E_U = E_X + (NMAX + 1) * NX, E_DV = E_U + NVP, E_LDS = E_DV + NVP;
     // interior point kernel: the small vectors first (the diagonal-block substitution reads up to 15 doubles in front of a
     // packed row with a zero multiplier: in front of row 0 that lands on them, finite data), then the KKT matrix
@@ -182,14 +185,14 @@ template <int NT_, bool SN>
 __global__ void __launch_bounds__(64, (NT_ == 5) ? 2 : 1) cond_kernel(const PArgs pa)
 {
     PD_LOCALS
-    constexpr int C_REC = D::C_REC, C_STAGE = D::C_STAGE, C_GS = D::C_GS, C_U0 = D::C_U0, C_CH = D::C_CH, C_WT = D::C_WT;
+    constexpr int C_REC = D::C_REC, C_STAGE = D::C_STAGE, C_GS = D::C_GS, C_U0 = D::C_U0, C_WT = D::C_WT;
     __shared__ __attribute__((aligned(16))) double lds[D::C_LDS];
     const KArgs &ka = pa.ka;
     const int lane = threadIdx.x, b = blockIdx.x;
     if (b >= ka.batch) return;
     const int N = ka.N, nv = 2 * N;
     const double dt = ka.dt;
-    double *sRec = lds + C_REC, *sStage = lds + C_STAGE, *sGs = lds + C_GS, *sU0 = lds + C_U0, *sCh = lds + C_CH, *sWt = lds + C_WT;
+    double *sRec = lds + C_REC, *sStage = lds + C_STAGE, *sGs = lds + C_GS, *sU0 = lds + C_U0, *sWt = lds + C_WT;
     const double *grec = pa.rec + (size_t)b * (N + 1) * PREC;
     const double *gx0 = ka.x0 + (size_t)b * NX;
     const double *gX = ka.X + (size_t)b * (N + 1) * NX;
@@ -218,6 +221,10 @@ __global__ void __launch_bounds__(64, (NT_ == 5) ? 2 : 1) cond_kernel(const PArg
     d4 Ht[NTT];
 #pragma unroll
     for (int i = 0; i < NTT; i++) Ht[i] = d4{0.0, 0.0, 0.0, 0.0};
+    if constexpr (NT_ == 5) {
+#pragma unroll
+        for (int K = 0; K < D::C_NPARK; K++) reinterpret_cast<d4 *>(lds + D::C_PARK)[K * 64 + lane] = d4{0.0, 0.0, 0.0, 0.0};
+    }
     {
         double w0[8], w1[8];
 #pragma unroll
@@ -290,8 +297,16 @@ __global__ void __launch_bounds__(64, (NT_ == 5) ? 2 : 1) cond_kernel(const PArg
                 gvec[PV_D + 2 * (s - 1)] = rec[PR_XD] + w1[6];
                 gvec[PV_D + 2 * (s - 1) + 1] = hd + hr1;
             }
-            if (lane < 2 * s) sCh[hoff(s) + lane] = hr0;
-            if (lane < NB1 && 64 + lane < 2 * s) sCh[hoff(s) + 64 + lane] = hr1;
+            // the gg row of stage s goes straight to the workspace in the MFMA operand layout the interior point kernel loads it in:
+            // row s = 4 c + lq + 1 of chunk c, the 16 columns of tile T at cidx(c, T) -- one store per bank; the columns right of the
+            // row's end hold zeros already. (Rounds 2-3 staged all rows in LDS, 13 KB, and re-laid them out behind the last stage.)
+            {
+                const int c_ = (s - 1) >> 2;
+                double *gcs = pa.cws + (size_t)b * NCH * 64 + 16 * ((s - 1) & 3) + lc;
+                if (2 * lq <= c_) gcs[cidx(c_, lq) * 64] = hr0;
+                const int T1 = 4 + lq;
+                if (lane < NB1 && 2 * T1 <= c_) gcs[cidx(c_, T1) * 64] = hr1;
+            }
 #pragma unroll
             for (int r = 0; r < 3; r++) sStage[r * NVP + lane] = w0[r];
             sStage[3 * NVP + lane] = c30;
@@ -319,11 +334,21 @@ __global__ void __launch_bounds__(64, (NT_ == 5) ? 2 : 1) cond_kernel(const PArg
             double bop[Ts];
 #pragma unroll
             for (int T = 0; T < Ts; T++) bop[T] = sStage[lq * NVP + 16 * T + lc];
+            // Last segment of the five-tile build: all 15 tiles are live and the register allocator sent one of them to scratch and back
+            // in every stage. The first C_NPARK tiles of the last block column -- touched by this segment only -- wait in LDS between
+            // the stages instead (the LDS the staged gg rows used to take): loaded, updated, stored again.
+            constexpr bool PARK = (NT_ == 5) && (Ts == NT_);
+            d4 *sPark = reinterpret_cast<d4 *>(lds + D::C_PARK) + lane;
 #pragma unroll
             for (int K = 0; K < Ts; K++) {
                 const double aop = bop[K] * wl;          // (one weighted operand at a time: five of them held were the registers the last segment lacked)
 #pragma unroll
-                for (int I = K; I < Ts; I++) Ht[tidx(K, I)] = mfma(aop, bop[I], Ht[tidx(K, I)]);
+                for (int I = K; I < Ts; I++) {
+                    if constexpr (PARK) {
+                        if (I == NT_ - 1 && K < D::C_NPARK) { sPark[K * 64] = mfma(aop, bop[I], sPark[K * 64]); continue; }
+                    }
+                    Ht[tidx(K, I)] = mfma(aop, bop[I], Ht[tidx(K, I)]);
+                }
             }
             // next stage's record into the other slot (its global load has been in flight for a whole stage)
             sRec[((k + 1) & 1) * PREC + lane] = pre;
@@ -335,8 +360,17 @@ __global__ void __launch_bounds__(64, (NT_ == 5) ? 2 : 1) cond_kernel(const PArg
             constexpr int Ts = decltype(tsc)::value;
             for (int k = 8 * (Ts - 1); k < N && k < 8 * Ts; k++) stage_body(k, tsc);
         });
-        for (int s = N + 1; s <= NMAX; s++)
-            for (int c = lane; c < 2 * s; c += 64) sCh[hoff(s) + c] = 0.0;
+        for (int s = N + 1; s <= NMAX; s++) {          // rows beyond the horizon: zeros
+            const int c_ = (s - 1) >> 2;
+            double *gcs = pa.cws + (size_t)b * NCH * 64 + 16 * ((s - 1) & 3) + lc;
+            if (2 * lq <= c_) gcs[cidx(c_, lq) * 64] = 0.0;
+            const int T1 = 4 + lq;
+            if (lane < NB1 && 2 * T1 <= c_) gcs[cidx(c_, T1) * 64] = 0.0;
+        }
+    }
+    if constexpr (NT_ == 5) {      // (the parked tiles come back)
+#pragma unroll
+        for (int K = 0; K < D::C_NPARK; K++) Ht[tidx(K, NT - 1)] = reinterpret_cast<d4 *>(lds + D::C_PARK)[K * 64 + lane];
     }
     // input cost (R) and padding on the diagonal, gradient of the input cost
 #pragma unroll
@@ -357,26 +391,13 @@ __global__ void __launch_bounds__(64, (NT_ == 5) ? 2 : 1) cond_kernel(const PArg
         const int j1e = 32 + (lane_e >> 1);
         if (lane < NB1 && 64 + lane < nv) q1 += dt * sWt[j1e * 6 + 4 + r0] * (sU0[64 + lane] - gyref[j1e * 6 + 4 + r0]);
     }
-    // ---- hand-over: H tiles, q, the gg rows in MFMA operand layout (masked: entries right of a row's end are zero)
+    // ---- hand-over: H tiles, q (the gg rows went out stage by stage)
     {
         d4 *gh = reinterpret_cast<d4 *>(pa.hws) + (size_t)b * NTT * 64 + lane;
 #pragma unroll
         for (int t = 0; t < NTT; t++) gh[t * 64] = Ht[t];
         gvec[PV_Q + lane] = q0;
         if (lane < NB1) gvec[PV_Q + 64 + lane] = q1;
-        wsync();
-        __builtin_amdgcn_sched_barrier(0);       // (the reads below are not to be requested while the 15 tiles are still waiting to go out)
-        double *gc = pa.cws + (size_t)b * NCH * 64 + lane;
-#pragma unroll
-        for (int T = 0; T < NT; T++) {
-#pragma unroll
-            for (int c = 2 * T; c < NC; c++) {
-                const int s = 4 * c + lq + 1;
-                const double v = sCh[hoff(s) + 16 * T + lc];
-                gc[cidx(c, T) * 64] = (c >= 2 * T + 2) ? v : ((16 * T + lc < 2 * s) ? v : 0.0);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-        }
     }
 }
 
