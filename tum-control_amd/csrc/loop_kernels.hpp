@@ -46,14 +46,27 @@ __global__ void __launch_bounds__(64) planner_kernel(const double *track, int n,
         if (od < best || (od == best && oi < bi)) { best = od; bi = oi; }
     }
     const int i0 = bi;
-    // ---- walk forward (wave-uniform): indices are consecutive modulo n
-    int m = 1, cur = i0; double T = 0.0; bool over = false;
-    while (T <= Tp) {
-        int nxt = cur + 1;
-        if (nxt >= n) { if (!loop_circuit) break; nxt = 0; }
-        T += hypot(track[4 * nxt] - track[4 * cur], track[4 * nxt + 1] - track[4 * cur + 1]) / track[4 * nxt + 3];
-        cur = nxt; m++;
-        if (m >= PLAN_MAXM) { over = true; break; }
+    // ---- walk forward: indices are consecutive modulo n. The travel times of the next 64 segments are computed by the 64 lanes at
+    // once (loads, hypot, division in parallel); the running sum and its termination test stay SEQUENTIAL and wave-uniform, in the
+    // reference's order of additions (T = ((0 + s0) + s1) + ...: the number of points m must not depend on a summation order).
+    // (One lane walking the line paid a dependent global load per point: 15 of this kernel's 21 us in the small-batch loops.)
+    int m = 1; double T = 0.0; bool over = false;
+    {
+        auto wrap = [&](int i) -> int { return (i >= n) ? i - n * (i / n) : i; };
+        bool done = false;
+        for (int base = 0; !done; base += 64) {
+            const int ia = i0 + base + lane, ib = ia + 1;
+            const bool ok = loop_circuit || ib < n;
+            const int pa = wrap(ia), pb = ok ? wrap(ib) : pa;
+            const double seg = hypot(track[4 * pb] - track[4 * pa], track[4 * pb + 1] - track[4 * pa + 1]) / track[4 * pb + 3];
+            for (int j = 0; j < 64; j++) {
+                if (!(T <= Tp)) { done = true; break; }
+                if (!loop_circuit && i0 + base + j + 1 >= n) { done = true; break; }
+                T += rl(seg, j);
+                m++;
+                if (m >= PLAN_MAXM) { over = true; done = true; break; }
+            }
+        }
     }
     if (over && lane == 0 && err) atomicOr(err, 1);
     auto at = [&](int j) -> int { int i = i0 + j; return (i >= n) ? i - n * (i / n) : i; };
