@@ -148,9 +148,21 @@ struct PlantModel {
     double fr0, fr1, fr4;
 };
 
-// Same formulas as the reference's plant, arranged for a short instruction stream (this kernel is one thread's latency
-// per instance): constants folded on the host, one reciprocal of vlong, sincos, cos(asin(G)) = sqrt(1 - G^2).
-__device__ __forceinline__ void plant_xdot(const PlantModel &p, const double x[7], double a, double sr, double xd[7])
+// Same formulas as the reference's plant, arranged for a short instruction stream: this kernel is ONE pass of latency per
+// control step (16 model evaluations in sequence), so what counts is the number of instructions a wavefront issues per
+// evaluation. Four lanes (a DPP quad) serve one vehicle and split the transcendental chains of the model between them:
+//   role 0  front tyre: slip angle (atan), magic formula (atan, atan, sin), friction-circle factor (sqrt)
+//   role 1  rear tyre:  the same chain with the rear constants
+//   role 2  sin / cos of the yaw angle          role 3  sin / cos of the steering angle
+// Every lane runs the SAME instructions (the tyre chain on roles 2, 3 works on the front / rear operands again and its
+// result is ignored; the one sincos serves the magic formula on roles 0, 1 and the angles on roles 2, 3), the four results
+// are exchanged by DPP quad broadcasts and the cheap remainder is computed redundantly by all four. Three atan, one sincos
+// and one sqrt per evaluation instead of six, four and two; every number is produced by the same operations on the same
+// operands as with one lane per vehicle (constants folded on the host, one reciprocal of vlong, cos(asin(G)) = sqrt(1 - G^2)).
+struct PlantLane { double B, C, D, E, invFmax; bool front; int role; };
+template <int K> __device__ __forceinline__ double quad_bcast(double v) { return dpp0_f64<0x55 * K>(v); }
+
+__device__ __forceinline__ void plant_xdot(const PlantModel &p, const PlantLane &t, const double x[7], double a, double sr, double xd[7])
 {
     const double yaw = x[2], vl = x[3], vt = x[4], r = x[5], de = x[6];
     const double w = 0.036 * sqrt(vl * vl + vt * vt);          // v[km/h] / 100
@@ -158,22 +170,21 @@ __device__ __forceinline__ void plant_xdot(const PlantModel &p, const double x[7
     const double fr = p.fr0 + p.fr1 * w + p.fr4 * w2 * w2;
     const double Fx_f = -fr * p.Fz_f;
     const double Fx_r = p.m * a - fr * p.Fz_r;
-    double al_f = 0.0, al_r = 0.0;
+    double al = 0.0;
     if (vl > 0.001) {
         const double ivl = 1.0 / vl;
-        al_f = de - fast_atan((vt + p.lf * r) * ivl);
-        al_r = fast_atan((p.lr * r - vt) * ivl);
+        const double nf = vt + p.lf * r, nr = p.lr * r - vt;
+        const double at = fast_atan((t.front ? nf : nr) * ivl);
+        al = t.front ? de - at : at;
     }
-    const double xf = p.Bf * al_f, xr = p.Br * al_r;
-    double sf, sr_, unused;
-    fast_sincos(p.Cf * fast_atan(xf - p.Ef * (xf - fast_atan(xf))), &sf, &unused);
-    fast_sincos(p.Cr * fast_atan(xr - p.Er * (xr - fast_atan(xr))), &sr_, &unused);
-    const double Fy_f_lat = p.Df * sf, Fy_r_lat = p.Dr * sr_;
-    const double Gf = fmin(fmax(Fx_f * p.invFmax_f, -0.98), 0.98), Gr = fmin(fmax(Fx_r * p.invFmax_r, -0.98), 0.98);
-    const double Fy_f = Fy_f_lat * fast_sqrt_pos(1.0 - Gf * Gf), Fy_r = Fy_r_lat * fast_sqrt_pos(1.0 - Gr * Gr);
-    double sy, cy, sd, cd;
-    fast_sincos(yaw, &sy, &cy);
-    fast_sincos(de, &sd, &cd);
+    const double xx = t.B * al;
+    const double th = fast_atan(xx - t.E * (xx - fast_atan(xx)));
+    double sn, cs;
+    fast_sincos(t.role < 2 ? t.C * th : (t.role == 2 ? yaw : de), &sn, &cs);
+    const double G = fmin(fmax((t.front ? Fx_f : Fx_r) * t.invFmax, -0.98), 0.98);
+    const double Fy = (t.D * sn) * fast_sqrt_pos(1.0 - G * G);
+    const double Fy_f = quad_bcast<0>(Fy), Fy_r = quad_bcast<1>(Fy);
+    const double sy = quad_bcast<2>(sn), cy = quad_bcast<2>(cs), sd = quad_bcast<3>(sn), cd = quad_bcast<3>(cs);
     const double front = Fy_f * cd + Fx_f * sd;
     xd[0] = vl * cy - vt * sy;
     xd[1] = vl * sy + vt * cy;
@@ -199,23 +210,32 @@ struct SimArgs {
     double *lCiLX, *lSimX, *lU, *lREF, *lDBG;         // logs (nullable): (cap+1,B,7) (cap+1,B,8) (cap,B,2) (cap,B,4) (cap,B,5)
 };
 
-// One thread per instance: simMode 0 of sim_step. The plant takes the predicted acceleration of stage 1 and the steering
-// rate of stage 0, integrates Ts with classic RK4 in n_elem equal sub-steps; the estimator is a per-state moving average
-// over the last win[i] samples (fewer while the buffer fills); the filtered state becomes the next x0 of the OCP.
+// Four lanes per instance (see plant_xdot): simMode 0 of sim_step. The plant takes the predicted acceleration of stage 1
+// and the steering rate of stage 0, integrates Ts with classic RK4 in n_elem equal sub-steps; the estimator is a per-state
+// moving average over the last win[i] samples (fewer while the buffer fills); the filtered state becomes the next x0 of
+// the OCP. The four lanes of an instance share the stores (estimator states i = role, role + 4; one log each; the stages
+// k = role mod 4 of a re-initialisation).
+constexpr int PLANT_LANES = 4;
 __global__ void __launch_bounds__(64) plant_advance_kernel(const SimArgs sa)
 {
 #pragma clang fp contract(off)
-    const int b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b >= sa.batch) return;
+    const int gl = blockIdx.x * blockDim.x + threadIdx.x;
+    // lanes past the batch stay in the kernel (DPP reads of a quad never cross instances; they only repeat the last one's loads)
+    const bool live = (gl >> 2) < sa.batch;
+    const int b = live ? (gl >> 2) : sa.batch - 1, role = gl & 3;
     const int N = sa.N, B = sa.batch;
     const int step = sa.step_counter[0];              // control steps done before this one
+    PlantLane tl;
+    tl.role = role; tl.front = !(role & 1);
+    tl.B = tl.front ? sa.pm.Bf : sa.pm.Br; tl.C = tl.front ? sa.pm.Cf : sa.pm.Cr; tl.D = tl.front ? sa.pm.Df : sa.pm.Dr;
+    tl.E = tl.front ? sa.pm.Ef : sa.pm.Er; tl.invFmax = tl.front ? sa.pm.invFmax_f : sa.pm.invFmax_r;
     double x1[8], u0[2];
 #pragma unroll
     for (int i = 0; i < 8; i++) x1[i] = sa.X[((size_t)b * (N + 1) + 1) * NX + i];
     u0[0] = sa.U[(size_t)b * N * NU]; u0[1] = sa.U[(size_t)b * N * NU + 1];
     const double a_in = x1[7], sr_in = u0[1];
     const int st_b = sa.status[b];
-    if (st_b != 0) {
+    if (st_b != 0 && live) {
         // main.py:59-61: a failed solve is followed by MPC.reintialize_solver(x_next) -- a FRESH solver, cold-started at the
         // state the failed solve started from (x_k = x0 for all k, u = 0; NMPC_class.py:256-267), with the nominal bounds
         // (R2NMPC: the tightening of the previous solves is gone) and the sample copies at their initial conditions (SNMPC).
@@ -224,16 +244,16 @@ __global__ void __launch_bounds__(64) plant_advance_kernel(const SimArgs sa)
         double xv[8];
 #pragma unroll
         for (int i = 0; i < 8; i++) xv[i] = xo[i];
-        for (int k = 0; k <= N; k++)
+        for (int k = role; k <= N; k += PLANT_LANES)
 #pragma unroll
             for (int i = 0; i < 8; i++) sa.X[((size_t)b * (N + 1) + k) * NX + i] = xv[i];
-        for (int i = 0; i < N * NU; i++) sa.U[(size_t)b * N * NU + i] = 0.0;
+        for (int i = role; i < N * NU; i += PLANT_LANES) sa.U[(size_t)b * N * NU + i] = 0.0;
         if (sa.ns > 0)
-            for (int k = 0; k <= N; k++)
+            for (int k = role; k <= N; k += PLANT_LANES)
                 for (int i = 0; i < sa.ns * NX; i++) sa.XS[((size_t)b * (N + 1) + k) * sa.ns * NX + i] = sa.xs0[(size_t)b * sa.ns * NX + i];
         if (sa.r2) {
             double *bb = sa.bnd + (size_t)b * 6 * (N + 1);
-            for (int k = 1; k < N; k++) { bb[2 * (N + 1) + k] = sa.r2_dmin; bb[3 * (N + 1) + k] = sa.r2_dmax; bb[5 * (N + 1) + k] = sa.r2_uh; }
+            for (int k = 1 + role; k < N; k += PLANT_LANES) { bb[2 * (N + 1) + k] = sa.r2_dmin; bb[3 * (N + 1) + k] = sa.r2_dmax; bb[5 * (N + 1) + k] = sa.r2_uh; }
         }
     }
     double x[7];
@@ -254,37 +274,51 @@ __global__ void __launch_bounds__(64) plant_advance_kernel(const SimArgs sa)
             double t[7], k[7];
 #pragma unroll
             for (int i = 0; i < 7; i++) t[i] = (st == 0) ? x[i] : x[i] + ci * h * kprev[i];
-            plant_xdot(sa.pm, t, a_in, sr_in, k);
+            plant_xdot(sa.pm, tl, t, a_in, sr_in, k);
 #pragma unroll
             for (int i = 0; i < 7; i++) { acc[i] = (st == 0) ? k[i] : acc[i] + wi * k[i]; kprev[i] = k[i]; }
         }
 #pragma unroll
         for (int i = 0; i < 7; i++) x[i] = x[i] + h / 6.0 * acc[i];
     }
+    if (live) {
+        if (role == 0) {
 #pragma unroll
-    for (int i = 0; i < 7; i++) sa.x_sim[(size_t)b * 7 + i] = x[i];
-    sa.pose[(size_t)b * 2] = x[0]; sa.pose[(size_t)b * 2 + 1] = x[1];
-    // state estimation: sample number k (1-based) goes to ring slot (k-1) & 3
-    const int k = step + 1;
+            for (int i = 0; i < 7; i++) sa.x_sim[(size_t)b * 7 + i] = x[i];
+            sa.pose[(size_t)b * 2] = x[0]; sa.pose[(size_t)b * 2 + 1] = x[1];
+        }
+        // state estimation: sample number k (1-based) goes to ring slot (k-1) & 3; this lane filters states role and role + 4
+        const int k = step + 1;
 #pragma unroll
-    for (int i = 0; i < 8; i++) {
-        const double v = (i < 7) ? x[i] : a_in;
-        double *hst = sa.hist + ((size_t)b * 8 + i) * 4;
-        hst[(k - 1) & 3] = v;
-        const int cnt = (sa.win[i] < k) ? sa.win[i] : k;
-        double s = hst[(k - cnt) & 3];
-        for (int t = k - cnt + 1; t < k; t++) s = s + hst[t & 3];
-        sa.x0[(size_t)b * NX + i] = s / (double)cnt;
-    }
-    if (sa.lCiLX && step < sa.log_cap) {
-        const size_t s = step;
+        for (int j = 0; j < 2; j++) {
+            const int i = role + 4 * j;
+            double v = a_in;
 #pragma unroll
-        for (int i = 0; i < 7; i++) sa.lCiLX[((s + 1) * B + b) * 7 + i] = x[i];
-        for (int i = 0; i < 8; i++) sa.lSimX[((s + 1) * B + b) * 8 + i] = x1[i];
-        sa.lU[(s * B + b) * 2] = u0[0]; sa.lU[(s * B + b) * 2 + 1] = u0[1];
-        for (int i = 0; i < 4; i++) sa.lREF[(s * B + b) * 4 + i] = sa.ref0[(size_t)b * 4 + i];
-        double *d = sa.lDBG + (s * B + b) * 5;
-        d[0] = sa.cost[b]; d[1] = 0.0; d[2] = 1.0; d[3] = (double)sa.qp_iter[b]; d[4] = (double)st_b;
+            for (int q = 0; q < 7; q++) v = (i == q) ? x[q] : v;
+            double *hst = sa.hist + ((size_t)b * 8 + i) * 4;
+            hst[(k - 1) & 3] = v;
+            const int wn = (role == 0) ? sa.win[4 * j] : (role == 1) ? sa.win[4 * j + 1] : (role == 2) ? sa.win[4 * j + 2] : sa.win[4 * j + 3];
+            const int cnt = (wn < k) ? wn : k;
+            double s = (cnt == 1) ? v : hst[(k - cnt) & 3];
+            for (int t = k - cnt + 1; t < k; t++) s = s + ((t == k - 1) ? v : hst[t & 3]);
+            sa.x0[(size_t)b * NX + i] = s / (double)cnt;
+        }
+        if (sa.lCiLX && step < sa.log_cap) {
+            const size_t s = step;
+            if (role == 0) {
+#pragma unroll
+                for (int i = 0; i < 7; i++) sa.lCiLX[((s + 1) * B + b) * 7 + i] = x[i];
+            } else if (role == 1) {
+#pragma unroll
+                for (int i = 0; i < 8; i++) sa.lSimX[((s + 1) * B + b) * 8 + i] = x1[i];
+            } else if (role == 2) {
+                sa.lU[(s * B + b) * 2] = u0[0]; sa.lU[(s * B + b) * 2 + 1] = u0[1];
+                for (int i = 0; i < 4; i++) sa.lREF[(s * B + b) * 4 + i] = sa.ref0[(size_t)b * 4 + i];
+            } else {
+                double *d = sa.lDBG + (s * B + b) * 5;
+                d[0] = sa.cost[b]; d[1] = 0.0; d[2] = 1.0; d[3] = (double)sa.qp_iter[b]; d[4] = (double)st_b;
+            }
+        }
     }
     // the last block to get here closes the control step (every block has read the counter by then)
     if (threadIdx.x == 0) {

@@ -1418,7 +1418,7 @@ extern "C" int tum_sim_advance(tum_sim *s)
     sa.bnd = c->dbnd; sa.r2 = c->r2 ? 1 : 0; sa.r2_dmin = c->r2_dmin; sa.r2_dmax = c->r2_dmax; sa.r2_uh = c->r2_uh;
     sa.x_sim = s->dxsim; sa.x0 = c->dx0; sa.pose = s->dpose; sa.hist = s->dhist; sa.ref0 = s->dref0;
     sa.lCiLX = s->lCiLX; sa.lSimX = s->lSimX; sa.lU = s->lU; sa.lREF = s->lREF; sa.lDBG = s->lDBG;
-    hipLaunchKernelGGL(plant_advance_kernel, dim3((c->batch + 63) / 64), dim3(64), 0, c->stream, sa);
+    hipLaunchKernelGGL(plant_advance_kernel, dim3((c->batch * PLANT_LANES + 63) / 64), dim3(64), 0, c->stream, sa);
     HIPCHK(hipGetLastError());
     s->step++;
     return 0;
