@@ -160,7 +160,6 @@ struct PlantModel {
 // and one sqrt per evaluation instead of six, four and two; every number is produced by the same operations on the same
 // operands as with one lane per vehicle (constants folded on the host, one reciprocal of vlong, cos(asin(G)) = sqrt(1 - G^2)).
 struct PlantLane { double B, C, D, E, invFmax; bool front; int role; };
-template <int K> __device__ __forceinline__ double quad_bcast(double v) { return dpp0_f64<0x55 * K>(v); }
 
 __device__ __forceinline__ void plant_xdot(const PlantModel &p, const PlantLane &t, const double x[7], double a, double sr, double xd[7])
 {

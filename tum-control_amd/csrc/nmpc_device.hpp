@@ -235,6 +235,8 @@ __device__ __forceinline__ d4 mfma(double a, double b, d4 c) { return __builtin_
 __device__ __forceinline__ double mfma4(double a, double b) { return __builtin_amdgcn_mfma_f64_4x4x4f64(a, b, 0.0, 0, 0, 0); }
 __device__ __forceinline__ double mfma4a(double a, double b, double c) { return __builtin_amdgcn_mfma_f64_4x4x4f64(a, b, c, 0, 0, 0); }
 // rotation by N lanes inside every row of 16 lanes: lane (q, c) takes the value of lane (q, (c - N) mod 16)   (DPP row_ror)
+// value of lane K of the DPP quad (4 consecutive lanes) in all four
+template <int K> __device__ __forceinline__ double quad_bcast(double v) { return dpp0_f64<0x55 * K>(v); }
 template <int N> __device__ __forceinline__ double row_ror(double v) { return dpp0_f64<0x120 + N>(v); }    // (every lane has a source)
 // LDS ordering point between the lanes of the ONE wavefront of a workgroup. The LDS executes a wave's DS
 // instructions in issue order, so a later ds_read already observes an earlier ds_write of another lane: no

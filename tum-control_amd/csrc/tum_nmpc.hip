@@ -53,6 +53,7 @@ struct tum_ocp {
     double *dXS, *dxs0, *dApce, *dws2, *dpro, *ddv, *doffs;
     int *dxs_dirty; bool xs_lazy;          // sample copies of the stages > uph not yet frozen (snmpc_freeze_kernel)
     bool have_offs, fanout;        // sample initial conditions derived from the nominal x0 at every solve
+    int lin_cols;                      // linearisation with eight lanes per (instance, stage): -1 the library's choice (small batches), 0 never, 1 always (tum_ocp_set_kernel)
     int sn_prologue;                   // prologue of the SNMPC OCP: -1 the library's choice, 2 the matrix-core kernel, 0 column slots and passes (tum_ocp_set_kernel)
     // R2NMPC tightening after every solve (tum_ocp_r2_attach)
     bool r2; int r2_uph; double r2_dmin, r2_dmax, r2_uh; double *dr2S, *dr2B;
@@ -122,7 +123,7 @@ extern "C" tum_ocp *tum_ocp_create(const tum_ocp_desc *desc)
     tum_ocp *c = new tum_ocp();
     c->d = *desc; c->N = desc->N; c->batch = desc->batch; c->last_ms = 0; c->solved = false; c->epoch = 0;
     c->sn = false; c->dXS = c->dxs0 = c->dApce = c->dws2 = c->dpro = c->ddv = c->doffs = nullptr; c->dxs_dirty = nullptr; c->xs_lazy = false;
-    c->have_offs = c->fanout = false; c->sn_prologue = -1;
+    c->have_offs = c->fanout = false; c->sn_prologue = -1; c->lin_cols = -1;
     c->r2 = false; c->dr2S = c->dr2B = nullptr;
     c->p_dirty = false; c->uph_cap = 0; c->gamma = 0.0; c->dpceA = nullptr; c->pce_L = c->pce_S = 0; c->dbnd_snap = nullptr;
     c->dsum = nullptr; c->res_head = c->res_count = 0;
@@ -643,6 +644,9 @@ extern "C" int tum_ocp_set_kernel(tum_ocp *c, const char *name)
     if (n == "auto") c->kmode = 0;
     else if (n == "pipeline") c->kmode = 2;
     // the prologue of the coupled SNMPC OCP: the matrix-core kernel (default where n_samples <= 10) or the column-slot / pass variants
+    // the linearisation: one lane per (instance, stage) or eight (default: eight while the batch is one round of wavefronts)
+    else if (n == "lin-lane-per-stage") c->lin_cols = 0;
+    else if (n == "lin-eight-lanes") c->lin_cols = 1;
     else if (n == "prologue-passes" || n == "prologue-mfma") {
         if (c->sn) {
             const int want = (n == "prologue-passes") ? 0 : 2;
@@ -658,7 +662,7 @@ extern "C" int tum_ocp_set_kernel(tum_ocp *c, const char *name)
     else if (n == "fused" || n == "pipeline4")
         return fail("set_kernel: kernel '" + n + "' exists in the development build only (libtumnmpc_dev.so); this library is the pipeline");
 #endif
-    else return fail("set_kernel: unknown kernel '" + n + "' (auto | pipeline | prologue-mfma | prologue-passes; development build: fused | pipeline4)");
+    else return fail("set_kernel: unknown kernel '" + n + "' (auto | pipeline | lin-lane-per-stage | lin-eight-lanes | prologue-mfma | prologue-passes; development build: fused | pipeline4)");
     c->epoch++;
     return 0;
 }
@@ -713,7 +717,14 @@ static int launch_pipeline(tum_ocp *c, bool events)
         sn_launch_lin(c);
         sn_launch_prologue(c);
         hipLaunchKernelGGL(lin_kernel<true>, dim3((unsigned)((items + 63) / 64)), dim3(64), 0, c->stream, pa);
-    } else hipLaunchKernelGGL(lin_kernel<false>, dim3((unsigned)((items + 63) / 64)), dim3(64), 0, c->stream, pa);
+    } else {
+        // eight lanes per item while that still is one round of wavefronts on the chip (256 CUs x 4 SIMDs), see lin_cols_kernel
+        static const int cols_env = [] { const char *e = getenv("TUM_LIN_COLS"); return e ? atoi(e) : -1; }();
+        const int want = (c->lin_cols >= 0) ? c->lin_cols : cols_env;
+        const bool cols = want > 0 || (want < 0 && items * LC_LANES <= 64LL * 1024);
+        if (cols) hipLaunchKernelGGL(lin_cols_kernel, dim3((unsigned)((items + LC_ITEMS - 1) / LC_ITEMS)), dim3(64), 0, c->stream, pa);
+        else hipLaunchKernelGGL(lin_kernel<false>, dim3((unsigned)((items + 63) / 64)), dim3(64), 0, c->stream, pa);
+    }
     // (development aid: a larger LDS request lowers the number of OCPs that share a CU)
     // The expansion as the tail of the interior point kernel pays where a batch is at most one round of resident wavefronts (one
     // launch less: 0.424 against 0.432 ms per solve() call at 26 instances, 0.457 against 0.469 at 1024); beyond that its
