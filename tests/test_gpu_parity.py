@@ -882,3 +882,30 @@ def test_linearisation_eight_lanes_per_stage_vs_lane_per_stage(N, B):
             o.solve()
         for r in (p, q):
             assert np.abs(r[1][b] - o.U).max() < 1e-7 and np.abs(r[0][b] - o.X).max() < 1e-7
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("N,B", [(40, 26), (38, 7), (45, 3), (48, 2), (17, 5), (1, 3)])
+def test_condensing_six_wavefronts_per_ocp_is_the_same_arithmetic(N, B):
+    """cond_wide_kernel (small batches: the column recursion on two wavefronts, the Hessian tiles dealt to four, the gradient
+    on two more) against cond_kernel (one wavefront per OCP): every sum is formed from the same operands in the same order, so
+    the condensed QP -- and with it the iterate, the cost, the slacks and the iteration counts of a warm-started sequence --
+    agree to the last bit."""
+    from tum_control_amd.workloads import nominal_batch
+    x0, yref = nominal_batch(B, N=N, seed=77)
+    out = {}
+    for name in ("cond-one-wavefront", "cond-six-wavefronts"):
+        s = _mk(N, B)
+        s.set_kernel(name)
+        s.set_x0(x0); s.set_yref_all(yref); s.cold_start()
+        for _ in range(3):
+            assert s.solve() == 0
+        X, U = s.get_iterate()
+        out[name] = (X, U, np.atleast_1d(s.get_cost()), s.get_stats("qp_iter"), s.get_stats("res"), s.get(1, "su") if N > 1 else X)
+    for p, q in zip(out["cond-one-wavefront"], out["cond-six-wavefronts"]):
+        assert np.array_equal(p, q)
+    o = _oracle_default(N)
+    o.cold_start(x0[B - 1]); o.yref[:] = yref[B - 1]
+    for _ in range(3):
+        o.solve()
+    assert np.abs(out["cond-six-wavefronts"][1][B - 1] - o.U).max() < 1e-7

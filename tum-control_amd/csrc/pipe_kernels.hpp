@@ -621,6 +621,278 @@ __global__ void __launch_bounds__(64, (NT_ == 5) ? 2 : 1) cond_kernel(const PArg
     }
 }
 
+// ---- K2 for small batches: SIX wavefronts per OCP.
+// cond_kernel is one wavefront walking the N stages, each stage the column recursion, an exchange through LDS and the stage's
+// share of the SYRK on the matrix cores: ~2400 cycles a stage, 41 us at N = 40 whatever the batch. Only the recursion is
+// sequential in the stages. Here
+//   phase 1  wavefronts 0 and 1 run the recursion alone -- ONE column per lane (wavefront 0 the columns 0..63, wavefront 1 the
+//            columns 64.. and the constant column g), all records preloaded into LDS by the whole workgroup, no exchange and no
+//            wave barrier inside a stage -- and leave behind: the four cost rows of every G_s in LDS (stage s: 16 ceil(s/8) live
+//            columns), the g column, the gg rows and d (straight to the workspace, as cond_kernel does);
+//   phase 2  (one workgroup barrier later) wavefronts 0..3 accumulate the Hessian tiles -- every tile by ONE wavefront, over
+//            the stages in order, with the operands cond_kernel forms: the same sums in the same order -- and wavefronts 4, 5
+//            the gradient q of the columns 0..63 / 64...
+// Tiles are dealt to the four wavefronts longest-first (tile (K, I) is touched by the 8 (NT - I) stages behind block column I).
+// The results are the ones cond_kernel writes, to the last bit (tests/test_gpu_parity.py::test_condensing_six_wavefronts_...).
+// Launched while the batch is at most one workgroup per CU (tum_nmpc.hip: launch_pipeline); the nominal OCP only.
+constexpr int CW_WAVES = 6, CW_SYRK = 4;
+template <int NT_> struct CondWideTab { int own[PD<NT_>::NTT]; };
+template <int NT_> constexpr CondWideTab<NT_> cond_wide_deal()
+{
+    CondWideTab<NT_> t{};
+    int load[CW_SYRK] = {};
+    for (int I = 0; I < NT_; I++)
+        for (int K = 0; K <= I; K++) {
+            int best = 0;
+            for (int w = 1; w < CW_SYRK; w++) if (load[w] < load[best]) best = w;
+            t.own[PD<NT_>::tidx(K, I)] = best; load[best] += 8 * (NT_ - I);
+        }
+    return t;
+}
+template <int NT_> struct CondWide {
+    using D = PD<NT_>;
+    static constexpr CondWideTab<NT_> tab = cond_wide_deal<NT_>();
+    static constexpr int ROWS = 512 * NT_ * (NT_ + 1) / 2;          // doubles: 4 rows x 16 Ts columns x 8 stages per segment Ts
+    // first double of stage s (1-based) in the row store; the stage holds 4 rows of 16 ceil(s/8) columns
+    static __device__ __forceinline__ int rowoff(int s) { const int Ts = (s + 7) >> 3; return 64 * (4 * Ts * (Ts - 1) + (s - 1 - 8 * (Ts - 1)) * Ts); }
+};
+
+template <int NT_>
+__global__ void __launch_bounds__(64 * CW_WAVES) cond_wide_kernel(const PArgs pa)
+{
+    PD_LOCALS
+    using CW = CondWide<NT_>;
+    __shared__ __attribute__((aligned(16))) double sRec[(NMAX + 1) * PREC];
+    __shared__ __attribute__((aligned(16))) double sRows[CW::ROWS];
+    __shared__ double sG[(NMAX + 1) * 4], sWt[(NMAX + 1) * 6], sU0[NVP];
+    const KArgs &ka = pa.ka;
+    const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63, b = blockIdx.x;
+    if (b >= ka.batch) return;
+    const int N = ka.N, nv = 2 * N;
+    const double dt = ka.dt;
+    const double *grec = pa.rec + (size_t)b * (N + 1) * PREC;
+    const double *gx0 = ka.x0 + (size_t)b * NX;
+    const double *gX = ka.X + (size_t)b * (N + 1) * NX;
+    const double *gU = ka.U + (size_t)b * N * NU;
+    const double *gyref = ka.yref + (size_t)b * (N + 1) * 6;
+    const double *gW = ka.W + (size_t)b * (N + 1) * 6;
+    double *gvec = pa.vec + (size_t)b * PVEC;
+    for (int i = tid; i < (N + 1) * PREC; i += 64 * CW_WAVES) sRec[i] = grec[i];
+    for (int i = tid; i < (N + 1) * 6; i += 64 * CW_WAVES) sWt[i] = gW[i];
+    for (int i = tid; i < NVP; i += 64 * CW_WAVES) sU0[i] = (i < nv) ? gU[i] : 0.0;
+    __syncthreads();
+#if defined(TUM_CW_STOP) && TUM_CW_STOP == 1
+    return;
+#endif
+
+    // ---- phase 1: the column recursion
+    if (wv < 2) {
+        const bool isg = (wv == 1) && (lane == NB1);
+        const bool colv = (wv == 0) || (lane < NB1);
+        const int col = 64 * wv + lane;                          // condensed variable of this lane (where colv)
+        const int j = col >> 1, r0 = col & 1, T = col >> 4, lc = col & 15;
+        double w[8];
+#pragma unroll
+        for (int i = 0; i < 8; i++) w[i] = 0.0;
+        if (isg) {
+#pragma unroll
+            for (int i = 0; i < 8; i++) w[i] = gx0[i] - gX[i];
+        }
+        // The record of a stage is wave-uniform data in LDS; read where it is used, every group of FMAs waits for its own
+        // broadcast read (measured: 1180 cycles a stage, 24 waits). The reads are issued half a stage ahead instead: the first
+        // half of the record (Sp and the rows px, py, psi of S: h1) during the second half of the previous stage, the second half
+        // (rows vl, vt, r of S, the columns of B, b, the gg row: h2) at the top of the stage, under the FMAs of the first half.
+        // (sched_barrier: the scheduler would move every read back down to its use.)
+        double h1[17];
+        auto fetch1 = [&](int k) {
+            const double *rec = sRec + k * PREC;
+            h1[0] = rec[0]; h1[1] = rec[1];
+#pragma unroll
+            for (int i = 0; i < 3; i++)
+#pragma unroll
+                for (int c = 0; c < 5; c++) h1[2 + 5 * i + c] = rec[2 + i * 7 + c];
+        };
+        fetch1(0);
+        for (int k = 0; k < N; k++) {
+            const double *rec = sRec + k * PREC;
+            double S2[3][5], Bc[6], bk[8], gg[5];
+#pragma unroll
+            for (int i = 0; i < 3; i++)
+#pragma unroll
+                for (int c = 0; c < 5; c++) S2[i][c] = rec[2 + (3 + i) * 7 + c];
+#pragma unroll
+            for (int i = 0; i < 6; i++) Bc[i] = rec[2 + i * 7 + 5 + r0];
+            if (wv == 1) {
+#pragma unroll
+                for (int i = 0; i < 8; i++) bk[i] = rec[44 + i];
+            }
+#pragma unroll
+            for (int i = 0; i < 4; i++) gg[i] = rec[PREC + PR_GH + i];
+            gg[4] = rec[PREC + PR_XD];
+            __builtin_amdgcn_sched_barrier(0);
+            // w <- A_k w (apply_A, nmpc_device.hpp), rows px, py, psi
+            double n[6];
+            n[0] = w[0] + h1[0] * w[2];
+            n[1] = w[1] + h1[1] * w[2];
+            n[2] = w[2];
+#pragma unroll
+            for (int i = 0; i < 3; i++)
+#pragma unroll
+                for (int c = 0; c < 5; c++) n[i] += h1[2 + 5 * i + c] * w[3 + c];
+            __builtin_amdgcn_sched_barrier(0);
+            if (k + 1 < N) fetch1(k + 1);
+            __builtin_amdgcn_sched_barrier(0);
+            // rows vl, vt, r; the column of B_k / b_k this lane takes up at stage k
+            n[3] = 0.0; n[4] = 0.0; n[5] = 0.0;
+#pragma unroll
+            for (int i = 0; i < 3; i++)
+#pragma unroll
+                for (int c = 0; c < 5; c++) n[3 + i] += S2[i][c] * w[3 + c];
+#pragma unroll
+            for (int i = 0; i < 6; i++) w[i] = n[i];
+            {
+                const double sel = (colv && j == k) ? 1.0 : 0.0;
+#pragma unroll
+                for (int i = 0; i < 6; i++) w[i] += sel * Bc[i];
+                const double b6 = r0 ? dt : 0.0, b7 = r0 ? 0.0 : dt;
+                w[6] += sel * b6; w[7] += sel * b7;
+                if (wv == 1) {
+                    const double selg = isg ? 1.0 : 0.0;
+#pragma unroll
+                    for (int i = 0; i < 8; i++) w[i] += selg * bk[i];
+                }
+            }
+            const int s = k + 1, Ts = (s + 7) >> 3;
+            const double hr = gg[0] * w[3] + gg[1] * w[5] + gg[2] * w[7];
+            if (isg) {
+#pragma unroll
+                for (int i = 0; i < 4; i++) sG[s * 4 + i] = w[i];
+                gvec[PV_D + 2 * (s - 1)] = gg[4] + w[6];
+                gvec[PV_D + 2 * (s - 1) + 1] = gg[3] + hr;
+            }
+            {   // the gg row of stage s in the operand layout of the interior point kernel (see cond_kernel)
+                const int c_ = (s - 1) >> 2;
+                double *gcs = pa.cws + (size_t)b * NCH * 64 + 16 * ((s - 1) & 3) + lc;
+                if (colv && 2 * T <= c_) gcs[(T * (NC - T - 1) + c_) * 64] = hr;
+            }
+            if (colv && T < Ts) {
+                double *row = sRows + CW::rowoff(s) + col;
+                const int pitch = 16 * Ts;
+#pragma unroll
+                for (int r = 0; r < 4; r++) row[r * pitch] = w[r];
+            }
+        }
+        for (int s = N + 1; s <= NMAX; s++) {          // rows beyond the horizon: zeros
+            const int c_ = (s - 1) >> 2;
+            double *gcs = pa.cws + (size_t)b * NCH * 64 + 16 * ((s - 1) & 3) + lc;
+            if (colv && 2 * T <= c_) gcs[(T * (NC - T - 1) + c_) * 64] = 0.0;
+        }
+    }
+    __syncthreads();
+#if defined(TUM_CW_STOP) && TUM_CW_STOP == 2
+    return;
+#endif
+
+    // ---- phase 2
+    const int lq = lane >> 4, lc = lane & 15;
+#if defined(TUM_CW_STOP) && TUM_CW_STOP == 3
+    if (wv >= CW_SYRK) return;
+#endif
+#if defined(TUM_CW_STOP) && TUM_CW_STOP == 4
+    if (wv < CW_SYRK) return;
+#endif
+    if (wv < CW_SYRK) {
+        auto syrk = [&](auto wvc) {
+            constexpr int WV = decltype(wvc)::value;
+            d4 Ht[NTT];
+#pragma unroll
+            for (int i = 0; i < NTT; i++) Ht[i] = d4{0.0, 0.0, 0.0, 0.0};
+            static_for<1, NT>([&](auto tsc) {
+                constexpr int Ts = decltype(tsc)::value;
+                // (the operands of the next stage are read while the matrix cores work on this one: two register sets, as in phase 1)
+                auto ldop = [&](int s, double (&bo)[Ts], double &wl) {
+                    const double sc = (s < N) ? dt : 1.0;
+                    wl = sc * sWt[s * 6 + lq];
+                    const double *row = sRows + CW::rowoff(s) + lq * (16 * Ts) + lc;
+#pragma unroll
+                    for (int T = 0; T < Ts; T++) bo[T] = row[16 * T];
+                };
+                auto mm = [&](const double (&bop)[Ts], const double wl) {
+                    static_for<0, Ts - 1>([&](auto Kc) {
+                        constexpr int K = decltype(Kc)::value;
+                        const double aop = bop[K] * wl;
+                        static_for<K, Ts - 1>([&](auto Ic) {
+                            constexpr int I = decltype(Ic)::value;
+                            if constexpr (CW::tab.own[D::tidx(K, I)] == WV) Ht[D::tidx(K, I)] = mfma(aop, bop[I], Ht[D::tidx(K, I)]);
+                        });
+                    });
+                };
+                const int se = (N < 8 * Ts) ? N : 8 * Ts;
+                int s = 8 * (Ts - 1) + 1;
+                double ba[Ts], bb[Ts], wa = 0.0, wb = 0.0;
+                if (s <= se) ldop(s, ba, wa);
+                for (; s <= se; s += 2) {
+                    if (s + 1 <= se) ldop(s + 1, bb, wb);
+                    mm(ba, wa);
+                    if (s + 1 <= se) {
+                        if (s + 2 <= se) ldop(s + 2, ba, wa);
+                        mm(bb, wb);
+                    }
+                }
+            });
+            // input cost (R) and padding on the diagonal; hand-over of this wavefront's tiles
+            d4 *gh = reinterpret_cast<d4 *>(pa.hws) + (size_t)b * NTT * 64 + lane;
+            static_for<0, NT - 1>([&](auto Ic) {
+                constexpr int I = decltype(Ic)::value;
+                static_for<0, I>([&](auto Kc) {
+                    constexpr int K = decltype(Kc)::value;
+                    if constexpr (CW::tab.own[D::tidx(K, I)] == WV) {
+                        if constexpr (K == I) {
+#pragma unroll
+                            for (int jj = 0; jj < 4; jj++) {
+                                const int rw = lq + 4 * jj;
+                                if (rw == lc) {
+                                    const int idx = 16 * K + rw;
+                                    Ht[tidx(K, K)][jj] += (idx < nv) ? dt * sWt[(idx >> 1) * 6 + 4 + (idx & 1)] : 1.0;
+                                }
+                            }
+                        }
+                        gh[tidx(K, I) * 64] = Ht[tidx(K, I)];
+                    }
+                });
+            });
+        };
+        if (wv == 0) syrk(std::integral_constant<int, 0>());
+        else if (wv == 1) syrk(std::integral_constant<int, 1>());
+        else if (wv == 2) syrk(std::integral_constant<int, 2>());
+        else syrk(std::integral_constant<int, 3>());
+    } else {
+        // gradient of the tracking cost through G_s (wavefront 4: columns 0..63, wavefront 5: columns 64..), input cost
+        const int col = 64 * (wv - CW_SYRK) + lane;
+        const bool colv = col < NVP;
+        const int T = col >> 4, j = col >> 1, r0 = col & 1;
+        double q = 0.0;
+#pragma unroll 4
+        for (int s = 1; s <= N; s++) {
+            const int Ts = (s + 7) >> 3;
+            const double sc = (s < N) ? dt : 1.0;
+            const double *recn = sRec + s * PREC;
+            const bool live = colv && T < Ts;
+            const double *row = sRows + CW::rowoff(s) + (live ? col : 0);
+            double a = 0.0;
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const double e = (sc * sWt[s * 6 + r]) * (recn[PR_RES + r] + sG[s * 4 + r]);
+                const double wr_ = live ? row[r * 16 * Ts] : 0.0;
+                a += e * wr_;
+            }
+            q += a;
+        }
+        if (col < nv) q += dt * sWt[j * 6 + 4 + r0] * (sU0[col] - gyref[j * 6 + 4 + r0]);
+        if (colv) gvec[PV_Q + col] = q;
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------------------- K4
 // The expansion of ONE instance by one wavefront: dx recursion, full step, cost at the new iterate. `lds` holds PD::E_LDS doubles;
 // FUSED: the caller (the tail of ipm_kernel) has put the step of the inputs into lds[E_DV ..] and passes status / slack cost in

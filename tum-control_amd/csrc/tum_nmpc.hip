@@ -53,6 +53,7 @@ struct tum_ocp {
     double *dXS, *dxs0, *dApce, *dws2, *dpro, *ddv, *doffs;
     int *dxs_dirty; bool xs_lazy;          // sample copies of the stages > uph not yet frozen (snmpc_freeze_kernel)
     bool have_offs, fanout;        // sample initial conditions derived from the nominal x0 at every solve
+    int cond_wide;                     // condensing with six wavefronts per OCP: -1 the library's choice (at most one workgroup per CU), 0 never, 1 always
     int lin_cols;                      // linearisation with eight lanes per (instance, stage): -1 the library's choice (small batches), 0 never, 1 always (tum_ocp_set_kernel)
     int sn_prologue;                   // prologue of the SNMPC OCP: -1 the library's choice, 2 the matrix-core kernel, 0 column slots and passes (tum_ocp_set_kernel)
     // R2NMPC tightening after every solve (tum_ocp_r2_attach)
@@ -123,7 +124,7 @@ extern "C" tum_ocp *tum_ocp_create(const tum_ocp_desc *desc)
     tum_ocp *c = new tum_ocp();
     c->d = *desc; c->N = desc->N; c->batch = desc->batch; c->last_ms = 0; c->solved = false; c->epoch = 0;
     c->sn = false; c->dXS = c->dxs0 = c->dApce = c->dws2 = c->dpro = c->ddv = c->doffs = nullptr; c->dxs_dirty = nullptr; c->xs_lazy = false;
-    c->have_offs = c->fanout = false; c->sn_prologue = -1; c->lin_cols = -1;
+    c->have_offs = c->fanout = false; c->sn_prologue = -1; c->lin_cols = -1; c->cond_wide = -1;
     c->r2 = false; c->dr2S = c->dr2B = nullptr;
     c->p_dirty = false; c->uph_cap = 0; c->gamma = 0.0; c->dpceA = nullptr; c->pce_L = c->pce_S = 0; c->dbnd_snap = nullptr;
     c->dsum = nullptr; c->res_head = c->res_count = 0;
@@ -645,6 +646,8 @@ extern "C" int tum_ocp_set_kernel(tum_ocp *c, const char *name)
     else if (n == "pipeline") c->kmode = 2;
     // the prologue of the coupled SNMPC OCP: the matrix-core kernel (default where n_samples <= 10) or the column-slot / pass variants
     // the linearisation: one lane per (instance, stage) or eight (default: eight while the batch is one round of wavefronts)
+    else if (n == "cond-one-wavefront") c->cond_wide = 0;
+    else if (n == "cond-six-wavefronts") c->cond_wide = 1;
     else if (n == "lin-lane-per-stage") c->lin_cols = 0;
     else if (n == "lin-eight-lanes") c->lin_cols = 1;
     else if (n == "prologue-passes" || n == "prologue-mfma") {
@@ -662,7 +665,7 @@ extern "C" int tum_ocp_set_kernel(tum_ocp *c, const char *name)
     else if (n == "fused" || n == "pipeline4")
         return fail("set_kernel: kernel '" + n + "' exists in the development build only (libtumnmpc_dev.so); this library is the pipeline");
 #endif
-    else return fail("set_kernel: unknown kernel '" + n + "' (auto | pipeline | lin-lane-per-stage | lin-eight-lanes | prologue-mfma | prologue-passes; development build: fused | pipeline4)");
+    else return fail("set_kernel: unknown kernel '" + n + "' (auto | pipeline | lin-lane-per-stage | lin-eight-lanes | cond-one-wavefront | cond-six-wavefronts | prologue-mfma | prologue-passes; development build: fused | pipeline4)");
     c->epoch++;
     return 0;
 }
@@ -737,7 +740,14 @@ static int launch_pipeline(tum_ocp *c, bool events)
         constexpr int NTv = decltype(ntc)::value;
         const int ipm_lds = lds_req > PD<NTv>::I_LDS_BYTES ? lds_req : PD<NTv>::I_LDS_BYTES;
         if (c->sn) hipLaunchKernelGGL((cond_kernel<NTv, true>), dim3(c->batch), dim3(64), 0, c->stream, pa);
-        else hipLaunchKernelGGL((cond_kernel<NTv, false>), dim3(c->batch), dim3(64), 0, c->stream, pa);
+        else {
+            // six wavefronts per OCP while every OCP can have a CU's LDS to itself (cond_wide_kernel)
+            static const int wide_env = [] { const char *e = getenv("TUM_COND_WIDE"); return e ? atoi(e) : -1; }();
+            const int want = (c->cond_wide >= 0) ? c->cond_wide : wide_env;
+            if (want > 0 || (want < 0 && c->batch <= 256))
+                hipLaunchKernelGGL((cond_wide_kernel<NTv>), dim3(c->batch), dim3(64 * CW_WAVES), 0, c->stream, pa);
+            else hipLaunchKernelGGL((cond_kernel<NTv, false>), dim3(c->batch), dim3(64), 0, c->stream, pa);
+        }
         if (events) (void)hipEventRecord(c->evi0, c->stream);
         bool expanded = false;
 #ifdef TUM_DEV_KERNELS
