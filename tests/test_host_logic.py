@@ -239,7 +239,9 @@ def test_shipped_kernels_resource_budget():
         # no scratch anywhere in the five-tile (N <= 40) build -- the condensing kernel's 52 B of rounds 2-3 are gone --; the
         # six-tile interior point kernel (N = 41..48, the whole register file and then some) keeps a few dozen bytes
         assert scratch == 0 or ("ipm_kernel<false, 6" in name and scratch <= 64), (name, scratch)
-        assert vgpr + agpr <= 512 and lds <= 40 * 1024, name
+        # (cond_wide_kernel: one workgroup of six wavefronts per CU by design -- records, row store of every stage and g column in LDS)
+        lds_cap = 160 * 1024 if "cond_wide_kernel" in name else 40 * 1024
+        assert vgpr + agpr <= 512 and lds <= lds_cap, name
     for name in ("ipm_kernel<false, 5, true>", "ipm_kernel<false, 5, false>"):      # headline: the expansion fused into its tail; SNMPC: without
         ipm = kernel(name)
         assert ipm[2:5] == [0, 0, 0] and ipm[6] == 1, (name, ipm)

@@ -621,21 +621,23 @@ __global__ void __launch_bounds__(64, (NT_ == 5) ? 2 : 1) cond_kernel(const PArg
     }
 }
 
-// ---- K2 for small batches: SIX wavefronts per OCP.
+// ---- K2 for small batches: six (N <= 40) or seven wavefronts per OCP.
 // cond_kernel is one wavefront walking the N stages, each stage the column recursion, an exchange through LDS and the stage's
 // share of the SYRK on the matrix cores: ~2400 cycles a stage, 41 us at N = 40 whatever the batch. Only the recursion is
 // sequential in the stages. Here
-//   phase 1  wavefronts 0 and 1 run the recursion alone -- ONE column per lane (wavefront 0 the columns 0..63, wavefront 1 the
-//            columns 64.. and the constant column g), all records preloaded into LDS by the whole workgroup, no exchange and no
-//            wave barrier inside a stage -- and leave behind: the four cost rows of every G_s in LDS (stage s: 16 ceil(s/8) live
-//            columns), the g column, the gg rows and d (straight to the workspace, as cond_kernel does);
+//   phase 1  the recursion alone, FOUR lanes (a DPP quad) per column of G -- lane 0 the rows px and vl of A_k w, lane 1 py and vt,
+//            lane 2 psi and r, each row's sum in apply_A's order; the new vl, vt, r, psi go round the quad by DPP broadcasts; lane 3
+//            forms the gg row -- ~40 instructions a stage instead of ~150. All records are preloaded into LDS by the whole
+//            workgroup and read one stage ahead (two register sets). Left behind: the four cost rows of every G_s in LDS (stage
+//            s: 16 ceil(s/8) live columns), the g column, the gg rows and d (straight to the workspace, as cond_kernel does);
 //   phase 2  (one workgroup barrier later) wavefronts 0..3 accumulate the Hessian tiles -- every tile by ONE wavefront, over
 //            the stages in order, with the operands cond_kernel forms: the same sums in the same order -- and wavefronts 4, 5
 //            the gradient q of the columns 0..63 / 64...
 // Tiles are dealt to the four wavefronts longest-first (tile (K, I) is touched by the 8 (NT - I) stages behind block column I).
 // The results are the ones cond_kernel writes, to the last bit (tests/test_gpu_parity.py::test_condensing_six_wavefronts_...).
 // Launched while the batch is at most one workgroup per CU (tum_nmpc.hip: launch_pipeline); the nominal OCP only.
-constexpr int CW_WAVES = 6, CW_SYRK = 4;
+constexpr int CW_SYRK = 4;
+template <int NT_> constexpr int cw_waves() { return (4 * (PD<NT_>::NVP + 1) + 63) / 64 > CW_SYRK + 2 ? (4 * (PD<NT_>::NVP + 1) + 63) / 64 : CW_SYRK + 2; }
 template <int NT_> struct CondWideTab { int own[PD<NT_>::NTT]; };
 template <int NT_> constexpr CondWideTab<NT_> cond_wide_deal()
 {
@@ -658,13 +660,14 @@ template <int NT_> struct CondWide {
 };
 
 template <int NT_>
-__global__ void __launch_bounds__(64 * CW_WAVES) cond_wide_kernel(const PArgs pa)
+__global__ void __launch_bounds__(64 * cw_waves<NT_>()) cond_wide_kernel(const PArgs pa)
 {
     PD_LOCALS
     using CW = CondWide<NT_>;
-    __shared__ __attribute__((aligned(16))) double sRec[(NMAX + 1) * PREC];
+    constexpr int CW_WAVES = cw_waves<NT_>();
+    __shared__ __attribute__((aligned(16))) double sRec[(NMAX + 3) * PREC];       // (+2: the read-ahead of the last stage stays inside)
     __shared__ __attribute__((aligned(16))) double sRows[CW::ROWS];
-    __shared__ double sG[(NMAX + 1) * 4], sWt[(NMAX + 1) * 6], sU0[NVP];
+    __shared__ double sG[(NMAX + 1) * 4], sWt[(NMAX + 1) * 6], sU0[NVP], sEq[2 * ((NMAX + 1) * 4 + 2)];
     const KArgs &ka = pa.ka;
     const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63, b = blockIdx.x;
     if (b >= ka.batch) return;
@@ -681,126 +684,79 @@ __global__ void __launch_bounds__(64 * CW_WAVES) cond_wide_kernel(const PArgs pa
     for (int i = tid; i < (N + 1) * 6; i += 64 * CW_WAVES) sWt[i] = gW[i];
     for (int i = tid; i < NVP; i += 64 * CW_WAVES) sU0[i] = (i < nv) ? gU[i] : 0.0;
     __syncthreads();
-#if defined(TUM_CW_STOP) && TUM_CW_STOP == 1
-    return;
-#endif
 
-    // ---- phase 1: the column recursion
-    if (wv < 2) {
-        const bool isg = (wv == 1) && (lane == NB1);
-        const bool colv = (wv == 0) || (lane < NB1);
-        const int col = 64 * wv + lane;                          // condensed variable of this lane (where colv)
-        const int j = col >> 1, r0 = col & 1, T = col >> 4, lc = col & 15;
-        double w[8];
-#pragma unroll
-        for (int i = 0; i < 8; i++) w[i] = 0.0;
+    // ---- phase 1: the column recursion, four lanes per column (column slot NVP: the constant column g)
+    if (tid < 4 * (NVP + 1)) {
+        const int cs = tid >> 2, rho = tid & 3;
+        const bool isg = (cs == NVP), colv = (cs < NVP);
+        const int j = cs >> 1, r0 = cs & 1, T = cs >> 4, lc = cs & 15;
+        const int ra = (rho == 3) ? 2 : rho, rb = ra + 3;         // rows of A_k w this lane forms (lane 3 repeats lane 2's and stores neither)
+        // wa, wb: rows ra, rb of the column; w2..w5 as the quad last exchanged them; w6, w7 (delta, a: integrators of the inputs) on every lane
+        double wa = 0.0, wb = 0.0, w2 = 0.0, w3 = 0.0, w4 = 0.0, w5 = 0.0, w6 = 0.0, w7 = 0.0;
         if (isg) {
-#pragma unroll
-            for (int i = 0; i < 8; i++) w[i] = gx0[i] - gX[i];
+            wa = gx0[ra] - gX[ra]; wb = gx0[rb] - gX[rb];
+            w2 = gx0[2] - gX[2]; w3 = gx0[3] - gX[3]; w4 = gx0[4] - gX[4]; w5 = gx0[5] - gX[5]; w6 = gx0[6] - gX[6]; w7 = gx0[7] - gX[7];
         }
-        // The record of a stage is wave-uniform data in LDS; read where it is used, every group of FMAs waits for its own
-        // broadcast read (measured: 1180 cycles a stage, 24 waits). The reads are issued half a stage ahead instead: the first
-        // half of the record (Sp and the rows px, py, psi of S: h1) during the second half of the previous stage, the second half
-        // (rows vl, vt, r of S, the columns of B, b, the gg row: h2) at the top of the stage, under the FMAs of the first half.
-        // (sched_barrier: the scheduler would move every read back down to its use.)
-        double h1[17];
-        auto fetch1 = [&](int k) {
+        struct Rk { double Sa[5], Sb[5], sp, Ba, Bb, ba, bb, b6, b7, g3, g5, g7, hd, xd; };
+        auto fetch = [&](int k, Rk &r) {
             const double *rec = sRec + k * PREC;
-            h1[0] = rec[0]; h1[1] = rec[1];
 #pragma unroll
-            for (int i = 0; i < 3; i++)
-#pragma unroll
-                for (int c = 0; c < 5; c++) h1[2 + 5 * i + c] = rec[2 + i * 7 + c];
+            for (int c = 0; c < 5; c++) { r.Sa[c] = rec[2 + ra * 7 + c]; r.Sb[c] = rec[2 + rb * 7 + c]; }
+            r.sp = rec[ra & 1];                                 // (used by the rows px, py only)
+            r.Ba = rec[2 + ra * 7 + 5 + r0]; r.Bb = rec[2 + rb * 7 + 5 + r0];
+            r.ba = rec[44 + ra]; r.bb = rec[44 + rb]; r.b6 = rec[44 + 6]; r.b7 = rec[44 + 7];
+            r.g3 = rec[PREC + PR_GH + 0]; r.g5 = rec[PREC + PR_GH + 1]; r.g7 = rec[PREC + PR_GH + 2]; r.hd = rec[PREC + PR_GH + 3];
+            r.xd = rec[PREC + PR_XD];
         };
-        fetch1(0);
-        for (int k = 0; k < N; k++) {
-            const double *rec = sRec + k * PREC;
-            double S2[3][5], Bc[6], bk[8], gg[5];
-#pragma unroll
-            for (int i = 0; i < 3; i++)
-#pragma unroll
-                for (int c = 0; c < 5; c++) S2[i][c] = rec[2 + (3 + i) * 7 + c];
-#pragma unroll
-            for (int i = 0; i < 6; i++) Bc[i] = rec[2 + i * 7 + 5 + r0];
-            if (wv == 1) {
-#pragma unroll
-                for (int i = 0; i < 8; i++) bk[i] = rec[44 + i];
-            }
-#pragma unroll
-            for (int i = 0; i < 4; i++) gg[i] = rec[PREC + PR_GH + i];
-            gg[4] = rec[PREC + PR_XD];
-            __builtin_amdgcn_sched_barrier(0);
-            // w <- A_k w (apply_A, nmpc_device.hpp), rows px, py, psi
-            double n[6];
-            n[0] = w[0] + h1[0] * w[2];
-            n[1] = w[1] + h1[1] * w[2];
-            n[2] = w[2];
-#pragma unroll
-            for (int i = 0; i < 3; i++)
-#pragma unroll
-                for (int c = 0; c < 5; c++) n[i] += h1[2 + 5 * i + c] * w[3 + c];
-            __builtin_amdgcn_sched_barrier(0);
-            if (k + 1 < N) fetch1(k + 1);
-            __builtin_amdgcn_sched_barrier(0);
-            // rows vl, vt, r; the column of B_k / b_k this lane takes up at stage k
-            n[3] = 0.0; n[4] = 0.0; n[5] = 0.0;
-#pragma unroll
-            for (int i = 0; i < 3; i++)
-#pragma unroll
-                for (int c = 0; c < 5; c++) n[3 + i] += S2[i][c] * w[3 + c];
-#pragma unroll
-            for (int i = 0; i < 6; i++) w[i] = n[i];
-            {
-                const double sel = (colv && j == k) ? 1.0 : 0.0;
-#pragma unroll
-                for (int i = 0; i < 6; i++) w[i] += sel * Bc[i];
-                const double b6 = r0 ? dt : 0.0, b7 = r0 ? 0.0 : dt;
-                w[6] += sel * b6; w[7] += sel * b7;
-                if (wv == 1) {
-                    const double selg = isg ? 1.0 : 0.0;
-#pragma unroll
-                    for (int i = 0; i < 8; i++) w[i] += selg * bk[i];
-                }
-            }
+        auto stage = [&](int k, const Rk &r, Rk &nxt) {
+            fetch(k + 1, nxt);      // (unconditional: behind a branch the wait for the previous stage's reads would cover these too; sRec holds N + 2 records)
+            // w <- A_k w (apply_A, nmpc_device.hpp: rows px, py start from w + Sp w_psi, row psi from w_psi, the rest from 0)
+            double na = (ra < 2) ? wa + r.sp * w2 : wa, nb = 0.0;
+            na += r.Sa[0] * w3; na += r.Sa[1] * w4; na += r.Sa[2] * w5; na += r.Sa[3] * w6; na += r.Sa[4] * w7;
+            nb += r.Sb[0] * w3; nb += r.Sb[1] * w4; nb += r.Sb[2] * w5; nb += r.Sb[3] * w6; nb += r.Sb[4] * w7;
+            // the column of B_k (b_k for g) this column takes up at stage k
+            const double sel = (colv && j == k) ? 1.0 : 0.0, selg = isg ? 1.0 : 0.0;
+            na += sel * r.Ba; nb += sel * r.Bb;
+            const double b6 = r0 ? dt : 0.0, b7 = r0 ? 0.0 : dt;
+            w6 += sel * b6; w7 += sel * b7;
+            na += selg * r.ba; nb += selg * r.bb; w6 += selg * r.b6; w7 += selg * r.b7;
+            wa = na; wb = nb;
+            w2 = quad_bcast<2>(na); w3 = quad_bcast<0>(nb); w4 = quad_bcast<1>(nb); w5 = quad_bcast<2>(nb);
             const int s = k + 1, Ts = (s + 7) >> 3;
-            const double hr = gg[0] * w[3] + gg[1] * w[5] + gg[2] * w[7];
+            const double hr = r.g3 * w3 + r.g5 * w5 + r.g7 * w7;
+            const double wrow = (rho == 3) ? w3 : na;           // row rho of G_s (row 3 of the cost: vl)
             if (isg) {
-#pragma unroll
-                for (int i = 0; i < 4; i++) sG[s * 4 + i] = w[i];
-                gvec[PV_D + 2 * (s - 1)] = gg[4] + w[6];
-                gvec[PV_D + 2 * (s - 1) + 1] = gg[3] + hr;
+                sG[s * 4 + rho] = wrow;
+                if (rho == 3) {
+                    gvec[PV_D + 2 * (s - 1)] = r.xd + w6;
+                    gvec[PV_D + 2 * (s - 1) + 1] = r.hd + hr;
+                }
             }
             {   // the gg row of stage s in the operand layout of the interior point kernel (see cond_kernel)
                 const int c_ = (s - 1) >> 2;
                 double *gcs = pa.cws + (size_t)b * NCH * 64 + 16 * ((s - 1) & 3) + lc;
-                if (colv && 2 * T <= c_) gcs[(T * (NC - T - 1) + c_) * 64] = hr;
+                if (rho == 3 && colv && 2 * T <= c_) gcs[(T * (NC - T - 1) + c_) * 64] = hr;
             }
-            if (colv && T < Ts) {
-                double *row = sRows + CW::rowoff(s) + col;
-                const int pitch = 16 * Ts;
-#pragma unroll
-                for (int r = 0; r < 4; r++) row[r * pitch] = w[r];
+            if (colv && T < Ts) sRows[CW::rowoff(s) + rho * (16 * Ts) + cs] = wrow;
+        };
+        {
+            Rk ra_, rb_;
+            fetch(0, ra_);
+            for (int k = 0; k < N; k += 2) {
+                stage(k, ra_, rb_);
+                if (k + 1 < N) stage(k + 1, rb_, ra_);
             }
         }
         for (int s = N + 1; s <= NMAX; s++) {          // rows beyond the horizon: zeros
             const int c_ = (s - 1) >> 2;
             double *gcs = pa.cws + (size_t)b * NCH * 64 + 16 * ((s - 1) & 3) + lc;
-            if (colv && 2 * T <= c_) gcs[(T * (NC - T - 1) + c_) * 64] = 0.0;
+            if (rho == 3 && colv && 2 * T <= c_) gcs[(T * (NC - T - 1) + c_) * 64] = 0.0;
         }
     }
     __syncthreads();
-#if defined(TUM_CW_STOP) && TUM_CW_STOP == 2
-    return;
-#endif
 
     // ---- phase 2
     const int lq = lane >> 4, lc = lane & 15;
-#if defined(TUM_CW_STOP) && TUM_CW_STOP == 3
-    if (wv >= CW_SYRK) return;
-#endif
-#if defined(TUM_CW_STOP) && TUM_CW_STOP == 4
-    if (wv < CW_SYRK) return;
-#endif
     if (wv < CW_SYRK) {
         auto syrk = [&](auto wvc) {
             constexpr int WV = decltype(wvc)::value;
@@ -867,27 +823,38 @@ __global__ void __launch_bounds__(64 * CW_WAVES) cond_wide_kernel(const PArgs pa
         else if (wv == 2) syrk(std::integral_constant<int, 2>());
         else syrk(std::integral_constant<int, 3>());
     } else {
-        // gradient of the tracking cost through G_s (wavefront 4: columns 0..63, wavefront 5: columns 64..), input cost
+        // gradient of the tracking cost through G_s (wavefront 4: columns 0..63, wavefront 5: columns 64..), input cost.
+        // e_r(s) = w_r (res_r + g_r) of every stage first (a table per wavefront: wave-level ordering only), then the sums over the
+        // stages with nothing but loads and FMAs in the loop (dead columns read a zero instead of being branched round)
+        if (wv >= CW_SYRK + 2) return;
         const int col = 64 * (wv - CW_SYRK) + lane;
         const bool colv = col < NVP;
         const int T = col >> 4, j = col >> 1, r0 = col & 1;
-        double q = 0.0;
-#pragma unroll 4
-        for (int s = 1; s <= N; s++) {
-            const int Ts = (s + 7) >> 3;
+        double *sE = sEq + (wv - CW_SYRK) * ((NMAX + 1) * 4 + 2);
+        for (int i = lane; i < 4 * N; i += 64) {
+            const int s = 1 + (i >> 2), r = i & 3;
             const double sc = (s < N) ? dt : 1.0;
-            const double *recn = sRec + s * PREC;
-            const bool live = colv && T < Ts;
-            const double *row = sRows + CW::rowoff(s) + (live ? col : 0);
-            double a = 0.0;
-#pragma unroll
-            for (int r = 0; r < 4; r++) {
-                const double e = (sc * sWt[s * 6 + r]) * (recn[PR_RES + r] + sG[s * 4 + r]);
-                const double wr_ = live ? row[r * 16 * Ts] : 0.0;
-                a += e * wr_;
-            }
-            q += a;
+            sE[4 * s + r] = (sc * sWt[s * 6 + r]) * (sRec[s * PREC + PR_RES + r] + sG[s * 4 + r]);
         }
+        if (lane == 0) sE[0] = 0.0;
+        wsync();
+        double q = 0.0;
+        static_for<1, NT>([&](auto tsc) {
+            constexpr int Ts = decltype(tsc)::value;
+            const bool live = colv && T < Ts;
+            const int se = (N < 8 * Ts) ? N : 8 * Ts;
+#pragma unroll 4
+            for (int s = 8 * (Ts - 1) + 1; s <= se; s++) {
+                const double *row = live ? sRows + CW::rowoff(s) + col : sE;      // (sE[0] = 0, and what lies 16 Ts, 32 Ts, 48 Ts doubles behind it is finite)
+                double a = 0.0;
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    const double wr_ = live ? row[r * 16 * Ts] : 0.0;
+                    a += sE[4 * s + r] * wr_;
+                }
+                q += a;
+            }
+        });
         if (col < nv) q += dt * sWt[j * 6 + 4 + r0] * (sU0[col] - gyref[j * 6 + 4 + r0]);
         if (colv) gvec[PV_Q + col] = q;
     }

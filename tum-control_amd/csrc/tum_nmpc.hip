@@ -745,7 +745,7 @@ static int launch_pipeline(tum_ocp *c, bool events)
             static const int wide_env = [] { const char *e = getenv("TUM_COND_WIDE"); return e ? atoi(e) : -1; }();
             const int want = (c->cond_wide >= 0) ? c->cond_wide : wide_env;
             if (want > 0 || (want < 0 && c->batch <= 256))
-                hipLaunchKernelGGL((cond_wide_kernel<NTv>), dim3(c->batch), dim3(64 * CW_WAVES), 0, c->stream, pa);
+                hipLaunchKernelGGL((cond_wide_kernel<NTv>), dim3(c->batch), dim3(64 * cw_waves<NTv>()), 0, c->stream, pa);
             else hipLaunchKernelGGL((cond_kernel<NTv, false>), dim3(c->batch), dim3(64), 0, c->stream, pa);
         }
         if (events) (void)hipEventRecord(c->evi0, c->stream);
