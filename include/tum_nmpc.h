@@ -158,7 +158,16 @@ int tum_ocp_set_schedule(tum_ocp *c, int longest_first);
  * Two further names choose the PROLOGUE of a coupled SNMPC capsule without touching the rest: "prologue-mfma" (the column
  * recursions of the samples as v_mfma_f64_4x4x4_4b products; n_samples <= 10, where it is the library's own choice) and
  * "prologue-passes" (the column-slot / pass kernels of rounds 1-3, the only ones for n_samples > 10): two implementations of
- * the same hand-over the tests hold against each other. */
+ * the same hand-over the tests hold against each other.
+ * Small batches are bound by the length of ONE pass of a kernel, not by throughput; for them the library launches wider forms of
+ * the first two kernels of the pipeline, and four more names pin the choice (tests, A/B runs):
+ *   "lin-eight-lanes" / "lin-lane-per-stage"      linearisation with eight lanes per (instance, stage) -- one sensitivity column per
+ *       lane, the tyre chains of the model split over a DPP quad -- or one; default: eight while batch x (N+1) x 8 lanes are one
+ *       round of wavefronts (batch <= 199 at N = 40). b_k identical, A_k / B_k to 3e-15 relative (FMA contraction).
+ *   "cond-six-wavefronts" / "cond-one-wavefront"  condensing with a workgroup of six (N > 40: seven) wavefronts per OCP -- column
+ *       recursion with four lanes per column, Hessian tiles dealt to four wavefronts, gradient on two -- or one wavefront;
+ *       default: the workgroup while batch <= 256 (one per CU). Bit-identical results. The nominal OCP only.
+ * Environment overrides (read once): TUM_LIN_COLS, TUM_COND_WIDE = 0 | 1. */
 int tum_ocp_set_kernel(tum_ocp *c, const char *name);
 /* last kernel launch time in milliseconds (HIP events on the launch stream) */
 double tum_ocp_last_kernel_ms(tum_ocp *c);

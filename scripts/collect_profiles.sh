@@ -32,6 +32,9 @@ $T rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/sn38 -o s -- pyt
 $T rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/sn05 -o s -- python scripts/dev/sn_uph_profile.py 38 5 > /dev/null 2>&1 < /dev/null
 $T python scripts/pcie_inclusive.py 1 3 2>&1 < /dev/null | grep -v amdgpu.ids > $OUT/pcie.txt
 $T python scripts/closed_loop_variants.py 2>&1 < /dev/null | grep -v amdgpu.ids > $OUT/closed_loops.txt
+# the latency path: wide linearisation / condensing kernels against the ones they replace for small batches; per-kernel times of the 26-vehicle loop
+$T python scripts/small_batch_variants.py 2>&1 < /dev/null | grep -v amdgpu.ids > $OUT/small_batch_variants.txt
+$T rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/loop26 -o s -- python scripts/loop_prof.py 26 > /dev/null 2>&1 < /dev/null
 # round 4: the library of commit f5e2d65 (packed-triangular factor; scripts/dev/build_exp_lib.sh f5e2d65) against the shipped one (tiled factor)
 [ -f exp_libs/lib_f5e2d65.so ] && $T python scripts/dev/ab2.py exp_libs/lib_f5e2d65.so shipped 2>&1 < /dev/null | grep -v amdgpu.ids > $OUT/ab_tiled_factor_vs_shipped.txt
 for f in 0 1; do echo "TUM_FUSED_EXPAND=$f" >> $OUT/fused_expand.txt; TUM_FUSED_EXPAND=$f $T python scripts/probes/solve_wall_time.py 2>&1 < /dev/null | grep pipeline >> $OUT/fused_expand.txt; TUM_FUSED_EXPAND=$f $T python bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-schedule-legs --no-host-legs 2>/dev/null < /dev/null | grep metric | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('  config 2, three streams: value %.3f M solves/s'%(d['value']/1e6))" >> $OUT/fused_expand.txt; done

@@ -19,7 +19,10 @@ def main():
     w = snm.hammersley_normal(10, 3)
     A = snm.pce_matrix(w, snm.alpha_generation(3, 2))
     offs = snm.x0_offsets(w, stds)
-    for N, uph in ((38, 5), (40, 5), (38, 9), (40, 15), (40, 24), (38, 38)):      # (38, 38): UPH = Tp as in the ACC24 campaign of the reference
+    cases = ((38, 5), (40, 5), (38, 9), (40, 15), (40, 24), (38, 38))               # (38, 38): UPH = Tp as in the ACC24 campaign of the reference
+    if os.environ.get("SN_ONLY"):                                                   # e.g. SN_ONLY=38,38
+        cases = (tuple(int(v) for v in os.environ["SN_ONLY"].split(",")),)
+    for N, uph in cases:
         x0, yref = nominal_batch(B, N=N)
         X0 = np.concatenate([x0[:, None, :], x0[:, None, :] + offs[None]], axis=1)          # (B, 11, 8)
         s = CoupledSnmpcSolver(N=N, dt=0.08, batch=B, Apce=A, uph=uph, gamma=config.MPC["gamma"])
@@ -51,6 +54,33 @@ def main():
             print(f"  CPU restatement (88-state condensing that skips the zero blocks, one thread): {1e3 * np.median(t):.1f} ms per solve; "
                   f"reference acados SNMPC: about 6.1 ms per solve (its logs)")
         del s
+        if (N, uph) in ((38, 5), (38, 38)) and int(os.environ.get("SN_STREAMS", 3)) > 1:
+            # several batches in flight, as the headline of bench.py: S capsules on their own streams, a cold start + solve
+            # enqueued on each in turn (independent batches: scenario sweeps have nothing to wait for), wall clock over K rounds
+            from tum_control_amd.streaming import SolverRing
+            S = int(os.environ.get("SN_STREAMS", 3))
+
+            def mk(_):
+                c = CoupledSnmpcSolver(N=N, dt=0.08, batch=B, Apce=A, uph=uph, gamma=config.MPC["gamma"])
+                c.install_reference_ocp()
+                c.constraints_set(0, "lbx", X0.reshape(B, -1)); c.constraints_set(0, "ubx", X0.reshape(B, -1))
+                c.set_yref_all(yref)
+                return c
+            ring = SolverRing(S, mk)
+            for _ in range(2 * S):
+                _, c = ring.acquire(); c.cold_start(); c.solve_async()
+            ring.synchronize()
+            K = 8 * S
+            t0 = time.perf_counter()
+            for _ in range(K):
+                _, c = ring.acquire(); c.cold_start(); c.solve_async()
+            ring.synchronize()
+            dt_ = time.perf_counter() - t0
+            ok = min((c.get_stats("status") == 0).mean() for c in ring)
+            print(f"  {S} capsules in flight (cold start + solve each, {K} batches): {1e3 * dt_ / K:.3f} ms per batch -> {B * K / dt_:,.0f} solves/s (status0 {ok:.4f})")
+            del ring
+    if os.environ.get("SN_ONLY"):
+        return
     # the SNMPC controller in closed loop, planner / plant / estimator / x0 fan-out as device kernels
     from tum_control_amd.closed_loop import ClosedLoopBatch
     for Bc, steps in ((1, 1000), (4096, 200)):
