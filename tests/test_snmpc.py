@@ -874,3 +874,37 @@ def test_gpu_pipeline_instrumented_kernel_agrees():
         res[mode] = (s.get_iterate()[1].copy(), s.get_stats("qp_iter").copy(), s.get_cost().copy())
     for i in range(3):
         np.testing.assert_array_equal(res["phases"][i], res["plain"][i])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("N,uph", [(38, 5), (40, 24), (38, 38), (48, 12), (12, 12), (38, 0)])
+def test_gpu_snmpc_condensing_six_wavefronts_is_the_same_arithmetic(golden_dir, N, uph):
+    """cond_wide_kernel<., true> (small batches) against cond_kernel<., true> on the nominal copy of the coupled SNMPC OCP:
+    stages <= uph from the prologue's hand-over, the recursion behind them, |v| speed row -- every sum from the same operands
+    in the same order, so three warm-started solves end bit-identical."""
+    from tum_control_amd.solver import CoupledSnmpcSolver
+    snm, stds, w, A = _pce()
+    d = np.load(os.path.join(golden_dir, "kat0.npz"))
+    poses = (0, 26, 30)
+    B = len(poses)
+    X0 = np.zeros((B, 11, 8)); Y = np.zeros((B, N + 1, 6))
+    for j, i in enumerate(poses):
+        X0[j] = snm.compute_x0dist(d["x0"][i].copy(), w, stds)
+        yr = d["yref"][i]
+        Y[j, :min(N, 38) + 1, :4] = yr[:min(N, 38) + 1]
+        for k in range(39, N + 1):
+            Y[j, k, :4] = 2 * Y[j, k - 1, :4] - Y[j, k - 2, :4]
+    out = {}
+    for name in ("cond-one-wavefront", "cond-six-wavefronts"):
+        s = CoupledSnmpcSolver(N=N, dt=0.08, batch=B, Apce=A, uph=uph, gamma=0.8)
+        s.set_kernel(name)
+        s.install_reference_ocp()
+        s.constraints_set(0, "lbx", X0.reshape(B, -1)); s.constraints_set(0, "ubx", X0.reshape(B, -1))
+        s.set_yref_all(Y); s.cold_start()
+        for _ in range(3):
+            assert s.solve() == 0
+        Xn, U = s.get_iterate()
+        XS = np.stack([np.atleast_2d(s.get(k, "x")) for k in (0, 1, max(uph, 1), N)])
+        out[name] = (Xn, U, np.atleast_1d(s.get_cost()), s.get_stats("qp_iter"), XS)
+    for p, q in zip(out["cond-one-wavefront"], out["cond-six-wavefronts"]):
+        assert np.array_equal(p, q)

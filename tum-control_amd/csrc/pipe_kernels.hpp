@@ -659,15 +659,19 @@ template <int NT_> struct CondWide {
     static __device__ __forceinline__ int rowoff(int s) { const int Ts = (s + 7) >> 3; return 64 * (4 * Ts * (Ts - 1) + (s - 1 - 8 * (Ts - 1)) * Ts); }
 };
 
-template <int NT_>
+// SN = true: the nominal copy of the coupled SNMPC OCP -- G_s, g_s and the chance-constraint rows of the stages s <= uph come
+// from the prologue kernel's hand-over buffer, the recursion starts behind them; speed row |v|, gg row with its vt partial
+// (the same differences as between cond_kernel<., false> and cond_kernel<., true>)
+template <int NT_, bool SN>
 __global__ void __launch_bounds__(64 * cw_waves<NT_>()) cond_wide_kernel(const PArgs pa)
 {
     PD_LOCALS
     using CW = CondWide<NT_>;
     constexpr int CW_WAVES = cw_waves<NT_>();
+    constexpr int GSTR = SN ? 8 : 4;            // doubles of the g column kept per stage (rows px, py, psi, vl; SN: vt too)
     __shared__ __attribute__((aligned(16))) double sRec[(NMAX + 3) * PREC];       // (+2: the read-ahead of the last stage stays inside)
     __shared__ __attribute__((aligned(16))) double sRows[CW::ROWS];
-    __shared__ double sG[(NMAX + 1) * 4], sWt[(NMAX + 1) * 6], sU0[NVP], sEq[2 * ((NMAX + 1) * 4 + 2)];
+    __shared__ double sG[(NMAX + 1) * GSTR], sWt[(NMAX + 1) * 6], sU0[NVP], sEq[2 * ((NMAX + 1) * 4 + 2)];
     const KArgs &ka = pa.ka;
     const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63, b = blockIdx.x;
     if (b >= ka.batch) return;
@@ -680,6 +684,9 @@ __global__ void __launch_bounds__(64 * cw_waves<NT_>()) cond_wide_kernel(const P
     const double *gyref = ka.yref + (size_t)b * (N + 1) * 6;
     const double *gW = ka.W + (size_t)b * (N + 1) * 6;
     double *gvec = pa.vec + (size_t)b * PVEC;
+    const int uph = SN ? ka.uph : 0;
+    const int PP = SN ? sn_pro_pitch(uph) : 64, PSTAGE = 9 * PP;
+    const double *gpro = SN ? ka.pro + (size_t)b * uph * PSTAGE : nullptr;
     for (int i = tid; i < (N + 1) * PREC; i += 64 * CW_WAVES) sRec[i] = grec[i];
     for (int i = tid; i < (N + 1) * 6; i += 64 * CW_WAVES) sWt[i] = gW[i];
     for (int i = tid; i < NVP; i += 64 * CW_WAVES) sU0[i] = (i < nv) ? gU[i] : 0.0;
@@ -697,7 +704,44 @@ __global__ void __launch_bounds__(64 * cw_waves<NT_>()) cond_wide_kernel(const P
             wa = gx0[ra] - gX[ra]; wb = gx0[rb] - gX[rb];
             w2 = gx0[2] - gX[2]; w3 = gx0[3] - gX[3]; w4 = gx0[4] - gX[4]; w5 = gx0[5] - gX[5]; w6 = gx0[6] - gX[6]; w7 = gx0[7] - gX[7];
         }
-        struct Rk { double Sa[5], Sb[5], sp, Ba, Bb, ba, bb, b6, b7, g3, g5, g7, hd, xd; };
+        // what a stage leaves behind (na: row ra as this lane formed or fetched it)
+        auto leave = [&](int s, double na, double nb, double hr, double hd, double xd, double cvl, double cvt) {
+            const int Ts = (s + 7) >> 3;
+            const double c3 = SN ? cvl * w3 + cvt * w4 : w3;    // the speed row of the cost: vl (nominal OCP) or |v|
+            const double wrow = (rho == 3) ? c3 : na;           // row rho of the cost rows of G_s
+            if (isg) {
+                sG[s * GSTR + rho] = (rho == 3) ? w3 : na;
+                if (SN && rho == 1) sG[s * GSTR + 4] = nb;
+                if (rho == 3) {
+                    gvec[PV_D + 2 * (s - 1)] = xd + w6;
+                    gvec[PV_D + 2 * (s - 1) + 1] = hd + hr;
+                }
+            }
+            {   // the gg row of stage s in the operand layout of the interior point kernel (see cond_kernel)
+                const int c_ = (s - 1) >> 2;
+                double *gcs = pa.cws + (size_t)b * NCH * 64 + 16 * ((s - 1) & 3) + lc;
+                if (rho == 3 && colv && 2 * T <= c_) gcs[(T * (NC - T - 1) + c_) * 64] = hr;
+            }
+            if (colv && T < Ts) sRows[CW::rowoff(s) + rho * (16 * Ts) + cs] = wrow;
+        };
+        if constexpr (SN) {
+            // stages s = k + 1 <= uph: PCE means of the sample recursions (prologue kernel), live columns only
+            for (int k = 0; k < uph && k < N; k++) {
+                const double *pg = gpro + (size_t)k * PSTAGE, *recn = sRec + (k + 1) * PREC;
+                const int s = k + 1;
+                const bool live = isg || (colv && cs < 2 * s);
+                const int idx = isg ? 2 * uph : (live ? cs : 0);
+                const double na = live ? pg[ra * PP + idx] : 0.0, nb = live ? pg[rb * PP + idx] : 0.0;
+                w2 = live ? pg[2 * PP + idx] : 0.0; w3 = live ? pg[3 * PP + idx] : 0.0; w4 = live ? pg[4 * PP + idx] : 0.0;
+                w5 = live ? pg[5 * PP + idx] : 0.0; w6 = live ? pg[6 * PP + idx] : 0.0; w7 = live ? pg[7 * PP + idx] : 0.0;
+                wa = na; wb = nb;
+                double hr = recn[PR_GH + 0] * w3 + recn[PR_GH + 1] * w5 + recn[PR_GH + 2] * w7, hd = recn[PR_GH + 3];
+                hr += recn[PR_G4] * w4;
+                if (s < uph) { hr = live ? pg[8 * PP + idx] : 0.0; hd = 0.0; }       // chance-constraint row E + kappa sqrt(Var) over the samples
+                leave(s, na, nb, hr, hd, recn[PR_XD], recn[PR_CV], recn[PR_CV + 1]);
+            }
+        }
+        struct Rk { double Sa[5], Sb[5], sp, Ba, Bb, ba, bb, b6, b7, g3, g5, g7, hd, xd, g4, cvl, cvt; };
         auto fetch = [&](int k, Rk &r) {
             const double *rec = sRec + k * PREC;
 #pragma unroll
@@ -707,6 +751,8 @@ __global__ void __launch_bounds__(64 * cw_waves<NT_>()) cond_wide_kernel(const P
             r.ba = rec[44 + ra]; r.bb = rec[44 + rb]; r.b6 = rec[44 + 6]; r.b7 = rec[44 + 7];
             r.g3 = rec[PREC + PR_GH + 0]; r.g5 = rec[PREC + PR_GH + 1]; r.g7 = rec[PREC + PR_GH + 2]; r.hd = rec[PREC + PR_GH + 3];
             r.xd = rec[PREC + PR_XD];
+            if constexpr (SN) { r.g4 = rec[PREC + PR_G4]; r.cvl = rec[PREC + PR_CV]; r.cvt = rec[PREC + PR_CV + 1]; }
+            else { r.g4 = 0.0; r.cvl = 1.0; r.cvt = 0.0; }
         };
         auto stage = [&](int k, const Rk &r, Rk &nxt) {
             fetch(k + 1, nxt);      // (unconditional: behind a branch the wait for the previous stage's reads would cover these too; sRec holds N + 2 records)
@@ -722,27 +768,15 @@ __global__ void __launch_bounds__(64 * cw_waves<NT_>()) cond_wide_kernel(const P
             na += selg * r.ba; nb += selg * r.bb; w6 += selg * r.b6; w7 += selg * r.b7;
             wa = na; wb = nb;
             w2 = quad_bcast<2>(na); w3 = quad_bcast<0>(nb); w4 = quad_bcast<1>(nb); w5 = quad_bcast<2>(nb);
-            const int s = k + 1, Ts = (s + 7) >> 3;
-            const double hr = r.g3 * w3 + r.g5 * w5 + r.g7 * w7;
-            const double wrow = (rho == 3) ? w3 : na;           // row rho of G_s (row 3 of the cost: vl)
-            if (isg) {
-                sG[s * 4 + rho] = wrow;
-                if (rho == 3) {
-                    gvec[PV_D + 2 * (s - 1)] = r.xd + w6;
-                    gvec[PV_D + 2 * (s - 1) + 1] = r.hd + hr;
-                }
-            }
-            {   // the gg row of stage s in the operand layout of the interior point kernel (see cond_kernel)
-                const int c_ = (s - 1) >> 2;
-                double *gcs = pa.cws + (size_t)b * NCH * 64 + 16 * ((s - 1) & 3) + lc;
-                if (rho == 3 && colv && 2 * T <= c_) gcs[(T * (NC - T - 1) + c_) * 64] = hr;
-            }
-            if (colv && T < Ts) sRows[CW::rowoff(s) + rho * (16 * Ts) + cs] = wrow;
+            double hr = r.g3 * w3 + r.g5 * w5 + r.g7 * w7;
+            if constexpr (SN) hr += r.g4 * w4;
+            leave(k + 1, na, nb, hr, r.hd, r.xd, r.cvl, r.cvt);
         };
         {
             Rk ra_, rb_;
-            fetch(0, ra_);
-            for (int k = 0; k < N; k += 2) {
+            const int k0 = (uph < N) ? uph : N;
+            fetch(k0, ra_);
+            for (int k = k0; k < N; k += 2) {
                 stage(k, ra_, rb_);
                 if (k + 1 < N) stage(k + 1, rb_, ra_);
             }
@@ -834,7 +868,8 @@ __global__ void __launch_bounds__(64 * cw_waves<NT_>()) cond_wide_kernel(const P
         for (int i = lane; i < 4 * N; i += 64) {
             const int s = 1 + (i >> 2), r = i & 3;
             const double sc = (s < N) ? dt : 1.0;
-            sE[4 * s + r] = (sc * sWt[s * 6 + r]) * (sRec[s * PREC + PR_RES + r] + sG[s * 4 + r]);
+            const double gs = (SN && r == 3) ? sRec[s * PREC + PR_CV] * sG[s * GSTR + 3] + sRec[s * PREC + PR_CV + 1] * sG[s * GSTR + 4] : sG[s * GSTR + r];
+            sE[4 * s + r] = (sc * sWt[s * 6 + r]) * (sRec[s * PREC + PR_RES + r] + gs);
         }
         if (lane == 0) sE[0] = 0.0;
         wsync();

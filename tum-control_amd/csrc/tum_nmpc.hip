@@ -739,13 +739,14 @@ static int launch_pipeline(tum_ocp *c, bool events)
     auto rest = [&](auto ntc) {
         constexpr int NTv = decltype(ntc)::value;
         const int ipm_lds = lds_req > PD<NTv>::I_LDS_BYTES ? lds_req : PD<NTv>::I_LDS_BYTES;
-        if (c->sn) hipLaunchKernelGGL((cond_kernel<NTv, true>), dim3(c->batch), dim3(64), 0, c->stream, pa);
-        else {
+        {
             // six wavefronts per OCP while every OCP can have a CU's LDS to itself (cond_wide_kernel)
             static const int wide_env = [] { const char *e = getenv("TUM_COND_WIDE"); return e ? atoi(e) : -1; }();
             const int want = (c->cond_wide >= 0) ? c->cond_wide : wide_env;
-            if (want > 0 || (want < 0 && c->batch <= 256))
-                hipLaunchKernelGGL((cond_wide_kernel<NTv>), dim3(c->batch), dim3(64 * cw_waves<NTv>()), 0, c->stream, pa);
+            const bool wide = want > 0 || (want < 0 && c->batch <= 256);
+            if (wide && c->sn) hipLaunchKernelGGL((cond_wide_kernel<NTv, true>), dim3(c->batch), dim3(64 * cw_waves<NTv>()), 0, c->stream, pa);
+            else if (wide) hipLaunchKernelGGL((cond_wide_kernel<NTv, false>), dim3(c->batch), dim3(64 * cw_waves<NTv>()), 0, c->stream, pa);
+            else if (c->sn) hipLaunchKernelGGL((cond_kernel<NTv, true>), dim3(c->batch), dim3(64), 0, c->stream, pa);
             else hipLaunchKernelGGL((cond_kernel<NTv, false>), dim3(c->batch), dim3(64), 0, c->stream, pa);
         }
         if (events) (void)hipEventRecord(c->evi0, c->stream);
