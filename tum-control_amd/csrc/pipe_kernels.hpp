@@ -342,6 +342,7 @@ __device__ __forceinline__ void rk4_sens_col(const Model &p, const TyreLane &t, 
     for (int i = 0; i < 8; i++) xn[i] = x[i];
 }
 
+template <bool SN>
 __global__ void __launch_bounds__(64, 1) lin_cols_kernel(const PArgs pa)
 {
     __shared__ double sT[LC_ITEMS * L_PITCH];
@@ -365,15 +366,25 @@ __global__ void __launch_bounds__(64, 1) lin_cols_kernel(const PArgs pa)
     double *rw = sT + li * L_PITCH;
     // the fields outside the sensitivity block are computed by every lane of the group (same loads, same operations) and
     // stored by lane 0
-    const double res0 = xk[0] - yr[0], res1 = xk[1] - yr[1], res2 = wrap_yaw(xk[2]) - yr[2], res3 = xk[3] - yr[3];
-    double h = 0.0, g3 = 0.0, g5 = 0.0, g7 = 0.0;
-    if (k >= 1) h_con(ka.mp, xk[3], xk[5], xk[7], h, g3, g5, g7);
+    const double res0 = xk[0] - yr[0], res1 = xk[1] - yr[1], res2 = wrap_yaw(xk[2]) - yr[2];
+    double res3 = xk[3] - yr[3], cv0 = 0.0, cv1 = 0.0;
+    if (SN) {           // the speed row |v| of the coupled SNMPC OCP and its gradient (lin_kernel<true>)
+        const double vabs = sqrt(xk[3] * xk[3] + xk[4] * xk[4]), iv = (vabs > 0.0) ? 1.0 / vabs : 0.0;
+        res3 = vabs - yr[3];
+        cv0 = xk[3] * iv; cv1 = xk[4] * iv;
+    }
+    double h = 0.0, g3 = 0.0, g4 = 0.0, g5 = 0.0, g7 = 0.0;
+    if (k >= 1) {
+        if (SN) h_con_vabs(ka.mp, xk[3], xk[4], xk[5], xk[7], h, g3, g4, g5, g7);
+        else h_con(ka.mp, xk[3], xk[5], xk[7], h, g3, g5, g7);
+    }
     if (col == 0) {
         rw[PR_RES + 0] = res0; rw[PR_RES + 1] = res1; rw[PR_RES + 2] = res2; rw[PR_RES + 3] = res3;
         rw[PR_GH + 0] = g3; rw[PR_GH + 1] = g5; rw[PR_GH + 2] = g7; rw[PR_GH + 3] = h;
         rw[PR_XD] = xk[6];
+        if (SN) { rw[PR_CV] = cv0; rw[PR_CV + 1] = cv1; rw[PR_G4] = g4; }
     }
-    if (k < N) {        // (uniform over the eight lanes of an item; the DPP exchanges stay inside a quad)
+    if (k < N && (!SN || k >= ka.uph)) {        // (uniform over the eight lanes of an item; the DPP exchanges stay inside a quad)
         const double *gU = ka.U + ((size_t)b * N + k) * NU;
         double uk[2] = {gU[0], gU[1]};
         double xn[8], Sc[6];
@@ -391,7 +402,7 @@ __global__ void __launch_bounds__(64, 1) lin_cols_kernel(const PArgs pa)
         for (int i = col; i < PR_RES; i += LC_LANES) rw[i] = 0.0;
     }
     wsync();
-    constexpr int NF = PR_XD + 1;          // fields in use
+    constexpr int NF = SN ? PREC : PR_XD + 1;          // fields in use
     double *dst = pa.rec + (size_t)g0 * PREC;
     const int nitem = (int)((total - g0 < LC_ITEMS) ? (total - g0) : LC_ITEMS);
     for (int it = 0; it < nitem; it++)

@@ -715,18 +715,20 @@ static int launch_pipeline(tum_ocp *c, bool events)
     pa.ka = c->ka; pa.rec = c->drec; pa.hws = c->dhws; pa.cws = c->dcws; pa.vec = c->dvec;
     const bool prof = (c->ka.flags & 4) != 0;
     const long long items = (long long)c->batch * (c->N + 1);
+    // linearisation: eight lanes per item while that still is one round of wavefronts on the chip (256 CUs x 4 SIMDs), see lin_cols_kernel
+    static const int cols_env = [] { const char *e = getenv("TUM_LIN_COLS"); return e ? atoi(e) : -1; }();
+    const int want_cols = (c->lin_cols >= 0) ? c->lin_cols : cols_env;
+    const bool cols = want_cols > 0 || (want_cols < 0 && items * LC_LANES <= 64LL * 1024);
+    const dim3 g_cols((unsigned)((items + LC_ITEMS - 1) / LC_ITEMS)), g_lane((unsigned)((items + 63) / 64));
     if (c->sn) {   // coupled SNMPC OCP: sample fan-out and prologue first, the QP solution goes to the epilogue through the workspace
         if (c->fanout && sn_fanout(c)) return 1;
         sn_launch_lin(c);
         sn_launch_prologue(c);
-        hipLaunchKernelGGL(lin_kernel<true>, dim3((unsigned)((items + 63) / 64)), dim3(64), 0, c->stream, pa);
+        if (cols) hipLaunchKernelGGL(lin_cols_kernel<true>, g_cols, dim3(64), 0, c->stream, pa);
+        else hipLaunchKernelGGL(lin_kernel<true>, g_lane, dim3(64), 0, c->stream, pa);
     } else {
-        // eight lanes per item while that still is one round of wavefronts on the chip (256 CUs x 4 SIMDs), see lin_cols_kernel
-        static const int cols_env = [] { const char *e = getenv("TUM_LIN_COLS"); return e ? atoi(e) : -1; }();
-        const int want = (c->lin_cols >= 0) ? c->lin_cols : cols_env;
-        const bool cols = want > 0 || (want < 0 && items * LC_LANES <= 64LL * 1024);
-        if (cols) hipLaunchKernelGGL(lin_cols_kernel, dim3((unsigned)((items + LC_ITEMS - 1) / LC_ITEMS)), dim3(64), 0, c->stream, pa);
-        else hipLaunchKernelGGL(lin_kernel<false>, dim3((unsigned)((items + 63) / 64)), dim3(64), 0, c->stream, pa);
+        if (cols) hipLaunchKernelGGL(lin_cols_kernel<false>, g_cols, dim3(64), 0, c->stream, pa);
+        else hipLaunchKernelGGL(lin_kernel<false>, g_lane, dim3(64), 0, c->stream, pa);
     }
     // (development aid: a larger LDS request lowers the number of OCPs that share a CU)
     // The expansion as the tail of the interior point kernel pays where a batch is at most one round of resident wavefronts (one
