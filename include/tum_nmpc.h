@@ -167,7 +167,7 @@ int tum_ocp_set_schedule(tum_ocp *c, int longest_first);
  *   "cond-six-wavefronts" / "cond-one-wavefront"  condensing with a workgroup of six (N > 40: seven) wavefronts per OCP -- column
  *       recursion with four lanes per column, Hessian tiles dealt to four wavefronts, gradient on two -- or one wavefront;
  *       default: the workgroup while batch <= 256 (one per CU). Bit-identical results. The nominal OCP only.
- * Environment overrides (read once): TUM_LIN_COLS, TUM_COND_WIDE = 0 | 1. */
+ * "auto" hands both choices back to the library. Environment overrides (read once): TUM_LIN_COLS, TUM_COND_WIDE = 0 | 1. */
 int tum_ocp_set_kernel(tum_ocp *c, const char *name);
 /* last kernel launch time in milliseconds (HIP events on the launch stream) */
 double tum_ocp_last_kernel_ms(tum_ocp *c);

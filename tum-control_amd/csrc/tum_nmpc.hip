@@ -642,7 +642,7 @@ extern "C" int tum_ocp_set_kernel(tum_ocp *c, const char *name)
 {
     if (!c || !name) return fail("null argument");
     const std::string n(name);
-    if (n == "auto") c->kmode = 0;
+    if (n == "auto") { c->kmode = 0; c->lin_cols = -1; c->cond_wide = -1; }        // (the wide kernels of the latency path: the library decides by batch size again)
     else if (n == "pipeline") c->kmode = 2;
     // the prologue of the coupled SNMPC OCP: the matrix-core kernel (default where n_samples <= 10) or the column-slot / pass variants
     // the linearisation: one lane per (instance, stage) or eight (default: eight while the batch is one round of wavefronts)
