@@ -504,6 +504,167 @@ __device__ __forceinline__ void rk4_sens(const Model &p, const double x0[8], con
     for (int i = 0; i < 8; i++) xn[i] = x[i];
 }
 
+// ---- the same interval with the work of ONE item spread over eight lanes (lin_cols_kernel, snmpc_lin_cols_kernel: the latency
+// path for small batches): one sensitivity column per lane, the transcendental chains of the model split over
+// each DPP quad.
+struct TyreLane { double B, C, D, E, invFmax, Fz, lsgn; bool front; int qrole; };
+
+// the lane's share of the model inside its DPP quad: lane 0 front tyre, 1 rear tyre, 2 sin / cos psi, 3 sin / cos delta (lanes 2, 3
+// repeat a tyre chain whose result is not used)
+__device__ __forceinline__ TyreLane tyre_lane(const Model &mp, int lane_in_group)
+{
+    TyreLane t;
+    t.qrole = lane_in_group & 3; t.front = !(lane_in_group & 1);
+    t.B = t.front ? mp.Bf : mp.Br; t.C = t.front ? mp.Cf : mp.Cr; t.D = t.front ? mp.Df : mp.Dr; t.E = t.front ? mp.Ef : mp.Er;
+    t.invFmax = t.front ? mp.invFmax_f : mp.invFmax_r; t.Fz = t.front ? mp.Fz_f : mp.Fz_r; t.lsgn = t.front ? -mp.lf : mp.lr;
+    return t;
+}
+
+// stm_core with the quad's division of labour; also returns sin / cos of psi (quad lane 2)
+__device__ __forceinline__ void stm_core_quad(const Model &p, const TyreLane &t, double vl, double vt, double r, double de, double a,
+                                              double psi, double f[3], double J[3][5], double &sn_psi, double &cs_psi)
+{
+    const double vv = vl * vl + vt * vt;
+    const double sp = fast_sqrt_pos(vv);
+    const double w = 0.036 * sp;                       // v[km/h] / 100
+    const double w2 = w * w;
+    const double fr = p.fr0 + p.fr1 * w + p.fr4 * w2 * w2;
+    const double dfr_dw = p.fr1 + 4.0 * p.fr4 * w2 * w;
+    const double isp = 0.036 * frcp(sp);
+    const double fr_vl = dfr_dw * isp * vl, fr_vt = dfr_dw * isp * vt;
+    const double Fxf = -fr * p.Fz_f;
+    const double Fxr = p.m * a - fr * p.Fz_r;
+    // ---- this lane's tyre
+    double al = 0, al_vl = 0, al_vt = 0, al_r = 0, al_de = 0;
+    if (vl > 0.001) {
+        const double ivl = frcp(vl);
+        const double nf = vt + p.lf * r, nr = p.lr * r - vt;
+        const double q = (t.front ? nf : nr) * ivl, c2 = frcp(1.0 + q * q);
+        const double at = fast_atan(q);
+        al = t.front ? de - at : at;
+        const double qs = t.front ? q : -q;
+        al_vl = qs * ivl * c2; al_vt = -ivl * c2; al_r = t.lsgn * ivl * c2; al_de = 1.0;
+    }
+    const double x1 = t.B * al;
+    const double at1 = fast_atan(x1);
+    const double inner = x1 - t.E * (x1 - at1);
+    const double th = fast_atan(inner);
+    double sn, cs;
+    fast_sincos(t.qrole < 2 ? t.C * th : (t.qrole == 2 ? psi : de), &sn, &cs);
+    const double Fy_lat = t.D * sn;
+    const double dFy = t.D * cs * t.C * frcp(1.0 + inner * inner) * (1.0 - t.E + t.E * frcp(1.0 + x1 * x1)) * t.B;
+    // combined slip weighting, clipped at +-0.98
+    double G = (t.front ? Fxf : Fxr) * t.invFmax, g_on = 1.0;
+    if (G > 0.98) { G = 0.98; g_on = 0.0; } else if (G < -0.98) { G = -0.98; g_on = 0.0; }
+    const double cg = fast_sqrt_pos(1.0 - G * G);                               // cos(asin(G)), |G| <= 0.98
+    const double dcg = -G * frcp(cg) * g_on * t.invFmax;                        // d cg / d Fx
+    const double Fx_vl = -t.Fz * fr_vl, Fx_vt = -t.Fz * fr_vt;
+    const double tFy = Fy_lat * cg;
+    const double tFy_vl = dFy * al_vl * cg + Fy_lat * dcg * Fx_vl;
+    const double tFy_vt = dFy * al_vt * cg + Fy_lat * dcg * Fx_vt;
+    const double tFy_r = dFy * al_r * cg;
+    const double tX = t.front ? dFy * al_de * cg : Fy_lat * dcg * p.m;          // front: d Fyf / d delta; rear: d Fyr / d a
+    // ---- exchange inside the quad
+    const double Fyf = quad_bcast<0>(tFy), Fyf_vl = quad_bcast<0>(tFy_vl), Fyf_vt = quad_bcast<0>(tFy_vt), Fyf_r = quad_bcast<0>(tFy_r),
+                 Fyf_de = quad_bcast<0>(tX);
+    // (the rear tyre's Fy and d Fy / d r go over as their FACTORS: stm_core adds each of these two products to another term --
+    //  Fyr + front, Fyr_r + fr_r_ -- which the compiler contracts into one FMA there; a product rounded on the tyre lane would
+    //  differ from that in the last bit)
+    const double Fyr_lat = quad_bcast<1>(Fy_lat), cgr = quad_bcast<1>(cg), Pr = quad_bcast<1>(dFy * al_r);
+    const double Fyr = Fyr_lat * cgr, Fyr_r = Pr * cgr;
+    const double Fyr_vl = quad_bcast<1>(tFy_vl), Fyr_vt = quad_bcast<1>(tFy_vt), Fyr_a = quad_bcast<1>(tX);
+    sn_psi = quad_bcast<2>(sn); cs_psi = quad_bcast<2>(cs);
+    const double sd = quad_bcast<3>(sn), cd = quad_bcast<3>(cs);
+    const double Fxf_vl = -p.Fz_f * fr_vl, Fxf_vt = -p.Fz_f * fr_vt;
+    const double Fxr_vl = -p.Fz_r * fr_vl, Fxr_vt = -p.Fz_r * fr_vt;
+    const double im = p.inv_m;
+    f[0] = (Fxr - p.ka * vl * vl - Fyf * sd + Fxf * cd) * im + vt * r;
+    J[0][0] = (Fxr_vl - 2.0 * p.ka * vl - Fyf_vl * sd + Fxf_vl * cd) * im;
+    J[0][1] = (Fxr_vt - Fyf_vt * sd + Fxf_vt * cd) * im + r;
+    J[0][2] = -Fyf_r * sd * im + vt;
+    J[0][3] = (-Fyf_de * sd - Fyf * cd - Fxf * sd) * im;
+    J[0][4] = 1.0;
+    const double front = Fyf * cd + Fxf * sd;
+    const double fr_vl_ = Fyf_vl * cd + Fxf_vl * sd, fr_vt_ = Fyf_vt * cd + Fxf_vt * sd;
+    const double fr_r_ = Fyf_r * cd, fr_de_ = Fyf_de * cd - Fyf * sd + Fxf * cd;
+    f[1] = (Fyr + front) * im - vl * r;
+    J[1][0] = (Fyr_vl + fr_vl_) * im - r;
+    J[1][1] = (Fyr_vt + fr_vt_) * im;
+    J[1][2] = (Fyr_r + fr_r_) * im - vl;
+    J[1][3] = fr_de_ * im;
+    J[1][4] = Fyr_a * im;
+    const double iz = p.inv_Iz;
+    f[2] = (p.lf * front - p.lr * Fyr) * iz;
+    J[2][0] = (p.lf * fr_vl_ - p.lr * Fyr_vl) * iz;
+    J[2][1] = (p.lf * fr_vt_ - p.lr * Fyr_vt) * iz;
+    J[2][2] = (p.lf * fr_r_ - p.lr * Fyr_r) * iz;
+    J[2][3] = p.lf * fr_de_ * iz;
+    J[2][4] = -p.lr * Fyr_a * iz;
+}
+
+// rk4_sens with one sensitivity column per lane: col 0..6 = column of S (w.r.t. vl0, vt0, r0, delta0, a0, jerk, steering rate),
+// col 7 = the psi0 column (rows px, py move; its psi entry is the constant 1). Sc: the lane's column, rows (px, py, psi, vl, vt, r).
+__device__ __forceinline__ void rk4_sens_col(const Model &p, const TyreLane &t, int col, const double x0[8], const double u[2], double dt,
+                                             int nsub, double xn[8], double Sc[6])
+{
+    double x[8];
+#pragma unroll
+    for (int i = 0; i < 8; i++) x[i] = x0[i];
+#pragma unroll
+    for (int i = 0; i < 6; i++) Sc[i] = 0.0;
+    Sc[2] = (col == 7) ? 1.0 : 0.0; Sc[3] = (col == 0) ? 1.0 : 0.0; Sc[4] = (col == 1) ? 1.0 : 0.0; Sc[5] = (col == 2) ? 1.0 : 0.0;
+    const bool cpsi = col == 7;
+    const double h = dt / nsub;
+    for (int sub = 0; sub < nsub; sub++) {
+        double xacc[6], kp[6], Sacc[6], Kp[6];
+#pragma unroll
+        for (int i = 0; i < 6; i++) { xacc[i] = 0.0; kp[i] = 0.0; Sacc[i] = 0.0; Kp[i] = 0.0; }
+#pragma unroll 1
+        for (int st = 0; st < 4; st++) {
+            const double ci = (st == 0) ? 0.0 : (st == 3 ? 1.0 : 0.5);
+            const double bi = (st == 0 || st == 3) ? (1.0 / 6.0) : (2.0 / 6.0);
+            const double ch = ci * h;
+            const double tau = sub * h + ch;                 // time since the start of the interval
+            const double psi = x[2] + ch * kp[2];
+            const double vl = x[3] + ch * kp[3], vt = x[4] + ch * kp[4], r = x[5] + ch * kp[5];
+            const double de = x[6] + ch * u[1], a = x[7] + ch * u[0];
+            double f[3], J[3][5], sn, cs;
+            stm_core_quad(p, t, vl, vt, r, de, a, psi, f, J, sn, cs);
+            double k[6];
+            k[0] = vl * cs - vt * sn; k[1] = vl * sn + vt * cs; k[2] = r;
+            k[3] = f[0]; k[4] = f[1]; k[5] = f[2];
+            const double J02 = -k[1], J12 = k[0];            // d(px_dot,py_dot)/dpsi
+            {
+                double s[6];
+#pragma unroll
+                for (int i = 0; i < 6; i++) s[i] = Sc[i] + ch * Kp[i];
+                const double sde = (col == 3) ? 1.0 : ((col == 6) ? tau : 0.0);
+                const double sa = (col == 4) ? 1.0 : ((col == 5) ? tau : 0.0);
+                double K[6];
+                const double K0 = J02 * s[2] + cs * s[3] - sn * s[4];
+                const double K1 = J12 * s[2] + sn * s[3] + cs * s[4];
+                K[0] = cpsi ? J02 : K0;                      // (the psi0 column: rows px, py only, S[psi][psi0] = 1)
+                K[1] = cpsi ? J12 : K1;
+                K[2] = s[5];
+#pragma unroll
+                for (int i = 0; i < 3; i++)
+                    K[3 + i] = J[i][0] * s[3] + J[i][1] * s[4] + J[i][2] * s[5] + J[i][3] * sde + J[i][4] * sa;
+#pragma unroll
+                for (int i = 0; i < 6; i++) { Sacc[i] += bi * K[i]; Kp[i] = K[i]; }
+            }
+#pragma unroll
+            for (int i = 0; i < 6; i++) { xacc[i] += bi * k[i]; kp[i] = k[i]; }
+        }
+#pragma unroll
+        for (int i = 0; i < 6; i++) x[i] += h * xacc[i];
+        x[6] += h * u[1]; x[7] += h * u[0];
+#pragma unroll
+        for (int i = 0; i < 6; i++) Sc[i] += h * Sacc[i];
+    }
+#pragma unroll
+    for (int i = 0; i < 8; i++) xn[i] = x[i];
+}
+
 // w <- A_k w using the compact record (Sp[2] | S[6][7] | b[8]); rows 6,7 of A are identity rows.
 __device__ __forceinline__ void apply_A(const double *rec, double w[8])
 {

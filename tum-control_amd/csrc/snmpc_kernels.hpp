@@ -162,6 +162,54 @@ __global__ void __launch_bounds__(64, 1) snmpc_lin_kernel(const SnArgs sa)
         if ((int)threadIdx.x < 52) dst[(size_t)it * ABS + threadIdx.x] = sT[it * ABS + threadIdx.x];
 }
 
+// K-S1 for small batches: eight lanes per (instance, stage, sample) item -- one sensitivity column per lane, tyre chains split over
+// each DPP quad (rk4_sens_col, nmpc_device.hpp; lin_cols_kernel is the nominal counterpart). The state step is bit-identical to
+// snmpc_lin_kernel's, the sensitivities agree to 3e-15 relative (FMA contraction, see lin_cols_kernel).
+constexpr int SLC_LANES = 8, SLC_ITEMS = 64 / SLC_LANES;
+__global__ void __launch_bounds__(64, 1) snmpc_lin_cols_kernel(const SnArgs sa)
+{
+    __shared__ double sT[SLC_ITEMS * ABS];
+    const int N = sa.N, ns = sa.ns, nitem = sa.uph * ns;
+    const long long total = (long long)sa.batch * nitem;
+    const int li = threadIdx.x / SLC_LANES, col = threadIdx.x % SLC_LANES;
+    const long long g0 = (long long)blockIdx.x * SLC_ITEMS, gl = g0 + li;
+    const bool live = gl < total;
+    const long long g = live ? gl : total - 1;          // (groups beyond the last item shadow it and store nothing)
+    const int b = (int)(g / nitem), item = (int)(g - (long long)b * nitem);
+    const int k = item / ns, i = item - k * ns;
+    const double *gXS = sa.XS + (size_t)b * (N + 1) * ns * NX;
+    const double *gU = sa.U + (size_t)b * N * NU;
+    const double *xp = gXS + ((size_t)k * ns + i) * NX;
+    double xk[8], uk[2] = {gU[2 * k], gU[2 * k + 1]};
+#pragma unroll
+    for (int r = 0; r < 8; r++) xk[r] = xp[r];
+    const TyreLane t = tyre_lane(sa.mp, col);
+    double xn[8], Sc[6];
+    rk4_sens_col(sa.mp, t, col, xk, uk, sa.dt, 1, xn, Sc);
+    double *rec = sT + li * ABS;
+    if (col == 7) { rec[0] = Sc[0]; rec[1] = Sc[1]; }
+    else {
+#pragma unroll
+        for (int r = 0; r < 6; r++) rec[2 + r * 7 + col] = Sc[r];
+    }
+    const double *xq = gXS + ((size_t)(k + 1) * ns + i) * NX;
+    double dn = xn[0] - xq[0];
+#pragma unroll
+    for (int r = 1; r < 8; r++) dn = (col == r) ? xn[r] - xq[r] : dn;
+    rec[44 + col] = dn;
+    double h = 0.0, g3 = 0.0, g4 = 0.0, g5 = 0.0, g7 = 0.0;
+    if (k >= 1) h_con_vabs(sa.mp, xk[3], xk[4], xk[5], xk[7], h, g3, g4, g5, g7);
+    if (live && col < 5) {
+        const double v = (col == 0) ? h : (col == 1) ? g3 : (col == 2) ? g4 : (col == 3) ? g5 : g7;
+        sa.gh[(size_t)g * 5 + col] = v;
+    }
+    wsync();
+    double *dst = sa.ws2 + (size_t)g0 * ABS;
+    const int nit = (int)((total - g0 < SLC_ITEMS) ? (total - g0) : SLC_ITEMS);
+    for (int it = 0; it < nit; it++)
+        if ((int)threadIdx.x < 52) dst[(size_t)it * ABS + threadIdx.x] = sT[it * ABS + threadIdx.x];
+}
+
 template <int NPM>
 __global__ void __launch_bounds__(64) snmpc_prologue_kernel(const SnArgs sa)
 {

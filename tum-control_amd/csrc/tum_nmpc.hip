@@ -341,7 +341,13 @@ static int sn_set_p(tum_ocp *c, int stage, const double *v, int len, int nb, int
 static void sn_launch_lin(tum_ocp *c)
 {
     const long long items = (long long)c->batch * c->sa.uph * c->sa.ns;
-    if (items > 0) hipLaunchKernelGGL(snmpc_lin_kernel, dim3((unsigned)((items + 63) / 64)), dim3(64), 0, c->stream, c->sa);
+    if (items <= 0) return;
+    // eight lanes per item while that still is one round of wavefronts on the chip (the same rule as launch_pipeline's for lin_cols_kernel)
+    static const int cols_env = [] { const char *e = getenv("TUM_LIN_COLS"); return e ? atoi(e) : -1; }();
+    const int want = (c->lin_cols >= 0) ? c->lin_cols : cols_env;
+    if (want > 0 || (want < 0 && items * SLC_LANES <= 64LL * 1024))
+        hipLaunchKernelGGL(snmpc_lin_cols_kernel, dim3((unsigned)((items + SLC_ITEMS - 1) / SLC_ITEMS)), dim3(64), 0, c->stream, c->sa);
+    else hipLaunchKernelGGL(snmpc_lin_kernel, dim3((unsigned)((items + 63) / 64)), dim3(64), 0, c->stream, c->sa);
 }
 
 // the epilogue leaves the sample copies of the stages > uph for later (snmpc_epilogue_kernel); this brings them up to date
