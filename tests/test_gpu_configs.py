@@ -367,3 +367,41 @@ def test_results_on_the_host_through_pinned_slabs():
     Xr, Ur = s2.get_iterate()
     assert np.array_equal(Xb, Xr) and np.array_equal(Ub, Ur) and not np.array_equal(Ua, Ub)
     assert a.ctypes.data != b.ctypes.data and np.array_equal(b[:, :2], Ur[:, 0])
+
+
+@pytest.mark.gpu
+def test_one_call_control_step_equals_setters_solve_getters():
+    """tum_ocp_step_async (x0 and yref through pinned staging, the solve and the results request behind them) + results_wait
+    against the acados-style sequence constraints_set / set_yref_all / solve / getters: a warm-started sequence of control
+    steps with a new x0 and a new reference every step ends bit-identical; null inputs keep what the capsule has; two steps
+    may be outstanding and a third is refused."""
+    from tum_control_amd.workloads import nominal_batch
+    B, K = 5, 4
+    seq = [nominal_batch(B, N=N, seed=300 + k) for k in range(K)]
+    a, b = _mk(B), _mk(B)
+    for s in (a, b):
+        s.set_x0(seq[0][0]); s.set_yref_all(seq[0][1]); s.cold_start()
+    for k in range(K):
+        x0, yr = seq[k]
+        a.set_x0(x0); a.set_yref_all(yr)
+        assert a.solve() == 0
+        Xa, Ua = a.get_iterate()
+        summ, Xb, Ub = b.step(x0=x0, yref=yr, with_iterate=True)
+        assert np.array_equal(Xa, Xb) and np.array_equal(Ua, Ub)
+        assert np.array_equal(summ[:, :2], Ua[:, 0]) and np.array_equal(summ[:, 2], a.get_cost())
+        assert np.array_equal(summ[:, 3], a.get_stats("status")) and np.array_equal(summ[:, 4], a.get_stats("qp_iter"))
+    # null inputs: another real-time iteration on the same data
+    assert a.solve() == 0
+    summ, Xb, Ub = b.step(with_iterate=True)
+    Xa, Ua = a.get_iterate()
+    assert np.array_equal(Xa, Xb) and np.array_equal(Ua, Ub)
+    # two steps in flight (each with its own staging area and slabs), a third refused
+    b.step_async(x0=seq[1][0], yref=seq[1][1]); b.step_async(x0=seq[2][0], yref=seq[2][1])
+    with pytest.raises(Exception, match="two requests outstanding"):
+        b.step_async()
+    r1, r2 = b.results_wait(), b.results_wait()
+    a.set_x0(seq[1][0]); a.set_yref_all(seq[1][1]); a.solve(); U1 = a.get_iterate()[1].copy()
+    a.set_x0(seq[2][0]); a.set_yref_all(seq[2][1]); a.solve(); U2 = a.get_iterate()[1]
+    assert np.array_equal(r1[2], U1) and np.array_equal(r2[2], U2)
+    with pytest.raises(Exception, match="expected"):
+        b.step(x0=np.zeros(3))

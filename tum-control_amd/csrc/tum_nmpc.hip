@@ -66,6 +66,7 @@ struct tum_ocp {
     // host slabs, the event behind the copies
     // two sets, used in turn: the request for the NEXT batch can be enqueued before the previous batch's results have been read
     double *dsum, *hsum[2], *hX[2], *hU[2]; hipEvent_t evres[2]; bool res_iter[2]; int res_head, res_count;
+    double *hin[2];                    // pinned staging of x0 | yref of a step (tum_ocp_step_async), one per result slot
 };
 
 static const int DBG_STRIDE = 20480;
@@ -128,7 +129,7 @@ extern "C" tum_ocp *tum_ocp_create(const tum_ocp_desc *desc)
     c->r2 = false; c->dr2S = c->dr2B = nullptr;
     c->p_dirty = false; c->uph_cap = 0; c->gamma = 0.0; c->dpceA = nullptr; c->pce_L = c->pce_S = 0; c->dbnd_snap = nullptr;
     c->dsum = nullptr; c->res_head = c->res_count = 0;
-    for (int i = 0; i < 2; i++) { c->hsum[i] = c->hX[i] = c->hU[i] = nullptr; c->evres[i] = nullptr; c->res_iter[i] = false; }
+    for (int i = 0; i < 2; i++) { c->hsum[i] = c->hX[i] = c->hU[i] = c->hin[i] = nullptr; c->evres[i] = nullptr; c->res_iter[i] = false; }
     const int N = c->N; const size_t B = c->batch;
     bool ok = true;
     ok &= hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) == hipSuccess; c->own_stream = true;
@@ -236,6 +237,7 @@ extern "C" void tum_ocp_free(tum_ocp *c)
     (void)hipFree(c->dsum);
     for (int i = 0; i < 2; i++) {
         if (c->hsum[i]) (void)hipHostFree(c->hsum[i]);
+        if (c->hin[i]) (void)hipHostFree(c->hin[i]);
         if (c->hX[i]) (void)hipHostFree(c->hX[i]);
         if (c->hU[i]) (void)hipHostFree(c->hU[i]);
         if (c->evres[i]) (void)hipEventDestroy(c->evres[i]);
@@ -1062,6 +1064,28 @@ extern "C" int tum_ocp_results_wait(tum_ocp *c, const double **summary, const do
     if (U) *U = c->res_iter[r] ? c->hU[r] : nullptr;
     c->res_head ^= 1; c->res_count--;
     return 0;
+}
+
+extern "C" int tum_ocp_step_async(tum_ocp *c, const double *x0, const double *yref, int with_iterate)
+{
+    if (!c) return fail("null capsule");
+    DevGuard guard(c->d.device); GUARD_OK(guard);
+    if (c->res_count == 2) return fail("step_async: two requests outstanding on this capsule (call tum_ocp_results_wait first)");
+    const size_t B = c->batch, nx0 = B * NX, nyr = B * (size_t)(c->N + 1) * 6;
+    // the staging area of the result slot this step will use: its previous step has been waited for, so its uploads are done
+    const int w = (c->res_head + c->res_count) & 1;
+    if ((x0 || yref) && !c->hin[w]) HIPCHK(hipHostMalloc((void **)&c->hin[w], sizeof(double) * (nx0 + nyr), hipHostMallocDefault));
+    if (x0) {
+        if (c->sn) { if (!c->have_offs) return fail("step_async x0: an SNMPC capsule needs its sample offsets (tum_ocp_snmpc_set_offsets)"); c->fanout = true; }
+        memcpy(c->hin[w], x0, sizeof(double) * nx0);
+        HIPCHK(hipMemcpyAsync(c->dx0, c->hin[w], sizeof(double) * nx0, hipMemcpyHostToDevice, c->stream));
+    }
+    if (yref) {
+        memcpy(c->hin[w] + nx0, yref, sizeof(double) * nyr);
+        HIPCHK(hipMemcpyAsync(c->dyref, c->hin[w] + nx0, sizeof(double) * nyr, hipMemcpyHostToDevice, c->stream));
+    }
+    if (launch(c)) return 1;
+    return tum_ocp_results_async(c, with_iterate);
 }
 
 // device-to-device upload of per-instance inputs from caller-owned HBM (asynchronous, on the capsule's stream)

@@ -125,33 +125,44 @@ class Nonlinear_Model_Predictive_Controller:
     def solve(self, current_ref_traj):
         """NMPC_class.py:163-241: set yref on every stage, one SQP-RTI step, read u0 / predictions / stats."""
         s, N = self.acados_solver, self.N
-        # (the reference issues one set() per stage and one get() per stage, 79 ctypes calls per step; the batched
-        # setters / getters of the binding move the same data in three)
         y = np.zeros((N + 1, 6))
         y[:, 0] = np.asarray(current_ref_traj['pos_x'][:N + 1]); y[:, 1] = np.asarray(current_ref_traj['pos_y'][:N + 1])
         y[:, 2] = np.asarray(current_ref_traj['ref_yaw'][:N + 1]); y[:, 3] = np.asarray(current_ref_traj['ref_v'][:N + 1])
-        s.set_yref_all(y)
-        status = s.solve()
-        X, U = s.get_iterate()
-        X, U = np.asarray(X).reshape(-1, N + 1, self.nx)[0], np.asarray(U).reshape(-1, N, 2)[0]     # batch = 1
+        # (the reference issues one set() per stage and one get() per stage -- 79 ctypes calls per step, every one a round trip; here
+        #  the reference, the solve and the read-back of u0 / predictions / cost / status are ONE enqueue and ONE wait:
+        #  tum_ocp_step_async + tum_ocp_results_wait, inputs and results through pinned memory the capsule owns)
+        summ, X, U = s.step(x0=getattr(self, "_x0_pending", None), yref=y, with_iterate=True)
+        self._x0_pending = None
+        status = int(np.max(summ[:, 3]))
+        s.status = status
+        X, U = X[0], U[0]                                   # batch = 1
         u0 = np.array(U[0])
         if status == 0:
             self.pred_X = np.array(X[:N])
-        self.stats[0] = s.get_cost()
+        self.stats[0] = float(summ[0, 2])
         self.stats[1] = s.get_stats('time_tot')
         self.stats[2] = s.get_stats('sqp_iter')
-        self.stats[3] = np.max(s.get_stats('qp_iter'))
+        self.stats[3] = float(np.max(summ[:, 4]))
         self.stats[4] = status
         return u0, self.pred_X, self.stats
 
     def set_initial_state(self, x0):
+        """NMPC_class.py:243-246 (lbx_0 = ubx_0 = x0). The state rides with the next solve(): it goes up in the same enqueue as the
+        reference trajectory (tum_ocp_step_async) instead of two synchronous setter calls of its own; whoever touches the solver
+        in between flushes it (_flush_x0)."""
         self.x0 = x0
-        self.acados_solver.constraints_set(0, "lbx", self.x0)
-        self.acados_solver.constraints_set(0, "ubx", self.x0)
+        self._x0_pending = np.array(x0, dtype=float).reshape(-1)
+
+    def _flush_x0(self):
+        if getattr(self, "_x0_pending", None) is not None:
+            self.acados_solver.constraints_set(0, "lbx", self._x0_pending)
+            self.acados_solver.constraints_set(0, "ubx", self._x0_pending)
+            self._x0_pending = None
 
     def reset(self, x0):
         self.acados_solver.reset()
         self.set_initial_state(x0)
+        self._flush_x0()
         for i in range(self.N + 1):
             self.acados_solver.set(i, 'x', self.x0)
 

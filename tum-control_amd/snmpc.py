@@ -202,17 +202,20 @@ class Stochastic_Nonlinear_Model_Predictive_Controller:
         y = np.zeros((N + 1, 6))
         y[:, 0] = np.asarray(current_ref_traj['pos_x'][:N + 1]); y[:, 1] = np.asarray(current_ref_traj['pos_y'][:N + 1])
         y[:, 2] = np.asarray(current_ref_traj['ref_yaw'][:N + 1]); y[:, 3] = np.asarray(current_ref_traj['ref_v'][:N + 1])
-        s.set_yref_all(y)
-        status = s.solve()
-        X, U = s.get_iterate()          # nominal copy
-        X, U = np.asarray(X).reshape(-1, N + 1, 8)[0], np.asarray(U).reshape(-1, N, 2)[0]
+        # (the reference issues one set() per stage and one get() per stage -- 79 ctypes calls per step, every one a round trip; here
+        #  the reference, the solve and the read-back of u0 / predictions / cost / status are ONE enqueue and ONE wait:
+        #  tum_ocp_step_async + tum_ocp_results_wait, inputs and results through pinned memory the capsule owns)
+        summ, X, U = s.step(yref=y, with_iterate=True)
+        status = int(np.max(summ[:, 3]))
+        s.status = status
+        X, U = X[0], U[0]                                   # batch = 1
         u0 = np.array(U[0])
         if status == 0:
             self.pred_X = np.array(X[:N])
-        self.stats[0] = s.get_cost()
+        self.stats[0] = float(summ[0, 2])
         self.stats[1] = s.get_stats('time_tot')
         self.stats[2] = s.get_stats('sqp_iter')
-        self.stats[3] = np.max(s.get_stats('qp_iter'))
+        self.stats[3] = float(np.max(summ[:, 4]))
         self.stats[4] = status
         return u0, self.pred_X, self.stats
 

@@ -67,7 +67,7 @@ C_SYMBOLS = ["tum_ocp_create", "tum_ocp_free", "tum_ocp_last_error", "tum_ocp_ba
              "tum_ocp_set", "tum_ocp_get", "tum_ocp_constraints_set", "tum_ocp_cost_set",
              "tum_ocp_solve", "tum_ocp_solve_async", "tum_ocp_synchronize",
              "tum_ocp_get_cost", "tum_ocp_get_stats", "tum_ocp_reset", "tum_ocp_get_from_qp_in",
-             "tum_ocp_set_stream", "tum_ocp_get_device", "tum_ocp_put_device", "tum_ocp_results_async", "tum_ocp_results_wait", "tum_ocp_cold_start", "tum_ocp_last_kernel_ms",
+             "tum_ocp_set_stream", "tum_ocp_get_device", "tum_ocp_put_device", "tum_ocp_results_async", "tum_ocp_results_wait", "tum_ocp_step_async", "tum_ocp_cold_start", "tum_ocp_last_kernel_ms",
              "tum_ocp_debug_dump", "tum_ocp_profile_phases", "tum_ocp_set_schedule", "tum_ocp_set_kernel",
              "tum_ocp_set_x0_fanout", "tum_pce_moments", "tum_pce_attach", "tum_pce_moments_device",
              "tum_ocp_bounds_snapshot", "tum_ocp_bounds_restore", "tum_ocp_r2_backoff", "tum_ocp_r2_attach", "tum_ocp_constraints_get",
@@ -114,6 +114,8 @@ def load_library(path=None):
     if hasattr(L, "tum_ocp_results_async"):          # (absent from the libraries of earlier revisions that scripts/dev/ab2.py loads beside this one)
         L.tum_ocp_results_async.argtypes = [vp, ci]
         L.tum_ocp_results_wait.argtypes = [vp, ctypes.POINTER(dp), ctypes.POINTER(dp), ctypes.POINTER(dp)]
+    if hasattr(L, "tum_ocp_step_async"):
+        L.tum_ocp_step_async.argtypes = [vp, vp, vp, ci]
     L.tum_ocp_last_kernel_ms.restype = ctypes.c_double; L.tum_ocp_last_kernel_ms.argtypes = [vp]
     L.tum_ocp_debug_dump.argtypes = [vp, ci, dp, ci]
     L.tum_ocp_profile_phases.argtypes = [vp, ctypes.POINTER(ctypes.c_longlong)]
@@ -366,6 +368,26 @@ class BatchedOcpSolver:
         X = np.ctypeslib.as_array(px, shape=(B, N + 1, 8)) if px else None
         U = np.ctypeslib.as_array(pu, shape=(B, N, 2)) if pu else None
         return summ, X, U
+
+    def step_async(self, x0=None, yref=None, with_iterate=True):
+        """One control step of a host-driven loop in one call (tum_ocp_step_async): x0 (batch, 8) and yref (batch, N+1, 6) -- None:
+        keep -- uploaded through pinned staging on the capsule's stream, one SQP-RTI behind them, the results request behind the
+        solve. Returns at once; results_wait() delivers."""
+        def arr(a, n):
+            if a is None:
+                return None, None
+            a = np.ascontiguousarray(a, dtype=np.float64)
+            if a.size != n:
+                raise Exception(f"BatchedOcpSolver.step: expected {n} values, got {a.size}")
+            return a, ctypes.c_void_p(a.ctypes.data)
+        a0, p0 = arr(x0, self.batch * 8)
+        a1, p1 = arr(yref, self.batch * (self.N + 1) * 6)
+        self._chk(self._L.tum_ocp_step_async(self._h, p0, p1, int(bool(with_iterate))), "step_async")
+
+    def step(self, x0=None, yref=None, with_iterate=True):
+        """step_async + results_wait: (summary (batch, 5): u0[2], cost, status, qp_iter; X; U) as views of the capsule's pinned slabs"""
+        self.step_async(x0, yref, with_iterate)
+        return self.results_wait()
 
     def set_schedule(self, longest_first=True):
         """Dispatch instances longest-first by the previous solve's iteration counts (default) or in natural order."""
