@@ -120,4 +120,28 @@ __global__ void pack_summary_kernel(const double *U, const double *cost, const i
     dst[5 * i + 2] = cost[b]; dst[5 * i + 3] = (double)status[b]; dst[5 * i + 4] = (double)qp_iter[b];
 }
 
+// The same plus the whole iterate into (host-mapped) slabs: for small batches one launch instead of the summary kernel and two
+// copy commands (tum_ocp_results_async with_iterate; 3 KB per instance across PCIe as plain stores).
+__global__ void pack_results_kernel(const double *X, const double *U, const double *cost, const int *status, const int *qp_iter, int N, int nb,
+                                    double *dsum, double *hX, double *hU)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x, nth = gridDim.x * blockDim.x;
+    if (i < nb) {
+        dsum[5 * i + 0] = U[(size_t)i * N * NU]; dsum[5 * i + 1] = U[(size_t)i * N * NU + 1];
+        dsum[5 * i + 2] = cost[i]; dsum[5 * i + 3] = (double)status[i]; dsum[5 * i + 4] = (double)qp_iter[i];
+    }
+    const size_t nX = (size_t)nb * (N + 1) * NX, nU = (size_t)nb * N * NU;
+    for (size_t k = i; k < nX; k += nth) hX[k] = X[k];
+    for (size_t k = i; k < nU; k += nth) hU[k] = U[k];
+}
+
+// x0 | yref of a step from the capsule's (host-mapped) staging area into their device arrays: one launch instead of two copy
+// commands (tum_ocp_step_async, small batches)
+__global__ void stage_in_kernel(const double *hin, double *x0, int nx0, double *yref, int nyr, int have_x0, int have_yref)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x, nth = gridDim.x * blockDim.x;
+    if (have_x0) for (int k = i; k < nx0; k += nth) x0[k] = hin[k];
+    if (have_yref) for (int k = i; k < nyr; k += nth) yref[k] = hin[nx0 + k];
+}
+
 }  // namespace tum

@@ -44,6 +44,7 @@ struct tum_ocp {
     bool solved_pipe;              // the LAST solve ran the pipeline: its linearisation is in the stage records, not in qpin
     double *drec, *dcws, *dvec;    // pipeline workspace: stage records, gg rows in operand layout, q | d | dv
     hipEvent_t evi0, evi1;         // around the interior point kernel of the pipeline
+    bool skip_ipm_events, ipm_timed;   // a step leaves them out (tum_ocp_step_async); was the LAST solve timed with them
     float last_ms;
     bool solved;
     std::vector<double> stage;     // host staging
@@ -171,7 +172,7 @@ extern "C" tum_ocp *tum_ocp_create(const tum_ocp_desc *desc)
       if (k == "fused") c->kmode = 1; else if (k == "pipeline4") c->kmode = 3;
 #endif
       c->pipe = false; c->solved_pipe = false; }
-    c->drec = c->dcws = c->dvec = nullptr; c->evi0 = c->evi1 = nullptr;
+    c->drec = c->dcws = c->dvec = nullptr; c->evi0 = c->evi1 = nullptr; c->skip_ipm_events = c->ipm_timed = false;
     ok &= hipEventCreate(&c->evi0) == hipSuccess && hipEventCreate(&c->evi1) == hipSuccess;
     if (!ok) { fail("device allocation failed"); tum_ocp_free(c); return nullptr; }
 
@@ -759,7 +760,7 @@ static int launch_pipeline(tum_ocp *c, bool events)
             else if (c->sn) hipLaunchKernelGGL((cond_kernel<NTv, true>), dim3(c->batch), dim3(64), 0, c->stream, pa);
             else hipLaunchKernelGGL((cond_kernel<NTv, false>), dim3(c->batch), dim3(64), 0, c->stream, pa);
         }
-        if (events) (void)hipEventRecord(c->evi0, c->stream);
+        if (events && !c->skip_ipm_events) (void)hipEventRecord(c->evi0, c->stream);
         bool expanded = false;
 #ifdef TUM_DEV_KERNELS
         if (prof && c->kmode == 3 && NTv == 5) hipLaunchKernelGGL((ipm4_kernel<true>), dim3(c->batch), dim3(256), I4::BYTES, c->stream, pa);
@@ -776,7 +777,7 @@ static int launch_pipeline(tum_ocp *c, bool events)
             if (c->sn || no_fuse) hipLaunchKernelGGL((ipm_kernel<false, NTv>), dim3(c->batch), dim3(64), ipm_lds, c->stream, pa);
             else { hipLaunchKernelGGL((ipm_kernel<false, NTv, true>), dim3(c->batch), dim3(64), ipm_lds, c->stream, pa); expanded = true; }
         }
-        if (events) (void)hipEventRecord(c->evi1, c->stream);
+        if (events && !c->skip_ipm_events) (void)hipEventRecord(c->evi1, c->stream);
         if (c->sn) {
             // the epilogue steps the sample copies AND the nominal copy of the stages 1..uph (their PCE mean); the expansion
             // kernel behind it takes the nominal recursion from stage uph to the end of the horizon and evaluates the cost
@@ -833,6 +834,7 @@ static int launch(tum_ocp *c, bool events = true)
     }
     c->solved = true;
     c->solved_pipe = c->pipe;
+    c->ipm_timed = events && !c->skip_ipm_events;
     return 0;
 }
 
@@ -897,7 +899,7 @@ extern "C" int tum_ocp_get_stats(tum_ocp *c, const char *field, void *out, int b
     const std::string f(field);
     if (f == "time_tot") { *(double *)out = tum_ocp_last_kernel_ms(c) * 1e-3; return 0; }
     if (f == "time_ipm") {    // pipeline only: device seconds of the interior point kernel of the last solve
-        if (!c->solved || !c->solved_pipe) return fail("get_stats time_ipm: pipeline kernel only, after a solve");
+        if (!c->solved || !c->solved_pipe || !c->ipm_timed) return fail("get_stats time_ipm: pipeline kernel only, after a solve() / solve_async() (a step leaves these events out)");
         DevGuard guard(c->d.device); GUARD_OK(guard);
         float ms = 0;
         if (hipEventSynchronize(c->evi1) != hipSuccess || hipEventElapsedTime(&ms, c->evi0, c->evi1) != hipSuccess) return fail("get_stats time_ipm: no timing");
@@ -1038,11 +1040,20 @@ extern "C" int tum_ocp_results_async(tum_ocp *c, int with_iterate)
     // the summary (40 B per instance) is written by the packing kernel STRAIGHT into the pinned slab (host memory mapped into the
     // device's address space): no copy command, no DMA engine and no signal round trip between the kernels of two batches
     static const bool zero_copy = [] { const char *e = getenv("TUM_RESULTS_ZERO_COPY"); return !(e && e[0] == '0'); }();
+    // small batches with the iterate: ONE kernel writes summary, X and U into the pinned slabs (a copy command costs 4-5 us on the
+    // stream whatever its size; the two of the iterate were a tenth of a host-driven control step of one instance)
+    const bool pack_all = zero_copy && with_iterate && B * (size_t)(N + 1) * NX <= 32768;
+    if (pack_all) {
+        hipLaunchKernelGGL(pack_results_kernel, dim3(8), dim3(256), 0, s, c->dX, c->dU, c->dcost, c->dstatus, c->dqpiter, N, (int)B,
+                           c->hsum[w], c->hX[w], c->hU[w]);
+        HIPCHK(hipGetLastError());
+    } else {
     hipLaunchKernelGGL(pack_summary_kernel, dim3((unsigned)((B + 255) / 256)), dim3(256), 0, s, c->dU, c->dcost, c->dstatus, c->dqpiter, N, 0, (int)B,
                        zero_copy ? c->hsum[w] : c->dsum);
     HIPCHK(hipGetLastError());
+    }
     if (!zero_copy) HIPCHK(hipMemcpyAsync(c->hsum[w], c->dsum, sizeof(double) * B * 5, hipMemcpyDeviceToHost, s));
-    if (with_iterate) {
+    if (with_iterate && !pack_all) {
         HIPCHK(hipMemcpyAsync(c->hX[w], c->dX, sizeof(double) * B * (N + 1) * NX, hipMemcpyDeviceToHost, s));
         HIPCHK(hipMemcpyAsync(c->hU[w], c->dU, sizeof(double) * B * N * NU, hipMemcpyDeviceToHost, s));
     }
@@ -1078,13 +1089,22 @@ extern "C" int tum_ocp_step_async(tum_ocp *c, const double *x0, const double *yr
     if (x0) {
         if (c->sn) { if (!c->have_offs) return fail("step_async x0: an SNMPC capsule needs its sample offsets (tum_ocp_snmpc_set_offsets)"); c->fanout = true; }
         memcpy(c->hin[w], x0, sizeof(double) * nx0);
-        HIPCHK(hipMemcpyAsync(c->dx0, c->hin[w], sizeof(double) * nx0, hipMemcpyHostToDevice, c->stream));
     }
-    if (yref) {
-        memcpy(c->hin[w] + nx0, yref, sizeof(double) * nyr);
-        HIPCHK(hipMemcpyAsync(c->dyref, c->hin[w] + nx0, sizeof(double) * nyr, hipMemcpyHostToDevice, c->stream));
+    if (yref) memcpy(c->hin[w] + nx0, yref, sizeof(double) * nyr);
+    if ((x0 || yref) && nx0 + nyr <= 32768) {      // small batches: one kernel reads the staging area (host memory mapped into the device's address space)
+        hipLaunchKernelGGL(stage_in_kernel, dim3(4), dim3(256), 0, c->stream, c->hin[w], c->dx0, (int)nx0, c->dyref, (int)nyr, x0 ? 1 : 0, yref ? 1 : 0);
+        HIPCHK(hipGetLastError());
+    } else {
+        if (x0) HIPCHK(hipMemcpyAsync(c->dx0, c->hin[w], sizeof(double) * nx0, hipMemcpyHostToDevice, c->stream));
+        if (yref) HIPCHK(hipMemcpyAsync(c->dyref, c->hin[w] + nx0, sizeof(double) * nyr, hipMemcpyHostToDevice, c->stream));
     }
-    if (launch(c)) return 1;
+    // (the two events around the interior point kernel -- get_stats "time_ipm" -- are left out of a step: every event on the stream
+    //  is a gap of a few microseconds between two kernels; "time_tot" keeps its events)
+    c->skip_ipm_events = true;
+    const int rc = launch(c);
+    c->skip_ipm_events = false;
+    if (rc) return 1;
+    c->ipm_timed = false;
     return tum_ocp_results_async(c, with_iterate);
 }
 
