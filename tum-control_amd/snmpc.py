@@ -194,6 +194,7 @@ class Stochastic_Nonlinear_Model_Predictive_Controller:
         for i in range(self.N + 1):
             s.set(i, "p", np.concatenate((self.A.flatten(), self.risk_parameter, self.stop_flags[i].reshape(1))))
         s.cold_start()                  # SNMPC_class.py:126-127: x_j = x0_samples for all j
+        s.set_x0_offsets(x0_offsets(self.w_samples, self.stds))       # for the 8-value x0 of a step (set_initial_state)
         return s
 
     def solve(self, current_ref_traj):
@@ -205,7 +206,8 @@ class Stochastic_Nonlinear_Model_Predictive_Controller:
         # (the reference issues one set() per stage and one get() per stage -- 79 ctypes calls per step, every one a round trip; here
         #  the reference, the solve and the read-back of u0 / predictions / cost / status are ONE enqueue and ONE wait:
         #  tum_ocp_step_async + tum_ocp_results_wait, inputs and results through pinned memory the capsule owns)
-        summ, X, U = s.step(yref=y, with_iterate=True)
+        summ, X, U = s.step(x0=getattr(self, "_x0_pending", None), yref=y, with_iterate=True)
+        self._x0_pending = None
         status = int(np.max(summ[:, 3]))
         s.status = status
         X, U = X[0], U[0]                                   # batch = 1
@@ -220,12 +222,22 @@ class Stochastic_Nonlinear_Model_Predictive_Controller:
         return u0, self.pred_X, self.stats
 
     def set_initial_state(self, x0):
+        """SNMPC_class.py:259-264 (lbx_0 = ubx_0 = compute_x0dist(x0)). The estimated state rides with the next solve()
+        (tum_ocp_step_async) and is fanned out to the sample initial conditions on the device -- x0 + stds (.) w_s, the same
+        sum compute_x0dist forms (tum_ocp_snmpc_set_offsets, set once in _build_solver); whoever touches the solver in between
+        flushes it (_flush_x0)."""
         self.x0 = x0
-        x0_samples = compute_x0dist(x0, self.w_samples, self.stds)
-        self.acados_solver.constraints_set(0, "lbx", x0_samples.flatten())
-        self.acados_solver.constraints_set(0, "ubx", x0_samples.flatten())
+        self._x0_pending = np.array(x0, dtype=float).reshape(-1)
+
+    def _flush_x0(self):
+        if getattr(self, "_x0_pending", None) is not None:
+            x0_samples = compute_x0dist(self._x0_pending, self.w_samples, self.stds)
+            self.acados_solver.constraints_set(0, "lbx", x0_samples.flatten())
+            self.acados_solver.constraints_set(0, "ubx", x0_samples.flatten())
+            self._x0_pending = None
 
     def reset(self, x0):
+        self._x0_pending = None
         self.acados_solver.reset()
         x0_samples = compute_x0dist(x0, self.w_samples, self.stds)
         self.acados_solver.constraints_set(0, "lbx", x0_samples.flatten())
