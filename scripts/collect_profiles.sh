@@ -35,6 +35,8 @@ $T python scripts/closed_loop_variants.py 2>&1 < /dev/null | grep -v amdgpu.ids 
 # the latency path: wide linearisation / condensing kernels against the ones they replace for small batches; per-kernel times of the 26-vehicle loop
 $T python scripts/small_batch_variants.py 2>&1 < /dev/null | grep -v amdgpu.ids > $OUT/small_batch_variants.txt
 $T rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/loop26 -o s -- python scripts/loop_prof.py 26 > /dev/null 2>&1 < /dev/null
+# the reference's own call pattern: one vehicle, set_initial_state + solve of the mirrored controller class every control step (host wall time)
+$T python scripts/probes/controller_step_time.py 2>&1 < /dev/null | grep -v amdgpu.ids > $OUT/controller_step.txt
 # round 4: the library of commit f5e2d65 (packed-triangular factor; scripts/dev/build_exp_lib.sh f5e2d65) against the shipped one (tiled factor)
 [ -f exp_libs/lib_f5e2d65.so ] && $T python scripts/dev/ab2.py exp_libs/lib_f5e2d65.so shipped 2>&1 < /dev/null | grep -v amdgpu.ids > $OUT/ab_tiled_factor_vs_shipped.txt
 for f in 0 1; do echo "TUM_FUSED_EXPAND=$f" >> $OUT/fused_expand.txt; TUM_FUSED_EXPAND=$f $T python scripts/probes/solve_wall_time.py 2>&1 < /dev/null | grep pipeline >> $OUT/fused_expand.txt; TUM_FUSED_EXPAND=$f $T python bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-schedule-legs --no-host-legs 2>/dev/null < /dev/null | grep metric | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('  config 2, three streams: value %.3f M solves/s'%(d['value']/1e6))" >> $OUT/fused_expand.txt; done
