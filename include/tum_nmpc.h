@@ -142,7 +142,9 @@ int tum_ocp_results_wait(tum_ocp *c, const double **summary, const double **X, c
  * yref (batch x (N+1) x 6) -- either may be null: the capsule keeps what it has -- are copied into PINNED staging memory the capsule
  * owns and uploaded on its stream, one SQP-RTI is enqueued behind them and a results request (tum_ocp_results_async) behind
  * the solve. Returns after enqueuing; tum_ocp_results_wait delivers summary / X / U. The caller's x0 / yref buffers are free on
- * return. Two steps may be outstanding, like two result requests. One instance, N = 38, warm: 0.34 -> 0.18 ms per control step
+ * return. Two steps may be outstanding, like two result requests. Small batches: one kernel reads the staging area, one writes
+ * summary and iterate into the pinned slabs, and the step's device time (get_stats "time_tot") is read from the device's wall clock
+ * by these two kernels -- no copy command and no event on the stream; get_stats "time_ipm" is not available after a step. One instance, N = 38, warm: 0.34 -> 0.15 ms per control step
  * of the mirrored controller class. */
 int tum_ocp_step_async(tum_ocp *c, const double *x0, const double *yref, int with_iterate);
 /* The other direction: per-instance inputs from caller-owned DEVICE memory (asynchronous D2D on the capsule's stream).

@@ -390,6 +390,11 @@ def test_one_call_control_step_equals_setters_solve_getters():
         assert np.array_equal(Xa, Xb) and np.array_equal(Ua, Ub)
         assert np.array_equal(summ[:, :2], Ua[:, 0]) and np.array_equal(summ[:, 2], a.get_cost())
         assert np.array_equal(summ[:, 3], a.get_stats("status")) and np.array_equal(summ[:, 4], a.get_stats("qp_iter"))
+    # the device time of a step (read from the device's wall clock by its first and last kernel) against the events of solve()
+    t_step, t_solve = b.get_stats("time_tot"), a.get_stats("time_tot")
+    assert 2e-5 < t_step < 5e-3 and 2e-5 < t_solve < 5e-3 and 0.3 < t_step / t_solve < 3.0
+    with pytest.raises(Exception, match="time_ipm"):
+        b.get_stats("time_ipm")                     # (a step leaves the events around the interior point kernel out)
     # null inputs: another real-time iteration on the same data
     assert a.solve() == 0
     summ, Xb, Ub = b.step(with_iterate=True)

@@ -122,10 +122,13 @@ __global__ void pack_summary_kernel(const double *U, const double *cost, const i
 
 // The same plus the whole iterate into (host-mapped) slabs: for small batches one launch instead of the summary kernel and two
 // copy commands (tum_ocp_results_async with_iterate; 3 KB per instance across PCIe as plain stores).
+// ts (nullable): [1] takes the device's wall clock (constant-rate counter) when this kernel starts -- the end of the step's device
+// time, whose start stage_in_kernel leaves in [0]: a step is timed without events on the stream (each one a 5 us gap)
 __global__ void pack_results_kernel(const double *X, const double *U, const double *cost, const int *status, const int *qp_iter, int N, int nb,
-                                    double *dsum, double *hX, double *hU)
+                                    double *dsum, double *hX, double *hU, unsigned long long *ts)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x, nth = gridDim.x * blockDim.x;
+    if (ts && i == 0) ts[1] = wall_clock64();
     if (i < nb) {
         dsum[5 * i + 0] = U[(size_t)i * N * NU]; dsum[5 * i + 1] = U[(size_t)i * N * NU + 1];
         dsum[5 * i + 2] = cost[i]; dsum[5 * i + 3] = (double)status[i]; dsum[5 * i + 4] = (double)qp_iter[i];
@@ -137,9 +140,10 @@ __global__ void pack_results_kernel(const double *X, const double *U, const doub
 
 // x0 | yref of a step from the capsule's (host-mapped) staging area into their device arrays: one launch instead of two copy
 // commands (tum_ocp_step_async, small batches)
-__global__ void stage_in_kernel(const double *hin, double *x0, int nx0, double *yref, int nyr, int have_x0, int have_yref)
+__global__ void stage_in_kernel(const double *hin, double *x0, int nx0, double *yref, int nyr, int have_x0, int have_yref, unsigned long long *ts)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x, nth = gridDim.x * blockDim.x;
+    if (ts && i == 0) ts[0] = wall_clock64();
     if (have_x0) for (int k = i; k < nx0; k += nth) x0[k] = hin[k];
     if (have_yref) for (int k = i; k < nyr; k += nth) yref[k] = hin[nx0 + k];
 }

@@ -68,6 +68,8 @@ struct tum_ocp {
     // two sets, used in turn: the request for the NEXT batch can be enqueued before the previous batch's results have been read
     double *dsum, *hsum[2], *hX[2], *hU[2]; hipEvent_t evres[2]; bool res_iter[2]; int res_head, res_count;
     double *hin[2];                    // pinned staging of x0 | yref of a step (tum_ocp_step_async), one per result slot
+    unsigned long long *hts[2];        // device wall clock at the start / end of a step timed without events (pinned, one pair per result slot)
+    int ts_slot; double ts_khz;        // slot whose clock pair times the LAST solve (-1: the events ev0 / ev1 do)
 };
 
 static const int DBG_STRIDE = 20480;
@@ -130,7 +132,7 @@ extern "C" tum_ocp *tum_ocp_create(const tum_ocp_desc *desc)
     c->r2 = false; c->dr2S = c->dr2B = nullptr;
     c->p_dirty = false; c->uph_cap = 0; c->gamma = 0.0; c->dpceA = nullptr; c->pce_L = c->pce_S = 0; c->dbnd_snap = nullptr;
     c->dsum = nullptr; c->res_head = c->res_count = 0;
-    for (int i = 0; i < 2; i++) { c->hsum[i] = c->hX[i] = c->hU[i] = c->hin[i] = nullptr; c->evres[i] = nullptr; c->res_iter[i] = false; }
+    for (int i = 0; i < 2; i++) { c->hsum[i] = c->hX[i] = c->hU[i] = c->hin[i] = nullptr; c->hts[i] = nullptr; c->evres[i] = nullptr; c->res_iter[i] = false; }
     const int N = c->N; const size_t B = c->batch;
     bool ok = true;
     ok &= hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) == hipSuccess; c->own_stream = true;
@@ -172,7 +174,7 @@ extern "C" tum_ocp *tum_ocp_create(const tum_ocp_desc *desc)
       if (k == "fused") c->kmode = 1; else if (k == "pipeline4") c->kmode = 3;
 #endif
       c->pipe = false; c->solved_pipe = false; }
-    c->drec = c->dcws = c->dvec = nullptr; c->evi0 = c->evi1 = nullptr; c->skip_ipm_events = c->ipm_timed = false;
+    c->drec = c->dcws = c->dvec = nullptr; c->evi0 = c->evi1 = nullptr; c->skip_ipm_events = c->ipm_timed = false; c->ts_slot = -1; c->ts_khz = 0.0;
     ok &= hipEventCreate(&c->evi0) == hipSuccess && hipEventCreate(&c->evi1) == hipSuccess;
     if (!ok) { fail("device allocation failed"); tum_ocp_free(c); return nullptr; }
 
@@ -239,6 +241,7 @@ extern "C" void tum_ocp_free(tum_ocp *c)
     for (int i = 0; i < 2; i++) {
         if (c->hsum[i]) (void)hipHostFree(c->hsum[i]);
         if (c->hin[i]) (void)hipHostFree(c->hin[i]);
+        if (c->hts[i]) (void)hipHostFree(c->hts[i]);
         if (c->hX[i]) (void)hipHostFree(c->hX[i]);
         if (c->hU[i]) (void)hipHostFree(c->hU[i]);
         if (c->evres[i]) (void)hipEventDestroy(c->evres[i]);
@@ -835,6 +838,7 @@ static int launch(tum_ocp *c, bool events = true)
     c->solved = true;
     c->solved_pipe = c->pipe;
     c->ipm_timed = events && !c->skip_ipm_events;
+    c->ts_slot = -1;          // (tum_ocp_step_async sets it behind this call)
     return 0;
 }
 
@@ -877,6 +881,13 @@ extern "C" double tum_ocp_last_kernel_ms(tum_ocp *c)
 {
     if (!c || !c->solved) return 0.0;
     DevGuard guard(c->d.device); if (!guard.ok) return 0.0;
+    if (c->ts_slot >= 0) {      // a step timed by the device's wall clock (tum_ocp_step_async): valid once its results have been waited for
+        const int w = c->ts_slot;
+        if (c->evres[w] && hipEventSynchronize(c->evres[w]) != hipSuccess) return 0.0;
+        const unsigned long long t0 = c->hts[w][0], t1 = c->hts[w][1];
+        c->last_ms = (float)((double)(t1 - t0) / c->ts_khz);
+        return c->last_ms;
+    }
     if (hipEventSynchronize(c->ev1) != hipSuccess) return 0.0;
     float ms = 0;
     if (hipEventElapsedTime(&ms, c->ev0, c->ev1) != hipSuccess) return 0.0;
@@ -1045,7 +1056,7 @@ extern "C" int tum_ocp_results_async(tum_ocp *c, int with_iterate)
     const bool pack_all = zero_copy && with_iterate && B * (size_t)(N + 1) * NX <= 32768;
     if (pack_all) {
         hipLaunchKernelGGL(pack_results_kernel, dim3(8), dim3(256), 0, s, c->dX, c->dU, c->dcost, c->dstatus, c->dqpiter, N, (int)B,
-                           c->hsum[w], c->hX[w], c->hU[w]);
+                           c->hsum[w], c->hX[w], c->hU[w], (c->ts_slot == w) ? c->hts[w] : (unsigned long long *)nullptr);
         HIPCHK(hipGetLastError());
     } else {
     hipLaunchKernelGGL(pack_summary_kernel, dim3((unsigned)((B + 255) / 256)), dim3(256), 0, s, c->dU, c->dcost, c->dstatus, c->dqpiter, N, 0, (int)B,
@@ -1091,8 +1102,17 @@ extern "C" int tum_ocp_step_async(tum_ocp *c, const double *x0, const double *yr
         memcpy(c->hin[w], x0, sizeof(double) * nx0);
     }
     if (yref) memcpy(c->hin[w] + nx0, yref, sizeof(double) * nyr);
-    if ((x0 || yref) && nx0 + nyr <= 32768) {      // small batches: one kernel reads the staging area (host memory mapped into the device's address space)
-        hipLaunchKernelGGL(stage_in_kernel, dim3(4), dim3(256), 0, c->stream, c->hin[w], c->dx0, (int)nx0, c->dyref, (int)nyr, x0 ? 1 : 0, yref ? 1 : 0);
+    // small batches with inputs and the iterate: the step is timed by the device's wall clock, read by its first and its last kernel
+    // (stage_in_kernel, pack_results_kernel), instead of by events around the solve -- every event on the stream is a gap of 5 us
+    const bool small_in = (x0 || yref) && nx0 + nyr <= 32768;
+    const bool clocked = small_in && with_iterate && B * (size_t)(c->N + 1) * NX <= 32768;
+    if (clocked) {
+        if (!c->hts[w]) HIPCHK(hipHostMalloc((void **)&c->hts[w], 2 * sizeof(unsigned long long), hipHostMallocDefault));
+        if (c->ts_khz == 0.0) { int khz = 0; HIPCHK(hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, c->d.device)); c->ts_khz = khz > 0 ? (double)khz : 1e5; }
+    }
+    if (small_in) {      // one kernel reads the staging area (host memory mapped into the device's address space)
+        hipLaunchKernelGGL(stage_in_kernel, dim3(4), dim3(256), 0, c->stream, c->hin[w], c->dx0, (int)nx0, c->dyref, (int)nyr, x0 ? 1 : 0, yref ? 1 : 0,
+                           clocked ? c->hts[w] : (unsigned long long *)nullptr);
         HIPCHK(hipGetLastError());
     } else {
         if (x0) HIPCHK(hipMemcpyAsync(c->dx0, c->hin[w], sizeof(double) * nx0, hipMemcpyHostToDevice, c->stream));
@@ -1101,11 +1121,14 @@ extern "C" int tum_ocp_step_async(tum_ocp *c, const double *x0, const double *yr
     // (the two events around the interior point kernel -- get_stats "time_ipm" -- are left out of a step: every event on the stream
     //  is a gap of a few microseconds between two kernels; "time_tot" keeps its events)
     c->skip_ipm_events = true;
-    const int rc = launch(c);
+    const int rc = launch(c, !clocked);
     c->skip_ipm_events = false;
     if (rc) return 1;
     c->ipm_timed = false;
-    return tum_ocp_results_async(c, with_iterate);
+    c->ts_slot = clocked ? w : -1;
+    const int rr = tum_ocp_results_async(c, with_iterate);
+    if (rr) c->ts_slot = -1;
+    return rr;
 }
 
 // device-to-device upload of per-instance inputs from caller-owned HBM (asynchronous, on the capsule's stream)
