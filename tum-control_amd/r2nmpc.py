@@ -60,15 +60,17 @@ class Reduced_Robustified_Nonlinear_Model_Predictive_Controller:
         self.acc_max = 1.0
         self.stats, self.pred_X = n.stats, n.pred_X
         self.WMPC = False
+        self._attach()
+
+    def _attach(self):
+        """The tightening for the next solve (:276-378) is part of every solve of this capsule -- one more kernel behind the
+        interior point method on the capsule's stream (tum_ocp_r2_attach), skipped for an instance whose solve failed
+        (`if status == 0:` at :276) -- instead of a call and a round trip of its own after solve()."""
+        self.acados_solver.r2_attach(self.Sigma0, self.BWB, self.uncertainty_propagation_horizon,
+                                     self.delta_f_min, self.delta_f_max, self.acc_max)
 
     def solve(self, current_ref_traj):
-        import time
-        u0, pred_X, stats = self._nom.solve(current_ref_traj)
-        if stats[4] == 0:
-            t0 = time.time()
-            self.acados_solver.r2_backoff(self.Sigma0, self.BWB, self.uncertainty_propagation_horizon,
-                                          self.delta_f_min, self.delta_f_max, self.acc_max)
-            stats[1] += time.time() - t0          # :379-381: time_tot includes the tightening
+        u0, pred_X, stats = self._nom.solve(current_ref_traj)          # (:379-381: time_tot includes the tightening -- it does: same stream)
         self.pred_X, self.stats = pred_X, stats
         return u0, pred_X, stats
 
@@ -82,6 +84,7 @@ class Reduced_Robustified_Nonlinear_Model_Predictive_Controller:
     def reintialize_solver(self, X0_MPC, solver_generate_C_code=False, solver_build=False):
         self._nom.reintialize_solver(X0_MPC)
         self.acados_solver = self._nom.acados_solver
+        self._attach()
 
     def update_cost_function_weights(self, params):
         self._nom.update_cost_function_weights(params)
