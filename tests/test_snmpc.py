@@ -917,3 +917,39 @@ def test_gpu_snmpc_condensing_six_wavefronts_is_the_same_arithmetic(golden_dir, 
     tol = 1e-8 if uph <= 5 else (1e-6 if uph <= 31 else 1e-5)
     for i in (0, 1, 4):
         assert np.abs(out["large-batch kernels"][i] - out["cond-one-wavefront"][i]).max() < tol
+
+
+@pytest.mark.gpu
+def test_gpu_snmpc_one_call_step_fans_the_state_out_on_the_device(golden_dir):
+    """tum_ocp_step_async on a coupled SNMPC capsule: the 8 values of the estimated state go up with the step and the sample
+    initial conditions are x0 + stds (.) w_s formed by the fan-out kernel -- the same numbers compute_x0dist forms on the host
+    and the 88-value constraints_set path uploads; three warm control steps end bit-identical."""
+    from tum_control_amd.solver import CoupledSnmpcSolver
+    snm, stds, w, A = _pce()
+    d = np.load(os.path.join(golden_dir, "kat0.npz"))
+    N, uph, poses = 38, 5, (0, 26, 30)
+    B = len(poses)
+    offs = snm.x0_offsets(w, stds)
+    Y = np.zeros((B, N + 1, 6)); x0 = np.stack([d["x0"][i] for i in poses])
+    for j, i in enumerate(poses):
+        Y[j, :, :4] = d["yref"][i][:N + 1]
+    sols = []
+    for _ in range(2):
+        s = CoupledSnmpcSolver(N=N, dt=0.08, batch=B, Apce=A, uph=uph, gamma=0.8, x0_offsets=offs)
+        s.install_reference_ocp()
+        X0 = np.stack([snm.compute_x0dist(x0[j], w, stds) for j in range(B)])
+        s.constraints_set(0, "lbx", X0.reshape(B, -1)); s.constraints_set(0, "ubx", X0.reshape(B, -1))
+        s.set_yref_all(Y); s.cold_start()
+        sols.append(s)
+    a, b = sols
+    rng = np.random.default_rng(3)
+    for k in range(3):
+        xk = x0 + k * 0.01 * rng.normal(size=x0.shape) * np.array([1, 1, .1, 1, .1, .02, .01, .1])
+        Xk = np.stack([snm.compute_x0dist(xk[j], w, stds) for j in range(B)])
+        a.constraints_set(0, "lbx", Xk.reshape(B, -1)); a.constraints_set(0, "ubx", Xk.reshape(B, -1))
+        assert a.solve() == 0
+        Xa, Ua = a.get_iterate()
+        summ, Xb, Ub = b.step(x0=xk, yref=Y, with_iterate=True)
+        assert (summ[:, 3] == 0).all()
+        assert np.array_equal(Xa, Xb) and np.array_equal(Ua, Ub)
+        assert np.array_equal(np.atleast_2d(a.get(1, "x")), np.atleast_2d(b.get(1, "x")))
