@@ -143,6 +143,9 @@ def test_reintialize_solver_keeps_the_controller_configuration(monkeypatch):
         def cold_start(self):
             self.calls.append(("cold_start",))
 
+        def set_x0_offsets(self, o):
+            self.calls.append(("set_x0_offsets", np.array(o)))
+
     monkeypatch.setattr(snmpc, "CoupledSnmpcSolver", FakeSolver)
     cfg = snmpc._config.default_config()
     cfg["mpc"].update(q_lon=7.5, r_jerk=11.0, L1_pen=55.0, n_samples=12, uncertainty_propagation_horizon=9, gamma=0.9,
@@ -169,6 +172,19 @@ def test_reintialize_solver_keeps_the_controller_configuration(monkeypatch):
     ps = [cl for cl in b.calls if cl[0] == "set" and cl[2] == "p"]
     assert len(ps) == 21 and [int(q[3][-1]) for q in ps] == [0] * 9 + [1] * 12
     assert ("cold_start",) in b.calls
+    # the sample offsets for the 8-value state of a control step (set_initial_state rides with the step): stds (.) w_s
+    offs = [cl for cl in b.calls if cl[0] == "set_x0_offsets"]
+    assert len(offs) == 1 and offs[0][1].shape == (12, 8)
+    np.testing.assert_allclose(offs[0][1][:, 3], 0.5 * c.w_samples[0], atol=1e-14)
+    assert (offs[0][1][:, [0, 1, 2, 6, 7]] == 0).all()
+    # set_initial_state no longer talks to the solver: the state is pending until the next solve() (or a flush)
+    n_calls = len(b.calls)
+    c.set_initial_state(x1 + 0.25)
+    assert len(b.calls) == n_calls and np.array_equal(c._x0_pending, x1 + 0.25)
+    c._flush_x0()
+    lbx2 = [cl for cl in b.calls[n_calls:] if cl[0] == "constraints_set" and cl[2] == "lbx"]
+    np.testing.assert_allclose(lbx2[0][3].reshape(13, 8)[0], x1 + 0.25)
+    assert c._x0_pending is None
 
 
 def test_problem_data_matches_exported_ocp(golden_dir):
