@@ -177,7 +177,12 @@ int tum_ocp_set_schedule(tum_ocp *c, int longest_first);
  *   "cond-six-wavefronts" / "cond-one-wavefront"  condensing with a workgroup of six (N > 40: seven) wavefronts per OCP -- column
  *       recursion with four lanes per column, Hessian tiles dealt to four wavefronts, gradient on two -- or one wavefront;
  *       default: the workgroup while batch <= 256 (one per CU). Bit-identical results. The nominal OCP only.
- * "auto" hands both choices back to the library. Environment overrides (read once): TUM_LIN_COLS, TUM_COND_WIDE = 0 | 1. */
+ *   "loop-fork" / "loop-serial"   device closed loops (tum_sim_run) of the nominal OCP on the latency path: the linearisation of a
+ *       control step's solve runs BESIDE the planner of that step, on a side stream of the simulation (the Runge-Kutta pass needs
+ *       the iterate, not the reference; the four residuals of the cost are formed by the condensing kernel) -- or behind it as in
+ *       a plain solve. Default: serial (the fork is bit-identical and measured slower: the cross-stream dependencies cost more
+ *       than the overlap gains). Environment: TUM_SIM_FORK = 0 | 1.
+ * "auto" hands all these choices back to the library. Environment overrides (read once): TUM_LIN_COLS, TUM_COND_WIDE = 0 | 1. */
 int tum_ocp_set_kernel(tum_ocp *c, const char *name);
 /* last kernel launch time in milliseconds (HIP events on the launch stream) */
 double tum_ocp_last_kernel_ms(tum_ocp *c);

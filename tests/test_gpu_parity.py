@@ -909,3 +909,26 @@ def test_condensing_six_wavefronts_per_ocp_is_the_same_arithmetic(N, B):
     for _ in range(3):
         o.solve()
     assert np.abs(out["cond-six-wavefronts"][1][B - 1] - o.U).max() < 1e-7
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("controller,B,steps", [("nominal", 26, 120), ("nominal", 3, 7), ("r2", 5, 60)])
+def test_device_loop_linearisation_beside_the_planner_is_the_same_loop(controller, B, steps):
+    """tum_sim_run with the linearisation of every solve forked beside the planner (side stream, residuals of the cost formed by
+    the condensing kernel from the reference the planner has just written) against the serial order: every logged quantity of
+    the closed loop bit-identical -- through the captured hipGraph chunks (>= 50 steps) and through plain launches."""
+    from tum_control_amd.closed_loop import ClosedLoopBatch
+    logs = {}
+    for mode in ("loop-serial", "loop-fork"):
+        cl = ClosedLoopBatch("monteblanco", batch=B, N=38, Tp=3.04, controller=controller, on_device=True, log_capacity=steps)
+        cl.dev.solver.set_kernel(mode)
+        logs[mode] = cl.run(steps)
+        if steps >= 50:
+            assert cl.dev.graph_steps > 0
+    a, b = logs["loop-serial"], logs["loop-fork"]
+    for k in ("CiLX", "MPC_SimX", "simU", "simREF", "simSolverDebug"):
+        x, y = np.asarray(a[k]), np.asarray(b[k])
+        if k == "simSolverDebug":
+            x, y = x[..., [0, 3, 4]], y[..., [0, 3, 4]]        # cost, qp_iter, status (not the solver time)
+        assert np.array_equal(x, y), k
+    assert (np.asarray(b["simSolverDebug"])[..., 4] == 0).all()

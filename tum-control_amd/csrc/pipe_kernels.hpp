@@ -212,12 +212,15 @@ __global__ void __launch_bounds__(64, 1) lin_cols_kernel(const PArgs pa)
     double xk[8];
 #pragma unroll
     for (int i = 0; i < 8; i++) xk[i] = gX[i];
+    // flags & 8 (the device closed loop, nominal OCP): this launch runs BESIDE the planner that writes yref for this solve -- the
+    // residuals of the cost are left to cond_wide_kernel, which forms them while it loads the records, and yref is not touched
+    const bool late_res = !SN && (ka.flags & 8);
     const double *yr = ka.yref + ((size_t)b * NB + k) * 6;
     double *rw = sT + li * L_PITCH;
     // the fields outside the sensitivity block are computed by every lane of the group (same loads, same operations) and
     // stored by lane 0
-    const double res0 = xk[0] - yr[0], res1 = xk[1] - yr[1], res2 = wrap_yaw(xk[2]) - yr[2];
-    double res3 = xk[3] - yr[3], cv0 = 0.0, cv1 = 0.0;
+    double res0 = 0.0, res1 = 0.0, res2 = 0.0, res3 = 0.0, cv0 = 0.0, cv1 = 0.0;
+    if (!late_res) { res0 = xk[0] - yr[0]; res1 = xk[1] - yr[1]; res2 = wrap_yaw(xk[2]) - yr[2]; res3 = xk[3] - yr[3]; }
     if (SN) {           // the speed row |v| of the coupled SNMPC OCP and its gradient (lin_kernel<true>)
         const double vabs = sqrt(xk[3] * xk[3] + xk[4] * xk[4]), iv = (vabs > 0.0) ? 1.0 / vabs : 0.0;
         res3 = vabs - yr[3];
@@ -548,7 +551,19 @@ __global__ void __launch_bounds__(64 * cw_waves<NT_>()) cond_wide_kernel(const P
     const int uph = SN ? ka.uph : 0;
     const int PP = SN ? sn_pro_pitch(uph) : 64, PSTAGE = 9 * PP;
     const double *gpro = SN ? ka.pro + (size_t)b * uph * PSTAGE : nullptr;
-    for (int i = tid; i < (N + 1) * PREC; i += 64 * CW_WAVES) sRec[i] = grec[i];
+    // (flags & 8: the linearisation ran beside the planner and left the residuals of the cost to this kernel -- the same
+    //  differences lin_cols_kernel forms, from the iterate and the reference of THIS solve)
+    const bool late_res = !SN && (ka.flags & 8);
+    for (int i = tid; i < (N + 1) * PREC; i += 64 * CW_WAVES) {
+        double v = grec[i];
+        const int f = i & (PREC - 1), r = f - PR_RES;
+        if (late_res && r >= 0 && r < 4) {
+            const int st = i / PREC;
+            const double xv = gX[(size_t)st * NX + r], yv = gyref[(size_t)st * 6 + r];
+            v = ((r == 2) ? wrap_yaw(xv) : xv) - yv;
+        }
+        sRec[i] = v;
+    }
     for (int i = tid; i < (N + 1) * 6; i += 64 * CW_WAVES) sWt[i] = gW[i];
     for (int i = tid; i < NVP; i += 64 * CW_WAVES) sU0[i] = (i < nv) ? gU[i] : 0.0;
     __syncthreads();

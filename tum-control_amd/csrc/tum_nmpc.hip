@@ -54,6 +54,7 @@ struct tum_ocp {
     double *dXS, *dxs0, *dApce, *dws2, *dpro, *ddv, *doffs;
     int *dxs_dirty; bool xs_lazy;          // sample copies of the stages > uph not yet frozen (snmpc_freeze_kernel)
     bool have_offs, fanout;        // sample initial conditions derived from the nominal x0 at every solve
+    int sim_fork; bool lin_ahead;      // device closed loop: linearisation beside the planner (-1 the library's choice, 0 never, 1 where possible); state of one step
     int cond_wide;                     // condensing with six wavefronts per OCP: -1 the library's choice (at most one workgroup per CU), 0 never, 1 always
     int lin_cols;                      // linearisation with eight lanes per (instance, stage): -1 the library's choice (small batches), 0 never, 1 always (tum_ocp_set_kernel)
     int sn_prologue;                   // prologue of the SNMPC OCP: -1 the library's choice, 2 the matrix-core kernel, 0 column slots and passes (tum_ocp_set_kernel)
@@ -128,7 +129,7 @@ extern "C" tum_ocp *tum_ocp_create(const tum_ocp_desc *desc)
     tum_ocp *c = new tum_ocp();
     c->d = *desc; c->N = desc->N; c->batch = desc->batch; c->last_ms = 0; c->solved = false; c->epoch = 0;
     c->sn = false; c->dXS = c->dxs0 = c->dApce = c->dws2 = c->dpro = c->ddv = c->doffs = nullptr; c->dxs_dirty = nullptr; c->xs_lazy = false;
-    c->have_offs = c->fanout = false; c->sn_prologue = -1; c->lin_cols = -1; c->cond_wide = -1;
+    c->have_offs = c->fanout = false; c->sn_prologue = -1; c->lin_cols = -1; c->cond_wide = -1; c->sim_fork = -1; c->lin_ahead = false;
     c->r2 = false; c->dr2S = c->dr2B = nullptr;
     c->p_dirty = false; c->uph_cap = 0; c->gamma = 0.0; c->dpceA = nullptr; c->pce_L = c->pce_S = 0; c->dbnd_snap = nullptr;
     c->dsum = nullptr; c->res_head = c->res_count = 0;
@@ -654,10 +655,12 @@ extern "C" int tum_ocp_set_kernel(tum_ocp *c, const char *name)
 {
     if (!c || !name) return fail("null argument");
     const std::string n(name);
-    if (n == "auto") { c->kmode = 0; c->lin_cols = -1; c->cond_wide = -1; }        // (the wide kernels of the latency path: the library decides by batch size again)
+    if (n == "auto") { c->kmode = 0; c->lin_cols = -1; c->cond_wide = -1; c->sim_fork = -1; }        // (the wide kernels of the latency path: the library decides by batch size again)
     else if (n == "pipeline") c->kmode = 2;
     // the prologue of the coupled SNMPC OCP: the matrix-core kernel (default where n_samples <= 10) or the column-slot / pass variants
     // the linearisation: one lane per (instance, stage) or eight (default: eight while the batch is one round of wavefronts)
+    else if (n == "loop-serial") c->sim_fork = 0;
+    else if (n == "loop-fork") c->sim_fork = 1;
     else if (n == "cond-one-wavefront") c->cond_wide = 0;
     else if (n == "cond-six-wavefronts") c->cond_wide = 1;
     else if (n == "lin-lane-per-stage") c->lin_cols = 0;
@@ -677,7 +680,7 @@ extern "C" int tum_ocp_set_kernel(tum_ocp *c, const char *name)
     else if (n == "fused" || n == "pipeline4")
         return fail("set_kernel: kernel '" + n + "' exists in the development build only (libtumnmpc_dev.so); this library is the pipeline");
 #endif
-    else return fail("set_kernel: unknown kernel '" + n + "' (auto | pipeline | lin-lane-per-stage | lin-eight-lanes | cond-one-wavefront | cond-six-wavefronts | prologue-mfma | prologue-passes; development build: fused | pipeline4)");
+    else return fail("set_kernel: unknown kernel '" + n + "' (auto | pipeline | lin-lane-per-stage | lin-eight-lanes | cond-one-wavefront | cond-six-wavefronts | loop-fork | loop-serial | prologue-mfma | prologue-passes; development build: fused | pipeline4)");
     c->epoch++;
     return 0;
 }
@@ -721,6 +724,40 @@ static void sn_launch_prologue(tum_ocp *c)
     }
 }
 
+// do the wide kernels of the latency path run for this capsule (host's choice by batch size, tum_ocp_set_kernel, environment)
+static bool use_lin_cols(const tum_ocp *c)
+{
+    static const int cols_env = [] { const char *e = getenv("TUM_LIN_COLS"); return e ? atoi(e) : -1; }();
+    const int want = (c->lin_cols >= 0) ? c->lin_cols : cols_env;
+    return want > 0 || (want < 0 && (long long)c->batch * (c->N + 1) * LC_LANES <= 64LL * 1024);
+}
+static bool use_cond_wide(const tum_ocp *c)
+{
+    static const int wide_env = [] { const char *e = getenv("TUM_COND_WIDE"); return e ? atoi(e) : -1; }();
+    const int want = (c->cond_wide >= 0) ? c->cond_wide : wide_env;
+    return want > 0 || (want < 0 && c->batch <= 256);
+}
+// The device closed loop (tum_sim_run) can run the linearisation of a solve BESIDE the planner of the same control step: the
+// Runge-Kutta pass needs the iterate, not the reference -- only the four residuals of the cost do, and cond_wide_kernel forms those
+// while it loads the records (flags & 8). Nominal OCP on the latency path only (lin_cols_kernel + cond_wide_kernel).
+static bool lin_ahead_ok(const tum_ocp *c)
+{
+    static const int fork_env = [] { const char *e = getenv("TUM_SIM_FORK"); return e ? atoi(e) : -1; }();
+    const int want = (c->sim_fork >= 0) ? c->sim_fork : fork_env;
+    // (off unless asked for: measured SLOWER -- 0.169 against 0.160 ms per control step at 26 vehicles, 0.158-0.162 against 0.156 at one:
+    //  the two cross-stream dependencies of a step cost more than the 15 us of planner the linearisation hides behind)
+    return want > 0 && c->pipe && !c->sn && !(c->ka.flags & 6) && use_lin_cols(c) && use_cond_wide(c);
+}
+static void launch_lin_ahead(tum_ocp *c, hipStream_t st)
+{
+    PArgs pa;
+    pa.ka = c->ka; pa.rec = c->drec; pa.hws = c->dhws; pa.cws = c->dcws; pa.vec = c->dvec;
+    pa.ka.flags |= 8;
+    const long long items = (long long)c->batch * (c->N + 1);
+    hipLaunchKernelGGL(lin_cols_kernel<false>, dim3((unsigned)((items + LC_ITEMS - 1) / LC_ITEMS)), dim3(64), 0, st, pa);
+    c->lin_ahead = true;          // the next launch_pipeline skips its linearisation and tells the condensing kernel (consumed there)
+}
+
 static int launch_pipeline(tum_ocp *c, bool events)
 {
     PArgs pa;
@@ -728,11 +765,12 @@ static int launch_pipeline(tum_ocp *c, bool events)
     const bool prof = (c->ka.flags & 4) != 0;
     const long long items = (long long)c->batch * (c->N + 1);
     // linearisation: eight lanes per item while that still is one round of wavefronts on the chip (256 CUs x 4 SIMDs), see lin_cols_kernel
-    static const int cols_env = [] { const char *e = getenv("TUM_LIN_COLS"); return e ? atoi(e) : -1; }();
-    const int want_cols = (c->lin_cols >= 0) ? c->lin_cols : cols_env;
-    const bool cols = want_cols > 0 || (want_cols < 0 && items * LC_LANES <= 64LL * 1024);
+    const bool cols = use_lin_cols(c);
     const dim3 g_cols((unsigned)((items + LC_ITEMS - 1) / LC_ITEMS)), g_lane((unsigned)((items + 63) / 64));
-    if (c->sn) {   // coupled SNMPC OCP: sample fan-out and prologue first, the QP solution goes to the epilogue through the workspace
+    const bool lin_done = c->lin_ahead;
+    c->lin_ahead = false;
+    if (lin_done) pa.ka.flags |= 8;          // (launch_lin_ahead ran it on another stream; the caller has joined that stream)
+    else if (c->sn) {   // coupled SNMPC OCP: sample fan-out and prologue first, the QP solution goes to the epilogue through the workspace
         if (c->fanout && sn_fanout(c)) return 1;
         sn_launch_lin(c);
         sn_launch_prologue(c);
@@ -755,9 +793,7 @@ static int launch_pipeline(tum_ocp *c, bool events)
         const int ipm_lds = lds_req > PD<NTv>::I_LDS_BYTES ? lds_req : PD<NTv>::I_LDS_BYTES;
         {
             // six wavefronts per OCP while every OCP can have a CU's LDS to itself (cond_wide_kernel)
-            static const int wide_env = [] { const char *e = getenv("TUM_COND_WIDE"); return e ? atoi(e) : -1; }();
-            const int want = (c->cond_wide >= 0) ? c->cond_wide : wide_env;
-            const bool wide = want > 0 || (want < 0 && c->batch <= 256);
+            const bool wide = use_cond_wide(c);
             if (wide && c->sn) hipLaunchKernelGGL((cond_wide_kernel<NTv, true>), dim3(c->batch), dim3(64 * cw_waves<NTv>()), 0, c->stream, pa);
             else if (wide) hipLaunchKernelGGL((cond_wide_kernel<NTv, false>), dim3(c->batch), dim3(64 * cw_waves<NTv>()), 0, c->stream, pa);
             else if (c->sn) hipLaunchKernelGGL((cond_kernel<NTv, true>), dim3(c->batch), dim3(64), 0, c->stream, pa);
@@ -1389,6 +1425,7 @@ struct tum_sim {
     hipGraphExec_t graph; int graph_steps;            // captured chunk of control steps (tum_sim_run)
     unsigned graph_epoch; bool graph_fanout;          // configuration of the capsule the chunk was captured with
     double *lCiLX, *lSimX, *lU, *lREF, *lDBG;
+    hipStream_t s2; hipEvent_t evF, evJ;              // side stream of the linearisation that runs beside the planner, fork / join events
 };
 
 extern "C" int tum_planner_emulate(const double *track, int n_track, const double *pose, int P, int n_points, double Tp,
@@ -1426,6 +1463,7 @@ extern "C" void tum_sim_free(tum_sim *s)
     (void)hipFree(s->dtrack); (void)hipFree(s->dxsim); (void)hipFree(s->dpose); (void)hipFree(s->dhist); (void)hipFree(s->dref0);
     (void)hipFree(s->dclosest); (void)hipFree(s->derr); (void)hipFree(s->dstep);
     if (s->graph) (void)hipGraphExecDestroy(s->graph);
+    if (s->s2) { (void)hipStreamSynchronize(s->s2); (void)hipStreamDestroy(s->s2); (void)hipEventDestroy(s->evF); (void)hipEventDestroy(s->evJ); }
     (void)hipFree(s->lCiLX); (void)hipFree(s->lSimX); (void)hipFree(s->lU); (void)hipFree(s->lREF); (void)hipFree(s->lDBG);
     delete s;
 }
@@ -1528,8 +1566,19 @@ extern "C" int tum_sim_advance(tum_sim *s)
 static const int GRAPH_STEPS = 25;
 static int sim_enqueue_step(tum_sim *s, bool events)
 {
-    if (tum_sim_plan(s)) return 1;
-    if (launch(s->c, events)) return 1;
+    tum_ocp *c = s->c;
+    if (lin_ahead_ok(c)) {
+        // fork: the linearisation of this step's solve on the side stream, behind everything the capsule's stream holds (the plant
+        // of the previous step may have re-initialised the iterate); the planner on the capsule's stream; join in front of the
+        // condensing kernel. Inside a stream capture this becomes two branches of the graph.
+        HIPCHK(hipEventRecord(s->evF, c->stream));
+        HIPCHK(hipStreamWaitEvent(s->s2, s->evF, 0));
+        launch_lin_ahead(c, s->s2);
+        HIPCHK(hipEventRecord(s->evJ, s->s2));
+        if (tum_sim_plan(s)) return 1;
+        HIPCHK(hipStreamWaitEvent(c->stream, s->evJ, 0));
+    } else if (tum_sim_plan(s)) return 1;
+    if (launch(c, events)) return 1;
     return tum_sim_advance(s);
 }
 
@@ -1541,6 +1590,10 @@ extern "C" int tum_sim_run(tum_sim *s, int nsteps)
     if (resolve_kernel(c)) return 1;          // (workspace allocation must not happen inside the capture below)
     // ... nor the reallocation / synchronisation a changed SNMPC parameter vector can trigger, nor the deferred freeze
     if (c->sn && (sn_apply_p(c) || sn_materialise(c))) return 1;
+    if (lin_ahead_ok(c) && !s->s2) {          // (created here: not inside the capture below)
+        HIPCHK(hipStreamCreateWithFlags(&s->s2, hipStreamNonBlocking));
+        HIPCHK(hipEventCreateWithFlags(&s->evF, hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&s->evJ, hipEventDisableTiming));
+    }
     int done = 0;
     if (nsteps >= 2 * GRAPH_STEPS) {
         // a captured chunk holds the kernel variant, the schedule flag, the SNMPC horizon / risk parameter / work-buffer
