@@ -932,3 +932,29 @@ def test_device_loop_linearisation_beside_the_planner_is_the_same_loop(controlle
             x, y = x[..., [0, 3, 4]], y[..., [0, 3, 4]]        # cost, qp_iter, status (not the solver time)
         assert np.array_equal(x, y), k
     assert (np.asarray(b["simSolverDebug"])[..., 4] == 0).all()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B", [199, 200, 256, 257])
+def test_latency_path_thresholds_hand_over_cleanly(B):
+    """The library's own choice of kernels around the batch sizes where it changes (eight-lane linearisation up to 199 instances at
+    N = 40, six-wavefront condensing up to 256) against the throughput kernels pinned: the same solves to 1e-7 (bit-identical
+    where only the condensing differs), every instance status 0, same iteration counts."""
+    from tum_control_amd.workloads import nominal_batch
+    x0, yref = nominal_batch(B, N=40, seed=17)
+    out = []
+    for pin in (False, True):
+        s = _mk(40, B)
+        if pin:
+            s.set_kernel("lin-lane-per-stage"); s.set_kernel("cond-one-wavefront")
+        s.set_x0(x0); s.set_yref_all(yref); s.cold_start()
+        for _ in range(2):
+            assert s.solve() == 0
+        X, U = s.get_iterate()
+        out.append((X, U, s.get_stats("qp_iter")))
+    (Xa, Ua, ia), (Xb, Ub, ib) = out
+    assert np.array_equal(ia, ib)
+    if B >= 200:        # (the linearisation is the same kernel in both runs)
+        assert np.array_equal(Xa, Xb) and np.array_equal(Ua, Ub)
+    else:               # (3e-15 on A_k, B_k through two condensed QPs: 1.8e-8 at worst over 199 instances, measured)
+        assert np.abs(Xa - Xb).max() < 1e-7 and np.abs(Ua - Ub).max() < 1e-7
