@@ -99,7 +99,16 @@ int tum_ocp_cost_set(tum_ocp *c, int stage, const char *field, const double *v, 
 
 /* status = acados_solver.solve()   NMPC_class.py:183, SNMPC_class.py:198, Reduced_Robustified_NMPC_class.py:264
  * One SQP real-time iteration for every instance. Returns the max status over the batch
- * (0 ok, 4 QP failure); per-instance values via tum_ocp_get_stats("status"). Synchronous. */
+ * (0 ok, 4 QP failure); per-instance values via tum_ocp_get_stats("status"). Synchronous.
+ * The reference's LITERAL per-step call sequence on a small capsule (batch x (N+1) x 8 <= 32768 doubles, N <= 63) -- N+1 x
+ * set(j,"yref"), constraints_set(0,"lbx"|"ubx"), solve(), get(0,"u"), N x get(j,"x"), get_cost(), 3 x get_stats, NMPC_class.py:169-206,
+ * 243-246 -- costs ONE device round trip: the per-stage "yref" setters and the stage-0 "lbx"/"ubx" land in a pinned shadow the capsule
+ * owns (with a map of the stages touched) and go up in one kernel in front of the solve; the solve ends with one kernel that writes
+ * u0 / cost / status / qp_iter and the whole iterate into pinned slabs; get "x" / "u", get_cost and get_stats "qp_iter" / "status" are
+ * then host copies until something changes the iterate (a set "x"/"u", reset, cold start, device upload, another solve). Same numbers as
+ * the one-call step (tum_ocp_step_async) and as the uncached getters, bit for bit (tests/test_gpu_call_sequence.py). On such a capsule
+ * the solve is timed by the device's wall clock (get_stats "time_tot") and the events around the interior point kernel are left out
+ * (get_stats "time_ipm" needs tum_ocp_set_kernel(c, "time-ipm")). */
 int tum_ocp_solve(tum_ocp *c);
 /* Asynchronous flavour for benchmarking / pipelining: enqueue on the capsule's stream, no host sync. */
 int tum_ocp_solve_async(tum_ocp *c);
@@ -137,6 +146,9 @@ int tum_ocp_get_device(tum_ocp *c, const char *field, void *dev_dst, int b0, int
  * iterate). A third request without a wait in between is an error. */
 int tum_ocp_results_async(tum_ocp *c, int with_iterate);
 int tum_ocp_results_wait(tum_ocp *c, const double **summary, const double **X, const double **U);
+/* number of result requests outstanding on this capsule (0, 1 or 2; tum_ocp_step_async makes one): a synchronous caller drains what
+ * an earlier, abandoned request left behind before it trusts tum_ocp_results_wait to deliver ITS solve (solver.py: step) */
+int tum_ocp_results_outstanding(const tum_ocp *c);
 /* One control step of a HOST-driven loop in one call (what NMPC_class.py:163-241 does with 2 + (N+1) setters, solve() and
  * 2 N + 5 getters, each a synchronous round trip): x0 (nb = batch instances x 8; SNMPC capsules: as tum_ocp_put_device "x0") and
  * yref (batch x (N+1) x 6) -- either may be null: the capsule keeps what it has -- are copied into PINNED staging memory the capsule
@@ -182,7 +194,10 @@ int tum_ocp_set_schedule(tum_ocp *c, int longest_first);
  *       the iterate, not the reference; the four residuals of the cost are formed by the condensing kernel) -- or behind it as in
  *       a plain solve. Default: serial (the fork is bit-identical and measured slower: the cross-stream dependencies cost more
  *       than the overlap gains). Environment: TUM_SIM_FORK = 0 | 1.
- * "auto" hands all these choices back to the library. Environment overrides (read once): TUM_LIN_COLS, TUM_COND_WIDE = 0 | 1. */
+ * "auto" hands all these choices back to the library. Environment overrides (read once): TUM_LIN_COLS, TUM_COND_WIDE = 0 | 1.
+ * Two names are timing options, not kernels: "time-ipm" keeps the two HIP events around the interior point kernel on EVERY solve
+ * (get_stats "time_ipm"), also where the library leaves them out -- steps, and synchronous solves of small capsules: every event on the
+ * stream is a gap of several microseconds between two kernels; "no-time-ipm" (default) hands that back. */
 int tum_ocp_set_kernel(tum_ocp *c, const char *name);
 /* last kernel launch time in milliseconds (HIP events on the launch stream) */
 double tum_ocp_last_kernel_ms(tum_ocp *c);
@@ -258,6 +273,13 @@ tum_sim *tum_sim_create(tum_ocp *c, const double *track, int n_track, double Tp,
 void tum_sim_free(tum_sim *s);
 /* x_sim: batch x 7 plant states, x_mpc: batch x 8 controller states (host); resets the estimator and the step counter */
 int tum_sim_set_state(tum_sim *s, const double *x_sim, const double *x_mpc, int cold_start);
+/* Disturbance realisation played back by the loop (Utils/SimulationMode_main_class.py:121-143: simulate_disturbances /
+ * simulate_state_estimation, as with disturbance_playback; the draws of Utils/MPC_sim_utils.py:54-86 are made on the host): w_deriv is
+ * added to the state derivatives of the plant for the whole control step (Vehicle_Simulator/sim_model_dynamic_stm_pacejka.py:196) in a
+ * SECOND plant step from the same state -- the true state stays the undisturbed step, as in the reference --, e_est is added to that
+ * disturbed state before the estimator. n_steps x batch x 7 doubles each (host, step-major), either may be null; control steps beyond
+ * n_steps run undisturbed; n_steps = 0 removes the realisation. tum_sim_set_state restarts the playback. */
+int tum_sim_set_disturbances(tum_sim *s, const double *w_deriv, const double *e_est, int n_steps);
 int tum_sim_plan(tum_sim *s);        /* yref of every instance from its pose (async on the capsule's stream) */
 /* plant step with (x1[7], u0[1]) of the iterate, estimator -> next x0 (async). An instance whose solve FAILED (status != 0)
  * is then treated as main.py:59-61 treats it (MPC.reintialize_solver(x_next)): its iterate is cold-started at the state the

@@ -235,6 +235,20 @@ typedef struct {
                            * kernel tracks its linear residuals, this code recomputes them: an instance whose test sits on the
                            * tolerance edge can stop one iteration apart; forced to the kernel's count the two follow the same
                            * path and are compared at full tolerance). 0 = off */
+    /* --- iteration-count experiments (round 5; all 0 = the shipped method). Studied by scripts/study/ipm_iterations.py,
+     * outcome in profiles/r05_ipm_iterations.txt and DESIGN.md */
+    int warm;             /* > 0: start from the multipliers / violation slacks of the PREVIOUS QP of this OCP (the reference's SNMPC
+                           * sets qp_solver_warm_start = 1, SNMPC_acados_settings.py:307), pushed back into the interior and re-centred
+                           * to warm_mu; the variants 1.. differ in how (see qp_ipm) */
+    double warm_mu;       /* complementarity target of a warm start */
+    int split;            /* 1: separate step lengths for the primal (v, t, s) and the dual (lam, mu) variables (HPIPM's split_step, which its
+                           * SPEED modes use and BALANCE -- the reference's mode -- does not) */
+    int vstart;           /* 1: primal start at the unconstrained minimiser v = -H^-1 q (one extra factorisation of H and one back-solve) instead
+                           * of v = 0; 2: only when the start v = 0 is far from stationary (a cold start), |q|_inf > vstart_q */
+    double vstart_q;
+    int ncorr;            /* Gondzio multiple centrality correctors per iteration (extra back-solves on the same factorisation) */
+    double corr_beta_lo, corr_beta_hi, corr_dalpha, corr_gain;   /* their usual constants: 0.1, 10, 0.1 (0.3), 1.01 */
+    long solves, factorisations, backsolves;                     /* work counters of the study (accumulated by qp_ipm) */
 } ipm_opts;
 
 typedef struct {
@@ -284,11 +298,17 @@ static void chol_solve(int n, const double *L, int ld, double *b)
  * (what HPIPM's dense IPM does after removing the soft-constraint slacks).
  * Side index: 0 = lower, 1 = upper; arrays are [2*m] with side-major layout.
  */
+static long g_work[3];          /* study counters over all OCPs (OpenMP-safe): QPs, factorisations, back-solves */
+void oracle_global_work(long *out, int reset)
+{
+    for (int i = 0; i < 3; i++) { out[i] = g_work[i]; if (reset) g_work[i] = 0; }
+}
 #define IPM_SO_ALPHA_MIN 0.1    /* second-order correction only if the affine step length reaches this */
 static void qp_ipm(int nv, int m, const double *H, const double *q, const double *C, const double *d,
                    const double *lb, const double *ub,
                    const double *zl, const double *zu, const double *Zl, const double *Zu,
-                   const ipm_opts *opt, double *v, double *s_out, double *lam_out, ipm_info *info)
+                   ipm_opts *opt, double *v, double *s_out, double *lam_out, ipm_info *info,
+                   const double *s_warm, const double *lam_warm)
 {
     const int M2 = 2 * m;
     double *s = calloc(8 * M2 + 8, sizeof(double));
@@ -306,21 +326,65 @@ static void qp_ipm(int nv, int m, const double *H, const double *q, const double
     }
     /* --- initial point: v = 0, t consistent with the slack, multipliers mu0 / (.) */
     for (int j = 0; j < nv; j++) v[j] = 0.0;
+    long n_fact = 0, n_back = 0;
+    double *e0 = NULL;
+    {
+        double qmax = 0.0;
+        for (int j = 0; j < nv; j++) if (fabs(q[j]) > qmax) qmax = fabs(q[j]);
+        if (opt->vstart == 1 || (opt->vstart == 2 && qmax > opt->vstart_q)) {
+            memcpy(Mx, H, sizeof(double) * nv * nv);
+            if (!chol_lower(nv, Mx, nv)) {
+                for (int j = 0; j < nv; j++) v[j] = -q[j];
+                chol_solve(nv, Mx, nv, v);
+                e0 = malloc(sizeof(double) * m);
+                for (int i = 0; i < m; i++) { double acc = 0.0; for (int j = 0; j < nv; j++) acc += C[i * nv + j] * v[j]; e0[i] = acc; }
+                n_fact++; n_back++; opt->factorisations++; opt->backsolves++;
+            }
+        }
+    }
+    const int warm = (opt->warm > 0 && s_warm && lam_warm) ? opt->warm : 0;
     for (int k = 0; k < M2; k++) {
         int i = k % m;
-        double r0 = eps[k] * (d[i] - bnd[k]);       /* >= 0 : satisfied at v = 0 */
+        double r0 = eps[k] * (d[i] + (e0 ? e0[i] : 0.0) - bnd[k]);       /* >= 0 : satisfied at the starting v */
         /* slack-equation-feasible start: the violation slack starts where s*z = mu0, its multiplier from
          * z + Z s - lam - mu = 0 (floored), the constraint residual t keeps a floor t0. Cuts the iteration
          * count of the plain s = t = sqrt(mu0) start by ~35 % cold and ~55 % warm on the reference's problems. */
-        double s0 = opt->mu0 / (z[k] > 1e-6 ? z[k] : 1e-6);
+        double mu0 = opt->mu0, t0 = opt->t0;
+        if (warm) { mu0 = opt->warm_mu; t0 = opt->warm_mu; }
+        double s0 = mu0 / (z[k] > 1e-6 ? z[k] : 1e-6);
+        if (warm >= 2 && s_warm[k] > s0) s0 = s_warm[k];          /* a violation slack the last QP ended with stays */
         s[k] = s0;
         t[k] = r0 + s0;
-        if (t[k] < opt->t0) t[k] = opt->t0;
-        lam[k] = opt->mu0 / t[k];
+        if (t[k] < t0) t[k] = t0;
+        lam[k] = mu0 / t[k];
+        if (warm == 5 || warm == 6) {
+            /* the last multiplier is trusted only as far as the row is still near its bound in the NEW problem: kept within a factor
+             * kcap of the centred value mu0 / t (a row that left its bound gets a small multiplier again instead of a badly centred pair) */
+            const double kcap = (warm == 5) ? 10.0 : 100.0;
+            double lw = lam_warm[k];
+            if (lw > kcap * lam[k]) lw = kcap * lam[k];
+            if (lw > lam[k]) {
+                double cap = 0.99 * (z[k] + Z[k] * s0); if (lw > cap) lw = cap;
+                lam[k] = lw;
+                double tc = mu0 / lam[k];
+                if (t[k] < tc) t[k] = tc;
+            }
+        } else
+        if (warm >= 2 && lam_warm[k] > lam[k]) {
+            /* the last QP's multiplier of a row that was active: kept, and the row pushed off the boundary to where the pair is
+             * centred at mu0 (t lam = mu0) unless the row is further inside anyway */
+            lam[k] = lam_warm[k];
+            if (warm >= 3) { double cap = 0.99 * (z[k] + Z[k] * s0); if (lam[k] > cap) lam[k] = cap; }
+            double tc = mu0 / lam[k];
+            if (warm == 2 || warm == 3) { if (t[k] < tc) t[k] = tc; }
+            else if (warm == 4) { if (r0 + s0 < tc) t[k] = tc; }
+        }
         double ms = z[k] + Z[k] * s0 - lam[k];
-        if (ms < 1e-2 * opt->mu0 / s0) ms = 1e-2 * opt->mu0 / s0;
+        if (ms < 1e-2 * mu0 / s0) ms = 1e-2 * mu0 / s0;
         mu[k] = ms;
     }
+    opt->solves++;
+    free(e0);
     int it = 0, status = 1;
     double res_stat = 0, res_ineq = 0, res_comp = 0;
     double qn = 1.0;
@@ -374,22 +438,44 @@ static void qp_ipm(int nv, int m, const double *H, const double *q, const double
             }
         }
         if (chol_lower(nv, Mx, nv)) { status = 3; break; }
+        opt->factorisations++; n_fact++;
 
-        double sigma = 0.0, mu_aff = 0.0, alpha = 1.0, so = 1.0;
-        for (int pass = 0; pass < 2; pass++) {
+        double sigma = 0.0, mu_aff = 0.0, alpha = 1.0, so = 1.0, alpha_p = 1.0, alpha_d = 1.0;
+        double amax_acc = 1.0, tau_c = 0.0;          /* (centrality correctors: step to the boundary of the accepted direction, its target) */
+        double *sav = NULL;
+        for (int pass = 0; pass < 2 + opt->ncorr; pass++) {
+            opt->backsolves++; n_back++;
             /* complementarity residuals: predictor (tau = 0) then corrector */
             for (int k = 0; k < M2; k++) {
                 if (pass == 0) { rc1[k] = t[k] * lam[k]; rc2[k] = s[k] * mu[k]; }
+                else if (pass >= 2) {
+                    /* Gondzio's multiple centrality correctors: at the trial point of an enlarged step the complementarity products
+                     * are projected into [beta_lo, beta_hi] x target; the projection error corrects the right-hand side */
+                    double at = amax_acc + opt->corr_dalpha; if (at > 1.0) at = 1.0;
+                    double lo = opt->corr_beta_lo * tau_c, hi = opt->corr_beta_hi * tau_c;
+                    double p1 = (t[k] + at * dt[k]) * (lam[k] + at * dlam[k]), p2 = (s[k] + at * ds[k]) * (mu[k] + at * dmu[k]);
+                    double c1 = (p1 < lo) ? lo - p1 : (p1 > hi ? hi - p1 : 0.0), c2 = (p2 < lo) ? lo - p2 : (p2 > hi ? hi - p2 : 0.0);
+                    if (c1 < -hi) c1 = -hi;
+                    if (c2 < -hi) c2 = -hi;
+                    rc1[k] -= c1; rc2[k] -= c2;
+                }
                 else {
                     /* centring target, floored so the products settle just below tol_comp instead of
                      * collapsing to 0 (which would blow up gamma = lam/t and the conditioning of M) */
                     double tau = sigma * gap;
                     if (tau < 0.1 * opt->tol_comp) tau = 0.1 * opt->tol_comp;
+                    tau_c = tau;
                     rc1[k] = t[k] * lam[k] + so * dt[k] * dlam[k] - tau;
                     rc2[k] = s[k] * mu[k] + so * ds[k] * dmu[k] - tau;
                 }
                 double Ds = Z[k] + mu[k] / s[k];
                 rho[k] = -rt[k] + rc1[k] / lam[k] - (rs[k] + rc2[k] / s[k]) / Ds;
+            }
+            if (pass >= 2) {          /* keep the accepted direction: a corrector that does not lengthen the step is dropped */
+                if (!sav) sav = malloc(sizeof(double) * (4 * M2 + nv + 2 * M2));
+                memcpy(sav, dt, sizeof(double) * M2); memcpy(sav + M2, ds, sizeof(double) * M2);
+                memcpy(sav + 2 * M2, dlam, sizeof(double) * M2); memcpy(sav + 3 * M2, dmu, sizeof(double) * M2);
+                memcpy(sav + 4 * M2, dv, sizeof(double) * nv);
             }
             for (int j = 0; j < nv; j++) rhs[j] = -rv[j];
             for (int i = 0; i < m; i++) {
@@ -404,7 +490,7 @@ static void qp_ipm(int nv, int m, const double *H, const double *q, const double
                 for (int j = 0; j < nv; j++) acc += C[i * nv + j] * dv[j];
                 cdv[i] = acc;
             }
-            double amax = 1.0;
+            double amax = 1.0, amax_p = 1.0, amax_d = 1.0;
             int blk = -1, blkw = 0;
             for (int k = 0; k < M2; k++) {
                 int i = k % m;
@@ -417,6 +503,10 @@ static void qp_ipm(int nv, int m, const double *H, const double *q, const double
                 if (ds[k] < 0.0 && -s[k] / ds[k] < amax) { amax = -s[k] / ds[k]; blk = k; blkw = 1; }
                 if (dlam[k] < 0.0 && -lam[k] / dlam[k] < amax) { amax = -lam[k] / dlam[k]; blk = k; blkw = 2; }
                 if (dmu[k] < 0.0 && -mu[k] / dmu[k] < amax) { amax = -mu[k] / dmu[k]; blk = k; blkw = 3; }
+                if (dt[k] < 0.0 && -t[k] / dt[k] < amax_p) amax_p = -t[k] / dt[k];
+                if (ds[k] < 0.0 && -s[k] / ds[k] < amax_p) amax_p = -s[k] / ds[k];
+                if (dlam[k] < 0.0 && -lam[k] / dlam[k] < amax_d) amax_d = -lam[k] / dlam[k];
+                if (dmu[k] < 0.0 && -mu[k] / dmu[k] < amax_d) amax_d = -mu[k] / dmu[k];
             }
             if (getenv("TUM_ORACLE_TRACE") && getenv("TUM_ORACLE_TRACE")[0] == '2') {
                 int kx = 0; double px = 0; int which = 0;
@@ -428,8 +518,12 @@ static void qp_ipm(int nv, int m, const double *H, const double *q, const double
             }
             if (pass == 0) {
                 mu_aff = 0.0;
-                for (int k = 0; k < M2; k++)
-                    mu_aff += (t[k] + amax * dt[k]) * (lam[k] + amax * dlam[k]) + (s[k] + amax * ds[k]) * (mu[k] + amax * dmu[k]);
+                const double ap0 = opt->split ? amax_p : amax, ad0 = opt->split == 1 ? amax_d : (opt->split == 2 ? amax_p : amax);
+                for (int k = 0; k < M2; k++) {
+                    double ln = lam[k] + ad0 * dlam[k], mn = mu[k] + ad0 * dmu[k];
+                    if (opt->split == 2) { if (ln < 0.0) ln = 0.0; if (mn < 0.0) mn = 0.0; }
+                    mu_aff += (t[k] + ap0 * dt[k]) * ln + (s[k] + ap0 * ds[k]) * mn;
+                }
                 mu_aff /= (2.0 * M2);
                 double ratio = mu_aff / gap;
                 sigma = ratio * ratio * ratio;
@@ -439,18 +533,59 @@ static void qp_ipm(int nv, int m, const double *H, const double *q, const double
                  * acados' own logs show iteration-cap hits in the same loops). Drop them for this iteration: the step becomes
                  * a plain centring step and the next iteration proceeds normally. */
                 so = (amax < IPM_SO_ALPHA_MIN) ? 0.0 : 1.0;
-            } else {
+            } else if (pass == 1) {
                 alpha = 0.995 * amax; if (amax >= 1.0) alpha = 1.0; if (alpha > 1.0) alpha = 1.0;
+                alpha_p = (amax_p >= 1.0) ? 1.0 : 0.995 * amax_p; alpha_d = (amax_d >= 1.0) ? 1.0 : 0.995 * amax_d;
+                amax_acc = amax;
+                if (amax >= 1.0) break;          /* a full step needs no corrector */
+            } else {
+                if (amax >= opt->corr_gain * amax_acc) {
+                    amax_acc = amax;
+                    alpha = 0.995 * amax; if (amax >= 1.0) alpha = 1.0; if (alpha > 1.0) alpha = 1.0;
+                    if (amax >= 1.0) break;
+                } else {          /* rejected: back to the accepted direction */
+                    memcpy(dt, sav, sizeof(double) * M2); memcpy(ds, sav + M2, sizeof(double) * M2);
+                    memcpy(dlam, sav + 2 * M2, sizeof(double) * M2); memcpy(dmu, sav + 3 * M2, sizeof(double) * M2);
+                    memcpy(dv, sav + 4 * M2, sizeof(double) * nv);
+                    break;
+                }
             }
         }
+        free(sav);
         if (getenv("TUM_ORACLE_TRACE"))
             fprintf(stderr, "ipm it %2d stat %.2e ineq %.2e comp %.2e gap %.2e sigma %.2e alpha %.4f\n", it, res_stat, res_ineq, res_comp, gap, sigma, alpha);
         if (alpha < 1e-12) { status = 2; break; }
-        for (int j = 0; j < nv; j++) v[j] += alpha * dv[j];
+        if (!opt->split) alpha_p = alpha_d = alpha;
+        for (int j = 0; j < nv; j++) v[j] += alpha_p * dv[j];
+        if (opt->split == 2) {
+            /* the step length is the PRIMAL one for everything; a multiplier that this step would take through zero keeps the
+             * fraction 0.005 of its value instead (the fraction-to-the-boundary rule per component): a vanishing multiplier of a
+             * row that leaves its bound no longer shortens the step of all the others */
+            for (int k = 0; k < M2; k++) {
+                t[k] += alpha_p * dt[k]; s[k] += alpha_p * ds[k];
+                double ln = lam[k] + alpha_p * dlam[k], mn = mu[k] + alpha_p * dmu[k];
+                lam[k] = (ln < 0.005 * lam[k]) ? 0.005 * lam[k] : ln;
+                mu[k] = (mn < 0.005 * mu[k]) ? 0.005 * mu[k] : mn;
+            }
+        } else
         for (int k = 0; k < M2; k++) {
-            t[k] += alpha * dt[k]; s[k] += alpha * ds[k];
-            lam[k] += alpha * dlam[k]; mu[k] += alpha * dmu[k];
+            t[k] += alpha_p * dt[k]; s[k] += alpha_p * ds[k];
+            lam[k] += alpha_d * dlam[k]; mu[k] += alpha_d * dmu[k];
         }
+    }
+    {
+#ifdef _OPENMP
+#pragma omp atomic
+#endif
+        g_work[0] += 1;
+#ifdef _OPENMP
+#pragma omp atomic
+#endif
+        g_work[1] += n_fact;
+#ifdef _OPENMP
+#pragma omp atomic
+#endif
+        g_work[2] += n_back;
     }
     if (s_out) memcpy(s_out, s, sizeof(double) * M2);
     if (lam_out) memcpy(lam_out, lam, sizeof(double) * M2);
@@ -483,6 +618,7 @@ typedef struct {
     double cost;
     int qp_iter, status;
     double res[3];
+    int have_qp;                         /* sl / su / lam hold a converged QP of this OCP (warm start experiments) */
 } oracle_ocp;
 
 oracle_ocp *oracle_create(int N, double dt, int nsub)
@@ -492,7 +628,20 @@ oracle_ocp *oracle_create(int N, double dt, int nsub)
     o->N = N; o->dt = dt; o->nsub = nsub;
     o->ipm.iter_max = 50; o->ipm.tol_stat = 1e-8; o->ipm.tol_ineq = 1e-8; o->ipm.tol_comp = 1e-8;
     o->ipm.mu0 = 0.05; o->ipm.t0 = 0.05; o->ipm.reg = 0.0;
+    o->ipm.warm_mu = 1e-3; o->ipm.corr_beta_lo = 0.1; o->ipm.corr_beta_hi = 10.0; o->ipm.corr_dalpha = 0.1; o->ipm.corr_gain = 1.01;
     return o;
+}
+/* iteration-count experiments (ipm_opts): warm-start variant, its complementarity target, number of centrality correctors */
+void oracle_set_ipm_vstart(oracle_ocp *o, int vstart, double qthr) { o->ipm.vstart = vstart; o->ipm.vstart_q = qthr; }
+void oracle_set_ipm_split(oracle_ocp *o, int split) { o->ipm.split = split; }
+void oracle_set_ipm_experiment(oracle_ocp *o, int warm, double warm_mu, int ncorr, double dalpha)
+{
+    o->ipm.warm = warm; if (warm_mu > 0) o->ipm.warm_mu = warm_mu; o->ipm.ncorr = ncorr; if (dalpha > 0) o->ipm.corr_dalpha = dalpha;
+}
+void oracle_work_counters(oracle_ocp *o, long *out, int reset)
+{
+    out[0] = o->ipm.solves; out[1] = o->ipm.factorisations; out[2] = o->ipm.backsolves;
+    if (reset) o->ipm.solves = o->ipm.factorisations = o->ipm.backsolves = 0;
 }
 void oracle_free(oracle_ocp *o) { free(o); }
 size_t oracle_sizeof(void) { return sizeof(oracle_ocp); }
@@ -655,10 +804,18 @@ int oracle_solve(oracle_ocp *o)
     /* 6. QP */
     double *sall = calloc(2 * m, sizeof(double));
     ipm_info info;
-    qp_ipm(nv, m, H, q, C, d, lb, ub, zl, zu, Zl, Zu, &o->ipm, v, sall, o->lam, &info);
+    double *swarm = NULL, *lwarm = NULL;
+    if (o->ipm.warm > 0 && o->have_qp) {          /* the previous QP's violation slacks and multipliers (side-major like sall) */
+        swarm = malloc(sizeof(double) * 4 * m); lwarm = swarm + 2 * m;
+        memcpy(swarm, o->sl, sizeof(double) * m); memcpy(swarm + m, o->su, sizeof(double) * m);
+        memcpy(lwarm, o->lam, sizeof(double) * 2 * m);
+    }
+    qp_ipm(nv, m, H, q, C, d, lb, ub, zl, zu, Zl, Zu, &o->ipm, v, sall, o->lam, &info, swarm, lwarm);
+    free(swarm);
     memcpy(o->sl, sall, sizeof(double) * m);
     memcpy(o->su, sall + m, sizeof(double) * m);
     o->qp_iter = info.iter;
+    o->have_qp = (info.status == 0);
     o->res[0] = info.res_stat; o->res[1] = info.res_ineq; o->res[2] = info.res_comp;
     /* acados: QP max-iter is not a failure; NaN / min-step -> 4 */
     o->status = (info.status == 0 || info.status == 1) ? 0 : 4;
@@ -1050,7 +1207,7 @@ int snmpc_solve(snmpc_ocp *o)
     /* 6. QP */
     double *sall = calloc(2 * m, sizeof(double));
     ipm_info info;
-    qp_ipm(nv, m, H, q, C, d, lb, ub, zl, zu, Zl, Zu, &o->ipm, v, sall, o->lam, &info);
+    qp_ipm(nv, m, H, q, C, d, lb, ub, zl, zu, Zl, Zu, &o->ipm, v, sall, o->lam, &info, NULL, NULL);
     memcpy(o->sl, sall, sizeof(double) * m);
     memcpy(o->su, sall + m, sizeof(double) * m);
     o->qp_iter = info.iter;

@@ -233,6 +233,25 @@ class OracleOcp:
         """tests: run exactly `it` interior point iterations (0 = normal termination test)"""
         lib().oracle_set_iter_force(self._h, int(it))
 
+    def set_ipm_experiment(self, warm=0, warm_mu=0.0, ncorr=0, dalpha=0.0):
+        """iteration-count experiments of the interior point method (scripts/study/ipm_iterations.py; all 0 = the shipped method):
+        warm-start variant and its complementarity target, number of Gondzio centrality correctors and their step enlargement"""
+        L = lib()
+        L.oracle_set_ipm_experiment.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_double, ctypes.c_int, ctypes.c_double]
+        L.oracle_set_ipm_experiment(self._h, int(warm), float(warm_mu), int(ncorr), float(dalpha))
+
+    def set_ipm_split(self, split=0):
+        """same study: separate primal / dual step lengths"""
+        L = lib()
+        L.oracle_set_ipm_split.argtypes = [ctypes.c_void_p, ctypes.c_int]
+        L.oracle_set_ipm_split(self._h, int(split))
+
+    def set_ipm_vstart(self, vstart=0, q_threshold=0.0):
+        """same study: primal start at the unconstrained minimiser (1: always, 2: only if |q|_inf > q_threshold)"""
+        L = lib()
+        L.oracle_set_ipm_vstart.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_double]
+        L.oracle_set_ipm_vstart(self._h, int(vstart), float(q_threshold))
+
     def solve(self):
         return lib().oracle_solve(self._h)
 
@@ -422,3 +441,11 @@ class OracleSnmpcOcp:
     @property
     def status(self):
         return lib().snmpc_status(self._h)
+
+
+def global_work(reset=False):
+    """(QPs, factorisations, back-solves) of every interior point solve of this process since the last reset (study counters)"""
+    L = lib()
+    out = (ctypes.c_long * 3)()
+    L.oracle_global_work(out, int(bool(reset)))
+    return tuple(out)

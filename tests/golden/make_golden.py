@@ -16,6 +16,8 @@ DATA (inputs + expected outputs), never reference source:
   snmpc_expr.npz      stacked dynamics / cost output / chance constraint of the exported SNMPC OCP evaluated at random points
   snmpc_json.npz      dimensions, weights, penalties, bounds and solver options of the exported SNMPC OCP (acados_ocp_SNMPC.json)
   r2.npz              P_propagation input/output pairs
+  disturbances.npz    the harness's disturbance set-up (initDisturbanceSim on the shipped sim_main_params.yaml) and seeded realisations of
+                      generate_disturbances for every distribution type, in sim_step's draw order; LonLatDeviations / postprocess_yaw pairs
   closed_loop_<t>_<n>.npz   first n steps of the 26 logged closed loops of one track (plant states, inputs, predictions)
   closed_loop_<t>_full_sub<k>.npz   the complete 5499-step loops, every k-th plant state + per-loop statistics
 
@@ -297,8 +299,39 @@ def make_r2():
     np.savez_compressed(os.path.join(OUT, "r2.npz"), P=P, A=A, B=B, W=W, Pn=Pn)
 
 
+def make_disturbances():
+    """Utils/MPC_sim_utils.py:15-99 (initDisturbanceSim, generate_disturbances, sampleFromEllipsoid) and :103-134 (LonLatDeviations,
+    postprocess_yaw) on the shipped Config/EDGAR/sim_main_params.yaml, with numpy's global generator seeded: what
+    tum_control_amd.closed_loop.DisturbanceModel / generate_disturbances / lon_lat_deviations / wrap_yaw must reproduce."""
+    import yaml
+    from Utils.MPC_sim_utils import LonLatDeviations, generate_disturbances, initDisturbanceSim
+    with open(os.path.join(REF, "Config/EDGAR/sim_main_params.yaml")) as f:
+        p = yaml.safe_load(f)
+    p = dict(p, simulate_disturbances=True, simulate_state_estimation=True, disturbance_playback=False)
+    (_, _, _, bd, be, types, _, _) = initDisturbanceSim(p, "", 10, 7)
+    out = dict(bounds_derivatives=np.array(bd, float), bounds_state_estimation=np.array(be, float), types=np.array(types))
+    for kind in ("uniform", "gaussian", "absolute", "box"):
+        np.random.seed(7)
+        out[f"deriv_{kind}"] = np.array([np.array(generate_disturbances(bd, kind), float) for _ in range(5)])
+        np.random.seed(8)
+        out[f"est_{kind}"] = np.array([np.array(generate_disturbances(be, kind), float) for _ in range(5)])
+    # one run in sim_step's order (SimulationMode_main_class.py:121-143): per control step the derivative draw, then the estimation draw
+    np.random.seed(3)
+    W, E = [], []
+    for _ in range(6):
+        W.append(np.array(generate_disturbances(bd, types[0]), float)); E.append(np.array(generate_disturbances(be, types[1]), float))
+    out["run_w"], out["run_e"] = np.array(W), np.array(E)
+    rng = np.random.default_rng(12)
+    yaw = rng.uniform(-7, 7, 20); ex, ey, rx, ry = rng.normal(size=(4, 20)) * 30
+    dl, dt_ = LonLatDeviations(yaw, ex, ey, rx, ry)
+    out.update(dev_in=np.stack([yaw, ex, ey, rx, ry]), dev_long=dl, dev_lat=dt_, wrapped=postprocess_yaw(yaw.copy()))
+    np.savez_compressed(os.path.join(OUT, "disturbances.npz"), **out)
+
+
 if __name__ == "__main__":
-    what = sys.argv[1:] or ["kat0", "replay", "replay_hard", "planner", "pce", "snmpc_json", "snmpc_expr", "r2", "closed_loop"]
+    what = sys.argv[1:] or ["kat0", "replay", "replay_hard", "planner", "pce", "snmpc_json", "snmpc_expr", "r2", "closed_loop", "disturbances"]
+    if "disturbances" in what:
+        make_disturbances()
     if "replay_hard" in what:
         make_replay_hard()
     if "kat0" in what:

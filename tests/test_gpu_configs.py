@@ -410,3 +410,41 @@ def test_one_call_control_step_equals_setters_solve_getters():
     assert np.array_equal(r1[2], U1) and np.array_equal(r2[2], U2)
     with pytest.raises(Exception, match="expected"):
         b.step(x0=np.zeros(3))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("which", ["derivatives", "state_estimation", "both"])
+def test_disturbed_closed_loop_device_against_host(which, tmp_path):
+    """sim_step's disturbance simulation (Utils/SimulationMode_main_class.py:121-143) in the device loop -- the realisation played back
+    by plant_advance_kernel: a second plant step with xdot + w for what the estimator sees, the estimation error on top, the TRUE state
+    still the undisturbed step -- against the host loop that applies the same realisation with the numpy plant; then the log file."""
+    from tum_control_amd.closed_loop import ClosedLoopBatch, DisturbanceModel, LOG_KEYS
+    m = DisturbanceModel(simulate_disturbances=which != "state_estimation", simulate_state_estimation=which != "derivatives")
+    n, B = 60, 3
+    w, e = m.draw(n - 10, B, seed=5)          # (shorter than the run: the last ten steps are undisturbed)
+    logs = {}
+    for dev in (False, True):
+        cl = ClosedLoopBatch("lvms", batch=B, N=38, Tp=3.04, on_device=dev, log_capacity=n, disturbances=(w, e))
+        logs[dev] = cl.run(n)
+    for f in ("simU", "CiLX", "MPC_SimX", "simREF"):
+        np.testing.assert_allclose(logs[True][f][:25], logs[False][f][:25], rtol=1e-8, atol=1e-8, err_msg=f)
+        np.testing.assert_allclose(logs[True][f], logs[False][f], rtol=1e-5, atol=1e-5, err_msg=f)
+    assert (logs[True]["simSolverDebug"][:, :, 4] == 0).all()
+    # the disturbance reaches the controller (the loops differ from the undisturbed one) but not the plant's own integration:
+    clean = ClosedLoopBatch("lvms", batch=B, N=38, Tp=3.04, on_device=True, log_capacity=n).run(n)
+    assert np.abs(clean["simU"][1:] - logs[True]["simU"][1:]).max() > 1e-3
+    np.testing.assert_array_equal(clean["CiLX"][:2], logs[True]["CiLX"][:2])          # step 0 is solved before any disturbance is seen
+    # the vehicles of a batch see different realisations
+    assert np.abs(logs[True]["simU"][5:, 0] - logs[True]["simU"][5:, 1]).max() > 1e-4
+    paths = cl.save(str(tmp_path / "{}.npz"))
+    assert len(paths) == B
+    f = np.load(paths[1])
+    assert set(f.files) == set(LOG_KEYS)
+    assert f["simU"].shape == (n - 1, 2) and f["CiLX"].shape == (n, 7) and f["sim_disturbance_derivatives"].shape == (n, 7) and f["t"].shape == (n - 1,)
+    if w is not None:
+        np.testing.assert_array_equal(f["sim_disturbance_derivatives"][:n - 10], w[:, 1])
+        assert not f["sim_disturbance_derivatives"][n - 10:].any()
+    else:
+        assert not f["sim_disturbance_derivatives"].any()
+    np.testing.assert_array_equal(f["simU"], logs[True]["simU"][:n - 1, 1])
+    assert (f["CiLX"][:, 2] >= 0).all() and (f["CiLX"][:, 2] < 2 * np.pi).all()

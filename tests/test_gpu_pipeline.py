@@ -44,6 +44,8 @@ def test_pipeline_matches_fused_and_oracle(N, B):
     out = {}
     for k in ("fused", "pipeline"):
         s = _mk(N, B, k)
+        if k == "pipeline":
+            s.set_kernel("time-ipm")          # (small capsules leave the events around the interior point kernel out of a synchronous solve)
         s.set_x0(x0); s.set_yref_all(yref); s.cold_start()
         assert s.solve() == 0
         X, U = s.get_iterate()

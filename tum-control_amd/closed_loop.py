@@ -8,7 +8,8 @@ Restates, for the code around the hot path only what is needed to drive it the w
   Vehicle_Simulator/sim_model_dynamic_stm_pacejka.py:137-195 + VehicleSimulator.py:73-77 plant: 7-state single track
                                                                                          (input = acceleration, steering rate),
                                                                                          CasADi 'rk' with 4 finite elements = RK4 x 4
-  Utils/Logging_Plotting.py:124-146,357-372                                             what gets logged (npz schema)
+  Utils/Logging_Plotting.py:124-146,321-372                                             what gets logged, and the npz file (save)
+  Utils/MPC_sim_utils.py:15-99                                                          disturbance set-up and generators
 Every instance may carry its own cost weights / penalties (the BO / RL weight sweep as one batch).
 """
 import numpy as np
@@ -53,35 +54,126 @@ def plant_xdot(x, a, sr, cfg):
     return xd
 
 
-def plant_step(x, a, sr, cfg, Ts=0.02, n_elem=4):
-    """One simulator step: classic RK4 with `n_elem` equal sub-steps over Ts, inputs held constant."""
+def plant_step(x, a, sr, cfg, Ts=0.02, n_elem=4, w=None):
+    """One simulator step: classic RK4 with `n_elem` equal sub-steps over Ts, inputs held constant. w (B,7): additive disturbance
+    of the state derivatives, constant over the step (simulator_step_disturbed: xdot + w, sim_model_dynamic_stm_pacejka.py:196)."""
     h = Ts / n_elem
     x = x.copy()
+    f = (lambda y: plant_xdot(y, a, sr, cfg)) if w is None else (lambda y: plant_xdot(y, a, sr, cfg) + w)
     for _ in range(n_elem):
-        k1 = plant_xdot(x, a, sr, cfg)
-        k2 = plant_xdot(x + 0.5 * h * k1, a, sr, cfg)
-        k3 = plant_xdot(x + 0.5 * h * k2, a, sr, cfg)
-        k4 = plant_xdot(x + h * k3, a, sr, cfg)
+        k1 = f(x)
+        k2 = f(x + 0.5 * h * k1)
+        k3 = f(x + 0.5 * h * k2)
+        k4 = f(x + h * k3)
         x = x + h / 6.0 * (k1 + 2 * k2 + 2 * k3 + k4)
     return x
 
 
-class MovingAverageEstimator:
-    """StateEstimation (SimulationMode_main_class.py:152-156): per-state moving average over the last
-    WINDOWS[i] samples (fewer while the buffer fills), buffers start empty."""
+STATE_NAMES = ("posx", "posy", "yaw", "vlong", "vlat", "yawrate", "delta_f")
 
-    def __init__(self, batch):
-        self.hist = [[] for _ in range(8)]
-        self.batch = batch
 
-    def __call__(self, x_next):
-        out = np.empty_like(x_next)
-        for i in range(8):
-            self.hist[i].append(x_next[:, i].copy())
-            if len(self.hist[i]) > 15:
-                self.hist[i].pop(0)
-            out[:, i] = np.mean(self.hist[i][-WINDOWS[i]:], axis=0)
+def sample_from_ellipsoid(w, Z, rng):
+    """Utils/MPC_sim_utils.py:70-86: a point of the ellipsoid with centre w and shape matrix Z -- radius rand()^(1/n), direction a
+    normalised Gaussian vector, mapped through the eigen-decomposition of Z. Same order of random draws as the reference (one rand(),
+    then n randn())."""
+    n = w.shape[0]
+    lam, v = np.linalg.eig(Z)
+    r = rng.rand() ** (1 / n)
+    x = rng.randn(n)
+    x = x / np.linalg.norm(x)
+    x *= r
+    return v @ (np.sqrt(lam) * x) + w
+
+
+def generate_disturbances(bounds, kind, rng):
+    """Utils/MPC_sim_utils.py:54-67: one realisation for the n channels of `bounds` ([-b, b] pairs). 'uniform' draws from the ELLIPSOID
+    with semi-axes sqrt(b) (the reference passes diag(b) as the shape matrix), 'gaussian' has standard deviation b, 'absolute'
+    returns b; anything else is uniform in the box."""
+    b = np.asarray(bounds, dtype=float)
+    if kind == 'uniform':
+        return sample_from_ellipsoid(np.zeros(len(b)), np.diag(b.T[1, :]), rng)
+    if kind == 'gaussian':
+        return np.array([rng.normal(0, b[j][1]) for j in range(len(b))])
+    if kind == 'absolute':
+        return np.array([b[j][1] for j in range(len(b))])
+    return np.array([rng.uniform(b[j][0], b[j][1]) for j in range(len(b))])
+
+
+class DisturbanceModel:
+    """The disturbance set-up of the reference's harness (initDisturbanceSim, Utils/MPC_sim_utils.py:15-51; switches and magnitudes:
+    Config/EDGAR/sim_main_params.yaml:44-80) and the realisations sim_step draws from it (SimulationMode_main_class.py:121-143).
+    `draw` pre-draws a whole run: the device loop plays a realisation back (as the reference does with disturbance_playback),
+    the host loop applies the same arrays step by step."""
+
+    def __init__(self, sim_main_params=None, **override):
+        p = dict(_config.SIM)
+        p.update(sim_main_params or {})
+        p.update(override)
+        self.derivatives = bool(p["simulate_disturbances"])
+        self.state_estimation = bool(p["simulate_state_estimation"])
+        self.types = [p["disturbance_type_derivatives"], p["disturbance_type_state_estimation"]]
+        self.bounds_derivatives = [[-p[f"w_{n}_dot"], p[f"w_{n}_dot"]] for n in STATE_NAMES]
+        self.bounds_state_estimation = [[-p[f"w_{n}"], p[f"w_{n}"]] for n in STATE_NAMES]
+
+    def draw(self, n_steps, batch=1, seed=0):
+        """(w_deriv, e_est): (n_steps, batch, 7) arrays or None. Vehicle b uses numpy's legacy generator seeded with seed + b and
+        draws in the reference's order -- per control step the derivative disturbance first, then the estimation error -- so
+        batch = 1 reproduces what main.py produces after np.random.seed(seed)."""
+        w = np.zeros((n_steps, batch, 7)) if self.derivatives else None
+        e = np.zeros((n_steps, batch, 7)) if self.state_estimation else None
+        for b in range(batch):
+            rng = np.random.RandomState(seed + b)
+            for i in range(n_steps):
+                if w is not None:
+                    w[i, b] = generate_disturbances(self.bounds_derivatives, self.types[0], rng)
+                if e is not None:
+                    e[i, b] = generate_disturbances(self.bounds_state_estimation, self.types[1], rng)
+        return w, e
+
+
+def lon_lat_deviations(ego_yaw, ego_x, ego_y, ref_x, ref_y):
+    """Utils/MPC_sim_utils.py:103-112: the deviation vector rotated into the vehicle frame"""
+    c, s_ = np.cos(-ego_yaw), np.sin(-ego_yaw)
+    return c * (ref_x - ego_x) - s_ * (ref_y - ego_y), s_ * (ref_x - ego_x) + c * (ref_y - ego_y)
+
+
+def wrap_yaw(yaw):
+    """postprocess_yaw (Utils/MPC_sim_utils.py:124-134): fmod into (-2 pi, 2 pi), negatives shifted up"""
+    y = np.fmod(np.asarray(yaw, dtype=float), 2 * np.pi)
+    return np.where(y < 0, y + 2 * np.pi, y)
+
+
+LOG_KEYS = ("MPC_SimX", "CiLX", "simU", "simREF", "simSolverDebug", "sim_disturbance_derivatives", "sim_disturbance_state_estimation",
+            "a_lat", "dev_lat", "dev_long", "dev_vel", "dev_yaw", "t")
+
+
+def log_file_arrays(logs, b, w_deriv=None, e_est=None, T=None, Ts=0.02, drop_last_step=True):
+    """The arrays of one vehicle's `full_logs.npz` as Logger.save_logs writes them (Utils/Logging_Plotting.py:321-395): the five raw
+    logs of instance b (yaw columns wrapped to [0, 2 pi) as the reference stores them), the disturbance realisation, and the derived
+    channels a_lat = vlong * yawrate, dev_lat / dev_long (vehicle frame), dev_vel, dev_yaw, t.
+    drop_last_step: Logger.truncate cuts at `current_step`, the INDEX of the last control step -- a run of n steps is stored as n - 1
+    rows of simU / simREF / simSolverDebug and n rows of CiLX / MPC_SimX (the reference's own files: 5500 steps run, 5499 stored), while
+    the disturbance arrays keep all n rows and t = linspace(0, T, n - 1). True reproduces that layout; False keeps every step."""
+    simU = np.array(logs["simU"][:, b])
+    n_run = len(simU)
+    n = n_run - 1 if (drop_last_step and n_run > 1) else n_run
+    CiLX = np.array(logs["CiLX"][:n + 1, b]); SimX = np.array(logs["MPC_SimX"][:n + 1, b])
+    simU = simU[:n]; simREF = np.array(logs["simREF"][:n, b]); dbg = np.array(logs["simSolverDebug"][:n, b])
+    dev_vel = np.abs(CiLX[1:, 3] - simREF[:, 3])
+    CiLX[:, 2] = wrap_yaw(CiLX[:, 2]); SimX[:, 2] = wrap_yaw(SimX[:, 2])
+    dev_yaw = np.abs(CiLX[1:, 2] - simREF[:, 2])
+    dev_long, dev_lat = lon_lat_deviations(CiLX[1:, 2], CiLX[1:, 0], CiLX[1:, 1], simREF[:, 0], simREF[:, 1])
+
+    def realisation(a):
+        out = np.zeros((n_run, 7))
+        if a is not None:
+            a = np.asarray(a)[:n_run, b]
+            out[:len(a)] = a
         return out
+    return dict(MPC_SimX=SimX, CiLX=CiLX, simU=simU, simREF=simREF, simSolverDebug=dbg,
+                sim_disturbance_derivatives=realisation(w_deriv), sim_disturbance_state_estimation=realisation(e_est),
+                a_lat=CiLX[:, 3] * CiLX[:, 5], dev_lat=dev_lat, dev_long=dev_long, dev_vel=dev_vel, dev_yaw=dev_yaw,
+                t=np.linspace(0.0, n_run * Ts if T is None else T, n))
 
 
 class ClosedLoopBatch:
@@ -89,7 +181,7 @@ class ClosedLoopBatch:
     [q_xy, q_yaw, q_vel, r_jerk, r_steer, L1, L2] as in update_cost_function_weights (None: YAML defaults x0.01)."""
 
     def __init__(self, track_name, batch=1, params=None, N=38, Tp=3.04, Ts=0.02, idx_start=0, cfg=None, device=0,
-                 on_device=False, log_capacity=0, controller="nominal"):
+                 on_device=False, log_capacity=0, controller="nominal", disturbances=None, disturbance_steps=0, seed=0):
         self.cfg = cfg or _config.default_config()
         self.track = load_track(track_name)
         self.B, self.N, self.Tp, self.Ts = batch, N, Tp, Ts
@@ -131,6 +223,20 @@ class ClosedLoopBatch:
             self.dev = DeviceClosedLoop(self.solver, self.track, Tp, Ts=Ts, n_elem=4, windows=WINDOWS, log_capacity=log_capacity)
             self.dev.set_state(self.x_sim, self.x_mpc, cold_start=True)
         self.log = dict(CiLX=[self.x_sim.copy()], MPC_SimX=[self.x_mpc.copy()], simU=[], simREF=[], simSolverDebug=[])
+        # disturbance realisation (sim_step's simulate_disturbances / simulate_state_estimation): a DisturbanceModel -- `disturbance_steps`
+        # control steps are drawn with `seed` -- or a (w_deriv, e_est) pair of (n_steps, B, 7) arrays / None to play back
+        self.w_deriv = self.e_est = None
+        self._i = 0
+        self._last_logs = None
+        if disturbances is not None:
+            w, e = disturbances.draw(disturbance_steps, batch, seed) if isinstance(disturbances, DisturbanceModel) else disturbances
+            self.set_disturbances(w, e)
+
+    def set_disturbances(self, w_deriv=None, e_est=None):
+        self.w_deriv = None if w_deriv is None else np.ascontiguousarray(w_deriv, dtype=float).reshape(-1, self.B, 7)
+        self.e_est = None if e_est is None else np.ascontiguousarray(e_est, dtype=float).reshape(-1, self.B, 7)
+        if self.dev is not None:
+            self.dev.set_disturbances(self.w_deriv, self.e_est)
 
     def set_weights(self, p):
         s, B, N = self.solver, self.B, self.N
@@ -162,7 +268,16 @@ class ClosedLoopBatch:
         if len(failed):
             self._reinitialise(failed, X, U)
         x_sim_next = plant_step(self.x_sim, a_in, sr_in, self.cfg, self.Ts)
-        x_next = np.concatenate([x_sim_next, a_in[:, None]], axis=1)
+        # SimulationMode_main_class.py:121-143: the TRUE state follows the undisturbed step; what the estimator is fed is a second step
+        # with disturbed derivatives (if simulated) plus the state estimation error (if simulated)
+        i = self._i
+        x_meas = x_sim_next
+        if self.w_deriv is not None and i < len(self.w_deriv):
+            x_meas = plant_step(self.x_sim, a_in, sr_in, self.cfg, self.Ts, w=self.w_deriv[i])
+        if self.e_est is not None and i < len(self.e_est):
+            x_meas = x_meas + self.e_est[i]
+        self._i += 1
+        x_next = np.concatenate([x_meas, a_in[:, None]], axis=1)
         self.pose = x_sim_next[:, :2].copy()
         self.x_sim = x_sim_next
         self.x_mpc = self.est(x_next)
@@ -201,7 +316,25 @@ class ClosedLoopBatch:
         if self.dev is not None:
             self.dev.run(n_steps)
             self.x_sim, self.x_mpc, self.pose = self.dev.get("x_sim"), self.dev.get("x_mpc"), self.dev.get("pose")
-            return self.dev.logs()
+            self._last_logs = self.dev.logs() if self.dev.log_capacity else None
+            return self._last_logs
         for _ in range(n_steps):
             self.step()
-        return {k: np.array(v) for k, v in self.log.items()}          # arrays are (steps[+1], B, dim)
+        self._last_logs = {k: np.array(v) for k, v in self.log.items()}          # arrays are (steps[+1], B, dim)
+        return self._last_logs
+
+    def save(self, path, instance=None, T=None, drop_last_step=True):
+        """Write the loop's logs as the reference's Logger.save_logs does (Utils/Logging_Plotting.py:321-372: np.savez with the keys
+        LOG_KEYS, yaw wrapped, derived deviation channels). instance = b: one file `path` for vehicle b -- what Papers_Plots and the
+        RL / BO tooling read; instance = None: one file per vehicle, `path` formatted with the vehicle index ('logs/{}.npz' ->
+        logs/0.npz, ... -- the layout of Learning_To_Adapt/SafeRL_WMPC/_baseline/F/<track>/<k>.npz). drop_last_step: as Logger.truncate
+        does (log_file_arrays). Returns the paths written."""
+        logs = self._last_logs
+        if logs is None:
+            raise Exception("ClosedLoopBatch.save: no logs (run() first; a device loop needs log_capacity > 0)")
+        out = []
+        for b in (range(self.B) if instance is None else [int(instance)]):
+            f = path.format(b) if instance is None else path
+            np.savez(f, **log_file_arrays(logs, b, self.w_deriv, self.e_est, T=T, Ts=self.Ts, drop_last_step=drop_last_step))
+            out.append(f)
+        return out

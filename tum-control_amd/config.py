@@ -24,8 +24,14 @@ MPC = dict(q_lon=2.8, q_lat=2.8, q_yaw=0.4, q_vel=0.2, r_jerk=38.1, r_steering_r
            L1_pen=106.7, L2_pen=9.9, combined_acc_limits=2,
            stds=[0.0, 0.0, 0.0, 0.8, 0.35, 0.035, 0.0, 0.0], uncertainty_propagation_horizon=5,
            n_samples=10, gamma=0.8, expansion_degree=2)
-SIM = dict(Ts=0.02, Tp=3.04, Ts_MPC=0.08,
-           w_state_estimation=[0.15, 0.15, 0.01, 0.8, 0.35, 0.05, 0.005, 0.0])
+SIM = dict(Ts=0.02, Tp=3.04, Ts_MPC=0.08, T=100.0,
+           w_state_estimation=[0.15, 0.15, 0.01, 0.8, 0.35, 0.05, 0.005, 0.0],
+           # Config/EDGAR/sim_main_params.yaml:44-80: the disturbance simulation of the closed-loop harness (both switched off in the
+           # shipped file; magnitudes and distribution types as shipped)
+           simulate_state_estimation=False, disturbance_type_state_estimation="gaussian",
+           w_posx=0.15, w_posy=0.15, w_yaw=0.01, w_vlong=0.8, w_vlat=0.35, w_yawrate=0.05, w_delta_f=0.005,
+           simulate_disturbances=False, disturbance_type_derivatives="uniform",
+           w_posx_dot=0.8, w_posy_dot=0.8, w_yaw_dot=0.1, w_vlong_dot=1.1, w_vlat_dot=0.1, w_yawrate_dot=0.05, w_delta_f_dot=0.1)
 
 
 def default_config():

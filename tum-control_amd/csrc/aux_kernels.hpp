@@ -148,4 +148,17 @@ __global__ void stage_in_kernel(const double *hin, double *x0, int nx0, double *
     if (have_yref) for (int k = i; k < nyr; k += nth) yref[k] = hin[nx0 + k];
 }
 
+// The pinned shadow of a small capsule's per-step setters (tum_ocp_set "yref" per stage, constraints_set lbx_0 / ubx_0) into the device
+// arrays, in front of the next solve: x0 when it was set, and the yref records of the stages in `mask` (bit k = stage k, `nst` stages per
+// instance) -- what no setter touched keeps its device value (a device-to-device upload may have written it). ts[0]: the device clock at
+// the start of a synchronous solve.
+__global__ void stage_in_masked_kernel(const double *hin, double *x0, int nx0, double *yref, int nyr, int nst, int have_x0, unsigned long long mask,
+                                       unsigned long long *ts)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x, nth = gridDim.x * blockDim.x;
+    if (ts && i == 0) ts[0] = wall_clock64();
+    if (have_x0) for (int k = i; k < nx0; k += nth) x0[k] = hin[k];
+    if (mask) for (int k = i; k < nyr; k += nth) if ((mask >> ((k / 6) % nst)) & 1ull) yref[k] = hin[nx0 + k];
+}
+
 }  // namespace tum

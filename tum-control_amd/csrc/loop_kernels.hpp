@@ -206,6 +206,9 @@ struct SimArgs {
     double *bnd; int r2; double r2_dmin, r2_dmax, r2_uh;
     double *x_sim, *x0, *pose, *hist;                 // [b][7], [b][8] (capsule x0), [b][2], [b][8][4]
     const double *ref0;                               // [b][4] first reference point of this step (planner output)
+    // disturbance realisation played back by the loop (Utils/SimulationMode_main_class.py:121-143; nullable): additive disturbance of
+    // the state DERIVATIVES, constant over a control step, and additive STATE ESTIMATION error, [step][b][7] each, dist_len steps
+    const double *dist_w, *dist_e; int dist_len;
     double *lCiLX, *lSimX, *lU, *lREF, *lDBG;         // logs (nullable): (cap+1,B,7) (cap+1,B,8) (cap,B,2) (cap,B,4) (cap,B,5)
 };
 
@@ -255,10 +258,21 @@ __global__ void __launch_bounds__(64) plant_advance_kernel(const SimArgs sa)
             for (int k = 1 + role; k < N; k += PLANT_LANES) { bb[2 * (N + 1) + k] = sa.r2_dmin; bb[3 * (N + 1) + k] = sa.r2_dmax; bb[5 * (N + 1) + k] = sa.r2_uh; }
         }
     }
-    double x[7];
+    double x[7], xd[7], xs[7], wv[7];
 #pragma unroll
-    for (int i = 0; i < 7; i++) x[i] = sa.x_sim[(size_t)b * 7 + i];
+    for (int i = 0; i < 7; i++) { xs[i] = sa.x_sim[(size_t)b * 7 + i]; wv[i] = 0.0; x[i] = xs[i]; }
     const double h = sa.Ts / sa.n_elem;
+    // sim_step (SimulationMode_main_class.py:112-143): the plant's TRUE next state is the undisturbed step (it is what the logger
+    // keeps as CiLX and what the next step starts from); with a disturbance of the state derivatives a SECOND step from the same
+    // state, xdot + w (sim_model_dynamic_stm_pacejka.py:196), gives the state the estimator is fed, and the state estimation error is
+    // added to that. Both passes share one copy of the integrator (pass loop not unrolled, see below).
+    const bool have_w = sa.dist_w && step < sa.dist_len, have_e = sa.dist_e && step < sa.dist_len;
+#pragma unroll 1
+    for (int pass = 0; pass < (have_w ? 2 : 1); pass++) {
+        if (pass == 1) {
+#pragma unroll
+            for (int i = 0; i < 7; i++) { xd[i] = x[i]; x[i] = xs[i]; wv[i] = sa.dist_w[((size_t)step * B + b) * 7 + i]; }
+        }
     for (int e = 0; e < sa.n_elem; e++) {
         // The four RK stages share ONE inlined copy of the model (stage loop not unrolled): this kernel runs its code
         // once per control step, so its time is instruction fetch -- four inlined copies (63 KB) cost 107 us per call,
@@ -274,11 +288,28 @@ __global__ void __launch_bounds__(64) plant_advance_kernel(const SimArgs sa)
 #pragma unroll
             for (int i = 0; i < 7; i++) t[i] = (st == 0) ? x[i] : x[i] + ci * h * kprev[i];
             plant_xdot(sa.pm, tl, t, a_in, sr_in, k);
+            if (pass == 1) {
+#pragma unroll
+                for (int i = 0; i < 7; i++) k[i] = k[i] + wv[i];
+            }
 #pragma unroll
             for (int i = 0; i < 7; i++) { acc[i] = (st == 0) ? k[i] : acc[i] + wi * k[i]; kprev[i] = k[i]; }
         }
 #pragma unroll
         for (int i = 0; i < 7; i++) x[i] = x[i] + h / 6.0 * acc[i];
+    }
+    }
+    // x: what the estimator sees (disturbed), xd: the true state
+    if (have_w) {
+#pragma unroll
+        for (int i = 0; i < 7; i++) { const double tmp = x[i]; x[i] = xd[i]; xd[i] = tmp; }
+    } else {
+#pragma unroll
+        for (int i = 0; i < 7; i++) xd[i] = x[i];
+    }
+    if (have_e) {
+#pragma unroll
+        for (int i = 0; i < 7; i++) xd[i] = xd[i] + sa.dist_e[((size_t)step * B + b) * 7 + i];
     }
     if (live) {
         if (role == 0) {
@@ -293,7 +324,7 @@ __global__ void __launch_bounds__(64) plant_advance_kernel(const SimArgs sa)
             const int i = role + 4 * j;
             double v = a_in;
 #pragma unroll
-            for (int q = 0; q < 7; q++) v = (i == q) ? x[q] : v;
+            for (int q = 0; q < 7; q++) v = (i == q) ? xd[q] : v;
             double *hst = sa.hist + ((size_t)b * 8 + i) * 4;
             hst[(k - 1) & 3] = v;
             const int wn = (role == 0) ? sa.win[4 * j] : (role == 1) ? sa.win[4 * j + 1] : (role == 2) ? sa.win[4 * j + 2] : sa.win[4 * j + 3];

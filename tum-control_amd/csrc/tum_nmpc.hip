@@ -70,7 +70,16 @@ struct tum_ocp {
     double *dsum, *hsum[2], *hX[2], *hU[2]; hipEvent_t evres[2]; bool res_iter[2]; int res_head, res_count;
     double *hin[2];                    // pinned staging of x0 | yref of a step (tum_ocp_step_async), one per result slot
     unsigned long long *hts[2];        // device wall clock at the start / end of a step timed without events (pinned, one pair per result slot)
-    int ts_slot; double ts_khz;        // slot whose clock pair times the LAST solve (-1: the events ev0 / ev1 do)
+    int ts_slot; double ts_khz;        // slot whose clock pair times the LAST solve (-1: the events ev0 / ev1 do; 2: the synchronous slot below)
+    // The reference's LITERAL call pattern on a small capsule (NMPC_class.py:169-206: N+1 x set yref, solve, 1 + N x get, get_cost,
+    // 3 x get_stats -- every one a synchronous call): the per-step setters land in a pinned shadow of x0 | yref with a dirty map and go
+    // up in ONE kernel in front of the next solve; a synchronous solve ends with ONE kernel that writes summary, X and U into pinned
+    // slabs, and the getters that follow are served from those slabs until something changes the iterate. 83 calls of ~21 us each
+    // (a stream synchronisation per call) become one solve and 82 host copies.
+    double *hin_s; unsigned long long in_mask; bool in_x0, in_inflight; hipEvent_t ev_in;      // shadow of x0 | yref, dirty stages, upload in flight
+    double *hsum_s, *hX_s, *hU_s; unsigned long long *hts_s; bool cache_valid;                 // results of the last synchronous solve
+    double *hXS_s; bool xs_cached;                                                             // ... and the sample copies of an SNMPC capsule, read back on first use
+    bool time_ipm;                     // keep the events around the interior point kernel also where the library leaves them out (tum_ocp_set_kernel "time-ipm")
 };
 
 static const int DBG_STRIDE = 20480;
@@ -133,6 +142,8 @@ extern "C" tum_ocp *tum_ocp_create(const tum_ocp_desc *desc)
     c->r2 = false; c->dr2S = c->dr2B = nullptr;
     c->p_dirty = false; c->uph_cap = 0; c->gamma = 0.0; c->dpceA = nullptr; c->pce_L = c->pce_S = 0; c->dbnd_snap = nullptr;
     c->dsum = nullptr; c->res_head = c->res_count = 0;
+    c->hin_s = c->hsum_s = c->hX_s = c->hU_s = nullptr; c->hts_s = nullptr; c->in_mask = 0; c->in_x0 = c->in_inflight = false; c->ev_in = nullptr;
+    c->cache_valid = false; c->time_ipm = false; c->hXS_s = nullptr; c->xs_cached = false;
     for (int i = 0; i < 2; i++) { c->hsum[i] = c->hX[i] = c->hU[i] = c->hin[i] = nullptr; c->hts[i] = nullptr; c->evres[i] = nullptr; c->res_iter[i] = false; }
     const int N = c->N; const size_t B = c->batch;
     bool ok = true;
@@ -239,6 +250,13 @@ extern "C" void tum_ocp_free(tum_ocp *c)
     (void)hipFree(c->dXS); (void)hipFree(c->dxs0); (void)hipFree(c->dApce); (void)hipFree(c->dws2); (void)hipFree(c->dpro); (void)hipFree(c->ddv); (void)hipFree(c->doffs); (void)hipFree(c->dxs_dirty);
     (void)hipFree(c->dr2S); (void)hipFree(c->dr2B); (void)hipFree(c->dpceA); (void)hipFree(c->dbnd_snap);
     (void)hipFree(c->dsum);
+    if (c->hin_s) (void)hipHostFree(c->hin_s);
+    if (c->hsum_s) (void)hipHostFree(c->hsum_s);
+    if (c->hX_s) (void)hipHostFree(c->hX_s);
+    if (c->hU_s) (void)hipHostFree(c->hU_s);
+    if (c->hts_s) (void)hipHostFree(c->hts_s);
+    if (c->hXS_s) (void)hipHostFree(c->hXS_s);
+    if (c->ev_in) (void)hipEventDestroy(c->ev_in);
     for (int i = 0; i < 2; i++) {
         if (c->hsum[i]) (void)hipHostFree(c->hsum[i]);
         if (c->hin[i]) (void)hipHostFree(c->hin[i]);
@@ -368,6 +386,21 @@ static int sn_materialise(tum_ocp *c)
     return 0;
 }
 
+// the stacked state behind a synchronous solve of a small SNMPC capsule: the reference reads get(j, "x")[0:8] on every stage
+// (SNMPC_class.py:205-209) -- the sample copies of all stages come back in ONE copy on the first such read
+static int sn_cache_samples(tum_ocp *c)
+{
+    if (!c->sn || !c->cache_valid || c->xs_cached) return 0;
+    if (sn_materialise(c)) return 1;
+    DevGuard guard(c->d.device); GUARD_OK(guard);
+    const size_t n = (size_t)c->batch * (c->N + 1) * c->sa.ns * NX;
+    if (!c->hXS_s) HIPCHK(hipHostMalloc((void **)&c->hXS_s, sizeof(double) * n, hipHostMallocDefault));
+    HIPCHK(hipMemcpyAsync(c->hXS_s, c->dXS, sizeof(double) * n, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    c->xs_cached = true;
+    return 0;
+}
+
 // resolve the per-stage parameters into (uph, kappa) before a solve
 static int sn_apply_p(tum_ocp *c)
 {
@@ -438,11 +471,66 @@ static int chk_range(tum_ocp *c, int b0, int nb)
     return 0;
 }
 
+// the summary (and, for small batches, the iterate) is written by the packing kernel STRAIGHT into the pinned slab; TUM_RESULTS_ZERO_COPY=0
+// (development aid) goes through a device slab and copy commands instead
+static bool results_zero_copy()
+{
+    static const bool zc = [] { const char *e = getenv("TUM_RESULTS_ZERO_COPY"); return !(e && e[0] == '0'); }();
+    return zc;
+}
+// does a results request of this capsule run as ONE kernel that writes summary, X and U into the pinned slabs (pack_results_kernel:
+// the kernel that also reads the device clock at the end of a clocked step, tum_ocp_step_async)
+static bool results_pack_all(const tum_ocp *c, int with_iterate)
+{
+    return results_zero_copy() && with_iterate && (size_t)c->batch * (size_t)(c->N + 1) * NX <= 32768;
+}
+
+// ---- the pinned shadow of the per-step inputs (x0 | yref) of a SMALL capsule
+static bool small_inputs(const tum_ocp *c) { return (size_t)c->batch * (NX + (size_t)(c->N + 1) * 6) <= 32768 && c->N + 1 <= 64; }
+static int shadow_ready(tum_ocp *c)
+{
+    if (!c->hin_s) {
+        HIPCHK(hipHostMalloc((void **)&c->hin_s, sizeof(double) * (size_t)c->batch * (NX + (size_t)(c->N + 1) * 6), hipHostMallocDefault));
+        HIPCHK(hipEventCreateWithFlags(&c->ev_in, hipEventDisableTiming));
+    }
+    // the upload kernel of an asynchronous solve may still be reading the shadow
+    if (c->in_inflight) { HIPCHK(hipEventSynchronize(c->ev_in)); c->in_inflight = false; }
+    return 0;
+}
+// host records (batch x len, `stride` apart; 0 = one record for all) into the shadow: x0 (stage < 0) or the yref record of a stage
+static int shadow_write(tum_ocp *c, int stage, const double *v, int len, int stride)
+{
+    DevGuard guard(c->d.device); GUARD_OK(guard);
+    if (shadow_ready(c)) return 1;
+    const size_t B = c->batch, rec = (size_t)(c->N + 1) * 6;
+    for (size_t b = 0; b < B; b++) {
+        const double *src = v + b * (size_t)stride;
+        double *dst = (stage < 0) ? c->hin_s + b * NX : c->hin_s + B * NX + b * rec + (size_t)stage * 6;
+        memcpy(dst, src, sizeof(double) * len);
+    }
+    if (stage < 0) c->in_x0 = true; else c->in_mask |= 1ull << stage;
+    return 0;
+}
+// pending setters -> device, one kernel on the capsule's stream (ts: the device clock at its start goes to ts[0])
+static int flush_inputs(tum_ocp *c, unsigned long long *ts = nullptr, bool force = false)
+{
+    if (!c->in_x0 && !c->in_mask && !force) return 0;
+    const size_t B = c->batch;
+    hipLaunchKernelGGL(stage_in_masked_kernel, dim3(4), dim3(256), 0, c->stream, c->hin_s, c->dx0, (int)(B * NX), c->dyref, (int)(B * (c->N + 1) * 6),
+                       c->N + 1, c->in_x0 ? 1 : 0, c->in_mask, ts);
+    HIPCHK(hipGetLastError());
+    if (c->in_x0 || c->in_mask) { HIPCHK(hipEventRecord(c->ev_in, c->stream)); c->in_inflight = true; }
+    c->in_x0 = false; c->in_mask = 0;
+    return 0;
+}
+
 // strided scatter: host records (nb x len, `stride` apart; stride 0 = broadcast) -> device rows
 static int put(tum_ocp *c, double *dbase, size_t rec, size_t off, const double *v, int len, int b0, int nb, int stride)
 {
     if (stride != 0 && stride < len) return fail("stride < len");
     DevGuard guard(c->d.device); GUARD_OK(guard);
+    if ((dbase == c->dx0 || dbase == c->dyref) && flush_inputs(c)) return 1;          // (older setters still in the shadow go first)
+    if (dbase == c->dX || dbase == c->dU) c->cache_valid = false;
     const double *src = v;
     size_t spitch = (size_t)stride * sizeof(double);
     if (stride == 0) {
@@ -496,6 +584,8 @@ extern "C" int tum_ocp_set(tum_ocp *c, int stage, const char *field, const doubl
         if (stage < 0 || stage > N) return fail("set yref: stage out of range");
         const int want = (stage < N) ? TUM_NY : TUM_NYE;
         if (len != want) return fail("set yref: mismatching dimension for this stage");
+        // the reference sets one stage per call, N + 1 calls per control step (NMPC_class.py:169-180): into the shadow, up with the solve
+        if (b0 == 0 && nb == c->batch && small_inputs(c) && (stride == 0 || stride >= len)) return shadow_write(c, stage, v, len, stride);
         return put(c, c->dyref, (N + 1) * 6, (size_t)stage * 6, v, len, b0, nb, stride);
     }
     if (f == "p") {
@@ -511,21 +601,46 @@ extern "C" int tum_ocp_get(tum_ocp *c, int stage, const char *field, double *v, 
     if (!field || !v) return fail("null argument");
     const int N = c->N;
     const std::string f(field);
+    // after a synchronous solve of a small capsule the iterate is in the capsule's pinned slabs (tum_ocp_solve): the N + 1 getters the
+    // reference issues per control step (NMPC_class.py:193-198) are host copies
+    auto cached = [&](const double *slab, size_t rec, size_t off) {
+        if (stride < len) return fail("stride < len");
+        for (int i = 0; i < nb; i++) memcpy(v + (size_t)i * stride, slab + (size_t)(b0 + i) * rec + off, sizeof(double) * len);
+        return 0;
+    };
     if (f == "x") {
-        if (stage == TUM_ALL_STAGES) { if (len != (N + 1) * NX) return fail("get x: len"); return fetch(c, c->dX, (N + 1) * NX, 0, v, len, b0, nb, stride); }
+        if (stage == TUM_ALL_STAGES) {
+            if (len != (N + 1) * NX) return fail("get x: len");
+            if (c->cache_valid) return cached(c->hX_s, (size_t)(N + 1) * NX, 0);
+            return fetch(c, c->dX, (N + 1) * NX, 0, v, len, b0, nb, stride);
+        }
         if (c->sn && stage >= 0 && stage <= N && len == NX * (c->sa.ns + 1)) {
             const int ns = c->sa.ns;
             if (stride < len) return fail("stride < len");
+            if (sn_cache_samples(c)) return 1;
+            if (c->cache_valid && c->hXS_s) {          // the stacked state of every stage, read back ONCE after the solve
+                for (int i = 0; i < nb; i++) {
+                    memcpy(v + (size_t)i * stride, c->hX_s + ((size_t)(b0 + i) * (N + 1) + stage) * NX, sizeof(double) * NX);
+                    memcpy(v + (size_t)i * stride + NX, c->hXS_s + ((size_t)(b0 + i) * (N + 1) + stage) * ns * NX, sizeof(double) * ns * NX);
+                }
+                return 0;
+            }
             if (stage > c->sa.uph && sn_materialise(c)) return 1;
             if (fetch(c, c->dX, (N + 1) * NX, (size_t)stage * NX, v, NX, b0, nb, stride)) return 1;
             return fetch(c, c->dXS, (size_t)(N + 1) * ns * NX, (size_t)stage * ns * NX, v + NX, ns * NX, b0, nb, stride);
         }
         if (stage < 0 || stage > N || len != NX) return fail("get x: bad stage/len");
+        if (c->cache_valid) return cached(c->hX_s, (size_t)(N + 1) * NX, (size_t)stage * NX);
         return fetch(c, c->dX, (N + 1) * NX, (size_t)stage * NX, v, len, b0, nb, stride);
     }
     if (f == "u") {
-        if (stage == TUM_ALL_STAGES) { if (len != N * NU) return fail("get u: len"); return fetch(c, c->dU, N * NU, 0, v, len, b0, nb, stride); }
+        if (stage == TUM_ALL_STAGES) {
+            if (len != N * NU) return fail("get u: len");
+            if (c->cache_valid) return cached(c->hU_s, (size_t)N * NU, 0);
+            return fetch(c, c->dU, N * NU, 0, v, len, b0, nb, stride);
+        }
         if (stage < 0 || stage >= N || len != NU) return fail("get u: bad stage/len");
+        if (c->cache_valid) return cached(c->hU_s, (size_t)N * NU, (size_t)stage * NU);
         return fetch(c, c->dU, N * NU, (size_t)stage * NU, v, len, b0, nb, stride);
     }
     if (f == "sl" || f == "su") {
@@ -566,6 +681,8 @@ extern "C" int tum_ocp_constraints_set(tum_ocp *c, int stage, const char *field,
                 if (!c->have_offs) return fail("constraints_set lbx/ubx at stage 0: an SNMPC capsule takes 8 (n_samples+1) values, or 8 after tum_ocp_snmpc_set_offsets");
                 c->fanout = true;
             }
+            // (set twice per control step, lbx and ubx: NMPC_class.py:243-246)
+            if (b0 == 0 && nb == c->batch && small_inputs(c) && (stride == 0 || stride >= len)) return shadow_write(c, -1, v, len, stride);
             return put(c, c->dx0, NX, 0, v, len, b0, nb, stride);
         }
         if (len != 1) return fail("constraints_set lbx/ubx: expected 1 value (steering angle)");
@@ -655,6 +772,8 @@ extern "C" int tum_ocp_set_kernel(tum_ocp *c, const char *name)
 {
     if (!c || !name) return fail("null argument");
     const std::string n(name);
+    if (n == "time-ipm") { c->time_ipm = true; return 0; }            // (timing options, not kernels: the events around the interior point kernel on EVERY solve)
+    if (n == "no-time-ipm") { c->time_ipm = false; return 0; }
     if (n == "auto") { c->kmode = 0; c->lin_cols = -1; c->cond_wide = -1; c->sim_fork = -1; }        // (the wide kernels of the latency path: the library decides by batch size again)
     else if (n == "pipeline") c->kmode = 2;
     // the prologue of the coupled SNMPC OCP: the matrix-core kernel (default where n_samples <= 10) or the column-slot / pass variants
@@ -799,7 +918,7 @@ static int launch_pipeline(tum_ocp *c, bool events)
             else if (c->sn) hipLaunchKernelGGL((cond_kernel<NTv, true>), dim3(c->batch), dim3(64), 0, c->stream, pa);
             else hipLaunchKernelGGL((cond_kernel<NTv, false>), dim3(c->batch), dim3(64), 0, c->stream, pa);
         }
-        if (events && !c->skip_ipm_events) (void)hipEventRecord(c->evi0, c->stream);
+        if ((events && !c->skip_ipm_events) || c->time_ipm) (void)hipEventRecord(c->evi0, c->stream);
         bool expanded = false;
 #ifdef TUM_DEV_KERNELS
         if (prof && c->kmode == 3 && NTv == 5) hipLaunchKernelGGL((ipm4_kernel<true>), dim3(c->batch), dim3(256), I4::BYTES, c->stream, pa);
@@ -816,7 +935,7 @@ static int launch_pipeline(tum_ocp *c, bool events)
             if (c->sn || no_fuse) hipLaunchKernelGGL((ipm_kernel<false, NTv>), dim3(c->batch), dim3(64), ipm_lds, c->stream, pa);
             else { hipLaunchKernelGGL((ipm_kernel<false, NTv, true>), dim3(c->batch), dim3(64), ipm_lds, c->stream, pa); expanded = true; }
         }
-        if (events && !c->skip_ipm_events) (void)hipEventRecord(c->evi1, c->stream);
+        if ((events && !c->skip_ipm_events) || c->time_ipm) (void)hipEventRecord(c->evi1, c->stream);
         if (c->sn) {
             // the epilogue steps the sample copies AND the nominal copy of the stages 1..uph (their PCE mean); the expansion
             // kernel behind it takes the nominal recursion from stage uph to the end of the horizon and evaluates the cost
@@ -835,6 +954,8 @@ static int launch(tum_ocp *c, bool events = true)
 {
     DevGuard guard(c->d.device); GUARD_OK(guard);
     if (resolve_kernel(c)) return 1;
+    c->cache_valid = false; c->xs_cached = false;
+    if (flush_inputs(c)) return 1;          // setters still in the pinned shadow (small capsules)
     if (events) HIPCHK(hipEventRecord(c->ev0, c->stream));
     // longest-first schedule from the previous solve's iteration counts (only matters when the batch is more than one
     // round of resident wavefronts)
@@ -873,7 +994,7 @@ static int launch(tum_ocp *c, bool events = true)
     }
     c->solved = true;
     c->solved_pipe = c->pipe;
-    c->ipm_timed = events && !c->skip_ipm_events;
+    c->ipm_timed = (events && !c->skip_ipm_events) || c->time_ipm;
     c->ts_slot = -1;          // (tum_ocp_step_async sets it behind this call)
     return 0;
 }
@@ -904,6 +1025,29 @@ extern "C" int tum_ocp_solve(tum_ocp *c)
 {
     if (!c) { fail("null capsule"); return -1; }
     DevGuard guard(c->d.device); if (!guard.ok) { fail("hipSetDevice failed"); return -1; }
+    if (small_inputs(c) && results_pack_all(c, 1)) {
+        // small capsule: [pending setters up + device clock] -> solve -> [summary, X, U into pinned slabs + device clock], ONE wait. No
+        // event and no copy command on the stream; the getters that follow read the slabs (cache_valid).
+        const size_t B = c->batch; const int N = c->N;
+        auto hm = [&](auto **pp, size_t bytes) { return *pp || hipHostMalloc((void **)pp, bytes, hipHostMallocDefault) == hipSuccess; };
+        if (shadow_ready(c)) return -1;
+        if (!hm(&c->hsum_s, sizeof(double) * B * 5) || !hm(&c->hX_s, sizeof(double) * B * (N + 1) * NX) || !hm(&c->hU_s, sizeof(double) * B * N * NU) ||
+            !hm(&c->hts_s, 2 * sizeof(unsigned long long))) { fail("solve: pinned allocation failed"); return -1; }
+        if (c->ts_khz == 0.0) { int khz = 0; if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, c->d.device) != hipSuccess) khz = 0; c->ts_khz = khz > 0 ? (double)khz : 1e5; }
+        if (flush_inputs(c, c->hts_s, true)) return -1;
+        c->skip_ipm_events = true;
+        const int rc = launch(c, false);
+        c->skip_ipm_events = false;
+        if (rc) return -1;
+        hipLaunchKernelGGL(pack_results_kernel, dim3(8), dim3(256), 0, c->stream, c->dX, c->dU, c->dcost, c->dstatus, c->dqpiter, N, (int)B,
+                           c->hsum_s, c->hX_s, c->hU_s, c->hts_s);
+        if (hipGetLastError() != hipSuccess || hipStreamSynchronize(c->stream) != hipSuccess) { fail("kernel execution failed"); return -1; }
+        c->in_inflight = false;
+        c->ts_slot = 2; c->cache_valid = true; c->xs_cached = false;
+        int mx = 0;
+        for (size_t b = 0; b < B; b++) { const int st = (int)c->hsum_s[b * 5 + 3]; if (st > mx) mx = st; }
+        return mx;
+    }
     if (launch(c)) return -1;
     if (hipStreamSynchronize(c->stream) != hipSuccess) { fail("kernel execution failed"); return -1; }
     std::vector<int> st(c->batch);
@@ -917,6 +1061,10 @@ extern "C" double tum_ocp_last_kernel_ms(tum_ocp *c)
 {
     if (!c || !c->solved) return 0.0;
     DevGuard guard(c->d.device); if (!guard.ok) return 0.0;
+    if (c->ts_slot == 2) {      // the synchronous solve of a small capsule: clocked by its first and last kernel, already waited for
+        c->last_ms = (float)((double)(c->hts_s[1] - c->hts_s[0]) / c->ts_khz);
+        return c->last_ms;
+    }
     if (c->ts_slot >= 0) {      // a step timed by the device's wall clock (tum_ocp_step_async): valid once its results have been waited for
         const int w = c->ts_slot;
         if (c->evres[w] && hipEventSynchronize(c->evres[w]) != hipSuccess) return 0.0;
@@ -934,6 +1082,7 @@ extern "C" double tum_ocp_last_kernel_ms(tum_ocp *c)
 extern "C" int tum_ocp_get_cost(tum_ocp *c, double *out, int b0, int nb)
 {
     if (chk_range(c, b0, nb)) return 1;
+    if (c->cache_valid) { for (int i = 0; i < nb; i++) out[i] = c->hsum_s[(size_t)(b0 + i) * 5 + 2]; return 0; }
     DevGuard guard(c->d.device); GUARD_OK(guard);
     HIPCHK(hipStreamSynchronize(c->stream));        // (the copy below runs on the NULL stream, which the capsule's non-blocking stream is not ordered with)
     HIPCHK(hipMemcpy(out, c->dcost + b0, sizeof(double) * nb, hipMemcpyDeviceToHost));
@@ -946,16 +1095,23 @@ extern "C" int tum_ocp_get_stats(tum_ocp *c, const char *field, void *out, int b
     const std::string f(field);
     if (f == "time_tot") { *(double *)out = tum_ocp_last_kernel_ms(c) * 1e-3; return 0; }
     if (f == "time_ipm") {    // pipeline only: device seconds of the interior point kernel of the last solve
-        if (!c->solved || !c->solved_pipe || !c->ipm_timed) return fail("get_stats time_ipm: pipeline kernel only, after a solve() / solve_async() (a step leaves these events out)");
+        if (!c->solved || !c->solved_pipe || !c->ipm_timed)
+            return fail("get_stats time_ipm: pipeline kernel only, after a solve() / solve_async() (a step, and the synchronous solve of a small capsule, leave these "
+                        "events out unless tum_ocp_set_kernel(c, \"time-ipm\") asked for them)");
         DevGuard guard(c->d.device); GUARD_OK(guard);
         float ms = 0;
         if (hipEventSynchronize(c->evi1) != hipSuccess || hipEventElapsedTime(&ms, c->evi0, c->evi1) != hipSuccess) return fail("get_stats time_ipm: no timing");
         *(double *)out = ms * 1e-3; return 0;
     }
     if (chk_range(c, b0, nb)) return 1;
+    if (f == "sqp_iter") { int *o = (int *)out; for (int i = 0; i < nb; i++) o[i] = 1; return 0; }
+    if (c->cache_valid && (f == "qp_iter" || f == "status")) {
+        int *o = (int *)out; const int col = (f == "status") ? 3 : 4;
+        for (int i = 0; i < nb; i++) o[i] = (int)c->hsum_s[(size_t)(b0 + i) * 5 + col];
+        return 0;
+    }
     DevGuard guard(c->d.device); GUARD_OK(guard);
     HIPCHK(hipStreamSynchronize(c->stream));        // (after tum_ocp_solve_async: the copies below are on the NULL stream)
-    if (f == "sqp_iter") { int *o = (int *)out; for (int i = 0; i < nb; i++) o[i] = 1; return 0; }
     if (f == "qp_iter") { HIPCHK(hipMemcpy(out, c->dqpiter + b0, sizeof(int) * nb, hipMemcpyDeviceToHost)); return 0; }
     if (f == "status") { HIPCHK(hipMemcpy(out, c->dstatus + b0, sizeof(int) * nb, hipMemcpyDeviceToHost)); return 0; }
     if (f == "qp_status") { HIPCHK(hipMemcpy(out, c->dqpstatus + b0, sizeof(int) * nb, hipMemcpyDeviceToHost)); return 0; }
@@ -967,6 +1123,7 @@ extern "C" int tum_ocp_reset(tum_ocp *c)
 {
     if (!c) return fail("null capsule");
     DevGuard guard(c->d.device); GUARD_OK(guard);
+    c->cache_valid = false;
     HIPCHK(hipMemsetAsync(c->dX, 0, sizeof(double) * (size_t)c->batch * (c->N + 1) * NX, c->stream));
     HIPCHK(hipMemsetAsync(c->dU, 0, sizeof(double) * (size_t)c->batch * c->N * NU, c->stream));
     if (c->sn) HIPCHK(hipMemsetAsync(c->dXS, 0, sizeof(double) * (size_t)c->batch * (c->N + 1) * c->sa.ns * NX, c->stream));
@@ -979,6 +1136,8 @@ extern "C" int tum_ocp_cold_start(tum_ocp *c)
 {
     if (!c) return fail("null capsule");
     DevGuard guard(c->d.device); GUARD_OK(guard);
+    c->cache_valid = false;
+    if (flush_inputs(c)) return 1;          // (the x0 it copies may still be in the pinned shadow)
     hipLaunchKernelGGL(cold_start_kernel, dim3(c->batch), dim3(64), 0, c->stream, c->dX, c->dU, c->dx0, c->N, c->batch);
     if (c->sn && c->fanout && sn_fanout(c)) return 1;
     if (c->sn) hipLaunchKernelGGL(snmpc_cold_start_kernel, dim3(c->batch), dim3(256), 0, c->stream, c->dXS, c->dxs0, c->N, c->sa.ns, c->batch);
@@ -1064,10 +1223,10 @@ extern "C" int tum_ocp_get_device(tum_ocp *c, const char *field, void *dst, int 
 
 // Results on the host behind an event instead of a stream synchronisation (include/tum_nmpc.h). The slabs are allocated on first
 // use: pinned memory is a scarce host resource and most capsules (closed loops on the device, the RCCL gather) never ask.
-extern "C" int tum_ocp_results_async(tum_ocp *c, int with_iterate)
+// from_step: the request closes a tum_ocp_step_async whose clock pair hts[w] the packing kernel completes; a plain request never
+// touches a clock pair (it would change the time_tot of the last step after the fact)
+static int results_enqueue(tum_ocp *c, int with_iterate, bool from_step)
 {
-    if (!c) return fail("null capsule");
-    DevGuard guard(c->d.device); GUARD_OK(guard);
     const size_t B = c->batch; const int N = c->N;
     // Two sets of slabs / events used in turn: a caller keeps one request outstanding per capsule while it enqueues the next batch
     // and its request, and only then reads the older one -- the stream never runs dry between two batches waiting for the host.
@@ -1086,13 +1245,13 @@ extern "C" int tum_ocp_results_async(tum_ocp *c, int with_iterate)
     hipStream_t s = c->stream;
     // the summary (40 B per instance) is written by the packing kernel STRAIGHT into the pinned slab (host memory mapped into the
     // device's address space): no copy command, no DMA engine and no signal round trip between the kernels of two batches
-    static const bool zero_copy = [] { const char *e = getenv("TUM_RESULTS_ZERO_COPY"); return !(e && e[0] == '0'); }();
+    const bool zero_copy = results_zero_copy();
     // small batches with the iterate: ONE kernel writes summary, X and U into the pinned slabs (a copy command costs 4-5 us on the
     // stream whatever its size; the two of the iterate were a tenth of a host-driven control step of one instance)
-    const bool pack_all = zero_copy && with_iterate && B * (size_t)(N + 1) * NX <= 32768;
+    const bool pack_all = results_pack_all(c, with_iterate);
     if (pack_all) {
         hipLaunchKernelGGL(pack_results_kernel, dim3(8), dim3(256), 0, s, c->dX, c->dU, c->dcost, c->dstatus, c->dqpiter, N, (int)B,
-                           c->hsum[w], c->hX[w], c->hU[w], (c->ts_slot == w) ? c->hts[w] : (unsigned long long *)nullptr);
+                           c->hsum[w], c->hX[w], c->hU[w], (from_step && c->ts_slot == w) ? c->hts[w] : (unsigned long long *)nullptr);
         HIPCHK(hipGetLastError());
     } else {
     hipLaunchKernelGGL(pack_summary_kernel, dim3((unsigned)((B + 255) / 256)), dim3(256), 0, s, c->dU, c->dcost, c->dstatus, c->dqpiter, N, 0, (int)B,
@@ -1109,6 +1268,15 @@ extern "C" int tum_ocp_results_async(tum_ocp *c, int with_iterate)
     c->res_count++;
     return 0;
 }
+
+extern "C" int tum_ocp_results_async(tum_ocp *c, int with_iterate)
+{
+    if (!c) return fail("null capsule");
+    DevGuard guard(c->d.device); GUARD_OK(guard);
+    return results_enqueue(c, with_iterate, false);
+}
+
+extern "C" int tum_ocp_results_outstanding(const tum_ocp *c) { return c ? c->res_count : -1; }
 
 extern "C" int tum_ocp_results_wait(tum_ocp *c, const double **summary, const double **X, const double **U)
 {
@@ -1129,6 +1297,7 @@ extern "C" int tum_ocp_step_async(tum_ocp *c, const double *x0, const double *yr
     if (!c) return fail("null capsule");
     DevGuard guard(c->d.device); GUARD_OK(guard);
     if (c->res_count == 2) return fail("step_async: two requests outstanding on this capsule (call tum_ocp_results_wait first)");
+    if (flush_inputs(c)) return 1;          // (setters older than this step's inputs)
     const size_t B = c->batch, nx0 = B * NX, nyr = B * (size_t)(c->N + 1) * 6;
     // the staging area of the result slot this step will use: its previous step has been waited for, so its uploads are done
     const int w = (c->res_head + c->res_count) & 1;
@@ -1141,7 +1310,8 @@ extern "C" int tum_ocp_step_async(tum_ocp *c, const double *x0, const double *yr
     // small batches with inputs and the iterate: the step is timed by the device's wall clock, read by its first and its last kernel
     // (stage_in_kernel, pack_results_kernel), instead of by events around the solve -- every event on the stream is a gap of 5 us
     const bool small_in = (x0 || yref) && nx0 + nyr <= 32768;
-    const bool clocked = small_in && with_iterate && B * (size_t)(c->N + 1) * NX <= 32768;
+    // (the packing kernel is what reads the clock at the end: the same predicate as its launch, results_pack_all)
+    const bool clocked = small_in && results_pack_all(c, with_iterate);
     if (clocked) {
         if (!c->hts[w]) HIPCHK(hipHostMalloc((void **)&c->hts[w], 2 * sizeof(unsigned long long), hipHostMallocDefault));
         if (c->ts_khz == 0.0) { int khz = 0; HIPCHK(hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, c->d.device)); c->ts_khz = khz > 0 ? (double)khz : 1e5; }
@@ -1160,9 +1330,9 @@ extern "C" int tum_ocp_step_async(tum_ocp *c, const double *x0, const double *yr
     const int rc = launch(c, !clocked);
     c->skip_ipm_events = false;
     if (rc) return 1;
-    c->ipm_timed = false;
+    c->ipm_timed = c->time_ipm;
     c->ts_slot = clocked ? w : -1;
-    const int rr = tum_ocp_results_async(c, with_iterate);
+    const int rr = results_enqueue(c, with_iterate, true);
     if (rr) c->ts_slot = -1;
     return rr;
 }
@@ -1176,6 +1346,8 @@ extern "C" int tum_ocp_put_device(tum_ocp *c, const char *field, const void *src
     const std::string f(field);
     DevGuard guard(c->d.device); GUARD_OK(guard);
     hipStream_t s = c->stream;
+    c->cache_valid = false;
+    if (flush_inputs(c)) return 1;          // (setters older than this upload)
     if (f == "x0") {
         if (c->sn) { if (!c->have_offs) return fail("put_device x0: an SNMPC capsule needs its sample offsets (tum_ocp_snmpc_set_offsets)"); c->fanout = true; }
         HIPCHK(hipMemcpyAsync(c->dx0 + (size_t)b0 * NX, src, 8 * (size_t)nb * NX, hipMemcpyDeviceToDevice, s)); return 0;
@@ -1262,6 +1434,7 @@ extern "C" int tum_ocp_set_x0_fanout(tum_ocp *c, const double *pose, const doubl
     const int S1 = S + 1;
     if (P < 1 || S < 0 || (long long)P * S1 != c->batch) return fail("set_x0_fanout: P*(S+1) must equal the batch size");
     DevGuard guard(c->d.device); GUARD_OK(guard);
+    if (flush_inputs(c)) return 1;
     DevTmp tp, to;
     HIPCHK(tp.alloc(sizeof(double) * P * NX));
     HIPCHK(to.alloc(sizeof(double) * (S > 0 ? S : 1) * NX));
@@ -1426,6 +1599,7 @@ struct tum_sim {
     unsigned graph_epoch; bool graph_fanout;          // configuration of the capsule the chunk was captured with
     double *lCiLX, *lSimX, *lU, *lREF, *lDBG;
     hipStream_t s2; hipEvent_t evF, evJ;              // side stream of the linearisation that runs beside the planner, fork / join events
+    double *ddw, *dde; int dist_len;                  // disturbance realisation played back by the loop (tum_sim_set_disturbances)
 };
 
 extern "C" int tum_planner_emulate(const double *track, int n_track, const double *pose, int P, int n_points, double Tp,
@@ -1465,6 +1639,7 @@ extern "C" void tum_sim_free(tum_sim *s)
     if (s->graph) (void)hipGraphExecDestroy(s->graph);
     if (s->s2) { (void)hipStreamSynchronize(s->s2); (void)hipStreamDestroy(s->s2); (void)hipEventDestroy(s->evF); (void)hipEventDestroy(s->evJ); }
     (void)hipFree(s->lCiLX); (void)hipFree(s->lSimX); (void)hipFree(s->lU); (void)hipFree(s->lREF); (void)hipFree(s->lDBG);
+    (void)hipFree(s->ddw); (void)hipFree(s->dde);
     delete s;
 }
 
@@ -1503,6 +1678,8 @@ extern "C" int tum_sim_set_state(tum_sim *s, const double *x_sim, const double *
     if (!s || !x_sim || !x_mpc) return fail("null argument");
     tum_ocp *c = s->c; const size_t B = c->batch;
     DevGuard guard(c->d.device); GUARD_OK(guard);
+    c->cache_valid = false;
+    if (flush_inputs(c)) return 1;
     HIPCHK(hipStreamSynchronize(c->stream));
     HIPCHK(hipMemcpy(s->dxsim, x_sim, sizeof(double) * B * 7, hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(c->dx0, x_mpc, sizeof(double) * B * 8, hipMemcpyHostToDevice));
@@ -1524,6 +1701,7 @@ extern "C" int tum_sim_plan(tum_sim *s)
     if (!s) return fail("null argument");
     tum_ocp *c = s->c;
     DevGuard guard(c->d.device); GUARD_OK(guard);
+    if (flush_inputs(c)) return 1;
     hipLaunchKernelGGL(planner_kernel, dim3(c->batch), dim3(64), 0, c->stream, s->dtrack, s->n_track, s->dpose, 2, c->N + 1, s->Tp,
                        s->loop_circuit, c->dyref, 6, s->dref0, s->dclosest, s->derr, c->batch, (int *)nullptr);
     HIPCHK(hipGetLastError());
@@ -1536,6 +1714,8 @@ extern "C" int tum_sim_advance(tum_sim *s)
     tum_ocp *c = s->c;
     if (!c->solved) return fail("sim_advance: no solve yet");
     DevGuard guard(c->d.device); GUARD_OK(guard);
+    c->cache_valid = false;          // (the plant re-initialises the iterate of an instance whose solve failed, and writes the next x0)
+    if (flush_inputs(c)) return 1;
     SimArgs sa;
     memset(&sa, 0, sizeof(sa));
     sa.N = c->N; sa.batch = c->batch; sa.n_elem = s->n_elem; sa.step_counter = s->dstep; sa.log_cap = s->log_cap; sa.Ts = s->Ts;
@@ -1553,6 +1733,7 @@ extern "C" int tum_sim_advance(tum_sim *s)
     sa.bnd = c->dbnd; sa.r2 = c->r2 ? 1 : 0; sa.r2_dmin = c->r2_dmin; sa.r2_dmax = c->r2_dmax; sa.r2_uh = c->r2_uh;
     sa.x_sim = s->dxsim; sa.x0 = c->dx0; sa.pose = s->dpose; sa.hist = s->dhist; sa.ref0 = s->dref0;
     sa.lCiLX = s->lCiLX; sa.lSimX = s->lSimX; sa.lU = s->lU; sa.lREF = s->lREF; sa.lDBG = s->lDBG;
+    sa.dist_w = s->ddw; sa.dist_e = s->dde; sa.dist_len = s->dist_len;
     hipLaunchKernelGGL(plant_advance_kernel, dim3((c->batch * PLANT_LANES + 63) / 64), dim3(64), 0, c->stream, sa);
     HIPCHK(hipGetLastError());
     s->step++;
@@ -1564,7 +1745,16 @@ extern "C" int tum_sim_advance(tum_sim *s)
 // a hipGraph and replayed; all per-step state (step counter, ring buffers, logs) lives in device memory, so the captured
 // kernel arguments never change.
 static const int GRAPH_STEPS = 25;
+static int sim_enqueue_step_body(tum_sim *s, bool events);
 static int sim_enqueue_step(tum_sim *s, bool events)
+{
+    // whatever goes wrong between the forked linearisation and the solve that consumes it (planner, join, a failed capture): the
+    // capsule must not keep the "linearisation already done" mark for a LATER solve, which would run on stale stage records
+    const int rc = sim_enqueue_step_body(s, events);
+    if (rc) s->c->lin_ahead = false;
+    return rc;
+}
+static int sim_enqueue_step_body(tum_sim *s, bool events)
 {
     tum_ocp *c = s->c;
     if (lin_ahead_ok(c)) {
@@ -1587,6 +1777,8 @@ extern "C" int tum_sim_run(tum_sim *s, int nsteps)
     if (!s || nsteps < 0) return fail("bad argument");
     tum_ocp *c = s->c;
     DevGuard guard(c->d.device); GUARD_OK(guard);
+    c->cache_valid = false;
+    if (flush_inputs(c)) return 1;            // (pending host setters go up before anything is captured)
     if (resolve_kernel(c)) return 1;          // (workspace allocation must not happen inside the capture below)
     // ... nor the reallocation / synchronisation a changed SNMPC parameter vector can trigger, nor the deferred freeze
     if (c->sn && (sn_apply_p(c) || sn_materialise(c))) return 1;
@@ -1612,7 +1804,7 @@ extern "C" int tum_sim_run(tum_sim *s, int nsteps)
             }
             if (ok && g) ok = hipGraphInstantiate(&s->graph, g, nullptr, nullptr, 0) == hipSuccess;
             if (g) (void)hipGraphDestroy(g);
-            if (!ok) { s->graph = nullptr; (void)hipGetLastError(); }  // fall back to plain launches
+            if (!ok) { s->graph = nullptr; c->lin_ahead = false; (void)hipGetLastError(); }  // fall back to plain launches
             s->graph_steps = GRAPH_STEPS;
         }
         while (s->graph && nsteps - done >= s->graph_steps) {
@@ -1634,6 +1826,26 @@ extern "C" int tum_sim_run(tum_sim *s, int nsteps)
 
 extern "C" int tum_sim_steps(const tum_sim *s) { return s ? s->step : -1; }
 
+// Disturbance realisation of the loop (Utils/SimulationMode_main_class.py:121-143 with disturbance_playback, and what
+// Utils/MPC_sim_utils.py:54-67 generate_disturbances draws otherwise -- drawn on the host, closed_loop.DisturbanceModel): w_deriv
+// (additive on the state derivatives, constant over a control step) and e_est (additive state estimation error), n_steps x batch x 7
+// each (host, step-major), either may be null. Control step i >= n_steps runs undisturbed. n_steps = 0 removes the realisation.
+extern "C" int tum_sim_set_disturbances(tum_sim *s, const double *w_deriv, const double *e_est, int n_steps)
+{
+    if (!s || n_steps < 0) return fail("bad argument");
+    tum_ocp *c = s->c;
+    DevGuard guard(c->d.device); GUARD_OK(guard);
+    HIPCHK(hipStreamSynchronize(c->stream));
+    (void)hipFree(s->ddw); (void)hipFree(s->dde); s->ddw = s->dde = nullptr; s->dist_len = 0;
+    if (s->graph) { (void)hipGraphExecDestroy(s->graph); s->graph = nullptr; }          // (the pointers are kernel arguments of a captured chunk)
+    if (n_steps == 0 || (!w_deriv && !e_est)) return 0;
+    const size_t n = (size_t)n_steps * c->batch * 7;
+    if (w_deriv) { HIPCHK(hipMalloc((void **)&s->ddw, sizeof(double) * n)); HIPCHK(hipMemcpy(s->ddw, w_deriv, sizeof(double) * n, hipMemcpyHostToDevice)); }
+    if (e_est) { HIPCHK(hipMalloc((void **)&s->dde, sizeof(double) * n)); HIPCHK(hipMemcpy(s->dde, e_est, sizeof(double) * n, hipMemcpyHostToDevice)); }
+    s->dist_len = n_steps;
+    return 0;
+}
+
 extern "C" int tum_sim_get(tum_sim *s, const char *field, double *out, long long len)
 {
     if (!s || !field || !out) return fail("null argument");
@@ -1641,6 +1853,7 @@ extern "C" int tum_sim_get(tum_sim *s, const char *field, double *out, long long
     const long long L = s->step < s->log_cap ? s->step : s->log_cap;
     const std::string f(field);
     DevGuard guard(c->d.device); GUARD_OK(guard);
+    if (flush_inputs(c)) return 1;
     HIPCHK(hipStreamSynchronize(c->stream));
     const double *src = nullptr; long long want = 0;
     if (f == "x_sim") { src = s->dxsim; want = B * 7; }

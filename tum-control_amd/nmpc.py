@@ -12,7 +12,7 @@ import types
 import numpy as np
 
 from . import config as _config
-from .solver import BatchedOcpSolver
+from .solver import ALL_STAGES, BatchedOcpSolver
 
 
 class _Sym:
@@ -83,12 +83,91 @@ def acados_settings(Tf, N, x0, Q, R, Qe, L1_pen, L2_pen, ax_max_interpolant=None
     return constraints, model, solver, ocp
 
 
-class Nonlinear_Model_Predictive_Controller:
+CALL_PATTERNS = ("step", "acados")
+
+
+def ref_rows(current_ref_traj, N):
+    """the planner's dict (Utils/MPC_sim_utils.py:137-194: pos_x, pos_y, ref_yaw, ref_v) as (N+1, 6) yref rows [x, y, yaw, v, 0, 0]"""
+    y = np.zeros((N + 1, 6))
+    for col, key in enumerate(("pos_x", "pos_y", "ref_yaw", "ref_v")):
+        y[:, col] = np.asarray(current_ref_traj[key][:N + 1])
+    return y
+
+
+def acados_call_sequence(ctl, current_ref_traj, stage_parameter=None):
+    """One control step as the LITERAL AcadosOcpSolver call sequence of the reference's controller classes -- NMPC_class.py:169-206,
+    SNMPC_class.py:181-214: N x set(j, "yref", 6 values) [+ set(j, "p", ...)], set(N, "yref", 4 values) [+ "p"], solve(),
+    get(0, "u"), N x get(j, "x") when the solve succeeded, get_cost(), get_stats('time_tot' | 'sqp_iter' | 'qp_iter') -- every call a
+    synchronous round trip through the C-ABI (2 N + 7 of them; 3 N + 8 with the parameter vector). What a maintainer gets who swaps
+    ONLY the solver object and keeps the reference's controller class; `call_pattern="acados"` of the mirrored classes runs it, the
+    tests hold it bit-equal to the one-call step (tum_ocp_step_async) and to the logged acados outputs.
+    stage_parameter(j) -> the per-stage parameter vector of the SNMPC OCP (None: nominal OCP)."""
+    s, N = ctl._solver, ctl.N
+    y = ref_rows(current_ref_traj, N)
+    for j in range(N + 1):
+        s.set(j, "yref", y[j] if j < N else y[N, :4])
+        if stage_parameter is not None:
+            s.set(j, "p", stage_parameter(j))
+    status = s.solve()
+    u0 = s.get(0, "u")
+    if status == 0:
+        ctl.pred_X = np.vstack([np.asarray(s.get(j, "x"))[:ctl.nx].reshape(1, -1) for j in range(N)])
+    ctl.stats[0] = s.get_cost()
+    ctl.stats[1] = s.get_stats('time_tot')
+    ctl.stats[2] = s.get_stats('sqp_iter')
+    ctl.stats[3] = np.max(s.get_stats('qp_iter'))
+    ctl.stats[4] = status
+    return u0, ctl.pred_X, ctl.stats
+
+
+def one_call_step(ctl, current_ref_traj):
+    """The same control step as ONE enqueue and ONE wait (tum_ocp_step_async + tum_ocp_results_wait): the pending initial state, the
+    reference, the solve and the read-back of u0 / predictions / cost / status, inputs and results through pinned memory the capsule
+    owns -- instead of the 2 N + 7 synchronous round trips of acados_call_sequence."""
+    s, N = ctl._solver, ctl.N
+    summ, X, U = s.step(x0=ctl._x0_pending, yref=ref_rows(current_ref_traj, N), with_iterate=True)
+    ctl._x0_pending = None
+    status = int(np.max(summ[:, 3]))
+    s.status = status
+    u0 = np.array(U[0, 0])                                  # batch = 1
+    if status == 0:
+        ctl.pred_X = np.array(X[0, :N])
+    ctl.stats[0] = float(summ[0, 2])
+    ctl.stats[1] = s.get_stats('time_tot')
+    ctl.stats[2] = s.get_stats('sqp_iter')
+    ctl.stats[3] = float(np.max(summ[:, 4]))
+    ctl.stats[4] = status
+    return u0, ctl.pred_X, ctl.stats
+
+
+class _SolverHandle:
+    """`controller.acados_solver`: reading the attribute from OUTSIDE the class first flushes an initial state that still waits for the
+    next one-call step (set_initial_state of call_pattern "step"), so code that follows the reference's other pattern --
+    set_initial_state(x); controller.acados_solver.solve() -- or reads bounds / uploads device buffers sees the solver in the state the
+    reference's eager setters would have left it in. The classes themselves use `_solver`."""
+
+    @property
+    def acados_solver(self):
+        self._flush_x0()
+        return self._solver
+
+    @acados_solver.setter
+    def acados_solver(self, s):
+        self._solver = s
+
+
+class Nonlinear_Model_Predictive_Controller(_SolverHandle):
     """NMPC_class.py:34-317. `sim_main_params` needs Tp, Ts, Ts_MPC (dict); config_path / MPC_params_file
-    may point at a TUM-CONTROL Config directory, or be None to use the built-in EDGAR constants."""
+    may point at a TUM-CONTROL Config directory, or be None to use the built-in EDGAR constants.
+    call_pattern: "step" (default) -- a control step is ONE enqueue and ONE wait (tum_ocp_step_async); "acados" -- the reference's
+    literal per-stage set / solve / get sequence (acados_call_sequence), eager setters; identical results."""
 
     def __init__(self, config_path=None, MPC_params_file=None, sim_main_params=None, X0_MPC=None, device=0,
-                 store_qp_in=False):
+                 store_qp_in=False, call_pattern="step"):
+        if call_pattern not in CALL_PATTERNS:
+            raise ValueError(f"call_pattern must be one of {CALL_PATTERNS}")
+        self.call_pattern = call_pattern
+        self._x0_pending = None
         if config_path is not None and MPC_params_file is not None:
             self.cfg = _config.load_reference_config(config_path, sim_main_params, MPC_params_file)
         else:
@@ -115,8 +194,8 @@ class Nonlinear_Model_Predictive_Controller:
         self.costfunction_type = self.ocp.cost.cost_type
         self.nx = 8
         self.x0 = X0_MPC
-        self.acados_solver.constraints_set(0, "lbx", self.x0)
-        self.acados_solver.constraints_set(0, "ubx", self.x0)
+        self._solver.constraints_set(0, "lbx", self.x0)
+        self._solver.constraints_set(0, "ubx", self.x0)
         self.stats = np.zeros(5)
         self.pred_X = np.empty((0, self.nx))
         self.nh, self.nh_e = 1, 1
@@ -124,47 +203,31 @@ class Nonlinear_Model_Predictive_Controller:
 
     def solve(self, current_ref_traj):
         """NMPC_class.py:163-241: set yref on every stage, one SQP-RTI step, read u0 / predictions / stats."""
-        s, N = self.acados_solver, self.N
-        y = np.zeros((N + 1, 6))
-        y[:, 0] = np.asarray(current_ref_traj['pos_x'][:N + 1]); y[:, 1] = np.asarray(current_ref_traj['pos_y'][:N + 1])
-        y[:, 2] = np.asarray(current_ref_traj['ref_yaw'][:N + 1]); y[:, 3] = np.asarray(current_ref_traj['ref_v'][:N + 1])
-        # (the reference issues one set() per stage and one get() per stage -- 79 ctypes calls per step, every one a round trip; here
-        #  the reference, the solve and the read-back of u0 / predictions / cost / status are ONE enqueue and ONE wait:
-        #  tum_ocp_step_async + tum_ocp_results_wait, inputs and results through pinned memory the capsule owns)
-        summ, X, U = s.step(x0=getattr(self, "_x0_pending", None), yref=y, with_iterate=True)
-        self._x0_pending = None
-        status = int(np.max(summ[:, 3]))
-        s.status = status
-        X, U = X[0], U[0]                                   # batch = 1
-        u0 = np.array(U[0])
-        if status == 0:
-            self.pred_X = np.array(X[:N])
-        self.stats[0] = float(summ[0, 2])
-        self.stats[1] = s.get_stats('time_tot')
-        self.stats[2] = s.get_stats('sqp_iter')
-        self.stats[3] = float(np.max(summ[:, 4]))
-        self.stats[4] = status
-        return u0, self.pred_X, self.stats
+        if self.call_pattern == "acados":
+            return acados_call_sequence(self, current_ref_traj)
+        return one_call_step(self, current_ref_traj)
 
     def set_initial_state(self, x0):
-        """NMPC_class.py:243-246 (lbx_0 = ubx_0 = x0). The state rides with the next solve(): it goes up in the same enqueue as the
-        reference trajectory (tum_ocp_step_async) instead of two synchronous setter calls of its own; whoever touches the solver
-        in between flushes it (_flush_x0)."""
+        """NMPC_class.py:243-246 (lbx_0 = ubx_0 = x0). call_pattern "step": the state rides with the next solve() -- it goes up in the
+        same enqueue as the reference trajectory (tum_ocp_step_async) instead of two synchronous setter calls of its own; reading
+        `acados_solver` from outside, reset() and update_cost_function_weights() flush it first (_flush_x0). "acados": set at once."""
         self.x0 = x0
         self._x0_pending = np.array(x0, dtype=float).reshape(-1)
+        if self.call_pattern == "acados":
+            self._flush_x0()
 
     def _flush_x0(self):
         if getattr(self, "_x0_pending", None) is not None:
-            self.acados_solver.constraints_set(0, "lbx", self._x0_pending)
-            self.acados_solver.constraints_set(0, "ubx", self._x0_pending)
-            self._x0_pending = None
+            x0, self._x0_pending = self._x0_pending, None
+            self._solver.constraints_set(0, "lbx", x0)
+            self._solver.constraints_set(0, "ubx", x0)
 
     def reset(self, x0):
-        self.acados_solver.reset()
+        self._solver.reset()
         self.set_initial_state(x0)
         self._flush_x0()
         for i in range(self.N + 1):
-            self.acados_solver.set(i, 'x', self.x0)
+            self._solver.set(i, 'x', self.x0)
 
     def reintialize_solver(self, X0_MPC, solver_generate_C_code=False, solver_build=False):
         self.constraint, self.model, self.acados_solver, self.ocp = acados_settings(
@@ -183,9 +246,12 @@ class Nonlinear_Model_Predictive_Controller:
         R = np.diag([params[3], params[4]])
         L1, L2 = params[5], params[6]
         W = np.zeros((6, 6)); W[:4, :4] = Q; W[4:, 4:] = R
-        s, N = self.acados_solver, self.N
-        for i in range(N):
-            s.cost_set(i, 'W', W)
+        s, N = self.acados_solver, self.N          # (the property: a pending initial state is flushed first)
+        if self.call_pattern == "acados":          # NMPC_class.py:294-296: one cost_set per stage
+            for i in range(N):
+                s.cost_set(i, 'W', W)
+        else:                                      # the same W on the stages 0..N-1 in ONE call (TUM_ALL_STAGES)
+            s.cost_set(ALL_STAGES, 'W', W)
         s.cost_set(N, 'W', Q)
         z0, Z0 = np.ones(self.nh) * L1, np.ones(self.nh) * L2
         for f, v in (('zl', z0), ('zu', z0), ('Zl', Z0), ('Zu', Z0)):

@@ -46,14 +46,15 @@ class Reduced_Robustified_Nonlinear_Model_Predictive_Controller:
     `store_qp_in`, plus -- after every successful solve -- the covariance propagation and constraint tightening for the next
     one (:276-378; `ZoRo: False`, the shipped setting) as one device kernel (K7)."""
 
-    def __init__(self, config_path=None, MPC_params_file=None, sim_main_params=None, X0_MPC=None, device=0):
+    def __init__(self, config_path=None, MPC_params_file=None, sim_main_params=None, X0_MPC=None, device=0, call_pattern="step"):
         from .nmpc import Nonlinear_Model_Predictive_Controller as _Nominal
-        self._nom = _Nominal(config_path, MPC_params_file, sim_main_params, X0_MPC, device=device, store_qp_in=True)
+        self._nom = _Nominal(config_path, MPC_params_file, sim_main_params, X0_MPC, device=device, store_qp_in=True,
+                             call_pattern=call_pattern)
         n = self._nom
         m, veh = n.cfg["mpc"], n.cfg["veh"]
         self.cfg, self.MPC_params = n.cfg, n.MPC_params
         self.N, self.Tp, self.Ts, self.Ts_MPC, self.nx = n.N, n.Tp, n.Ts, n.Ts_MPC, n.nx
-        self.acados_solver, self.model, self.constraint, self.ocp = n.acados_solver, n.model, n.constraint, n.ocp
+        self.model, self.constraint, self.ocp = n.model, n.constraint, n.ocp
         self.uncertainty_propagation_horizon = int(m["uncertainty_propagation_horizon"])
         self.Sigma0, self.BWB = r2_setup(m["stds"], self.Ts_MPC)
         self.delta_f_min, self.delta_f_max = veh["delta_f_min"], veh["delta_f_max"]
@@ -66,8 +67,13 @@ class Reduced_Robustified_Nonlinear_Model_Predictive_Controller:
         """The tightening for the next solve (:276-378) is part of every solve of this capsule -- one more kernel behind the
         interior point method on the capsule's stream (tum_ocp_r2_attach), skipped for an instance whose solve failed
         (`if status == 0:` at :276) -- instead of a call and a round trip of its own after solve()."""
-        self.acados_solver.r2_attach(self.Sigma0, self.BWB, self.uncertainty_propagation_horizon,
+        self._nom._solver.r2_attach(self.Sigma0, self.BWB, self.uncertainty_propagation_horizon,
                                      self.delta_f_min, self.delta_f_max, self.acc_max)
+
+    @property
+    def acados_solver(self):
+        """the nominal controller's solver (reading it flushes a pending initial state, nmpc._SolverHandle)"""
+        return self._nom.acados_solver
 
     def solve(self, current_ref_traj):
         u0, pred_X, stats = self._nom.solve(current_ref_traj)          # (:379-381: time_tot includes the tightening -- it does: same stream)
@@ -83,7 +89,6 @@ class Reduced_Robustified_Nonlinear_Model_Predictive_Controller:
 
     def reintialize_solver(self, X0_MPC, solver_generate_C_code=False, solver_build=False):
         self._nom.reintialize_solver(X0_MPC)
-        self.acados_solver = self._nom.acados_solver
         self._attach()
 
     def update_cost_function_weights(self, params):

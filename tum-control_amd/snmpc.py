@@ -16,6 +16,7 @@ import numpy as np
 from scipy.special import ndtri
 
 from . import config as _config
+from .nmpc import CALL_PATTERNS, _SolverHandle, acados_call_sequence, one_call_step
 from .solver import BatchedOcpSolver, CoupledSnmpcSolver
 
 
@@ -127,13 +128,19 @@ class ScenarioSNMPC:
         return st, U[::self.S + 1, 0], mean, var
 
 
-class Stochastic_Nonlinear_Model_Predictive_Controller:
+class Stochastic_Nonlinear_Model_Predictive_Controller(_SolverHandle):
     """Host-side mirror of the reference's SNMPC controller on the coupled OCP:
     Model_Predictive_Controller/Stochastic_NMPC/SNMPC_class.py:38-349, same method names, arguments and returns
     (`solve` -> u0, pred_X of the nominal copy, stats = [cost, time_tot, sqp_iter, max qp_iter, status]).
-    The RL weight-switching branch (SNMPC_class.py:134-177,215-246) is out of scope as in nmpc.py."""
+    The RL weight-switching branch (SNMPC_class.py:134-177,215-246) is out of scope as in nmpc.py.
+    call_pattern as in nmpc.py: "step" (default, one enqueue and one wait per control step) or "acados" (the reference's literal
+    sequence, SNMPC_class.py:181-214: set(j, "yref") AND set(j, "p") per stage, stacked 88-value lbx_0 / ubx_0 set at once)."""
 
-    def __init__(self, config_path=None, MPC_params_file=None, sim_main_params=None, X0_MPC=None, device=0):
+    def __init__(self, config_path=None, MPC_params_file=None, sim_main_params=None, X0_MPC=None, device=0, call_pattern="step"):
+        if call_pattern not in CALL_PATTERNS:
+            raise ValueError(f"call_pattern must be one of {CALL_PATTERNS}")
+        self.call_pattern = call_pattern
+        self._x0_pending = None
         if config_path is not None and MPC_params_file is not None:
             self.cfg = _config.load_reference_config(config_path, sim_main_params, MPC_params_file)
         else:
@@ -192,34 +199,20 @@ class Stochastic_Nonlinear_Model_Predictive_Controller:
         s.constraints_set(0, "lbx", x0_samples.flatten())
         s.constraints_set(0, "ubx", x0_samples.flatten())
         for i in range(self.N + 1):
-            s.set(i, "p", np.concatenate((self.A.flatten(), self.risk_parameter, self.stop_flags[i].reshape(1))))
+            s.set(i, "p", self._stage_parameter(i))
         s.cold_start()                  # SNMPC_class.py:126-127: x_j = x0_samples for all j
         s.set_x0_offsets(x0_offsets(self.w_samples, self.stds))       # for the 8-value x0 of a step (set_initial_state)
         return s
 
+    def _stage_parameter(self, j):
+        """p_j = [A_pce.flatten(), risk_parameter, stop_flag_j] (SNMPC_class.py:124,185,193)"""
+        return np.concatenate((self.A.flatten(), self.risk_parameter, self.stop_flags[j].reshape(1)))
+
     def solve(self, current_ref_traj):
         """SNMPC_class.py:179-257"""
-        s, N = self.acados_solver, self.N
-        y = np.zeros((N + 1, 6))
-        y[:, 0] = np.asarray(current_ref_traj['pos_x'][:N + 1]); y[:, 1] = np.asarray(current_ref_traj['pos_y'][:N + 1])
-        y[:, 2] = np.asarray(current_ref_traj['ref_yaw'][:N + 1]); y[:, 3] = np.asarray(current_ref_traj['ref_v'][:N + 1])
-        # (the reference issues one set() per stage and one get() per stage -- 79 ctypes calls per step, every one a round trip; here
-        #  the reference, the solve and the read-back of u0 / predictions / cost / status are ONE enqueue and ONE wait:
-        #  tum_ocp_step_async + tum_ocp_results_wait, inputs and results through pinned memory the capsule owns)
-        summ, X, U = s.step(x0=getattr(self, "_x0_pending", None), yref=y, with_iterate=True)
-        self._x0_pending = None
-        status = int(np.max(summ[:, 3]))
-        s.status = status
-        X, U = X[0], U[0]                                   # batch = 1
-        u0 = np.array(U[0])
-        if status == 0:
-            self.pred_X = np.array(X[:N])
-        self.stats[0] = float(summ[0, 2])
-        self.stats[1] = s.get_stats('time_tot')
-        self.stats[2] = s.get_stats('sqp_iter')
-        self.stats[3] = float(np.max(summ[:, 4]))
-        self.stats[4] = status
-        return u0, self.pred_X, self.stats
+        if self.call_pattern == "acados":
+            return acados_call_sequence(self, current_ref_traj, stage_parameter=self._stage_parameter)
+        return one_call_step(self, current_ref_traj)
 
     def set_initial_state(self, x0):
         """SNMPC_class.py:259-264 (lbx_0 = ubx_0 = compute_x0dist(x0)). The estimated state rides with the next solve()
@@ -228,22 +221,24 @@ class Stochastic_Nonlinear_Model_Predictive_Controller:
         flushes it (_flush_x0)."""
         self.x0 = x0
         self._x0_pending = np.array(x0, dtype=float).reshape(-1)
+        if self.call_pattern == "acados":
+            self._flush_x0()
 
     def _flush_x0(self):
         if getattr(self, "_x0_pending", None) is not None:
-            x0_samples = compute_x0dist(self._x0_pending, self.w_samples, self.stds)
-            self.acados_solver.constraints_set(0, "lbx", x0_samples.flatten())
-            self.acados_solver.constraints_set(0, "ubx", x0_samples.flatten())
-            self._x0_pending = None
+            x0, self._x0_pending = self._x0_pending, None
+            x0_samples = compute_x0dist(x0, self.w_samples, self.stds)
+            self._solver.constraints_set(0, "lbx", x0_samples.flatten())
+            self._solver.constraints_set(0, "ubx", x0_samples.flatten())
 
     def reset(self, x0):
         self._x0_pending = None
-        self.acados_solver.reset()
+        self._solver.reset()
         x0_samples = compute_x0dist(x0, self.w_samples, self.stds)
-        self.acados_solver.constraints_set(0, "lbx", x0_samples.flatten())
-        self.acados_solver.constraints_set(0, "ubx", x0_samples.flatten())
+        self._solver.constraints_set(0, "lbx", x0_samples.flatten())
+        self._solver.constraints_set(0, "ubx", x0_samples.flatten())
         for i in range(self.N + 1):
-            self.acados_solver.set(i, 'x', x0_samples.flatten())
+            self._solver.set(i, 'x', x0_samples.flatten())
 
     def reintialize_solver(self, X0_MPC, solver_generate_C_code=False, solver_build=False):
         """SNMPC_class.py:274-281: a fresh solver with the SAME Q / R / N / penalties / PCE set-up, cold-started at the

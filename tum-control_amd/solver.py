@@ -67,13 +67,13 @@ C_SYMBOLS = ["tum_ocp_create", "tum_ocp_free", "tum_ocp_last_error", "tum_ocp_ba
              "tum_ocp_set", "tum_ocp_get", "tum_ocp_constraints_set", "tum_ocp_cost_set",
              "tum_ocp_solve", "tum_ocp_solve_async", "tum_ocp_synchronize",
              "tum_ocp_get_cost", "tum_ocp_get_stats", "tum_ocp_reset", "tum_ocp_get_from_qp_in",
-             "tum_ocp_set_stream", "tum_ocp_get_device", "tum_ocp_put_device", "tum_ocp_results_async", "tum_ocp_results_wait", "tum_ocp_step_async", "tum_ocp_cold_start", "tum_ocp_last_kernel_ms",
+             "tum_ocp_set_stream", "tum_ocp_get_device", "tum_ocp_put_device", "tum_ocp_results_async", "tum_ocp_results_wait", "tum_ocp_results_outstanding", "tum_ocp_step_async", "tum_ocp_cold_start", "tum_ocp_last_kernel_ms",
              "tum_ocp_debug_dump", "tum_ocp_profile_phases", "tum_ocp_set_schedule", "tum_ocp_set_kernel",
              "tum_ocp_set_x0_fanout", "tum_pce_moments", "tum_pce_attach", "tum_pce_moments_device",
              "tum_ocp_bounds_snapshot", "tum_ocp_bounds_restore", "tum_ocp_r2_backoff", "tum_ocp_r2_attach", "tum_ocp_constraints_get",
              "tum_ocp_snmpc_attach", "tum_ocp_snmpc_samples", "tum_ocp_snmpc_set_offsets",
              "tum_planner_emulate", "tum_sim_create", "tum_sim_free", "tum_sim_set_state", "tum_sim_plan", "tum_sim_advance",
-             "tum_sim_run", "tum_sim_steps", "tum_sim_get"]
+             "tum_sim_run", "tum_sim_steps", "tum_sim_get", "tum_sim_set_disturbances"]
 
 
 def load_library(path=None):
@@ -114,6 +114,8 @@ def load_library(path=None):
     if hasattr(L, "tum_ocp_results_async"):          # (absent from the libraries of earlier revisions that scripts/dev/ab2.py loads beside this one)
         L.tum_ocp_results_async.argtypes = [vp, ci]
         L.tum_ocp_results_wait.argtypes = [vp, ctypes.POINTER(dp), ctypes.POINTER(dp), ctypes.POINTER(dp)]
+    if hasattr(L, "tum_ocp_results_outstanding"):
+        L.tum_ocp_results_outstanding.argtypes = [vp]
     if hasattr(L, "tum_ocp_step_async"):
         L.tum_ocp_step_async.argtypes = [vp, vp, vp, ci]
     L.tum_ocp_last_kernel_ms.restype = ctypes.c_double; L.tum_ocp_last_kernel_ms.argtypes = [vp]
@@ -138,6 +140,8 @@ def load_library(path=None):
     L.tum_sim_plan.argtypes = [vp]; L.tum_sim_advance.argtypes = [vp]; L.tum_sim_run.argtypes = [vp, ci]
     L.tum_sim_steps.argtypes = [vp]
     L.tum_sim_get.argtypes = [vp, cs, dp, ctypes.c_longlong]
+    if hasattr(L, "tum_sim_set_disturbances"):
+        L.tum_sim_set_disturbances.argtypes = [vp, dp, dp, ci]
     _libs[p] = L
     if p == LIB_PATH:
         _lib = L
@@ -246,9 +250,9 @@ class BatchedOcpSolver:
         self._put(self._L.tum_ocp_constraints_set, stage, field, value, "constraints_set")
 
     def cost_set(self, stage, field, value):
-        """acados_solver.cost_set. RESTRICTION (include/tum_nmpc.h): all stages < N share ONE W per instance -- the
-        reference installs the same blockdiag(Q, R) on every stage (NMPC_class.py:295-296); a W set at any stage < N
-        replaces the weight of all of them."""
+        """acados_solver.cost_set (NMPC_class.py:294-317). 'W' is PER STAGE, as in acados: cost_set(i, 'W', W) touches stage i only
+        (stage N: the 4 x 4 terminal weight); cost_set(ALL_STAGES, 'W', W6x6) sets the stages 0..N-1 in one call. W must be
+        diagonal (include/tum_nmpc.h). 'zl' | 'zu' | 'Zl' | 'Zu': per penalty class (stage 0 / 1..N-1 / N)."""
         v = np.asarray(value, dtype=np.float64)
         if field == "W":
             ny = 6 if (stage < self.N) else 4          # (stage == ALL_STAGES = -1: one 6 x 6 W for all the stages 0..N-1)
@@ -384,8 +388,17 @@ class BatchedOcpSolver:
         a1, p1 = arr(yref, self.batch * (self.N + 1) * 6)
         self._chk(self._L.tum_ocp_step_async(self._h, p0, p1, int(bool(with_iterate))), "step_async")
 
+    def results_outstanding(self):
+        """result requests enqueued on this capsule and not yet waited for (0, 1 or 2)"""
+        return int(self._L.tum_ocp_results_outstanding(self._h))
+
     def step(self, x0=None, yref=None, with_iterate=True):
-        """step_async + results_wait: (summary (batch, 5): u0[2], cost, status, qp_iter; X; U) as views of the capsule's pinned slabs"""
+        """step_async + results_wait: (summary (batch, 5): u0[2], cost, status, qp_iter; X; U) as views of the capsule's pinned slabs.
+        SYNCHRONOUS: the results returned are those of THIS step. results_wait delivers the OLDEST outstanding request, so requests an
+        earlier caller left behind on this capsule (a results_async never waited for, a step whose wait was interrupted) are drained
+        and dropped first -- otherwise every later step would hand out the previous step's results, one control step late."""
+        while self.results_outstanding() > 0:
+            self.results_wait()
         self.step_async(x0, yref, with_iterate)
         return self.results_wait()
 
@@ -594,6 +607,19 @@ class DeviceClosedLoop:
         x_sim = np.ascontiguousarray(np.broadcast_to(x_sim, (self.B, 7)), dtype=np.float64)
         x_mpc = np.ascontiguousarray(np.broadcast_to(x_mpc, (self.B, 8)), dtype=np.float64)
         self._chk(self._L.tum_sim_set_state(self._s, _dp(x_sim), _dp(x_mpc), int(cold_start)), "sim_set_state")
+
+    def set_disturbances(self, w_deriv=None, e_est=None):
+        """disturbance realisation played back by the loop: (n_steps, B, 7) additive disturbances of the state derivatives and / or
+        (n_steps, B, 7) state estimation errors (closed_loop.DisturbanceModel.draw); both None: none"""
+        arrs = [None if a is None else np.ascontiguousarray(a, dtype=np.float64) for a in (w_deriv, e_est)]
+        n = 0
+        for a in arrs:
+            if a is not None:
+                if a.ndim != 3 or a.shape[1:] != (self.B, 7) or (n and a.shape[0] != n):
+                    raise Exception("DeviceClosedLoop.set_disturbances: expected (n_steps, batch, 7) arrays of equal length")
+                n = a.shape[0]
+        self._chk(self._L.tum_sim_set_disturbances(self._s, None if arrs[0] is None else _dp(arrs[0]), None if arrs[1] is None else _dp(arrs[1]), n),
+                  "sim_set_disturbances")
 
     def plan(self):
         self._chk(self._L.tum_sim_plan(self._s), "sim_plan")
