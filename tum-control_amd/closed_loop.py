@@ -176,6 +176,24 @@ def log_file_arrays(logs, b, w_deriv=None, e_est=None, T=None, Ts=0.02, drop_las
                 t=np.linspace(0.0, n_run * Ts if T is None else T, n))
 
 
+class MovingAverageEstimator:
+    """StateEstimation (SimulationMode_main_class.py:152-156): per-state moving average over the last
+    WINDOWS[i] samples (fewer while the buffer fills), buffers start empty."""
+
+    def __init__(self, batch):
+        self.hist = [[] for _ in range(8)]
+        self.batch = batch
+
+    def __call__(self, x_next):
+        out = np.empty_like(x_next)
+        for i in range(8):
+            self.hist[i].append(x_next[:, i].copy())
+            if len(self.hist[i]) > 15:
+                self.hist[i].pop(0)
+            out[:, i] = np.mean(self.hist[i][-WINDOWS[i]:], axis=0)
+        return out
+
+
 class ClosedLoopBatch:
     """B independent closed loops on one track, one OCP instance each; `params` (B,7) are per-instance
     [q_xy, q_yaw, q_vel, r_jerk, r_steer, L1, L2] as in update_cost_function_weights (None: YAML defaults x0.01)."""

@@ -313,13 +313,21 @@ __global__ void __launch_bounds__(64, (NT_ == 5) ? 2 : 1) cond_kernel(const PArg
         double w0[8], w1[8];
 #pragma unroll
         for (int i = 0; i < 8; i++) { w0[i] = 0.0; w1[i] = 0.0; }
-        if (isg) {
+        // The constant column g of the recursion rides in bank 0 -- on lane 63 -- while the stages leave that lane free (stage s has 2 s
+        // columns: s <= 24, the first three segments) and moves to its lane of bank 1 in front of the fourth: until then bank 1 holds
+        // nothing, and the second copy of the column update, the gg row, the staging stores and the gradient terms of bank 1 are not
+        // issued at all (55 of the ~130 FP64 instructions of a stage; the same operations on the same operands for every column that
+        // exists -- results unchanged to the bit, tests/test_gpu_parity.py::test_condensing_six_wavefronts_is_the_same_arithmetic).
+        // (The coupled SNMPC OCP loads its first stages from the prologue's buffer in the two-bank layout and keeps it.)
+        constexpr int G0_SEGS = SN ? 0 : 3;
+        if (G0_SEGS > 0 ? lane == 63 : isg) {
 #pragma unroll
-            for (int i = 0; i < 8; i++) w1[i] = gx0[i] - gX[i];
+            for (int i = 0; i < 8; i++) (G0_SEGS > 0 ? w0[i] : w1[i]) = gx0[i] - gX[i];
         }
         const int lane_cond = lane;
         auto stage_body = [&](const int k, auto tsc) {
             constexpr int Ts = decltype(tsc)::value;
+            constexpr bool G0 = Ts <= G0_SEGS;
             // (everything derived from the lane id is derived again in every stage, from a copy the optimiser cannot see through:
             //  held across the stage loop these values cost the registers the last segment lacks)
             int lane_s = lane_cond;
@@ -344,6 +352,15 @@ __global__ void __launch_bounds__(64, (NT_ == 5) ? 2 : 1) cond_kernel(const PArg
                     w1[i] = isg ? gg : g1;
                 }
             } else {
+            if constexpr (G0) {
+                apply_A(rec, w0);
+                const double sel0 = (j0 == k) ? 1.0 : 0.0, selg = (lane == 63) ? 1.0 : 0.0;
+#pragma unroll
+                for (int i = 0; i < 6; i++) w0[i] += sel0 * rec[2 + i * 7 + 5 + r0];
+                w0[6] += sel0 * (r0 ? dt : 0.0); w0[7] += sel0 * (r0 ? 0.0 : dt);
+#pragma unroll
+                for (int i = 0; i < 8; i++) w0[i] += selg * rec[44 + i];
+            } else {
             apply_A2(rec, w0, w1);
             {
                 const double sel0 = (j0 == k) ? 1.0 : 0.0, sel1 = (lane < NB1 && j1 == k) ? 1.0 : 0.0, selg = isg ? 1.0 : 0.0;
@@ -358,11 +375,12 @@ __global__ void __launch_bounds__(64, (NT_ == 5) ? 2 : 1) cond_kernel(const PArg
                 for (int i = 0; i < 8; i++) w1[i] += selg * rec[44 + i];
             }
             }
+            }
             const int s = k + 1;                         // stage whose G_s the lanes now hold
             const double sc = (s < N) ? dt : 1.0;
             const double g3 = rec[PR_GH + 0], g5 = rec[PR_GH + 1], g7 = rec[PR_GH + 2];
             const double g4 = SN ? rec[PR_G4] : 0.0, cvl = SN ? rec[PR_CV] : 1.0, cvt = SN ? rec[PR_CV + 1] : 0.0;
-            double hr0 = g3 * w0[3] + g5 * w0[5] + g7 * w0[7], hr1 = g3 * w1[3] + g5 * w1[5] + g7 * w1[7];
+            double hr0 = g3 * w0[3] + g5 * w0[5] + g7 * w0[7], hr1 = G0 ? 0.0 : g3 * w1[3] + g5 * w1[5] + g7 * w1[7];
             double hd = rec[PR_GH + 3];
             if (SN) {
                 hr0 += g4 * w0[4]; hr1 += g4 * w1[4];
@@ -375,6 +393,14 @@ __global__ void __launch_bounds__(64, (NT_ == 5) ? 2 : 1) cond_kernel(const PArg
             }
             // the speed row of the cost: vl (nominal OCP) or |v| (SNMPC: gradient (vl, vt)/|v|)
             const double c30 = SN ? cvl * w0[3] + cvt * w0[4] : w0[3], c31 = SN ? cvl * w1[3] + cvt * w1[4] : w1[3];
+            if constexpr (G0) {
+                if (lane == 63) {
+#pragma unroll
+                    for (int i = 0; i < 8; i++) sGs[i] = w0[i];
+                    gvec[PV_D + 2 * (s - 1)] = rec[PR_XD] + w0[6];
+                    gvec[PV_D + 2 * (s - 1) + 1] = hd + hr0;
+                }
+            } else
             if (isg) {
 #pragma unroll
                 for (int i = 0; i < 8; i++) sGs[i] = w1[i];
@@ -387,14 +413,14 @@ __global__ void __launch_bounds__(64, (NT_ == 5) ? 2 : 1) cond_kernel(const PArg
             {
                 const int c_ = (s - 1) >> 2;
                 double *gcs = pa.cws + (size_t)b * NCH * 64 + 16 * ((s - 1) & 3) + lc;
-                if (2 * lq <= c_) gcs[cidx(c_, lq) * 64] = hr0;
+                if (2 * lq <= c_) gcs[cidx(c_, lq) * 64] = hr0;          // (G0: the lanes 48..63 do not store before stage 25)
                 const int T1 = 4 + lq;
-                if (lane < NB1 && 2 * T1 <= c_) gcs[cidx(c_, T1) * 64] = hr1;
+                if (!G0 && lane < NB1 && 2 * T1 <= c_) gcs[cidx(c_, T1) * 64] = hr1;
             }
 #pragma unroll
             for (int r = 0; r < 3; r++) sStage[r * NVP + lane] = w0[r];
-            sStage[3 * NVP + lane] = c30;
-            if (lane < NB1) {
+            sStage[3 * NVP + lane] = c30;          // (G0: what lane 63 stages is g, in a column the tiles of these segments do not read)
+            if (!G0 && lane < NB1) {
 #pragma unroll
                 for (int r = 0; r < 3; r++) sStage[r * NVP + 64 + lane] = w1[r];
                 sStage[3 * NVP + 64 + lane] = c31;
@@ -409,10 +435,11 @@ __global__ void __launch_bounds__(64, (NT_ == 5) ? 2 : 1) cond_kernel(const PArg
                 for (int r = 0; r < 4; r++) {
                     const double gs = (SN && r == 3) ? cvl * sGs[3] + cvt * sGs[4] : sGs[r];
                     const double e = wr[r] * (rec[PR_RES + r] + gs);
-                    a0 += e * ((r == 3) ? c30 : w0[r]); a1 += e * ((r == 3) ? c31 : w1[r]);
+                    a0 += e * ((r == 3) ? c30 : w0[r]);
+                    if constexpr (!G0) a1 += e * ((r == 3) ? c31 : w1[r]);
                 }
-                q0 += a0;
-                q1 += (lane < NB1) ? a1 : 0.0;
+                q0 += (G0 && lane == 63) ? 0.0 : a0;
+                if constexpr (!G0) q1 += (lane < NB1) ? a1 : 0.0;
             }
             const double wl = (lq == 0) ? wr[0] : (lq == 1) ? wr[1] : (lq == 2) ? wr[2] : wr[3];
             double bop[Ts];
@@ -442,6 +469,10 @@ __global__ void __launch_bounds__(64, (NT_ == 5) ? 2 : 1) cond_kernel(const PArg
         // stage s = k+1 touches columns < 2s, i.e. ceil(s/8) tiles: one instantiation of the stage per segment of 8 stages
         static_for<1, NT>([&](auto tsc) {
             constexpr int Ts = decltype(tsc)::value;
+            if constexpr (G0_SEGS > 0 && Ts == G0_SEGS + 1) {          // g moves from lane 63 of bank 0 to its lane of bank 1
+#pragma unroll
+                for (int i = 0; i < 8; i++) { const double gv = rl(w0[i], 63); w1[i] = isg ? gv : 0.0; w0[i] = (lane == 63) ? 0.0 : w0[i]; }
+            }
             for (int k = 8 * (Ts - 1); k < N && k < 8 * Ts; k++) stage_body(k, tsc);
         });
         for (int s = N + 1; s <= NMAX; s++) {          // rows beyond the horizon: zeros
