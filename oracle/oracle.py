@@ -115,6 +115,7 @@ def lib():
         L.oracle_solve_batch_cold_forced.argtypes = [ctypes.c_void_p, ctypes.c_int, dp, dp, dp, dp, dp, ctypes.c_int,
                                                      ctypes.POINTER(ctypes.c_int)]
         L.oracle_set_iter_force.argtypes = [ctypes.c_void_p, ctypes.c_int]
+        L.oracle_forget_qp.argtypes = [ctypes.c_void_p]
         _lib = L
     return _lib
 
@@ -218,6 +219,11 @@ class OracleOcp:
         self.x0[:] = x0
         self.X[:] = np.asarray(x0)[None, :]
         self.U[:] = 0.0
+        lib().oracle_forget_qp(self._h)          # (the interior point method of the next solve starts cold too)
+
+    def qp_warm_start(self, on=True, warm_mu=0.0):
+        """interior point warm start from the previous QP's multipliers in a sequence of solves (default: on, IPM_WARM_DEFAULT)"""
+        self.set_ipm_experiment(5 if on else 0, warm_mu, 0, 0.0)
 
     def set_yref(self, pos_x, pos_y, ref_yaw, ref_v):
         """NMPC_class.py:169-180"""
@@ -313,6 +319,7 @@ def _snmpc_bind(L):
     L.snmpc_field.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.POINTER(ctypes.c_int)]
     L.snmpc_set_model.argtypes = [ctypes.c_void_p, ctypes.POINTER(StmModel)]
     L.snmpc_set_iter_max.argtypes = [ctypes.c_void_p, ctypes.c_int]
+    L.snmpc_forget_qp.argtypes = [ctypes.c_void_p]
     L.snmpc_solve.argtypes = [ctypes.c_void_p]
     L.snmpc_solve.restype = ctypes.c_int
     L.snmpc_qp_iter.argtypes = [ctypes.c_void_p]
@@ -398,6 +405,13 @@ class OracleSnmpcOcp:
         self.x0[:] = x0_samples
         self.X[:] = np.asarray(x0_samples)[None]
         self.U[:] = 0.0
+        lib().snmpc_forget_qp(self._h)
+
+    def qp_warm_start(self, on=True, warm_mu=0.0):
+        """interior point warm start from the previous QP (default: on, as the reference's SNMPC solver: qp_solver_warm_start = 1)"""
+        L = lib()
+        L.snmpc_set_ipm_warm.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_double]
+        L.snmpc_set_ipm_warm(self._h, 5 if on else 0, float(warm_mu))
 
     def set_initial_state(self, x0_samples):
         self.x0[:] = x0_samples

@@ -45,6 +45,9 @@ VARIANTS = {
     "warm4-mu1e-3":       (4, 1e-3, 0, 0.0),
     "warm4-mu1e-4":       (4, 1e-4, 0, 0.0),
     "warm5-mu1e-2":       (5, 1e-2, 0, 0.0),
+    "warm5-mu7e-3":       (5, 7e-3, 0, 0.0),
+    "warm5-mu4e-3":       (5, 4e-3, 0, 0.0),
+    "warm6-mu5e-3":       (6, 5e-3, 0, 0.0),
     "warm5-mu1e-3":       (5, 1e-3, 0, 0.0),
     "warm5-mu1e-4":       (5, 1e-4, 0, 0.0),
     "warm6-mu1e-3":       (6, 1e-3, 0, 0.0),

@@ -21,6 +21,9 @@ def _lib_for(kernel):
 
 def _mk(N, B, kernel, **kw):
     from tum_control_amd.solver import BatchedOcpSolver
+    # a NAMED kernel variant is one side of a comparison between variants: the development build's kernels always cold-start the interior
+    # point method, so both sides do ("auto": the library's defaults, warm start of the interior point method included)
+    kw.setdefault("qp_warm_start", kernel == "auto")
     with _lib_for(kernel):
         s = BatchedOcpSolver(N=N, dt=0.08, nsub=3, batch=B, **kw)
     s.install_reference_ocp()

@@ -282,6 +282,8 @@ def _gpu_vs_oracle(golden_dir, N, uph, poses, nsolve=3, shift_ref=0, kernel=None
         o = orc.OracleSnmpcOcp(N=N, dt=0.08, Apce=A, uph=uph)
         o.set_weights(m["q_lon"], m["q_yaw"], m["q_vel"], m["r_jerk"], m["r_steering_rate"], m["L1_pen"], m["L2_pen"], scale=0.01)
         o.yref[:] = Y[j]; o.cold_start(X0[j])
+        if kernel == "fused":
+            o.qp_warm_start(False)          # (the development build's kernels always cold-start the interior point method)
         orcs.append(o)
     for it in range(nsolve):
         assert s.solve() == 0

@@ -33,10 +33,11 @@ __global__ void __launch_bounds__(1024) lpt_order_kernel(const int *qp_iter, int
 }
 
 // cold start on the device: X_k = x0, U = 0 (acados create / reset + set(i,'x',x0); NMPC_class.py:250-254)
-__global__ void cold_start_kernel(double *X, double *U, const double *x0, int N, int batch)
+__global__ void cold_start_kernel(double *X, double *U, const double *x0, int N, int batch, double *qp_lam)
 {
     const int b = blockIdx.x;
     if (b >= batch) return;
+    if (qp_lam && threadIdx.x == 0) qp_lam[(size_t)b * (6 * N + 2) + 6 * N] = 0.0;          // (the interior point method of the next solve starts cold as well)
     for (int i = threadIdx.x; i < (N + 1) * NX; i += blockDim.x) X[(size_t)b * (N + 1) * NX + i] = x0[(size_t)b * NX + (i & 7)];
     for (int i = threadIdx.x; i < N * NU; i += blockDim.x) U[(size_t)b * N * NU + i] = 0.0;
 }

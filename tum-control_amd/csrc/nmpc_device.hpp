@@ -115,6 +115,11 @@ struct KArgs {
     int uph;                                          // uncertainty propagation horizon: stages 1..uph come from `pro`
     const double *pro;                                // [b][uph][sn_pro_stage(uph)] G_nom,s | chance-constraint row of stage s
     double *dv;                                       // [b][NVP] QP solution for the epilogue kernel
+    // warm start of the interior point method (pipeline kernels): per instance the multipliers of the last QP in the layout of `slack`,
+    // then 1.0 where that QP converged / 0.0 (one pointer: it is live across the whole kernel); the complementarity target of a warm
+    // start (0: always cold)
+    double *qp_lam;                                   // [b][6N + 2]
+    double warm_mu;
 };
 
 // ---------------------------------------------------------------- wave helpers

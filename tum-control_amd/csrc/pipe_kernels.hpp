@@ -1041,6 +1041,14 @@ __global__ void __launch_bounds__(64, IPM_WPS) ipm_kernel(const PArgs pa)
                 dval[rr] = (t_ == 0) ? gU[2 * i_ + 1] : gvec[PV_D + 2 * (i_ - 1) + ((t_ == 2) ? 1 : 0)];
                 lo[rr] = gbnd[(2 * t_) * NB + i_]; hi[rr] = gbnd[(2 * t_ + 1) * NB + i_];
             }
+            // Warm start (acados: qp_solver_warm_start, SNMPC_acados_settings.py:307): when the previous QP of this instance converged, the method starts
+            // at the smaller complementarity target warm_mu, a violation slack the last QP ended with stays, and the last multiplier of a
+            // row is kept as far as the row is still near its bound in the new problem (within ten times the centred value mu / t, below
+            // the slack-equation bound), the row pushed off the boundary to t lam = mu. -9 % interior point iterations over the logged
+            // warm-started loops (profiles/r05_ipm_iterations.txt); a cold start is untouched.
+            const double *gsl = ka.slack + (size_t)b * 6 * N, *glm = ka.qp_lam + (size_t)b * (6 * N + 2);
+            const bool warm = ka.warm_mu > 0.0 && glm[6 * N] != 0.0;          // (wave-uniform)
+            const double mu0_ = warm ? ka.warm_mu : p_mu0, t0_ = warm ? ka.warm_mu : p_t0;
 #pragma unroll
             for (int rr = 0; rr < SLOTS; rr++)
 #pragma unroll
@@ -1050,12 +1058,26 @@ __global__ void __launch_bounds__(64, IPM_WPS) ipm_kernel(const PArgs pa)
                     const double eps = sd ? -1.0 : 1.0, bnd = sd ? hi[rr] : lo[rr];
                     const double r0v = eps * (dval[rr] - bnd);
                     const double z = pen(rr, sd, 0), Z = pen(rr, sd, 1);
-                    const double s0 = p_mu0 / (z > 1e-6 ? z : 1e-6);
+                    double s0 = mu0_ / (z > 1e-6 ? z : 1e-6);
+                    const int widx = sd * 3 * N + (on_ ? ((ty[rr] == 0) ? stg[rr] : N + 2 * (stg[rr] - 1) + ((ty[rr] == 2) ? 1 : 0)) : 0);
+                    const double sw = warm ? gsl[widx] : 0.0, lw0 = warm ? glm[widx] : 0.0;
+                    if (sw > s0) s0 = sw;
                     double t = r0v + s0;
-                    if (t < p_t0) t = p_t0;
-                    const double lam = p_mu0 / t;
+                    if (t < t0_) t = t0_;
+                    double lam = mu0_ / t;
+                    {
+                        double lw = lw0;
+                        if (lw > 10.0 * lam) lw = 10.0 * lam;
+                        if (lw > lam) {
+                            const double cap = 0.99 * (z + Z * s0);
+                            if (lw > cap) lw = cap;
+                            lam = lw;
+                            const double tc = mu0_ / lam;
+                            if (t < tc) t = tc;
+                        }
+                    }
                     double ms = z + Z * s0 - lam;
-                    const double msf = 1e-2 * p_mu0 / s0;
+                    const double msf = 1e-2 * mu0_ / s0;
                     if (ms < msf) ms = msf;
                     ROWF(0, k) = on_ ? s0 : 1.0; ROWF(1, k) = on_ ? t : 1.0; ROWF(2, k) = on_ ? lam : 1.0; ROWF(3, k) = on_ ? ms : 1.0;
                     ROWF(4, k) = on_ ? z + Z * s0 - lam - ms : 0.0;
@@ -1744,6 +1766,7 @@ __global__ void __launch_bounds__(64, IPM_WPS) ipm_kernel(const PArgs pa)
                     if (!on[rr]) continue;
                     const int idx = (ty[rr] == 0) ? stg[rr] : N + 2 * (stg[rr] - 1) + ((ty[rr] == 2) ? 1 : 0);
                     sl[sd * 3 * N + idx] = ROWF(0, 2 * rr + sd);
+                    ka.qp_lam[(size_t)b * (6 * N + 2) + sd * 3 * N + idx] = ROWF(2, 2 * rr + sd);          // (the next solve's warm start)
                 }
         }
     }
@@ -1760,6 +1783,7 @@ __global__ void __launch_bounds__(64, IPM_WPS) ipm_kernel(const PArgs pa)
         ka.status[b] = status;
         ka.qp_iter[b] = it;
         ka.qp_status[b] = qp_status;
+        ka.qp_lam[(size_t)b * (6 * N + 2) + 6 * N] = (qp_status == 0) ? 1.0 : 0.0;
         ka.res[b * 3 + 0] = res_stat; ka.res[b * 3 + 1] = res_ineq; ka.res[b * 3 + 2] = res_comp;
     }
     if constexpr (FUSE) {

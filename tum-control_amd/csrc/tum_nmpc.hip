@@ -32,7 +32,7 @@ struct tum_ocp {
     hipStream_t stream; bool own_stream;
     hipEvent_t ev0, ev1;
     KArgs ka;
-    double *dX, *dU, *dx0, *dyref, *dW, *dpen, *dbnd, *dcost, *dres, *dslack, *dqpin, *ddbg;
+    double *dX, *dU, *dx0, *dyref, *dW, *dpen, *dbnd, *dcost, *dres, *dslack, *dqpin, *ddbg, *dqplam;
     int *dstatus, *dqpiter, *dqpstatus, *dorder;
     bool lpt, order_valid;
     long long *dprof;
@@ -163,6 +163,7 @@ extern "C" tum_ocp *tum_ocp_create(const tum_ocp_desc *desc)
     ok &= dalloc(&c->dqpiter, B) == hipSuccess;
     ok &= dalloc(&c->dqpstatus, B) == hipSuccess;
     ok &= dalloc(&c->dorder, B) == hipSuccess;
+    ok &= dalloc(&c->dqplam, B * (6 * (size_t)N + 2)) == hipSuccess;      // warm start of the interior point method: multipliers | converged flag
     { const char *e = getenv("TUM_NMPC_SCHEDULE"); c->lpt = !(e && std::string(e) == "natural"); }
     if (ok) {   // start from the identity map: the schedule is always a valid permutation
         std::vector<int> id(B);
@@ -200,6 +201,9 @@ extern "C" tum_ocp *tum_ocp_create(const tum_ocp_desc *desc)
     ka.mu0 = desc->qp_mu0 > 0 ? desc->qp_mu0 : 0.05;
     ka.t0 = desc->qp_t0 > 0 ? desc->qp_t0 : 0.05;
     ka.reg = 0.0;
+    // qp_solver_warm_start (SNMPC_acados_settings.py:307): the interior point method starts from the previous QP's multipliers
+    ka.warm_mu = desc->qp_warm_start ? (desc->qp_warm_mu > 0 ? desc->qp_warm_mu : 1e-2) : 0.0;
+    ka.qp_lam = c->dqplam;
     Model &m = ka.mp;
     m.lf = desc->lf; m.lr = desc->lr; m.m = desc->m; m.inv_m = 1.0 / desc->m; m.inv_Iz = 1.0 / desc->Iz;
     m.ka = 0.5 * desc->ro * desc->S * desc->Cd;
@@ -242,6 +246,7 @@ extern "C" void tum_ocp_free(tum_ocp *c)
     if (!c) return;
     DevGuard guard(c->d.device);
     (void)hipFree(c->dX); (void)hipFree(c->dU); (void)hipFree(c->dx0); (void)hipFree(c->dyref); (void)hipFree(c->dW); (void)hipFree(c->dpen); (void)hipFree(c->dbnd);
+    (void)hipFree(c->dqplam);
     (void)hipFree(c->dcost); (void)hipFree(c->dres); (void)hipFree(c->dslack); (void)hipFree(c->dstatus); (void)hipFree(c->dqpiter); (void)hipFree(c->dqpstatus); (void)hipFree(c->dorder);
     if (c->dqpin) (void)hipFree(c->dqpin);
     (void)hipFree(c->ddbg); (void)hipFree(c->dprof); (void)hipFree(c->dws); (void)hipFree(c->dhws); (void)hipFree(c->drec); (void)hipFree(c->dcws); (void)hipFree(c->dvec);
@@ -809,6 +814,8 @@ static int resolve_kernel(tum_ocp *c)
 {
 #ifdef TUM_DEV_KERNELS
     c->pipe = !(c->ka.flags & 2) && c->kmode != 1;
+    if (c->ka.warm_mu > 0.0 && (c->kmode == 1 || c->kmode == 3))
+        return fail("solve: the development kernels 'fused' / 'pipeline4' always cold-start the interior point method: create the capsule with qp_warm_start = 0");
     if (c->N > NMAX) {      // the fused kernel covers N <= 40; longer horizons exist as a pipeline instantiation only
         if (c->ka.flags & 2) return fail("debug_dump: the condensed-QP dump is built for N <= 40");
         if (c->kmode == 1) return fail("solve: kernel 'fused' is built for N <= 40 (use 'auto' or 'pipeline')");
@@ -976,6 +983,7 @@ static int launch(tum_ocp *c, bool events = true)
         hipLaunchKernelGGL(snmpc_epilogue_kernel, dim3(c->batch), dim3(64), 0, c->stream, c->sa); c->xs_lazy = true;
     }
     else { if (prof) fused(nmpc_rti_kernel<true>); else fused(nmpc_rti_kernel<false>); }
+    if (!c->pipe) HIPCHK(hipMemsetAsync(c->dqplam, 0, sizeof(double) * (size_t)c->batch * (6 * (size_t)c->N + 2), c->stream));      // (the fused kernel leaves no multipliers behind)
 #else
     if (launch_pipeline(c, events)) return 1;
 #endif
@@ -1124,6 +1132,7 @@ extern "C" int tum_ocp_reset(tum_ocp *c)
     if (!c) return fail("null capsule");
     DevGuard guard(c->d.device); GUARD_OK(guard);
     c->cache_valid = false;
+    HIPCHK(hipMemsetAsync(c->dqplam, 0, sizeof(double) * (size_t)c->batch * (6 * (size_t)c->N + 2), c->stream));
     HIPCHK(hipMemsetAsync(c->dX, 0, sizeof(double) * (size_t)c->batch * (c->N + 1) * NX, c->stream));
     HIPCHK(hipMemsetAsync(c->dU, 0, sizeof(double) * (size_t)c->batch * c->N * NU, c->stream));
     if (c->sn) HIPCHK(hipMemsetAsync(c->dXS, 0, sizeof(double) * (size_t)c->batch * (c->N + 1) * c->sa.ns * NX, c->stream));
@@ -1138,7 +1147,7 @@ extern "C" int tum_ocp_cold_start(tum_ocp *c)
     DevGuard guard(c->d.device); GUARD_OK(guard);
     c->cache_valid = false;
     if (flush_inputs(c)) return 1;          // (the x0 it copies may still be in the pinned shadow)
-    hipLaunchKernelGGL(cold_start_kernel, dim3(c->batch), dim3(64), 0, c->stream, c->dX, c->dU, c->dx0, c->N, c->batch);
+    hipLaunchKernelGGL(cold_start_kernel, dim3(c->batch), dim3(64), 0, c->stream, c->dX, c->dU, c->dx0, c->N, c->batch, c->dqplam);
     if (c->sn && c->fanout && sn_fanout(c)) return 1;
     if (c->sn) hipLaunchKernelGGL(snmpc_cold_start_kernel, dim3(c->batch), dim3(256), 0, c->stream, c->dXS, c->dxs0, c->N, c->sa.ns, c->batch);
     if (c->sn) { HIPCHK(hipMemsetAsync(c->dxs_dirty, 0, sizeof(int) * (size_t)c->batch, c->stream)); c->xs_lazy = false; }

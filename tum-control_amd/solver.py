@@ -40,7 +40,8 @@ class TumOcpDesc(ctypes.Structure):
            ("ggv_v", ctypes.c_double * 16), ("ggv_ax", ctypes.c_double * 16), ("ggv_ay", ctypes.c_double * 16),
            ("qp_iter_max", ctypes.c_int),
            ("qp_tol_stat", ctypes.c_double), ("qp_tol_ineq", ctypes.c_double), ("qp_tol_comp", ctypes.c_double),
-           ("qp_mu0", ctypes.c_double), ("qp_t0", ctypes.c_double), ("store_qp_in", ctypes.c_int)]
+           ("qp_mu0", ctypes.c_double), ("qp_t0", ctypes.c_double), ("store_qp_in", ctypes.c_int),
+           ("qp_warm_start", ctypes.c_int), ("qp_warm_mu", ctypes.c_double)]
     )
 
 
@@ -149,7 +150,7 @@ def load_library(path=None):
 
 
 def make_desc(N, dt, nsub, batch, device=0, cfg=None, store_qp_in=False, qp_iter_max=50,
-              qp_tol=(1e-8, 1e-8, 1e-8), qp_mu0=0.05, qp_t0=0.05):
+              qp_tol=(1e-8, 1e-8, 1e-8), qp_mu0=0.05, qp_t0=0.05, qp_warm_start=True, qp_warm_mu=0.0):
     cfg = cfg or _config.default_config()
     d = TumOcpDesc()
     d.N, d.nsub, d.dt, d.batch, d.device = int(N), int(nsub), float(dt), int(batch), int(device)
@@ -170,6 +171,8 @@ def make_desc(N, dt, nsub, batch, device=0, cfg=None, store_qp_in=False, qp_iter
     d.qp_mu0 = float(qp_mu0)
     d.qp_t0 = float(qp_t0)
     d.store_qp_in = 1 if store_qp_in else 0
+    d.qp_warm_start = 1 if qp_warm_start else 0
+    d.qp_warm_mu = float(qp_warm_mu)
     return d
 
 
@@ -181,11 +184,14 @@ class BatchedOcpSolver:
     """`batch` independent copies of the nominal NMPC OCP on one MI355X; acados method names."""
 
     def __init__(self, N=38, dt=0.08, nsub=3, batch=1, device=0, cfg=None, store_qp_in=False,
-                 qp_iter_max=50, qp_tol=(1e-8, 1e-8, 1e-8), qp_mu0=0.05, qp_t0=0.05):
+                 qp_iter_max=50, qp_tol=(1e-8, 1e-8, 1e-8), qp_mu0=0.05, qp_t0=0.05, qp_warm_start=None, qp_warm_mu=0.0):
         self._L = load_library()
         self.N, self.dt, self.nsub, self.batch = int(N), float(dt), int(nsub), int(batch)
         self.cfg = cfg or _config.default_config()
-        self._desc = make_desc(N, dt, nsub, batch, device, self.cfg, store_qp_in, qp_iter_max, qp_tol, qp_mu0, qp_t0)
+        if qp_warm_start is None:
+            # (acados: qp_solver_warm_start) on by default; the development build's extra kernels always cold-start the method
+            qp_warm_start = (_default_path or LIB_PATH) != DEV_LIB_PATH
+        self._desc = make_desc(N, dt, nsub, batch, device, self.cfg, store_qp_in, qp_iter_max, qp_tol, qp_mu0, qp_t0, qp_warm_start, qp_warm_mu)
         self._h = self._L.tum_ocp_create(ctypes.byref(self._desc))
         if not self._h:
             raise RuntimeError("tum_ocp_create failed: " + self._err())
@@ -519,9 +525,9 @@ class CoupledSnmpcSolver(BatchedOcpSolver):
     """
 
     def __init__(self, N=38, dt=0.08, batch=1, Apce=None, uph=5, gamma=0.8, device=0, cfg=None,
-                 qp_iter_max=50, qp_tol=(1e-8, 1e-8, 1e-8), qp_mu0=0.05, qp_t0=0.05, x0_offsets=None):
+                 qp_iter_max=50, qp_tol=(1e-8, 1e-8, 1e-8), qp_mu0=0.05, qp_t0=0.05, x0_offsets=None, qp_warm_start=None, qp_warm_mu=0.0):
         super().__init__(N=N, dt=dt, nsub=1, batch=batch, device=device, cfg=cfg, qp_iter_max=qp_iter_max,
-                         qp_tol=qp_tol, qp_mu0=qp_mu0, qp_t0=qp_t0)
+                         qp_tol=qp_tol, qp_mu0=qp_mu0, qp_t0=qp_t0, qp_warm_start=qp_warm_start, qp_warm_mu=qp_warm_mu)
         self.Apce = np.ascontiguousarray(Apce, dtype=np.float64)
         if self.Apce.ndim != 2:
             raise Exception("CoupledSnmpcSolver: Apce must be (num_poly_terms, n_samples)")
