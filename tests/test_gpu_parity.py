@@ -713,9 +713,10 @@ def test_full_logged_loops_sets_13_16_batch_gpu(golden_dir):
 
 
 def test_exception_loops_per_solve_gpu(golden_dir):
-    """ALL six logged loops that hold the gate's exceptions (Monteblanco, weight sets 8, 10, 12, 13, 16, 21: every one of the
-    30 solves of the 283 615 comparable ones that deviates from its log by more than 1e-4, worst 8.2e-3 at set 21 step 3852)
-    through the HIP path PER SOLVE: one batch of six instances with per-instance weights, 5499 sequential warm-started
+    """ALL six logged loops that have ever held exceptions of the gate (Monteblanco, weight sets 8, 10, 12, 13, 16, 21: with the
+    interior point method cold-started every solve, rounds 3-4, 30 of the 283 615 comparable solves deviated from their log by more
+    than 1e-4, worst 8.2e-3 at set 21 step 3852; with its warm start, round 5, 13 on the sets 8, 12, 16, 21, worst 6.4e-3 at the
+    same step -- whatever the committed report lists is what is held here) through the HIP path PER SOLVE: one batch of six instances with per-instance weights, 5499 sequential warm-started
     real-time iterations. Held (a) to the logs with the gate of tests/golden/replay_full_logs.py -- 1e-4 scale-relative on
     every comparable solve outside the recorded exception steps -- and (b) to the CPU oracle replaying the same six loops
     beside it: on EVERY step, the exception steps included, the GPU's (u0, x1) equals the oracle's to 1e-6 scale-relative --
@@ -772,7 +773,6 @@ def test_exception_loops_per_solve_gpu(golden_dir):
         dev = R.solve_errors(U0[:, b], X1[:, b], OU[:, b], OX[:, b], sc)
         assert dev.max() < 1e-6, (k, int(dev.argmax()), float(dev.max()))
         entry = [r for r in rep["logs"] if r["track"] == "monteblanco" and r["k"] == k][0]
-        assert entry["exceptions"], k
         for e in entry["exceptions"]:
             nexc += 1
             assert dev[e["step"]] < 1e-6, (k, e["step"], float(dev[e["step"]]))
@@ -780,7 +780,9 @@ def test_exception_loops_per_solve_gpu(golden_dir):
             oerr = R.solve_errors(OU[e["step"]:e["step"] + 1, b], OX[e["step"]:e["step"] + 1, b], g[key + "_u0"][e["step"]:e["step"] + 1],
                                   g[key + "_x1"][e["step"]:e["step"] + 1], sc)[0]
             assert abs(oerr - e["err"]) <= 1e-6 + 0.05 * e["err"], (k, e["step"], oerr, e["err"])
-    assert nexc == 30
+    # every exception of the report sits in one of these six loops, i.e. has been through the HIP path and the oracle above
+    assert nexc == sum(len(r["exceptions"]) for r in rep["logs"]) and 0 < nexc <= 30
+    assert all(r["k"] in sets and r["track"] == "monteblanco" for r in rep["logs"] if r["exceptions"])
     worst = [r for r in rep["logs"] if r["track"] == "monteblanco" and r["k"] == 21][0]
     assert any(e["step"] == 3852 for e in worst["exceptions"])
 

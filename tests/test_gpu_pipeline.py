@@ -140,7 +140,7 @@ def test_pipeline_in_the_device_closed_loop(golden_dir):
     logs = {}
     for k in ("fused", "pipeline"):
         with _lib_for(k):
-            cl = ClosedLoopBatch("lvms", batch=4, N=38, Tp=3.04, on_device=True, log_capacity=80)
+            cl = ClosedLoopBatch("lvms", batch=4, N=38, Tp=3.04, on_device=True, log_capacity=80, qp_warm_start=False)      # (the fused kernel cold-starts the interior point method)
         cl.solver.set_kernel(k)
         logs[k] = cl.run(80)
         assert cl.dev.graph_steps == 25

@@ -502,8 +502,9 @@ def test_gpu_snmpc_longer_horizon_after_deferred_freeze():
     x0, yref = nominal_batch(B, N=N, seed=21)
     off = snm.x0_offsets(w, stds)
 
+    # (the second capsule is handed the ITERATE of the first, not the multipliers of its last QP: both cold-start the interior point method)
     def warm(uph0):
-        s = CoupledSnmpcSolver(N=N, batch=B, Apce=A, uph=uph0, gamma=0.8, x0_offsets=off)
+        s = CoupledSnmpcSolver(N=N, batch=B, Apce=A, uph=uph0, gamma=0.8, x0_offsets=off, qp_warm_start=False)
         s.install_reference_ocp(); s.set_x0(x0); s.set_yref_all(yref); s.cold_start()
         assert s.solve() == 0 and s.solve() == 0
         return s
@@ -517,7 +518,7 @@ def test_gpu_snmpc_longer_horizon_after_deferred_freeze():
     b = warm(5)
     stacked = [np.atleast_2d(b.get(k, "x")).copy() for k in range(N + 1)]
     U = b.get_iterate()[1].copy()
-    c = CoupledSnmpcSolver(N=N, batch=B, Apce=A, uph=9, gamma=0.8, x0_offsets=off)
+    c = CoupledSnmpcSolver(N=N, batch=B, Apce=A, uph=9, gamma=0.8, x0_offsets=off, qp_warm_start=False)
     c.install_reference_ocp(); c.set_x0(x0); c.set_yref_all(yref); c.cold_start()
     for k in range(N + 1):
         c.set(k, "x", stacked[k])
