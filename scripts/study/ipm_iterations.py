@@ -7,7 +7,7 @@ multipliers, or Gondzio's MULTIPLE CENTRALITY CORRECTORS, save interior point WO
   warm   the 52 complete logged acados closed loops, 285 948 warm-started real-time iterations, replayed per solve by
          tests/golden/replay_full_logs.py with its parity gate (the gate and its 30 exceptions must not get worse)
 
-Everything is run with the CPU oracle (oracle/nmpc_oracle.c, switches in ipm_opts; defaults = the shipped method). Work model, from
+Everything is run with the CPU oracle (oracle/nmpc_oracle.c, switches in ipm_opts; all switches 0 = the method as shipped until round 4; since round 5 the warm start "warm5-mu1e-2" is the default). Work model, from
 the measured phase split of ipm_kernel (profiles/r04_phase_cycles.txt): one factorisation (assembly + LDL') is half of a
 predictor-corrector iteration, one back-solve with its row phases a quarter:  work = 0.5 x factorisations + 0.25 x back-solves
 (a Mehrotra iteration = 1.0; an extra centrality corrector = 0.25). ADOPT only what saves >= 8 % of the work on both legs without
@@ -29,7 +29,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
 
 # name -> (warm variant, warm_mu, ncorr, dalpha)
 VARIANTS = {
-    "shipped":            (0, 0.0, 0, 0.0),
+    "round-4":            (0, 0.0, 0, 0.0),
     "corr1":              (0, 0.0, 1, 0.1),
     "corr2":              (0, 0.0, 2, 0.1),
     "corr1-d0.3":         (0, 0.0, 1, 0.3),
@@ -148,14 +148,14 @@ if __name__ == "__main__":
         t = time.time()
         c = cold_leg(cold_n, var) if (var[0] == 0 or len(var) > 5) else None          # (a cold start has no previous QP: the warm variants do not change it)
         w = warm_leg(logs, var, procs)
-        if nm == "shipped":
+        if nm == "round-4":
             base_c, base_w = c, w
         line = f"{nm:20s}"
         if c is not None:
             dev = np.abs(c["u0"] - base_c["u0"]).max() if base_c is not None else 0.0
-            line += f" cold: it {c['it']:.3f} (max {c['itmax']}) work {c['work']:.3f}" + (f" ({100 * (c['work'] / base_c['work'] - 1):+.1f} %)" if base_c else "") + f" ok {c['ok']:.4f} |du0| vs shipped {dev:.1e};"
+            line += f" cold: it {c['it']:.3f} (max {c['itmax']}) work {c['work']:.3f}" + (f" ({100 * (c['work'] / base_c['work'] - 1):+.1f} %)" if base_c else "") + f" ok {c['ok']:.4f} |du0| vs round-4 {dev:.1e};"
         else:
-            line += " cold: (= shipped);"
+            line += " cold: (= round-4);"
         line += (f" warm: it {w['it']:.3f} (max {w['itmax']}) work {w['work']:.3f}" + (f" ({100 * (w['work'] / base_w['work'] - 1):+.1f} %)" if base_w else "") +
                  f" above 1e-4: {w['n_above_tol']} above 1e-6: {w['n_above_1e6']} worst {w['worst']:.1e} exceptions {w['n_exc']}; {w['gate']}  [{time.time() - t:.0f} s]")
         print(line, flush=True)
