@@ -149,6 +149,9 @@ def parse_args(argv=None):
     ap.add_argument("--same-batch", action="store_true",
                     help="solve the SAME batch every step (batch 0; the longest-first dispatch then has exact history) instead of "
                          "rotating fresh batches: round 2's headline, kept for profiling the repeated-batch leg on its own")
+    ap.add_argument("--gather-iterate", action="store_true",
+                    help="the rooted gather carries the whole iterate as well (X, U: (N+1)*8 + N*2 doubles per instance behind the 40 B summary; "
+                         "SURVEY 8(e): 3264 B per instance at N = 40, 53 MB per GPU on config 4)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-host-legs", action="store_true", help="skip the host-visible legs (N=1 only)")
     ap.add_argument("--no-schedule-legs", action="store_true",
@@ -242,19 +245,24 @@ class Job:
         S = self.S = max(1, int(n_slots if n_slots is not None else args.streams))
         if self.cuda:
             self.streams = [torch.cuda.current_stream()] if S == 1 else [torch.cuda.Stream() for _ in range(S)]
-            self.ring = SolverRing(S, make, [st.cuda_stream for st in self.streams])
+            self.ring = SolverRing(S, make, [st.cuda_stream for st in self.streams], allow_unstable=True)      # (--streams 4, 6: the measurement of WHY the ring caps at three)
         else:
             self.streams = [None] * S
-            self.ring = SolverRing(S, make)
+            self.ring = SolverRing(S, make, allow_unstable=True)
         self.s = self.ring[0]
         self.spp = C["solves_per_step"]
         # result slab gathered to rank 0 each step: (u0[2], cost, status, qp_iter) as 5 doubles per instance, for config 3
         # followed by the PCE mean / variance of x_1 of every scenario group (16 doubles per group): ONE flat buffer, packed
         # on the device by the library, moved with ONE rooted gather. Shards of a strong-scaling job may differ by one group:
         # every rank sends the size of the LARGEST shard (the tail is padding).
+        # --gather-iterate: X ((N+1) x 8) and U (N x 2) of every instance follow, in two blocks sized for the LARGEST shard:
+        # [summary B x 5 | moments P x nmom | pad][X B x (N+1) x 8 | pad][U B x N x 2 | pad]
+        self.with_iterate = bool(getattr(args, "gather_iterate", False))
         self.slab_len = B * 5 + P * self.nmom
         mx = max((sharding.shard_range(groups_total, world, r)[1] - sharding.shard_range(groups_total, world, r)[0]) for r in range(world))
-        self.slab_pad = mx * gsz * 5 + mx * self.nmom
+        self.slab_head = mx * gsz * 5 + mx * self.nmom
+        self.off_X, self.off_U = self.slab_head, self.slab_head + mx * gsz * (N + 1) * 8
+        self.slab_pad = self.slab_head + (mx * gsz * ((N + 1) * 8 + N * 2) if self.with_iterate else 0)
         self.slabs = [torch.zeros(self.slab_pad, dtype=torch.float64, device=dev) for _ in range(S)]      # one per capsule
         self.gather = sharding.ResultGatherer(world, rank, 1, dev, nf=self.slab_pad, ni=1) if self.distributed else None
         # resident copies of the rotated batches
@@ -312,6 +320,8 @@ class Job:
             if marks is not None:
                 marks.append(self.clock.mark())
             s.get_device("summary", slab.data_ptr())
+            if self.with_iterate:
+                s.get_device("X", slab.data_ptr() + 8 * self.off_X); s.get_device("U", slab.data_ptr() + 8 * self.off_U)
             self.gather.gather(slab.view(1, -1))
             if marks is not None:
                 marks.append(self.clock.mark())
@@ -489,7 +499,9 @@ def run(args, torch, dist, dev, world, rank, local_rank, solver_factory, workloa
                                    "`value_single_stream` is the same loop on one capsule / one stream",
                    "parallelism": f"scenario groups sharded x{world} (a group never straddles ranks), RCCL gather of "
                                   f"{job.slab_pad * 8} B per rank (u0, cost, status, qp_iter"
-                                  + (", PCE mean/var of x_1 per group" if job.nmom else "") + "), one collective per step",
+                                  + (", PCE mean/var of x_1 per group" if job.nmom else "")
+                                  + (", the whole iterate X, U" if job.with_iterate else "") + "), one collective per step",
+                   "gather_iterate": job.with_iterate, "gather_bytes_per_rank": job.slab_pad * 8,
                    "schedule": "workgroups take instances longest-first by the previous solve's IPM iteration count "
                                "(tum_ocp_set_schedule): stale history when every step brings a new batch (`value`, "
                                "`value_single_stream`), exact when the same batch is solved again (`value_repeated_batch`)",

@@ -358,6 +358,12 @@ class _StandInSolver:
         self.res[:, 3] = 0.0; self.res[:, 4] = 5 + (np.arange(self.B) % 3)
 
     def get_device(self, field, ptr):
+        if field == "X":          # (--gather-iterate) a recognisable iterate: X[b, k, i] = x0[b, i] + k, U[b, k, j] = res[b, j] - k
+            self._view(ptr, self.B * (self.N + 1) * 8)[:] = (self.x0[:, None, :] + np.arange(self.N + 1)[None, :, None]).reshape(-1)
+            return
+        if field == "U":
+            self._view(ptr, self.B * self.N * 2)[:] = (self.res[:, None, :2] - np.arange(self.N)[None, :, None]).reshape(-1)
+            return
         assert field == "summary"
         self.calls["summary"] += 1
         self._view(ptr, self.B * 5)[:] = self.res.reshape(-1)
@@ -389,7 +395,7 @@ def _gloo_bench_worker(rank, world, port, out, argv):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("scaling", ["weak", "strong"])
+@pytest.mark.parametrize("scaling", ["weak", "strong", "weak+iterate"])
 def test_bench_control_flow_world2_gloo(scaling):
     """bench.py's own step / gather / timing control flow at world size 2 on CPU (gloo), with a stand-in solver: what the
     driver's first real multi-GPU run executes, minus the kernels. Weak scaling: every rank its share; strong scaling: a fixed
@@ -398,12 +404,14 @@ def test_bench_control_flow_world2_gloo(scaling):
     import torch.multiprocessing as mp
     from tum_control_amd.workloads import config_groups
     steps, warm, N = 3, 1, 6
+    with_iterate = scaling.endswith("+iterate")          # (--gather-iterate: X and U ride behind the summary in the same rooted gather)
+    scaling = scaling.split("+")[0]
     argv = ["--gpus", "2", "--steps", str(steps), "--warmup", str(warm), "--config", "4", "--horizon", str(N), "--no-cpu-baseline",
-            "--streams", "2"]
+            "--streams", "2"] + (["--gather-iterate"] if with_iterate else [])
     argv += ["--batch", "48"] if scaling == "weak" else ["--scaling", "strong", "--global-batch", "80"]
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 33500 + (os.getpid() % 2000) + (7 if scaling == "strong" else 0)
+    port = 33500 + (os.getpid() % 2000) + (7 if scaling == "strong" else 0) + (13 if with_iterate else 0)
     ps = [ctx.Process(target=_gloo_bench_worker, args=(r, 2, port, q, argv)) for r in range(2)]
     for p in ps:
         p.start()
@@ -425,7 +433,9 @@ def test_bench_control_flow_world2_gloo(scaling):
     assert calls == dict(cold=n, solve=n, put=2 * n, summary=n) and o["config"]["streams"] == 2
     assert [c["solve"] for c in per_slot] == [n - n // 2, n // 2]
     # what the root holds after the last step = the stand-in's results for the last rotated batch, in shard order
-    assert pad == 48 * 5 and allf.shape == (2, 1, pad)
+    per_inst = 5 + (((N + 1) * 8 + N * 2) if with_iterate else 0)
+    assert pad == 48 * per_inst and allf.shape == (2, 1, pad) and o["config"]["gather_iterate"] == with_iterate
+    assert o["config"]["gather_bytes_per_rank"] == 8 * pad
     variant = (steps - 1) % 4 + 1
     x0, _, _ = config_groups(4, 0, G, G, N=N, variant=variant)
     lo = 0
@@ -434,6 +444,11 @@ def test_bench_control_flow_world2_gloo(scaling):
         np.testing.assert_array_equal(got[:, 0:2], 2.0 * x0[lo:lo + sz, 3:5])
         np.testing.assert_allclose(got[:, 2], x0[lo:lo + sz].sum(axis=1), rtol=1e-15)
         assert (got[:, 3] == 0).all() and np.array_equal(got[:, 4], 5 + (np.arange(sz) % 3))
+        if with_iterate:          # X and U of the rank's shard behind the summary block (blocks sized for the largest shard: 48)
+            X = allf[r, 0, 48 * 5:48 * 5 + sz * (N + 1) * 8].reshape(sz, N + 1, 8)
+            U = allf[r, 0, 48 * 5 + 48 * (N + 1) * 8:48 * 5 + 48 * (N + 1) * 8 + sz * N * 2].reshape(sz, N, 2)
+            np.testing.assert_array_equal(X, x0[lo:lo + sz, None, :] + np.arange(N + 1)[None, :, None])
+            np.testing.assert_array_equal(U, got[:, None, :2] - np.arange(N)[None, :, None])
         lo += sz
 
 
@@ -482,6 +497,12 @@ def test_solver_ring_results_bookkeeping():
     assert list(ring.drain()) == [] and ring.take_results(2) is None
     with pytest.raises(ValueError):
         SolverRing(0, Fake)
+    # four or more capsules: measured unstable on the MI355X (streams share hardware queues) -> cut back to three, loudly
+    from tum_control_amd import streaming
+    with pytest.warns(UserWarning, match="3 created"):
+        r4 = SolverRing(4, Fake, streams=None)
+    assert len(r4) == streaming.MAX_STABLE_SLOTS == 3
+    assert len(SolverRing(5, Fake, allow_unstable=True)) == 5
 
 
 def test_external_cost_type_is_refused_loudly(monkeypatch):
