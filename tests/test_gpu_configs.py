@@ -292,8 +292,10 @@ def test_closed_loop_recovers_from_a_failed_solve(controller):
     np.testing.assert_allclose(dev["CiLX"][:, 0], ref["CiLX"][:, 0], rtol=1e-9, atol=1e-9)
 
 
-def test_bench_under_torchrun_world_size_1_rccl():
-    """The multi-GPU code path of bench.py on hardware, at world size 1: launched by torch.distributed.run like the driver's
+@pytest.mark.parametrize("iterate", [False, True])
+def test_bench_under_torchrun_world_size_1_rccl(iterate):
+    """(iterate: --gather-iterate, the whole iterate X, U -- 3264 B per instance, 53 MB for this shard -- rides in the same rooted
+    gather) The multi-GPU code path of bench.py on hardware, at world size 1: launched by torch.distributed.run like the driver's
     N > 1 runs (one rank per GPU), so `init_process_group("nccl")` (= RCCL), the device-packed result slab, the rooted
     `dist.gather` inside the timed region and the max-over-ranks `all_reduce` all run on the GPU -- everything of SURVEY 8(e)
     except a second rank. Config 4 (Monte-Carlo scenarios, LVMS) in its strong-scaling form with the 16384-instance share of
@@ -310,7 +312,7 @@ def test_bench_under_torchrun_world_size_1_rccl():
         env.pop(k, None)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "1", "--config", "4", "--scaling", "strong",
-           "--global-batch", "16384", "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-schedule-legs"]
+           "--global-batch", "16384", "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-schedule-legs"] + (["--gather-iterate"] if iterate else [])
     r = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{") and '"metric"' in ln]
@@ -322,6 +324,7 @@ def test_bench_under_torchrun_world_size_1_rccl():
     assert out["status_ok_frac"] == 1.0
     assert out["value"] > 1e5
     assert out["config"]["collective_backend"] == "nccl"          # (nccl IS RCCL on ROCm)
+    assert out["config"]["gather_iterate"] == iterate and out["config"]["gather_bytes_per_rank"] == 8 * 16384 * (5 + (41 * 8 + 40 * 2 if iterate else 0))
 
 
 def test_results_on_the_host_through_pinned_slabs():
