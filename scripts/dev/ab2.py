@@ -39,4 +39,5 @@ for r in range(ROUNDS):
     for i, s in enumerate(sol):
         s.cold_start(); s.solve(); ms[i].append(s.last_kernel_ms()); ipm[i].append(1e3 * s.get_stats("time_ipm"))
 for n, s, m, t in zip(names, sol, ms, ipm):
-    print(f"{n:40s} qp_iter {s.get_stats('qp_iter').mean():.3f} pipeline ms min {min(m):.4f} med {np.median(m):.4f} | ipm ms min {min(t):.4f} med {np.median(t):.4f}", flush=True)
+    rest = np.array(m) - np.array(t)
+    print(f"{n:40s} qp_iter {s.get_stats('qp_iter').mean():.3f} pipeline ms min {min(m):.4f} med {np.median(m):.4f} | ipm ms min {min(t):.4f} med {np.median(t):.4f} | lin + cond + expand ms min {rest.min():.4f} med {np.median(rest):.4f}", flush=True)

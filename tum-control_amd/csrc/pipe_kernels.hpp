@@ -263,10 +263,61 @@ __global__ void __launch_bounds__(64, 1) lin_cols_kernel(const PArgs pa)
 }
 
 // ---------------------------------------------------------------------------------------------------------------- K2
+// The stage record of the condensing kernel through the SCALAR data path: a record is wave-uniform data (every lane multiplies its
+// own column by the same 61 numbers), so it is read with s_load straight from the workspace into scalar registers -- the constant
+// address space makes the compiler emit scalar loads for these uniform addresses and fold the values into the FMAs as their one scalar
+// operand -- instead of being staged in LDS by the lanes and broadcast back to all of them with 25 ds_read per stage (rounds 2-4: the
+// LDS unit was busy for half of this kernel's cycles). Nothing in this kernel writes the records.
+#ifndef COND_SREC
+#define COND_SREC 0
+#endif
+#ifndef COND_WPS
+#define COND_WPS 2          // wavefronts per SIMD the five-tile condensing kernel is bounded to
+#endif
+#ifndef COND_PF
+#define COND_PF 0           // COND_SREC: the record two stages ahead is touched by a per-lane vector load (it is in L2 when the scalar loads ask for it)
+#endif
+typedef const double __attribute__((address_space(4))) cdbl_t;
+struct RecScalar {          // fields 0..51 of record k (A_k, B_k, b_k), fields 52.. of record k + 1 (residuals, gg row, delta of stage k + 1)
+    cdbl_t *a, *b;
+    __device__ __forceinline__ double operator[](int i) const { return (i < PR_RES) ? a[i] : b[i]; }
+};
+template <typename R>
+__device__ __forceinline__ void apply_A_rec(const R &rec, double w[8])
+{
+    double n[6];
+    n[0] = w[0] + rec[0] * w[2];
+    n[1] = w[1] + rec[1] * w[2];
+    n[2] = w[2];
+    n[3] = 0.0; n[4] = 0.0; n[5] = 0.0;
+#pragma unroll
+    for (int i = 0; i < 6; i++)
+#pragma unroll
+        for (int c = 0; c < 5; c++) n[i] += rec[2 + i * 7 + c] * w[3 + c];
+#pragma unroll
+    for (int i = 0; i < 6; i++) w[i] = n[i];
+}
+template <typename R>
+__device__ __forceinline__ void apply_A2_rec(const R &rec, double w[8], double v[8])
+{
+    const double sp0 = rec[0], sp1 = rec[1];
+    double n[6], m[6];
+    n[0] = w[0] + sp0 * w[2]; m[0] = v[0] + sp0 * v[2];
+    n[1] = w[1] + sp1 * w[2]; m[1] = v[1] + sp1 * v[2];
+    n[2] = w[2]; m[2] = v[2];
+    n[3] = 0.0; n[4] = 0.0; n[5] = 0.0; m[3] = 0.0; m[4] = 0.0; m[5] = 0.0;
+#pragma unroll
+    for (int i = 0; i < 6; i++)
+#pragma unroll
+        for (int c = 0; c < 5; c++) { const double sv = rec[2 + i * 7 + c]; n[i] += sv * w[3 + c]; m[i] += sv * v[3 + c]; }
+#pragma unroll
+    for (int i = 0; i < 6; i++) { w[i] = n[i]; v[i] = m[i]; }
+}
+
 // LDS of the condensing kernel (PD::C_*): stage record double buffer | 4 staging rows of the SYRK | g_s of the current stage |
 // iterate U | packed gg rows (staging for the operand layout)
 template <int NT_, bool SN>
-__global__ void __launch_bounds__(64, (NT_ == 5) ? 2 : 1) cond_kernel(const PArgs pa)
+__global__ void __launch_bounds__(64, (NT_ == 5) ? COND_WPS : 1) cond_kernel(const PArgs pa)
 {
     PD_LOCALS
     constexpr int C_REC = D::C_REC, C_STAGE = D::C_STAGE, C_GS = D::C_GS, C_U0 = D::C_U0, C_WT = D::C_WT;
@@ -291,11 +342,19 @@ __global__ void __launch_bounds__(64, (NT_ == 5) ? 2 : 1) cond_kernel(const PArg
     const int uph = SN ? ka.uph : 0;
     const int PP = SN ? sn_pro_pitch(uph) : 64, PSTAGE = 9 * PP;
     const double *gpro = SN ? ka.pro + (size_t)b * uph * PSTAGE : nullptr;
-    double pre = fetch(0);
     sU0[lane] = (lane < nv) ? gU[lane] : 0.0;
     if (lane < NB1) sU0[64 + lane] = (64 + lane < nv) ? gU[64 + lane] : 0.0;
+#if !COND_SREC
+    double pre = fetch(0);
     sRec[lane] = pre;
     if (N > 1) pre = fetch(1);
+#else
+    (void)fetch; (void)sRec;
+#if COND_PF
+    double pf = grec[(size_t)((N >= 2) ? 2 : N) * PREC + lane];
+    { const double t0_ = grec[lane], t1_ = grec[(size_t)((N >= 1) ? 1 : 0) * PREC + lane]; asm volatile("" :: "v"(t0_), "v"(t1_)); }
+#endif
+#endif
     wsync();
 
     const int j0 = lane >> 1, r0 = lane & 1, j1 = 32 + (lane >> 1);
@@ -336,7 +395,14 @@ __global__ void __launch_bounds__(64, (NT_ == 5) ? 2 : 1) cond_kernel(const PArg
             const int j0 = lane >> 1, r0 = lane & 1, j1 = 32 + (lane >> 1);
             const bool isg = (lane == NB1);
             const int lq = lane >> 4, lc = lane & 15;
+#if COND_SREC
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Wold-style-cast"
+            const RecScalar rec{(cdbl_t *)(grec + (size_t)k * PREC), (cdbl_t *)(grec + (size_t)(k + 1) * PREC)};
+#pragma clang diagnostic pop
+#else
             const double *rec = sRec + (k & 1) * PREC;
+#endif
             if (SN && k < uph) {
                 // stage s = k+1 <= uph: G_nom,s and g_nom,s are PCE means of the sample recursions (prologue kernel)
                 // (columns 0..63 in bank 0, 64..2 uph-1 on the lanes of bank 1, the constant column on the g lane)
@@ -353,7 +419,7 @@ __global__ void __launch_bounds__(64, (NT_ == 5) ? 2 : 1) cond_kernel(const PArg
                 }
             } else {
             if constexpr (G0) {
-                apply_A(rec, w0);
+                apply_A_rec(rec, w0);
                 const double sel0 = (j0 == k) ? 1.0 : 0.0, selg = (lane == 63) ? 1.0 : 0.0;
 #pragma unroll
                 for (int i = 0; i < 6; i++) w0[i] += sel0 * rec[2 + i * 7 + 5 + r0];
@@ -361,7 +427,7 @@ __global__ void __launch_bounds__(64, (NT_ == 5) ? 2 : 1) cond_kernel(const PArg
 #pragma unroll
                 for (int i = 0; i < 8; i++) w0[i] += selg * rec[44 + i];
             } else {
-            apply_A2(rec, w0, w1);
+            apply_A2_rec(rec, w0, w1);
             {
                 const double sel0 = (j0 == k) ? 1.0 : 0.0, sel1 = (lane < NB1 && j1 == k) ? 1.0 : 0.0, selg = isg ? 1.0 : 0.0;
 #pragma unroll
@@ -461,9 +527,14 @@ __global__ void __launch_bounds__(64, (NT_ == 5) ? 2 : 1) cond_kernel(const PArg
                     Ht[tidx(K, I)] = mfma(aop, bop[I], Ht[tidx(K, I)]);
                 }
             }
+#if !COND_SREC
             // next stage's record into the other slot (its global load has been in flight for a whole stage)
             sRec[((k + 1) & 1) * PREC + lane] = pre;
             if (k + 2 < N) pre = fetch(k + 2);
+#elif COND_PF
+            asm volatile("" :: "v"(pf));          // (the touch of the record two stages ahead has landed: the load is kept, its value is not used)
+            if (k + 3 <= N) pf = grec[(size_t)(k + 3) * PREC + lane];
+#endif
             wsync();
         };
         // stage s = k+1 touches columns < 2s, i.e. ceil(s/8) tiles: one instantiation of the stage per segment of 8 stages
