@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Do the four instantiations of the fused kernel of an OLDER build of libtumnmpc.so agree bit for bit?
    python scripts/probes/old_lib_check.py /path/to/libtumnmpc.so
-(used while chasing the wrong instrumented build of round 1: DESIGN.md, "An unexplained build failure"). Symbols the old
+(used while chasing the wrong instrumented build of round 1: HISTORY.md, "An unexplained build failure"). Symbols the old
 library lacks are replaced by no-ops so that today's binding loads it."""
 import ctypes, os, sys
 import numpy as np

@@ -210,7 +210,7 @@ def test_cabi_exports_every_declared_symbol():
 def test_shipped_kernels_resource_budget():
     """What the compiler reports for every kernel of the SHIPPED library (build() keeps the kernel-resource-usage remarks in
     libtumnmpc.so.resources): no kernel spills more than 64 SGPRs (the fused kernel's 129-158 went with an unexplained
-    miscompile, DESIGN §7 -- it lives in the development build only), scratch stays small everywhere, and the headline
+    miscompile, HISTORY.md (round-4 document, section 7) -- it lives in the development build only), scratch stays small everywhere, and the headline
     instantiation of the interior point kernel has no spills, no scratch and one wavefront per SIMD."""
     import shutil
     import subprocess

@@ -291,7 +291,7 @@ def _gpu_vs_oracle(golden_dir, N, uph, poses, nsolve=3, shift_ref=0, kernel=None
         cost = np.atleast_1d(s.get_cost())
         # Propagating the samples over more than ~30 stages makes the real-time iteration itself ill-conditioned: in the oracle
         # alone a 1e-9 perturbation of the iterate moves the NEXT solve by 2e-7 (uph = 33) / 2e-6 (uph = 38) against 1e-8 at
-        # uph = 5 (measured). The oracle therefore starts each warm iteration of a long propagation horizon
+        # uph = 5 (measured, HISTORY.md (round-4 document, section 2)). The oracle therefore starts each warm iteration of a long propagation horizon
         # from the GPU's iterate (below), so that nothing accumulates from the solves before -- and even on IDENTICAL inputs the
         # two implementations of a warm solve at uph = 38 end 1.9e-6 apart (measured on the box: the condensed QP of that
         # iterate is conditioned badly enough that two interior point runs that both stop at 1e-8 differ at that level). The
@@ -932,7 +932,7 @@ def test_gpu_snmpc_condensing_six_wavefronts_is_the_same_arithmetic(golden_dir, 
         assert np.array_equal(p, q)
     # the eight-lane linearisation differs from the one-lane kernel by FMA contraction (3e-15 on A_k, B_k); three solves later:
     # (a real-time iteration that propagates the samples over many stages amplifies a perturbation of its linearisation by two
-    #  orders of magnitude per solve, DESIGN section 2: 4.7e-8 measured at N = uph = 12 after three solves)
+    #  orders of magnitude per solve, HISTORY.md (round-4 document, section 2): 4.7e-8 measured at N = uph = 12 after three solves)
     tol = 1e-8 if uph <= 5 else (1e-6 if uph <= 31 else 1e-5)
     for i in (0, 1, 4):
         assert np.abs(out["large-batch kernels"][i] - out["cond-one-wavefront"][i]).max() < tol

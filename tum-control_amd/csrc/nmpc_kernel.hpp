@@ -1,7 +1,7 @@
 // nmpc_kernel.hpp -- the fused SQP-RTI kernel (one wavefront = one OCP instance).
 // DEVELOPMENT BUILD ONLY (-DTUM_DEV_KERNELS -> libtumnmpc_dev.so): round 1's kernel, kept as the second implementation the
 // pipeline is held against in the tests. The shipped library is the pipeline alone: this 115 KB kernel sits at the register
-// ceiling (129-158 spilled SGPRs; DESIGN.md "An unexplained build failure") and is not part of the product any more.
+// ceiling (129-158 spilled SGPRs; HISTORY.md, "An unexplained build failure") and is not part of the product any more.
 #pragma once
 #include <type_traits>
 
@@ -84,7 +84,7 @@ __global__ void __launch_bounds__(64, 1) nmpc_rti_kernel(const KArgs ka)
     const double dt = ka.dt;
     // The scalars of the interior point method are copied into vector registers here. As kernel arguments they would be
     // fetched through the kernel-argument base pointer where the IPM starts, and in the largest instantiation of this
-    // kernel exactly those late scalar loads once came out wrong ("An unexplained build failure").
+    // kernel exactly those late scalar loads once came out wrong (HISTORY.md, "An unexplained build failure").
     double p_mu0 = ka.mu0, p_t0 = ka.t0, p_reg = ka.reg, p_ts = ka.tol_stat, p_ti = ka.tol_ineq, p_tc = ka.tol_comp;
     int p_itmax = ka.iter_max;
     asm volatile("" : "+v"(p_mu0), "+v"(p_t0), "+v"(p_reg), "+v"(p_ts), "+v"(p_ti), "+v"(p_tc), "+v"(p_itmax));

@@ -12,7 +12,7 @@
 //                       rows, 26 KiB -- the gg rows live in registers in MFMA operand layout, H is streamed tile by tile from
 //                       the workspace (L2); the tile operands of the substitutions are read from LDS straight into accumulator
 //                       registers. (Built with -DIPM_WPS=2 the same source is bounded to 256 registers, two wavefronts per
-//                       SIMD: measured slower)
+//                       SIMD: measured slower, HISTORY.md (round-4 document, section 7).)
 //   K3' ipm4_kernel     (ipm4_kernel.hpp) the same method with FOUR wavefronts per OCP, each below 128 registers.
 //   K4  expand_kernel   one wavefront per OCP: dx recursion, full step, cost at the new iterate. For batches of at most one
 //                       round of resident wavefronts the nominal OCP runs it as the tail of K3 instead (ipm_kernel<., ., true>).
@@ -23,7 +23,7 @@
 #include "common_kernels.hpp"
 #include "snmpc_kernels.hpp"
 
-// wavefronts per SIMD the interior point kernel is bounded to (1: the whole register file; 2: an experiment build)
+// wavefronts per SIMD the interior point kernel is bounded to (1: the whole register file; 2: an experiment build, HISTORY.md (round-4 document, section 7))
 #ifndef IPM_WPS
 #define IPM_WPS 1
 #endif
@@ -1397,7 +1397,7 @@ __global__ void __launch_bounds__(64, IPM_WPS) ipm_kernel(const PArgs pa)
                 owed(2);
                 const double a00 = c01[0], a10 = c01[1], a20 = c23[0], a30 = c23[1], a21 = e23[0], a31 = e23[1], a22 = f23[0], a32 = f23[1];
 #ifdef TUM_EXP_PIV2
-                // (experiment, DESIGN section 7: the four pivots in TWO reciprocal levels instead of four -- 1/d1 = a00 / det(A[0:2,0:2])
+                // (experiment, HISTORY.md (round-4 document, section 7): the four pivots in TWO reciprocal levels instead of four -- 1/d1 = a00 / det(A[0:2,0:2])
                 //  beside 1/d0, 1/d3 = d2 / det of the 2x2 Schur block beside 1/d2)
                 const double d0 = a00, i0 = frcp(d0);
                 const double det2 = fma(a00, a11, -(a10 * a10)), r2 = frcp(det2);

@@ -463,7 +463,7 @@ __global__ void __launch_bounds__(64) snmpc_prologue_kernel(const SnArgs sa)
 // the output of a product is the input of the next stage's. The A operand of block (rb, kb) is the SAME for all columns: lane
 // (q, x) reads entry (4 rb + x, 4 kb + q) of the sample's 8 x 8 stage matrix straight out of the compact record in LDS (the
 // structural zeros, ones and dt are three constants appended to the record's image, so it is a plain load at a lane-constant
-// offset): FOUR LDS reads per (stage, sample) where a lane-per-column kernel (built first in this round) needs 45
+// offset): FOUR LDS reads per (stage, sample) where a lane-per-column kernel (built first in round 4, HISTORY.md) needs 45
 // broadcasts and is bound by its LDS instructions. And the matrix instructions only run over the column groups that hold a live column
 // (stage k has 2 k + 3: one group of 16 for the first seven stages, two for the next eight, ...), which a lane mapping cannot
 // do. Per (stage, sample, group): 4 products (2 x 2 blocks of the 8 x 8 matrix), the input column, the PCE mean and the chance row

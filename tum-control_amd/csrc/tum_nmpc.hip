@@ -871,7 +871,7 @@ static bool lin_ahead_ok(const tum_ocp *c)
     static const int fork_env = [] { const char *e = getenv("TUM_SIM_FORK"); return e ? atoi(e) : -1; }();
     const int want = (c->sim_fork >= 0) ? c->sim_fork : fork_env;
     // (off unless asked for: measured SLOWER -- 0.169 against 0.160 ms per control step at 26 vehicles, 0.158-0.162 against 0.156 at one:
-    //  the two cross-stream dependencies of a step cost more than the 15 us of planner the linearisation hides behind)
+    //  the two cross-stream dependencies of a step cost more than the 15 us of planner the linearisation hides behind; HISTORY.md (round-4 document, section 7))
     return want > 0 && c->pipe && !c->sn && !(c->ka.flags & 6) && use_lin_cols(c) && use_cond_wide(c);
 }
 static void launch_lin_ahead(tum_ocp *c, hipStream_t st)

@@ -68,7 +68,7 @@ def acados_settings(Tf, N, x0, Q, R, Qe, L1_pen, L2_pen, ax_max_interpolant=None
     if combined_acc_limits != 2:
         # 0 / 1 have two h rows per stage; in the reference itself they cannot construct a solver: the stage-0 slack
         # penalties are sized nh + 0 (NMPC_STM_acados_settings.py:192-198) while stage 0 has exactly one soft constraint
-        # (ns_0 = 1), so the sizes only agree for nh = 1, the shipped variant 2 (DESIGN.md, section 1)
+        # (ns_0 = 1), so the sizes only agree for nh = 1, the shipped variant 2 (DESIGN.md, section 0)
         raise NotImplementedError("only combined_acc_limits == 2 (circle), the shipped variant, is built")
     cfg = cfg or _config.default_config()
     veh = cfg["veh"]
