@@ -99,9 +99,11 @@ def load_library(path=None):
     L.tum_ocp_free.restype = None; L.tum_ocp_free.argtypes = [vp]
     L.tum_ocp_last_error.restype = cs; L.tum_ocp_last_error.argtypes = []
     L.tum_ocp_batch.argtypes = [vp]; L.tum_ocp_horizon.argtypes = [vp]
+    # (the data pointer of the per-call setters / getters goes over as a plain address -- `a.ctypes.data` -- : building a typed ctypes
+    #  pointer per call costs 1.9 us, twice the rest of a call; the reference issues 83 of them per control step)
     for name in ("tum_ocp_set", "tum_ocp_constraints_set", "tum_ocp_cost_set"):
-        getattr(L, name).argtypes = [vp, ci, cs, dp, ci, ci, ci, ci]
-    L.tum_ocp_get.argtypes = [vp, ci, cs, dp, ci, ci, ci, ci]
+        getattr(L, name).argtypes = [vp, ci, cs, vp, ci, ci, ci, ci]
+    L.tum_ocp_get.argtypes = [vp, ci, cs, vp, ci, ci, ci, ci]
     L.tum_ocp_get_from_qp_in.argtypes = [vp, ci, cs, dp, ci, ci, ci, ci]
     L.tum_ocp_solve.argtypes = [vp]; L.tum_ocp_solve_async.argtypes = [vp]; L.tum_ocp_synchronize.argtypes = [vp]
     L.tum_ocp_get_cost.argtypes = [vp, dp, ci, ci]
@@ -180,6 +182,9 @@ def _dp(a):
     return a.ctypes.data_as(ctypes.POINTER(ctypes.c_double))
 
 
+_FIELD_BYTES = {}          # field name -> bytes, encoded once
+
+
 class BatchedOcpSolver:
     """`batch` independent copies of the nominal NMPC OCP on one MI355X; acados method names."""
 
@@ -216,18 +221,18 @@ class BatchedOcpSolver:
 
     def _put(self, fn, stage, field, value, what):
         v = np.ascontiguousarray(value, dtype=np.float64)
+        fb = _FIELD_BYTES.get(field) or _FIELD_BYTES.setdefault(field, field.encode())
         if v.ndim >= 2 and v.shape[0] == self.batch and self.batch > 1:
             v = v.reshape(self.batch, -1)
             ln = v.shape[1]
-            self._chk(fn(self._h, stage, field.encode(), _dp(v), ln, 0, self.batch, ln), what)
+            self._chk(fn(self._h, stage, fb, v.ctypes.data, ln, 0, self.batch, ln), what)
         else:
             scalar_field = field in ("uh", "lh", "lbu", "ubu") or (field in ("lbx", "ubx") and stage != 0)
             if self.batch > 1 and v.ndim >= 1 and v.shape[0] == self.batch and scalar_field:   # one value per instance
                 v = v.reshape(self.batch, 1)
-                self._chk(fn(self._h, stage, field.encode(), _dp(v), 1, 0, self.batch, 1), what)
+                self._chk(fn(self._h, stage, fb, v.ctypes.data, 1, 0, self.batch, 1), what)
                 return
-            v = v.reshape(-1)
-            self._chk(fn(self._h, stage, field.encode(), _dp(v), v.size, 0, self.batch, 0), what)
+            self._chk(fn(self._h, stage, fb, v.ctypes.data, v.size, 0, self.batch, 0), what)
 
     def _out(self, a):
         return a[0] if self.batch == 1 else a
@@ -248,9 +253,10 @@ class BatchedOcpSolver:
             ln = 1 if stage == 0 else (2 if stage == N else 3)
         else:
             raise Exception(f"BatchedOcpSolver.get: unknown field '{field}'")
-        out = np.zeros((self.batch, ln))
-        self._chk(self._L.tum_ocp_get(self._h, stage, field.encode(), _dp(out), ln, 0, self.batch, ln), "get")
-        return self._out(out)
+        out = np.empty((self.batch, ln))
+        fb = _FIELD_BYTES.get(field) or _FIELD_BYTES.setdefault(field, field.encode())
+        self._chk(self._L.tum_ocp_get(self._h, stage, fb, out.ctypes.data, ln, 0, self.batch, ln), "get")
+        return out[0] if self.batch == 1 else out
 
     def constraints_set(self, stage, field, value):
         self._put(self._L.tum_ocp_constraints_set, stage, field, value, "constraints_set")
@@ -336,8 +342,8 @@ class BatchedOcpSolver:
     def get_iterate(self):
         N = self.N
         X = np.zeros((self.batch, (N + 1) * 8)); U = np.zeros((self.batch, N * 2))
-        self._chk(self._L.tum_ocp_get(self._h, ALL_STAGES, b"x", _dp(X), X.shape[1], 0, self.batch, X.shape[1]), "get")
-        self._chk(self._L.tum_ocp_get(self._h, ALL_STAGES, b"u", _dp(U), U.shape[1], 0, self.batch, U.shape[1]), "get")
+        self._chk(self._L.tum_ocp_get(self._h, ALL_STAGES, b"x", X.ctypes.data, X.shape[1], 0, self.batch, X.shape[1]), "get")
+        self._chk(self._L.tum_ocp_get(self._h, ALL_STAGES, b"u", U.ctypes.data, U.shape[1], 0, self.batch, U.shape[1]), "get")
         return X.reshape(self.batch, N + 1, 8), U.reshape(self.batch, N, 2)
 
     def cold_start(self):
@@ -555,14 +561,14 @@ class CoupledSnmpcSolver(BatchedOcpSolver):
             if v.size != self.L * self.ns + 2:
                 raise Exception(f"CoupledSnmpcSolver.set: mismatching dimension for field \"p\" with dimension "
                                 f"{self.L * self.ns + 2} (you have {v.size})")
-            self._chk(self._L.tum_ocp_set(self._h, int(stage), b"p", _dp(v), v.size, 0, self.batch, 0), "set")
+            self._chk(self._L.tum_ocp_set(self._h, int(stage), b"p", v.ctypes.data, v.size, 0, self.batch, 0), "set")
             return
         super().set(stage, field, value)
 
     def get(self, stage, field):
         if field == "x":
             out = np.zeros((self.batch, self.nx))
-            self._chk(self._L.tum_ocp_get(self._h, stage, b"x", _dp(out), self.nx, 0, self.batch, self.nx), "get")
+            self._chk(self._L.tum_ocp_get(self._h, stage, b"x", out.ctypes.data, self.nx, 0, self.batch, self.nx), "get")
             return self._out(out)
         return super().get(stage, field)
 
