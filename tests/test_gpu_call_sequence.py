@@ -294,3 +294,35 @@ def test_per_stage_setters_wait_in_the_shadow_in_order(golden_dir):
     assert np.array_equal(a.get_iterate()[0], b.get_iterate()[0])
     a.solve(); b.set_x0(x0 + 0.03); b.solve()
     assert np.array_equal(a.get_iterate()[0], b.get_iterate()[0])
+
+
+def test_snmpc_eight_value_initial_state_through_the_shadow(golden_dir):
+    """A coupled SNMPC capsule with registered sample offsets takes the 8 nominal values at lbx_0 / ubx_0 and fans them out on the
+    device; on a small capsule that setter is parked in the pinned shadow like the nominal one. Against a capsule that is given the
+    stacked 88 values (uploaded at once), over warm steps; then the stacked form again on the first capsule (fan-out switched off)."""
+    from tum_control_amd import config, snmpc as snm
+    from tum_control_amd.solver import CoupledSnmpcSolver
+    stds = np.asarray(config.MPC["stds"], dtype=float)
+    w = snm.hammersley_normal(10, 3); A = snm.pce_matrix(w, snm.alpha_generation(3, 2)); offs = snm.x0_offsets(w, stds)
+    d = dict(np.load(os.path.join(golden_dir, "kat0.npz")))
+    N, B = 38, 2
+    x0 = np.stack([d["x0"][0], d["x0"][30]]); Y = np.zeros((B, N + 1, 6)); Y[0, :, :4] = d["yref"][0]; Y[1, :, :4] = d["yref"][30]
+    stack = lambda x: np.stack([snm.compute_x0dist(x[j], w, stds) for j in range(B)]).reshape(B, -1)
+    sol = []
+    for _ in range(2):
+        s = CoupledSnmpcSolver(N=N, dt=0.08, batch=B, Apce=A, uph=5, gamma=0.8, x0_offsets=offs)
+        s.install_reference_ocp()
+        s.constraints_set(0, "lbx", stack(x0)); s.constraints_set(0, "ubx", stack(x0)); s.set_yref_all(Y); s.cold_start()
+        sol.append(s)
+    a, b = sol
+    for k in range(4):
+        xk = x0 + 0.01 * k * np.array([1, -1, 0.1, 1, 0.1, 0.02, 0.01, 0.1])
+        if k < 3:
+            a.constraints_set(0, "lbx", xk); a.constraints_set(0, "ubx", xk)                    # 8 values: shadow + fan-out kernel
+        else:
+            a.constraints_set(0, "lbx", stack(xk)); a.constraints_set(0, "ubx", stack(xk))      # back to explicit samples
+        b.constraints_set(0, "lbx", stack(xk)); b.constraints_set(0, "ubx", stack(xk))
+        assert a.solve() == b.solve() == 0
+        assert all(np.array_equal(p, q) for p, q in zip(a.get_iterate(), b.get_iterate()))
+        for j in (0, 3, 9, N):
+            assert np.array_equal(a.get(j, "x"), b.get(j, "x"))          # the stacked 88-value state (cached read-back on both)
