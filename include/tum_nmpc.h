@@ -61,7 +61,8 @@ typedef struct tum_ocp_desc {
     int store_qp_in;       /* keep A_k,B_k,b_k of the last linearisation for tum_ocp_get_from_qp_in */
     /* acados: qp_solver_warm_start (1 in Stochastic_NMPC/SNMPC_acados_settings.py:307, unset = 0 for the nominal solver). != 0: in a
      * sequence of solves the interior point method of an instance starts from the multipliers and violation slacks its previous QP
-     * ended with -- when that QP converged; tum_ocp_cold_start / tum_ocp_reset forget them -- pushed back into the interior and
+     * ended with -- when that QP converged and the new problem is close to it (at most 16 row sides changed their activity, no new
+     * violation above 0.1; otherwise it starts cold); tum_ocp_cold_start / tum_ocp_reset forget them -- pushed back into the interior and
      * re-centred to the complementarity target qp_warm_mu (0: the default 1e-2). The QP solution is the same to the solver's
      * tolerances; 9 % fewer interior point iterations over the reference's logged closed loops (profiles/r05_ipm_iterations.txt).
      * The Python binding switches it on by default. */

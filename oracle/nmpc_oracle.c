@@ -249,6 +249,18 @@ typedef struct {
     int ncorr;            /* Gondzio multiple centrality correctors per iteration (extra back-solves on the same factorisation) */
     double corr_beta_lo, corr_beta_hi, corr_dalpha, corr_gain;   /* their usual constants: 0.1, 10, 0.1 (0.3), 1.01 */
     long solves, factorisations, backsolves;                     /* work counters of the study (accumulated by qp_ipm) */
+    /* how far the previous QP's final point is from the new problem (computed when a warm start is offered, study + safeguard):
+     * [0] max lam_prev * margin_new over the rows (old multipliers on rows that are inactive now), [1] the largest new violation beyond
+     * the old slack, [2] max |lam_prev|, [3] the number of rows whose activity differs */
+    double warm_meas[4];
+    double warm_gate[2];  /* study: a warm start is used only if warm_meas[0] <= warm_gate[0] and warm_meas[1] <= warm_gate[1] (0: no gate) */
+    int warm_flips;       /* safeguard (shipped: IPM_WARM_FLIPS_DEFAULT, together with warm_gate[1] = IPM_WARM_VIOL_DEFAULT): the warm start is used
+                           * only if at most this many row sides changed their activity between the previous QP's solution and the new problem
+                           * (warm_meas[3]) and no row is violated by more than warm_gate[1] beyond its old slack (warm_meas[1]); < 0: no gate.
+                           * Consecutive QPs of a closed loop differ in 0-2 row sides (99 % of the logged solves pass), a real-time iteration
+                           * sequence whose initial state jumps differs in dozens -- there the stale multipliers cost iterations (8.55 against
+                           * 8.09 cold) and can stall the method at its iteration cap; gated: 7.91 (scripts/study/warm_gate.py) */
+    int warm_used;        /* out: did the last QP start warm */
 } ipm_opts;
 
 typedef struct {
@@ -311,6 +323,8 @@ void oracle_global_work(long *out, int reset)
  * QP of the same OCP converged; a cold start (no previous QP) is untouched. oracle_set_ipm_experiment(o, 0, ...) switches it off. */
 #define IPM_WARM_DEFAULT 5
 #define IPM_WARM_MU_DEFAULT 1e-2
+#define IPM_WARM_FLIPS_DEFAULT 16
+#define IPM_WARM_VIOL_DEFAULT 0.1
 static void qp_ipm(int nv, int m, const double *H, const double *q, const double *C, const double *d,
                    const double *lb, const double *ub,
                    const double *zl, const double *zu, const double *Zl, const double *Zu,
@@ -349,7 +363,23 @@ static void qp_ipm(int nv, int m, const double *H, const double *q, const double
             }
         }
     }
-    const int warm = (opt->warm > 0 && s_warm && lam_warm) ? opt->warm : 0;
+    int warm = (opt->warm > 0 && s_warm && lam_warm) ? opt->warm : 0;
+    if (warm) {
+        double m0 = 0.0, m1 = 0.0, m2 = 0.0, m3 = 0.0;
+        for (int k = 0; k < M2; k++) {
+            int i = k % m;
+            double r0 = eps[k] * (d[i] + (e0 ? e0[i] : 0.0) - bnd[k]);
+            double a = lam_warm[k] * (r0 > 0.0 ? r0 : 0.0), b = -r0 - s_warm[k];
+            if (a > m0) m0 = a;
+            if (b > m1) m1 = b;
+            if (lam_warm[k] > m2) m2 = lam_warm[k];
+            if ((lam_warm[k] > 1e-3) != (r0 + s_warm[k] < 1e-3)) m3 += 1.0;
+        }
+        opt->warm_meas[0] = m0; opt->warm_meas[1] = m1; opt->warm_meas[2] = m2; opt->warm_meas[3] = m3;
+        if ((opt->warm_gate[0] > 0.0 && m0 > opt->warm_gate[0]) || (opt->warm_gate[1] > 0.0 && m1 > opt->warm_gate[1])) warm = 0;
+        if (opt->warm_flips >= 0 && m3 > (double)opt->warm_flips) warm = 0;
+    }
+    opt->warm_used = warm != 0;
     for (int k = 0; k < M2; k++) {
         int i = k % m;
         double r0 = eps[k] * (d[i] + (e0 ? e0[i] : 0.0) - bnd[k]);       /* >= 0 : satisfied at the starting v */
@@ -636,7 +666,7 @@ oracle_ocp *oracle_create(int N, double dt, int nsub)
     o->ipm.iter_max = 50; o->ipm.tol_stat = 1e-8; o->ipm.tol_ineq = 1e-8; o->ipm.tol_comp = 1e-8;
     o->ipm.mu0 = 0.05; o->ipm.t0 = 0.05; o->ipm.reg = 0.0;
     o->ipm.corr_beta_lo = 0.1; o->ipm.corr_beta_hi = 10.0; o->ipm.corr_dalpha = 0.1; o->ipm.corr_gain = 1.01;
-    o->ipm.warm = IPM_WARM_DEFAULT; o->ipm.warm_mu = IPM_WARM_MU_DEFAULT;
+    o->ipm.warm = IPM_WARM_DEFAULT; o->ipm.warm_mu = IPM_WARM_MU_DEFAULT; o->ipm.warm_flips = IPM_WARM_FLIPS_DEFAULT; o->ipm.warm_gate[1] = IPM_WARM_VIOL_DEFAULT;
     return o;
 }
 /* the multipliers of the last QP no longer belong to this OCP's next solve (cold start, reset) */
@@ -644,6 +674,9 @@ void oracle_forget_qp(oracle_ocp *o) { o->have_qp = 0; }
 /* iteration-count experiments (ipm_opts): warm-start variant, its complementarity target, number of centrality correctors */
 void oracle_set_ipm_vstart(oracle_ocp *o, int vstart, double qthr) { o->ipm.vstart = vstart; o->ipm.vstart_q = qthr; }
 void oracle_set_ipm_split(oracle_ocp *o, int split) { o->ipm.split = split; }
+void oracle_set_warm_gate(oracle_ocp *o, double g0, double g1) { o->ipm.warm_gate[0] = g0; o->ipm.warm_gate[1] = g1; }
+void oracle_set_warm_flips(oracle_ocp *o, int flips) { o->ipm.warm_flips = flips; }
+void oracle_warm_meas(oracle_ocp *o, double *out) { for (int i = 0; i < 4; i++) out[i] = o->ipm.warm_meas[i]; out[4] = o->ipm.warm_used; }
 void oracle_set_ipm_experiment(oracle_ocp *o, int warm, double warm_mu, int ncorr, double dalpha)
 {
     o->ipm.warm = warm; if (warm_mu > 0) o->ipm.warm_mu = warm_mu; o->ipm.ncorr = ncorr; if (dalpha > 0) o->ipm.corr_dalpha = dalpha;
@@ -943,7 +976,7 @@ snmpc_ocp *snmpc_create(int N, double dt, int ns, int L, double gamma)
     o->kappa = sqrt((1.0 - gamma) / gamma);          /* SNMPC_acados_settings.py:187 */
     o->ipm.iter_max = 50; o->ipm.tol_stat = 1e-8; o->ipm.tol_ineq = 1e-8; o->ipm.tol_comp = 1e-8;
     o->ipm.mu0 = 0.05; o->ipm.t0 = 0.05; o->ipm.reg = 0.0;
-    o->ipm.warm = IPM_WARM_DEFAULT; o->ipm.warm_mu = IPM_WARM_MU_DEFAULT;
+    o->ipm.warm = IPM_WARM_DEFAULT; o->ipm.warm_mu = IPM_WARM_MU_DEFAULT; o->ipm.warm_flips = IPM_WARM_FLIPS_DEFAULT; o->ipm.warm_gate[1] = IPM_WARM_VIOL_DEFAULT;
     return o;
 }
 void snmpc_forget_qp(snmpc_ocp *o) { o->have_qp = 0; }

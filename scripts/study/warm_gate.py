@@ -1,0 +1,76 @@
+#!/usr/bin/env python3
+"""When does the interior point warm start pay? For every solve of (a) logged closed loops and (b) the synthetic 'moving x0, unshifted iterate'
+sequence of tests/test_gpu_pipeline.py, the SAME QP is solved warm (previous multipliers) and cold; recorded: both iteration counts and the
+proximity measures of qp_ipm (warm_meas). Output: iteration totals under the rule 'warm only if meas0 <= g0 and meas1 <= g1'."""
+import os, sys, ctypes
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+from oracle.oracle import OracleOcp, lib
+from tum_control_amd import config
+from tum_control_amd.workloads import nominal_batch
+
+L = lib()
+L.oracle_warm_meas.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_double)]
+L.oracle_set_warm_flips.argtypes = [ctypes.c_void_p, ctypes.c_int]
+def meas(o):
+    out = (ctypes.c_double * 5)(); L.oracle_warm_meas(o._h, out); return list(out)
+
+def pair(N):
+    m = config.MPC
+    os_ = []
+    for w in (True, False):
+        o = OracleOcp(N, 0.08, 3)
+        o.set_weights(m["q_lon"], m["q_yaw"], m["q_vel"], m["r_jerk"], m["r_steering_rate"], m["L1_pen"], m["L2_pen"], scale=0.01)
+        o.qp_warm_start(w); L.oracle_set_warm_flips(o._h, -1); os_.append(o)          # (study: the warm side ALWAYS warm-starts)
+    return os_
+
+rows = []          # regime, it_warm, it_cold, m0, m1, m2, m3
+# (b) synthetic sequence
+x0, yref = nominal_batch(512, N=40, seed=9)
+for b in range(0, 512, 4):
+    ow, oc = pair(40)
+    for o in (ow, oc):
+        o.cold_start(x0[b]); o.yref[:] = yref[b]
+    ow.solve(); oc.solve()
+    for k in range(5):
+        oc.X[:] = ow.X; oc.U[:] = ow.U
+        for o in (ow, oc):
+            o.x0[:] = ow.X[1]
+        ow.solve(); oc.solve()
+        rows.append(["synthetic", ow.qp_iter, oc.qp_iter] + meas(ow)[:4])
+# (a) logged loops (subset of steps)
+import replay_full_logs as R
+from tum_control_amd.planner import load_track, planner_emulator, yref_from_ref
+F = np.loadtxt(R.FCSV, delimiter=",")
+for track, k in (("monteblanco", 0), ("lvms", 0), ("monteblanco", 13), ("lvms", 16), ("monteblanco", 21)):
+    g = R.log_inputs(track, k); tr = load_track(track)
+    ow, oc = OracleOcp(38, 0.08, 3), OracleOcp(38, 0.08, 3)
+    for o, w in ((ow, True), (oc, False)):
+        o.set_weights(*F[k]); o.qp_warm_start(w); L.oracle_set_warm_flips(o._h, -1)
+    for i in range(0, 1500):
+        _, ref = planner_emulator(tr, g["pose"][i], 39, 3.04, True)
+        y = yref_from_ref(ref, 38)
+        if i == 0:
+            ow.cold_start(g["x0"][0])
+        oc.X[:] = ow.X; oc.U[:] = ow.U
+        for o in (ow, oc):
+            o.x0[:] = g["x0"][i]; o.yref[:] = y
+        ow.solve(); oc.solve()
+        if i:
+            rows.append([f"log", ow.qp_iter, oc.qp_iter] + meas(ow)[:4])
+A = np.array([r[1:] for r in rows], dtype=float); reg = np.array([r[0] for r in rows])
+for name in ("synthetic", "log"):
+    S = A[reg == name]
+    print(f"{name}: {len(S)} solves; always warm {S[:,0].mean():.3f}, always cold {S[:,1].mean():.3f}, oracle choice (min) {np.minimum(S[:,0],S[:,1]).mean():.3f}; "
+          f"meas0 quantiles {np.quantile(S[:,2],[.5,.9,.99]).round(4)}, meas1 {np.quantile(S[:,3],[.5,.9,.99]).round(4)}, maxlam {np.quantile(S[:,4],[.5,.9,.99]).round(3)}, flips {np.quantile(S[:,5],[.5,.9,.99])}")
+print("rule: warm iff meas0 <= g0 and meas1 <= g1 and flips <= f  -> mean iterations synthetic | log (warm fraction)")
+for g0 in (1e9,):
+    for g1 in (1e-1, 1e9):
+        for f in (2, 6, 10, 16, 24, 1e9):
+            out = []
+            for name in ("synthetic", "log"):
+                S = A[reg == name]
+                w = (S[:, 2] <= g0) & (S[:, 3] <= g1) & (S[:, 5] <= f)
+                out.append((np.where(w, S[:, 0], S[:, 1]).mean(), w.mean(), np.where(w, S[:, 0], S[:, 1]).max()))
+            print(f"g0 {g0:7.0e} g1 {g1:7.0e} flips {f:5.0e}: {out[0][0]:.3f} ({out[0][1]:.2f}, max {out[0][2]:.0f}) | {out[1][0]:.3f} ({out[1][1]:.2f}, max {out[1][2]:.0f})")

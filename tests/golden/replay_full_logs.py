@@ -131,6 +131,11 @@ def replay_log(args):
     if os.environ.get("REPLAY_IPM"):          # (iteration-count experiments, scripts/study/ipm_iterations.py: "warm,warm_mu,ncorr,dalpha")
         w, wmu, nc, da = os.environ["REPLAY_IPM"].split(",")
         o.set_ipm_experiment(int(w), float(wmu), int(nc), float(da))
+    if os.environ.get("REPLAY_FLIPS"):          # (same study: the activity-change gate of the warm start; -1 = always warm)
+        from oracle.oracle import lib as _lib
+        import ctypes as _ct
+        _lib().oracle_set_warm_flips.argtypes = [_ct.c_void_p, _ct.c_int]
+        _lib().oracle_set_warm_flips(o._h, int(os.environ["REPLAY_FLIPS"]))
     if os.environ.get("REPLAY_SPLIT"):
         o.set_ipm_split(int(os.environ["REPLAY_SPLIT"]))
     if os.environ.get("REPLAY_VSTART"):

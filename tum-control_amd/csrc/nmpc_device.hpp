@@ -120,6 +120,9 @@ struct KArgs {
     // start (0: always cold)
     double *qp_lam;                                   // [b][6N + 2]
     double warm_mu;
+    // safeguard of the warm start: used only when at most warm_flips row sides changed their activity between the previous QP's solution
+    // and the new problem and no row is violated by more than warm_viol beyond its old slack (warm_flips < 0: always)
+    int warm_flips; double warm_viol;
 };
 
 // ---------------------------------------------------------------- wave helpers

@@ -1118,7 +1118,38 @@ __global__ void __launch_bounds__(64, IPM_WPS) ipm_kernel(const PArgs pa)
             // the slack-equation bound), the row pushed off the boundary to t lam = mu. -9 % interior point iterations over the logged
             // warm-started loops (profiles/r05_ipm_iterations.txt); a cold start is untouched.
             const double *gsl = ka.slack + (size_t)b * 6 * N, *glm = ka.qp_lam + (size_t)b * (6 * N + 2);
-            const bool warm = ka.warm_mu > 0.0 && glm[6 * N] != 0.0;          // (wave-uniform)
+            bool warm = ka.warm_mu > 0.0 && glm[6 * N] != 0.0;          // (wave-uniform)
+            double r0a[NS2], swa[NS2], lwa[NS2];
+            {
+                // how far is the previous QP's final point from the new problem: row sides whose activity changed (multiplier above 1e-3
+                // against margin + old slack below 1e-3) and the largest violation beyond the old slack. A closed loop changes 0-2 row
+                // sides per control step; a sequence whose initial state jumps changes dozens, and there stale multipliers cost iterations
+                // and can stall the method: then it starts cold (scripts/study/warm_gate.py: 8.55 -> 7.91 iterations on such a sequence,
+                // 99 % of the logged closed-loop solves still start warm)
+                int flips = 0; double viol = -1e300;
+#pragma unroll
+                for (int rr = 0; rr < SLOTS; rr++)
+#pragma unroll
+                    for (int sd = 0; sd < 2; sd++) {
+                        const int k = rr * 2 + sd;
+                        const bool on_ = on[rr];
+                        const double eps = sd ? -1.0 : 1.0, bnd = sd ? hi[rr] : lo[rr];
+                        r0a[k] = eps * (dval[rr] - bnd);
+                        const int widx = sd * 3 * N + (on_ ? ((ty[rr] == 0) ? stg[rr] : N + 2 * (stg[rr] - 1) + ((ty[rr] == 2) ? 1 : 0)) : 0);
+                        swa[k] = warm ? gsl[widx] : 0.0; lwa[k] = warm ? glm[widx] : 0.0;
+                        const bool mis = on_ && ((lwa[k] > 1e-3) != (r0a[k] + swa[k] < 1e-3));
+                        flips += __popcll(__ballot(mis));
+                        viol = fmax(viol, on_ ? -r0a[k] - swa[k] : -1e300);
+                    }
+                if (warm && ka.warm_flips >= 0) {
+                    viol = wave_max(viol);
+                    if (flips > ka.warm_flips || viol > ka.warm_viol) {
+                        warm = false;
+#pragma unroll
+                        for (int k = 0; k < NS2; k++) { swa[k] = 0.0; lwa[k] = 0.0; }
+                    }
+                }
+            }
             const double mu0_ = warm ? ka.warm_mu : p_mu0, t0_ = warm ? ka.warm_mu : p_t0;
 #pragma unroll
             for (int rr = 0; rr < SLOTS; rr++)
@@ -1126,12 +1157,10 @@ __global__ void __launch_bounds__(64, IPM_WPS) ipm_kernel(const PArgs pa)
                 for (int sd = 0; sd < 2; sd++) {
                     const int k = rr * 2 + sd;
                     const bool on_ = on[rr];
-                    const double eps = sd ? -1.0 : 1.0, bnd = sd ? hi[rr] : lo[rr];
-                    const double r0v = eps * (dval[rr] - bnd);
+                    const double r0v = r0a[k];
                     const double z = pen(rr, sd, 0), Z = pen(rr, sd, 1);
                     double s0 = mu0_ / (z > 1e-6 ? z : 1e-6);
-                    const int widx = sd * 3 * N + (on_ ? ((ty[rr] == 0) ? stg[rr] : N + 2 * (stg[rr] - 1) + ((ty[rr] == 2) ? 1 : 0)) : 0);
-                    const double sw = warm ? gsl[widx] : 0.0, lw0 = warm ? glm[widx] : 0.0;
+                    const double sw = swa[k], lw0 = lwa[k];
                     if (sw > s0) s0 = sw;
                     double t = r0v + s0;
                     if (t < t0_) t = t0_;

@@ -204,6 +204,8 @@ extern "C" tum_ocp *tum_ocp_create(const tum_ocp_desc *desc)
     // qp_solver_warm_start (SNMPC_acados_settings.py:307): the interior point method starts from the previous QP's multipliers
     ka.warm_mu = desc->qp_warm_start ? (desc->qp_warm_mu > 0 ? desc->qp_warm_mu : 1e-2) : 0.0;
     ka.qp_lam = c->dqplam;
+    // (the gate of the warm start: constants of the oracle study, scripts/study/warm_gate.py; TUM_WARM_GATE=0 removes it -- development aid)
+    { const char *e = getenv("TUM_WARM_GATE"); ka.warm_flips = (e && e[0] == '0') ? -1 : 16; ka.warm_viol = 0.1; }
     Model &m = ka.mp;
     m.lf = desc->lf; m.lr = desc->lr; m.m = desc->m; m.inv_m = 1.0 / desc->m; m.inv_Iz = 1.0 / desc->Iz;
     m.ka = 0.5 * desc->ro * desc->S * desc->Cd;
