@@ -13,6 +13,7 @@ from tum_control_amd.workloads import nominal_batch
 L = lib()
 L.oracle_warm_meas.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_double)]
 L.oracle_set_warm_flips.argtypes = [ctypes.c_void_p, ctypes.c_int]
+L.oracle_set_warm_gate.argtypes = [ctypes.c_void_p, ctypes.c_double, ctypes.c_double]
 def meas(o):
     out = (ctypes.c_double * 5)(); L.oracle_warm_meas(o._h, out); return list(out)
 
@@ -22,7 +23,7 @@ def pair(N):
     for w in (True, False):
         o = OracleOcp(N, 0.08, 3)
         o.set_weights(m["q_lon"], m["q_yaw"], m["q_vel"], m["r_jerk"], m["r_steering_rate"], m["L1_pen"], m["L2_pen"], scale=0.01)
-        o.qp_warm_start(w); L.oracle_set_warm_flips(o._h, -1); os_.append(o)          # (study: the warm side ALWAYS warm-starts)
+        o.qp_warm_start(w); L.oracle_set_warm_flips(o._h, -1); L.oracle_set_warm_gate(o._h, 0.0, 0.0); os_.append(o)          # (study: the warm side ALWAYS warm-starts)
     return os_
 
 rows = []          # regime, it_warm, it_cold, m0, m1, m2, m3
@@ -47,7 +48,7 @@ for track, k in (("monteblanco", 0), ("lvms", 0), ("monteblanco", 13), ("lvms", 
     g = R.log_inputs(track, k); tr = load_track(track)
     ow, oc = OracleOcp(38, 0.08, 3), OracleOcp(38, 0.08, 3)
     for o, w in ((ow, True), (oc, False)):
-        o.set_weights(*F[k]); o.qp_warm_start(w); L.oracle_set_warm_flips(o._h, -1)
+        o.set_weights(*F[k]); o.qp_warm_start(w); L.oracle_set_warm_flips(o._h, -1); L.oracle_set_warm_gate(o._h, 0.0, 0.0)
     for i in range(0, 1500):
         _, ref = planner_emulator(tr, g["pose"][i], 39, 3.04, True)
         y = yref_from_ref(ref, 38)
