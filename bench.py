@@ -152,6 +152,10 @@ def parse_args(argv=None):
     ap.add_argument("--gather-iterate", action="store_true",
                     help="the rooted gather carries the whole iterate as well (X, U: (N+1)*8 + N*2 doubles per instance behind the 40 B summary; "
                          "SURVEY 8(e): 3264 B per instance at N = 40, 53 MB per GPU on config 4)")
+    ap.add_argument("--bind-inputs", action="store_true",
+                    help="let the capsule read every step's resident batch (x0, yref) in place (tum_ocp_bind_device) instead of copying it "
+                         "device-to-device into the capsule's own arrays inside the timed region (tum_ocp_put_device, the default and what "
+                         "rounds 1-5 report; measured difference 4.037 vs 4.032 M solves/s, profiles/r05_bind_inputs.txt)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-host-legs", action="store_true", help="skip the host-visible legs (N=1 only)")
     ap.add_argument("--no-schedule-legs", action="store_true",
@@ -270,6 +274,7 @@ class Job:
         self.dyr = [torch.from_numpy(np.ascontiguousarray(h[1])).to(dev) for h in self.host[1:]]
         # host-visible legs: every step's results (u0, cost, status, qp_iter -- optionally the whole iterate) land in the capsule's
         # pinned host slab behind an event (tum_ocp_results_async); the host reads them when the capsule's turn comes round again
+        self.bind_inputs = bool(getattr(args, "bind_inputs", False))
         self.host_results = None          # None | "summary" | "iterate"
         self.host_ok = self.host_seen = 0
         self.host_checksum = 0.0
@@ -299,7 +304,12 @@ class Job:
         cid, slab = self.cid, self.slabs[slot]
         if fresh is not None:
             k = fresh % self.nb
-            s.put_device("x0", self.dx0[k].data_ptr()); s.put_device("yref", self.dyr[k].data_ptr())
+            # the step's batch is resident in HBM and copied into the capsule's own arrays first (a copy kernel per field: 8 MB of yref
+            # per step on config 2, inside the timed region); --bind-inputs: the capsule reads it where it lies instead
+            if self.bind_inputs:
+                s.bind_device("x0", self.dx0[k].data_ptr()); s.bind_device("yref", self.dyr[k].data_ptr())
+            else:
+                s.put_device("x0", self.dx0[k].data_ptr()); s.put_device("yref", self.dyr[k].data_ptr())
         if cid == 5:
             s.bounds_restore()
         s.cold_start()
@@ -422,6 +432,8 @@ def run(args, torch, dist, dev, world, rank, local_rank, solver_factory, workloa
         except Exception:
             pass
         # (a) the SAME batch every step (batch 0): the longest-first order has this batch's exact iteration counts
+        if job1.bind_inputs:          # (back to the capsule's own arrays: the setters below would write through into a resident batch)
+            s.bind_device("x0", None); s.bind_device("yref", None)
         s.set_x0(job.host[0][0]); s.set_yref_all(job.host[0][1])
         for _ in range(2):
             job1.step()
@@ -501,6 +513,8 @@ def run(args, torch, dist, dev, world, rank, local_rank, solver_factory, workloa
                                   f"{job.slab_pad * 8} B per rank (u0, cost, status, qp_iter"
                                   + (", PCE mean/var of x_1 per group" if job.nmom else "")
                                   + (", the whole iterate X, U" if job.with_iterate else "") + "), one collective per step",
+                   "inputs": ("every step's resident batch (x0, yref) is read in place (tum_ocp_bind_device)" if job.bind_inputs else
+                              "every step's resident batch (x0, yref) is copied device-to-device into the capsule's arrays inside the timed region (tum_ocp_put_device)"),
                    "gather_iterate": job.with_iterate, "gather_bytes_per_rank": job.slab_pad * 8,
                    "schedule": "workgroups take instances longest-first by the previous solve's IPM iteration count "
                                "(tum_ocp_set_schedule): stale history when every step brings a new batch (`value`, "

@@ -171,6 +171,12 @@ int tum_ocp_step_async(tum_ocp *c, const double *x0, const double *yref, int wit
 /* The other direction: per-instance inputs from caller-owned DEVICE memory (asynchronous D2D on the capsule's stream).
  * field: "x0" (nb x 8, = constraints_set(0,"lbx")), "yref" (nb x (N+1)*6), "X" (nb x (N+1)*8), "U" (nb x N*2). */
 int tum_ocp_put_device(tum_ocp *c, const char *field, const void *dev_src, int b0, int nb);
+/* Zero-copy flavour of the above for "x0" / "yref" (whole batch): the capsule USES the caller's device array as its own -- kernels read
+ * it in place, setters and the device closed loop write through to it -- until dev_ptr = NULL hands the capsule's own array back. The
+ * memory must stay valid, and unchanged by others, while solves that use it are in flight. For callers that rotate batches resident in
+ * HBM (bench.py --bind-inputs). Measured (profiles/r05_bind_inputs.txt): the copy kernels of tum_ocp_put_device cost 1.2 % on one stream
+ * and disappear behind another capsule's solve with three capsules in flight (4.037 against 4.032 M solves/s). */
+int tum_ocp_bind_device(tum_ocp *c, const char *field, void *dev_ptr);
 /* cold start every instance on the device: X_k = x0 for all k, U = 0 (acados create / reset + set x;
  * NMPC_class.py:250-254) using the x0 already uploaded with constraints_set(0,"lbx"). */
 int tum_ocp_cold_start(tum_ocp *c);

@@ -451,3 +451,41 @@ def test_disturbed_closed_loop_device_against_host(which, tmp_path):
         assert not f["sim_disturbance_derivatives"].any()
     np.testing.assert_array_equal(f["simU"], logs[True]["simU"][:n - 1, 1])
     assert (f["CiLX"][:, 2] >= 0).all() and (f["CiLX"][:, 2] < 2 * np.pi).all()
+
+
+@pytest.mark.gpu
+def test_bound_device_inputs_are_read_in_place():
+    """tum_ocp_bind_device: the capsule uses the caller's device arrays as its x0 / yref arrays -- no copy. Same results as the copying upload
+    (tum_ocp_put_device), rebinding to another resident batch switches batches, setters write THROUGH to the caller's memory while bound, and
+    unbinding hands the capsule's own arrays back with their old contents."""
+    import torch
+    from tum_control_amd.workloads import nominal_batch
+    B = 300
+    b0, b1 = nominal_batch(B, N=N, seed=41), nominal_batch(B, N=N, seed=42)
+    dev = [[torch.as_tensor(np.ascontiguousarray(v), device="cuda:0") for v in b] for b in (b0, b1)]
+    a, c = _mk(B), _mk(B)
+    for s in (a, c):
+        s.set_x0(b0[0]); s.set_yref_all(b0[1]); s.cold_start(); assert s.solve() == 0          # the capsules' own arrays hold batch 0
+    for k in (1, 0, 1):
+        x, y = dev[k]
+        a.put_device("x0", x.data_ptr()); a.put_device("yref", y.data_ptr())
+        c.bind_device("x0", x.data_ptr()); c.bind_device("yref", y.data_ptr())
+        for s in (a, c):
+            s.cold_start(); assert s.solve() == 0
+        assert all(np.array_equal(p, q) for p, q in zip(a.get_iterate(), c.get_iterate()))
+    # setters write through while bound
+    x1 = b1[0] + 0.01
+    c.set_x0(x1); c.synchronize()
+    assert np.array_equal(dev[1][0].cpu().numpy(), x1)
+    a.set_x0(x1)
+    for s in (a, c):
+        s.cold_start(); assert s.solve() == 0
+    assert all(np.array_equal(p, q) for p, q in zip(a.get_iterate(), c.get_iterate()))
+    # unbound: the capsule's own arrays again, still holding batch 0
+    c.bind_device("x0", None); c.bind_device("yref", None)
+    a.set_x0(b0[0]); a.set_yref_all(b0[1])
+    for s in (a, c):
+        s.cold_start(); assert s.solve() == 0
+    assert all(np.array_equal(p, q) for p, q in zip(a.get_iterate(), c.get_iterate()))
+    with pytest.raises(Exception, match="field must be"):
+        c.bind_device("X", dev[0][0].data_ptr())

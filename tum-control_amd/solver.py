@@ -68,7 +68,7 @@ C_SYMBOLS = ["tum_ocp_create", "tum_ocp_free", "tum_ocp_last_error", "tum_ocp_ba
              "tum_ocp_set", "tum_ocp_get", "tum_ocp_constraints_set", "tum_ocp_cost_set",
              "tum_ocp_solve", "tum_ocp_solve_async", "tum_ocp_synchronize",
              "tum_ocp_get_cost", "tum_ocp_get_stats", "tum_ocp_reset", "tum_ocp_get_from_qp_in",
-             "tum_ocp_set_stream", "tum_ocp_get_device", "tum_ocp_put_device", "tum_ocp_results_async", "tum_ocp_results_wait", "tum_ocp_results_outstanding", "tum_ocp_step_async", "tum_ocp_cold_start", "tum_ocp_last_kernel_ms",
+             "tum_ocp_set_stream", "tum_ocp_get_device", "tum_ocp_put_device", "tum_ocp_bind_device", "tum_ocp_results_async", "tum_ocp_results_wait", "tum_ocp_results_outstanding", "tum_ocp_step_async", "tum_ocp_cold_start", "tum_ocp_last_kernel_ms",
              "tum_ocp_debug_dump", "tum_ocp_profile_phases", "tum_ocp_set_schedule", "tum_ocp_set_kernel",
              "tum_ocp_set_x0_fanout", "tum_pce_moments", "tum_pce_attach", "tum_pce_moments_device",
              "tum_ocp_bounds_snapshot", "tum_ocp_bounds_restore", "tum_ocp_r2_backoff", "tum_ocp_r2_attach", "tum_ocp_constraints_get",
@@ -114,6 +114,8 @@ def load_library(path=None):
     L.tum_ocp_set_kernel.argtypes = [vp, cs]
     L.tum_ocp_get_device.argtypes = [vp, cs, vp, ci, ci]
     L.tum_ocp_put_device.argtypes = [vp, cs, vp, ci, ci]
+    if hasattr(L, "tum_ocp_bind_device"):
+        L.tum_ocp_bind_device.argtypes = [vp, cs, vp]
     if hasattr(L, "tum_ocp_results_async"):          # (absent from the libraries of earlier revisions that scripts/dev/ab2.py loads beside this one)
         L.tum_ocp_results_async.argtypes = [vp, ci]
         L.tum_ocp_results_wait.argtypes = [vp, ctypes.POINTER(dp), ctypes.POINTER(dp), ctypes.POINTER(dp)]
@@ -367,6 +369,11 @@ class BatchedOcpSolver:
         """'x0' | 'yref' | 'X' | 'U' from caller-owned device memory (asynchronous D2D on the capsule's stream)"""
         nb = self.batch - b0 if nb is None else nb
         self._chk(self._L.tum_ocp_put_device(self._h, field.encode(), ctypes.c_void_p(dev_ptr), b0, nb), "put_device")
+
+    def bind_device(self, field, dev_ptr):
+        """'x0' | 'yref': use the caller's device array (whole batch) IN PLACE as the capsule's own -- no copy; dev_ptr None / 0 hands the
+        capsule's own array back. The memory must stay valid and unchanged while solves that use it are in flight."""
+        self._chk(self._L.tum_ocp_bind_device(self._h, field.encode(), ctypes.c_void_p(dev_ptr or 0)), "bind_device")
 
     def results_async(self, with_iterate=False):
         """Enqueue, behind the solve on this capsule's stream, the copy of the results into the capsule's pinned host slabs
