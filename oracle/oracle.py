@@ -252,6 +252,12 @@ class OracleOcp:
         L.oracle_set_ipm_split.argtypes = [ctypes.c_void_p, ctypes.c_int]
         L.oracle_set_ipm_split(self._h, int(split))
 
+    def set_ipm_skip(self, sigma_thr=0.0, amax_thr=0.0):
+        """study switch: skip the corrector pass when the predictor asks for centring sigma <= sigma_thr at a step to the boundary >= amax_thr"""
+        L = lib()
+        L.oracle_set_ipm_skip.argtypes = [ctypes.c_void_p, ctypes.c_double, ctypes.c_double]
+        L.oracle_set_ipm_skip(self._h, float(sigma_thr), float(amax_thr))
+
     def set_ipm_vstart(self, vstart=0, q_threshold=0.0):
         """same study: primal start at the unconstrained minimiser (1: always, 2: only if |q|_inf > q_threshold)"""
         L = lib()

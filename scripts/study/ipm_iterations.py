@@ -77,6 +77,13 @@ VARIANTS = {
     "split+warm5-mu2e-2": (5, 2e-2, 0, 0.0, None, (0, 0.0), 1),
     "split+warm6-mu5e-3": (6, 5e-3, 0, 0.0, None, (0, 0.0), 1),
     "split+warm2-mu5e-3": (2, 5e-3, 0, 0.0, None, (0, 0.0), 1),
+    # the corrector pass skipped when the predictor asks for (next to) no centring (eighth entry: (sigma threshold, step-to-boundary threshold))
+    "skip-s1e-3-a0.9":    (0, 0.0, 0, 0.0, None, (0, 0.0), 0, (1e-3, 0.9)),
+    "skip-s1e-2-a0.8":    (0, 0.0, 0, 0.0, None, (0, 0.0), 0, (1e-2, 0.8)),
+    "skip-s1e-4-a0.95":   (0, 0.0, 0, 0.0, None, (0, 0.0), 0, (1e-4, 0.95)),
+    "skip-s1e-1-a0.5":    (0, 0.0, 0, 0.0, None, (0, 0.0), 0, (1e-1, 0.5)),
+    "warm5-mu1e-2+skip-s1e-3-a0.9": (5, 1e-2, 0, 0.0, None, (0, 0.0), 0, (1e-3, 0.9)),
+    "warm5-mu1e-2+skip-s1e-2-a0.8": (5, 1e-2, 0, 0.0, None, (0, 0.0), 0, (1e-2, 0.8)),
 }
 
 
@@ -100,6 +107,8 @@ def cold_leg(n, var):
         o.set_ipm_vstart(*var[5])
     if len(var) > 6:
         o.set_ipm_split(var[6])
+    if len(var) > 7:
+        o.set_ipm_skip(*var[7])
     global_work(reset=True)
     u0, X1, st = o.solve_batch_cold(x0, yref, max(1, len(os.sched_getaffinity(0))))
     w = global_work(reset=True)
@@ -118,6 +127,9 @@ def warm_leg(logs, var, procs):
         os.environ["REPLAY_VSTART"] = ",".join(str(v) for v in var[5])
     if len(var) > 6:
         os.environ["REPLAY_SPLIT"] = str(var[6])
+    os.environ.pop("REPLAY_SKIP", None)
+    if len(var) > 7:
+        os.environ["REPLAY_SKIP"] = ",".join(str(v) for v in var[7])
     rep = R.run(logs, procs)
     n = sum(r["n"] for r in rep)
     w = np.sum([r["work"] for r in rep], axis=0)

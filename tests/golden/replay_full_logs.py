@@ -138,6 +138,8 @@ def replay_log(args):
         _lib().oracle_set_warm_flips(o._h, int(os.environ["REPLAY_FLIPS"]))
     if os.environ.get("REPLAY_SPLIT"):
         o.set_ipm_split(int(os.environ["REPLAY_SPLIT"]))
+    if os.environ.get("REPLAY_SKIP"):          # (same study: skip the corrector pass, "sigma_thr,amax_thr")
+        o.set_ipm_skip(*[float(v) for v in os.environ["REPLAY_SKIP"].split(",")])
     if os.environ.get("REPLAY_VSTART"):
         vs, qt = os.environ["REPLAY_VSTART"].split(",")
         o.set_ipm_vstart(int(vs), float(qt))
