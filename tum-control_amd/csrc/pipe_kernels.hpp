@@ -31,6 +31,15 @@
 namespace tum {
 
 constexpr int PREC = 64;                        // doubles per stage record
+#ifndef COND_STAGE_LDS
+#define COND_STAGE_LDS 1        // COND_DPP 2: the four cost rows reach the MFMA operand layout through LDS (1) or by row swaps between registers (0)
+#endif
+#ifndef COND_GS_LDS
+#define COND_GS_LDS 1           // COND_DPP 2: the first rows of g_s reach every lane through LDS (1) or by v_readlane (0)
+#endif
+#ifndef COND_NPARK
+#define COND_NPARK 3        // (LDS form of the kernel only) Hessian tiles of the last block column that the five-tile condensing kernel keeps in LDS between the stages of its last segment
+#endif
 // record fields: [0,1] Sp | [2..43] S[6][7] | [44..51] defect b | [52..55] cost residuals | [56..59] g3 g5 g7 h | [60] delta_f
 constexpr int PR_RES = 52, PR_GH = 56, PR_XD = 60;
 // coupled SNMPC OCP only: [61, 62] gradient (vl, vt)/|v| of the speed row of the cost, [63] d h / d vt of the gg row at |v|
@@ -48,7 +57,7 @@ template <int NT_> struct PD {
     static constexpr int PV_Q = 0, PV_D = NVP, PV_DV = 2 * NVP, PV_SC = 3 * NVP, PVEC = 3 * NVP + 16;   // q | d | dv | slack cost
     // (C_WT: the weights of every stage; C_PARK: the Hessian tiles of the last block column wait here between the stages of the
     //  last segment -- d4 per lane and tile)
-    static constexpr int C_NPARK = 3;
+    static constexpr int C_NPARK = COND_NPARK;
     static constexpr int C_REC = 0, C_STAGE = 2 * PREC, C_GS = C_STAGE + 4 * NVP, C_U0 = C_GS + 8,
                          C_WT = C_U0 + NVP, C_PARK = (C_WT + (NMAX + 1) * 6 + 1) & ~1, C_LDS = C_PARK + C_NPARK * 256;
     static constexpr int E_REC = 0, E_X = 2 * PREC, E_U = E_X + (NMAX + 1) * NX, E_DV = E_U + NVP, E_LDS = E_DV + NVP;
@@ -263,25 +272,12 @@ __global__ void __launch_bounds__(64, 1) lin_cols_kernel(const PArgs pa)
 }
 
 // ---------------------------------------------------------------------------------------------------------------- K2
-// The stage record of the condensing kernel through the SCALAR data path: a record is wave-uniform data (every lane multiplies its
-// own column by the same 61 numbers), so it is read with s_load straight from the workspace into scalar registers -- the constant
-// address space makes the compiler emit scalar loads for these uniform addresses and fold the values into the FMAs as their one scalar
-// operand -- instead of being staged in LDS by the lanes and broadcast back to all of them with 25 ds_read per stage (rounds 2-4: the
-// LDS unit was busy for half of this kernel's cycles). Nothing in this kernel writes the records.
-#ifndef COND_SREC
-#define COND_SREC 0
-#endif
 #ifndef COND_WPS
 #define COND_WPS 2          // wavefronts per SIMD the five-tile condensing kernel is bounded to
 #endif
-#ifndef COND_PF
-#define COND_PF 0           // COND_SREC: the record two stages ahead is touched by a per-lane vector load (it is in L2 when the scalar loads ask for it)
-#endif
-typedef const double __attribute__((address_space(4))) cdbl_t;
-struct RecScalar {          // fields 0..51 of record k (A_k, B_k, b_k), fields 52.. of record k + 1 (residuals, gg row, delta of stage k + 1)
-    cdbl_t *a, *b;
-    __device__ __forceinline__ double operator[](int i) const { return (i < PR_RES) ? a[i] : b[i]; }
-};
+// (Round 5 also built the stage record through the SCALAR data path -- address space 4, s_load, the fields as scalar operands of the FMAs:
+//  +38 us, every stage waits for its loads -- and three wavefronts per SIMD: slower in every form; profiles/r05_ab_cond_variants.txt,
+//  HISTORY.md. What replaced the LDS broadcasts is the DPP form below.)
 template <typename R>
 __device__ __forceinline__ void apply_A_rec(const R &rec, double w[8])
 {
@@ -314,6 +310,81 @@ __device__ __forceinline__ void apply_A2_rec(const R &rec, double w[8], double v
     for (int i = 0; i < 6; i++) { w[i] = n[i]; v[i] = m[i]; }
 }
 
+// The stage record in REGISTERS, read by the 64-bit DPP broadcast (round 5). A record is wave-uniform data; rounds 2-5 staged it in LDS
+// and broadcast it back with ~25 ds_read per stage. gfx90a+ vector FP64 takes ONE DPP control, row_newbcast:n -- every lane of a 16-lane
+// row reads lane n of its row (probed: scripts/probes/probe_dpp64_bcast.cpp, same issue cost as a plain v_fma_f64) -- on v_fmac_f64 only.
+// So the 64 fields of a stage slot live in four registers, field 16 r + n on lane n of EVERY row of register r (four coalesced 128-byte
+// loads per stage, straight from the workspace, two stages ahead in two register sets), and every use of a field is `acc += field * x`
+// with the field as the DPP operand: no LDS read, no scalar register, no extra instruction. The sums are formed in the order the
+// compiler's contraction of the LDS form forms them (x * 1.0 and + 0.0 are exact), so the results are the same to the bit (the tests
+// hold this kernel against cond_wide_kernel, which kept the LDS form). With the stage's weights riding along (lane (q, c) holds W_s[q]:
+// no select chain for the operand scale) and 30 registers fewer, all 15 Hessian tiles stay in registers (COND_NPARK 0).
+// COND_DPP 2 (shipped) adds two choices, measured (profiles/r05_ab_cond_dpp.txt): COND_STAGE_LDS 0 moves the four cost rows to the MFMA
+// operand layout (lane (q, c) of tile T <- row q of column 16 T + c, held by lane 16 T + c) by a 4 x 4 transposition of 16-lane rows
+// among four registers -- two levels of gfx950 row swaps (v_permlane32_swap, v_permlane16_swap: 8 instructions for the four tiles of bank
+// 0, 6 for bank 1) -- and COND_GS_LDS 0 takes the first rows of the constant column g_s from their lane by v_readlane: a stage without
+// any LDS traffic, bit-identical, and 1-2 us SLOWER than staging both through LDS (the swaps and lane reads and their copies are 30-40
+// vector instructions a stage on the issue port; what this kernel waits for is not the LDS pipe). 1: the record alone in registers.
+#ifndef COND_DPP
+#define COND_DPP 2
+#endif
+// rows of 16 lanes swapped between two registers (gfx950): the upper two rows of a with the lower two of b / the odd rows of a with the even rows of b
+__device__ __forceinline__ void rows_swap32(double &a, double &b)
+{
+    const tum_u32x2 l = __builtin_amdgcn_permlane32_swap(__double2loint(a), __double2loint(b), false, false);
+    const tum_u32x2 h = __builtin_amdgcn_permlane32_swap(__double2hiint(a), __double2hiint(b), false, false);
+    a = __hiloint2double(h[0], l[0]); b = __hiloint2double(h[1], l[1]);
+}
+__device__ __forceinline__ void rows_swap16(double &a, double &b)
+{
+    const tum_u32x2 l = __builtin_amdgcn_permlane16_swap(__double2loint(a), __double2loint(b), false, false);
+    const tum_u32x2 h = __builtin_amdgcn_permlane16_swap(__double2hiint(a), __double2hiint(b), false, false);
+    a = __hiloint2double(h[0], l[0]); b = __hiloint2double(h[1], l[1]);
+}
+// out[T] (T < NOUT), lane (q, c)  <-  a_q, lane (T, c): the MFMA operands of tile T of a bank whose rows a_0..a_3 live on lane = column
+template <int NOUT>
+__device__ __forceinline__ void rows_to_tiles(double a0, double a1, double a2, double a3, double *out)
+{
+    rows_swap32(a0, a2); rows_swap32(a1, a3);
+    rows_swap16(a0, a1);
+    out[0] = a0;
+    if constexpr (NOUT > 1) out[1] = a1;
+    if constexpr (NOUT > 2) { rows_swap16(a2, a3); out[2] = a2; if constexpr (NOUT > 3) out[3] = a3; }
+}
+struct RecRows {
+    double g[4];
+    double wq;          // W_s[lane >> 4] of the stage s = k + 1 the slot belongs to (COND_DPP 2)
+    // acc += field F * x
+    template <int F> __device__ __forceinline__ void fmac(double &acc, double x) const
+    {
+        static_assert(F >= 0 && F < 64, "record field");
+        asm("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(g[F >> 4]), "v"(x), "n"(F & 15));
+    }
+    // (a DPP operand must not be read within two wait states of a vector instruction that wrote it -- the compiler does not look into
+    //  the asm above: one s_nop behind whatever produced the registers, which every later use depends on)
+    __device__ __forceinline__ void settle() { asm volatile("s_nop 1" : "+v"(g[0]), "+v"(g[1]), "+v"(g[2]), "+v"(g[3])); }
+};
+// w <- A_k w (+ the same for a second bank v): apply_A's sums, term by term in its order
+// (the rows 0..2 -- px, py, psi -- are no operands of any row: updated in place, row 2 behind the two rows that read it; only the
+//  rows 3..5 need fresh accumulators. The instruction is destructive -- acc is source and destination --, every copy is a vector move)
+template <bool TWO>
+__device__ __forceinline__ void apply_A_rows(const RecRows &R, double w[8], double v[8])
+{
+    double n[3] = {0.0, 0.0, 0.0}, m[3] = {0.0, 0.0, 0.0};
+    R.fmac<0>(w[0], w[2]); R.fmac<1>(w[1], w[2]);
+    if constexpr (TWO) { R.fmac<0>(v[0], v[2]); R.fmac<1>(v[1], v[2]); }
+    static_for<0, 5>([&](auto ic) {
+        constexpr int i = decltype(ic)::value;
+        static_for<0, 4>([&](auto cc) {
+            constexpr int c = decltype(cc)::value;
+            R.fmac<2 + i * 7 + c>(i < 3 ? w[i] : n[i - 3], w[3 + c]);
+            if constexpr (TWO) R.fmac<2 + i * 7 + c>(i < 3 ? v[i] : m[i - 3], v[3 + c]);
+        });
+    });
+#pragma unroll
+    for (int i = 0; i < 3; i++) { w[3 + i] = n[i]; if constexpr (TWO) v[3 + i] = m[i]; }
+}
+
 // LDS of the condensing kernel (PD::C_*): stage record double buffer | 4 staging rows of the SYRK | g_s of the current stage |
 // iterate U | packed gg rows (staging for the operand layout)
 template <int NT_, bool SN>
@@ -337,24 +408,42 @@ __global__ void __launch_bounds__(64, (NT_ == 5) ? COND_WPS : 1) cond_kernel(con
     double *gvec = pa.vec + (size_t)b * PVEC;
     for (int i = lane; i < (N + 1) * 6; i += 64) sWt[i] = gW[i];
 
+    // The nominal OCP reads its stage records from REGISTERS by DPP broadcasts (RecRows above); the coupled SNMPC OCP -- whose first uph
+    // stages take their columns from the prologue's buffer and use nine fields of a record -- keeps the LDS form (measured with the
+    // register form: 266 -> 287 us at UPH = Tp, 32 spilled scalar registers)
+    constexpr bool DPPK = (COND_DPP >= 1) && !SN, DPP2 = (COND_DPP >= 2) && !SN;
+    // Hessian tiles of the last block column parked in LDS between the stages of the last segment: none in the register form (it needs
+    // 30 registers fewer), D::C_NPARK in the LDS form
+    constexpr int NPARK = (DPPK || NT_ != 5) ? 0 : D::C_NPARK;
     // stage slot k & 1: fields 0..51 of record k (A_k, B_k, b_k), fields 52..60 of record k+1 (residuals, gg row, delta of stage k+1)
     auto fetch = [&](int k) -> double { return (lane < PR_RES) ? grec[(size_t)k * PREC + lane] : ((lane <= (SN ? PR_G4 : PR_XD)) ? grec[(size_t)(k + 1) * PREC + lane] : 0.0); };
+    // field 16 r + (lane & 15) of the stage slot k, and the weight of cost row lane >> 4 of stage k + 1
+    auto fetch_rows = [&](int k, RecRows &R) {
+        const int p_ = lane & 15;
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const int f = 16 * r + p_;
+            R.g[r] = (f < PR_RES) ? grec[(size_t)k * PREC + f] : ((f <= PR_XD) ? grec[(size_t)(k + 1) * PREC + f] : 0.0);
+        }
+        R.wq = gW[(size_t)(k + 1) * 6 + (lane >> 4)];
+    };
     const int uph = SN ? ka.uph : 0;
     const int PP = SN ? sn_pro_pitch(uph) : 64, PSTAGE = 9 * PP;
     const double *gpro = SN ? ka.pro + (size_t)b * uph * PSTAGE : nullptr;
     sU0[lane] = (lane < nv) ? gU[lane] : 0.0;
     if (lane < NB1) sU0[64 + lane] = (64 + lane < nv) ? gU[64 + lane] : 0.0;
-#if !COND_SREC
-    double pre = fetch(0);
-    sRec[lane] = pre;
-    if (N > 1) pre = fetch(1);
-#else
-    (void)fetch; (void)sRec;
-#if COND_PF
-    double pf = grec[(size_t)((N >= 2) ? 2 : N) * PREC + lane];
-    { const double t0_ = grec[lane], t1_ = grec[(size_t)((N >= 1) ? 1 : 0) * PREC + lane]; asm volatile("" :: "v"(t0_), "v"(t1_)); }
-#endif
-#endif
+    // register form: two register sets, the even stages' and the odd stages': a stage reads its own and, done with it, requests the
+    // record two stages on into it (a rotation of the sets would be ten vector moves per stage, on the issue port this kernel is bound by)
+    RecRows Ra{}, Rb{};
+    double pre = 0.0;
+    if constexpr (DPPK) {
+        fetch_rows(0, Ra);
+        if (N > 1) fetch_rows(1, Rb); else Rb = Ra;
+    } else {
+        pre = fetch(0);
+        sRec[lane] = pre;
+        if (N > 1) pre = fetch(1);
+    }
     wsync();
 
     const int j0 = lane >> 1, r0 = lane & 1, j1 = 32 + (lane >> 1);
@@ -366,7 +455,7 @@ __global__ void __launch_bounds__(64, (NT_ == 5) ? COND_WPS : 1) cond_kernel(con
     for (int i = 0; i < NTT; i++) Ht[i] = d4{0.0, 0.0, 0.0, 0.0};
     if constexpr (NT_ == 5) {
 #pragma unroll
-        for (int K = 0; K < D::C_NPARK; K++) reinterpret_cast<d4 *>(lds + D::C_PARK)[K * 64 + lane] = d4{0.0, 0.0, 0.0, 0.0};
+        for (int K = 0; K < NPARK; K++) reinterpret_cast<d4 *>(lds + D::C_PARK)[K * 64 + lane] = d4{0.0, 0.0, 0.0, 0.0};
     }
     {
         double w0[8], w1[8];
@@ -384,7 +473,8 @@ __global__ void __launch_bounds__(64, (NT_ == 5) ? COND_WPS : 1) cond_kernel(con
             for (int i = 0; i < 8; i++) (G0_SEGS > 0 ? w0[i] : w1[i]) = gx0[i] - gX[i];
         }
         const int lane_cond = lane;
-        auto stage_body = [&](const int k, auto tsc) {
+        // (two call sites per segment: inlined by force, or every captured array lives in scratch)
+        auto stage_body = [&](const int k, auto tsc, RecRows &R) __attribute__((always_inline)) {
             constexpr int Ts = decltype(tsc)::value;
             constexpr bool G0 = Ts <= G0_SEGS;
             // (everything derived from the lane id is derived again in every stage, from a copy the optimiser cannot see through:
@@ -395,14 +485,9 @@ __global__ void __launch_bounds__(64, (NT_ == 5) ? COND_WPS : 1) cond_kernel(con
             const int j0 = lane >> 1, r0 = lane & 1, j1 = 32 + (lane >> 1);
             const bool isg = (lane == NB1);
             const int lq = lane >> 4, lc = lane & 15;
-#if COND_SREC
-#pragma clang diagnostic push
-#pragma clang diagnostic ignored "-Wold-style-cast"
-            const RecScalar rec{(cdbl_t *)(grec + (size_t)k * PREC), (cdbl_t *)(grec + (size_t)(k + 1) * PREC)};
-#pragma clang diagnostic pop
-#else
-            const double *rec = sRec + (k & 1) * PREC;
-#endif
+            const double *rec = sRec + (k & 1) * PREC;          // (LDS form)
+            const double one = 1.0;
+            if constexpr (DPPK) R.settle();
             if (SN && k < uph) {
                 // stage s = k+1 <= uph: G_nom,s and g_nom,s are PCE means of the sample recursions (prologue kernel)
                 // (columns 0..63 in bank 0, 64..2 uph-1 on the lanes of bank 1, the constant column on the g lane)
@@ -417,61 +502,100 @@ __global__ void __launch_bounds__(64, (NT_ == 5) ? COND_WPS : 1) cond_kernel(con
                     w0[i] = gv;
                     w1[i] = isg ? gg : g1;
                 }
-            } else {
-            if constexpr (G0) {
-                apply_A_rec(rec, w0);
-                const double sel0 = (j0 == k) ? 1.0 : 0.0, selg = (lane == 63) ? 1.0 : 0.0;
-#pragma unroll
-                for (int i = 0; i < 6; i++) w0[i] += sel0 * rec[2 + i * 7 + 5 + r0];
-                w0[6] += sel0 * (r0 ? dt : 0.0); w0[7] += sel0 * (r0 ? 0.0 : dt);
-#pragma unroll
-                for (int i = 0; i < 8; i++) w0[i] += selg * rec[44 + i];
-            } else {
-            apply_A2_rec(rec, w0, w1);
-            {
-                const double sel0 = (j0 == k) ? 1.0 : 0.0, sel1 = (lane < NB1 && j1 == k) ? 1.0 : 0.0, selg = isg ? 1.0 : 0.0;
-#pragma unroll
-                for (int i = 0; i < 6; i++) {
-                    const double bc = rec[2 + i * 7 + 5 + r0];
-                    w0[i] += sel0 * bc; w1[i] += sel1 * bc;
+            } else if constexpr (DPPK) {
+                // (the input column of a lane: B_k's column r0 -- two accumulations, the one of the other parity adds 0.0 * field)
+                if constexpr (G0) {
+                    apply_A_rows<false>(R, w0, w0);
+                    const double sel0 = (j0 == k) ? 1.0 : 0.0, selg = (lane == 63) ? 1.0 : 0.0;
+                    const double sa0 = r0 ? 0.0 : sel0, sb0 = r0 ? sel0 : 0.0;
+                    static_for<0, 5>([&](auto ic) {
+                        constexpr int i = decltype(ic)::value;
+                        R.fmac<2 + i * 7 + 5>(w0[i], sa0); R.fmac<2 + i * 7 + 6>(w0[i], sb0);
+                    });
+                    w0[6] += sel0 * (r0 ? dt : 0.0); w0[7] += sel0 * (r0 ? 0.0 : dt);
+                    static_for<0, 7>([&](auto ic) { constexpr int i = decltype(ic)::value; R.fmac<44 + i>(w0[i], selg); });
+                } else {
+                    apply_A_rows<true>(R, w0, w1);
+                    // (the input columns of stage k sit in bank 0 while k < 32 -- the segments 1..4 -- and in bank 1 behind: the other bank's
+                    //  accumulations would add 0.0 * field)
+                    constexpr bool IN0 = Ts <= 4;
+                    const double selk = IN0 ? ((j0 == k) ? 1.0 : 0.0) : ((lane < NB1 && j1 == k) ? 1.0 : 0.0), selg = isg ? 1.0 : 0.0;
+                    const double sa = r0 ? 0.0 : selk, sb = r0 ? selk : 0.0;
+                    double *wi = IN0 ? w0 : w1;
+                    static_for<0, 5>([&](auto ic) {
+                        constexpr int i = decltype(ic)::value;
+                        R.fmac<2 + i * 7 + 5>(wi[i], sa); R.fmac<2 + i * 7 + 6>(wi[i], sb);
+                    });
+                    wi[6] += selk * (r0 ? dt : 0.0); wi[7] += selk * (r0 ? 0.0 : dt);
+                    static_for<0, 7>([&](auto ic) { constexpr int i = decltype(ic)::value; R.fmac<44 + i>(w1[i], selg); });
                 }
-                const double b6 = r0 ? dt : 0.0, b7 = r0 ? 0.0 : dt;
-                w0[6] += sel0 * b6; w0[7] += sel0 * b7; w1[6] += sel1 * b6; w1[7] += sel1 * b7;
+            } else {
+                if constexpr (G0) {
+                    apply_A_rec(rec, w0);
+                    const double sel0 = (j0 == k) ? 1.0 : 0.0, selg = (lane == 63) ? 1.0 : 0.0;
 #pragma unroll
-                for (int i = 0; i < 8; i++) w1[i] += selg * rec[44 + i];
-            }
-            }
+                    for (int i = 0; i < 6; i++) w0[i] += sel0 * rec[2 + i * 7 + 5 + r0];
+                    w0[6] += sel0 * (r0 ? dt : 0.0); w0[7] += sel0 * (r0 ? 0.0 : dt);
+#pragma unroll
+                    for (int i = 0; i < 8; i++) w0[i] += selg * rec[44 + i];
+                } else {
+                    apply_A2_rec(rec, w0, w1);
+                    const double sel0 = (j0 == k) ? 1.0 : 0.0, sel1 = (lane < NB1 && j1 == k) ? 1.0 : 0.0, selg = isg ? 1.0 : 0.0;
+#pragma unroll
+                    for (int i = 0; i < 6; i++) {
+                        const double bc = rec[2 + i * 7 + 5 + r0];
+                        w0[i] += sel0 * bc; w1[i] += sel1 * bc;
+                    }
+                    const double b6 = r0 ? dt : 0.0, b7 = r0 ? 0.0 : dt;
+                    w0[6] += sel0 * b6; w0[7] += sel0 * b7; w1[6] += sel1 * b6; w1[7] += sel1 * b7;
+#pragma unroll
+                    for (int i = 0; i < 8; i++) w1[i] += selg * rec[44 + i];
+                }
             }
             const int s = k + 1;                         // stage whose G_s the lanes now hold
             const double sc = (s < N) ? dt : 1.0;
-            const double g3 = rec[PR_GH + 0], g5 = rec[PR_GH + 1], g7 = rec[PR_GH + 2];
-            const double g4 = SN ? rec[PR_G4] : 0.0, cvl = SN ? rec[PR_CV] : 1.0, cvt = SN ? rec[PR_CV + 1] : 0.0;
-            double hr0 = g3 * w0[3] + g5 * w0[5] + g7 * w0[7], hr1 = G0 ? 0.0 : g3 * w1[3] + g5 * w1[5] + g7 * w1[7];
-            double hd = rec[PR_GH + 3];
-            if (SN) {
-                hr0 += g4 * w0[4]; hr1 += g4 * w1[4];
-                if (s < uph) {   // chance-constraint row E + kappa sqrt(Var) over the samples (prologue kernel)
-                    const double *pr = gpro + (size_t)k * PSTAGE + 8 * PP;
-                    const double rv = (lane < 2 * s) ? pr[lane] : 0.0, rg = pr[2 * uph];
-                    const double r1 = (lane < NB1 && 64 + lane < 2 * s) ? pr[64 + lane] : 0.0;
-                    hr0 = rv; hr1 = isg ? rg : r1; hd = 0.0;
-                }
-            }
-            // the speed row of the cost: vl (nominal OCP) or |v| (SNMPC: gradient (vl, vt)/|v|)
-            const double c30 = SN ? cvl * w0[3] + cvt * w0[4] : w0[3], c31 = SN ? cvl * w1[3] + cvt * w1[4] : w1[3];
-            if constexpr (G0) {
-                if (lane == 63) {
+            double hr0 = 0.0, hr1 = 0.0, c30, c31;          // gg row and speed row of stage s (per bank)
+            double cvl = 1.0, cvt = 0.0;                     // (LDS form, SNMPC: gradient of |v|)
+            if constexpr (DPPK) {
+                // (g3 w3 + g5 w5 + g7 w7 as the compiler contracts the LDS form's expression: the SECOND product is rounded, the first and
+                //  the third are fused onto it)
+                R.fmac<PR_GH + 1>(hr0, w0[5]); R.fmac<PR_GH + 0>(hr0, w0[3]); R.fmac<PR_GH + 2>(hr0, w0[7]);
+                if constexpr (!G0) { R.fmac<PR_GH + 1>(hr1, w1[5]); R.fmac<PR_GH + 0>(hr1, w1[3]); R.fmac<PR_GH + 2>(hr1, w1[7]); }
+                c30 = w0[3]; c31 = w1[3];          // the speed row of the cost: vl
+                // d of the two rows of stage s on the lane that holds the constant column: field + column entry
+                double dbx = G0 ? w0[6] : w1[6], dh = G0 ? hr0 : hr1;
+                R.fmac<PR_XD>(dbx, one); R.fmac<PR_GH + 3>(dh, one);
+                if (G0 ? lane == 63 : isg) {
+                    if constexpr (!DPP2 || COND_GS_LDS) {
 #pragma unroll
-                    for (int i = 0; i < 8; i++) sGs[i] = w0[i];
-                    gvec[PV_D + 2 * (s - 1)] = rec[PR_XD] + w0[6];
-                    gvec[PV_D + 2 * (s - 1) + 1] = hd + hr0;
+                        for (int i = 0; i < 4; i++) sGs[i] = G0 ? w0[i] : w1[i];
+                    }
+                    gvec[PV_D + 2 * (s - 1)] = dbx;
+                    gvec[PV_D + 2 * (s - 1) + 1] = dh;
                 }
-            } else
-            if (isg) {
+            } else {
+                const double g3 = rec[PR_GH + 0], g5 = rec[PR_GH + 1], g7 = rec[PR_GH + 2];
+                const double g4 = SN ? rec[PR_G4] : 0.0;
+                if (SN) { cvl = rec[PR_CV]; cvt = rec[PR_CV + 1]; }
+                hr0 = g3 * w0[3] + g5 * w0[5] + g7 * w0[7]; hr1 = G0 ? 0.0 : g3 * w1[3] + g5 * w1[5] + g7 * w1[7];
+                double hd = rec[PR_GH + 3];
+                if (SN) {
+                    hr0 += g4 * w0[4]; hr1 += g4 * w1[4];
+                    if (s < uph) {   // chance-constraint row E + kappa sqrt(Var) over the samples (prologue kernel)
+                        const double *pr = gpro + (size_t)k * PSTAGE + 8 * PP;
+                        const double rv = (lane < 2 * s) ? pr[lane] : 0.0, rg = pr[2 * uph];
+                        const double r1 = (lane < NB1 && 64 + lane < 2 * s) ? pr[64 + lane] : 0.0;
+                        hr0 = rv; hr1 = isg ? rg : r1; hd = 0.0;
+                    }
+                }
+                // the speed row of the cost: vl (nominal OCP) or |v| (SNMPC: gradient (vl, vt)/|v|)
+                c30 = SN ? cvl * w0[3] + cvt * w0[4] : w0[3]; c31 = SN ? cvl * w1[3] + cvt * w1[4] : w1[3];
+                if (G0 ? lane == 63 : isg) {
 #pragma unroll
-                for (int i = 0; i < 8; i++) sGs[i] = w1[i];
-                gvec[PV_D + 2 * (s - 1)] = rec[PR_XD] + w1[6];
-                gvec[PV_D + 2 * (s - 1) + 1] = hd + hr1;
+                    for (int i = 0; i < 8; i++) sGs[i] = G0 ? w0[i] : w1[i];
+                    gvec[PV_D + 2 * (s - 1)] = rec[PR_XD] + (G0 ? w0[6] : w1[6]);
+                    gvec[PV_D + 2 * (s - 1) + 1] = hd + (G0 ? hr0 : hr1);
+                }
             }
             // the gg row of stage s goes straight to the workspace in the MFMA operand layout the interior point kernel loads it in:
             // row s = 4 c + lq + 1 of chunk c, the 16 columns of tile T at cidx(c, T) -- one store per bank; the columns right of the
@@ -483,37 +607,61 @@ __global__ void __launch_bounds__(64, (NT_ == 5) ? COND_WPS : 1) cond_kernel(con
                 const int T1 = 4 + lq;
                 if (!G0 && lane < NB1 && 2 * T1 <= c_) gcs[cidx(c_, T1) * 64] = hr1;
             }
+            // the four cost rows to the MFMA operand layout, the stage's weights, the first rows of g_s
+            constexpr bool STAGE_LDS = !DPP2 || COND_STAGE_LDS, GS_LDS = !DPP2 || COND_GS_LDS;
+            if constexpr (STAGE_LDS) {
 #pragma unroll
-            for (int r = 0; r < 3; r++) sStage[r * NVP + lane] = w0[r];
-            sStage[3 * NVP + lane] = c30;          // (G0: what lane 63 stages is g, in a column the tiles of these segments do not read)
-            if (!G0 && lane < NB1) {
+                for (int r = 0; r < 3; r++) sStage[r * NVP + lane] = w0[r];
+                sStage[3 * NVP + lane] = c30;          // (G0: what lane 63 stages is g, in a column the tiles of these segments do not read)
+                if (!G0 && lane < NB1) {
 #pragma unroll
-                for (int r = 0; r < 3; r++) sStage[r * NVP + 64 + lane] = w1[r];
-                sStage[3 * NVP + 64 + lane] = c31;
+                    for (int r = 0; r < 3; r++) sStage[r * NVP + 64 + lane] = w1[r];
+                    sStage[3 * NVP + 64 + lane] = c31;
+                }
             }
-            wsync();
-            double wr[4];
+            if constexpr (STAGE_LDS || GS_LDS) wsync();
+            double wl, wr[4], gsr[5];
+            if constexpr (DPP2) {
+                wl = sc * R.wq;          // (the stage's own weights; stage N: W_e)
 #pragma unroll
-            for (int r = 0; r < 4; r++) wr[r] = sc * sWt[s * 6 + r];          // (the stage's own weights; stage N: W_e)
+                for (int r = 0; r < 4; r++) wr[r] = readlane_f64(wl, 16 * r);
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; r++) wr[r] = sc * sWt[s * 6 + r];
+                wl = (lq == 0) ? wr[0] : (lq == 1) ? wr[1] : (lq == 2) ? wr[2] : wr[3];
+            }
+            if constexpr (GS_LDS) {
+#pragma unroll
+                for (int r = 0; r < (SN ? 5 : 4); r++) gsr[r] = sGs[r];
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; r++) gsr[r] = G0 ? readlane_f64(w0[r], 63) : readlane_f64(w1[r], NB1);
+            }
             {
                 double a0 = 0.0, a1 = 0.0;
-#pragma unroll
-                for (int r = 0; r < 4; r++) {
-                    const double gs = (SN && r == 3) ? cvl * sGs[3] + cvt * sGs[4] : sGs[r];
-                    const double e = wr[r] * (rec[PR_RES + r] + gs);
+                static_for<0, 3>([&](auto rc) {
+                    constexpr int r = decltype(rc)::value;
+                    double gs = gsr[r];
+                    if constexpr (DPPK) R.fmac<PR_RES + r>(gs, one);          // residual + g_s
+                    else gs = rec[PR_RES + r] + ((SN && r == 3) ? cvl * gsr[3] + cvt * gsr[4] : gsr[r]);
+                    const double e = wr[r] * gs;
                     a0 += e * ((r == 3) ? c30 : w0[r]);
                     if constexpr (!G0) a1 += e * ((r == 3) ? c31 : w1[r]);
-                }
+                });
                 q0 += (G0 && lane == 63) ? 0.0 : a0;
                 if constexpr (!G0) q1 += (lane < NB1) ? a1 : 0.0;
             }
-            const double wl = (lq == 0) ? wr[0] : (lq == 1) ? wr[1] : (lq == 2) ? wr[2] : wr[3];
             double bop[Ts];
+            if constexpr (STAGE_LDS) {
 #pragma unroll
-            for (int T = 0; T < Ts; T++) bop[T] = sStage[lq * NVP + 16 * T + lc];
-            // Last segment of the five-tile build: all 15 tiles are live and the register allocator sent one of them to scratch and back
-            // in every stage. The first C_NPARK tiles of the last block column -- touched by this segment only -- wait in LDS between
-            // the stages instead (the LDS the staged gg rows used to take): loaded, updated, stored again.
+                for (int T = 0; T < Ts; T++) bop[T] = sStage[lq * NVP + 16 * T + lc];
+            } else {
+                rows_to_tiles<(Ts < 4 ? Ts : 4)>(w0[0], w0[1], w0[2], c30, bop);
+                if constexpr (Ts > 4) rows_to_tiles<Ts - 4>(w1[0], w1[1], w1[2], c31, bop + 4);
+            }
+            // Last segment of the five-tile build when tiles are parked (COND_NPARK > 0; rounds 2-5 until the stage record left the
+            // register file's competitors): the first C_NPARK tiles of the last block column -- touched by this segment only -- wait in
+            // LDS between the stages: loaded, updated, stored again.
             constexpr bool PARK = (NT_ == 5) && (Ts == NT_);
             d4 *sPark = reinterpret_cast<d4 *>(lds + D::C_PARK) + lane;
 #pragma unroll
@@ -522,20 +670,20 @@ __global__ void __launch_bounds__(64, (NT_ == 5) ? COND_WPS : 1) cond_kernel(con
 #pragma unroll
                 for (int I = K; I < Ts; I++) {
                     if constexpr (PARK) {
-                        if (I == NT_ - 1 && K < D::C_NPARK) { sPark[K * 64] = mfma(aop, bop[I], sPark[K * 64]); continue; }
+                        if (I == NT_ - 1 && K < NPARK) { sPark[K * 64] = mfma(aop, bop[I], sPark[K * 64]); continue; }
                     }
                     Ht[tidx(K, I)] = mfma(aop, bop[I], Ht[tidx(K, I)]);
                 }
             }
-#if !COND_SREC
-            // next stage's record into the other slot (its global load has been in flight for a whole stage)
-            sRec[((k + 1) & 1) * PREC + lane] = pre;
-            if (k + 2 < N) pre = fetch(k + 2);
-#elif COND_PF
-            asm volatile("" :: "v"(pf));          // (the touch of the record two stages ahead has landed: the load is kept, its value is not used)
-            if (k + 3 <= N) pf = grec[(size_t)(k + 3) * PREC + lane];
-#endif
-            wsync();
+            if constexpr (DPPK) {
+                // the record two stages on, into the register set this stage is done with
+                if (k + 2 < N) fetch_rows(k + 2, R);
+            } else {
+                // next stage's record into the other slot (its global load has been in flight for a whole stage)
+                sRec[((k + 1) & 1) * PREC + lane] = pre;
+                if (k + 2 < N) pre = fetch(k + 2);
+            }
+            if constexpr (STAGE_LDS || GS_LDS || !DPPK) wsync();
         };
         // stage s = k+1 touches columns < 2s, i.e. ceil(s/8) tiles: one instantiation of the stage per segment of 8 stages
         static_for<1, NT>([&](auto tsc) {
@@ -544,7 +692,14 @@ __global__ void __launch_bounds__(64, (NT_ == 5) ? COND_WPS : 1) cond_kernel(con
 #pragma unroll
                 for (int i = 0; i < 8; i++) { const double gv = rl(w0[i], 63); w1[i] = isg ? gv : 0.0; w0[i] = (lane == 63) ? 0.0 : w0[i]; }
             }
-            for (int k = 8 * (Ts - 1); k < N && k < 8 * Ts; k++) stage_body(k, tsc);
+            if constexpr (DPPK) {
+                for (int k = 8 * (Ts - 1); k < N && k < 8 * Ts; k += 2) {
+                    stage_body(k, tsc, Ra);
+                    if (k + 1 < N) stage_body(k + 1, tsc, Rb);
+                }
+            } else {
+                for (int k = 8 * (Ts - 1); k < N && k < 8 * Ts; k++) stage_body(k, tsc, Ra);
+            }
         });
         for (int s = N + 1; s <= NMAX; s++) {          // rows beyond the horizon: zeros
             const int c_ = (s - 1) >> 2;
@@ -556,7 +711,7 @@ __global__ void __launch_bounds__(64, (NT_ == 5) ? COND_WPS : 1) cond_kernel(con
     }
     if constexpr (NT_ == 5) {      // (the parked tiles come back)
 #pragma unroll
-        for (int K = 0; K < D::C_NPARK; K++) Ht[tidx(K, NT - 1)] = reinterpret_cast<d4 *>(lds + D::C_PARK)[K * 64 + lane];
+        for (int K = 0; K < NPARK; K++) Ht[tidx(K, NT - 1)] = reinterpret_cast<d4 *>(lds + D::C_PARK)[K * 64 + lane];
     }
     // input cost (R) and padding on the diagonal, gradient of the input cost
 #pragma unroll

@@ -1373,9 +1373,9 @@ extern "C" int tum_ocp_put_device(tum_ocp *c, const char *field, const void *src
 
 // Zero-copy inputs for callers whose batches are resident in HBM already (scenario fan-outs, sweeps: bench.py rotates resident batches):
 // the capsule USES the caller's array as its x0 / yref array -- kernels read it in place, setters and the device closed loop write
-// through to it -- instead of copying it into its own (tum_ocp_put_device: a blit kernel per field and step, 8 MB for yref at 4096 x
-// N = 40, 0.09 ms per step on the capsule's stream). Whole batch only; the memory must stay valid and unchanged while solves that use
-// it are in flight. dev_ptr = NULL hands the capsule's own array back (its contents are what they were before the binding).
+// through to it -- instead of copying it into its own (tum_ocp_put_device: a blit kernel per field and step, 8 MB for yref at 16384 x
+// N = 40; measured 1.2 % of a step on one stream, nothing with three capsules in flight, profiles/r05_bind_inputs.txt). Whole batch
+// only; the memory must stay valid and unchanged while solves that use it are in flight. dev_ptr = NULL hands the capsule's own array back (its contents are what they were before the binding).
 extern "C" int tum_ocp_bind_device(tum_ocp *c, const char *field, void *dev_ptr)
 {
     if (!c || !field) return fail("null argument");
