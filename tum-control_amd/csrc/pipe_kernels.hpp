@@ -353,7 +353,6 @@ __device__ __forceinline__ void rows_to_tiles(double a0, double a1, double a2, d
 }
 struct RecRows {
     double g[4];
-    double wq;          // W_s[lane >> 4] of the stage s = k + 1 the slot belongs to (COND_DPP 2)
     // acc += field F * x
     template <int F> __device__ __forceinline__ void fmac(double &acc, double x) const
     {
@@ -406,7 +405,8 @@ __global__ void __launch_bounds__(64, (NT_ == 5) ? COND_WPS : 1) cond_kernel(con
     const double *gyref = ka.yref + (size_t)b * (N + 1) * 6;
     const double *gW = ka.W + (size_t)b * (N + 1) * 6;      // diagonal of W per stage (cost_set(i, 'W', ...), NMPC_class.py:294-296)
     double *gvec = pa.vec + (size_t)b * PVEC;
-    for (int i = lane; i < (N + 1) * 6; i += 64) sWt[i] = gW[i];
+    // the weights as the sums take them: dt W_s of the stages s < N, W_e of stage N (one product per weight, here instead of in every stage)
+    for (int i = lane; i < (N + 1) * 6; i += 64) sWt[i] = ((i < 6 * N) ? dt : 1.0) * gW[i];
 
     // The nominal OCP reads its stage records from REGISTERS by DPP broadcasts (RecRows above); the coupled SNMPC OCP -- whose first uph
     // stages take their columns from the prologue's buffer and use nine fields of a record -- keeps the LDS form (measured with the
@@ -425,7 +425,6 @@ __global__ void __launch_bounds__(64, (NT_ == 5) ? COND_WPS : 1) cond_kernel(con
             const int f = 16 * r + p_;
             R.g[r] = (f < PR_RES) ? grec[(size_t)k * PREC + f] : ((f <= PR_XD) ? grec[(size_t)(k + 1) * PREC + f] : 0.0);
         }
-        R.wq = gW[(size_t)(k + 1) * 6 + (lane >> 4)];
     };
     const int uph = SN ? ka.uph : 0;
     const int PP = SN ? sn_pro_pitch(uph) : 64, PSTAGE = 9 * PP;
@@ -436,9 +435,19 @@ __global__ void __launch_bounds__(64, (NT_ == 5) ? COND_WPS : 1) cond_kernel(con
     // record two stages on into it (a rotation of the sets would be ten vector moves per stage, on the issue port this kernel is bound by)
     RecRows Ra{}, Rb{};
     double pre = 0.0;
+    // register form: the input column of a lane -- column (lane & 1) of B_j, j the stage of the lane's variable -- enters the recursion
+    // once, at stage j: fetched once per bank (bank 1 in front of its segment) instead of broadcast to every lane in every stage
+    double bcol[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+    auto fetch_bcol = [&](int j) {
+#pragma unroll
+        for (int i = 0; i < 6; i++) bcol[i] = (j < N) ? grec[(size_t)j * PREC + 2 + i * 7 + 5 + (lane & 1)] : 0.0;
+    };
+    const double notg63 = (lane == 63) ? 0.0 : 1.0;
+    const double b6c = (lane & 1) ? dt : 0.0, b7c = (lane & 1) ? 0.0 : dt;          // (rows 6, 7 of that column: the integrators of the two inputs)
     if constexpr (DPPK) {
         fetch_rows(0, Ra);
         if (N > 1) fetch_rows(1, Rb); else Rb = Ra;
+        fetch_bcol(lane >> 1);
     } else {
         pre = fetch(0);
         sRec[lane] = pre;
@@ -480,7 +489,7 @@ __global__ void __launch_bounds__(64, (NT_ == 5) ? COND_WPS : 1) cond_kernel(con
             // (everything derived from the lane id is derived again in every stage, from a copy the optimiser cannot see through:
             //  held across the stage loop these values cost the registers the last segment lacks)
             int lane_s = lane_cond;
-            asm volatile("" : "+v"(lane_s));
+            if constexpr (!DPPK) asm volatile("" : "+v"(lane_s));          // (the register form has ~40 registers to spare: there the optimiser may keep what it likes -- 45 of 270 vector instructions per pair of stages)
             const int lane = lane_s;
             const int j0 = lane >> 1, r0 = lane & 1, j1 = 32 + (lane >> 1);
             const bool isg = (lane == NB1);
@@ -507,26 +516,20 @@ __global__ void __launch_bounds__(64, (NT_ == 5) ? COND_WPS : 1) cond_kernel(con
                 if constexpr (G0) {
                     apply_A_rows<false>(R, w0, w0);
                     const double sel0 = (j0 == k) ? 1.0 : 0.0, selg = (lane == 63) ? 1.0 : 0.0;
-                    const double sa0 = r0 ? 0.0 : sel0, sb0 = r0 ? sel0 : 0.0;
-                    static_for<0, 5>([&](auto ic) {
-                        constexpr int i = decltype(ic)::value;
-                        R.fmac<2 + i * 7 + 5>(w0[i], sa0); R.fmac<2 + i * 7 + 6>(w0[i], sb0);
-                    });
-                    w0[6] += sel0 * (r0 ? dt : 0.0); w0[7] += sel0 * (r0 ? 0.0 : dt);
+#pragma unroll
+                    for (int i = 0; i < 6; i++) w0[i] += sel0 * bcol[i];
+                    w0[6] += sel0 * b6c; w0[7] += sel0 * b7c;
                     static_for<0, 7>([&](auto ic) { constexpr int i = decltype(ic)::value; R.fmac<44 + i>(w0[i], selg); });
                 } else {
                     apply_A_rows<true>(R, w0, w1);
                     // (the input columns of stage k sit in bank 0 while k < 32 -- the segments 1..4 -- and in bank 1 behind: the other bank's
-                    //  accumulations would add 0.0 * field)
+                    //  accumulations would add 0.0 * entry)
                     constexpr bool IN0 = Ts <= 4;
                     const double selk = IN0 ? ((j0 == k) ? 1.0 : 0.0) : ((lane < NB1 && j1 == k) ? 1.0 : 0.0), selg = isg ? 1.0 : 0.0;
-                    const double sa = r0 ? 0.0 : selk, sb = r0 ? selk : 0.0;
                     double *wi = IN0 ? w0 : w1;
-                    static_for<0, 5>([&](auto ic) {
-                        constexpr int i = decltype(ic)::value;
-                        R.fmac<2 + i * 7 + 5>(wi[i], sa); R.fmac<2 + i * 7 + 6>(wi[i], sb);
-                    });
-                    wi[6] += selk * (r0 ? dt : 0.0); wi[7] += selk * (r0 ? 0.0 : dt);
+#pragma unroll
+                    for (int i = 0; i < 6; i++) wi[i] += selk * bcol[i];
+                    wi[6] += selk * b6c; wi[7] += selk * b7c;
                     static_for<0, 7>([&](auto ic) { constexpr int i = decltype(ic)::value; R.fmac<44 + i>(w1[i], selg); });
                 }
             } else {
@@ -553,7 +556,6 @@ __global__ void __launch_bounds__(64, (NT_ == 5) ? COND_WPS : 1) cond_kernel(con
                 }
             }
             const int s = k + 1;                         // stage whose G_s the lanes now hold
-            const double sc = (s < N) ? dt : 1.0;
             double hr0 = 0.0, hr1 = 0.0, c30, c31;          // gg row and speed row of stage s (per bank)
             double cvl = 1.0, cvt = 0.0;                     // (LDS form, SNMPC: gradient of |v|)
             if constexpr (DPPK) {
@@ -621,15 +623,10 @@ __global__ void __launch_bounds__(64, (NT_ == 5) ? COND_WPS : 1) cond_kernel(con
             }
             if constexpr (STAGE_LDS || GS_LDS) wsync();
             double wl, wr[4], gsr[5];
-            if constexpr (DPP2) {
-                wl = sc * R.wq;          // (the stage's own weights; stage N: W_e)
 #pragma unroll
-                for (int r = 0; r < 4; r++) wr[r] = readlane_f64(wl, 16 * r);
-            } else {
-#pragma unroll
-                for (int r = 0; r < 4; r++) wr[r] = sc * sWt[s * 6 + r];
-                wl = (lq == 0) ? wr[0] : (lq == 1) ? wr[1] : (lq == 2) ? wr[2] : wr[3];
-            }
+            for (int r = 0; r < 4; r++) wr[r] = sWt[s * 6 + r];          // (the stage's own weights, scaled; stage N: W_e)
+            if constexpr (DPP2) wl = sWt[s * 6 + lq];                    // (an LDS read instead of a select chain)
+            else wl = (lq == 0) ? wr[0] : (lq == 1) ? wr[1] : (lq == 2) ? wr[2] : wr[3];
             if constexpr (GS_LDS) {
 #pragma unroll
                 for (int r = 0; r < (SN ? 5 : 4); r++) gsr[r] = sGs[r];
@@ -648,7 +645,8 @@ __global__ void __launch_bounds__(64, (NT_ == 5) ? COND_WPS : 1) cond_kernel(con
                     a0 += e * ((r == 3) ? c30 : w0[r]);
                     if constexpr (!G0) a1 += e * ((r == 3) ? c31 : w1[r]);
                 });
-                q0 += (G0 && lane == 63) ? 0.0 : a0;
+                if constexpr (DPPK && G0) q0 += a0 * notg63;          // (lane 63 holds g, not a column)
+                else q0 += (G0 && lane == 63) ? 0.0 : a0;
                 if constexpr (!G0) q1 += (lane < NB1) ? a1 : 0.0;
             }
             double bop[Ts];
@@ -693,6 +691,7 @@ __global__ void __launch_bounds__(64, (NT_ == 5) ? COND_WPS : 1) cond_kernel(con
                 for (int i = 0; i < 8; i++) { const double gv = rl(w0[i], 63); w1[i] = isg ? gv : 0.0; w0[i] = (lane == 63) ? 0.0 : w0[i]; }
             }
             if constexpr (DPPK) {
+                if constexpr (Ts == 5) fetch_bcol(32 + (lane >> 1));          // (bank 1's input columns: the stages from 32 on)
                 for (int k = 8 * (Ts - 1); k < N && k < 8 * Ts; k += 2) {
                     stage_body(k, tsc, Ra);
                     if (k + 1 < N) stage_body(k + 1, tsc, Rb);
@@ -721,16 +720,16 @@ __global__ void __launch_bounds__(64, (NT_ == 5) ? COND_WPS : 1) cond_kernel(con
             const int row = lq + 4 * jj;
             if (row == lc) {
                 const int idx = 16 * K + row;
-                Ht[tidx(K, K)][jj] += (idx < nv) ? dt * sWt[(idx >> 1) * 6 + 4 + (idx & 1)] : 1.0;
+                Ht[tidx(K, K)][jj] += (idx < nv) ? sWt[(idx >> 1) * 6 + 4 + (idx & 1)] : 1.0;
             }
         }
-    if (lane < nv) q0 += dt * sWt[j0 * 6 + 4 + r0] * (sU0[lane] - gyref[j0 * 6 + 4 + r0]);
+    if (lane < nv) q0 += sWt[j0 * 6 + 4 + r0] * (sU0[lane] - gyref[j0 * 6 + 4 + r0]);
     {   // (the stage of a bank-1 column is recomputed from an opaque copy of the lane id: held since the top of the kernel it was the
         //  one value the register allocator sent to scratch)
         int lane_e = lane;
         asm volatile("" : "+v"(lane_e));
         const int j1e = 32 + (lane_e >> 1);
-        if (lane < NB1 && 64 + lane < nv) q1 += dt * sWt[j1e * 6 + 4 + r0] * (sU0[64 + lane] - gyref[j1e * 6 + 4 + r0]);
+        if (lane < NB1 && 64 + lane < nv) q1 += sWt[j1e * 6 + 4 + r0] * (sU0[64 + lane] - gyref[j1e * 6 + 4 + r0]);
     }
     // ---- hand-over: H tiles, q (the gg rows went out stage by stage)
     {
