@@ -245,7 +245,7 @@ def test_shipped_kernels_resource_budget():
     for name in ("ipm_kernel<false, 5, true>", "ipm_kernel<false, 5, false>"):      # headline: the expansion fused into its tail; SNMPC: without
         ipm = kernel(name)
         assert ipm[2:5] == [0, 0, 0] and ipm[6] == 1, (name, ipm)
-    cond = kernel("cond_kernel<5, false>")
+    cond = kernel("cond_kernel<5, false, true>")            # the headline's: the register form of the stage record
     assert cond[2:5] == [0, 0, 0] and cond[6] == 2          # no spills, two wavefronts per SIMD
 
 

@@ -386,7 +386,9 @@ __device__ __forceinline__ void apply_A_rows(const RecRows &R, double w[8], doub
 
 // LDS of the condensing kernel (PD::C_*): stage record double buffer | 4 staging rows of the SYRK | g_s of the current stage |
 // iterate U | packed gg rows (staging for the operand layout)
-template <int NT_, bool SN>
+// REGF: the register form of the stage record (RecRows); the LDS form is kept for the coupled SNMPC OCP at long propagation horizons
+// (the host decides, tum_nmpc.hip: launch_pipeline)
+template <int NT_, bool SN, bool REGF = !SN>
 __global__ void __launch_bounds__(64, (NT_ == 5) ? COND_WPS : 1) cond_kernel(const PArgs pa)
 {
     PD_LOCALS
@@ -408,13 +410,13 @@ __global__ void __launch_bounds__(64, (NT_ == 5) ? COND_WPS : 1) cond_kernel(con
     // the weights as the sums take them: dt W_s of the stages s < N, W_e of stage N (one product per weight, here instead of in every stage)
     for (int i = lane; i < (N + 1) * 6; i += 64) sWt[i] = ((i < 6 * N) ? dt : 1.0) * gW[i];
 
-    // The nominal OCP reads its stage records from REGISTERS by DPP broadcasts (RecRows above); the coupled SNMPC OCP -- whose first uph
-    // stages take their columns from the prologue's buffer and use nine fields of a record -- keeps the LDS form (measured with the
-    // register form: 266 -> 287 us at UPH = Tp, 32 spilled scalar registers)
-    constexpr bool DPPK = (COND_DPP >= 1) && !SN, DPP2 = (COND_DPP >= 2) && !SN;
+    // The nominal OCP reads its stage records from REGISTERS by DPP broadcasts (RecRows above). The coupled SNMPC OCP takes the columns
+    // of its first uph stages from the prologue's buffer and uses nine fields of a record there: at UPH = Tp the register form costs it
+    // 6 % (four loads a stage instead of one), behind stage uph it gains what the nominal OCP gains -- REGF is the host's choice by uph
+    constexpr bool DPPK = (COND_DPP >= 1) && REGF, DPP2 = (COND_DPP >= 2) && REGF;
     // Hessian tiles of the last block column parked in LDS between the stages of the last segment: none in the register form (it needs
     // 30 registers fewer), D::C_NPARK in the LDS form
-    constexpr int NPARK = (DPPK || NT_ != 5) ? 0 : D::C_NPARK;
+    constexpr int NPARK = ((DPPK && !SN) || NT_ != 5) ? 0 : D::C_NPARK;
     // stage slot k & 1: fields 0..51 of record k (A_k, B_k, b_k), fields 52..60 of record k+1 (residuals, gg row, delta of stage k+1)
     auto fetch = [&](int k) -> double { return (lane < PR_RES) ? grec[(size_t)k * PREC + lane] : ((lane <= (SN ? PR_G4 : PR_XD)) ? grec[(size_t)(k + 1) * PREC + lane] : 0.0); };
     // field 16 r + (lane & 15) of the stage slot k, and the weight of cost row lane >> 4 of stage k + 1
@@ -423,7 +425,7 @@ __global__ void __launch_bounds__(64, (NT_ == 5) ? COND_WPS : 1) cond_kernel(con
 #pragma unroll
         for (int r = 0; r < 4; r++) {
             const int f = 16 * r + p_;
-            R.g[r] = (f < PR_RES) ? grec[(size_t)k * PREC + f] : ((f <= PR_XD) ? grec[(size_t)(k + 1) * PREC + f] : 0.0);
+            R.g[r] = (f < PR_RES) ? grec[(size_t)k * PREC + f] : ((f <= (SN ? PR_G4 : PR_XD)) ? grec[(size_t)(k + 1) * PREC + f] : 0.0);
         }
     };
     const int uph = SN ? ka.uph : 0;
@@ -489,7 +491,7 @@ __global__ void __launch_bounds__(64, (NT_ == 5) ? COND_WPS : 1) cond_kernel(con
             // (everything derived from the lane id is derived again in every stage, from a copy the optimiser cannot see through:
             //  held across the stage loop these values cost the registers the last segment lacks)
             int lane_s = lane_cond;
-            if constexpr (!DPPK) asm volatile("" : "+v"(lane_s));          // (the register form has ~40 registers to spare: there the optimiser may keep what it likes -- 45 of 270 vector instructions per pair of stages)
+            if constexpr (!DPPK || SN) asm volatile("" : "+v"(lane_s));          // (the register form has ~40 registers to spare: there the optimiser may keep what it likes -- 45 of 270 vector instructions per pair of stages)
             const int lane = lane_s;
             const int j0 = lane >> 1, r0 = lane & 1, j1 = 32 + (lane >> 1);
             const bool isg = (lane == NB1);
@@ -563,14 +565,28 @@ __global__ void __launch_bounds__(64, (NT_ == 5) ? COND_WPS : 1) cond_kernel(con
                 //  the third are fused onto it)
                 R.fmac<PR_GH + 1>(hr0, w0[5]); R.fmac<PR_GH + 0>(hr0, w0[3]); R.fmac<PR_GH + 2>(hr0, w0[7]);
                 if constexpr (!G0) { R.fmac<PR_GH + 1>(hr1, w1[5]); R.fmac<PR_GH + 0>(hr1, w1[3]); R.fmac<PR_GH + 2>(hr1, w1[7]); }
-                c30 = w0[3]; c31 = w1[3];          // the speed row of the cost: vl
+                double hdon = 1.0;          // (the constant of the gg row, field PR_GH + 3: dropped where the chance-constraint row stands in)
+                c30 = w0[3]; c31 = w1[3];          // the speed row of the cost: vl (nominal OCP) ...
+                if constexpr (SN) {
+                    R.fmac<PR_G4>(hr0, w0[4]); R.fmac<PR_G4>(hr1, w1[4]);
+                    if (s < uph) {   // chance-constraint row E + kappa sqrt(Var) over the samples (prologue kernel)
+                        const double *pr = gpro + (size_t)k * PSTAGE + 8 * PP;
+                        const double rv = (lane < 2 * s) ? pr[lane] : 0.0, rg = pr[2 * uph];
+                        const double r1 = (lane < NB1 && 64 + lane < 2 * s) ? pr[64 + lane] : 0.0;
+                        hr0 = rv; hr1 = isg ? rg : r1; hdon = 0.0;
+                    }
+                    // ... or |v| (SNMPC: gradient (vl, vt)/|v|; the second product rounded, the first fused onto it)
+                    c30 = 0.0; c31 = 0.0;
+                    R.fmac<PR_CV + 1>(c30, w0[4]); R.fmac<PR_CV>(c30, w0[3]);
+                    R.fmac<PR_CV + 1>(c31, w1[4]); R.fmac<PR_CV>(c31, w1[3]);
+                }
                 // d of the two rows of stage s on the lane that holds the constant column: field + column entry
                 double dbx = G0 ? w0[6] : w1[6], dh = G0 ? hr0 : hr1;
-                R.fmac<PR_XD>(dbx, one); R.fmac<PR_GH + 3>(dh, one);
+                R.fmac<PR_XD>(dbx, one); R.fmac<PR_GH + 3>(dh, hdon);
                 if (G0 ? lane == 63 : isg) {
                     if constexpr (!DPP2 || COND_GS_LDS) {
 #pragma unroll
-                        for (int i = 0; i < 4; i++) sGs[i] = G0 ? w0[i] : w1[i];
+                        for (int i = 0; i < (SN ? 5 : 4); i++) sGs[i] = G0 ? w0[i] : w1[i];
                     }
                     gvec[PV_D + 2 * (s - 1)] = dbx;
                     gvec[PV_D + 2 * (s - 1) + 1] = dh;
@@ -632,15 +648,17 @@ __global__ void __launch_bounds__(64, (NT_ == 5) ? COND_WPS : 1) cond_kernel(con
                 for (int r = 0; r < (SN ? 5 : 4); r++) gsr[r] = sGs[r];
             } else {
 #pragma unroll
-                for (int r = 0; r < 4; r++) gsr[r] = G0 ? readlane_f64(w0[r], 63) : readlane_f64(w1[r], NB1);
+                for (int r = 0; r < (SN ? 5 : 4); r++) gsr[r] = G0 ? readlane_f64(w0[r], 63) : readlane_f64(w1[r], NB1);
             }
             {
                 double a0 = 0.0, a1 = 0.0;
                 static_for<0, 3>([&](auto rc) {
                     constexpr int r = decltype(rc)::value;
                     double gs = gsr[r];
-                    if constexpr (DPPK) R.fmac<PR_RES + r>(gs, one);          // residual + g_s
-                    else gs = rec[PR_RES + r] + ((SN && r == 3) ? cvl * gsr[3] + cvt * gsr[4] : gsr[r]);
+                    if constexpr (DPPK) {
+                        if constexpr (SN && r == 3) { gs = 0.0; R.fmac<PR_CV + 1>(gs, gsr[4]); R.fmac<PR_CV>(gs, gsr[3]); }
+                        R.fmac<PR_RES + r>(gs, one);          // residual + g_s
+                    } else gs = rec[PR_RES + r] + ((SN && r == 3) ? cvl * gsr[3] + cvt * gsr[4] : gsr[r]);
                     const double e = wr[r] * gs;
                     a0 += e * ((r == 3) ? c30 : w0[r]);
                     if constexpr (!G0) a1 += e * ((r == 3) ? c31 : w1[r]);

@@ -926,7 +926,9 @@ static int launch_pipeline(tum_ocp *c, bool events)
             const bool wide = use_cond_wide(c);
             if (wide && c->sn) hipLaunchKernelGGL((cond_wide_kernel<NTv, true>), dim3(c->batch), dim3(64 * cw_waves<NTv>()), 0, c->stream, pa);
             else if (wide) hipLaunchKernelGGL((cond_wide_kernel<NTv, false>), dim3(c->batch), dim3(64 * cw_waves<NTv>()), 0, c->stream, pa);
-            else if (c->sn) hipLaunchKernelGGL((cond_kernel<NTv, true>), dim3(c->batch), dim3(64), 0, c->stream, pa);
+            // (coupled SNMPC: the register form of the stage record pays behind stage uph and costs in front of it, pipe_kernels.hpp)
+            else if (c->sn && 2 * c->sa.uph <= c->N) hipLaunchKernelGGL((cond_kernel<NTv, true, true>), dim3(c->batch), dim3(64), 0, c->stream, pa);
+            else if (c->sn) hipLaunchKernelGGL((cond_kernel<NTv, true, false>), dim3(c->batch), dim3(64), 0, c->stream, pa);
             else hipLaunchKernelGGL((cond_kernel<NTv, false>), dim3(c->batch), dim3(64), 0, c->stream, pa);
         }
         if ((events && !c->skip_ipm_events) || c->time_ipm) (void)hipEventRecord(c->evi0, c->stream);
