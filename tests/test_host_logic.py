@@ -570,3 +570,53 @@ def test_log_file_has_the_reference_schema(tmp_path, golden_dir):
     for k in r.files:
         assert mine[k].shape == r[k].shape, k
         np.testing.assert_allclose(mine[k], r[k], rtol=1e-12, atol=1e-12, err_msg=k)
+
+
+def test_dpp_operands_of_the_condensing_kernel_are_settled(tmp_path):
+    """cond_kernel reads its stage record with `v_fmac_f64_dpp ... row_newbcast:n` written as inline asm (csrc/pipe_kernels.hpp,
+    RecRows): the compiler's hazard recogniser does not look into it, and gfx9 needs two wait states between a vector instruction
+    that WRITES a register and a DPP read of it. The record registers are only ever written by loads -- unless the register
+    allocator copies them. This test disassembles the shipped library and checks every DPP accumulation: no vector instruction in
+    the two issue slots in front of it (an `s_nop n` counts n + 1) writes its DPP source."""
+    import re
+    import shutil
+    import subprocess
+    import __graft_entry__ as g
+    objdump = "/opt/rocm/lib/llvm/bin/llvm-objdump"
+    if not os.path.exists(objdump) or not os.path.exists(g.LIB):
+        pytest.skip("no llvm-objdump / no built library on this host")
+    lib = shutil.copy(g.LIB, tmp_path / "lib.so")
+    subprocess.run([objdump, "--offloading", str(lib)], cwd=tmp_path, check=True, capture_output=True)
+    co = [f for f in os.listdir(tmp_path) if "gfx950" in f]
+    assert len(co) == 1, os.listdir(tmp_path)
+    dis = subprocess.run([objdump, "-d", "--no-show-raw-insn", str(tmp_path / co[0])], capture_output=True, text=True, check=True).stdout
+
+    def regs(tok):
+        m = re.fullmatch(r"v\[(\d+):(\d+)\]", tok)
+        if m:
+            return set(range(int(m.group(1)), int(m.group(2)) + 1))
+        m = re.fullmatch(r"v(\d+)", tok)
+        return {int(m.group(1))} if m else set()
+
+    n_dpp = 0
+    window = []          # (registers written by a vector instruction, wait states it is away from the next instruction)
+    for line in dis.splitlines():
+        s = line.split("//")[0].strip()
+        if not s or s.endswith(":") or not re.match(r"^[a-z]", s):
+            continue
+        op, _, rest = s.partition(" ")
+        ops = [t.strip() for t in rest.split(",")] if rest else []
+        if op.startswith("v_fmac_f64_dpp"):
+            n_dpp += 1
+            src = regs(ops[1].split()[0])
+            assert src, s
+            for written, dist in window:
+                assert dist >= 2 or not (written & src), ("a vector instruction writes the DPP source within two wait states", s)
+        ws = (int(ops[0]) + 1) if op == "s_nop" else 1
+        window = [(w, d + ws) for w, d in window if d + ws < 3]
+        if op.startswith("v_") and not op.startswith(("v_cmp", "v_readlane", "v_readfirstlane")) and ops:
+            written = regs(ops[0].split()[0])
+            if op.startswith("v_permlane") and len(ops) > 1:
+                written |= regs(ops[1].split()[0])
+            window.append((written, 0))
+    assert n_dpp > 500          # (the register form is in the library: ~110 accumulations per stage instantiation)
