@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
-"""cycle counters of the phases of snmpc_prologue_mfma_kernel (workgroup 256 of a 4096-instance launch, both wavefronts)"""
+"""cycle counters of the phases of snmpc_prologue_mfma_kernel (workgroup 256 of a 4096-instance launch, both wavefronts);
+the counters live in the DEVELOPMENT build of the library only (libtumnmpc_dev.so)"""
 import os, sys
+os.environ.setdefault("TUM_NMPC_DEV", "1")
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch

@@ -568,8 +568,14 @@ __global__ void __launch_bounds__(64 * NWV, 2) snmpc_prologue_mfma_kernel(const 
     oV[1] = (q == 0) ? 1 : (q == 1) ? 2 : (q == 3) ? 3 : 4;
     constexpr int NCH = (NWV * NSW * ABS + NT - 1) / NT;
 
+    // phase cycle counters (scripts/dev/sn_mfma_phases.py): in the development build only -- six 64-bit accumulators are 14 registers the
+    // shipped kernel has no room for
+#ifdef TUM_DEV_KERNELS
     long long tacc[6] = {0, 0, 0, 0, 0, 0}, tprev = __builtin_readcyclecounter();
 #define SN_TICK(j) do { if (sa.dbg && b == 256) { const long long t_ = __builtin_readcyclecounter(); tacc[j] += t_ - tprev; tprev = t_; } } while (0)
+#else
+#define SN_TICK(j) do { } while (0)
+#endif
     for (int phase = 0; phase < 2; phase++) {
         if (phase == 1 && 2 * uph < 64) break;         // (no column beyond 63)
         const int kbeg = phase ? 31 : 0;               // input column 63 belongs to stage 31
@@ -605,16 +611,17 @@ __global__ void __launch_bounds__(64 * NWV, 2) snmpc_prologue_mfma_kernel(const 
         };
         sync();                                        // (phase 1: everybody is through with the buffers of phase 0)
         if (kbeg < uph) { fetch(kbeg); stash(kbeg); }
-        for (int k = kbeg; k < uph; k++) {
+        // the number of column groups with a live column is a compile-time constant of the stage body (one instantiation per count,
+        // the stages of a phase in four runs): with it a run-time value every `if (cg < ncg)` was a branch whose join copied the column
+        // state -- ~100 of the ~500 vector instructions of a stage were such moves
+        auto stage = [&](const int k, auto ncgc) __attribute__((always_inline)) {
+            constexpr int ncg = decltype(ncgc)::value;
             const int s = k + 1;
             SN_TICK(5);
             sync();
             SN_TICK(0);
             if (k + 1 < uph) fetch(k + 1);
             const double *recs = sRec + (k & 1) * ns * SN_MREC, *g4s = sG4 + (k & 1) * ns * 5;
-            // column groups with a live column in this stage (live columns: 0 .. 2 k + 2)
-            const int nlive = 2 * k + 3 - 64 * phase;
-            const int ncg = (nlive >= 49) ? 4 : (nlive >= 33) ? 3 : (nlive >= 17) ? 2 : 1;
             double sel[4];
 #pragma unroll
             for (int cg = 0; cg < 4; cg++) {
@@ -637,26 +644,23 @@ __global__ void __launch_bounds__(64 * NWV, 2) snmpc_prologue_mfma_kernel(const 
                     const double cf = (s < uph) ? sCoef[s * ns + gi] : 0.0;
                     const double gv0 = cf * g4s[gi * 5 + oV[0]], gv1 = cf * g4s[gi * 5 + oV[1]];
 #pragma unroll
-                    for (int cg = 0; cg < 4; cg++) {
-                        if (cg < ncg) {
-                            double d0 = __builtin_amdgcn_mfma_f64_4x4x4f64(a00, W[i][0][cg], 0.0, 0, 0, 0);
-                            double d1 = __builtin_amdgcn_mfma_f64_4x4x4f64(a10, W[i][0][cg], 0.0, 0, 0, 0);
-                            d0 = __builtin_amdgcn_mfma_f64_4x4x4f64(a01, W[i][1][cg], d0, 0, 0, 0);
-                            d1 = __builtin_amdgcn_mfma_f64_4x4x4f64(a11, W[i][1][cg], d1, 0, 0, 0);
-                            d0 += sel[cg] * (cg == 0 ? bg0 : bn0);
-                            d1 += sel[cg] * (cg == 0 ? bg1 : bn1);
-                            W[i][0][cg] = d0; W[i][1][cg] = d1;
-                            M[0][cg] += ai * d0; M[1][cg] += ai * d1;
-                            Mc[cg] += gv0 * d0 + gv1 * d1;
-                        }
+                    for (int cg = 0; cg < ncg; cg++) {
+                        double d0 = __builtin_amdgcn_mfma_f64_4x4x4f64(a00, W[i][0][cg], 0.0, 0, 0, 0);
+                        double d1 = __builtin_amdgcn_mfma_f64_4x4x4f64(a10, W[i][0][cg], 0.0, 0, 0, 0);
+                        d0 = __builtin_amdgcn_mfma_f64_4x4x4f64(a01, W[i][1][cg], d0, 0, 0, 0);
+                        d1 = __builtin_amdgcn_mfma_f64_4x4x4f64(a11, W[i][1][cg], d1, 0, 0, 0);
+                        d0 += sel[cg] * (cg == 0 ? bg0 : bn0);
+                        d1 += sel[cg] * (cg == 0 ? bg1 : bn1);
+                        W[i][0][cg] = d0; W[i][1][cg] = d1;
+                        M[0][cg] += ai * d0; M[1][cg] += ai * d1;
+                        Mc[cg] += gv0 * d0 + gv1 * d1;
                     }
                 }
             }
             SN_TICK(1);
             // the chance row: sum over the four row lanes of a column
 #pragma unroll
-            for (int cg = 0; cg < 4; cg++)
-                if (cg < ncg) Mc[cg] = quad_sum(Mc[cg]);
+            for (int cg = 0; cg < ncg; cg++) Mc[cg] = quad_sum(Mc[cg]);
             // the two sample halves meet: wavefront 1 hands its partial sums over, wavefront 0 adds and stores the stage
             if (NWV > 1 && grp == 1) {
 #pragma unroll
@@ -671,10 +675,10 @@ __global__ void __launch_bounds__(64 * NWV, 2) snmpc_prologue_mfma_kernel(const 
             if (grp == 0) {
                 double *pg = pro + (size_t)k * PSTAGE;
 #pragma unroll
-                for (int cg = 0; cg < 4; cg++) {
+                for (int cg = 0; cg < ncg; cg++) {
                     const int c = cbase + 16 * cg;
                     const bool isg = (cg == 0) && isg0;
-                    if (cg < ncg && c <= 2 * k + 2 && c <= 2 * uph) {      // (the live columns only: the rest of the buffer is zero and stays zero)
+                    if (c <= 2 * k + 2 && c <= 2 * uph) {      // (the live columns only: the rest of the buffer is zero and stays zero)
                         const int colo = isg ? 2 * uph : c - 1;
 #pragma unroll
                         for (int rb = 0; rb < 2; rb++) {
@@ -686,10 +690,19 @@ __global__ void __launch_bounds__(64 * NWV, 2) snmpc_prologue_mfma_kernel(const 
                 }
             }
             SN_TICK(4);
-        }
+        };
+        // column groups with a live column in stage k (live columns: 0 .. 2 k + 2): nlive = 2 k + 3 - 64 phase, one group per 16
+        static_for<1, 4>([&](auto ncgc) {
+            constexpr int ncg = decltype(ncgc)::value;
+            const int klo = (ncg == 1) ? kbeg : (16 * (ncg - 1) + 64 * phase - 1) / 2;          // first k with nlive >= 16 (ncg - 1) + 1
+            const int khi = (ncg == 4) ? uph : (16 * ncg + 64 * phase - 1) / 2;                  // first k with nlive >= 16 ncg + 1
+            for (int k = (klo > kbeg ? klo : kbeg); k < khi && k < uph; k++) stage(k, ncgc);
+        });
     }
+#ifdef TUM_DEV_KERNELS
     if (sa.dbg && b == 256 && lane == 0)
         for (int j = 0; j < 6; j++) sa.dbg[10 * grp + j] = (double)tacc[j];
+#endif
 #undef SN_TICK
 }
 
