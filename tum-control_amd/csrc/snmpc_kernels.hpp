@@ -474,7 +474,9 @@ __host__ __device__ inline int sn_mfma_lds_doubles(int uph, int ns)
 {
     return 2 * uph * ns + (uph + 1) + uph * 8 + SN_LMAX * SN_NSMAX + uph * SN_LMAX + 2 * ns * SN_MREC + 2 * ns * 5 + 12 * 64;
 }
-// NWV wavefronts per OCP, NSW samples per wavefront (NWV x NSW >= n_samples)
+// NWV wavefronts per OCP, NSW samples per wavefront (NWV x NSW >= n_samples). (A variant without the per-sample guards for the
+// reference's ten samples was built in round 5: 30 % fewer vector instructions in the stage loops, and 31 registers spilled around
+// them -- +35 us per launch; not kept.)
 template <int NSW, int NWV>
 __global__ void __launch_bounds__(64 * NWV, 2) snmpc_prologue_mfma_kernel(const SnArgs sa)
 {
@@ -553,19 +555,19 @@ __global__ void __launch_bounds__(64 * NWV, 2) snmpc_prologue_mfma_kernel(const 
 #pragma unroll
     for (int rb = 0; rb < 2; rb++)
 #pragma unroll
-        for (int kb = 0; kb < 2; kb++) oA[rb][kb] = aidx(4 * rb + x, 4 * kb + q);
+        for (int kb = 0; kb < 2; kb++) oA[rb][kb] = aidx(4 * rb + x, 4 * kb + q) + i0 * SN_MREC;          // (+ the wavefront's first sample: sample i of it is an immediate offset)
     // the input column B[:, r0] (rows 6, 7: dt on the row the input integrates into) and the defect b, rows 4 rb + q
     const int r0 = (x + 1) & 1;                        // parity of the input column c - 1 of column c = 16 cg + 4 blk + x
     int oB[2], oG[2], oV[2];
 #pragma unroll
     for (int rb = 0; rb < 2; rb++) {
         const int row = 4 * rb + q;
-        oB[rb] = (row < 6) ? 2 + 7 * row + 5 + r0 : ((row == 6) ? (r0 ? ABS + 2 : ABS) : (r0 ? ABS : ABS + 2));
-        oG[rb] = 44 + row;
+        oB[rb] = ((row < 6) ? 2 + 7 * row + 5 + r0 : ((row == 6) ? (r0 ? ABS + 2 : ABS) : (r0 ? ABS : ABS + 2))) + i0 * SN_MREC;
+        oG[rb] = 44 + row + i0 * SN_MREC;
     }
     // gradient of the gg value w.r.t. (vl, vt, r, a) = rows 3, 4, 5, 7: index into the sample's table [g3, g4, g5, g7, 0.0]
-    oV[0] = (q == 3) ? 0 : 4;
-    oV[1] = (q == 0) ? 1 : (q == 1) ? 2 : (q == 3) ? 3 : 4;
+    oV[0] = ((q == 3) ? 0 : 4) + i0 * 5;
+    oV[1] = ((q == 0) ? 1 : (q == 1) ? 2 : (q == 3) ? 3 : 4) + i0 * 5;
     constexpr int NCH = (NWV * NSW * ABS + NT - 1) / NT;
 
     // phase cycle counters (scripts/dev/sn_mfma_phases.py): in the development build only -- six 64-bit accumulators are 14 registers the
@@ -636,13 +638,13 @@ __global__ void __launch_bounds__(64 * NWV, 2) snmpc_prologue_mfma_kernel(const 
                 if (i0 + i < ns) {
                     asm volatile("" ::: "memory");      // (the operand reads of a sample stay behind the arithmetic of the one before)
                     const int gi = i0 + i;
-                    const double *rec = recs + gi * SN_MREC;
+                    const double *rec = recs + i * SN_MREC;          // (the wavefront's first sample is in the lane offsets)
                     const double a00 = rec[oA[0][0]], a01 = rec[oA[0][1]], a10 = rec[oA[1][0]], a11 = rec[oA[1][1]];
                     const double bn0 = rec[oB[0]], bn1 = rec[oB[1]];
                     const double bg0 = isg0 ? rec[oG[0]] : bn0, bg1 = isg0 ? rec[oG[1]] : bn1;      // (group 0: the g lanes take the defect)
                     const double ai = sA[gi];
                     const double cf = (s < uph) ? sCoef[s * ns + gi] : 0.0;
-                    const double gv0 = cf * g4s[gi * 5 + oV[0]], gv1 = cf * g4s[gi * 5 + oV[1]];
+                    const double gv0 = cf * g4s[i * 5 + oV[0]], gv1 = cf * g4s[i * 5 + oV[1]];
 #pragma unroll
                     for (int cg = 0; cg < ncg; cg++) {
                         double d0 = __builtin_amdgcn_mfma_f64_4x4x4f64(a00, W[i][0][cg], 0.0, 0, 0, 0);
