@@ -491,7 +491,7 @@ __global__ void __launch_bounds__(64, (NT_ == 5) ? COND_WPS : 1) cond_kernel(con
             // (everything derived from the lane id is derived again in every stage, from a copy the optimiser cannot see through:
             //  held across the stage loop these values cost the registers the last segment lacks)
             int lane_s = lane_cond;
-            if constexpr (!DPPK || SN) asm volatile("" : "+v"(lane_s));          // (the register form has ~40 registers to spare: there the optimiser may keep what it likes -- 45 of 270 vector instructions per pair of stages)
+            if constexpr (!DPPK || SN) asm volatile("" : "+v"(lane_s));          // (the SNMPC LDS form with them kept: 246 registers, no change in time -- its stages wait for the prologue's buffer)          // (the register form has ~40 registers to spare: there the optimiser may keep what it likes -- 45 of 270 vector instructions per pair of stages)
             const int lane = lane_s;
             const int j0 = lane >> 1, r0 = lane & 1, j1 = 32 + (lane >> 1);
             const bool isg = (lane == NB1);
