@@ -485,9 +485,12 @@ __global__ void __launch_bounds__(64, (NT_ == 5) ? COND_WPS : 1) cond_kernel(con
         }
         const int lane_cond = lane;
         // (two call sites per segment: inlined by force, or every captured array lives in scratch)
-        auto stage_body = [&](const int k, auto tsc, RecRows &R) __attribute__((always_inline)) {
+        auto stage_body = [&](const int k, auto tsc, auto g0c, RecRows &R) __attribute__((always_inline)) {
             constexpr int Ts = decltype(tsc)::value;
-            constexpr bool G0 = Ts <= G0_SEGS;
+            // G0: the constant column rides on lane 63 of bank 0 and bank 1 is not issued. LATE: ... in a segment whose tiles reach
+            // column 63 (the register form keeps g there through stage 31, whose input column is the first to need the lane): what
+            // lane 63 stages and stores as its share of the gg row is masked to the zeros of the column that is not there yet
+            constexpr bool G0 = decltype(g0c)::value, LATE = G0 && Ts > G0_SEGS;
             // (everything derived from the lane id is derived again in every stage, from a copy the optimiser cannot see through:
             //  held across the stage loop these values cost the registers the last segment lacks)
             int lane_s = lane_cond;
@@ -621,7 +624,7 @@ __global__ void __launch_bounds__(64, (NT_ == 5) ? COND_WPS : 1) cond_kernel(con
             {
                 const int c_ = (s - 1) >> 2;
                 double *gcs = pa.cws + (size_t)b * NCH * 64 + 16 * ((s - 1) & 3) + lc;
-                if (2 * lq <= c_) gcs[cidx(c_, lq) * 64] = hr0;          // (G0: the lanes 48..63 do not store before stage 25)
+                if (2 * lq <= c_) gcs[cidx(c_, lq) * 64] = LATE ? hr0 * notg63 : hr0;          // (G0: the lanes 48..63 do not store before stage 25)
                 const int T1 = 4 + lq;
                 if (!G0 && lane < NB1 && 2 * T1 <= c_) gcs[cidx(c_, T1) * 64] = hr1;
             }
@@ -629,8 +632,8 @@ __global__ void __launch_bounds__(64, (NT_ == 5) ? COND_WPS : 1) cond_kernel(con
             constexpr bool STAGE_LDS = !DPP2 || COND_STAGE_LDS, GS_LDS = !DPP2 || COND_GS_LDS;
             if constexpr (STAGE_LDS) {
 #pragma unroll
-                for (int r = 0; r < 3; r++) sStage[r * NVP + lane] = w0[r];
-                sStage[3 * NVP + lane] = c30;          // (G0: what lane 63 stages is g, in a column the tiles of these segments do not read)
+                for (int r = 0; r < 3; r++) sStage[r * NVP + lane] = LATE ? w0[r] * notg63 : w0[r];
+                sStage[3 * NVP + lane] = LATE ? c30 * notg63 : c30;          // (G0: what lane 63 stages is g, in a column the tiles of the first three segments do not read)
                 if (!G0 && lane < NB1) {
 #pragma unroll
                     for (int r = 0; r < 3; r++) sStage[r * NVP + 64 + lane] = w1[r];
@@ -704,18 +707,35 @@ __global__ void __launch_bounds__(64, (NT_ == 5) ? COND_WPS : 1) cond_kernel(con
         // stage s = k+1 touches columns < 2s, i.e. ceil(s/8) tiles: one instantiation of the stage per segment of 8 stages
         static_for<1, NT>([&](auto tsc) {
             constexpr int Ts = decltype(tsc)::value;
-            if constexpr (G0_SEGS > 0 && Ts == G0_SEGS + 1) {          // g moves from lane 63 of bank 0 to its lane of bank 1
+            constexpr bool G0S = Ts <= G0_SEGS;
+            auto move_g = [&] {          // g moves from lane 63 of bank 0 to its lane of bank 1
 #pragma unroll
                 for (int i = 0; i < 8; i++) { const double gv = rl(w0[i], 63); w1[i] = isg ? gv : 0.0; w0[i] = (lane == 63) ? 0.0 : w0[i]; }
-            }
-            if constexpr (DPPK) {
-                if constexpr (Ts == 5) fetch_bcol(32 + (lane >> 1));          // (bank 1's input columns: the stages from 32 on)
-                for (int k = 8 * (Ts - 1); k < N && k < 8 * Ts; k += 2) {
-                    stage_body(k, tsc, Ra);
-                    if (k + 1 < N) stage_body(k + 1, tsc, Rb);
+            };
+            using yes = std::integral_constant<bool, true>;
+            using no = std::integral_constant<bool, false>;
+            if constexpr (DPPK && G0_SEGS > 0 && Ts == G0_SEGS + 1) {
+                // the fourth segment of the register form: lane 63 is free until stage 31 inserts its input column -- seven more stages
+                // without bank 1 (its column update, gg row, staging stores and gradient terms: ~60 of ~150 vector instructions a stage)
+                constexpr int kl = 8 * Ts - 1;          // the stage that needs the lane
+                for (int k = 8 * (Ts - 1); k < N && k < kl - 1; k += 2) {
+                    stage_body(k, tsc, yes(), Ra);
+                    if (k + 1 < N) stage_body(k + 1, tsc, yes(), Rb);
                 }
+                if (kl - 1 < N) stage_body(kl - 1, tsc, yes(), Ra);
+                move_g();
+                if (kl < N) stage_body(kl, tsc, no(), Rb);
             } else {
-                for (int k = 8 * (Ts - 1); k < N && k < 8 * Ts; k++) stage_body(k, tsc, Ra);
+                if constexpr (G0_SEGS > 0 && Ts == G0_SEGS + 1) move_g();
+                if constexpr (DPPK) {
+                    if constexpr (Ts == 5) fetch_bcol(32 + (lane >> 1));          // (bank 1's input columns: the stages from 32 on)
+                    for (int k = 8 * (Ts - 1); k < N && k < 8 * Ts; k += 2) {
+                        stage_body(k, tsc, std::integral_constant<bool, G0S>(), Ra);
+                        if (k + 1 < N) stage_body(k + 1, tsc, std::integral_constant<bool, G0S>(), Rb);
+                    }
+                } else {
+                    for (int k = 8 * (Ts - 1); k < N && k < 8 * Ts; k++) stage_body(k, tsc, std::integral_constant<bool, G0S>(), Ra);
+                }
             }
         });
         for (int s = N + 1; s <= NMAX; s++) {          // rows beyond the horizon: zeros
