@@ -317,8 +317,9 @@ __device__ __forceinline__ void apply_A2_rec(const R &rec, double w[8], double v
 // loads per stage, straight from the workspace, two stages ahead in two register sets), and every use of a field is `acc += field * x`
 // with the field as the DPP operand: no LDS read, no scalar register, no extra instruction. The sums are formed in the order the
 // compiler's contraction of the LDS form forms them (x * 1.0 and + 0.0 are exact), so the results are the same to the bit (the tests
-// hold this kernel against cond_wide_kernel, which kept the LDS form). With the stage's weights riding along (lane (q, c) holds W_s[q]:
-// no select chain for the operand scale) and 30 registers fewer, all 15 Hessian tiles stay in registers (COND_NPARK 0).
+// hold this kernel against cond_wide_kernel, which kept the LDS form). With 30 registers fewer all 15 Hessian tiles stay in registers
+// (no tile parked in LDS), lane-derived values are kept instead of re-derived per stage, a lane's input column is fetched once, and the
+// weights are scaled by dt once, in LDS, where a lane reads the one of its operand row (no select chain).
 // COND_DPP 2 (shipped) adds two choices, measured (profiles/r05_ab_cond_dpp.txt): COND_STAGE_LDS 0 moves the four cost rows to the MFMA
 // operand layout (lane (q, c) of tile T <- row q of column 16 T + c, held by lane 16 T + c) by a 4 x 4 transposition of 16-lane rows
 // among four registers -- two levels of gfx950 row swaps (v_permlane32_swap, v_permlane16_swap: 8 instructions for the four tiles of bank
