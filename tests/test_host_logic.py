@@ -575,9 +575,10 @@ def test_log_file_has_the_reference_schema(tmp_path, golden_dir):
 def test_dpp_operands_of_the_condensing_kernel_are_settled(tmp_path):
     """cond_kernel reads its stage record with `v_fmac_f64_dpp ... row_newbcast:n` written as inline asm (csrc/pipe_kernels.hpp,
     RecRows): the compiler's hazard recogniser does not look into it, and gfx9 needs two wait states between a vector instruction
-    that WRITES a register and a DPP read of it. The record registers are only ever written by loads -- unless the register
-    allocator copies them. This test disassembles the shipped library and checks every DPP accumulation: no vector instruction in
-    the two issue slots in front of it (an `s_nop n` counts n + 1) writes its DPP source."""
+    that WRITES a register and a DPP read of it (five after one that writes EXEC). The record registers are only ever written by
+    loads -- unless the register allocator copies them. This test disassembles the shipped library and checks every DPP accumulation:
+    no vector instruction in the two issue slots in front of it (an `s_nop n` counts n + 1) writes its DPP source, none in the five
+    in front of it writes EXEC."""
     import re
     import shutil
     import subprocess
@@ -599,6 +600,7 @@ def test_dpp_operands_of_the_condensing_kernel_are_settled(tmp_path):
         return {int(m.group(1))} if m else set()
 
     n_dpp = 0
+    exec_age = 99        # wait states since a VECTOR instruction wrote EXEC (v_cmpx ...: a DPP operation needs five behind it)
     window = []          # (registers written by a vector instruction, wait states it is away from the next instruction)
     for line in dis.splitlines():
         s = line.split("//")[0].strip()
@@ -612,7 +614,9 @@ def test_dpp_operands_of_the_condensing_kernel_are_settled(tmp_path):
             assert src, s
             for written, dist in window:
                 assert dist >= 2 or not (written & src), ("a vector instruction writes the DPP source within two wait states", s)
+            assert exec_age >= 5, ("a vector instruction writes EXEC within five wait states of a DPP operation", s)
         ws = (int(ops[0]) + 1) if op == "s_nop" else 1
+        exec_age = 0 if (op.startswith("v_cmpx") or (op.startswith("v_") and ops and ops[0].split()[0].startswith("exec"))) else min(exec_age + ws, 99)
         window = [(w, d + ws) for w, d in window if d + ws < 3]
         if op.startswith("v_") and not op.startswith(("v_cmp", "v_readlane", "v_readfirstlane")) and ops:
             written = regs(ops[0].split()[0])
