@@ -1096,6 +1096,7 @@ extern "C" double tum_ocp_last_kernel_ms(tum_ocp *c)
 extern "C" int tum_ocp_get_cost(tum_ocp *c, double *out, int b0, int nb)
 {
     if (chk_range(c, b0, nb)) return 1;
+    if (!out) return fail("null argument");
     if (c->cache_valid) { for (int i = 0; i < nb; i++) out[i] = c->hsum_s[(size_t)(b0 + i) * 5 + 2]; return 0; }
     DevGuard guard(c->d.device); GUARD_OK(guard);
     HIPCHK(hipStreamSynchronize(c->stream));        // (the copy below runs on the NULL stream, which the capsule's non-blocking stream is not ordered with)
