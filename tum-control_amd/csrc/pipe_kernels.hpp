@@ -485,6 +485,33 @@ __global__ void __launch_bounds__(64, (NT_ == 5) ? COND_WPS : 1) cond_kernel(con
             for (int i = 0; i < 8; i++) (G0_SEGS > 0 ? w0[i] : w1[i]) = gx0[i] - gX[i];
         }
         const int lane_cond = lane;
+        // coupled SNMPC OCP: the columns G_nom,s / g_nom,s of a stage s <= uph and its chance-constraint row come from the prologue's
+        // buffer -- requested ONE STAGE AHEAD (18 doubles per lane): fetched where they are used, every one of the uph stages waited a
+        // memory round trip for them
+        double nP0[8], nP1[8], nH0 = 0.0, nH1 = 0.0;
+        auto fetch_pro = [&](const int k, const int ln) {
+            const double *pg = gpro + (size_t)k * PSTAGE;
+            const bool b0 = ln < 2 * (k + 1), b1 = ln < NB1 && 64 + ln < 2 * (k + 1), isg_ = (ln == NB1);
+#pragma unroll
+            for (int i = 0; i < 8; i++) {
+                // (only the 2 (k + 1) live columns of the stage are fetched: the rest of a row is zero, and at UPH = Tp the full rows
+                //  were 200 KB of the 350 KB this kernel read per instance)
+                const double gv = b0 ? pg[i * PP + ln] : 0.0, gg = pg[i * PP + 2 * uph];
+                const double g1 = b1 ? pg[i * PP + 64 + ln] : 0.0;
+                nP0[i] = gv;
+                nP1[i] = isg_ ? gg : g1;
+            }
+            if (k + 1 < uph) {   // chance-constraint row E + kappa sqrt(Var) over the samples of stage s = k + 1
+                const double *pr = pg + 8 * PP;
+                const int s_ = k + 1;
+                const double rv = (ln < 2 * s_) ? pr[ln] : 0.0, rg = pr[2 * uph];
+                const double r1 = (ln < NB1 && 64 + ln < 2 * s_) ? pr[64 + ln] : 0.0;
+                nH0 = rv; nH1 = isg_ ? rg : r1;
+            }
+        };
+        // (the LDS form, which is the one for long propagation horizons; the register form has no 36 registers to spare and few such stages)
+        constexpr bool PRO_AHEAD = SN && !DPPK;
+        if constexpr (PRO_AHEAD) { if (uph > 0) fetch_pro(0, lane); }
         // (two call sites per segment: inlined by force, or every captured array lives in scratch)
         auto stage_body = [&](const int k, auto tsc, auto g0c, RecRows &R) __attribute__((always_inline)) {
             constexpr int Ts = decltype(tsc)::value;
@@ -503,20 +530,15 @@ __global__ void __launch_bounds__(64, (NT_ == 5) ? COND_WPS : 1) cond_kernel(con
             const double *rec = sRec + (k & 1) * PREC;          // (LDS form)
             const double one = 1.0;
             if constexpr (DPPK) R.settle();
+            double cr0 = 0.0, cr1 = 0.0;          // (SNMPC: the chance-constraint row of this stage)
             if (SN && k < uph) {
                 // stage s = k+1 <= uph: G_nom,s and g_nom,s are PCE means of the sample recursions (prologue kernel)
                 // (columns 0..63 in bank 0, 64..2 uph-1 on the lanes of bank 1, the constant column on the g lane)
-                // (only the 2 (k + 1) live columns of the stage are fetched: the rest of a row is zero, and at UPH = Tp the full rows
-                //  were 200 KB of the 350 KB this kernel read per instance)
-                const double *pg = gpro + (size_t)k * PSTAGE;
-                const bool b0 = lane < 2 * (k + 1), b1 = lane < NB1 && 64 + lane < 2 * (k + 1);
+                if constexpr (!PRO_AHEAD) fetch_pro(k, lane);
 #pragma unroll
-                for (int i = 0; i < 8; i++) {
-                    const double gv = b0 ? pg[i * PP + lane] : 0.0, gg = pg[i * PP + 2 * uph];
-                    const double g1 = b1 ? pg[i * PP + 64 + lane] : 0.0;
-                    w0[i] = gv;
-                    w1[i] = isg ? gg : g1;
-                }
+                for (int i = 0; i < 8; i++) { w0[i] = nP0[i]; w1[i] = nP1[i]; }
+                cr0 = nH0; cr1 = nH1;
+                if constexpr (PRO_AHEAD) { if (k + 1 < uph) fetch_pro(k + 1, lane); }
             } else if constexpr (DPPK) {
                 // (the input column of a lane: B_k's column r0 -- two accumulations, the one of the other parity adds 0.0 * field)
                 if constexpr (G0) {
@@ -573,12 +595,7 @@ __global__ void __launch_bounds__(64, (NT_ == 5) ? COND_WPS : 1) cond_kernel(con
                 c30 = w0[3]; c31 = w1[3];          // the speed row of the cost: vl (nominal OCP) ...
                 if constexpr (SN) {
                     R.fmac<PR_G4>(hr0, w0[4]); R.fmac<PR_G4>(hr1, w1[4]);
-                    if (s < uph) {   // chance-constraint row E + kappa sqrt(Var) over the samples (prologue kernel)
-                        const double *pr = gpro + (size_t)k * PSTAGE + 8 * PP;
-                        const double rv = (lane < 2 * s) ? pr[lane] : 0.0, rg = pr[2 * uph];
-                        const double r1 = (lane < NB1 && 64 + lane < 2 * s) ? pr[64 + lane] : 0.0;
-                        hr0 = rv; hr1 = isg ? rg : r1; hdon = 0.0;
-                    }
+                    if (s < uph) { hr0 = cr0; hr1 = cr1; hdon = 0.0; }   // chance-constraint row E + kappa sqrt(Var) over the samples (prologue kernel)
                     // ... or |v| (SNMPC: gradient (vl, vt)/|v|; the second product rounded, the first fused onto it)
                     c30 = 0.0; c31 = 0.0;
                     R.fmac<PR_CV + 1>(c30, w0[4]); R.fmac<PR_CV>(c30, w0[3]);
@@ -603,12 +620,7 @@ __global__ void __launch_bounds__(64, (NT_ == 5) ? COND_WPS : 1) cond_kernel(con
                 double hd = rec[PR_GH + 3];
                 if (SN) {
                     hr0 += g4 * w0[4]; hr1 += g4 * w1[4];
-                    if (s < uph) {   // chance-constraint row E + kappa sqrt(Var) over the samples (prologue kernel)
-                        const double *pr = gpro + (size_t)k * PSTAGE + 8 * PP;
-                        const double rv = (lane < 2 * s) ? pr[lane] : 0.0, rg = pr[2 * uph];
-                        const double r1 = (lane < NB1 && 64 + lane < 2 * s) ? pr[64 + lane] : 0.0;
-                        hr0 = rv; hr1 = isg ? rg : r1; hd = 0.0;
-                    }
+                    if (s < uph) { hr0 = cr0; hr1 = cr1; hd = 0.0; }   // chance-constraint row E + kappa sqrt(Var) over the samples (prologue kernel)
                 }
                 // the speed row of the cost: vl (nominal OCP) or |v| (SNMPC: gradient (vl, vt)/|v|)
                 c30 = SN ? cvl * w0[3] + cvt * w0[4] : w0[3]; c31 = SN ? cvl * w1[3] + cvt * w1[4] : w1[3];
