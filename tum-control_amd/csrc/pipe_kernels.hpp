@@ -367,10 +367,13 @@ struct RecRows {
 // w <- A_k w (+ the same for a second bank v): apply_A's sums, term by term in its order
 // (the rows 0..2 -- px, py, psi -- are no operands of any row: updated in place, row 2 behind the two rows that read it; only the
 //  rows 3..5 need fresh accumulators. The instruction is destructive -- acc is source and destination --, every copy is a vector move)
-template <bool TWO>
-__device__ __forceinline__ void apply_A_rows(const RecRows &R, double w[8], double v[8])
+// INS: the rows 3..5 of bank w start from ins[0..2] (the lane's input column times its stage selector: a product that is zero wherever
+// the sum behind it is not, so the order of the two does not matter) instead of from zero -- three vector moves and three FMAs less
+template <bool TWO, bool INS = false>
+__device__ __forceinline__ void apply_A_rows(const RecRows &R, double w[8], double v[8], const double *ins = nullptr)
 {
     double n[3] = {0.0, 0.0, 0.0}, m[3] = {0.0, 0.0, 0.0};
+    if constexpr (INS) { n[0] = ins[0]; n[1] = ins[1]; n[2] = ins[2]; }
     R.fmac<0>(w[0], w[2]); R.fmac<1>(w[1], w[2]);
     if constexpr (TWO) { R.fmac<0>(v[0], v[2]); R.fmac<1>(v[1], v[2]); }
     static_for<0, 5>([&](auto ic) {
@@ -542,10 +545,11 @@ __global__ void __launch_bounds__(64, (NT_ == 5) ? COND_WPS : 1) cond_kernel(con
             } else if constexpr (DPPK) {
                 // (the input column of a lane: B_k's column r0 -- two accumulations, the one of the other parity adds 0.0 * field)
                 if constexpr (G0) {
-                    apply_A_rows<false>(R, w0, w0);
                     const double sel0 = (j0 == k) ? 1.0 : 0.0, selg = (lane == 63) ? 1.0 : 0.0;
+                    const double ins[3] = {sel0 * bcol[3], sel0 * bcol[4], sel0 * bcol[5]};
+                    apply_A_rows<false, true>(R, w0, w0, ins);
 #pragma unroll
-                    for (int i = 0; i < 6; i++) w0[i] += sel0 * bcol[i];
+                    for (int i = 0; i < 3; i++) w0[i] += sel0 * bcol[i];
                     w0[6] += sel0 * b6c; w0[7] += sel0 * b7c;
                     static_for<0, 7>([&](auto ic) { constexpr int i = decltype(ic)::value; R.fmac<44 + i>(w0[i], selg); });
                 } else {
