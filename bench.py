@@ -158,6 +158,8 @@ def parse_args(argv=None):
                          "rounds 1-5 report; measured difference 4.037 vs 4.032 M solves/s, profiles/r05_bind_inputs.txt)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-host-legs", action="store_true", help="skip the host-visible legs (N=1 only)")
+    ap.add_argument("--no-other-configs", action="store_true",
+                    help="skip the bounded legs of configs 3 / 4 / 5 and the coupled SNMPC OCP that the default N=1 line carries as `other_configs`")
     ap.add_argument("--no-schedule-legs", action="store_true",
                     help="skip the repeated-batch, natural-order and N = 38 legs (N=1 only)")
     return ap.parse_args(argv)
@@ -352,8 +354,13 @@ class Job:
             self.drain()                      # (the last results have been READ on the host when the clock stops)
         self.barrier()
         elapsed = time.perf_counter() - t0
+        self.rank_elapsed = [elapsed]
         if self.distributed:
+            # max over ranks = the job's time; every rank's own time rides along (per-rank rates in the line)
             tt = self.torch.tensor([elapsed], dtype=self.torch.float64, device=self.dev)
+            every = [self.torch.zeros_like(tt) for _ in range(self.world)]
+            self.dist.all_gather(every, tt)
+            self.rank_elapsed = [float(t.item()) for t in every]
             self.dist.all_reduce(tt, op=self.dist.ReduceOp.MAX)
             elapsed = float(tt.item())
         return elapsed, marks
@@ -375,6 +382,7 @@ def run(args, torch, dist, dev, world, rank, local_rank, solver_factory, workloa
     for i in range(args.warmup):
         job.step(fresh=None if args.same_batch else i)
     elapsed, marks = job.timed(args.steps, fresh=not args.same_batch)
+    rank_elapsed = list(job.rank_elapsed)
     kern_ms = job.solve_ms(marks)             # device time between the events around a solve (S > 1: shared with other batches)
     gat_ms = job.gather_ms(marks)
     # correctness of what was timed: statuses and iteration counts of the batches the capsules solved last
@@ -506,6 +514,7 @@ def run(args, torch, dist, dev, world, rank, local_rank, solver_factory, workloa
                    "scenario_group": gsz, "groups_per_gpu": P, "solves_per_step": spp,
                    "streams": S,
                    "collective_backend": (dist.get_backend() if job.distributed else None),
+                   "collective_world_size": (dist.get_world_size() if job.distributed else None),
                    "streams_note": "steps are dealt to `streams` capsules in turn, each with its own buffers on its own HIP stream: every "
                                    "step is a complete pass over one fresh batch, consecutive batches overlap on the GPU (`value`); "
                                    "`value_single_stream` is the same loop on one capsule / one stream",
@@ -529,6 +538,10 @@ def run(args, torch, dist, dev, world, rank, local_rank, solver_factory, workloa
                              "(`value_host_visible_with_iterate`), through pinned slabs and an event per capsule (tum_ocp_results_async / "
                              "_wait): the copy of one batch crosses PCIe while the next batches run",
         "solve_ms_per_step": kern_ms * spp, "gather_ms_per_step": gat_ms,
+        "per_rank": {"value": [(sharding_size(job, r) * spp * args.steps / t) for r, t in enumerate(rank_elapsed)],
+                     "ms_per_step": [1e3 * t / args.steps for t in rank_elapsed],
+                     "note": "every rank's own instances / its own wall time between the two barriers (rank 0's gather_ms_per_step is the "
+                             "rooted gather as the root sees it); `value` = all instances / the slowest rank's time"},
         "roofline": {"bound": "mfma", "achieved": ach_tf, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
                      "frac": ach_tf / FP64_PEAK_TFLOPS, "traffic": traffic, "traffic_source": traffic_src,
                      "kernel": "pipeline of lin_kernel + cond_kernel + ipm_kernel + expand_kernel (kernel_ms = device time of one solve"
@@ -548,6 +561,13 @@ def run(args, torch, dist, dev, world, rank, local_rank, solver_factory, workloa
     return out, job
 
 
+def sharding_size(job, r):
+    """instances of rank r's shard"""
+    from tum_control_amd import sharding
+    lo, hi = sharding.shard_range(job.groups_total, job.world, r)
+    return (hi - lo) * job.gsz
+
+
 def n38_leg(args, torch, dev, solver_factory):
     """"also report N = 38" (the reference's own horizon, Tp = 3.04 s): fresh-batch rate of config 2 at N = 38."""
     a = argparse.Namespace(**vars(args)); a.horizon = 38; a.config = 2; a.batch = None; a.scaling = "weak"; a.no_schedule_legs = True
@@ -557,34 +577,189 @@ def n38_leg(args, torch, dev, solver_factory):
             "mean_qp_iter": out["roofline"]["mean_qp_iter"], "status_ok_frac": out["status_ok_frac"]}
 
 
+def _free_port():
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
+def self_launch(args, argv):
+    """`python bench.py --gpus N` started WITHOUT a launcher (no RANK in the environment): start the N ranks ourselves -- one
+    process per GPU, the same script and arguments, RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR=127.0.0.1 / MASTER_PORT (a free
+    port) in the environment exactly as torch.distributed.run would set them -- and wait for them. Rank 0's ONE JSON line goes to
+    our stdout (inherited); a rank that fails takes the others down with it (the exact PIDs started here) and its exit code is
+    ours. Under torch.distributed.run (RANK set) this function is never reached: that path is unchanged."""
+    import signal
+    import subprocess
+    n = args.gpus
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+               BENCH_SELF_LAUNCHED="1")
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")        # (dmabuf IPC: RCCL between processes needs it on this driver)
+    env.setdefault("OMP_NUM_THREADS", str(max(1, usable_cores() // n)))
+    cmd = [sys.executable, os.path.abspath(__file__)] + list(sys.argv[1:] if argv is None else argv)
+    procs = []
+    for r in range(n):
+        procs.append(subprocess.Popen(cmd, env=dict(env, RANK=str(r), LOCAL_RANK=str(r)), stdin=subprocess.DEVNULL))
+    deadline = time.time() + float(os.environ.get("BENCH_LAUNCH_TIMEOUT", 1800))
+    rc = 0
+    try:
+        live = list(procs)
+        while live:
+            for p in list(live):
+                c = p.poll()
+                if c is not None:
+                    live.remove(p)
+                    if c != 0 and rc == 0:
+                        rc = c
+            if rc != 0 or time.time() > deadline:
+                if rc == 0:
+                    rc = 124
+                break
+            time.sleep(0.05)
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.send_signal(signal.SIGTERM)
+        for p in procs:
+            try:
+                p.wait(timeout=20)
+            except subprocess.TimeoutExpired:
+                p.kill()
+    if rc != 0:
+        raise SystemExit(f"bench.py --gpus {n}: a rank exited with code {rc}" if rc != 124 else f"bench.py --gpus {n}: ranks timed out")
+
+
+def _test_solver_factory():
+    """TUM_BENCH_TEST_SOLVER=module:Class (tests only): the control flow of this file on CPU / gloo with a stand-in solver class the
+    TEST supplies (tests/test_host_logic.py). The product has no CPU path: without this switch a missing GPU is an error."""
+    spec = os.environ.get("TUM_BENCH_TEST_SOLVER")
+    if not spec:
+        return None
+    import importlib
+    mod, attr = spec.split(":")
+    return getattr(importlib.import_module(mod), attr)
+
+
+def other_configs_legs(args, torch, dev, solver_factory, steps=8, warmup=3):
+    """The other BASELINE configurations and the coupled SNMPC OCP inside the driver-timed line (N = 1 only, a bounded leg each):
+    configs 3 / 4 / 5 at their per-GPU size through the SAME `run` as the headline (fresh batches over three capsules, barriers and
+    device syncs around `steps` steps), the coupled 88-state SNMPC OCP (N = 38, ten samples) at the shipped propagation
+    horizon (uph = 5) and at UPH = Tp (uph = 38): cold start + solve of 4096 instances, one capsule and three in flight."""
+    out = {}
+    for cid in (3, 4, 5):
+        try:
+            a = argparse.Namespace(**vars(args)); a.config = cid; a.batch = None; a.scaling = "weak"; a.steps = steps; a.warmup = warmup
+            a.no_schedule_legs = True; a.no_host_legs = True
+            o, job = run(a, torch, None, dev, 1, 0, dev.index or 0, solver_factory, extra_legs=False)
+            out[str(cid)] = {"value": o["value"], "ms_per_step": o["ms_per_step"], "batch": o["config"]["batch_per_gpu"],
+                             "solves_per_step": o["config"]["solves_per_step"], "steps": steps, "streams": o["config"]["streams"],
+                             "status_ok_frac": o["status_ok_frac"], "mean_qp_iter": o["roofline"]["mean_qp_iter"],
+                             "roofline": {"frac": o["roofline"]["sustained"]["frac"], "achieved": o["roofline"]["sustained"]["achieved"],
+                                          "unit": "TFLOP/s", "note": "algorithmic FLOPs per solve x value / FP64 peak (rate of the timed region)"},
+                             "workload": o["config"]["workload"]}
+            del job, o
+        except Exception as e:       # (a leg that fails must not take the headline with it; it says so in the line)
+            out[str(cid)] = {"error": repr(e)}
+    try:
+        out.update(snmpc_legs(dev))
+    except Exception as e:
+        out["snmpc"] = {"error": repr(e)}
+    return out
+
+
+def snmpc_legs(dev, B=4096, N=38, rounds=6):
+    from tum_control_amd import config, snmpc as snm
+    from tum_control_amd.solver import CoupledSnmpcSolver
+    from tum_control_amd.streaming import SolverRing
+    from tum_control_amd.workloads import nominal_batch
+    import torch
+    stds = np.asarray(config.MPC["stds"], dtype=float)
+    w = snm.hammersley_normal(10, 3)
+    A = snm.pce_matrix(w, snm.alpha_generation(3, 2))
+    offs = snm.x0_offsets(w, stds)
+    x0, yref = nominal_batch(B, N=N)
+    X0 = np.concatenate([x0[:, None, :], x0[:, None, :] + offs[None]], axis=1).reshape(B, -1)
+    out = {}
+    for uph in (5, 38):
+        def mk(_):
+            c = CoupledSnmpcSolver(N=N, dt=0.08, batch=B, Apce=A, uph=uph, gamma=config.MPC["gamma"], device=dev.index or 0)
+            c.install_reference_ocp()
+            c.constraints_set(0, "lbx", X0); c.constraints_set(0, "ubx", X0)
+            c.set_yref_all(yref)
+            return c
+        res = {"N": N, "uph": uph, "n_samples": 10, "batch": B}
+        for S in (1, 3):
+            ring = SolverRing(S, mk)
+            for _ in range(2 * S):
+                _, c = ring.acquire(); c.cold_start(); c.solve_async()
+            ring.synchronize(); torch.cuda.synchronize()
+            K = rounds * S
+            t0 = time.perf_counter()
+            for _ in range(K):
+                _, c = ring.acquire(); c.cold_start(); c.solve_async()
+            ring.synchronize(); torch.cuda.synchronize()
+            dt_ = time.perf_counter() - t0
+            ok = min(float((c.get_stats("status") == 0).mean()) for c in ring)
+            it = float(np.mean([c.get_stats("qp_iter").mean() for c in ring]))
+            key = "single_capsule" if S == 1 else "three_capsules"
+            res[key] = {"value": B * K / dt_, "ms_per_batch": 1e3 * dt_ / K, "batches": K, "status_ok_frac": ok, "mean_qp_iter": it}
+            del ring
+        res["value"] = res["three_capsules"]["value"]
+        out[f"snmpc_uph{uph}"] = res
+    return out
+
+
 def main(argv=None):
     args = parse_args(argv)
+    launched = os.environ.get("RANK") is not None             # by torch.distributed.run, or by self_launch below
+    if not launched and (args.gpus > 1 or os.environ.get("BENCH_SELF_LAUNCH") == "1"):
+        return self_launch(args, argv)
     import torch
     import torch.distributed as dist
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    distributed = world > 1 or os.environ.get("RANK") is not None     # launched by torch.distributed.run
-    if not torch.cuda.is_available():
+    distributed = world > 1 or launched
+    stand_in = _test_solver_factory()
+    if stand_in is None and not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the solver has no CPU fallback)")
     if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE is {world}: launch with `python -m torch.distributed.run --nnodes=1 "
-                         f"--nproc-per-node {args.gpus} ... bench.py --gpus {args.gpus}` (one rank per GPU)")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE is {world}: start it as `python bench.py --gpus {args.gpus}` (it launches its "
+                         f"own ranks) or as `python -m torch.distributed.run --nnodes=1 --nproc-per-node {args.gpus} ... bench.py --gpus {args.gpus}`")
+    if stand_in is None:
+        if local_rank >= torch.cuda.device_count():
+            raise SystemExit(f"rank {rank}: LOCAL_RANK {local_rank} but only {torch.cuda.device_count()} GPU(s) are visible (one rank per GPU)")
+        torch.cuda.set_device(local_rank)
+        dev = torch.device("cuda", local_rank)
+    else:
+        dev = torch.device("cpu")
     if distributed:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group(backend="nccl", device_id=dev)
-        assert dist.get_world_size() == args.gpus, f"RCCL world size {dist.get_world_size()} != --gpus {args.gpus}"
-    from tum_control_amd.solver import BatchedOcpSolver
+        if stand_in is None:
+            dist.init_process_group(backend="nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend="gloo")
+        assert dist.get_world_size() == args.gpus, f"world size {dist.get_world_size()} != --gpus {args.gpus}"
+    if stand_in is None:
+        from tum_control_amd.solver import BatchedOcpSolver as factory
+    else:
+        factory = stand_in
 
-    res = run(args, torch, dist if distributed else None, dev, world, rank, local_rank, BatchedOcpSolver)
+    res = run(args, torch, dist if distributed else None, dev, world, rank, local_rank, factory)
     if rank == 0:
         out, job = res
-        if world == 1 and not args.no_schedule_legs and args.horizon != 38 and args.config == 2:
-            out["n38"] = n38_leg(args, torch, dev, BatchedOcpSolver)
-        if not args.no_cpu_baseline and world == 1:
+        out["launch"] = ("self-launched ranks (bench.py --gpus N)" if os.environ.get("BENCH_SELF_LAUNCHED") == "1" else
+                         "torch.distributed.run" if launched else "single process")
+        if stand_in is not None:
+            out["data"] = "stand-in solver on CPU / gloo (control-flow test, not a measurement)"
+        gpu_legs = stand_in is None and world == 1
+        if gpu_legs and not args.no_schedule_legs and args.horizon != 38 and args.config == 2:
+            out["n38"] = n38_leg(args, torch, dev, factory)
+        if gpu_legs and not args.no_other_configs and args.config == 2 and args.horizon == 40 and not args.same_batch:
+            out["other_configs"] = other_configs_legs(args, torch, dev, factory)
+        if not args.no_cpu_baseline and world == 1 and stand_in is None:
             x0, yref = job.host[0]
             cb, u_ref = cpu_baseline(job.N, x0, yref, job.s.cfg)
             out["cpu_baseline"] = cb

@@ -327,6 +327,33 @@ def test_bench_under_torchrun_world_size_1_rccl(iterate):
     assert out["config"]["gather_iterate"] == iterate and out["config"]["gather_bytes_per_rank"] == 8 * 16384 * (5 + (41 * 8 + 40 * 2 if iterate else 0))
 
 
+def test_bench_self_launched_world_size_1_rccl():
+    """`python bench.py --gpus N` with no launcher around it starts its own ranks (bench.self_launch); BENCH_SELF_LAUNCH=1 forces that
+    branch at N = 1, so the whole self-launched multi-GPU path runs on the MI355X -- child process per GPU, MASTER_ADDR 127.0.0.1 and a
+    free port, init_process_group("nccl") (= RCCL), the rooted gather and the per-rank all_gather inside / behind the timed region --
+    minus a second rank. The line says how it was launched and what the collective library reports."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, BENCH_SELF_LAUNCH="1")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "BENCH_SELF_LAUNCHED"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "5", "--warmup", "2", "--no-cpu-baseline",
+           "--no-schedule-legs", "--no-host-legs", "--no-other-configs"]
+    r = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{") and '"metric"' in ln]
+    assert len(lines) == 1, r.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["launch"].startswith("self-launched") and out["n_gpus"] == 1
+    assert out["config"]["collective_backend"] == "nccl" and out["config"]["collective_world_size"] == 1
+    assert out["config"]["batch_per_gpu"] == 4096 and out["status_ok_frac"] == 1.0
+    assert isinstance(out["gather_ms_per_step"], float) and 0.0 < out["gather_ms_per_step"] < 50.0
+    assert len(out["per_rank"]["value"]) == 1 and abs(out["per_rank"]["value"][0] / out["value"] - 1.0) < 0.05
+    assert out["value"] > 1e6
+
+
 def test_results_on_the_host_through_pinned_slabs():
     """tum_ocp_results_async / _wait: the summary (u0, cost, status, qp_iter) and the whole iterate of a batch arrive in the
     capsule's pinned host slabs behind an event, equal to what the synchronous getters return; three capsules in a ring with

@@ -452,6 +452,50 @@ def test_bench_control_flow_world2_gloo(scaling):
         lo += sz
 
 
+def test_bench_launches_its_own_ranks_world2_gloo():
+    """`python bench.py --gpus 2` with NO launcher around it (the shape of the driver's BENCH command with a larger N): bench.py
+    starts its two ranks itself (bench.self_launch: RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR = 127.0.0.1 / a free port, as
+    torch.distributed.run sets them), the ranks form a process group (gloo here, with the stand-in solver the test supplies through
+    TUM_BENCH_TEST_SOLVER; nccl = RCCL on GPUs), rank 0 prints the ONE JSON line, exit code 0. Round 5's bench.py exited with
+    "launch with torch.distributed.run" here."""
+    import json
+    import subprocess
+    env = dict(os.environ, TUM_BENCH_TEST_SOLVER="test_host_logic:_StandInSolver",
+               PYTHONPATH=os.pathsep.join([os.path.join(ROOT, "tests"), ROOT, os.environ.get("PYTHONPATH", "")]))
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "BENCH_SELF_LAUNCHED"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--config", "4", "--horizon", "6",
+           "--batch", "48", "--streams", "2", "--no-cpu-baseline"]
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{") and '"metric"' in ln]
+    assert len(lines) == 1, r.stdout[-2000:]
+    o = json.loads(lines[0])
+    assert o["n_gpus"] == 2 and o["steps"] == 3 and o["scaling"] == "weak"
+    assert o["launch"].startswith("self-launched")
+    assert o["config"]["collective_backend"] == "gloo" and o["config"]["collective_world_size"] == 2
+    assert o["config"]["global_batch"] == 96 and o["config"]["batch_per_gpu"] == 48
+    assert o["value"] > 0 and abs(o["value"] * o["ms_per_step"] * 1e-3 - 96) < 1e-6 * 96
+    assert len(o["per_rank"]["value"]) == 2 and all(v > 0 for v in o["per_rank"]["value"])
+    assert o["value"] <= sum(o["per_rank"]["value"]) * (1 + 1e-9)          # the job's rate is set by the slowest rank
+    assert o["gather_ms_per_step"] >= 0 and o["status_ok_frac"] == 1.0
+    assert "stand-in" in o["data"] and o["cpu_baseline"] is None
+
+
+def test_bench_self_launch_propagates_a_failing_rank():
+    """a rank that dies takes the job down with a non-zero exit code and no JSON line (here: more ranks than scenario groups)"""
+    import subprocess
+    env = dict(os.environ, TUM_BENCH_TEST_SOLVER="test_host_logic:_StandInSolver",
+               PYTHONPATH=os.pathsep.join([os.path.join(ROOT, "tests"), ROOT, os.environ.get("PYTHONPATH", "")]))
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "BENCH_SELF_LAUNCHED"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--config", "4", "--horizon", "6",
+           "--scaling", "strong", "--global-batch", "16", "--no-cpu-baseline"]
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0
+    assert not [ln for ln in r.stdout.splitlines() if '"metric"' in ln]
+
+
 def test_workload_variants_are_fresh_batches_of_the_same_workload():
     """variant 0 is the BASELINE configuration; variants k > 0 (what bench.py rotates through) differ from it and from each
     other in every instance but keep the group structure (one yref per scenario group)."""
