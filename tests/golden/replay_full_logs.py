@@ -188,6 +188,12 @@ def replay_log(args):
                 acados_mean_qp_iter=float(aq.mean()), exceptions=exc)
 
 
+# Ratchet (round 6): the gate holds what is committed -- 13 exceptions on four Monteblanco loops (sets 8, 12, 16, 21; at most 7 on
+# one loop; worst 6.44e-3 at set 21 step 3852). A change that adds an exception, lengthens a run or worsens the worst case fails;
+# one that removes exceptions passes and the constants are then lowered with the regenerated report.
+MAX_EXC, MAX_EXC_PER_LOG, WORST_BOUND = 13, 7, 6.5e-3
+
+
 def gate(report):
     """The assertion of the gate on a report (list of per-log entries). Returns a one-line summary."""
     nexc = 0
@@ -197,12 +203,13 @@ def gate(report):
             nexc += 1
             assert e["shift_when_tolerances_tighten_100x"] < 0.1 * TOL, (r["track"], r["k"], e)      # (i) our answer is converged
             assert e["acados_qp_iter_max_lookback"] >= HARD_IT, (r["track"], r["k"], e)               # (ii) acados laboured there
-        assert len(r["exceptions"]) <= 15, (r["track"], r["k"])                                        # (iii) short runs
+        assert len(r["exceptions"]) <= MAX_EXC_PER_LOG, (r["track"], r["k"])                           # (iii) short runs
+        assert r["worst_comparable"] <= WORST_BOUND, (r["track"], r["k"], r["worst_comparable"])       # (iv) and bounded
         assert r["worst_comparable"] <= TOL or r["exceptions"], (r["track"], r["k"])
         if r["track"] == "lvms":
             assert not r["exceptions"], (r["track"], r["k"])
     ncomp = sum(r["n_comparable"] for r in report)
-    assert nexc <= 2e-4 * ncomp, (nexc, ncomp)
+    assert nexc <= MAX_EXC, (nexc, ncomp)
     return (f"{len(report)} logs, {sum(r['n'] for r in report)} solves, {ncomp} comparable, {ncomp - nexc} within {TOL:g}, {nexc} exceptions "
             f"on {sum(bool(r['exceptions']) for r in report)} logs (each with its evidence)")
 
