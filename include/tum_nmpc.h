@@ -65,9 +65,15 @@ typedef struct tum_ocp_desc {
      * violation above 0.1; otherwise it starts cold); tum_ocp_cold_start / tum_ocp_reset forget them -- pushed back into the interior and
      * re-centred to the complementarity target qp_warm_mu (0: the default 1e-2). The QP solution is the same to the solver's
      * tolerances; 9 % fewer interior point iterations over the reference's logged closed loops (profiles/r05_ipm_iterations.txt).
-     * The Python binding switches it on by default. */
+     * The Python binding switches it on by default for every controller -- for the nominal and R2 solvers a documented deviation from
+     * the reference's setting ("Interior point warm start"). */
     int qp_warm_start;
     double qp_warm_mu;
+    /* the proximity gate of the warm start: an instance starts warm only when at most qp_warm_flips row sides changed their activity
+     * against the previous QP (0: the default 16; < 0: no gate -- a development aid, measured to stall solves at the iteration cap on
+     * jumping sequences, profiles/r05_warm_gate.txt) and no new violation exceeds qp_warm_viol (0: the default 0.1). */
+    int qp_warm_flips;
+    double qp_warm_viol;
 } tum_ocp_desc;
 
 /* AcadosOcpSolver(ocp, json_file=..., generate=..., build=...)   NMPC_STM_acados_settings.py:243 */

@@ -10,7 +10,7 @@ N, B = 40, int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 x0, yref = nominal_batch(B, N=N)
 from tum_control_amd import solver as _sv
 with _sv.dev_library():
-    s = BatchedOcpSolver(N=N, dt=0.08, nsub=3, batch=B)
+    s = BatchedOcpSolver(N=N, dt=0.08, nsub=3, batch=B, qp_warm_start=False)
 s.install_reference_ocp(); s.set_x0(x0); s.set_yref_all(yref); s.set_kernel("pipeline4")
 s.cold_start(); s.solve(); ms0 = s.last_kernel_ms()
 s.cold_start(); p = s.profile_phases(); it = s.get_stats("qp_iter")

@@ -13,7 +13,7 @@ import contextlib
 from tum_control_amd import solver as _sv
 x0, yref = nominal_batch(B, N=N)
 with (_sv.dev_library() if KERNEL in ("fused", "pipeline4") else contextlib.nullcontext()):      # (development build)
-    s = BatchedOcpSolver(N=N, dt=0.08, nsub=3, batch=B)
+    s = BatchedOcpSolver(N=N, dt=0.08, nsub=3, batch=B, qp_warm_start=(False if KERNEL in ("fused", "pipeline4") else None))
 s.install_reference_ocp(); s.set_x0(x0); s.set_yref_all(yref); s.set_kernel(KERNEL)
 s.cold_start(); s.solve(); ms0 = s.last_kernel_ms()
 s.cold_start(); p = s.profile_phases(); ms1 = s.last_kernel_ms()

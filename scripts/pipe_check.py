@@ -15,7 +15,7 @@ for name in sys.argv[1:] or ["fused", "pipeline"]:
     import contextlib
     from tum_control_amd import solver as _sv
     with (_sv.dev_library() if name in ("fused", "pipeline4") and "TUM_NMPC_LIB" not in os.environ else contextlib.nullcontext()):
-        s = BatchedOcpSolver(N=N, batch=B, store_qp_in=False)      # (fused / pipeline4: development build)
+        s = BatchedOcpSolver(N=N, batch=B, store_qp_in=False, qp_warm_start=(False if name in ("fused", "pipeline4") else None))      # (fused / pipeline4: development build, cold-started interior point method)
     s.install_reference_ocp(); s.set_kernel(name); s.set_kernel("time-ipm")
     s.set_x0(x0); s.set_yref_all(yref)
     ms, ipm = [], []

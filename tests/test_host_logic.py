@@ -541,11 +541,11 @@ def test_solver_ring_results_bookkeeping():
     assert list(ring.drain()) == [] and ring.take_results(2) is None
     with pytest.raises(ValueError):
         SolverRing(0, Fake)
-    # four or more capsules: measured unstable on the MI355X (streams share hardware queues) -> cut back to three, loudly
+    # four or more capsules: measured unstable on the MI355X (streams share hardware queues) -> refused unless the caller insists
     from tum_control_amd import streaming
-    with pytest.warns(UserWarning, match="3 created"):
-        r4 = SolverRing(4, Fake, streams=None)
-    assert len(r4) == streaming.MAX_STABLE_SLOTS == 3
+    with pytest.raises(ValueError, match="allow_unstable"):
+        SolverRing(4, Fake, streams=None)
+    assert streaming.MAX_STABLE_SLOTS == 3 and ring.n_slots == len(ring) == 3
     assert len(SolverRing(5, Fake, allow_unstable=True)) == 5
 
 
@@ -607,6 +607,7 @@ def test_log_file_has_the_reference_schema(tmp_path, golden_dir):
     for k in ("CiLX", "MPC_SimX"):
         raw[k] = np.concatenate([raw[k], raw[k][-1:]])
     a = cl.log_file_arrays(raw, 0, T=110.0)
+    assert cl.log_file_arrays(raw, 0)["t"][-1] == 100.0          # default: sim_main_params['T'] as Logger.save_logs takes it, not the run length
     p = tmp_path / "full_logs.npz"
     np.savez(p, **a)
     mine = np.load(p)

@@ -256,7 +256,7 @@ def _gpu_vs_oracle(golden_dir, N, uph, poses, nsolve=3, shift_ref=0, kernel=None
     import contextlib
     from tum_control_amd import solver as _sv
     with (_sv.dev_library() if kernel == "fused" else contextlib.nullcontext()):      # (the fused kernel: development build)
-        s = CoupledSnmpcSolver(N=N, dt=0.08, batch=B, Apce=A, uph=uph, gamma=0.8)
+        s = CoupledSnmpcSolver(N=N, dt=0.08, batch=B, Apce=A, uph=uph, gamma=0.8, qp_warm_start=(False if kernel == "fused" else None))
     if kernel:
         s.set_kernel(kernel)
     if prologue:
@@ -384,7 +384,7 @@ def test_gpu_coupled_snmpc_condensed_qp(golden_dir, N, uph, lib):
     o.yref[:] = Y; o.x0[:] = xs + 1e-3; o.X[:] = X; o.U[:] = U
     _, qp = o.solve_debug()
     with (_sv.dev_library() if lib == "dev" else contextlib.nullcontext()):
-        s = CoupledSnmpcSolver(N=N, dt=0.08, batch=1, Apce=A, uph=uph, gamma=0.8)
+        s = CoupledSnmpcSolver(N=N, dt=0.08, batch=1, Apce=A, uph=uph, gamma=0.8, qp_warm_start=(False if lib == "dev" else None))
     s.install_reference_ocp()
     s.constraints_set(0, "lbx", (xs + 1e-3).flatten()); s.constraints_set(0, "ubx", (xs + 1e-3).flatten())
     s.set_yref_all(Y)
@@ -609,7 +609,7 @@ def test_gpu_snmpc_errors():
         CoupledSnmpcSolver(N=40, batch=1, Apce=A, uph=41)
     from tum_control_amd import solver as _sv
     with _sv.dev_library():
-        f = CoupledSnmpcSolver(N=40, batch=1, Apce=A, uph=32)       # beyond 31 stages: pipeline only
+        f = CoupledSnmpcSolver(N=40, batch=1, Apce=A, uph=32, qp_warm_start=False)       # beyond 31 stages: pipeline only
     f.install_reference_ocp(); f.set_kernel("fused")
     with pytest.raises(Exception, match="fused"):
         f.solve()
@@ -856,9 +856,9 @@ def test_gpu_instrumented_kernels_agree(kind):
     for mode in ("plain", "phases", "dump"):
         with _sv.dev_library():        # (the fused kernel lives in the development build; the pipeline has its own test below)
             if kind == "snmpc":
-                s = CoupledSnmpcSolver(N=40, batch=8, Apce=A, uph=5, x0_offsets=snm.x0_offsets(w, stds))
+                s = CoupledSnmpcSolver(N=40, batch=8, Apce=A, uph=5, x0_offsets=snm.x0_offsets(w, stds), qp_warm_start=False)
             else:
-                s = BatchedOcpSolver(N=40, batch=8)
+                s = BatchedOcpSolver(N=40, batch=8, qp_warm_start=False)
         s.set_kernel("fused")
         s.install_reference_ocp(); s.set_x0(x0); s.set_yref_all(yref); s.cold_start()
         if mode == "plain":

@@ -173,7 +173,7 @@ def log_file_arrays(logs, b, w_deriv=None, e_est=None, T=None, Ts=0.02, drop_las
     return dict(MPC_SimX=SimX, CiLX=CiLX, simU=simU, simREF=simREF, simSolverDebug=dbg,
                 sim_disturbance_derivatives=realisation(w_deriv), sim_disturbance_state_estimation=realisation(e_est),
                 a_lat=CiLX[:, 3] * CiLX[:, 5], dev_lat=dev_lat, dev_long=dev_long, dev_vel=dev_vel, dev_yaw=dev_yaw,
-                t=np.linspace(0.0, n_run * Ts if T is None else T, n))
+                t=np.linspace(0.0, _config.SIM["T"] if T is None else T, n))      # (Logging_Plotting.py:348-349: always sim_main_params['T'], whatever the run length)
 
 
 class MovingAverageEstimator:

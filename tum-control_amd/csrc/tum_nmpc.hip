@@ -207,7 +207,10 @@ extern "C" tum_ocp *tum_ocp_create(const tum_ocp_desc *desc)
     ka.warm_mu = desc->qp_warm_start ? (desc->qp_warm_mu > 0 ? desc->qp_warm_mu : 1e-2) : 0.0;
     ka.qp_lam = c->dqplam;
     // (the gate of the warm start: constants of the oracle study, scripts/study/warm_gate.py; TUM_WARM_GATE=0 removes it -- development aid)
-    { const char *e = getenv("TUM_WARM_GATE"); ka.warm_flips = (e && e[0] == '0') ? -1 : 16; ka.warm_viol = 0.1; }
+    // tum_ocp_desc.qp_warm_flips / qp_warm_viol override them (flips < 0: no gate)
+    { const char *e = getenv("TUM_WARM_GATE");
+      ka.warm_flips = (e && e[0] == '0') ? -1 : (desc->qp_warm_flips != 0 ? desc->qp_warm_flips : 16);
+      ka.warm_viol = desc->qp_warm_viol > 0 ? desc->qp_warm_viol : 0.1; }
     Model &m = ka.mp;
     m.lf = desc->lf; m.lr = desc->lr; m.m = desc->m; m.inv_m = 1.0 / desc->m; m.inv_Iz = 1.0 / desc->Iz;
     m.ka = 0.5 * desc->ro * desc->S * desc->Cd;
@@ -500,6 +503,8 @@ static int shadow_ready(tum_ocp *c)
 {
     if (!c->hin_s) {
         HIPCHK(hipHostMalloc((void **)&c->hin_s, sizeof(double) * (size_t)c->batch * (NX + (size_t)(c->N + 1) * 6), hipHostMallocDefault));
+        // (a stage-N reference has four entries: the two behind it in its six-double record are uploaded with it and must not be garbage)
+        memset(c->hin_s, 0, sizeof(double) * (size_t)c->batch * (NX + (size_t)(c->N + 1) * 6));
         HIPCHK(hipEventCreateWithFlags(&c->ev_in, hipEventDisableTiming));
     }
     // the upload kernel of an asynchronous solve may still be reading the shadow

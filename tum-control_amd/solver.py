@@ -41,7 +41,8 @@ class TumOcpDesc(ctypes.Structure):
            ("qp_iter_max", ctypes.c_int),
            ("qp_tol_stat", ctypes.c_double), ("qp_tol_ineq", ctypes.c_double), ("qp_tol_comp", ctypes.c_double),
            ("qp_mu0", ctypes.c_double), ("qp_t0", ctypes.c_double), ("store_qp_in", ctypes.c_int),
-           ("qp_warm_start", ctypes.c_int), ("qp_warm_mu", ctypes.c_double)]
+           ("qp_warm_start", ctypes.c_int), ("qp_warm_mu", ctypes.c_double),
+           ("qp_warm_flips", ctypes.c_int), ("qp_warm_viol", ctypes.c_double)]
     )
 
 
@@ -154,7 +155,8 @@ def load_library(path=None):
 
 
 def make_desc(N, dt, nsub, batch, device=0, cfg=None, store_qp_in=False, qp_iter_max=50,
-              qp_tol=(1e-8, 1e-8, 1e-8), qp_mu0=0.05, qp_t0=0.05, qp_warm_start=True, qp_warm_mu=0.0):
+              qp_tol=(1e-8, 1e-8, 1e-8), qp_mu0=0.05, qp_t0=0.05, qp_warm_start=True, qp_warm_mu=0.0,
+              qp_warm_flips=0, qp_warm_viol=0.0):
     cfg = cfg or _config.default_config()
     d = TumOcpDesc()
     d.N, d.nsub, d.dt, d.batch, d.device = int(N), int(nsub), float(dt), int(batch), int(device)
@@ -177,6 +179,7 @@ def make_desc(N, dt, nsub, batch, device=0, cfg=None, store_qp_in=False, qp_iter
     d.store_qp_in = 1 if store_qp_in else 0
     d.qp_warm_start = 1 if qp_warm_start else 0
     d.qp_warm_mu = float(qp_warm_mu)
+    d.qp_warm_flips, d.qp_warm_viol = int(qp_warm_flips), float(qp_warm_viol)      # (0: the library's defaults 16 / 0.1)
     return d
 
 
@@ -191,14 +194,19 @@ class BatchedOcpSolver:
     """`batch` independent copies of the nominal NMPC OCP on one MI355X; acados method names."""
 
     def __init__(self, N=38, dt=0.08, nsub=3, batch=1, device=0, cfg=None, store_qp_in=False,
-                 qp_iter_max=50, qp_tol=(1e-8, 1e-8, 1e-8), qp_mu0=0.05, qp_t0=0.05, qp_warm_start=None, qp_warm_mu=0.0):
+                 qp_iter_max=50, qp_tol=(1e-8, 1e-8, 1e-8), qp_mu0=0.05, qp_t0=0.05, qp_warm_start=None, qp_warm_mu=0.0,
+                 qp_warm_flips=0, qp_warm_viol=0.0):
         self._L = load_library()
         self.N, self.dt, self.nsub, self.batch = int(N), float(dt), int(nsub), int(batch)
         self.cfg = cfg or _config.default_config()
         if qp_warm_start is None:
-            # (acados: qp_solver_warm_start) on by default; the development build's extra kernels always cold-start the method
-            qp_warm_start = (_default_path or LIB_PATH) != DEV_LIB_PATH
-        self._desc = make_desc(N, dt, nsub, batch, device, self.cfg, store_qp_in, qp_iter_max, qp_tol, qp_mu0, qp_t0, qp_warm_start, qp_warm_mu)
+            # (acados: qp_solver_warm_start) ON by default for every controller, whichever library is loaded -- a deliberate, documented
+            # deviation for the nominal and R2 solvers, where the reference leaves the option at acados' default 0 (INTEGRATION.md,
+            # "Interior point warm start"; qp_warm_start=False gives the cold-started method). The development build's extra kernels
+            # ("fused", "pipeline4") always cold-start the method and ignore the flag.
+            qp_warm_start = True
+        self._desc = make_desc(N, dt, nsub, batch, device, self.cfg, store_qp_in, qp_iter_max, qp_tol, qp_mu0, qp_t0, qp_warm_start, qp_warm_mu,
+                               qp_warm_flips, qp_warm_viol)
         self._h = self._L.tum_ocp_create(ctypes.byref(self._desc))
         if not self._h:
             raise RuntimeError("tum_ocp_create failed: " + self._err())
@@ -409,6 +417,8 @@ class BatchedOcpSolver:
 
     def results_outstanding(self):
         """result requests enqueued on this capsule and not yet waited for (0, 1 or 2)"""
+        if not hasattr(self._L, "tum_ocp_results_outstanding"):      # (a saved build of an earlier round, scripts/dev/ab2.py)
+            return 0
         return int(self._L.tum_ocp_results_outstanding(self._h))
 
     def step(self, x0=None, yref=None, with_iterate=True):
@@ -538,9 +548,11 @@ class CoupledSnmpcSolver(BatchedOcpSolver):
     """
 
     def __init__(self, N=38, dt=0.08, batch=1, Apce=None, uph=5, gamma=0.8, device=0, cfg=None,
-                 qp_iter_max=50, qp_tol=(1e-8, 1e-8, 1e-8), qp_mu0=0.05, qp_t0=0.05, x0_offsets=None, qp_warm_start=None, qp_warm_mu=0.0):
+                 qp_iter_max=50, qp_tol=(1e-8, 1e-8, 1e-8), qp_mu0=0.05, qp_t0=0.05, x0_offsets=None, qp_warm_start=None, qp_warm_mu=0.0,
+                 qp_warm_flips=0, qp_warm_viol=0.0):
         super().__init__(N=N, dt=dt, nsub=1, batch=batch, device=device, cfg=cfg, qp_iter_max=qp_iter_max,
-                         qp_tol=qp_tol, qp_mu0=qp_mu0, qp_t0=qp_t0, qp_warm_start=qp_warm_start, qp_warm_mu=qp_warm_mu)
+                         qp_tol=qp_tol, qp_mu0=qp_mu0, qp_t0=qp_t0, qp_warm_start=qp_warm_start, qp_warm_mu=qp_warm_mu,
+                         qp_warm_flips=qp_warm_flips, qp_warm_viol=qp_warm_viol)
         self.Apce = np.ascontiguousarray(Apce, dtype=np.float64)
         if self.Apce.ndim != 2:
             raise Exception("CoupledSnmpcSolver: Apce must be (num_poly_terms, n_samples)")

@@ -11,8 +11,8 @@ cold start, solve, result packing) runs on that capsule's stream, so consecutive
 still gets a complete, independent solve. Measured on config 2 (4096 x N = 40, fresh batch every step; profiles/r04_streams.txt,
 round 5: profiles/r05_streams.txt): 3.3 M solves/s on one capsule, 3.8 / 4.0 M on two / three. FOUR OR MORE ARE NOT STABLE: 2.8-4.0 M
 at four, 1.8-3.7 M at six from run to run -- the runtime multiplexes streams onto four hardware queues, and once capsules share a queue
-their batches serialise in an order the caller does not control. `SolverRing` therefore caps the number of capsules at
-MAX_STABLE_SLOTS = 3 (with a warning) unless the caller insists (`allow_unstable=True`).
+their batches serialise in an order the caller does not control. `SolverRing` therefore refuses more than
+MAX_STABLE_SLOTS = 3 capsules unless the caller insists (`allow_unstable=True`).
 
 Results on the host ride the same ring: `request_results(slot)` enqueues, behind the solve on that capsule's stream, the copy
 of the batch's results into one of the capsule's two pinned host slabs and an event (C-ABI: tum_ocp_results_async);
@@ -35,16 +35,15 @@ class SolverRing:
     def __init__(self, n_slots, factory, streams=None, allow_unstable=False):
         """factory(slot) -> a configured BatchedOcpSolver (all slots must describe the same OCP); streams: optional list of
         raw hipStream_t handles (ints), one per slot (default: every capsule keeps the non-blocking stream it created).
-        More than MAX_STABLE_SLOTS capsules are cut back to that number, with a warning, unless allow_unstable."""
+        More than MAX_STABLE_SLOTS capsules are refused (ValueError) unless allow_unstable."""
         if n_slots < 1:
             raise ValueError("n_slots < 1")
         if n_slots > MAX_STABLE_SLOTS and not allow_unstable:
-            import warnings
-            warnings.warn(f"SolverRing: {n_slots} capsules asked for, {MAX_STABLE_SLOTS} created -- with four or more streams the measured rate "
-                          f"varies by up to 2x from run to run (capsules start sharing hardware queues); allow_unstable=True overrides")
-            if streams is not None:
-                streams = list(streams)[:MAX_STABLE_SLOTS]
-            n_slots = MAX_STABLE_SLOTS
+            # (rounds 4-5 cut the ring back with a warning: a caller that sized its own per-slot structures by ITS number then indexed
+            #  past the ring. Refused instead; len(ring) / ring.n_slots is the number of capsules a ring has.)
+            raise ValueError(f"SolverRing: {n_slots} capsules asked for, at most {MAX_STABLE_SLOTS} run with a reproducible rate -- with four or "
+                             f"more streams the measured rate varies by up to 2x from run to run (capsules start sharing hardware queues); "
+                             f"allow_unstable=True overrides")
         self.solvers = [factory(i) for i in range(n_slots)]
         if streams is not None:
             if len(streams) != n_slots:
@@ -55,6 +54,10 @@ class SolverRing:
         self._pending = [0] * n_slots          # outstanding result requests per capsule (the C-ABI allows two)
 
     def __len__(self):
+        return len(self.solvers)
+
+    @property
+    def n_slots(self):
         return len(self.solvers)
 
     def __getitem__(self, i):
