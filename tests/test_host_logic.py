@@ -618,7 +618,9 @@ def test_log_file_has_the_reference_schema(tmp_path, golden_dir):
 
 
 def test_dpp_operands_of_the_condensing_kernel_are_settled(tmp_path):
-    """cond_kernel reads its stage record with `v_fmac_f64_dpp ... row_newbcast:n` written as inline asm (csrc/pipe_kernels.hpp,
+    """(Round 6: the interior point kernel's lane-distributed micro-panels use the same instruction -- fnmac_bc / fmac_bc of csrc/pipe_kernels.hpp --
+    and are covered by the same scan, plus the check of their results' consumers among the matrix instructions.)
+    cond_kernel reads its stage record with `v_fmac_f64_dpp ... row_newbcast:n` written as inline asm (csrc/pipe_kernels.hpp,
     RecRows): the compiler's hazard recogniser does not look into it, and gfx9 needs two wait states between a vector instruction
     that WRITES a register and a DPP read of it (five after one that writes EXEC). The record registers are only ever written by
     loads -- unless the register allocator copies them. This test disassembles the shipped library and checks every DPP accumulation:
@@ -647,6 +649,7 @@ def test_dpp_operands_of_the_condensing_kernel_are_settled(tmp_path):
     n_dpp = 0
     exec_age = 99        # wait states since a VECTOR instruction wrote EXEC (v_cmpx ...: a DPP operation needs five behind it)
     window = []          # (registers written by a vector instruction, wait states it is away from the next instruction)
+    dpp_window = []      # the same for the DPP accumulations alone (their consumers among the matrix instructions)
     for line in dis.splitlines():
         s = line.split("//")[0].strip()
         if not s or s.endswith(":") or not re.match(r"^[a-z]", s):
@@ -655,12 +658,21 @@ def test_dpp_operands_of_the_condensing_kernel_are_settled(tmp_path):
         ops = [t.strip() for t in rest.split(",")] if rest else []
         if op.startswith("v_fmac_f64_dpp"):
             n_dpp += 1
-            src = regs(ops[1].split()[0])
+            src = regs(ops[1].split()[0].lstrip("-"))          # (a negated broadcast operand: -v[a:b])
             assert src, s
             for written, dist in window:
                 assert dist >= 2 or not (written & src), ("a vector instruction writes the DPP source within two wait states", s)
             assert exec_age >= 5, ("a vector instruction writes EXEC within five wait states of a DPP operation", s)
+        if op.startswith("v_mfma"):
+            # (round 6, found at N = 48) the hazard recogniser does not know that the inline asm is a vector instruction either: a matrix
+            # instruction must not take a register a DPP accumulation wrote within two wait states as its A / B operand
+            srcs = set().union(*(regs(t.split()[0]) for t in ops[1:3]))
+            for written, dist in dpp_window:
+                assert dist >= 2 or not (written & srcs), ("a matrix instruction reads a register a DPP accumulation wrote within two wait states", s)
         ws = (int(ops[0]) + 1) if op == "s_nop" else 1
+        dpp_window = [(w, d + ws) for w, d in dpp_window if d + ws < 3]
+        if op.startswith("v_fmac_f64_dpp"):
+            dpp_window.append((regs(ops[0].split()[0]), 0))
         exec_age = 0 if (op.startswith("v_cmpx") or (op.startswith("v_") and ops and ops[0].split()[0].startswith("exec"))) else min(exec_age + ws, 99)
         window = [(w, d + ws) for w, d in window if d + ws < 3]
         if op.startswith("v_") and not op.startswith(("v_cmp", "v_readlane", "v_readfirstlane")) and ops:

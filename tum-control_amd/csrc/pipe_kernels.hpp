@@ -364,6 +364,31 @@ struct RecRows {
     //  the asm above: one s_nop behind whatever produced the registers, which every later use depends on)
     __device__ __forceinline__ void settle() { asm volatile("s_nop 1" : "+v"(g[0]), "+v"(g[1]), "+v"(g[2]), "+v"(g[3])); }
 };
+// ---- lane-distributed 4 x 4 pivot blocks of the interior point kernel's micro-panels (round 6): a value that lives on ONE lane of every
+// 16-lane row is consumed as the `row_newbcast` operand of an FP64 FMA / reciprocal -- no wave-uniform copy of it, no lane select
+// acc -= (lane L of the row of b) * x
+template <int L> __device__ __forceinline__ void fnmac_bc(double &acc, double b, double x)
+{
+    static_assert(L >= 0 && L < 16, "lane of the row");
+    asm("v_fmac_f64_dpp %0, -%1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(b), "v"(x), "n"(L));
+}
+// acc -= (lane L of the row of acc) * x
+// SETTLE: two wait states behind it. The compiler's hazard recogniser does not know that the asm is a vector instruction: a MATRIX instruction
+// that takes acc as an operand right behind it read a stale register (found at N = 48: the last micro-panel of the last block column hands its
+// X straight to a 4x4x4 product -- 3e-4 on the last stage's jerk, everything else exact). Results that go to plain vector instructions first
+// need nothing: the hardware interlocks those.
+template <int L, bool SETTLE = false> __device__ __forceinline__ void fnmac_bc_self(double &acc, double x)
+{
+    if constexpr (SETTLE) asm("v_fmac_f64_dpp %0, -%0, %1 row_newbcast:%2 row_mask:0xf bank_mask:0xf\n\ts_nop 1" : "+v"(acc) : "v"(x), "n"(L));
+    else asm("v_fmac_f64_dpp %0, -%0, %1 row_newbcast:%2 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(x), "n"(L));
+}
+// acc += (lane L of the row of b) * x
+// (v_rcp_f64_dpp assembles but does not work: scripts/probes/probe_dpp_f64.cpp returns inf -- the reciprocal of a pivot is taken on every lane
+//  and its lane reaches the others through this FMA)
+template <int L> __device__ __forceinline__ void fmac_bc(double &acc, double b, double x)
+{
+    asm("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(b), "v"(x), "n"(L));
+}
 // w <- A_k w (+ the same for a second bank v): apply_A's sums, term by term in its order
 // (the rows 0..2 -- px, py, psi -- are no operands of any row: updated in place, row 2 behind the two rows that read it; only the
 //  rows 3..5 need fresh accumulators. The instruction is destructive -- acc is source and destination --, every copy is a vector move)
@@ -1514,17 +1539,18 @@ __global__ void __launch_bounds__(64, IPM_WPS) ipm_kernel(const PArgs pa)
         }
         // ---- blocked L D L' factorisation (row-panel register tiles as in the fused kernel; the 4-column micro-panels differ:
         //      no LDS round trips, see below)
-        // smallest pivot, tracked through the HIGH WORDS of the (wave-uniform) pivots as signed integers: for positive doubles
-        // the order is the same, a negative pivot has a negative high word; integer minima instead of 4 v_min_f64 (+ 4
-        // canonicalising v_max_f64) per micro-panel
+        // smallest pivot, tracked through the HIGH WORDS of the pivots as signed integers (every lane its own: lane x of a block holds
+        // pivot x; any lane below the threshold fails the factorisation): for positive doubles the order is the same, a negative
+        // pivot has a negative high word; one integer minimum per micro-panel
         int dmin_hi = 0x3ff00000;
-        // lane predicates of the P operand (opaque to the optimiser: as plain compares of lc the select chains below become a
-        // switch with branches)
-        // (P is replicated over the four 4-lane blocks of a DPP row: lane (k, 4 blk + x) holds P[k][x] for every blk, the A
-        //  operand layout of v_mfma_f64_4x4x4_4b below)
-        int ec0 = (lc & 3) == 0, ec1 = (lc & 3) == 1, ec2 = (lc & 3) == 2, eq0 = lq == 0, eq1 = lq == 1, eq2 = lq == 2;
-        const double eu0 = (lq == 0) ? 1.0 : 0.0, eu1 = (lq == 1) ? 1.0 : 0.0, eu2 = (lq == 2) ? 1.0 : 0.0, eu3 = (lq == 3) ? 1.0 : 0.0;
-        asm volatile("" : "+v"(ec0), "+v"(ec1), "+v"(ec2), "+v"(eq0), "+v"(eq1), "+v"(eq2));
+        // lane-distributed pivot blocks: x = lc & 3 is the lane's row of the 4 x 4 block; its column j is read from the strip of the
+        // micro-panel at 16 j + 4 m + x, its diagonal at 17 x + 4 m; masks of the strictly lower part, the unit vector of the lane's row
+        // of lanes (X = L^-1 e_lq) and (lq == 0)
+        const int mpx = lc & 3;
+        const double *mp_col = sBk + mpx, *mp_dg = sBk + 17 * mpx;
+        double mpM0 = (mpx > 0) ? 1.0 : 0.0, mpM1 = (mpx > 1) ? 1.0 : 0.0, mpM2 = (mpx > 2) ? 1.0 : 0.0;
+        double mp_ex = (mpx == lq) ? 1.0 : 0.0, mp_e0 = (lq == 0) ? 1.0 : 0.0;
+        asm volatile("" : "+v"(mpM0), "+v"(mpM1), "+v"(mpM2), "+v"(mp_ex), "+v"(mp_e0));
         // tiled factor: element (row lc, column 4 q + lq) of a tile, q = 0..3 (operands of the left-looking update, column stores of
         // the micro-panels), and (row 4 q + lq, column lc) (stores of the inverse diagonal blocks)
         const int slc = D::tile_swz(lc);
@@ -1587,7 +1613,7 @@ __global__ void __launch_bounds__(64, IPM_WPS) ipm_kernel(const PArgs pa)
                 }
             TUM_TICK(10);
             // four 4-column micro-panels. The 4x4 diagonal block sits in column m of the diagonal tile: entry (i, j) on lane
-            // 16 j + 4 m + i. It is read into scalars (v_readlane) and factorised uniformly; the panel below it is scaled by
+            // 16 j + 4 m + i. It is factorised lane-distributed (below); the panel below it is scaled by
             // ONE MFMA per tile with the 4x4 upper triangular P = L^-T D^-1 as the A operand (new column block = E P, straight
             // into the lanes that hold E), so there is no LDS round trip inside a micro-panel: finished columns are only
             // stored. The scaling is FOUR independent 4x4x4 products (16 rows x 4 columns, K = 4): one v_mfma_f64_4x4x4_4b
@@ -1601,7 +1627,7 @@ __global__ void __launch_bounds__(64, IPM_WPS) ipm_kernel(const PArgs pa)
             // The identity tile T[NT] goes through the same two MFMAs: what comes out is W = L^-T D^-1 of the 16x16 diagonal
             // block, and L^-1 = (W D)^T is stored into the strict lower triangle of the block (the solves use the inverse
             // diagonal blocks; L of the diagonal block itself is never read again).
-            double Lc[NT + 1], bd = 0.0, pop = 0.0, dselp = 0.0;
+            double Lc[NT + 1], bd = 0.0, pop = 0.0, bprev = 0.0, LcW = 0.0;
 #pragma unroll
             for (int m = 0; m < 4; m++) {
                 const int c0 = 16 * J + 4 * m;
@@ -1611,103 +1637,94 @@ __global__ void __launch_bounds__(64, IPM_WPS) ipm_kernel(const PArgs pa)
                     if (m > 0 && k < nd) {
                         const int I = J + 1 + k;
                         Lc[I] = mfma4(pop, T[I][m - 1]);
+                        if (I == NT) LcW = mfma4(bprev, T[NT][m - 1]);          // rows of L^-1 of the diagonal block: the unscaled X through the identity tile
                     } else if (m > 0 && k < 2 * nd) {
                         const int I = J + 1 + k - nd;
                         if (I < NT) { if constexpr (D::TILED) sT[D::offt(I, J) * 256 + e4[m > 0 ? m - 1 : 0]] = Lc[I]; else sM[rb[I] + c0 - 4 + lq] = Lc[I]; }
-                        else if constexpr (D::DENSE_W) lds[(4 * (m - 1) + lq > lc) ? D::I_W + J * D::W_TILE + w4[m > 0 ? m - 1 : 0] : I_DUMMY] = Lc[NT] * dselp;
-                        else sM[(4 * (m - 1) + lq > lc) ? lpk_row(c0 - 4, lq, trilq) + 16 * J + lc : (I_DUMMY - I_M)] = Lc[NT] * dselp;
+                        // (every lane stores: the unscaled X through the identity tile gives EXACTLY 1 on the diagonal of L^-1 and 0 above it --
+                        //  the identity tile's entries above its diagonal only ever meet zero factors -- so the store needs no lane condition)
+                        else if constexpr (D::DENSE_W) lds[D::I_W + J * D::W_TILE + w4[m > 0 ? m - 1 : 0]] = LcW;
+                        else sM[(4 * (m - 1) + lq > lc) ? lpk_row(c0 - 4, lq, trilq) + 16 * J + lc : (I_DUMMY - I_M)] = LcW;
                         T[I] = mfma(bd, Lc[I], T[I]);
                     }
                     __builtin_amdgcn_sched_barrier(0);
                 };
-                // The ten entries of the block reach every lane through LDS: the strip is stored as it is and read back at
-                // wave-uniform addresses (broadcasts: 4 x 16 bytes + 2 x 8). Twenty v_readlane into scalar registers cost as
-                // many issue slots as the whole pivot arithmetic, and a dozen moves back on top (a VALU instruction of this
-                // part takes ONE scalar operand); the round trip runs under the matrix instructions the previous micro-panel owes.
-                typedef double dpair __attribute__((ext_vector_type(2)));
+                // The 4 x 4 block is factorised LANE-DISTRIBUTED (round 6; rounds 2-5 read its ten entries back from the strip at wave-uniform
+                // addresses and ran the whole pivot arithmetic wave-uniform, with twenty v_cndmask per micro-panel to place P, the
+                // reciprocals and the pivots on their lanes). The strip goes through LDS once and every lane reads ITS entries. Lane x (= lc & 3, the same in every 4-lane block of every row)
+                // holds row x of the block: column j in register Aj (entries on and below the diagonal: the strip's upper triangle read
+                // transposed), the diagonal in Dg. A pivot row's entry reaches the other lanes as the `row_newbcast` operand of the FMA
+                // that uses it (fnmac_bc, fmac_bc; the reciprocal of pivot j is taken on every lane and lane j's is the broadcast one): nothing of the block is
+                // wave-uniform any more -- no ten broadcast reads, no lane selects of P, the reciprocals and the pivots (rounds 2-5: 40 FP64
+                // instructions and 20 v_cndmask per micro-panel; now 28 and none). Dg ends as (d_0 .. d_3) on the lanes x = 0 .. 3, so
+                // 1 / d_x for the scaling of P is one reciprocal of Dg; row lq runs the substitution L X = e_lq across its lanes, and
+                // L D of the diagonal tile (the A operand of the rank-4 update) comes out of a second 4x4x4 product with the UNSCALED X
+                // instead of a select of the pivots and a multiplication.
                 sBk[lane] = T[J][m];
-                const dpair c01 = *reinterpret_cast<const dpair *>(sBk + 4 * m), c23 = *reinterpret_cast<const dpair *>(sBk + 4 * m + 2);
-                const double a11 = sBk[16 + 4 * m + 1];
-                const dpair e23 = *reinterpret_cast<const dpair *>(sBk + 16 + 4 * m + 2), f23 = *reinterpret_cast<const dpair *>(sBk + 32 + 4 * m + 2);
-                const double a33 = sBk[48 + 4 * m + 3];
+                double A0 = mp_col[4 * m], A1 = mp_col[16 + 4 * m], A2 = mp_col[32 + 4 * m], Dg = mp_dg[4 * m];
                 owed(0);
                 owed(1);
                 owed(2);
-                const double a00 = c01[0], a10 = c01[1], a20 = c23[0], a30 = c23[1], a21 = e23[0], a31 = e23[1], a22 = f23[0], a32 = f23[1];
-#ifdef TUM_EXP_PIV2
-                // (experiment, HISTORY.md (round-4 document, section 7): the four pivots in TWO reciprocal levels instead of four -- 1/d1 = a00 / det(A[0:2,0:2])
-                //  beside 1/d0, 1/d3 = d2 / det of the 2x2 Schur block beside 1/d2)
-                const double d0 = a00, i0 = frcp(d0);
-                const double det2 = fma(a00, a11, -(a10 * a10)), r2 = frcp(det2);
+                // pivot 0
+                const double r0 = frcp(Dg);                       // (lane 0: 1 / d_0)
+                const double AM0 = A0 * mpM0;
                 owed(3);
-                const double l10 = a10 * i0, l20 = a20 * i0, l30 = a30 * i0;
-                const double i1 = a00 * r2, d1 = det2 * i0;
+                double lm0 = 0.0;
+                fmac_bc<0>(lm0, r0, AM0);                       // column 0 of L below the diagonal (0 on the lanes x <= 0)
+                Dg = fma(-lm0, A0, Dg);
+                fnmac_bc<1>(A1, A0, lm0);
+                fnmac_bc<2>(A2, A0, lm0);
+                double bx = fma(-lm0, mp_e0, mp_ex);               // X = e_lq - l_0 X_0
                 owed(4);
-                const double y21 = a21 - l20 * a10, y31 = a31 - l30 * a10;
-                const double l21 = y21 * i1, l31 = y31 * i1;
+                // pivot 1
+                const double r1 = frcp(Dg);                       // (lane 1: 1 / d_1)
+                const double AM1 = A1 * mpM1;
                 owed(5);
-                const double d2 = a22 - l20 * a20 - l21 * y21, i2 = frcp(d2);
-                const double y32 = a32 - l30 * a20 - l31 * y21;
-                const double s33 = a33 - l30 * a30 - l31 * y31;
+                double lm1 = 0.0;
+                fmac_bc<1>(lm1, r1, AM1);
+                Dg = fma(-lm1, A1, Dg);
+                fnmac_bc<2>(A2, A1, lm1);
+                fnmac_bc_self<1>(bx, lm1);
                 owed(6);
-                const double det2b = fma(d2, s33, -(y32 * y32)), r2b = frcp(det2b);
-                const double l32 = y32 * i2;
-                const double X1 = eu1 - l10 * eu0;
+                // pivot 2
+                const double r2 = frcp(Dg);                       // (lane 2: 1 / d_2)
+                const double AM2 = A2 * mpM2;
                 owed(7);
-                const double i3 = d2 * r2b, d3 = det2b * i2;
-                const double X2 = eu2 - l20 * eu0 - l21 * X1;
+                double lm2 = 0.0;
+                fmac_bc<2>(lm2, r2, AM2);
+                Dg = fma(-lm2, A2, Dg);
+                fnmac_bc_self<2, true>(bx, lm2);          // (bx goes to matrix instructions: settled)
                 owed(8);
-#else
-                const double d0 = a00, i0 = frcp(d0);
-                owed(3);
-                const double l10 = a10 * i0, l20 = a20 * i0, l30 = a30 * i0;
-                const double d1 = a11 - l10 * a10, i1 = frcp(d1);
-                owed(4);
-                const double y21 = a21 - l20 * a10, y31 = a31 - l30 * a10;
-                const double l21 = y21 * i1, l31 = y31 * i1;
-                owed(5);
-                const double d2 = a22 - l20 * a20 - l21 * y21, i2 = frcp(d2);
-                owed(6);
-                const double y32 = a32 - l30 * a20 - l31 * y21;
-                const double l32 = y32 * i2;
-                // P[k][x] = (L^-1)[x][k] / d_x on lane (k, x) = (lq, lc), x < 4: every lane runs the substitution for ITS column
-                // k of L^-1 (unit vector e_k as the start: one instruction stream, six FMAs), then picks row x
-                const double X1 = eu1 - l10 * eu0;
-                owed(7);
-                const double d3 = a33 - l30 * a30 - l31 * y31 - l32 * y32, i3 = frcp(d3);
-                const double X2 = eu2 - l20 * eu0 - l21 * X1;
-                owed(8);
-#endif
-                dmin_hi = min(min(min(dmin_hi, __double2hiint(d0)), min(__double2hiint(d1), __double2hiint(d2))), __double2hiint(d3));
-                const double X3 = eu3 - l30 * eu0 - l31 * X1 - l32 * X2;
+                // 1 / d_x on lane x, P = X / d, and the smallest pivot (per lane here: any lane may hold it)
+                const double RR = frcp(Dg);
+                dmin_hi = min(dmin_hi, __double2hiint(Dg));
                 owed(9);
-                const double Xx = ec0 ? eu0 : ec1 ? X1 : ec2 ? X2 : X3;
+                const double popn = bx * RR;
                 owed(10);
-                const double ix = ec0 ? i0 : ec1 ? i1 : ec2 ? i2 : i3;
                 owed(11);
-                const double popn = Xx * ix;
                 owed(12);
-                const double dsel = eq0 ? d0 : eq1 ? d1 : eq2 ? d2 : d3;
                 const int rel = lc - (4 * m + lq);              // row - column inside the diagonal tile
+                bprev = bx;
                 pop = popn;
-                dselp = dsel;
                 Lc[J] = mfma4(pop, T[J][m]);
-                if constexpr (D::TILED) lds[(rel == 0) ? D::I_D + c0 + lq : I_DUMMY] = dsel;
-                else sM[(rel == 0) ? rb[J] + c0 + lq : (I_DUMMY - I_M)] = dsel;
+                bd = mfma4(-bx, T[J][m]);                       // - (L D) of the diagonal tile's columns
+                // (the lane (lq, 4 m + lq) that stores pivot lq holds it in Dg: x = lq there)
+                if constexpr (D::TILED) lds[(rel == 0) ? D::I_D + c0 + lq : I_DUMMY] = Dg;
+                else sM[(rel == 0) ? rb[J] + c0 + lq : (I_DUMMY - I_M)] = Dg;
                 // (the rank-4 update takes the scaled columns as they are: their rows on and above the 4x4 diagonal block --
                 //  1 and 0 up to rounding -- only reach entries of the diagonal tile in rows or columns that are finished and
                 //  never read again)
-                bd = -Lc[J] * dsel;
                 if (m < 3) T[J] = mfma(bd, Lc[J], T[J]);
             }
             // what the last micro-panel owes: scaled columns
 #pragma unroll
             for (int I = J + 1; I <= NT; I++) Lc[I] = mfma4(pop, T[I][3]);
+            LcW = mfma4(bprev, T[NT][3]);
 #pragma unroll
             for (int I = J + 1; I <= NT; I++) {
                 if (I < NT) { if constexpr (D::TILED) sT[D::offt(I, J) * 256 + e4[3]] = Lc[I]; else sM[rb[I] + 16 * J + 12 + lq] = Lc[I]; }
-                else if constexpr (D::DENSE_W) lds[(12 + lq > lc) ? D::I_W + J * D::W_TILE + w4[3] : I_DUMMY] = Lc[NT] * dselp;
-                else sM[(12 + lq > lc) ? lpk_row(16 * J + 12, lq, trilq) + 16 * J + lc : (I_DUMMY - I_M)] = Lc[NT] * dselp;
+                else if constexpr (D::DENSE_W) lds[D::I_W + J * D::W_TILE + w4[3]] = LcW;
+                else sM[(12 + lq > lc) ? lpk_row(16 * J + 12, lq, trilq) + 16 * J + lc : (I_DUMMY - I_M)] = LcW;
             }
             wsync();
             TUM_TICK(11);
@@ -1724,7 +1741,7 @@ __global__ void __launch_bounds__(64, IPM_WPS) ipm_kernel(const PArgs pa)
         }
         TUM_TICK(4);
 
-        if (dmin_hi < 0x01a56e1f) { qp_status = 3; break; }          // a pivot below 1e-300 (or negative): the factorisation failed
+        if (__any(dmin_hi < 0x01a56e1f)) { qp_status = 3; break; }          // a pivot below 1e-300 (or negative): the factorisation failed
         // ---- predictor / corrector
         if constexpr (!HOLD_DG) {
             int lane_r = lane_outer;
