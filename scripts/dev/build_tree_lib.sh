@@ -1,7 +1,7 @@
 #!/bin/bash
 # Builds the library of the WORKING TREE with extra flags (experiment macros) for A/B runs against the shipped one:
 #   scripts/dev/build_tree_lib.sh <tag> [extra hipcc flags ...]   ->   exp_libs/lib_tree_<tag>.so
-# e.g.   scripts/dev/build_tree_lib.sh piv2 -DTUM_EXP_PIV2
+# e.g.   scripts/dev/build_tree_lib.sh o2 -O2      (the experiment macros of rounds 3-5 are gone: round 6 removed the switches that lost)
 set -eu
 TAG=$1; shift
 ROOT=$(git rev-parse --show-toplevel)

@@ -11,8 +11,8 @@
 //                       diagonal, the inverse diagonal blocks and the pivot vector, 31 KiB (34 KiB in all); six tiles: packed by
 //                       rows, 26 KiB -- the gg rows live in registers in MFMA operand layout, H is streamed tile by tile from
 //                       the workspace (L2); the tile operands of the substitutions are read from LDS straight into accumulator
-//                       registers. (Built with -DIPM_WPS=2 the same source is bounded to 256 registers, two wavefronts per
-//                       SIMD: measured slower, HISTORY.md (round-4 document, section 7).)
+//                       registers. (Bounded to 256 registers -- two wavefronts per SIMD -- the same method was measured slower:
+//                       HISTORY.md, round-4 document, section 7; the build switch went with round 6's clean-up.)
 //   K3' ipm4_kernel     (ipm4_kernel.hpp) the same method with FOUR wavefronts per OCP, each below 128 registers.
 //   K4  expand_kernel   one wavefront per OCP: dx recursion, full step, cost at the new iterate. For batches of at most one
 //                       round of resident wavefronts the nominal OCP runs it as the tail of K3 instead (ipm_kernel<., ., true>).
@@ -24,22 +24,10 @@
 #include "snmpc_kernels.hpp"
 
 // wavefronts per SIMD the interior point kernel is bounded to (1: the whole register file; 2: an experiment build, HISTORY.md (round-4 document, section 7))
-#ifndef IPM_WPS
-#define IPM_WPS 1
-#endif
 
 namespace tum {
 
 constexpr int PREC = 64;                        // doubles per stage record
-#ifndef COND_STAGE_LDS
-#define COND_STAGE_LDS 1        // COND_DPP 2: the four cost rows reach the MFMA operand layout through LDS (1) or by row swaps between registers (0)
-#endif
-#ifndef COND_GS_LDS
-#define COND_GS_LDS 1           // COND_DPP 2: the first rows of g_s reach every lane through LDS (1) or by v_readlane (0)
-#endif
-#ifndef COND_NPARK
-#define COND_NPARK 3        // (LDS form of the kernel only) Hessian tiles of the last block column that the five-tile condensing kernel keeps in LDS between the stages of its last segment
-#endif
 // record fields: [0,1] Sp | [2..43] S[6][7] | [44..51] defect b | [52..55] cost residuals | [56..59] g3 g5 g7 h | [60] delta_f
 constexpr int PR_RES = 52, PR_GH = 56, PR_XD = 60;
 // coupled SNMPC OCP only: [61, 62] gradient (vl, vt)/|v| of the speed row of the cost, [63] d h / d vt of the gg row at |v|
@@ -57,7 +45,7 @@ template <int NT_> struct PD {
     static constexpr int PV_Q = 0, PV_D = NVP, PV_DV = 2 * NVP, PV_SC = 3 * NVP, PVEC = 3 * NVP + 16;   // q | d | dv | slack cost
     // (C_WT: the weights of every stage; C_PARK: the Hessian tiles of the last block column wait here between the stages of the
     //  last segment -- d4 per lane and tile)
-    static constexpr int C_NPARK = COND_NPARK;
+    static constexpr int C_NPARK = 3;
     static constexpr int C_REC = 0, C_STAGE = 2 * PREC, C_GS = C_STAGE + 4 * NVP, C_U0 = C_GS + 8,
                          C_WT = C_U0 + NVP, C_PARK = (C_WT + (NMAX + 1) * 6 + 1) & ~1, C_LDS = C_PARK + C_NPARK * 256;
     static constexpr int E_REC = 0, E_X = 2 * PREC, E_U = E_X + (NMAX + 1) * NX, E_DV = E_U + NVP, E_LDS = E_DV + NVP;
@@ -79,7 +67,7 @@ template <int NT_> struct PD {
     // update's and on the pitch-17 inverse blocks, 850 conflict cycles per iteration; and every row start was a multiply.)
     // Six tiles (N = 41..48): no room for the inverse blocks as tiles of their own -- the factor stays packed, the inverse blocks
     // in the strict lower triangle of its diagonal tiles, read with masks.
-    static constexpr bool DENSE_W = (NT_ == 5 && IPM_WPS == 1);
+    static constexpr bool DENSE_W = (NT_ == 5);
     static constexpr bool TILED = DENSE_W;
     static constexpr int NOT = NT_ * (NT_ - 1) / 2, W_TILE = 256;
     static constexpr int I_M = TILED ? ((I_PZ + 18 + 31) & ~31) : I_PZ + 18;      // LPK (packed) | NOT tiles, on a 256-byte boundary
@@ -272,9 +260,6 @@ __global__ void __launch_bounds__(64, 1) lin_cols_kernel(const PArgs pa)
 }
 
 // ---------------------------------------------------------------------------------------------------------------- K2
-#ifndef COND_WPS
-#define COND_WPS 2          // wavefronts per SIMD the five-tile condensing kernel is bounded to
-#endif
 // (Round 5 also built the stage record through the SCALAR data path -- address space 4, s_load, the fields as scalar operands of the FMAs:
 //  +38 us, every stage waits for its loads -- and three wavefronts per SIMD: slower in every form; profiles/r05_ab_cond_variants.txt,
 //  HISTORY.md. What replaced the LDS broadcasts is the DPP form below.)
@@ -320,38 +305,8 @@ __device__ __forceinline__ void apply_A2_rec(const R &rec, double w[8], double v
 // hold this kernel against cond_wide_kernel, which kept the LDS form). With 30 registers fewer all 15 Hessian tiles stay in registers
 // (no tile parked in LDS), lane-derived values are kept instead of re-derived per stage, a lane's input column is fetched once, and the
 // weights are scaled by dt once, in LDS, where a lane reads the one of its operand row (no select chain).
-// COND_DPP 2 (shipped) adds two choices, measured (profiles/r05_ab_cond_dpp.txt): COND_STAGE_LDS 0 moves the four cost rows to the MFMA
-// operand layout (lane (q, c) of tile T <- row q of column 16 T + c, held by lane 16 T + c) by a 4 x 4 transposition of 16-lane rows
-// among four registers -- two levels of gfx950 row swaps (v_permlane32_swap, v_permlane16_swap: 8 instructions for the four tiles of bank
-// 0, 6 for bank 1) -- and COND_GS_LDS 0 takes the first rows of the constant column g_s from their lane by v_readlane: a stage without
-// any LDS traffic, bit-identical, and 1-2 us SLOWER than staging both through LDS (the swaps and lane reads and their copies are 30-40
-// vector instructions a stage on the issue port; what this kernel waits for is not the LDS pipe). 1: the record alone in registers.
-#ifndef COND_DPP
-#define COND_DPP 2
-#endif
-// rows of 16 lanes swapped between two registers (gfx950): the upper two rows of a with the lower two of b / the odd rows of a with the even rows of b
-__device__ __forceinline__ void rows_swap32(double &a, double &b)
-{
-    const tum_u32x2 l = __builtin_amdgcn_permlane32_swap(__double2loint(a), __double2loint(b), false, false);
-    const tum_u32x2 h = __builtin_amdgcn_permlane32_swap(__double2hiint(a), __double2hiint(b), false, false);
-    a = __hiloint2double(h[0], l[0]); b = __hiloint2double(h[1], l[1]);
-}
-__device__ __forceinline__ void rows_swap16(double &a, double &b)
-{
-    const tum_u32x2 l = __builtin_amdgcn_permlane16_swap(__double2loint(a), __double2loint(b), false, false);
-    const tum_u32x2 h = __builtin_amdgcn_permlane16_swap(__double2hiint(a), __double2hiint(b), false, false);
-    a = __hiloint2double(h[0], l[0]); b = __hiloint2double(h[1], l[1]);
-}
-// out[T] (T < NOUT), lane (q, c)  <-  a_q, lane (T, c): the MFMA operands of tile T of a bank whose rows a_0..a_3 live on lane = column
-template <int NOUT>
-__device__ __forceinline__ void rows_to_tiles(double a0, double a1, double a2, double a3, double *out)
-{
-    rows_swap32(a0, a2); rows_swap32(a1, a3);
-    rows_swap16(a0, a1);
-    out[0] = a0;
-    if constexpr (NOUT > 1) out[1] = a1;
-    if constexpr (NOUT > 2) { rows_swap16(a2, a3); out[2] = a2; if constexpr (NOUT > 3) out[3] = a3; }
-}
+// (Measured and dropped, profiles/r05_ab_cond_dpp.txt and HISTORY.md: the four cost rows to the MFMA operand layout by gfx950 row swaps
+// instead of through LDS, and the first rows of g_s by v_readlane -- a stage without any LDS traffic, bit-identical, 1-2 us slower.)
 struct RecRows {
     double g[4];
     // acc += field F * x
@@ -418,7 +373,7 @@ __device__ __forceinline__ void apply_A_rows(const RecRows &R, double w[8], doub
 // REGF: the register form of the stage record (RecRows); the LDS form is kept for the coupled SNMPC OCP at long propagation horizons
 // (the host decides, tum_nmpc.hip: launch_pipeline)
 template <int NT_, bool SN, bool REGF = !SN>
-__global__ void __launch_bounds__(64, (NT_ == 5) ? COND_WPS : 1) cond_kernel(const PArgs pa)
+__global__ void __launch_bounds__(64, (NT_ == 5) ? 2 : 1) cond_kernel(const PArgs pa)
 {
     PD_LOCALS
     constexpr int C_REC = D::C_REC, C_STAGE = D::C_STAGE, C_GS = D::C_GS, C_U0 = D::C_U0, C_WT = D::C_WT;
@@ -442,10 +397,9 @@ __global__ void __launch_bounds__(64, (NT_ == 5) ? COND_WPS : 1) cond_kernel(con
     // The nominal OCP reads its stage records from REGISTERS by DPP broadcasts (RecRows above). The coupled SNMPC OCP takes the columns
     // of its first uph stages from the prologue's buffer and uses nine fields of a record there: at UPH = Tp the register form costs it
     // 6 % (four loads a stage instead of one), behind stage uph it gains what the nominal OCP gains -- REGF is the host's choice by uph
-    constexpr bool DPPK = (COND_DPP >= 1) && REGF, DPP2 = (COND_DPP >= 2) && REGF;
     // Hessian tiles of the last block column parked in LDS between the stages of the last segment: none in the register form (it needs
     // 30 registers fewer), D::C_NPARK in the LDS form
-    constexpr int NPARK = ((DPPK && !SN) || NT_ != 5) ? 0 : D::C_NPARK;
+    constexpr int NPARK = ((REGF && !SN) || NT_ != 5) ? 0 : D::C_NPARK;
     // stage slot k & 1: fields 0..51 of record k (A_k, B_k, b_k), fields 52..60 of record k+1 (residuals, gg row, delta of stage k+1)
     auto fetch = [&](int k) -> double { return (lane < PR_RES) ? grec[(size_t)k * PREC + lane] : ((lane <= (SN ? PR_G4 : PR_XD)) ? grec[(size_t)(k + 1) * PREC + lane] : 0.0); };
     // field 16 r + (lane & 15) of the stage slot k, and the weight of cost row lane >> 4 of stage k + 1
@@ -475,7 +429,7 @@ __global__ void __launch_bounds__(64, (NT_ == 5) ? COND_WPS : 1) cond_kernel(con
     };
     const double notg63 = (lane == 63) ? 0.0 : 1.0;
     const double b6c = (lane & 1) ? dt : 0.0, b7c = (lane & 1) ? 0.0 : dt;          // (rows 6, 7 of that column: the integrators of the two inputs)
-    if constexpr (DPPK) {
+    if constexpr (REGF) {
         fetch_rows(0, Ra);
         if (N > 1) fetch_rows(1, Rb); else Rb = Ra;
         fetch_bcol(lane >> 1);
@@ -538,7 +492,7 @@ __global__ void __launch_bounds__(64, (NT_ == 5) ? COND_WPS : 1) cond_kernel(con
             }
         };
         // (the LDS form, which is the one for long propagation horizons; the register form has no 36 registers to spare and few such stages)
-        constexpr bool PRO_AHEAD = SN && !DPPK;
+        constexpr bool PRO_AHEAD = SN && !REGF;
         if constexpr (PRO_AHEAD) { if (uph > 0) fetch_pro(0, lane); }
         // (two call sites per segment: inlined by force, or every captured array lives in scratch)
         auto stage_body = [&](const int k, auto tsc, auto g0c, RecRows &R) __attribute__((always_inline)) {
@@ -550,14 +504,14 @@ __global__ void __launch_bounds__(64, (NT_ == 5) ? COND_WPS : 1) cond_kernel(con
             // (everything derived from the lane id is derived again in every stage, from a copy the optimiser cannot see through:
             //  held across the stage loop these values cost the registers the last segment lacks)
             int lane_s = lane_cond;
-            if constexpr (!DPPK || SN) asm volatile("" : "+v"(lane_s));          // (the SNMPC LDS form with them kept: 246 registers, no change in time -- its stages wait for the prologue's buffer)          // (the register form has ~40 registers to spare: there the optimiser may keep what it likes -- 45 of 270 vector instructions per pair of stages)
+            if constexpr (!REGF || SN) asm volatile("" : "+v"(lane_s));          // (the SNMPC LDS form with them kept: 246 registers, no change in time -- its stages wait for the prologue's buffer)          // (the register form has ~40 registers to spare: there the optimiser may keep what it likes -- 45 of 270 vector instructions per pair of stages)
             const int lane = lane_s;
             const int j0 = lane >> 1, r0 = lane & 1, j1 = 32 + (lane >> 1);
             const bool isg = (lane == NB1);
             const int lq = lane >> 4, lc = lane & 15;
             const double *rec = sRec + (k & 1) * PREC;          // (LDS form)
             const double one = 1.0;
-            if constexpr (DPPK) R.settle();
+            if constexpr (REGF) R.settle();
             double cr0 = 0.0, cr1 = 0.0;          // (SNMPC: the chance-constraint row of this stage)
             if (SN && k < uph) {
                 // stage s = k+1 <= uph: G_nom,s and g_nom,s are PCE means of the sample recursions (prologue kernel)
@@ -567,7 +521,7 @@ __global__ void __launch_bounds__(64, (NT_ == 5) ? COND_WPS : 1) cond_kernel(con
                 for (int i = 0; i < 8; i++) { w0[i] = nP0[i]; w1[i] = nP1[i]; }
                 cr0 = nH0; cr1 = nH1;
                 if constexpr (PRO_AHEAD) { if (k + 1 < uph) fetch_pro(k + 1, lane); }
-            } else if constexpr (DPPK) {
+            } else if constexpr (REGF) {
                 // (the input column of a lane: B_k's column r0 -- two accumulations, the one of the other parity adds 0.0 * field)
                 if constexpr (G0) {
                     const double sel0 = (j0 == k) ? 1.0 : 0.0, selg = (lane == 63) ? 1.0 : 0.0;
@@ -615,7 +569,7 @@ __global__ void __launch_bounds__(64, (NT_ == 5) ? COND_WPS : 1) cond_kernel(con
             const int s = k + 1;                         // stage whose G_s the lanes now hold
             double hr0 = 0.0, hr1 = 0.0, c30, c31;          // gg row and speed row of stage s (per bank)
             double cvl = 1.0, cvt = 0.0;                     // (LDS form, SNMPC: gradient of |v|)
-            if constexpr (DPPK) {
+            if constexpr (REGF) {
                 // (g3 w3 + g5 w5 + g7 w7 as the compiler contracts the LDS form's expression: the SECOND product is rounded, the first and
                 //  the third are fused onto it)
                 R.fmac<PR_GH + 1>(hr0, w0[5]); R.fmac<PR_GH + 0>(hr0, w0[3]); R.fmac<PR_GH + 2>(hr0, w0[7]);
@@ -634,7 +588,7 @@ __global__ void __launch_bounds__(64, (NT_ == 5) ? COND_WPS : 1) cond_kernel(con
                 double dbx = G0 ? w0[6] : w1[6], dh = G0 ? hr0 : hr1;
                 R.fmac<PR_XD>(dbx, one); R.fmac<PR_GH + 3>(dh, hdon);
                 if (G0 ? lane == 63 : isg) {
-                    if constexpr (!DPP2 || COND_GS_LDS) {
+                    {
 #pragma unroll
                         for (int i = 0; i < (SN ? 5 : 4); i++) sGs[i] = G0 ? w0[i] : w1[i];
                     }
@@ -671,8 +625,7 @@ __global__ void __launch_bounds__(64, (NT_ == 5) ? COND_WPS : 1) cond_kernel(con
                 if (!G0 && lane < NB1 && 2 * T1 <= c_) gcs[cidx(c_, T1) * 64] = hr1;
             }
             // the four cost rows to the MFMA operand layout, the stage's weights, the first rows of g_s
-            constexpr bool STAGE_LDS = !DPP2 || COND_STAGE_LDS, GS_LDS = !DPP2 || COND_GS_LDS;
-            if constexpr (STAGE_LDS) {
+            {
 #pragma unroll
                 for (int r = 0; r < 3; r++) sStage[r * NVP + lane] = LATE ? w0[r] * notg63 : w0[r];
                 sStage[3 * NVP + lane] = LATE ? c30 * notg63 : c30;          // (G0: what lane 63 stages is g, in a column the tiles of the first three segments do not read)
@@ -682,25 +635,20 @@ __global__ void __launch_bounds__(64, (NT_ == 5) ? COND_WPS : 1) cond_kernel(con
                     sStage[3 * NVP + 64 + lane] = c31;
                 }
             }
-            if constexpr (STAGE_LDS || GS_LDS) wsync();
+            wsync();
             double wl, wr[4], gsr[5];
 #pragma unroll
             for (int r = 0; r < 4; r++) wr[r] = sWt[s * 6 + r];          // (the stage's own weights, scaled; stage N: W_e)
-            if constexpr (DPP2) wl = sWt[s * 6 + lq];                    // (an LDS read instead of a select chain)
+            if constexpr (REGF) wl = sWt[s * 6 + lq];                    // (an LDS read instead of a select chain)
             else wl = (lq == 0) ? wr[0] : (lq == 1) ? wr[1] : (lq == 2) ? wr[2] : wr[3];
-            if constexpr (GS_LDS) {
 #pragma unroll
-                for (int r = 0; r < (SN ? 5 : 4); r++) gsr[r] = sGs[r];
-            } else {
-#pragma unroll
-                for (int r = 0; r < (SN ? 5 : 4); r++) gsr[r] = G0 ? readlane_f64(w0[r], 63) : readlane_f64(w1[r], NB1);
-            }
+            for (int r = 0; r < (SN ? 5 : 4); r++) gsr[r] = sGs[r];
             {
                 double a0 = 0.0, a1 = 0.0;
                 static_for<0, 3>([&](auto rc) {
                     constexpr int r = decltype(rc)::value;
                     double gs = gsr[r];
-                    if constexpr (DPPK) {
+                    if constexpr (REGF) {
                         if constexpr (SN && r == 3) { gs = 0.0; R.fmac<PR_CV + 1>(gs, gsr[4]); R.fmac<PR_CV>(gs, gsr[3]); }
                         R.fmac<PR_RES + r>(gs, one);          // residual + g_s
                     } else gs = rec[PR_RES + r] + ((SN && r == 3) ? cvl * gsr[3] + cvt * gsr[4] : gsr[r]);
@@ -708,19 +656,14 @@ __global__ void __launch_bounds__(64, (NT_ == 5) ? COND_WPS : 1) cond_kernel(con
                     a0 += e * ((r == 3) ? c30 : w0[r]);
                     if constexpr (!G0) a1 += e * ((r == 3) ? c31 : w1[r]);
                 });
-                if constexpr (DPPK && G0) q0 += a0 * notg63;          // (lane 63 holds g, not a column)
+                if constexpr (REGF && G0) q0 += a0 * notg63;          // (lane 63 holds g, not a column)
                 else q0 += (G0 && lane == 63) ? 0.0 : a0;
                 if constexpr (!G0) q1 += (lane < NB1) ? a1 : 0.0;
             }
             double bop[Ts];
-            if constexpr (STAGE_LDS) {
 #pragma unroll
-                for (int T = 0; T < Ts; T++) bop[T] = sStage[lq * NVP + 16 * T + lc];
-            } else {
-                rows_to_tiles<(Ts < 4 ? Ts : 4)>(w0[0], w0[1], w0[2], c30, bop);
-                if constexpr (Ts > 4) rows_to_tiles<Ts - 4>(w1[0], w1[1], w1[2], c31, bop + 4);
-            }
-            // Last segment of the five-tile build when tiles are parked (COND_NPARK > 0; rounds 2-5 until the stage record left the
+            for (int T = 0; T < Ts; T++) bop[T] = sStage[lq * NVP + 16 * T + lc];
+            // Last segment of the five-tile build when tiles are parked (the LDS form; rounds 2-5 until the stage record left the
             // register file's competitors): the first C_NPARK tiles of the last block column -- touched by this segment only -- wait in
             // LDS between the stages: loaded, updated, stored again.
             constexpr bool PARK = (NT_ == 5) && (Ts == NT_);
@@ -736,7 +679,7 @@ __global__ void __launch_bounds__(64, (NT_ == 5) ? COND_WPS : 1) cond_kernel(con
                     Ht[tidx(K, I)] = mfma(aop, bop[I], Ht[tidx(K, I)]);
                 }
             }
-            if constexpr (DPPK) {
+            if constexpr (REGF) {
                 // the record two stages on, into the register set this stage is done with
                 if (k + 2 < N) fetch_rows(k + 2, R);
             } else {
@@ -744,7 +687,7 @@ __global__ void __launch_bounds__(64, (NT_ == 5) ? COND_WPS : 1) cond_kernel(con
                 sRec[((k + 1) & 1) * PREC + lane] = pre;
                 if (k + 2 < N) pre = fetch(k + 2);
             }
-            if constexpr (STAGE_LDS || GS_LDS || !DPPK) wsync();
+            wsync();
         };
         // stage s = k+1 touches columns < 2s, i.e. ceil(s/8) tiles: one instantiation of the stage per segment of 8 stages
         static_for<1, NT>([&](auto tsc) {
@@ -756,7 +699,7 @@ __global__ void __launch_bounds__(64, (NT_ == 5) ? COND_WPS : 1) cond_kernel(con
             };
             using yes = std::integral_constant<bool, true>;
             using no = std::integral_constant<bool, false>;
-            if constexpr (DPPK && G0_SEGS > 0 && Ts == G0_SEGS + 1) {
+            if constexpr (REGF && G0_SEGS > 0 && Ts == G0_SEGS + 1) {
                 // the fourth segment of the register form: lane 63 is free until stage 31 inserts its input column -- seven more stages
                 // without bank 1 (its column update, gg row, staging stores and gradient terms: ~60 of ~150 vector instructions a stage)
                 constexpr int kl = 8 * Ts - 1;          // the stage that needs the lane
@@ -769,7 +712,7 @@ __global__ void __launch_bounds__(64, (NT_ == 5) ? COND_WPS : 1) cond_kernel(con
                 if (kl < N) stage_body(kl, tsc, no(), Rb);
             } else {
                 if constexpr (G0_SEGS > 0 && Ts == G0_SEGS + 1) move_g();
-                if constexpr (DPPK) {
+                if constexpr (REGF) {
                     if constexpr (Ts == 5) fetch_bcol(32 + (lane >> 1));          // (bank 1's input columns: the stages from 32 on)
                     for (int k = 8 * (Ts - 1); k < N && k < 8 * Ts; k += 2) {
                         stage_body(k, tsc, std::integral_constant<bool, G0S>(), Ra);
@@ -1284,7 +1227,7 @@ __global__ void __launch_bounds__(64) expand_kernel(const PArgs pa)
 // expansion's loads running at this kernel's occupancy); the nominal OCP only -- the coupled SNMPC OCP keeps its own expansion
 // kernel between this kernel and its epilogue
 template <bool PROF, int NT_, bool FUSE = false>
-__global__ void __launch_bounds__(64, IPM_WPS) ipm_kernel(const PArgs pa)
+__global__ void __launch_bounds__(64, 1) ipm_kernel(const PArgs pa)
 {
     PD_LOCALS
     constexpr int I_WH = D::I_WH, I_WB = D::I_WB, I_SFX = D::I_SFX, I_DV = D::I_DV, I_DUMMY = D::I_DUMMY, I_PZ = D::I_PZ, I_M = D::I_M;
@@ -1317,8 +1260,7 @@ __global__ void __launch_bounds__(64, IPM_WPS) ipm_kernel(const PArgs pa)
         for (int i = lane; i < NT * D::W_TILE; i += 64) { const int row = (i >> 4) & 15; lds[D::I_W + i] = (((i & 15) ^ D::tile_swz(row)) == row) ? 1.0 : 0.0; }
     if (lane < 18) sPZ[lane] = gpen[(lane >> 1) * 4 + 2 + (lane & 1)];
     // the gg rows, MFMA operand layout (30 coalesced loads), resident in registers for the whole solve: the KKT assembly and the
-    // row phases take their operands from them. (Only the IPM_WPS = 2 build re-reads them from the workspace behind every
-    // factorisation instead of holding 60 registers across it.)
+    // row phases take their operands from them.
     double chv[NCH];
     const double *gcw = pa.cws + (size_t)b * NCH * 64 + lane;
 #pragma unroll
@@ -1447,7 +1389,7 @@ __global__ void __launch_bounds__(64, IPM_WPS) ipm_kernel(const PArgs pa)
         double gap;
         // D, G of every row side, fixed for both solves of an iteration: the five-tile build computes them with gamma and HOLDS them
         // across the factorisation (16 registers); the six-tile build, at the top of the register file, recomputes them behind it
-        constexpr bool HOLD_DG = (NT_ == 5) && (IPM_WPS == 1);
+        constexpr bool HOLD_DG = (NT_ == 5);
         double rD[NS2], rG[NS2];
         {
             double ls = fmax(fabs(rv0), fabs(rv1)), li = 0.0, lcmp = 0.0, lg = 0.0;
@@ -1731,14 +1673,6 @@ __global__ void __launch_bounds__(64, IPM_WPS) ipm_kernel(const PArgs pa)
         });
         // (a failed factorisation -- a pivot that is not positive -- is acted upon after the parked registers are back:
         //  leaving the loop here would keep all of them alive across the factorisation for the code behind the loop)
-        // bounded to two wavefronts per SIMD (IPM_WPS 2) the gg rows come back now, their latency running under the block
-        // inverses; with the whole register file (IPM_WPS 1) they simply stay
-        if (IPM_WPS > 1) {
-            const double *gc2 = gcw;
-            asm volatile("" : "+v"(gc2));          // (opaque: the reload must stay behind the micro-panels)
-#pragma unroll
-            for (int i = 0; i < NCH; i++) chv[i] = gc2[i * 64];
-        }
         TUM_TICK(4);
 
         if (__any(dmin_hi < 0x01a56e1f)) { qp_status = 3; break; }          // a pivot below 1e-300 (or negative): the factorisation failed
