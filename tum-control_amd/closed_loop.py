@@ -200,8 +200,9 @@ class ClosedLoopBatch:
 
     def __init__(self, track_name, batch=1, params=None, N=38, Tp=3.04, Ts=0.02, idx_start=0, cfg=None, device=0,
                  on_device=False, log_capacity=0, controller="nominal", disturbances=None, disturbance_steps=0, seed=0,
-                 qp_warm_start=None):
+                 qp_warm_start=None, qp_tol=None):
         self.cfg = cfg or _config.default_config()
+        kw = {} if qp_tol is None else dict(qp_tol=tuple(qp_tol))          # (termination tolerances of the interior point method; default: the solver's 1e-8)
         self.track = load_track(track_name)
         self.B, self.N, self.Tp, self.Ts = batch, N, Tp, Ts
         tr = self.track
@@ -211,7 +212,7 @@ class ClosedLoopBatch:
         self.pose = self.x_mpc[:, :2].copy()
         self.controller = controller
         if controller == "nominal":       # main.py:33-36 picks the controller class by MPC_params['MPC_type']
-            self.solver = BatchedOcpSolver(N=N, dt=Tp / N, nsub=3, batch=batch, device=device, cfg=self.cfg, qp_warm_start=qp_warm_start)
+            self.solver = BatchedOcpSolver(N=N, dt=Tp / N, nsub=3, batch=batch, device=device, cfg=self.cfg, qp_warm_start=qp_warm_start, **kw)
         elif controller == "snmpc":       # the coupled SNMPC OCP; x0_samples = compute_x0dist(x0) before every solve
             from . import snmpc as _snm
             m = self.cfg["mpc"]
@@ -221,12 +222,12 @@ class ClosedLoopBatch:
             A = _snm.pce_matrix(w, _snm.alpha_generation(nvar, m["expansion_degree"]))
             self._x0_offsets = _snm.x0_offsets(w, stds)
             self.solver = CoupledSnmpcSolver(N=N, dt=Tp / N, batch=batch, Apce=A, uph=min(int(m["uncertainty_propagation_horizon"]), N),
-                                             gamma=m["gamma"], device=device, cfg=self.cfg, x0_offsets=self._x0_offsets, qp_warm_start=qp_warm_start)
+                                             gamma=m["gamma"], device=device, cfg=self.cfg, x0_offsets=self._x0_offsets, qp_warm_start=qp_warm_start, **kw)
         elif controller == "r2":          # nominal OCP + covariance back-off after every solve (K7 attached to the solve)
             from .r2nmpc import r2_setup
             m, veh = self.cfg["mpc"], self.cfg["veh"]
             self.solver = BatchedOcpSolver(N=N, dt=Tp / N, nsub=3, batch=batch, device=device, cfg=self.cfg, store_qp_in=True,
-                                           qp_warm_start=qp_warm_start)
+                                           qp_warm_start=qp_warm_start, **kw)
             S0, BWB = r2_setup(m["stds"], Tp / N)
             self.solver.r2_attach(S0, BWB, int(m["uncertainty_propagation_horizon"]), veh["delta_f_min"], veh["delta_f_max"], 1.0)
         else:
