@@ -1077,9 +1077,14 @@ __device__ __forceinline__ void expand_instance(const PArgs &pa, const int b, do
     const double *gpro = SN ? ka.pro + (size_t)b * uph * PSTAGE : nullptr;
     for (int i = lane; i < (N + 1) * NX; i += 64) sX[i] = gX[i];
     for (int i = lane; i < NVP; i += 64) { sU1[i] = (i < nv) ? gU[i] : 0.0; if (!FUSED) sDv[i] = gvec[PV_DV + i]; }
-    double pre = (lane < PR_RES) ? grec[lane] : 0.0;
-    sRec[lane] = pre;
-    if (N > 1) pre = (lane < PR_RES) ? grec[PREC + lane] : 0.0;
+    // The stage records come in EX_AHEAD stages ahead of their use, through a ring of registers (rounds 2-5: two ahead -- the 40-stage recursion
+    // then waits half a load latency per stage, and the kernel was that wait: 36 us for 4096 instances, a quarter of a single vehicle's control step
+    // as the tail of the interior point kernel)
+    constexpr int EX_AHEAD = 8;
+    double pre[EX_AHEAD];
+    sRec[lane] = (lane < PR_RES) ? grec[lane] : 0.0;
+#pragma unroll
+    for (int j = 0; j < EX_AHEAD; j++) pre[j] = (lane < PR_RES && 1 + j <= N) ? grec[(size_t)(1 + j) * PREC + lane] : 0.0;          // records 1 .. EX_AHEAD
     const double gx0r = gx0[(lane < 8) ? lane : 0];
     wsync();
     if (status == 0) {
@@ -1094,7 +1099,11 @@ __device__ __forceinline__ void expand_instance(const PArgs &pa, const int b, do
             // which runs in front of this one; the recursion continues from its step of stage uph
             dxi = gvec[PV_SC + 8 + ri];
         }
-        for (int k = 0; k < N; k++) {
+        for (int k0 = 0; k0 < N; k0 += EX_AHEAD)
+#pragma unroll
+        for (int j = 0; j < EX_AHEAD; j++) {
+            const int k = k0 + j;
+            if (k >= N) break;
             const double *rec = sRec + (k & 1) * PREC;
             if (k >= uph) {
             const double *Si = rec + 2 + (core ? ri : 0) * 7;
@@ -1112,8 +1121,8 @@ __device__ __forceinline__ void expand_instance(const PArgs &pa, const int b, do
             dxi = acc0 + acc1;
             if (lane < 8) sX[(k + 1) * NX + lane] += dxi;
             }
-            sRec[((k + 1) & 1) * PREC + lane] = pre;
-            if (k + 2 < N) pre = (lane < PR_RES) ? grec[(size_t)(k + 2) * PREC + lane] : 0.0;
+            sRec[((k + 1) & 1) * PREC + lane] = pre[j];          // record k + 1 (requested EX_AHEAD stages ago)
+            if (k + 1 + EX_AHEAD < N) pre[j] = (lane < PR_RES) ? grec[(size_t)(k + 1 + EX_AHEAD) * PREC + lane] : 0.0;
             wsync();
         }
         sU1[lane] += sDv[lane];
