@@ -105,8 +105,11 @@ int tum_ocp_get(tum_ocp *c, int stage, const char *field, double *v, int len, in
 int tum_ocp_constraints_set(tum_ocp *c, int stage, const char *field, const double *v, int len, int b0, int nb, int stride);
 
 /* acados_solver.cost_set(stage, field, value)   NMPC_class.py:295-317
- * "W": ny*ny (stage<N: 36, stage N: 16) column-major, must be diagonal (the reference only installs blockdiag(Q,R) with
- * diagonal Q, R). Per STAGE, as in acados: the reference sets every stage in a loop (NMPC_class.py:294-296), and a caller may
+ * "W": ny*ny (stage<N: 36, stage N: 16) column-major. Any matrix, as in acados (its symmetric part is what the cost sees and what is kept). The
+ * reference only installs blockdiag(Q,R) with diagonal Q, R: a capsule whose W have always been diagonal stores the diagonal and condenses with the
+ * kernels of the headline; the first W with an off-diagonal entry switches the capsule to a full 6 x 6 per stage (nominal / R2 OCP on the pipeline;
+ * the condensing then runs as the six-wavefront kernel's full-W instantiation whatever the batch size; refused by the coupled SNMPC OCP, whose cost
+ * rows come from the prologue kernel, and by the development build's fused kernel). Per STAGE, as in acados: the reference sets every stage in a loop (NMPC_class.py:294-296), and a caller may
  * give every stage its own weights. stage == TUM_ALL_STAGES with a 6 x 6 W: all the stages 0..N-1 in one call. (The development
  * build's fused kernel reads stage 0's W for all stages < N; the shipped pipeline honours every stage.)
  * "zl","zu","Zl","Zu": 1 value at stage 0 [sbu], 3 at stages 1..N-1 [sbu,sbx,sh], 2 at stage N [sbx,sh]. */

@@ -654,6 +654,10 @@ typedef struct {
     double x0[NX];                       /* lbx_0 = ubx_0 */
     double yref[(NMAXH + 1) * 6];        /* stage N uses the first 4 */
     double W[(NMAXH + 1) * 6];           /* diagonal of W per stage (stage N: first 4) */
+    /* a full (symmetric) W per stage, 6 x 6 row-major (stage N: its leading 4 x 4), used instead of the diagonal when full_w != 0:
+     * acados' cost_set(i, 'W', W) takes any matrix (NMPC_class.py:290-296); the reference only ever installs a diagonal one */
+    double Wf[(NMAXH + 1) * 36];
+    double full_w;
     double lbu[NMAXH], ubu[NMAXH];       /* steering-rate box, stages 0..N-1 */
     double lbx[NMAXH + 1], ubx[NMAXH + 1]; /* delta box, stages 1..N */
     double lh[NMAXH + 1], uh[NMAXH + 1];   /* stages 1..N */
@@ -707,7 +711,7 @@ double *oracle_field(oracle_ocp *o, const char *name, int *len)
     const int N = o->N;
 #define F(nm, ptr, n) if (!strcmp(name, nm)) { *len = (n); return (ptr); }
     F("X", o->X, (N + 1) * NX) F("U", o->U, N * NU) F("x0", o->x0, NX)
-    F("yref", o->yref, (N + 1) * 6) F("W", o->W, (N + 1) * 6)
+    F("yref", o->yref, (N + 1) * 6) F("W", o->W, (N + 1) * 6) F("Wf", o->Wf, (N + 1) * 36) F("full_w", &o->full_w, 1)
     F("lbu", o->lbu, N) F("ubu", o->ubu, N)
     F("lbx", o->lbx, N + 1) F("ubx", o->ubx, N + 1) F("lh", o->lh, N + 1) F("uh", o->uh, N + 1)
     F("zl", o->zl, (N + 1) * 3) F("zu", o->zu, (N + 1) * 3) F("Zl", o->Zl, (N + 1) * 3) F("Zu", o->Zu, (N + 1) * 3)
@@ -737,6 +741,10 @@ static double eval_cost(const oracle_ocp *o)
         int ny = 4;
         if (k < N) { y[4] = o->U[k * NU]; y[5] = o->U[k * NU + 1]; ny = 6; }
         double acc = 0.0;
+        if (o->full_w != 0.0) {
+            const double *Wk = o->Wf + k * 36;
+            for (int i = 0; i < ny; i++) for (int j = 0; j < ny; j++) acc += 0.5 * Wk[i * 6 + j] * (y[i] - yr[i]) * (y[j] - yr[j]);
+        } else
         for (int i = 0; i < ny; i++) { double r = y[i] - yr[i]; acc += 0.5 * W[i] * r * r; }
         c += sc * acc;
     }
@@ -797,6 +805,31 @@ int oracle_solve(oracle_ocp *o)
         const double *x = o->X + k * NX, *yr = o->yref + k * 6, *W = o->W + k * 6;
         const double *Gk = G + (size_t)k * NX * nv;
         double y[4] = {x[0], x[1], wrap_yaw(x[2]), x[3]};
+        if (o->full_w != 0.0) {
+            /* full W: rows of the output Jacobian in the condensed variables -- J_r = row r of G_k (r < 4), J_{4+r} = unit row of input
+             * r of stage k -- and H += J' (sc W) J, q += J' (sc W) res, the dumbest way */
+            const double *Wk = o->Wf + k * 36;
+            const int ny = (k < N) ? 6 : 4;
+            double res[6];
+            for (int r = 0; r < 4; r++) res[r] = y[r] - yr[r] + g[k * NX + r];
+            if (k < N) for (int r = 0; r < NU; r++) res[4 + r] = o->U[k * NU + r] - yr[4 + r];
+            const int ncol = (k < N) ? NU * (k + 1) : NU * k;       /* columns the stage's rows reach */
+            for (int j = 0; j < ncol; j++) {
+                double Jj[6];
+                for (int r = 0; r < 4; r++) Jj[r] = (j < NU * k) ? Gk[r * nv + j] : 0.0;
+                for (int r = 0; r < NU; r++) Jj[4 + r] = (k < N && j == NU * k + r) ? 1.0 : 0.0;
+                double WJ[6];
+                for (int a = 0; a < ny; a++) { double t = 0.0; for (int c2 = 0; c2 < ny; c2++) t += sc * Wk[a * 6 + c2] * Jj[c2]; WJ[a] = t; }
+                for (int a = 0; a < ny; a++) q[j] += WJ[a] * res[a];
+                for (int l = 0; l <= j; l++) {
+                    double t = 0.0;
+                    for (int a = 0; a < 4; a++) t += WJ[a] * ((l < NU * k) ? Gk[a * nv + l] : 0.0);
+                    for (int r = 0; r < NU; r++) if (k < N && l == NU * k + r) t += WJ[4 + r];
+                    H[j * nv + l] += t;
+                }
+            }
+            continue;
+        }
         for (int r = 0; r < 4; r++) {
             const double w = sc * W[r];
             const double res = y[r] - yr[r] + g[k * NX + r];     /* residual incl. the constant part of dx */

@@ -172,6 +172,8 @@ class OracleOcp:
         self.x0 = self._view("x0")
         self.yref = self._view("yref").reshape(N + 1, 6)
         self.W = self._view("W").reshape(N + 1, 6)
+        self.Wf = self._view("Wf").reshape(N + 1, 6, 6)          # full W per stage (stage N: its leading 4 x 4), used when full_w[0] != 0
+        self.full_w = self._view("full_w")
         self.lbu, self.ubu = self._view("lbu"), self._view("ubu")
         self.lbx, self.ubx = self._view("lbx"), self._view("ubx")
         self.lh, self.uh = self._view("lh"), self._view("uh")
@@ -213,6 +215,16 @@ class OracleOcp:
             a[:] = L1
         for a in (self.Zl, self.Zu):
             a[:] = L2
+
+    def set_full_W(self, W):
+        """cost_set(i, 'W', W) with an arbitrary symmetric W: (N+1, 6, 6) (stage N: the leading 4 x 4 is used) or one (6, 6) for every stage.
+        None: back to the diagonal self.W."""
+        if W is None:
+            self.full_w[0] = 0.0
+            return
+        W = np.asarray(W, dtype=float)
+        self.Wf[:] = 0.5 * (W + np.swapaxes(W, -1, -2))
+        self.full_w[0] = 1.0
 
     def cold_start(self, x0):
         """acados create / reset(): x_k = x0 for all k, u = 0 (NMPC_class.py:250-254)."""

@@ -268,7 +268,7 @@ def test_acados_error_behaviour():
     with pytest.raises(Exception):
         s.get(39, "x")
     with pytest.raises(Exception):
-        s.cost_set(0, "W", np.ones((6, 6)))    # non-diagonal W
+        s.cost_set(0, "W", np.ones((5, 5)))    # wrong dimension (a non-diagonal 6 x 6 W is accepted since round 6: tests/test_full_w.py)
     with pytest.raises(Exception):
         s.get_from_qp_in(0, "A")               # capsule built without store_qp_in
     assert s.get(0, "x").shape == (8,) and s.get(0, "u").shape == (2,)

@@ -120,6 +120,14 @@ __global__ void pack_summary_kernel(const double *U, const double *cost, const i
     dst[5 * i + 2] = cost[b]; dst[5 * i + 3] = (double)status[b]; dst[5 * i + 4] = (double)qp_iter[b];
 }
 
+// the full-W array of a capsule from its diagonal one (first cost_set 'W' with an off-diagonal entry): n = batch x (N + 1) stage slots
+__global__ void wf_from_diag_kernel(const double *W, double *Wf, long long n)
+{
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    for (int e = 0; e < 36; e++) Wf[i * 36 + e] = (e / 6 == e % 6) ? W[i * 6 + e / 6] : 0.0;
+}
+
 // The same plus the whole iterate into (host-mapped) slabs: for small batches one launch instead of the summary kernel and two
 // copy commands (tum_ocp_results_async with_iterate; 3 KB per instance across PCIe as plain stores).
 // ts (nullable): [1] takes the device's wall clock (constant-rate counter) when this kernel starts -- the end of the step's device

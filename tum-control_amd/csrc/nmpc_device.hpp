@@ -123,6 +123,9 @@ struct KArgs {
     // safeguard of the warm start: used only when at most warm_flips row sides changed their activity between the previous QP's solution
     // and the new problem and no row is violated by more than warm_viol beyond its old slack (warm_flips < 0: always)
     int warm_flips; double warm_viol;
+    // a full symmetric W per stage (round 6; acados' cost_set(i, 'W', W) takes any matrix, NMPC_class.py:290-296): [b][N+1][36] row-major, stage N its
+    // leading 4 x 4 -- or null: the diagonal in W above. The pipeline then condenses with cond_wide_kernel<., false, true>.
+    const double *Wf;
 };
 
 // ---------------------------------------------------------------- wave helpers

@@ -805,9 +805,15 @@ template <int NT_> struct CondWide {
 // SN = true: the nominal copy of the coupled SNMPC OCP -- G_s, g_s and the chance-constraint rows of the stages s <= uph come
 // from the prologue kernel's hand-over buffer, the recursion starts behind them; speed row |v|, gg row with its vt partial
 // (the same differences as between cond_kernel<., false> and cond_kernel<., true>)
-template <int NT_, bool SN>
+// FULLW (round 6, nominal OCP only): the stage cost takes a full symmetric W (KArgs::Wf; acados' cost_set(i, 'W', W) accepts any matrix,
+// NMPC_class.py:290-296). With the output Jacobian of stage s in the condensed variables J = [rows 0..3 of G_s ; unit rows of the inputs 2s, 2s+1] and
+// W = [Q S; S' R]: the SYRK's A operand becomes Q-mixed rows (Q J_x instead of w_r J_r), the 2 x 2 block R goes onto the diagonal tile, the cross term
+// S' J_x is added to the rows 2s, 2s+1 of H (and, in the diagonal tiles, to their mirror image: the interior point kernel reads both triangles), and
+// the gradient takes W (res + g) over all six outputs. The diagonal instantiation is untouched.
+template <int NT_, bool SN, bool FULLW = false>
 __global__ void __launch_bounds__(64 * cw_waves<NT_>()) cond_wide_kernel(const PArgs pa)
 {
+    static_assert(!(SN && FULLW), "the coupled SNMPC OCP takes a diagonal W");
     PD_LOCALS
     using CW = CondWide<NT_>;
     constexpr int CW_WAVES = cw_waves<NT_>();
@@ -815,6 +821,7 @@ __global__ void __launch_bounds__(64 * cw_waves<NT_>()) cond_wide_kernel(const P
     __shared__ __attribute__((aligned(16))) double sRec[(NMAX + 3) * PREC];       // (+2: the read-ahead of the last stage stays inside)
     __shared__ __attribute__((aligned(16))) double sRows[CW::ROWS];
     __shared__ double sG[(NMAX + 1) * GSTR], sWt[(NMAX + 1) * 6], sU0[NVP], sEq[2 * ((NMAX + 1) * 4 + 2)];
+    __shared__ double sWf[FULLW ? (NMAX + 1) * 36 : 1];          // full W per stage, scaled by dt (stage N: 1)
     const KArgs &ka = pa.ka;
     const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63, b = blockIdx.x;
     if (b >= ka.batch) return;
@@ -844,6 +851,10 @@ __global__ void __launch_bounds__(64 * cw_waves<NT_>()) cond_wide_kernel(const P
         sRec[i] = v;
     }
     for (int i = tid; i < (N + 1) * 6; i += 64 * CW_WAVES) sWt[i] = gW[i];
+    if constexpr (FULLW) {
+        const double *gWf = ka.Wf + (size_t)b * (N + 1) * 36;
+        for (int i = tid; i < (N + 1) * 36; i += 64 * CW_WAVES) sWf[i] = ((i < 36 * N) ? dt : 1.0) * gWf[i];
+    }
     for (int i = tid; i < NVP; i += 64 * CW_WAVES) sU0[i] = (i < nv) ? gU[i] : 0.0;
     __syncthreads();
 
@@ -955,17 +966,29 @@ __global__ void __launch_bounds__(64 * cw_waves<NT_>()) cond_wide_kernel(const P
             static_for<1, NT>([&](auto tsc) {
                 constexpr int Ts = decltype(tsc)::value;
                 // (the operands of the next stage are read while the matrix cores work on this one: two register sets, as in phase 1)
-                auto ldop = [&](int s, double (&bo)[Ts], double &wl) {
+                // (FULLW: ao = row lq of Q J_x of the stage -- four reads and four FMAs per tile column instead of one product)
+                double ao_a[FULLW ? Ts : 1], ao_b[FULLW ? Ts : 1];
+                auto ldop = [&](int s, double (&bo)[Ts], double &wl, double *ao) {
                     const double sc = (s < N) ? dt : 1.0;
                     wl = sc * sWt[s * 6 + lq];
                     const double *row = sRows + CW::rowoff(s) + lq * (16 * Ts) + lc;
 #pragma unroll
                     for (int T = 0; T < Ts; T++) bo[T] = row[16 * T];
+                    if constexpr (FULLW) {
+                        const double *r0_ = sRows + CW::rowoff(s) + lc, *wq = sWf + s * 36 + lq * 6;
+#pragma unroll
+                        for (int T = 0; T < Ts; T++) {
+                            double a = 0.0;
+#pragma unroll
+                            for (int r = 0; r < 4; r++) a += wq[r] * r0_[r * (16 * Ts) + 16 * T];
+                            ao[T] = a;
+                        }
+                    }
                 };
-                auto mm = [&](const double (&bop)[Ts], const double wl) {
+                auto mm = [&](const double (&bop)[Ts], const double wl, const double *ao) {
                     static_for<0, Ts - 1>([&](auto Kc) {
                         constexpr int K = decltype(Kc)::value;
-                        const double aop = bop[K] * wl;
+                        const double aop = FULLW ? ao[K] : bop[K] * wl;
                         static_for<K, Ts - 1>([&](auto Ic) {
                             constexpr int I = decltype(Ic)::value;
                             if constexpr (CW::tab.own[D::tidx(K, I)] == WV) Ht[D::tidx(K, I)] = mfma(aop, bop[I], Ht[D::tidx(K, I)]);
@@ -975,13 +998,13 @@ __global__ void __launch_bounds__(64 * cw_waves<NT_>()) cond_wide_kernel(const P
                 const int se = (N < 8 * Ts) ? N : 8 * Ts;
                 int s = 8 * (Ts - 1) + 1;
                 double ba[Ts], bb[Ts], wa = 0.0, wb = 0.0;
-                if (s <= se) ldop(s, ba, wa);
+                if (s <= se) ldop(s, ba, wa, ao_a);
                 for (; s <= se; s += 2) {
-                    if (s + 1 <= se) ldop(s + 1, bb, wb);
-                    mm(ba, wa);
+                    if (s + 1 <= se) ldop(s + 1, bb, wb, ao_b);
+                    mm(ba, wa, ao_a);
                     if (s + 1 <= se) {
-                        if (s + 2 <= se) ldop(s + 2, ba, wa);
-                        mm(bb, wb);
+                        if (s + 2 <= se) ldop(s + 2, ba, wa, ao_a);
+                        mm(bb, wb, ao_b);
                     }
                 }
             });
@@ -992,7 +1015,27 @@ __global__ void __launch_bounds__(64 * cw_waves<NT_>()) cond_wide_kernel(const P
                 static_for<0, I>([&](auto Kc) {
                     constexpr int K = decltype(Kc)::value;
                     if constexpr (CW::tab.own[D::tidx(K, I)] == WV) {
-                        if constexpr (K == I) {
+                        if constexpr (FULLW) {
+#pragma unroll
+                            for (int jj = 0; jj < 4; jj++) {
+                                // component jj of lane (lq, lc) of tile (K, I) is H[16 I + lc][16 K + lq + 4 jj] (the matrix instruction's D[i][j]: i from the
+                                // A operand = column tile K, j from the B operand = row tile I)
+                                const int ir = 16 * I + lc, ic = 16 * K + lq + 4 * jj;
+                                double add = 0.0;
+                                // the 2 x 2 input block R of the stage both indices belong to; padding beyond the horizon
+                                if (K == I && (ir >> 1) == (ic >> 1)) add = (ir < nv) ? sWf[(ir >> 1) * 36 + (4 + (ir & 1)) * 6 + 4 + (ic & 1)] : ((ir == ic) ? 1.0 : 0.0);
+                                // the cross term S' J_x: row 2s + j of H against the columns below 2s -- and its mirror image in a diagonal tile
+                                const int hi = (ir > ic) ? ir : ic, lo = (ir > ic) ? ic : ir;
+                                const int s_ = hi >> 1, j_ = hi & 1;
+                                if (s_ >= 1 && s_ < N && lo < 2 * s_) {
+                                    const int Tss = (s_ + 7) >> 3;
+                                    const double *rw_ = sRows + CW::rowoff(s_) + lo, *ws = sWf + s_ * 36 + 4 + j_;
+#pragma unroll
+                                    for (int r = 0; r < 4; r++) add += ws[r * 6] * rw_[r * (16 * Tss)];
+                                }
+                                Ht[tidx(K, I)][jj] += add;
+                            }
+                        } else if constexpr (K == I) {
 #pragma unroll
                             for (int jj = 0; jj < 4; jj++) {
                                 const int rw = lq + 4 * jj;
@@ -1024,6 +1067,14 @@ __global__ void __launch_bounds__(64 * cw_waves<NT_>()) cond_wide_kernel(const P
             const int s = 1 + (i >> 2), r = i & 3;
             const double sc = (s < N) ? dt : 1.0;
             const double gs = (SN && r == 3) ? sRec[s * PREC + PR_CV] * sG[s * GSTR + 3] + sRec[s * PREC + PR_CV + 1] * sG[s * GSTR + 4] : sG[s * GSTR + r];
+            if constexpr (FULLW) {
+                // row r of W (res + g) over the stage's outputs: the four state outputs and (s < N) the two inputs
+                double a = 0.0;
+#pragma unroll
+                for (int r2 = 0; r2 < 4; r2++) a += sWf[s * 36 + r * 6 + r2] * (sRec[s * PREC + PR_RES + r2] + sG[s * GSTR + r2]);
+                if (s < N) a += sWf[s * 36 + r * 6 + 4] * (sU0[2 * s] - gyref[s * 6 + 4]) + sWf[s * 36 + r * 6 + 5] * (sU0[2 * s + 1] - gyref[s * 6 + 5]);
+                sE[4 * s + r] = a;
+            } else
             sE[4 * s + r] = (sc * sWt[s * 6 + r]) * (sRec[s * PREC + PR_RES + r] + gs);
         }
         if (lane == 0) sE[0] = 0.0;
@@ -1045,6 +1096,15 @@ __global__ void __launch_bounds__(64 * cw_waves<NT_>()) cond_wide_kernel(const P
                 q += a;
             }
         });
+        if constexpr (FULLW) {
+            if (col < nv) {      // the input output 4 + r0 of stage j: row 4 + r0 of W against all six residuals of that stage (stage 0: g = x0 - X_0)
+                const double *wr_ = sWf + j * 36 + (4 + r0) * 6;
+                double a = wr_[4] * (sU0[2 * j] - gyref[j * 6 + 4]) + wr_[5] * (sU0[2 * j + 1] - gyref[j * 6 + 5]);
+#pragma unroll
+                for (int r2 = 0; r2 < 4; r2++) a += wr_[r2] * (sRec[j * PREC + PR_RES + r2] + ((j == 0) ? gx0[r2] - gX[r2] : sG[j * GSTR + r2]));
+                q += a;
+            }
+        } else
         if (col < nv) q += dt * sWt[j * 6 + 4 + r0] * (sU0[col] - gyref[j * 6 + 4 + r0]);
         if (colv) gvec[PV_Q + col] = q;
     }
@@ -1147,6 +1207,16 @@ __device__ __forceinline__ void expand_instance(const PArgs &pa, const int b, do
         if (k < N) {
             e = sU1[2 * k] - yr[4]; acc += Wd[4] * e * e;
             e = sU1[2 * k + 1] - yr[5]; acc += Wd[5] * e * e;
+        }
+        if (!SN && ka.Wf) {      // a full W (cost_set 'W' with off-diagonal entries): r' W r over the stage's outputs instead of the diagonal sum
+            const double *Wk = ka.Wf + ((size_t)b * (N + 1) + k) * 36;
+            double rr[6];
+            rr[0] = sX[k * NX + 0] - yr[0]; rr[1] = sX[k * NX + 1] - yr[1]; rr[2] = wrap_yaw(sX[k * NX + 2]) - yr[2]; rr[3] = sX[k * NX + 3] - yr[3];
+            rr[4] = (k < N) ? sU1[2 * k] - yr[4] : 0.0; rr[5] = (k < N) ? sU1[2 * k + 1] - yr[5] : 0.0;
+            const int ny = (k < N) ? 6 : 4;
+            acc = 0.0;
+            for (int i = 0; i < ny; i++)
+                for (int j2 = 0; j2 < ny; j2++) acc += Wk[i * 6 + j2] * rr[i] * rr[j2];
         }
         cl += 0.5 * sc * acc;
     }

@@ -34,6 +34,7 @@ struct tum_ocp {
     KArgs ka;
     double *dx0_own, *dyref_own;        // the capsule's own x0 / yref arrays; dx0 / dyref below are what is IN USE (tum_ocp_bind_device: the caller's)
     double *dX, *dU, *dx0, *dyref, *dW, *dpen, *dbnd, *dcost, *dres, *dslack, *dqpin, *ddbg, *dqplam;
+    double *dWf;                       // full W per stage, [b][N+1][36] (allocated by the first cost_set 'W' with an off-diagonal entry; null: diagonal W)
     int *dstatus, *dqpiter, *dqpstatus, *dorder;
     bool lpt, order_valid;
     long long *dprof;
@@ -252,7 +253,7 @@ extern "C" void tum_ocp_free(tum_ocp *c)
 {
     if (!c) return;
     DevGuard guard(c->d.device);
-    (void)hipFree(c->dX); (void)hipFree(c->dU); (void)hipFree(c->dx0_own); (void)hipFree(c->dyref_own); (void)hipFree(c->dW); (void)hipFree(c->dpen); (void)hipFree(c->dbnd);
+    (void)hipFree(c->dX); (void)hipFree(c->dU); (void)hipFree(c->dx0_own); (void)hipFree(c->dyref_own); (void)hipFree(c->dW); if (c->dWf) (void)hipFree(c->dWf); (void)hipFree(c->dpen); (void)hipFree(c->dbnd);
     (void)hipFree(c->dqplam);
     (void)hipFree(c->dcost); (void)hipFree(c->dres); (void)hipFree(c->dslack); (void)hipFree(c->dstatus); (void)hipFree(c->dqpiter); (void)hipFree(c->dqpstatus); (void)hipFree(c->dorder);
     if (c->dqpin) (void)hipFree(c->dqpin);
@@ -297,6 +298,7 @@ extern "C" int tum_ocp_snmpc_attach(tum_ocp *c, int ns, int L, const double *Apc
 {
     if (!c || !Apce) return fail("null argument");
     if (c->sn) return fail("snmpc_attach: already attached");
+    if (c->dWf) return fail("snmpc_attach: the capsule holds a full W; the coupled SNMPC OCP takes a diagonal one");
     if (ns < 1 || ns > SN_NSMAX) return fail("snmpc_attach: n_samples out of range (1..16)");
     if (L < 1 || L > SN_LMAX) return fail("snmpc_attach: number of PCE terms out of range (1..16)");
     if (uph < 0 || uph > c->N || uph > SN_UPHMAX) return fail("snmpc_attach: uncertainty propagation horizon out of range (0..N)");
@@ -731,13 +733,37 @@ extern "C" int tum_ocp_cost_set(tum_ocp *c, int stage, const char *field, const 
         const int cnt = stride == 0 ? 1 : nb;
         const int rep = all ? N : 1;
         std::vector<double> diag((size_t)cnt * rep * ny);
+        bool offdiag = false;
         for (int i = 0; i < cnt; i++) {
             const double *Wm = v + (size_t)i * stride;
             for (int r = 0; r < ny; r++)
                 for (int q = 0; q < ny; q++) {
                     if (r == q) { for (int k = 0; k < rep; k++) diag[((size_t)i * rep + k) * ny + r] = Wm[r * ny + r]; }
-                    else if (Wm[q * ny + r] != 0.0) return fail("cost_set W: only diagonal W supported");
+                    else if (Wm[q * ny + r] != 0.0) offdiag = true;
                 }
+        }
+        // A W with off-diagonal entries (acados takes any matrix, NMPC_class.py:290-296; the reference installs diagonal ones): from the first such
+        // call on the capsule keeps a full symmetric 6 x 6 per stage (its symmetric part: the cost only sees that) beside the diagonal, and the
+        // pipeline condenses with the full-W instantiation of the six-wavefront condensing kernel. Nominal / R2 OCP through the pipeline only.
+        if (offdiag && !c->dWf) {
+            if (c->sn) return fail("cost_set W: the coupled SNMPC OCP takes a diagonal W (its cost rows come from the prologue kernel)");
+            DevGuard guard(c->d.device); GUARD_OK(guard);
+            HIPCHK(hipStreamSynchronize(c->stream));
+            if (dalloc(&c->dWf, (size_t)c->batch * (N + 1) * 36) != hipSuccess) return fail("cost_set W: device allocation failed");
+            const size_t n = (size_t)c->batch * (N + 1);
+            hipLaunchKernelGGL(wf_from_diag_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, c->dW, c->dWf, (long long)n);
+            HIPCHK(hipGetLastError());
+            c->ka.Wf = c->dWf; c->epoch++;
+        }
+        if (c->dWf) {
+            std::vector<double> full((size_t)cnt * rep * 36, 0.0);
+            for (int i = 0; i < cnt; i++) {
+                const double *Wm = v + (size_t)i * stride;
+                for (int k = 0; k < rep; k++)
+                    for (int r = 0; r < ny; r++)
+                        for (int q = 0; q < ny; q++) full[((size_t)i * rep + k) * 36 + r * 6 + q] = 0.5 * (Wm[q * ny + r] + Wm[r * ny + q]);
+            }
+            if (put(c, c->dWf, (size_t)(N + 1) * 36, all ? 0 : (size_t)stage * 36, full.data(), rep * 36, b0, nb, stride == 0 ? 0 : rep * 36)) return 1;
         }
         return put(c, c->dW, (size_t)(N + 1) * 6, all ? 0 : (size_t)stage * 6, diag.data(), rep * ny, b0, nb, stride == 0 ? 0 : rep * ny);
     }
@@ -823,6 +849,7 @@ static int resolve_kernel(tum_ocp *c)
 {
 #ifdef TUM_DEV_KERNELS
     c->pipe = !(c->ka.flags & 2) && c->kmode != 1;
+    if (c->dWf && c->kmode == 1) return fail("solve: a full W (cost_set 'W' with off-diagonal entries) runs on the pipeline only, not on the development kernel 'fused'");
     if (c->ka.warm_mu > 0.0 && (c->kmode == 1 || c->kmode == 3))
         return fail("solve: the development kernels 'fused' / 'pipeline4' always cold-start the interior point method: create the capsule with qp_warm_start = 0");
     if (c->N > NMAX) {      // the fused kernel covers N <= 40; longer horizons exist as a pipeline instantiation only
@@ -870,7 +897,7 @@ static bool use_cond_wide(const tum_ocp *c)
 {
     static const int wide_env = [] { const char *e = getenv("TUM_COND_WIDE"); return e ? atoi(e) : -1; }();
     const int want = (c->cond_wide >= 0) ? c->cond_wide : wide_env;
-    return want > 0 || (want < 0 && c->batch <= 256);
+    return want > 0 || (want < 0 && c->batch <= 256) || c->dWf != nullptr;          // (a full W exists as an instantiation of this kernel only)
 }
 // The device closed loop (tum_sim_run) can run the linearisation of a solve BESIDE the planner of the same control step: the
 // Runge-Kutta pass needs the iterate, not the reference -- only the four residuals of the cost do, and cond_wide_kernel forms those
@@ -930,6 +957,7 @@ static int launch_pipeline(tum_ocp *c, bool events)
             // six wavefronts per OCP while every OCP can have a CU's LDS to itself (cond_wide_kernel)
             const bool wide = use_cond_wide(c);
             if (wide && c->sn) hipLaunchKernelGGL((cond_wide_kernel<NTv, true>), dim3(c->batch), dim3(64 * cw_waves<NTv>()), 0, c->stream, pa);
+            else if (wide && c->dWf) hipLaunchKernelGGL((cond_wide_kernel<NTv, false, true>), dim3(c->batch), dim3(64 * cw_waves<NTv>()), 0, c->stream, pa);
             else if (wide) hipLaunchKernelGGL((cond_wide_kernel<NTv, false>), dim3(c->batch), dim3(64 * cw_waves<NTv>()), 0, c->stream, pa);
             // (coupled SNMPC: the register form of the stage record pays behind stage uph and costs in front of it, pipe_kernels.hpp)
             else if (c->sn && 2 * c->sa.uph <= c->N) hipLaunchKernelGGL((cond_kernel<NTv, true, true>), dim3(c->batch), dim3(64), 0, c->stream, pa);

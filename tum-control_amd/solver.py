@@ -273,12 +273,13 @@ class BatchedOcpSolver:
 
     def cost_set(self, stage, field, value):
         """acados_solver.cost_set (NMPC_class.py:294-317). 'W' is PER STAGE, as in acados: cost_set(i, 'W', W) touches stage i only
-        (stage N: the 4 x 4 terminal weight); cost_set(ALL_STAGES, 'W', W6x6) sets the stages 0..N-1 in one call. W must be
-        diagonal (include/tum_nmpc.h). 'zl' | 'zu' | 'Zl' | 'Zu': per penalty class (stage 0 / 1..N-1 / N)."""
+        (stage N: the 4 x 4 terminal weight); cost_set(ALL_STAGES, 'W', W6x6) sets the stages 0..N-1 in one call. W may be any
+        (symmetric) matrix, as in acados: diagonal ones -- all the reference installs -- keep the capsule on the headline's kernels, the first W with
+        an off-diagonal entry switches it to the full-W form (include/tum_nmpc.h). 'zl' | 'zu' | 'Zl' | 'Zu': per penalty class (stage 0 / 1..N-1 / N)."""
         v = np.asarray(value, dtype=np.float64)
         if field == "W":
             ny = 6 if (stage < self.N) else 4          # (stage == ALL_STAGES = -1: one 6 x 6 W for all the stages 0..N-1)
-            if v.ndim == 3:     # (batch, ny, ny): column-major per instance (diagonal => same either way)
+            if v.ndim == 3:     # (batch, ny, ny): column-major per instance
                 v = np.ascontiguousarray(v.transpose(0, 2, 1)).reshape(v.shape[0], ny * ny)
             else:
                 v = np.ascontiguousarray(v.T).reshape(-1)
