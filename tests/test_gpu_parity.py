@@ -273,7 +273,7 @@ def test_acados_error_behaviour():
         s.get_from_qp_in(0, "A")               # capsule built without store_qp_in
     assert s.get(0, "x").shape == (8,) and s.get(0, "u").shape == (2,)
     with pytest.raises(RuntimeError):
-        BatchedOcpSolver(N=49, batch=1)        # horizons up to 48 (TUM_N_MAX)
+        BatchedOcpSolver(N=57, batch=1)        # horizons up to 56 (TUM_N_MAX)
 
 
 def test_scenario_fanout_and_pce_moments():

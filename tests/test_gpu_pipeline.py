@@ -150,7 +150,7 @@ def test_pipeline_in_the_device_closed_loop(golden_dir):
     assert np.array_equal(logs["pipeline"]["simSolverDebug"][:, :, 3], logs["fused"]["simSolverDebug"][:, :, 3])
 
 
-@pytest.mark.parametrize("N,B", [(41, 5), (44, 33), (48, 1500), (48, 1)])
+@pytest.mark.parametrize("N,B", [(41, 5), (44, 33), (48, 1500), (48, 1), (49, 3), (50, 1100), (56, 300), (56, 1)])
 def test_long_horizons_vs_oracle(N, B):
     """Horizons 41..48 (six 16-wide tiles of condensed variables; the reference derives N from its YAML, NMPC_class.py:49) exist
     as a pipeline instantiation: cold start and a warm real-time iteration against the oracle, every instance; row mapping of
@@ -209,6 +209,17 @@ def test_long_horizon_closed_loops():
     for f in ("simU", "CiLX", "MPC_SimX"):
         np.testing.assert_allclose(logs[True][f], logs[False][f], rtol=1e-8, atol=1e-8, err_msg=f)
     assert (logs[True]["simSolverDebug"][:, :, 4] == 0).all()
+    # Tp = 4.0 s: N = 50, the seven-tile instantiation, host loop against the all-device loop
+    logs = {}
+    for dev in (False, True):
+        cl = ClosedLoopBatch("monteblanco", batch=2, N=50, Tp=4.0, on_device=dev, log_capacity=30)
+        logs[dev] = cl.run(30)
+    for f in ("simU", "CiLX", "MPC_SimX"):
+        np.testing.assert_allclose(logs[True][f], logs[False][f], rtol=1e-8, atol=1e-8, err_msg=f)
+    assert (logs[True]["simSolverDebug"][:, :, 4] == 0).all()
+    cl = ClosedLoopBatch("modena", batch=3, N=52, Tp=4.16, on_device=True, log_capacity=20, controller="r2")
+    lg = cl.run(20)
+    assert (lg["simSolverDebug"][:, :, 4] == 0).all()
     cl = ClosedLoopBatch("modena", batch=5, N=47, Tp=3.76, on_device=True, log_capacity=30, controller="r2")
     cl.solver.set_kernel("auto")
     lg = cl.run(30)
@@ -316,3 +327,77 @@ def test_interior_point_warm_start_semantics():
         assert (lg["simSolverDebug"][:, :, 4] == 0).all()
         its[warm] = lg["simSolverDebug"][50:, :, 3].mean()
     assert its[True] < 0.97 * its[False], its
+
+
+def test_seven_tiles_at_a_horizon_six_cover_is_the_same_solve(tmp_path):
+    """N = 49..56 run the pipeline's seven-tile instantiation (round 6: Tp = 4.0 s at Ts_MPC = 0.08 s is N = 50, NMPC_class.py:49). Beside the parity with
+    the oracle above: forced onto a horizon the six-tile build covers (TUM_FORCE_TILES = 7, a development switch read once per process) it must return the
+    six-tile build's iterate -- the padding variables must not matter -- and at N <= 40 the five-tile build's to solver accuracy (another factor layout)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = (
+        "import sys, numpy as np; sys.path.insert(0, %r)\n"
+        "import torch\n"
+        "from tum_control_amd.solver import BatchedOcpSolver\n"
+        "from tum_control_amd.workloads import nominal_batch\n"
+        "N = int(sys.argv[1]); x0, yref = nominal_batch(48, N=N, seed=7)\n"
+        "s = BatchedOcpSolver(N=N, dt=0.08, nsub=3, batch=48); s.install_reference_ocp(); s.set_x0(x0); s.set_yref_all(yref); s.cold_start()\n"
+        "assert s.solve() == 0 and s.solve() == 0\n"
+        "X, U = s.get_iterate(); np.savez(sys.argv[2], X=X, U=U, it=s.get_stats('qp_iter'))\n" % root)
+    out = {}
+    for N in (46, 36):
+        for force in ("0", "7"):
+            f = str(tmp_path / f"t{N}_{force}.npz")
+            env = dict(os.environ, TUM_FORCE_TILES=force)
+            r = subprocess.run([sys.executable, "-c", code, str(N), f], env=env, capture_output=True, text=True, timeout=600)
+            assert r.returncode == 0, r.stderr[-2000:]
+            out[(N, force)] = np.load(f)
+    a, b = out[(46, "0")], out[(46, "7")]
+    assert np.array_equal(a["U"], b["U"]) and np.array_equal(a["X"], b["X"]) and np.array_equal(a["it"], b["it"])
+    a, b = out[(36, "0")], out[(36, "7")]
+    assert np.abs(a["U"] - b["U"]).max() < 1e-6 and np.abs(a["it"] - b["it"]).max() <= 1
+
+
+def test_horizon_caps_are_stated():
+    """N <= 56; the coupled SNMPC OCP and a full W stop at N = 48 and say so"""
+    from tum_control_amd.solver import BatchedOcpSolver, CoupledSnmpcSolver
+    from tum_control_amd import snmpc as snm
+    with pytest.raises(RuntimeError, match="1..56"):
+        BatchedOcpSolver(N=57, batch=1)
+    s = BatchedOcpSolver(N=50, batch=2)
+    s.install_reference_ocp()
+    W = np.diag([1.0, 1.0, 1.0, 1.0, 1.0, 1.0]); W[0, 1] = W[1, 0] = 0.1
+    with pytest.raises(Exception, match="beyond 48"):
+        s.cost_set(3, "W", W)
+    w = snm.hammersley_normal(10, 3)
+    with pytest.raises(Exception, match="up to 48"):
+        CoupledSnmpcSolver(N=50, batch=1, Apce=snm.pce_matrix(w, snm.alpha_generation(3, 2)), uph=5)
+
+
+@pytest.mark.parametrize("pattern", ["step", "acados"])
+def test_controller_class_at_tp_4_seconds(pattern):
+    """The mirrored controller class with Tp = 4.0 s in sim_main_params: N = int(Tp / Ts_MPC) = 50 (NMPC_class.py:49), refused until round 6. Twelve control
+    steps of a host-driven loop on Monteblanco -- planner, solve(), the plant restatement --, each solve against the oracle fed the same inputs; both call
+    patterns of the mirror (the one-call step and the reference's literal setter / solve / getter sequence)."""
+    from tum_control_amd.nmpc import Nonlinear_Model_Predictive_Controller
+    from tum_control_amd.planner import load_track, planner_emulator
+    from tum_control_amd.closed_loop import plant_step
+    from tum_control_amd import config
+    tr = load_track("monteblanco")
+    x = np.array([tr[300, 0], tr[300, 1], np.mod(tr[300, 2], 2 * np.pi), tr[300, 3], 0, 0, 0, 0.0])
+    mpc = Nonlinear_Model_Predictive_Controller(sim_main_params=dict(Tp=4.0, Ts=0.02, Ts_MPC=0.08), X0_MPC=x, call_pattern=pattern)
+    assert mpc.N == 50
+    o = _oracle(50); o.cold_start(x)
+    cfg = config.default_config()
+    xs = x[:7].copy()
+    for i in range(12):
+        _, ref = planner_emulator(tr, xs[:2], 51, 4.0, True)
+        u0, pred_X, stats = mpc.solve(dict(pos_x=ref[:, 0], pos_y=ref[:, 1], ref_yaw=ref[:, 2], ref_v=ref[:, 3]))
+        assert stats[4] == 0
+        o.set_yref(ref[:, 0], ref[:, 1], ref[:, 2], ref[:, 3]); assert o.solve() == 0
+        assert np.abs(u0 - o.U[0]).max() < 1e-6 and np.abs(pred_X[1] - o.X[1]).max() < 1e-6, i
+        xs = plant_step(xs[None], np.array([pred_X[1][7]]), np.array([u0[1]]), cfg)[0]
+        xn = np.concatenate([xs, [pred_X[1][7]]])
+        mpc.set_initial_state(xn); o.x0[:] = xn

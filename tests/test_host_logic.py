@@ -238,7 +238,12 @@ def test_shipped_kernels_resource_budget():
         assert sgpr_spill <= 64, (name, sgpr_spill)
         # no scratch anywhere: the condensing kernel's 52 B of rounds 2-3 are gone, and since round 6 (lane-distributed micro-panels: ~26
         # registers fewer) the six-tile interior point kernel (N = 41..48) no longer spills its 10 registers / 44 B either
-        assert scratch == 0 and vgpr_spill == 0, (name, scratch, vgpr_spill)
+        # -- the five- and six-tile builds. The seven-tile interior point kernel (N = 49..56, round 6: 112 registers of gg rows alone) spills: stated
+        # in INTEGRATION.md with its measured rate
+        if "ipm_kernel<false, 7" in name:
+            assert scratch <= 256 and vgpr_spill <= 64, (name, scratch, vgpr_spill)
+        else:
+            assert scratch == 0 and vgpr_spill == 0, (name, scratch, vgpr_spill)
         # (cond_wide_kernel: one workgroup of six wavefronts per CU by design -- records, row store of every stage and g column in LDS)
         lds_cap = 160 * 1024 if "cond_wide_kernel" in name else 40 * 1024
         assert vgpr + agpr <= 512 and lds <= lds_cap, name

@@ -81,7 +81,7 @@ template <int NT_> struct PD {
     static constexpr int I_XS = I_ZERO + 2, I_XB = I_XS + (PRE_DIAG ? NVP : 0);
     static constexpr int I_LDS = I_XB + (PRE_DIAG ? NVP : 0), I_LDS_BYTES = I_LDS * 8;
     static_assert(NVP <= 2 * NMAX + 2, "the v-space alias must fit in the box / suffix buffers");
-    static_assert(I_LDS_BYTES <= 40 * 1024, "four workgroups per CU");
+    static_assert(I_LDS_BYTES <= (NT_ <= 6 ? 40 : 64) * 1024, "four workgroups per CU (seven tiles: the packed factor alone is 51 KB -- three)");
     static __host__ __device__ constexpr int tidx(int K, int I) { return K * NT_ - K * (K - 1) / 2 + (I - K); }   // K <= I
     static __host__ __device__ constexpr int offt(int I, int K) { return I * (I - 1) / 2 + K; }                 // tile (I, K), I > K
     // physical column of (row, col) inside a tile: col ^ tile_swz(row); bits of the row: [3 2 1 0] -> [1 3 2 0]
@@ -1281,7 +1281,7 @@ __global__ void __launch_bounds__(64) expand_kernel(const PArgs pa)
             t[T] = quad_sum(e0 + e1); \
         } \
         a0 += (lq == 0) ? t[0] : (lq == 1) ? t[1] : (lq == 2) ? t[2] : t[3]; \
-        a1 += (NT > 5 && lq == 1) ? t[NT - 1] : t[4];          /* bank 1: tile 4 on its lanes 0..15, tile 5 on 16..31 */ \
+        a1 += (NT > 6 && lq == 2) ? t[NT - 1] : (NT > 5 && lq == 1) ? t[5 < NT ? 5 : 4] : t[4];          /* bank 1: tile 4 on its lanes 0..15, tile 5 on 16..31, tile 6 on 32..47 */ \
         o0 = v0on ? a0 : 0.0; o1 = v1on ? a1 : 0.0; \
     }; \
     auto publish = [&](const double *w_, double *dstH) {   /* slot values of this lane -> box scalars, steering suffix sums, gg weights */ \
@@ -1724,6 +1724,7 @@ __global__ void __launch_bounds__(64, 1) ipm_kernel(const PArgs pa)
                 owed(10);
                 owed(11);
                 owed(12);
+                if constexpr (NT > 6) owed(13);          // (seven tiles: the first block column owes 2 x 7 slots)
                 const int rel = lc - (4 * m + lq);              // row - column inside the diagonal tile
                 bprev = bx;
                 pop = popn;
@@ -1976,7 +1977,7 @@ __global__ void __launch_bounds__(64, 1) ipm_kernel(const PArgs pa)
                 //  the lower and another in the upper half of every DPP row, at distance 4 two such registers are folded again ...
                 //  the last register holds a different row total in (almost) every lane: 9 merges of 7 instructions and 2 plain
                 //  steps of 3 instead of 40 steps of 3, and ONE store instead of one masked store per chunk)
-                static_assert(NC == 10 || NC == 12, "the reduction tree below is written for 10 or 12 row chunks");
+                static_assert(NC == 10 || NC == 12 || NC == 14, "the reduction tree below is written for 10, 12 or 14 row chunks");
                 double pr[NC];
 #pragma unroll
                 for (int c = 0; c < NC; c++) {
@@ -1995,13 +1996,16 @@ __global__ void __launch_bounds__(64, 1) ipm_kernel(const PArgs pa)
                 for (int q = 0; q < NC / 2; q++) R[q] = TUM_MERGE(0x140, h8, pr[2 * q], pr[2 * q + 1]);
                 const double S0 = TUM_MERGE(0x141, h4, R[0], R[1]), S1 = TUM_MERGE(0x141, h4, R[2], R[3]);
                 double S2;
-                if constexpr (NC == 12) S2 = TUM_MERGE(0x141, h4, R[4], R[NC / 2 - 1]); else S2 = TUM_FOLD(0x141, R[4]);
-                const double U0 = TUM_MERGE(0x1b, h2, S0, S1), U1 = TUM_FOLD(0x1b, S2);
+                if constexpr (NC >= 12) S2 = TUM_MERGE(0x141, h4, R[4], R[5]); else S2 = TUM_FOLD(0x141, R[4]);
+                double U1;
+                if constexpr (NC == 14) { const double S3 = TUM_FOLD(0x141, R[6]); U1 = TUM_MERGE(0x1b, h2, S2, S3); }      // (chunks 12, 13 in the h2 half of U1)
+                else U1 = TUM_FOLD(0x1b, S2);
+                const double U0 = TUM_MERGE(0x1b, h2, S0, S1);
                 const double V = TUM_MERGE(0xb1, h1, U0, U1);
 #undef TUM_MERGE
 #undef TUM_FOLD
                 // chunk whose row total this lane holds
-                const int cl = h1 ? 8 + ((NC == 12 && h4) ? 2 : 0) + (h8 ? 1 : 0) : (h2 ? 4 : 0) + (h4 ? 2 : 0) + (h8 ? 1 : 0);
+                const int cl = h1 ? ((NC == 14 && h2) ? 12 : 8 + ((NC >= 12 && h4) ? 2 : 0)) + (h8 ? 1 : 0) : (h2 ? 4 : 0) + (h4 ? 2 : 0) + (h8 ? 1 : 0);
                 wsync();
                 sWh[4 * cl + lq] = V;
                 wsync();

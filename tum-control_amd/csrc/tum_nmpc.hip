@@ -129,7 +129,7 @@ static hipError_t dalloc(T **p, size_t n)
 extern "C" tum_ocp *tum_ocp_create(const tum_ocp_desc *desc)
 {
     if (!desc) { fail("null desc"); return nullptr; }
-    if (desc->N < 1 || desc->N > TUM_N_MAX) { fail("N out of range (1..48)"); return nullptr; }
+    if (desc->N < 1 || desc->N > TUM_N_MAX) { fail("N out of range (1..56)"); return nullptr; }
     if (desc->batch < 1) { fail("batch < 1"); return nullptr; }
     if (desc->nsub < 1 || !(desc->dt > 0)) { fail("bad nsub/dt"); return nullptr; }
     if (desc->n_ggv < 2 || desc->n_ggv > 16) { fail("n_ggv out of range (2..16)"); return nullptr; }
@@ -298,6 +298,7 @@ extern "C" int tum_ocp_snmpc_attach(tum_ocp *c, int ns, int L, const double *Apc
 {
     if (!c || !Apce) return fail("null argument");
     if (c->sn) return fail("snmpc_attach: already attached");
+    if (c->N > 48) return fail("snmpc_attach: the coupled SNMPC OCP is built for horizons up to 48 (N = 49..56: nominal / R2 OCP)");
     if (c->dWf) return fail("snmpc_attach: the capsule holds a full W; the coupled SNMPC OCP takes a diagonal one");
     if (ns < 1 || ns > SN_NSMAX) return fail("snmpc_attach: n_samples out of range (1..16)");
     if (L < 1 || L > SN_LMAX) return fail("snmpc_attach: number of PCE terms out of range (1..16)");
@@ -746,6 +747,7 @@ extern "C" int tum_ocp_cost_set(tum_ocp *c, int stage, const char *field, const 
         // call on the capsule keeps a full symmetric 6 x 6 per stage (its symmetric part: the cost only sees that) beside the diagonal, and the
         // pipeline condenses with the full-W instantiation of the six-wavefront condensing kernel. Nominal / R2 OCP through the pipeline only.
         if (offdiag && !c->dWf) {
+            if (c->N > 48) return fail("cost_set W: horizons beyond 48 take a diagonal W (the full-W condensing kernel's row store does not fit there)");
             if (c->sn) return fail("cost_set W: the coupled SNMPC OCP takes a diagonal W (its cost rows come from the prologue kernel)");
             DevGuard guard(c->d.device); GUARD_OK(guard);
             HIPCHK(hipStreamSynchronize(c->stream));
@@ -786,12 +788,21 @@ extern "C" int tum_ocp_cost_set(tum_ocp *c, int stage, const char *field, const 
     return 0;
 }
 
+// MFMA tiles of condensed variables this capsule's pipeline runs with: five (N <= 40), six (41..48), seven (49..56).
+// (TUM_FORCE_TILES: development aid -- a larger instantiation at a horizon a smaller one covers: the padding variables must not change the answer.)
+static int tiles_of(const tum_ocp *c)
+{
+    static const int force = [] { const char *e = getenv("TUM_FORCE_TILES"); return e ? atoi(e) : 0; }();
+    const int need = c->N > 48 ? 7 : (c->N > NMAX ? 6 : 5);
+    return (force > need && force <= 7 && !c->sn) ? force : need;
+}
 // workspaces of the kernel variants, allocated when a variant is first used
 static int ensure_workspace(tum_ocp *c)
 {
     const size_t B = c->batch;
-    const bool big = c->N > NMAX;          // horizons beyond 40: six MFMA tiles (PD<6>)
-    const size_t ntt = big ? PD<6>::NTT : PD<5>::NTT, nch = big ? PD<6>::NCH : PD<5>::NCH, pvec = big ? PD<6>::PVEC : PD<5>::PVEC;
+    const int nt = tiles_of(c);          // horizons beyond 40: six MFMA tiles (PD<6>), beyond 48: seven (PD<7>)
+    const size_t ntt = nt == 7 ? PD<7>::NTT : nt == 6 ? PD<6>::NTT : PD<5>::NTT, nch = nt == 7 ? PD<7>::NCH : nt == 6 ? PD<6>::NCH : PD<5>::NCH,
+                 pvec = nt == 7 ? PD<7>::PVEC : nt == 6 ? PD<6>::PVEC : PD<5>::PVEC;
     if (c->pipe && !c->dhws) {
         if (dalloc(&c->dhws, B * ntt * 256) != hipSuccess) return fail("workspace allocation failed (H tiles)");
     }
@@ -897,6 +908,7 @@ static bool use_cond_wide(const tum_ocp *c)
 {
     static const int wide_env = [] { const char *e = getenv("TUM_COND_WIDE"); return e ? atoi(e) : -1; }();
     const int want = (c->cond_wide >= 0) ? c->cond_wide : wide_env;
+    if (tiles_of(c) == 7) return false;          // (seven tiles: the six-wavefront kernel's row store does not fit a CU's LDS beside a full W; one wavefront per OCP at every batch size)
     return want > 0 || (want < 0 && c->batch <= 256) || c->dWf != nullptr;          // (a full W exists as an instantiation of this kernel only)
 }
 // The device closed loop (tum_sim_run) can run the linearisation of a solve BESIDE the planner of the same control step: the
@@ -956,6 +968,9 @@ static int launch_pipeline(tum_ocp *c, bool events)
         {
             // six wavefronts per OCP while every OCP can have a CU's LDS to itself (cond_wide_kernel)
             const bool wide = use_cond_wide(c);
+            if constexpr (NTv == 7) {      // N = 49..56: the nominal OCP with a diagonal W, one wavefront per OCP (checked where the capsule is configured)
+                hipLaunchKernelGGL((cond_kernel<NTv, false>), dim3(c->batch), dim3(64), 0, c->stream, pa);
+            } else {
             if (wide && c->sn) hipLaunchKernelGGL((cond_wide_kernel<NTv, true>), dim3(c->batch), dim3(64 * cw_waves<NTv>()), 0, c->stream, pa);
             else if (wide && c->dWf) hipLaunchKernelGGL((cond_wide_kernel<NTv, false, true>), dim3(c->batch), dim3(64 * cw_waves<NTv>()), 0, c->stream, pa);
             else if (wide) hipLaunchKernelGGL((cond_wide_kernel<NTv, false>), dim3(c->batch), dim3(64 * cw_waves<NTv>()), 0, c->stream, pa);
@@ -963,6 +978,7 @@ static int launch_pipeline(tum_ocp *c, bool events)
             else if (c->sn && 2 * c->sa.uph <= c->N) hipLaunchKernelGGL((cond_kernel<NTv, true, true>), dim3(c->batch), dim3(64), 0, c->stream, pa);
             else if (c->sn) hipLaunchKernelGGL((cond_kernel<NTv, true, false>), dim3(c->batch), dim3(64), 0, c->stream, pa);
             else hipLaunchKernelGGL((cond_kernel<NTv, false>), dim3(c->batch), dim3(64), 0, c->stream, pa);
+            }
         }
         if ((events && !c->skip_ipm_events) || c->time_ipm) (void)hipEventRecord(c->evi0, c->stream);
         bool expanded = false;
@@ -977,11 +993,16 @@ static int launch_pipeline(tum_ocp *c, bool events)
             if (prof) hipLaunchKernelGGL((ipm_kernel<true, 5>), dim3(c->batch), dim3(64), ipm_lds, c->stream, pa);
             else if (c->sn || no_fuse) hipLaunchKernelGGL((ipm_kernel<false, 5>), dim3(c->batch), dim3(64), ipm_lds, c->stream, pa);
             else { hipLaunchKernelGGL((ipm_kernel<false, 5, true>), dim3(c->batch), dim3(64), ipm_lds, c->stream, pa); expanded = true; }
+        } else if constexpr (NTv == 7) {      // (seven tiles: the expansion stays a kernel of its own)
+            hipLaunchKernelGGL((ipm_kernel<false, NTv>), dim3(c->batch), dim3(64), ipm_lds, c->stream, pa);
         } else {
             if (c->sn || no_fuse) hipLaunchKernelGGL((ipm_kernel<false, NTv>), dim3(c->batch), dim3(64), ipm_lds, c->stream, pa);
             else { hipLaunchKernelGGL((ipm_kernel<false, NTv, true>), dim3(c->batch), dim3(64), ipm_lds, c->stream, pa); expanded = true; }
         }
         if ((events && !c->skip_ipm_events) || c->time_ipm) (void)hipEventRecord(c->evi1, c->stream);
+        if constexpr (NTv == 7) {
+            hipLaunchKernelGGL((expand_kernel<NTv, false>), dim3(c->batch), dim3(64), 0, c->stream, pa);
+        } else
         if (c->sn) {
             // the epilogue steps the sample copies AND the nominal copy of the stages 1..uph (their PCE mean); the expansion
             // kernel behind it takes the nominal recursion from stage uph to the end of the horizon and evaluates the cost
@@ -992,7 +1013,7 @@ static int launch_pipeline(tum_ocp *c, bool events)
             hipLaunchKernelGGL((expand_kernel<NTv, true>), dim3(c->batch), dim3(64), 0, c->stream, pa);
         } else if (!expanded) hipLaunchKernelGGL((expand_kernel<NTv, false>), dim3(c->batch), dim3(64), 0, c->stream, pa);
     };
-    if (c->N > NMAX) rest(std::integral_constant<int, 6>()); else rest(std::integral_constant<int, 5>());
+    { const int nt = tiles_of(c); if (nt == 7) rest(std::integral_constant<int, 7>()); else if (nt == 6) rest(std::integral_constant<int, 6>()); else rest(std::integral_constant<int, 5>()); }
     return 0;
 }
 
