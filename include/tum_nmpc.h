@@ -29,7 +29,7 @@ extern "C" {
 #define TUM_NYE 4
 #define TUM_N_MAX 56      /* horizon limit of this build: N <= 40 (five 16-wide MFMA tiles of condensed variables) on every kernel
                              variant, 41..48 (six tiles) on the pipeline variant only (nominal and coupled SNMPC OCP), 49..56 (seven
-                             tiles, round 6: Tp = 4.0 s at Ts_MPC = 0.08 s is N = 50) for the nominal / R2 OCP with a diagonal W */
+                             tiles, round 6: Tp = 4.0 s at Ts_MPC = 0.08 s is N = 50) with a diagonal W (nominal, R2 and coupled SNMPC OCP) */
 #define TUM_ALL_STAGES (-1)
 
 /* acados return codes the callers test (NMPC_class.py:183-206, main.py:59-61) */

@@ -361,7 +361,7 @@ def test_seven_tiles_at_a_horizon_six_cover_is_the_same_solve(tmp_path):
 
 
 def test_horizon_caps_are_stated():
-    """N <= 56; the coupled SNMPC OCP and a full W stop at N = 48 and say so"""
+    """N <= 56; a full W stops at N = 48 and the coupled SNMPC OCP's propagation horizon at 48 stages, and they say so"""
     from tum_control_amd.solver import BatchedOcpSolver, CoupledSnmpcSolver
     from tum_control_amd import snmpc as snm
     with pytest.raises(RuntimeError, match="1..56"):
@@ -372,8 +372,9 @@ def test_horizon_caps_are_stated():
     with pytest.raises(Exception, match="beyond 48"):
         s.cost_set(3, "W", W)
     w = snm.hammersley_normal(10, 3)
-    with pytest.raises(Exception, match="up to 48"):
-        CoupledSnmpcSolver(N=50, batch=1, Apce=snm.pce_matrix(w, snm.alpha_generation(3, 2)), uph=5)
+    c = CoupledSnmpcSolver(N=50, batch=1, Apce=snm.pce_matrix(w, snm.alpha_generation(3, 2)), uph=5)          # (the coupled OCP runs to N = 56 too: tests/test_snmpc.py)
+    with pytest.raises(Exception, match="propagation horizon"):
+        CoupledSnmpcSolver(N=56, batch=1, Apce=snm.pce_matrix(w, snm.alpha_generation(3, 2)), uph=49)      # (propagated stages: up to 48)
 
 
 @pytest.mark.parametrize("pattern", ["step", "acados"])

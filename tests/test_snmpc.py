@@ -325,7 +325,7 @@ def test_gpu_coupled_snmpc_vs_oracle(golden_dir, N, uph):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("N,uph", [(38, 5), (38, 15), (40, 5), (38, 0), (12, 12), (44, 5), (48, 12), (40, 24), (40, 33), (38, 38), (48, 48)])
+@pytest.mark.parametrize("N,uph", [(38, 5), (38, 15), (40, 5), (38, 0), (12, 12), (44, 5), (48, 12), (40, 24), (40, 33), (38, 38), (48, 48), (50, 5), (56, 20), (52, 40)])
 def test_gpu_coupled_snmpc_pipeline_vs_oracle(golden_dir, N, uph):
     """the same through the pipeline variant (prologue, lin_kernel<SN>, cond_kernel<., SN>, ipm_kernel, expand_kernel<., SN>,
     epilogue; what batches above 1024 instances run), including horizons beyond 40 (six-tile instantiation) and uncertainty

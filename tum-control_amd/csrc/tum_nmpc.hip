@@ -298,7 +298,6 @@ extern "C" int tum_ocp_snmpc_attach(tum_ocp *c, int ns, int L, const double *Apc
 {
     if (!c || !Apce) return fail("null argument");
     if (c->sn) return fail("snmpc_attach: already attached");
-    if (c->N > 48) return fail("snmpc_attach: the coupled SNMPC OCP is built for horizons up to 48 (N = 49..56: nominal / R2 OCP)");
     if (c->dWf) return fail("snmpc_attach: the capsule holds a full W; the coupled SNMPC OCP takes a diagonal one");
     if (ns < 1 || ns > SN_NSMAX) return fail("snmpc_attach: n_samples out of range (1..16)");
     if (L < 1 || L > SN_LMAX) return fail("snmpc_attach: number of PCE terms out of range (1..16)");
@@ -968,8 +967,10 @@ static int launch_pipeline(tum_ocp *c, bool events)
         {
             // six wavefronts per OCP while every OCP can have a CU's LDS to itself (cond_wide_kernel)
             const bool wide = use_cond_wide(c);
-            if constexpr (NTv == 7) {      // N = 49..56: the nominal OCP with a diagonal W, one wavefront per OCP (checked where the capsule is configured)
-                hipLaunchKernelGGL((cond_kernel<NTv, false>), dim3(c->batch), dim3(64), 0, c->stream, pa);
+            if constexpr (NTv == 7) {      // N = 49..56: a diagonal W, one wavefront per OCP at every batch size
+                if (c->sn && 2 * c->sa.uph <= c->N) hipLaunchKernelGGL((cond_kernel<NTv, true, true>), dim3(c->batch), dim3(64), 0, c->stream, pa);
+                else if (c->sn) hipLaunchKernelGGL((cond_kernel<NTv, true, false>), dim3(c->batch), dim3(64), 0, c->stream, pa);
+                else hipLaunchKernelGGL((cond_kernel<NTv, false>), dim3(c->batch), dim3(64), 0, c->stream, pa);
             } else {
             if (wide && c->sn) hipLaunchKernelGGL((cond_wide_kernel<NTv, true>), dim3(c->batch), dim3(64 * cw_waves<NTv>()), 0, c->stream, pa);
             else if (wide && c->dWf) hipLaunchKernelGGL((cond_wide_kernel<NTv, false, true>), dim3(c->batch), dim3(64 * cw_waves<NTv>()), 0, c->stream, pa);
@@ -1000,9 +1001,6 @@ static int launch_pipeline(tum_ocp *c, bool events)
             else { hipLaunchKernelGGL((ipm_kernel<false, NTv, true>), dim3(c->batch), dim3(64), ipm_lds, c->stream, pa); expanded = true; }
         }
         if ((events && !c->skip_ipm_events) || c->time_ipm) (void)hipEventRecord(c->evi1, c->stream);
-        if constexpr (NTv == 7) {
-            hipLaunchKernelGGL((expand_kernel<NTv, false>), dim3(c->batch), dim3(64), 0, c->stream, pa);
-        } else
         if (c->sn) {
             // the epilogue steps the sample copies AND the nominal copy of the stages 1..uph (their PCE mean); the expansion
             // kernel behind it takes the nominal recursion from stage uph to the end of the horizon and evaluates the cost
