@@ -354,6 +354,35 @@ def test_bench_self_launched_world_size_1_rccl():
     assert out["value"] > 1e6
 
 
+def test_bench_line_carries_the_other_configurations():
+    """the default N = 1 line of bench.py carries a bounded leg for each of the other BASELINE configurations and for the coupled SNMPC OCP
+    (`other_configs`: what the driver times next to the headline): all five present, every instance solved, rates in the range the
+    separate runs of the same configurations give (profiles/r06_configs.jsonl, r06_snmpc_bench.txt)"""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "BENCH_SELF_LAUNCH", "BENCH_SELF_LAUNCHED"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--steps", "4", "--warmup", "2", "--no-cpu-baseline", "--no-schedule-legs", "--no-host-legs"]
+    r = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{") and '"metric"' in ln][0])
+    oc = out["other_configs"]
+    assert sorted(oc) == ["3", "4", "5", "snmpc_uph38", "snmpc_uph5"]
+    for cid, batch in (("3", 16384), ("4", 16384), ("5", 4096)):
+        leg = oc[cid]
+        assert "error" not in leg, leg
+        assert leg["batch"] == batch and leg["status_ok_frac"] == 1.0 and leg["value"] > 2e6 and 0.2 < leg["roofline"]["frac"] < 0.6, leg
+    for key, lo in (("snmpc_uph5", 2.5e6), ("snmpc_uph38", 1.2e6)):
+        leg = oc[key]
+        assert "error" not in leg, leg
+        assert leg["single_capsule"]["status_ok_frac"] == 1.0 and leg["three_capsules"]["status_ok_frac"] == 1.0
+        assert leg["single_capsule"]["value"] > lo and leg["value"] >= 0.95 * leg["single_capsule"]["value"], leg
+    assert out["launch"] == "single process" and len(out["per_rank"]["value"]) == 1
+
+
 def test_results_on_the_host_through_pinned_slabs():
     """tum_ocp_results_async / _wait: the summary (u0, cost, status, qp_iter) and the whole iterate of a batch arrive in the
     capsule's pinned host slabs behind an event, equal to what the synchronous getters return; three capsules in a ring with
