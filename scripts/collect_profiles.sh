@@ -42,5 +42,8 @@ for L in exp_libs/lib_*.so; do [ -f "$L" ] && $T python scripts/dev/ab2.py $L sh
 # the rooted gather with the whole iterate (world size 1 under torch.distributed.run: RCCL initialised, the 53 MB slab gathered inside the timed region)
 for G in "" "--gather-iterate"; do $T python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29533 bench.py --gpus 1 --config 4 --scaling strong --global-batch 16384 --steps 10 --warmup 2 --no-cpu-baseline --no-schedule-legs $G 2>/dev/null < /dev/null | grep metric | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('config 4, world size 1 under torchrun (nccl = RCCL), gather_iterate', d['config']['gather_iterate'], ': gather %.0f B per rank, value %.3f M solves/s, ms/step %.3f (solve %.3f, gather %.3f)' % (d['config']['gather_bytes_per_rank'], d['value']/1e6, d['ms_per_step'], d['solve_ms_per_step'], d['gather_ms_per_step']))" >> $OUT/gather_iterate.txt; done
 for f in 0 1; do echo "TUM_FUSED_EXPAND=$f" >> $OUT/fused_expand.txt; TUM_FUSED_EXPAND=$f $T python scripts/probes/solve_wall_time.py 2>&1 < /dev/null | grep pipeline >> $OUT/fused_expand.txt; TUM_FUSED_EXPAND=$f $T python bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-schedule-legs --no-host-legs --no-other-configs 2>/dev/null < /dev/null | grep metric | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('  config 2, three streams: value %.3f M solves/s'%(d['value']/1e6))" >> $OUT/fused_expand.txt; done
+# round 6: horizons beyond 40 (six / seven tiles) and a full W against the diagonal one, 4096 instances each
+$T python scripts/dev/n56_time.py 2>&1 < /dev/null | grep "^N " > $OUT/long_horizons.txt
+$T python scripts/dev/fullw_time.py 2>&1 < /dev/null | grep "W 4096" > $OUT/full_w.txt
 $T python scripts/dev/ipm4_prof.py 4096 2>&1 < /dev/null | grep -v amdgpu.ids > $OUT/ipm4_phases.txt
 head -8 $OUT/stats/s_kernel_stats.csv | cut -c1-150; cut -c1-300 $OUT/bench.json
