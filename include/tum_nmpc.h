@@ -254,7 +254,10 @@ int tum_pce_moments_device(tum_ocp *c, const char *field, int stage, double *mea
  * Afterwards set/get "x" and constraints_set "lbx"/"ubx" at stage 0 also accept 8 (ns+1) values, cold_start copies the
  * stacked x0 to every stage (SNMPC_class.py:126-127), and solve runs prologue + fused kernel + epilogue. The cost acts
  * on the nominal copy with |v| as the speed row; the gg limits are looked up at |v|. 0 <= uph <= N (the reference ran
- * uph = N; beyond 31 stages the sample columns no longer fit one wavefront: pipeline kernels only). */
+ * uph = N; beyond 31 stages the sample columns no longer fit one wavefront: pipeline kernels only). 1 <= ns <= 32 and
+ * 1 <= L <= 32 (MPC_params.yaml's n_samples / expansion_degree, SNMPC_class.py:78-94; beyond 16 of either: pipeline kernels
+ * only, and ns x uph bounded by the prologue's 128 KiB of LDS -- uph <= 28 / 26 / 18 / 16 at 17 / 20 / 24 / 32 samples --
+ * otherwise refused here). */
 int tum_ocp_snmpc_attach(tum_ocp *c, int ns, int L, const double *Apce, int uph, double gamma);
 int tum_ocp_snmpc_samples(const tum_ocp *c);   /* ns, or 0 for a nominal capsule */
 /* Offsets of the sample initial conditions from the nominal one (compute_x0dist, Stochastic_NMPC/stochastic_mpc_utils.py:78-91;

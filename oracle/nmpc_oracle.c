@@ -989,8 +989,8 @@ void oracle_solve_batch_cold_forced(const oracle_ocp *tmpl, int nb, const double
  *  - the solve against the golden-pinned nominal restatement above (stop_flag = 1 everywhere), and its rows against finite
  *    differences of an independent rollout.
  */
-#define NSMAX 16                 /* max samples */
-#define NLMAX 16                 /* max PCE terms */
+#define NSMAX 32                 /* max samples */
+#define NLMAX 32                 /* max PCE terms */
 #define NXS   (NX * (NSMAX + 1))
 
 typedef struct {

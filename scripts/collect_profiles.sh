@@ -45,5 +45,6 @@ for f in 0 1; do echo "TUM_FUSED_EXPAND=$f" >> $OUT/fused_expand.txt; TUM_FUSED_
 # round 6: horizons beyond 40 (six / seven tiles) and a full W against the diagonal one, 4096 instances each
 $T python scripts/dev/n56_time.py 2>&1 < /dev/null | grep "^N " > $OUT/long_horizons.txt
 $T python scripts/dev/fullw_time.py 2>&1 < /dev/null | grep "W 4096" > $OUT/full_w.txt
+$T python scripts/dev/sn_samples_time.py 2>&1 < /dev/null | grep "^samples" > $OUT/snmpc_sample_counts.txt
 $T python scripts/dev/ipm4_prof.py 4096 2>&1 < /dev/null | grep -v amdgpu.ids > $OUT/ipm4_phases.txt
 head -8 $OUT/stats/s_kernel_stats.csv | cut -c1-150; cut -c1-300 $OUT/bench.json

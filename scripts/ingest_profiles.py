@@ -12,7 +12,7 @@ for d, n in (("sn38", "snmpc_uph38_kernel_stats.csv"), ("sn05", "snmpc_uph5_kern
     if os.path.exists(f"{src}/{d}/s_kernel_stats.csv"):
         shutil.copy(f"{src}/{d}/s_kernel_stats.csv", f"{dst}/{tag}_{n}")
 for f in ("ab_round3_instruction_work.txt", "fused_expand.txt", "snmpc_prologue_variants.txt", "phase_cycles.txt", "configs.jsonl", "kernel_variants.txt", "ipm_occupancy.txt", "snmpc_bench.txt", "pcie.txt", "streams.txt",
-          "closed_loops.txt", "long_horizons.txt", "full_w.txt", "ipm4_phases.txt", "small_batch_variants.txt", "controller_step.txt", "gather_iterate.txt", "ab_saved_builds.txt"):
+          "closed_loops.txt", "long_horizons.txt", "full_w.txt", "snmpc_sample_counts.txt", "ipm4_phases.txt", "small_batch_variants.txt", "controller_step.txt", "gather_iterate.txt", "ab_saved_builds.txt"):
     if os.path.exists(f"{src}/{f}"):
         shutil.copy(f"{src}/{f}", f"{dst}/{tag}_{f}")
 KERNELS = ("lin_kernel", "cond_kernel", "ipm_kernel", "expand_kernel", "nmpc_rti_kernel")

@@ -466,6 +466,50 @@ def test_gpu_coupled_snmpc_other_sample_counts(golden_dir, ns, L, N, uph, prolog
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("ns,L,N,uph", [(10, 10, 38, 5), (15, 10, 20, 6), (17, 17, 40, 3), (20, 20, 38, 5), (24, 10, 20, 8), (32, 32, 12, 6), (12, 20, 38, 5), (20, 20, 50, 4), (24, 20, 38, 18), (32, 20, 40, 16),
+                                        (17, 5, 44, 28)])
+def test_gpu_coupled_snmpc_more_than_sixteen_samples(golden_dir, ns, L, N, uph):
+    """n_samples and the number of PCE terms up to 32 (round 6; 16 before: MPC_params.yaml's n_samples / expansion_degree are free parameters of the
+    reference, SNMPC_class.py:78-94 -- degree 3 in three variables is 20 terms). Beyond 16 of either the capsule runs the column-slot prologue with its
+    column state in LDS and the epilogue in their 32-wide instantiations; everything up to 16 runs the kernels of rounds 1-5 unchanged. One solve from a
+    perturbed iterate against the oracle: inputs, nominal copy and the stacked sample copies of a few stages."""
+    from tum_control_amd.solver import CoupledSnmpcSolver
+    from tum_control_amd import config
+    x0, yref, p = _kat(golden_dir)
+    x0 = x0.copy(); x0[7] = -0.6; x0[5] = 0.1; x0[4] = -0.2
+    rng = np.random.default_rng(100 + ns + L)
+    A = rng.normal(0, 0.3 / np.sqrt(ns / 10.0), (L, ns)); A[0] = np.abs(A[0]) + 0.1; A[0] /= A[0].sum()
+    xs = np.tile(x0, (ns + 1, 1)); xs[1:, 3:6] += rng.normal(0, 1, (ns, 3)) * np.array([.8, .35, .035])
+    U = np.stack([rng.normal(0, 1.0, N), rng.normal(0, 0.05, N)], axis=1)
+    X, _ = _rollout(xs, U, A, uph, N, 0.08, 0.5)
+    X += rng.normal(0, 1e-3, X.shape)
+    Y = np.zeros((N + 1, 6)); Y[:min(N, 38) + 1, :4] = yref[:min(N, 38) + 1]
+    for k in range(39, N + 1):
+        Y[k, :4] = 2 * Y[k - 1, :4] - Y[k - 2, :4]
+    m = config.MPC
+    o = orc.OracleSnmpcOcp(N=N, dt=0.08, Apce=A, uph=uph)
+    o.set_weights(m["q_lon"], m["q_yaw"], m["q_vel"], m["r_jerk"], m["r_steering_rate"], m["L1_pen"], m["L2_pen"], scale=0.01)
+    o.yref[:] = Y; o.x0[:] = xs; o.X[:] = X; o.U[:] = U
+    s = CoupledSnmpcSolver(N=N, dt=0.08, batch=1, Apce=A, uph=uph, gamma=0.8)
+    s.install_reference_ocp()
+    s.constraints_set(0, "lbx", xs.flatten()); s.constraints_set(0, "ubx", xs.flatten())
+    s.set_yref_all(Y)
+    for k in range(N + 1):
+        s.set(k, "x", X[k].flatten())
+    s.set_iterate(U=U)
+    assert s.solve() == 0 and o.solve() == 0
+    Xn, Un = s.get_iterate()
+    np.testing.assert_allclose(Un.reshape(N, 2), o.U, rtol=1e-6, atol=1e-7)
+    for k in (0, 1, uph, N):
+        np.testing.assert_allclose(np.asarray(s.get(k, "x")).reshape(ns + 1, 8), o.X[k], rtol=1e-6, atol=1e-7, err_msg=f"stage {k}")
+    assert abs(float(np.atleast_1d(s.get_cost())[0]) - o.cost) < 1e-7 * max(1.0, abs(o.cost))
+    with pytest.raises(Exception, match="1..32"):
+        CoupledSnmpcSolver(N=10, batch=1, Apce=np.zeros((3, 33)), uph=2)
+    with pytest.raises(Exception, match="too large for the prologue kernel's LDS"):      # (128 KiB of column state: uph <= 28 / 26 / 18 / 16 at 17 / 20 / 24 / 32 samples)
+        CoupledSnmpcSolver(N=40, batch=1, Apce=np.zeros((10, 24)), uph=19)
+
+
+@pytest.mark.gpu
 def test_gpu_snmpc_frozen_sample_copies_are_deferred_not_lost():
     """The epilogue does not write the sample copies of the stages > uph (they equal stage uph, pred_model_dynamic_disc.py:203);
     they are brought up to date when asked for. Two solves without a read in between, then reads / a write beyond uph."""
@@ -601,6 +645,49 @@ def test_gpu_snmpc_closed_loop(golden_dir):
 
 
 @pytest.mark.gpu
+def test_gpu_snmpc_closed_loop_degree_three_expansion(golden_dir):
+    """MPC_params.yaml's n_samples / expansion_degree beyond the shipped 10 / 2 (SNMPC_class.py:78-94: free parameters of the reference): 24 Hammersley
+    samples and the degree-3 expansion in the three uncertain states (20 PCE terms), which the 32-wide instantiations of the prologue and the epilogue
+    run (round 6). The closed loop around the GPU solver against the same loop around the oracle, and the on-device loop against the host loop."""
+    import copy
+    from tum_control_amd.closed_loop import ClosedLoopBatch, plant_step, MovingAverageEstimator
+    from tum_control_amd.planner import planner_emulator, yref_from_ref
+    from tum_control_amd import config, snmpc as snm
+    cfg = copy.deepcopy(config.default_config())
+    cfg["mpc"]["n_samples"], cfg["mpc"]["expansion_degree"], cfg["mpc"]["uncertainty_propagation_horizon"] = 24, 3, 7
+    stds = np.asarray(cfg["mpc"]["stds"], dtype=float)
+    w = snm.hammersley_normal(24, 3)
+    A = snm.pce_matrix(w, snm.alpha_generation(3, 3))
+    assert A.shape == (20, 24)
+    steps, N, Tp = 24, 38, 3.04
+    cl = ClosedLoopBatch("monteblanco", batch=1, N=N, Tp=Tp, controller="snmpc", cfg=cfg)
+    lg = cl.run(steps)
+    m = cfg["mpc"]
+    o = orc.OracleSnmpcOcp(N=N, dt=Tp / N, Apce=A, uph=7)
+    o.set_weights(m["q_lon"], m["q_yaw"], m["q_vel"], m["r_jerk"], m["r_steering_rate"], m["L1_pen"], m["L2_pen"], scale=0.01)
+    x_mpc = lg["MPC_SimX"][0][0].copy(); x_sim = x_mpc[:7].copy()[None]; pose = x_mpc[:2].copy()
+    o.cold_start(snm.compute_x0dist(x_mpc, w, stds))
+    est = MovingAverageEstimator(1)
+    for t in range(steps):
+        _, ref = planner_emulator(cl.track, pose, N + 1, Tp, True)
+        o.yref[:] = yref_from_ref(ref, N)
+        assert o.solve() == 0
+        u0, x1 = o.U[0].copy(), o.X[1, 0].copy()
+        np.testing.assert_allclose(lg["simU"][t][0], u0, rtol=1e-6, atol=1e-7, err_msg=f"step {t}")
+        x_sim = plant_step(x_sim, np.array([x1[7]]), np.array([u0[1]]), cfg, 0.02)
+        pose = x_sim[0, :2].copy()
+        x_mpc = est(np.concatenate([x_sim, [[x1[7]]]], axis=1))[0]
+        o.set_initial_state(snm.compute_x0dist(x_mpc, w, stds))
+    np.testing.assert_allclose(lg["CiLX"][-1][0], x_sim[0], rtol=1e-7, atol=1e-7)
+    assert (lg["simSolverDebug"][:, 0, 4] == 0).all()
+    cd = ClosedLoopBatch("monteblanco", batch=3, N=N, Tp=Tp, controller="snmpc", cfg=cfg, on_device=True, log_capacity=steps)
+    ld = cd.run(steps)
+    for b in range(3):
+        np.testing.assert_allclose(ld["simU"][:, b], lg["simU"][:, 0], rtol=1e-7, atol=1e-8)
+        np.testing.assert_allclose(ld["CiLX"][:, b], lg["CiLX"][:, 0], rtol=1e-9, atol=1e-9)
+
+
+@pytest.mark.gpu
 def test_gpu_snmpc_errors():
     """acados-style failures of the coupled solver: wrong dimensions and unsupported configurations raise, nothing is silent"""
     from tum_control_amd.solver import CoupledSnmpcSolver, BatchedOcpSolver, _dp
@@ -614,7 +701,7 @@ def test_gpu_snmpc_errors():
     with pytest.raises(Exception, match="fused"):
         f.solve()
     with pytest.raises(Exception, match="n_samples"):
-        CoupledSnmpcSolver(N=10, batch=1, Apce=np.zeros((3, 17)), uph=2)
+        CoupledSnmpcSolver(N=10, batch=1, Apce=np.zeros((3, 33)), uph=2)
     n = BatchedOcpSolver(N=10, nsub=3, batch=1)
     assert n._L.tum_ocp_snmpc_attach(n._h, 10, 10, _dp(A), 5, 0.8) != 0 and "nsub = 1" in n._err()
     s = CoupledSnmpcSolver(N=10, batch=2, Apce=A, uph=3)

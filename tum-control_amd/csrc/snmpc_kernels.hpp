@@ -29,8 +29,12 @@
 
 namespace tum {
 
-constexpr int SN_NSMAX = 16;                 // max samples
-constexpr int SN_LMAX = 16;                  // max PCE terms
+constexpr int SN_NSMAX = 32;                 // max samples
+constexpr int SN_LMAX = 32;                  // max PCE terms
+// Compile-time bound of the short sums over samples / PCE terms and of the LDS tables sized by them: 16 wherever n_samples and the number of PCE
+// terms are at most 16 (the shipped 10 x 10 and everything rounds 1-5 covered: unchanged kernels), 32 beyond (round 6: the column-slot prologue with its
+// column state in LDS and the epilogue have a second instantiation; the matrix-core prologue takes at most ten samples anyway)
+constexpr int SN_B16 = 16;
 constexpr int SN_UPHMAX = 48;                // up to the whole horizon (the reference ran UPH = Tp, SNMPC_class.py:103-104)
 constexpr int SN_UPHMAX_FUSED = 31;          // the fused kernel reads `pro` with a fixed pitch of 64 columns
 // `pro` holds, per stage s <= uph, nine rows (8 rows of G_nom,s | the chance-constraint row) of 2 uph + 1 columns (the sample
@@ -84,17 +88,18 @@ __device__ __forceinline__ void h_con_vabs(const Model &p, double vl, double vt,
 // stage; the column state of P3 (8 doubles per lane and pass); A_pce and the PCE coefficients per stage
 __host__ __device__ inline int sn_prologue_passes(int uph, int ns) { const int cs = 64 / ns; return (2 * uph + 1 + cs - 1) / cs; }
 // (NPM = 0: the column state of P3 waits in LDS between the stages -- 4 KiB per pass; NPM > 0: it lives in registers, see below)
-__host__ __device__ inline int sn_prologue_lds_doubles(int uph, int ns, int npm = 0)
+__host__ __device__ inline int sn_prologue_lds_doubles(int uph, int ns, int npm = 0, int nsb = SN_B16)
 {
     // (NPM > 0: reduction rows of pitch 128 whose upper halves stay zero: the sum over the samples reads 16 cells of a row without a mask)
     return (npm > 0 ? 2 : 6) * uph * ns + (uph + 1) + ns * ABS + (npm > 0 ? 9 * 130 : 9 * 64) + uph * 8 + (npm > 0 ? 0 : sn_prologue_passes(uph, ns) * 8 * 64) +
-           SN_LMAX * SN_NSMAX + uph * SN_LMAX;
+           nsb * nsb + uph * nsb;
 }
 // register-resident variants of the prologue: the number of passes NPM a lane's column state is held for (8 doubles each).
 // Chosen on the host: the smallest instantiation that covers the passes of the last stage; 0 (column state in LDS) for short
 // propagation horizons, where the LDS variant's five wavefronts per SIMD win, and beyond the largest instantiation.
 __host__ inline int sn_prologue_variant(int uph, int ns)
 {
+    if (ns > SN_B16) return 0;          // (more than 16 samples: the LDS variant, instantiated with the 32-wide bounds)
     const int np = sn_prologue_passes(uph, ns);
     static const int forced = [] { const char *e = getenv("TUM_SN_PROLOGUE"); return e ? atoi(e) : -1; }();     // development aid
     if (forced == 0 || ((forced == 6 || forced == 9 || forced == 13 || forced == 17) && np <= forced && ns >= 8)) return forced;
@@ -210,9 +215,10 @@ __global__ void __launch_bounds__(64, 1) snmpc_lin_cols_kernel(const SnArgs sa)
         if ((int)threadIdx.x < 52) dst[(size_t)it * ABS + threadIdx.x] = sT[it * ABS + threadIdx.x];
 }
 
-template <int NPM>
+template <int NPM, int NSB = SN_B16>
 __global__ void __launch_bounds__(64) snmpc_prologue_kernel(const SnArgs sa)
 {
+    static_assert(NSB == SN_B16 || (NSB == SN_NSMAX && NPM == 0), "32-wide bounds exist for the LDS variant only");
     extern __shared__ __attribute__((aligned(16))) double sn_lds[];
     const int lane = threadIdx.x, b = blockIdx.x;
     if (b >= sa.batch) return;
@@ -223,7 +229,7 @@ __global__ void __launch_bounds__(64) snmpc_prologue_kernel(const SnArgs sa)
     double *sH = sn_lds, *sGh = sH + nitem, *sCoef = sGh + (NPM > 0 ? 0 : 4 * nitem), *sHval = sCoef + nitem;
     constexpr int RP = (NPM > 0) ? 130 : 64;          // pitch of a reduction row (130: 128 cells, and the nine rows a reducing instruction reads do not start in the same bank)
     double *sRec = sHval + (uph + 1), *sRed = sRec + ns * ABS, *sDef = sRed + 9 * RP, *sW = sDef + uph * 8;
-    double *sA = sW + (NPM > 0 ? 0 : sn_prologue_passes(uph, ns) * 8 * 64), *sC = sA + SN_LMAX * SN_NSMAX;
+    double *sA = sW + (NPM > 0 ? 0 : sn_prologue_passes(uph, ns) * 8 * 64), *sC = sA + NSB * NSB;
     const double dt = sa.dt;
     const double *gX = sa.X + (size_t)b * (N + 1) * NX;
     const double *gXS = sa.XS + (size_t)b * (N + 1) * ns * NX;
@@ -256,7 +262,7 @@ __global__ void __launch_bounds__(64) snmpc_prologue_kernel(const SnArgs sa)
         const int k = o / L, l = o - k * L;
         double cl = 0.0;
 #pragma unroll
-        for (int j = 0; j < SN_NSMAX; j++) cl += (j < ns) ? sA[l * ns + j] * sH[k * ns + j] : 0.0;
+        for (int j = 0; j < NSB; j++) cl += (j < ns) ? sA[l * ns + j] * sH[k * ns + j] : 0.0;
         sC[o] = cl;
     }
     __syncthreads();
@@ -266,7 +272,7 @@ __global__ void __launch_bounds__(64) snmpc_prologue_kernel(const SnArgs sa)
         if (k >= 1) {
             double var = 0.0, acc = 0.0;
 #pragma unroll
-            for (int l = 1; l < SN_LMAX; l++) {
+            for (int l = 1; l < NSB; l++) {
                 const double cl = (l < L) ? sC[k * L + l] : 0.0;
                 var += cl * cl; acc += (l < L) ? cl * sA[l * ns + i] : 0.0;
             }
@@ -282,7 +288,7 @@ __global__ void __launch_bounds__(64) snmpc_prologue_kernel(const SnArgs sa)
         const int s = (o >> 3) + 1, r = o & 7;
         double acc = -gX[s * NX + r];
 #pragma unroll
-        for (int ii = 0; ii < SN_NSMAX; ii++) acc += (ii < ns) ? sA[ii] * gXS[((size_t)s * ns + ii) * NX + r] : 0.0;
+        for (int ii = 0; ii < NSB; ii++) acc += (ii < ns) ? sA[ii] * gXS[((size_t)s * ns + ii) * NX + r] : 0.0;
         sDef[o] = acc;
     }
 
@@ -299,7 +305,7 @@ __global__ void __launch_bounds__(64) snmpc_prologue_kernel(const SnArgs sa)
     const bool act = si < ns;
     const int i = act ? si : 0;
     const int nrec = ns * ABS;
-    constexpr int NCH = (SN_NSMAX * ABS + 63) / 64;
+    constexpr int NCH = (NSB * ABS + 63) / 64;
     const double ai = sA[i];
     const int npass = sn_prologue_passes(uph, ns);
     // NPM > 0: the column state of this lane's slot in every pass stays in registers (8 NPM doubles) and the record of the lane's
@@ -393,7 +399,7 @@ __global__ void __launch_bounds__(64) snmpc_prologue_kernel(const SnArgs sa)
                         const double *rp = sRed + row * RP + cc;
                         double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
 #pragma unroll
-                        for (int ii = 0; ii < SN_NSMAX; ii += 4) { a0 += rp[ii * CS]; a1 += rp[(ii + 1) * CS]; a2 += rp[(ii + 2) * CS]; a3 += rp[(ii + 3) * CS]; }
+                        for (int ii = 0; ii < SN_B16; ii += 4) { a0 += rp[ii * CS]; a1 += rp[(ii + 1) * CS]; a2 += rp[(ii + 2) * CS]; a3 += rp[(ii + 3) * CS]; }
                         const double acc = (a0 + a1) + (a2 + a3);
                         const int qo = pass * CS + cc;
                         if (qo <= 2 * uph) {
@@ -472,7 +478,7 @@ __global__ void __launch_bounds__(64) snmpc_prologue_kernel(const SnArgs sa)
 constexpr int SN_MREC = 56;                  // LDS image of a record: ABS doubles | 0.0 | 1.0 | dt
 __host__ __device__ inline int sn_mfma_lds_doubles(int uph, int ns)
 {
-    return 2 * uph * ns + (uph + 1) + uph * 8 + SN_LMAX * SN_NSMAX + uph * SN_LMAX + 2 * ns * SN_MREC + 2 * ns * 5 + 12 * 64;
+    return 2 * uph * ns + (uph + 1) + uph * 8 + SN_B16 * SN_B16 + uph * SN_B16 + 2 * ns * SN_MREC + 2 * ns * 5 + 12 * 64;
 }
 // NWV wavefronts per OCP, NSW samples per wavefront (NWV x NSW >= n_samples). (A variant without the per-sample guards for the
 // reference's ten samples was built in round 5: 30 % fewer vector instructions in the stage loops, and 31 registers spilled around
@@ -488,7 +494,7 @@ __global__ void __launch_bounds__(64 * NWV, 2) snmpc_prologue_mfma_kernel(const 
     const int N = sa.N, ns = sa.ns, L = sa.L, uph = sa.uph;
     const int nitem = uph * ns;
     double *sH = sn_lds, *sCoef = sH + nitem, *sHval = sCoef + nitem, *sDef = sHval + (uph + 1), *sA = sDef + uph * 8;
-    double *sC = sA + SN_LMAX * SN_NSMAX, *sRec = sC + uph * SN_LMAX, *sG4 = sRec + 2 * ns * SN_MREC, *sX = sG4 + 2 * ns * 5;
+    double *sC = sA + SN_B16 * SN_B16, *sRec = sC + uph * SN_B16, *sG4 = sRec + 2 * ns * SN_MREC, *sX = sG4 + 2 * ns * 5;
     const double dt = sa.dt;
     const double *gX = sa.X + (size_t)b * (N + 1) * NX;
     const double *gXS = sa.XS + (size_t)b * (N + 1) * ns * NX;
@@ -511,7 +517,7 @@ __global__ void __launch_bounds__(64 * NWV, 2) snmpc_prologue_mfma_kernel(const 
         const int k = o / L, l = o - k * L;
         double cl = 0.0;
 #pragma unroll
-        for (int j = 0; j < SN_NSMAX; j++) cl += (j < ns) ? sA[l * ns + j] * sH[k * ns + j] : 0.0;
+        for (int j = 0; j < SN_B16; j++) cl += (j < ns) ? sA[l * ns + j] * sH[k * ns + j] : 0.0;
         sC[o] = cl;
     }
     __syncthreads();
@@ -521,7 +527,7 @@ __global__ void __launch_bounds__(64 * NWV, 2) snmpc_prologue_mfma_kernel(const 
         if (k >= 1) {
             double var = 0.0, acc = 0.0;
 #pragma unroll
-            for (int l = 1; l < SN_LMAX; l++) {
+            for (int l = 1; l < SN_B16; l++) {
                 const double cl = (l < L) ? sC[k * L + l] : 0.0;
                 var += cl * cl; acc += (l < L) ? cl * sA[l * ns + i] : 0.0;
             }
@@ -535,7 +541,7 @@ __global__ void __launch_bounds__(64 * NWV, 2) snmpc_prologue_mfma_kernel(const 
         const int s = (o >> 3) + 1, r = o & 7;
         double acc = -gX[s * NX + r];
 #pragma unroll
-        for (int ii = 0; ii < SN_NSMAX; ii++) acc += (ii < ns) ? sA[ii] * gXS[((size_t)s * ns + ii) * NX + r] : 0.0;
+        for (int ii = 0; ii < SN_B16; ii++) acc += (ii < ns) ? sA[ii] * gXS[((size_t)s * ns + ii) * NX + r] : 0.0;
         sDef[o] = acc;
     }
 
@@ -719,11 +725,12 @@ __global__ void __launch_bounds__(64 * NWV, 2) snmpc_prologue_mfma_kernel(const 
 // X_nom,s + dx_nom,s = sum_i a_i (X^(i)_s + dx^(i)_s) -- a 16-lane sum of what the lanes have just computed. Round 3's expansion
 // kernel formed the same step as G_nom,s dU + g_nom,s from the prologue's matrices: 2 s products per row and stage on eight
 // lanes and 200 KB of hand-over buffer read again per instance at UPH = Tp (0.21 ms per 4096 instances, now gone).
+template <int NSB = SN_B16>
 __global__ void __launch_bounds__(64) snmpc_epilogue_kernel(const SnArgs sa)
 {
     // the ns records of a stage are contiguous in ws2: all 64 lanes fetch them (coalesced, one stage ahead) and the sample
     // lanes read theirs from LDS -- a lane reading its own 424-byte record field by field touches ns sectors per load
-    __shared__ double sRec[SN_NSMAX * ABS];
+    __shared__ double sRec[NSB * ABS];
     const int lane = threadIdx.x, b = blockIdx.x;
     if (b >= sa.batch || sa.status[b] != 0) return;
     const int N = sa.N, ns = sa.ns, uph = sa.uph;
@@ -736,7 +743,7 @@ __global__ void __launch_bounds__(64) snmpc_epilogue_kernel(const SnArgs sa)
     const double *ws2 = sa.ws2 + (size_t)b * uph * ns * ABS;
     const double *dv = sa.dv + (size_t)b * sa.dv_stride;
     const int nrec = ns * ABS;
-    constexpr int NCH = (SN_NSMAX * ABS + 63) / 64;
+    constexpr int NCH = (NSB * ABS + 63) / 64;
     double pre[NCH];
 #pragma unroll
     for (int c = 0; c < NCH; c++) { const int idx = lane + 64 * c; pre[c] = (uph > 0 && idx < nrec) ? ws2[idx] : 0.0; }
@@ -781,12 +788,14 @@ __global__ void __launch_bounds__(64) snmpc_epilogue_kernel(const SnArgs sa)
             for (int r = 0; r < 8; r++) xq[r] = xn[r];
         }
         if (gXn) {
-            // PCE mean of the new sample copies: sum over the (at most 16) sample lanes of DPP row 0, total on lane 15
+            // PCE mean of the new sample copies: sum over the sample lanes of DPP row 0, total on lane 15 (more than 16 samples: row 1's total, on
+            // lane 31, joins it)
             double m[8];
 #pragma unroll
             for (int r = 0; r < 8; r++) {
                 double v = ai * xn[r];
                 v += row_shr<1>(v); v += row_shr<2>(v); v += row_shr<4>(v); v += row_shr<8>(v);
+                if constexpr (NSB > 16) v += rl(v, 31);
                 m[r] = v;
             }
             if (lane == 15) {

@@ -285,10 +285,13 @@ extern "C" void tum_ocp_free(tum_ocp *c)
 }
 
 // dynamic LDS (doubles) of the prologue kernel that `want` (a capsule's choice, < 0: the library's) selects for (uph, ns)
-static size_t sn_prologue_lds(int uph, int ns, int want)
+// (nsb: the compile-time bound of the kernels' sample / PCE-term sums: 16, or 32 where either count exceeds 16)
+static int sn_nsb(int ns, int L) { return (ns > SN_B16 || L > SN_B16) ? SN_NSMAX : SN_B16; }
+static size_t sn_prologue_lds(int uph, int ns, int want, int nsb = SN_B16)
 {
     const int kind = sn_prologue_kind(uph, ns, want);
-    return kind == 2 ? sn_mfma_lds_doubles(uph, ns) : sn_prologue_lds_doubles(uph, ns, sn_prologue_variant(uph, ns));
+    if (kind == 2 && nsb == SN_B16) return sn_mfma_lds_doubles(uph, ns);
+    return sn_prologue_lds_doubles(uph, ns, nsb == SN_B16 ? sn_prologue_variant(uph, ns) : 0, nsb);
 }
 
 // Turn the capsule into the coupled SNMPC OCP: the stacked state is the nominal copy followed by `ns`
@@ -299,18 +302,19 @@ extern "C" int tum_ocp_snmpc_attach(tum_ocp *c, int ns, int L, const double *Apc
     if (!c || !Apce) return fail("null argument");
     if (c->sn) return fail("snmpc_attach: already attached");
     if (c->dWf) return fail("snmpc_attach: the capsule holds a full W; the coupled SNMPC OCP takes a diagonal one");
-    if (ns < 1 || ns > SN_NSMAX) return fail("snmpc_attach: n_samples out of range (1..16)");
-    if (L < 1 || L > SN_LMAX) return fail("snmpc_attach: number of PCE terms out of range (1..16)");
+    if (ns < 1 || ns > SN_NSMAX) return fail("snmpc_attach: n_samples out of range (1..32)");
+    if (L < 1 || L > SN_LMAX) return fail("snmpc_attach: number of PCE terms out of range (1..32)");
     if (uph < 0 || uph > c->N || uph > SN_UPHMAX) return fail("snmpc_attach: uncertainty propagation horizon out of range (0..N)");
     if (!(gamma > 0.0 && gamma <= 1.0)) return fail("snmpc_attach: gamma out of range (0,1]");
     if (c->d.nsub != 1) return fail("snmpc_attach: the SNMPC model is DISCRETE with one RK4 step per stage: create the capsule with nsub = 1");
     if (c->d.store_qp_in) return fail("snmpc_attach: store_qp_in is not available for the stacked state");
     DevGuard guard(c->d.device); GUARD_OK(guard);
     {
-        const size_t lds = sizeof(double) * (sn_prologue_lds(uph, ns, c->sn_prologue));
+        const size_t lds = sizeof(double) * (sn_prologue_lds(uph, ns, c->sn_prologue, sn_nsb(ns, L)));
         if (lds > 128 * 1024) return fail("snmpc_attach: n_samples x uph too large for the prologue kernel's LDS");
         HIPCHK(hipFuncSetAttribute((const void *)snmpc_prologue_mfma_kernel<SN_MFMA_NSW, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
         HIPCHK(hipFuncSetAttribute((const void *)snmpc_prologue_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+        HIPCHK(hipFuncSetAttribute((const void *)snmpc_prologue_kernel<0, SN_NSMAX>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
         HIPCHK(hipFuncSetAttribute((const void *)snmpc_prologue_kernel<6>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
         HIPCHK(hipFuncSetAttribute((const void *)snmpc_prologue_kernel<9>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
         HIPCHK(hipFuncSetAttribute((const void *)snmpc_prologue_kernel<13>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
@@ -428,7 +432,7 @@ static int sn_apply_p(tum_ocp *c)
         if (c->p_stop[k] != 1.0) return fail("solve: stop_flag pattern not supported: it must be 0 on the stages < uph and 1 from stage uph on (stage " + std::to_string(k) + " is 0 after a 1)");
     if (uph > N) uph = N;                      // no stop flag at all: the samples are propagated over the whole horizon
     if (uph > SN_UPHMAX) return fail("solve: uncertainty propagation horizon from the stop flags exceeds " + std::to_string(SN_UPHMAX));
-    if (sizeof(double) * (sn_prologue_lds(uph, ns, c->sn_prologue)) > 128 * 1024)      // (the variant sn_launch_prologue will pick)
+    if (sizeof(double) * (sn_prologue_lds(uph, ns, c->sn_prologue, sn_nsb(ns, c->sa.L))) > 128 * 1024)      // (the variant sn_launch_prologue will pick)
         return fail("solve: n_samples x uph too large for the prologue kernel's LDS");
     // (the hand-over buffer of the prologue is sized uph x sn_pro_stage(uph): its row pitch doubles beyond uph = 31)
     if (uph > c->uph_cap || (size_t)uph * sn_pro_stage(uph) > c->pro_cap) {
@@ -837,7 +841,7 @@ extern "C" int tum_ocp_set_kernel(tum_ocp *c, const char *name)
     else if (n == "prologue-passes" || n == "prologue-mfma") {
         if (c->sn) {
             const int want = (n == "prologue-passes") ? 0 : 2;
-            const size_t lds = sizeof(double) * sn_prologue_lds(c->sa.uph, c->sa.ns, want);
+            const size_t lds = sizeof(double) * sn_prologue_lds(c->sa.uph, c->sa.ns, want, sn_nsb(c->sa.ns, c->sa.L));
             if (lds > 128 * 1024) return fail("set_kernel: n_samples x uph too large for that prologue kernel's LDS");
         }
         c->sn_prologue = (n == "prologue-passes") ? 0 : 2;
@@ -877,6 +881,11 @@ static int resolve_kernel(tum_ocp *c)
 // last stage) or, for short propagation horizons and beyond the largest instantiation, in LDS
 static void sn_launch_prologue(tum_ocp *c)
 {
+    if (sn_nsb(c->sa.ns, c->sa.L) != SN_B16) {      // more than 16 samples or PCE terms: the column-slot kernel, column state in LDS, 32-wide bounds
+        const size_t lds32 = sizeof(double) * sn_prologue_lds_doubles(c->sa.uph, c->sa.ns, 0, SN_NSMAX);
+        hipLaunchKernelGGL((snmpc_prologue_kernel<0, SN_NSMAX>), dim3(c->batch), dim3(64), lds32, c->stream, c->sa);
+        return;
+    }
     const int kind = sn_prologue_kind(c->sa.uph, c->sa.ns, c->sn_prologue);
     if (kind == 2) {      // the column recursions on the matrix cores, the samples split over the two wavefronts of a workgroup
         const size_t lds = sizeof(double) * sn_mfma_lds_doubles(c->sa.uph, c->sa.ns);
@@ -1007,7 +1016,9 @@ static int launch_pipeline(tum_ocp *c, bool events)
             SnArgs sa = c->sa;
             sa.dv = c->dvec + PD<NTv>::PV_DV; sa.dv_stride = PD<NTv>::PVEC;
             sa.Xn = c->dX; sa.dxu = c->dvec + PD<NTv>::PV_SC + 8;
-            hipLaunchKernelGGL(snmpc_epilogue_kernel, dim3(c->batch), dim3(64), 0, c->stream, sa); c->xs_lazy = true;
+            if (sn_nsb(sa.ns, sa.L) != SN_B16) hipLaunchKernelGGL((snmpc_epilogue_kernel<SN_NSMAX>), dim3(c->batch), dim3(64), 0, c->stream, sa);
+            else hipLaunchKernelGGL((snmpc_epilogue_kernel<>), dim3(c->batch), dim3(64), 0, c->stream, sa);
+            c->xs_lazy = true;
             hipLaunchKernelGGL((expand_kernel<NTv, true>), dim3(c->batch), dim3(64), 0, c->stream, pa);
         } else if (!expanded) hipLaunchKernelGGL((expand_kernel<NTv, false>), dim3(c->batch), dim3(64), 0, c->stream, pa);
     };
@@ -1030,6 +1041,8 @@ static int launch(tum_ocp *c, bool events = true)
 #ifdef TUM_DEV_KERNELS
     const bool prof = (c->ka.flags & 6) != 0;
     auto fused = [&](auto kern) { hipLaunchKernelGGL(kern, dim3(c->batch), dim3(64), LDS_BYTES, c->stream, c->ka); };
+    if (c->sn && !c->pipe && sn_nsb(c->sa.ns, c->sa.L) != SN_B16)
+        return fail("solve: kernel 'fused' takes at most 16 samples / PCE terms (use 'auto' or 'pipeline')");
     if (c->sn && !c->pipe && c->sa.uph > SN_UPHMAX_FUSED)
         return fail("solve: kernel 'fused' reads the sample columns of one wavefront: uncertainty propagation horizon <= 31 (use 'auto' or 'pipeline')");
     if (c->pipe) { if (launch_pipeline(c, events)) return 1; }
@@ -1038,7 +1051,7 @@ static int launch(tum_ocp *c, bool events = true)
         sn_launch_lin(c);
         sn_launch_prologue(c);
         if (prof) fused(nmpc_rti_kernel<true, true>); else fused(nmpc_rti_kernel<false, true>);
-        hipLaunchKernelGGL(snmpc_epilogue_kernel, dim3(c->batch), dim3(64), 0, c->stream, c->sa); c->xs_lazy = true;
+        hipLaunchKernelGGL((snmpc_epilogue_kernel<>), dim3(c->batch), dim3(64), 0, c->stream, c->sa); c->xs_lazy = true;
     }
     else { if (prof) fused(nmpc_rti_kernel<true>); else fused(nmpc_rti_kernel<false>); }
     if (!c->pipe) HIPCHK(hipMemsetAsync(c->dqplam, 0, sizeof(double) * (size_t)c->batch * (6 * (size_t)c->N + 2), c->stream));      // (the fused kernel leaves no multipliers behind)
