@@ -17,7 +17,7 @@ A "step" = one pass of the hot path over one batch, inputs resident in HBM befor
 
 `value` is the FRESH-BATCH throughput: NB differently seeded batches of the workload are resident in HBM and rotated, one per
 step, so no step sees a batch the solver has just solved (what a caller with new data every step gets). The steps are dealt
-to --streams S capsules in turn (default 3; tum-control_amd/streaming.py), each with its own buffers on its own HIP stream: a
+to --streams S capsules in turn (default 4: the optimum measured, profiles/r06_stream_counts.txt; tum-control_amd/streaming.py), each with its own buffers on its own HIP stream: a
 step is still one complete pass over one batch, but the GPU starts on the next batch while the last wavefronts of the
 previous one finish (a batch is only four rounds of resident wavefronts: run one at a time, a fifth of the chip idles in
 every batch's tail). At N = 1 the line also carries the same loop on ONE capsule / ONE stream (`value_single_stream`: the
@@ -143,7 +143,7 @@ def parse_args(argv=None):
                     help="--scaling strong: instances of the whole job (default: 8 x the config's per-GPU share)")
     ap.add_argument("--batch", type=int, default=None, help="instances per GPU (weak scaling; default: the config's per-GPU share)")
     ap.add_argument("--horizon", type=int, default=40)
-    ap.add_argument("--streams", type=int, default=3,
+    ap.add_argument("--streams", type=int, default=4,
                     help="capsules (each on its own HIP stream) the steps are dealt to in turn: step k runs on capsule k mod S, so the "
                          "tail of one batch's interior point kernel runs beside the head of the next batch (1 = one capsule, one stream)")
     ap.add_argument("--same-batch", action="store_true",
@@ -251,7 +251,7 @@ class Job:
         S = self.S = max(1, int(n_slots if n_slots is not None else args.streams))
         if self.cuda:
             self.streams = [torch.cuda.current_stream()] if S == 1 else [torch.cuda.Stream() for _ in range(S)]
-            self.ring = SolverRing(S, make, [st.cuda_stream for st in self.streams], allow_unstable=True)      # (--streams 4, 6: the measurement of WHY the ring caps at three)
+            self.ring = SolverRing(S, make, [st.cuda_stream for st in self.streams], allow_unstable=True)      # (--streams 5, 6, 8: the measurement of WHY the ring caps at four)
         else:
             self.streams = [None] * S
             self.ring = SolverRing(S, make, allow_unstable=True)
@@ -643,7 +643,7 @@ def _test_solver_factory():
 
 def other_configs_legs(args, torch, dev, solver_factory, steps=8, warmup=3):
     """The other BASELINE configurations and the coupled SNMPC OCP inside the driver-timed line (N = 1 only, a bounded leg each):
-    configs 3 / 4 / 5 at their per-GPU size through the SAME `run` as the headline (fresh batches over three capsules, barriers and
+    configs 3 / 4 / 5 at their per-GPU size through the SAME `run` as the headline (fresh batches over the default number of capsules, barriers and
     device syncs around `steps` steps), the coupled 88-state SNMPC OCP (N = 38, ten samples) at the shipped propagation
     horizon (uph = 5) and at UPH = Tp (uph = 38): cold start + solve of 4096 instances, one capsule and three in flight."""
     out = {}

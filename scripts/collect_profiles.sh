@@ -4,7 +4,7 @@
 # profiles/<tag>_*. Every step runs under `timeout` and with stdin closed.
 # The profiled command is `bench.py --streams 1` (one capsule, one stream: a launch has the chip to itself and the per-kernel
 # averages are what the `roofline` block of the default bench line quotes from its own one-stream leg); the default command
-# deals the steps to three streams, where launches of consecutive batches overlap.
+# deals the steps to four streams, where launches of consecutive batches overlap.
 set -u
 OUT=gpurun_out/final; rm -rf $OUT; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
@@ -25,7 +25,7 @@ done
 for k in pipeline fused; do $T python scripts/phase_profile.py 4096 $k 2>&1 < /dev/null | grep -v amdgpu >> $OUT/phase_cycles.txt; done
 for c in 3 4 5; do $T python bench.py --config $c --steps 10 --no-other-configs 2>/dev/null < /dev/null | grep metric >> $OUT/configs.jsonl; done
 for b in 1 512 4096 16384; do B=$b $T python scripts/pipe_check.py fused pipeline pipeline4 2>&1 < /dev/null | grep -E "^fused|^pipeline" | sed "s/^/batch $b: /" >> $OUT/kernel_variants.txt; done
-for S in 1 2 3 4 6; do $T python bench.py --steps 20 --warmup 3 --streams $S --no-cpu-baseline --no-schedule-legs --no-other-configs 2>/dev/null < /dev/null | grep metric | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('streams',d['config']['streams'],'value %.3f M solves/s'%(d['value']/1e6),'ms/step %.3f'%d['ms_per_step'])" >> $OUT/streams.txt; done
+for S in 1 2 3 4 5 6 8; do $T python bench.py --steps 20 --warmup 3 --streams $S --no-cpu-baseline --no-schedule-legs --no-other-configs 2>/dev/null < /dev/null | grep metric | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('streams',d['config']['streams'],'value %.3f M solves/s'%(d['value']/1e6),'ms/step %.3f'%d['ms_per_step'])" >> $OUT/streams.txt; done
 $T python scripts/snmpc_bench.py 2>&1 < /dev/null | grep -v amdgpu.ids > $OUT/snmpc_bench.txt
 for v in prologue-mfma prologue-passes; do echo "== set_kernel(\"$v\") on every capsule (default at ten samples: prologue-mfma)" >> $OUT/snmpc_prologue_variants.txt; SN_PROLOGUE=$v $T python scripts/snmpc_bench.py 2>&1 < /dev/null | grep "^coupled" >> $OUT/snmpc_prologue_variants.txt; done
 $T rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/sn38 -o s -- python scripts/dev/sn_uph_profile.py 38 38 > /dev/null 2>&1 < /dev/null
@@ -41,7 +41,7 @@ $T python scripts/probes/controller_step_time.py 2>&1 < /dev/null | grep -v amdg
 for L in exp_libs/lib_*.so; do [ -f "$L" ] && $T python scripts/dev/ab2.py $L shipped 2>&1 < /dev/null | grep -v amdgpu.ids >> $OUT/ab_saved_builds.txt; done
 # the rooted gather with the whole iterate (world size 1 under torch.distributed.run: RCCL initialised, the 53 MB slab gathered inside the timed region)
 for G in "" "--gather-iterate"; do $T python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29533 bench.py --gpus 1 --config 4 --scaling strong --global-batch 16384 --steps 10 --warmup 2 --no-cpu-baseline --no-schedule-legs $G 2>/dev/null < /dev/null | grep metric | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('config 4, world size 1 under torchrun (nccl = RCCL), gather_iterate', d['config']['gather_iterate'], ': gather %.0f B per rank, value %.3f M solves/s, ms/step %.3f (solve %.3f, gather %.3f)' % (d['config']['gather_bytes_per_rank'], d['value']/1e6, d['ms_per_step'], d['solve_ms_per_step'], d['gather_ms_per_step']))" >> $OUT/gather_iterate.txt; done
-for f in 0 1; do echo "TUM_FUSED_EXPAND=$f" >> $OUT/fused_expand.txt; TUM_FUSED_EXPAND=$f $T python scripts/probes/solve_wall_time.py 2>&1 < /dev/null | grep pipeline >> $OUT/fused_expand.txt; TUM_FUSED_EXPAND=$f $T python bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-schedule-legs --no-host-legs --no-other-configs 2>/dev/null < /dev/null | grep metric | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('  config 2, three streams: value %.3f M solves/s'%(d['value']/1e6))" >> $OUT/fused_expand.txt; done
+for f in 0 1; do echo "TUM_FUSED_EXPAND=$f" >> $OUT/fused_expand.txt; TUM_FUSED_EXPAND=$f $T python scripts/probes/solve_wall_time.py 2>&1 < /dev/null | grep pipeline >> $OUT/fused_expand.txt; TUM_FUSED_EXPAND=$f $T python bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-schedule-legs --no-host-legs --no-other-configs 2>/dev/null < /dev/null | grep metric | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('  config 2, default streams: value %.3f M solves/s'%(d['value']/1e6))" >> $OUT/fused_expand.txt; done
 # round 6: horizons beyond 40 (six / seven tiles) and a full W against the diagonal one, 4096 instances each
 $T python scripts/dev/n56_time.py 2>&1 < /dev/null | grep "^N " > $OUT/long_horizons.txt
 $T python scripts/dev/fullw_time.py 2>&1 < /dev/null | grep "W 4096" > $OUT/full_w.txt

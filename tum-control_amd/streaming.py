@@ -9,10 +9,12 @@ sweeps, Monte-Carlo runs: every batch configuration of BASELINE.json) can keep s
 capsules of the same OCP and hands them out in turn; everything enqueued on a capsule (device-to-device upload of x0 / yref,
 cold start, solve, result packing) runs on that capsule's stream, so consecutive batches overlap on the GPU while every batch
 still gets a complete, independent solve. Measured on config 2 (4096 x N = 40, fresh batch every step; profiles/r04_streams.txt,
-round 5: profiles/r05_streams.txt): 3.3 M solves/s on one capsule, 3.8 / 4.0 M on two / three. FOUR OR MORE ARE NOT STABLE: 2.8-4.0 M
-at four, 1.8-3.7 M at six from run to run -- the runtime multiplexes streams onto four hardware queues, and once capsules share a queue
-their batches serialise in an order the caller does not control. `SolverRing` therefore refuses more than
-MAX_STABLE_SLOTS = 3 capsules unless the caller insists (`allow_unstable=True`).
+round 6: profiles/r06_stream_counts.txt, six fresh processes per count on two boxes): 3.4 M solves/s on one capsule, 4.05 / 4.26 / 4.35 M on
+two / three / four, 4.15 / 4.23 / 4.22 M on five / six / eight -- FOUR is the optimum (the runtime multiplexes streams onto four hardware
+queues; GPU_MAX_HW_QUEUES = 8 / 16 changes nothing). Rounds 4-5 measured four and more as UNSTABLE from run to run (2.8-4.0 M at four,
+1.8-3.7 M at six) when every capsule still owned a second stream for its result copies; with one stream per capsule the spread at
+every count is below 2 %. `SolverRing` refuses more than MAX_STABLE_SLOTS = 4 capsules -- beyond the hardware queues capsules share a
+queue and their batches serialise in an order the caller does not control -- unless the caller insists (`allow_unstable=True`).
 
 Results on the host ride the same ring: `request_results(slot)` enqueues, behind the solve on that capsule's stream, the copy
 of the batch's results into one of the capsule's two pinned host slabs and an event (C-ABI: tum_ocp_results_async);
@@ -28,7 +30,7 @@ A closed loop -- where solve k + 1 needs the result of solve k -- has nothing to
 """
 
 
-MAX_STABLE_SLOTS = 3          # capsules (= HIP streams) a ring runs with a reproducible rate on an MI355X (see above)
+MAX_STABLE_SLOTS = 4          # capsules (= HIP streams) a ring runs with a reproducible rate on an MI355X (see above)
 
 
 class SolverRing:
@@ -41,8 +43,8 @@ class SolverRing:
         if n_slots > MAX_STABLE_SLOTS and not allow_unstable:
             # (rounds 4-5 cut the ring back with a warning: a caller that sized its own per-slot structures by ITS number then indexed
             #  past the ring. Refused instead; len(ring) / ring.n_slots is the number of capsules a ring has.)
-            raise ValueError(f"SolverRing: {n_slots} capsules asked for, at most {MAX_STABLE_SLOTS} run with a reproducible rate -- with four or "
-                             f"more streams the measured rate varies by up to 2x from run to run (capsules start sharing hardware queues); "
+            raise ValueError(f"SolverRing: {n_slots} capsules asked for, at most {MAX_STABLE_SLOTS} are useful -- with more streams than hardware queues "
+                             f"capsules share a queue and the measured rate falls (profiles/r06_stream_counts.txt); "
                              f"allow_unstable=True overrides")
         self.solvers = [factory(i) for i in range(n_slots)]
         if streams is not None:
