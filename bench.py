@@ -17,7 +17,7 @@ A "step" = one pass of the hot path over one batch, inputs resident in HBM befor
 
 `value` is the FRESH-BATCH throughput: NB differently seeded batches of the workload are resident in HBM and rotated, one per
 step, so no step sees a batch the solver has just solved (what a caller with new data every step gets). The steps are dealt
-to --streams S capsules in turn (default 4: the optimum measured, profiles/r06_stream_counts.txt; tum-control_amd/streaming.py), each with its own buffers on its own HIP stream: a
+to --streams S capsules in turn (default 3 -- four win 2 % in a long stream of batches and lose on this program's short legs, profiles/r06_stream_counts.txt; tum-control_amd/streaming.py), each with its own buffers on its own HIP stream: a
 step is still one complete pass over one batch, but the GPU starts on the next batch while the last wavefronts of the
 previous one finish (a batch is only four rounds of resident wavefronts: run one at a time, a fifth of the chip idles in
 every batch's tail). At N = 1 the line also carries the same loop on ONE capsule / ONE stream (`value_single_stream`: the
@@ -143,7 +143,7 @@ def parse_args(argv=None):
                     help="--scaling strong: instances of the whole job (default: 8 x the config's per-GPU share)")
     ap.add_argument("--batch", type=int, default=None, help="instances per GPU (weak scaling; default: the config's per-GPU share)")
     ap.add_argument("--horizon", type=int, default=40)
-    ap.add_argument("--streams", type=int, default=4,
+    ap.add_argument("--streams", type=int, default=3,
                     help="capsules (each on its own HIP stream) the steps are dealt to in turn: step k runs on capsule k mod S, so the "
                          "tail of one batch's interior point kernel runs beside the head of the next batch (1 = one capsule, one stream)")
     ap.add_argument("--same-batch", action="store_true",

@@ -4,7 +4,7 @@
 # profiles/<tag>_*. Every step runs under `timeout` and with stdin closed.
 # The profiled command is `bench.py --streams 1` (one capsule, one stream: a launch has the chip to itself and the per-kernel
 # averages are what the `roofline` block of the default bench line quotes from its own one-stream leg); the default command
-# deals the steps to four streams, where launches of consecutive batches overlap.
+# deals the steps to three streams, where launches of consecutive batches overlap.
 set -u
 OUT=gpurun_out/final; rm -rf $OUT; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT

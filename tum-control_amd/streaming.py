@@ -10,8 +10,9 @@ capsules of the same OCP and hands them out in turn; everything enqueued on a ca
 cold start, solve, result packing) runs on that capsule's stream, so consecutive batches overlap on the GPU while every batch
 still gets a complete, independent solve. Measured on config 2 (4096 x N = 40, fresh batch every step; profiles/r04_streams.txt,
 round 6: profiles/r06_stream_counts.txt, six fresh processes per count on two boxes): 3.4 M solves/s on one capsule, 4.05 / 4.26 / 4.35 M on
-two / three / four, 4.15 / 4.23 / 4.22 M on five / six / eight -- FOUR is the optimum (the runtime multiplexes streams onto four hardware
-queues; GPU_MAX_HW_QUEUES = 8 / 16 changes nothing). Rounds 4-5 measured four and more as UNSTABLE from run to run (2.8-4.0 M at four,
+two / three / four, 4.15 / 4.23 / 4.22 M on five / six / eight -- FOUR is the optimum of a long stream of batches (the runtime multiplexes
+streams onto four hardware queues; GPU_MAX_HW_QUEUES = 8 / 16 changes nothing; a run of a few batches per capsule is mostly ramp and drain: three are
+as good at 20 batches and better at 8, which is why bench.py's short legs keep three). Rounds 4-5 measured four and more as UNSTABLE from run to run (2.8-4.0 M at four,
 1.8-3.7 M at six) when every capsule still owned a second stream for its result copies; with one stream per capsule the spread at
 every count is below 2 %. `SolverRing` refuses more than MAX_STABLE_SLOTS = 4 capsules -- beyond the hardware queues capsules share a
 queue and their batches serialise in an order the caller does not control -- unless the caller insists (`allow_unstable=True`).
