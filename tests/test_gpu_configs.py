@@ -385,21 +385,21 @@ def test_bench_line_carries_the_other_configurations():
 
 def test_results_on_the_host_through_pinned_slabs():
     """tum_ocp_results_async / _wait: the summary (u0, cost, status, qp_iter) and the whole iterate of a batch arrive in the
-    capsule's pinned host slabs behind an event, equal to what the synchronous getters return; three capsules in a ring with
-    three different batches in flight hand every batch's OWN results back (streaming.SolverRing.request_results / take_results)."""
+    capsule's pinned host slabs behind an event, equal to what the synchronous getters return; four capsules in a ring (its cap) with
+    four different batches in flight hand every batch's OWN results back (streaming.SolverRing.request_results / take_results)."""
     from tum_control_amd.streaming import SolverRing
     from tum_control_amd.workloads import nominal_batch
     B = 1536
-    batches = [nominal_batch(B, N=N, seed=100 + k) for k in range(3)]
-    ring = SolverRing(3, lambda i: _mk(B))
+    batches = [nominal_batch(B, N=N, seed=100 + k) for k in range(4)]
+    ring = SolverRing(4, lambda i: _mk(B))
     assert ring.take_results(0) is None
-    for k in range(3):
+    for k in range(4):
         slot, s = ring.acquire()
         s.set_x0(batches[k][0]); s.set_yref_all(batches[k][1]); s.cold_start(); s.solve_async()
         ring.request_results(slot, with_iterate=True)
     got = dict(ring.drain())
-    assert sorted(got) == [0, 1, 2]
-    for k in range(3):
+    assert sorted(got) == [0, 1, 2, 3]
+    for k in range(4):
         summ, X, U = got[k]
         s = ring[k]
         Xr, Ur = s.get_iterate()
