@@ -340,9 +340,12 @@ template <int L, bool SETTLE = false> __device__ __forceinline__ void fnmac_bc_s
 // acc += (lane L of the row of b) * x
 // (v_rcp_f64_dpp assembles but does not work: scripts/probes/probe_dpp_f64.cpp returns inf -- the reciprocal of a pivot is taken on every lane
 //  and its lane reaches the others through this FMA)
-template <int L> __device__ __forceinline__ void fmac_bc(double &acc, double b, double x)
+// FRESH: b has just been produced by a vector instruction (the Newton step of a reciprocal): two wait states in FRONT of the DPP read, which the
+// compiler does not know it owes (with matrix instructions between the reciprocal and its use -- rounds 2-6a -- they were there by accident)
+template <int L, bool FRESH = false> __device__ __forceinline__ void fmac_bc(double &acc, double b, double x)
 {
-    asm("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(b), "v"(x), "n"(L));
+    if constexpr (FRESH) asm("s_nop 1\n\tv_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(b), "v"(x), "n"(L));
+    else asm("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(b), "v"(x), "n"(L));
 }
 // w <- A_k w (+ the same for a second bank v): apply_A's sums, term by term in its order
 // (the rows 0..2 -- px, py, psi -- are no operands of any row: updated in place, row 2 behind the two rows that read it; only the
@@ -1681,50 +1684,48 @@ __global__ void __launch_bounds__(64, 1) ipm_kernel(const PArgs pa)
                 // 1 / d_x for the scaling of P is one reciprocal of Dg; row lq runs the substitution L X = e_lq across its lanes, and
                 // L D of the diagonal tile (the A operand of the rank-4 update) comes out of a second 4x4x4 product with the UNSCALED X
                 // instead of a select of the pivots and a multiplication.
+                // Where the matrix instructions owed to the tiles below go (slots 0 .. 2 nd - 1, `owed`): rounds 2-5 and the first form of round 6
+                // spread them over the pivot chain (three behind the strip's reads, one between every two segments of the chain) "where their
+                // result latency costs nothing". Measured in round 6 (profiles/r06_ab_mp_slots.txt): every matrix instruction inside the chain costs
+                // MORE than its own issue time -- the chain's next instruction waits for it to drain whether it depends on it or not, and every
+                // change between the vector and the matrix pipe has its own wait states -- and the kernel is 3.7 % faster with NONE inside: MPE slots in
+                // front of the strip's store (they cover the rank-4 update of the diagonal tile the store waits for), MPM behind its reads (they
+                // cover the LDS round trip), the chain of 28 FP64 instructions in one piece. (Only the seven-tile build has a 14th slot; it stays
+                // behind the first segment.)
+                constexpr int MPE = 6, MPM = 7;
+                static_for<0, MPE - 1>([&](auto kc) { owed(decltype(kc)::value); });
                 sBk[lane] = T[J][m];
                 double A0 = mp_col[4 * m], A1 = mp_col[16 + 4 * m], A2 = mp_col[32 + 4 * m], Dg = mp_dg[4 * m];
-                owed(0);
-                owed(1);
-                owed(2);
+                static_for<MPE, MPE + MPM - 1>([&](auto kc) { owed(decltype(kc)::value); });
                 // pivot 0
                 const double r0 = frcp(Dg);                       // (lane 0: 1 / d_0)
                 const double AM0 = A0 * mpM0;
-                owed(3);
+                if constexpr (NT > 6) owed(13);          // (seven tiles: the first block column owes 2 x 7 slots)
                 double lm0 = 0.0;
-                fmac_bc<0>(lm0, r0, AM0);                       // column 0 of L below the diagonal (0 on the lanes x <= 0)
+                fmac_bc<0, true>(lm0, r0, AM0);                       // column 0 of L below the diagonal (0 on the lanes x <= 0)
                 Dg = fma(-lm0, A0, Dg);
                 fnmac_bc<1>(A1, A0, lm0);
                 fnmac_bc<2>(A2, A0, lm0);
                 double bx = fma(-lm0, mp_e0, mp_ex);               // X = e_lq - l_0 X_0
-                owed(4);
                 // pivot 1
                 const double r1 = frcp(Dg);                       // (lane 1: 1 / d_1)
                 const double AM1 = A1 * mpM1;
-                owed(5);
                 double lm1 = 0.0;
-                fmac_bc<1>(lm1, r1, AM1);
+                fmac_bc<1, true>(lm1, r1, AM1);
                 Dg = fma(-lm1, A1, Dg);
                 fnmac_bc<2>(A2, A1, lm1);
                 fnmac_bc_self<1>(bx, lm1);
-                owed(6);
                 // pivot 2
                 const double r2 = frcp(Dg);                       // (lane 2: 1 / d_2)
                 const double AM2 = A2 * mpM2;
-                owed(7);
                 double lm2 = 0.0;
-                fmac_bc<2>(lm2, r2, AM2);
+                fmac_bc<2, true>(lm2, r2, AM2);
                 Dg = fma(-lm2, A2, Dg);
                 fnmac_bc_self<2, true>(bx, lm2);          // (bx goes to matrix instructions: settled)
-                owed(8);
                 // 1 / d_x on lane x, P = X / d, and the smallest pivot (per lane here: any lane may hold it)
                 const double RR = frcp(Dg);
                 dmin_hi = min(dmin_hi, __double2hiint(Dg));
-                owed(9);
                 const double popn = bx * RR;
-                owed(10);
-                owed(11);
-                owed(12);
-                if constexpr (NT > 6) owed(13);          // (seven tiles: the first block column owes 2 x 7 slots)
                 const int rel = lc - (4 * m + lq);              // row - column inside the diagonal tile
                 bprev = bx;
                 pop = popn;
