@@ -623,7 +623,7 @@ def test_log_file_has_the_reference_schema(tmp_path, golden_dir):
 
 
 def test_dpp_operands_of_the_condensing_kernel_are_settled(tmp_path):
-    """(Round 6: the interior point kernel's lane-distributed micro-panels use the same instruction -- fnmac_bc / fmac_bc of csrc/pipe_kernels.hpp --
+    """(Round 6: the interior point kernel's lane-distributed micro-panels use the same instruction -- fnmac_bc / mul_bc_fresh of csrc/pipe_kernels.hpp --
     and are covered by the same scan, plus the check of their results' consumers among the matrix instructions.)
     cond_kernel reads its stage record with `v_fmac_f64_dpp ... row_newbcast:n` written as inline asm (csrc/pipe_kernels.hpp,
     RecRows): the compiler's hazard recogniser does not look into it, and gfx9 needs two wait states between a vector instruction

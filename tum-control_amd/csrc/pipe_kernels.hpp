@@ -332,20 +332,24 @@ template <int L> __device__ __forceinline__ void fnmac_bc(double &acc, double b,
 // that takes acc as an operand right behind it read a stale register (found at N = 48: the last micro-panel of the last block column hands its
 // X straight to a 4x4x4 product -- 3e-4 on the last stage's jerk, everything else exact). Results that go to plain vector instructions first
 // need nothing: the hardware interlocks those.
-template <int L, bool SETTLE = false> __device__ __forceinline__ void fnmac_bc_self(double &acc, double x)
+// FRESH: acc comes straight from a plain vector instruction: two wait states in FRONT of the DPP read (as mul_bc_fresh below)
+template <int L, bool SETTLE = false, bool FRESH = false> __device__ __forceinline__ void fnmac_bc_self(double &acc, double x)
 {
-    if constexpr (SETTLE) asm("v_fmac_f64_dpp %0, -%0, %1 row_newbcast:%2 row_mask:0xf bank_mask:0xf\n\ts_nop 1" : "+v"(acc) : "v"(x), "n"(L));
+    if constexpr (FRESH) asm("s_nop 1\n\tv_fmac_f64_dpp %0, -%0, %1 row_newbcast:%2 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(x), "n"(L));
+    else if constexpr (SETTLE) asm("v_fmac_f64_dpp %0, -%0, %1 row_newbcast:%2 row_mask:0xf bank_mask:0xf\n\ts_nop 1" : "+v"(acc) : "v"(x), "n"(L));
     else asm("v_fmac_f64_dpp %0, -%0, %1 row_newbcast:%2 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(x), "n"(L));
 }
-// acc += (lane L of the row of b) * x
+// lm = (lane L of the row of r) * (a * m)
 // (v_rcp_f64_dpp assembles but does not work: scripts/probes/probe_dpp_f64.cpp returns inf -- the reciprocal of a pivot is taken on every lane
-//  and its lane reaches the others through this FMA)
-// FRESH: b has just been produced by a vector instruction (the Newton step of a reciprocal): two wait states in FRONT of the DPP read, which the
-// compiler does not know it owes (with matrix instructions between the reciprocal and its use -- rounds 2-6a -- they were there by accident)
-template <int L, bool FRESH = false> __device__ __forceinline__ void fmac_bc(double &acc, double b, double x)
+//  and its lane reaches the others through this FMA.) r has JUST been produced by a vector instruction (the Newton step of the reciprocal): a DPP
+// read needs two wait states behind the write of its source, which the compiler does not know it owes to the asm -- the product a * m and the zero of
+// the accumulator stand there (while matrix instructions sat between the reciprocal and its use -- rounds 2-6a -- the distance was there by accident;
+// the disassembly test of tests/test_host_logic.py caught it when they left)
+template <int L> __device__ __forceinline__ double mul_bc_fresh(double r, double a, double m)
 {
-    if constexpr (FRESH) asm("s_nop 1\n\tv_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(b), "v"(x), "n"(L));
-    else asm("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(b), "v"(x), "n"(L));
+    double lm, am;
+    asm("v_mul_f64 %1, %3, %4\n\tv_mov_b64 %0, 0\n\tv_fmac_f64_dpp %0, %2, %1 row_newbcast:%5 row_mask:0xf bank_mask:0xf" : "=&v"(lm), "=&v"(am) : "v"(r), "v"(a), "v"(m), "n"(L));
+    return lm;
 }
 // w <- A_k w (+ the same for a second bank v): apply_A's sums, term by term in its order
 // (the rows 0..2 -- px, py, psi -- are no operands of any row: updated in place, row 2 behind the two rows that read it; only the
@@ -1678,7 +1682,7 @@ __global__ void __launch_bounds__(64, 1) ipm_kernel(const PArgs pa)
                 // reciprocals and the pivots on their lanes). The strip goes through LDS once and every lane reads ITS entries. Lane x (= lc & 3, the same in every 4-lane block of every row)
                 // holds row x of the block: column j in register Aj (entries on and below the diagonal: the strip's upper triangle read
                 // transposed), the diagonal in Dg. A pivot row's entry reaches the other lanes as the `row_newbcast` operand of the FMA
-                // that uses it (fnmac_bc, fmac_bc; the reciprocal of pivot j is taken on every lane and lane j's is the broadcast one): nothing of the block is
+                // that uses it (fnmac_bc, mul_bc_fresh; the reciprocal of pivot j is taken on every lane and lane j's is the broadcast one): nothing of the block is
                 // wave-uniform any more -- no ten broadcast reads, no lane selects of P, the reciprocals and the pivots (rounds 2-5: 40 FP64
                 // instructions and 20 v_cndmask per micro-panel; now 28 and none). Dg ends as (d_0 .. d_3) on the lanes x = 0 .. 3, so
                 // 1 / d_x for the scaling of P is one reciprocal of Dg; row lq runs the substitution L X = e_lq across its lanes, and
@@ -1692,34 +1696,28 @@ __global__ void __launch_bounds__(64, 1) ipm_kernel(const PArgs pa)
                 // front of the strip's store (they cover the rank-4 update of the diagonal tile the store waits for), MPM behind its reads (they
                 // cover the LDS round trip), the chain of 28 FP64 instructions in one piece. (Only the seven-tile build has a 14th slot; it stays
                 // behind the first segment.)
-                constexpr int MPE = 6, MPM = 7;
+                constexpr int MPE = 7, MPM = 6;
                 static_for<0, MPE - 1>([&](auto kc) { owed(decltype(kc)::value); });
                 sBk[lane] = T[J][m];
                 double A0 = mp_col[4 * m], A1 = mp_col[16 + 4 * m], A2 = mp_col[32 + 4 * m], Dg = mp_dg[4 * m];
                 static_for<MPE, MPE + MPM - 1>([&](auto kc) { owed(decltype(kc)::value); });
                 // pivot 0
                 const double r0 = frcp(Dg);                       // (lane 0: 1 / d_0)
-                const double AM0 = A0 * mpM0;
                 if constexpr (NT > 6) owed(13);          // (seven tiles: the first block column owes 2 x 7 slots)
-                double lm0 = 0.0;
-                fmac_bc<0, true>(lm0, r0, AM0);                       // column 0 of L below the diagonal (0 on the lanes x <= 0)
+                const double lm0 = mul_bc_fresh<0>(r0, A0, mpM0);          // column 0 of L below the diagonal (0 on the lanes x <= 0)
                 Dg = fma(-lm0, A0, Dg);
                 fnmac_bc<1>(A1, A0, lm0);
                 fnmac_bc<2>(A2, A0, lm0);
                 double bx = fma(-lm0, mp_e0, mp_ex);               // X = e_lq - l_0 X_0
                 // pivot 1
                 const double r1 = frcp(Dg);                       // (lane 1: 1 / d_1)
-                const double AM1 = A1 * mpM1;
-                double lm1 = 0.0;
-                fmac_bc<1, true>(lm1, r1, AM1);
+                const double lm1 = mul_bc_fresh<1>(r1, A1, mpM1);          // column 1 of L below the diagonal (0 on the lanes x <= 1)
                 Dg = fma(-lm1, A1, Dg);
                 fnmac_bc<2>(A2, A1, lm1);
-                fnmac_bc_self<1>(bx, lm1);
+                fnmac_bc_self<1, false, true>(bx, lm1);          // (bx: from the plain FMA above, wherever the compiler puts it)
                 // pivot 2
                 const double r2 = frcp(Dg);                       // (lane 2: 1 / d_2)
-                const double AM2 = A2 * mpM2;
-                double lm2 = 0.0;
-                fmac_bc<2, true>(lm2, r2, AM2);
+                const double lm2 = mul_bc_fresh<2>(r2, A2, mpM2);          // column 2 of L below the diagonal (0 on the lanes x <= 2)
                 Dg = fma(-lm2, A2, Dg);
                 fnmac_bc_self<2, true>(bx, lm2);          // (bx goes to matrix instructions: settled)
                 // 1 / d_x on lane x, P = X / d, and the smallest pivot (per lane here: any lane may hold it)
