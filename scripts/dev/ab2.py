@@ -10,7 +10,7 @@ import torch  # noqa: F401
 from tum_control_amd import solver as sv
 from tum_control_amd.workloads import nominal_batch
 
-N, B, ROUNDS = 40, int(os.environ.get("B", "4096")), int(os.environ.get("ROUNDS", "30"))
+N, B, ROUNDS = int(os.environ.get("N", "40")), int(os.environ.get("B", "4096")), int(os.environ.get("ROUNDS", "30"))
 x0, yref = nominal_batch(B, N=N)
 names = sys.argv[1:]
 sol = []

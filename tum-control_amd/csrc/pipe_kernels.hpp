@@ -1696,7 +1696,7 @@ __global__ void __launch_bounds__(64, 1) ipm_kernel(const PArgs pa)
                 // front of the strip's store (they cover the rank-4 update of the diagonal tile the store waits for), MPM behind its reads (they
                 // cover the LDS round trip), the chain of 28 FP64 instructions in one piece. (Only the seven-tile build has a 14th slot; it stays
                 // behind the first segment.)
-                constexpr int MPE = 7, MPM = 6;
+                constexpr int MPE = (NT == 6) ? 6 : 7, MPM = 13 - MPE;          // (measured per instantiation; six tiles: 6 + 7)
                 static_for<0, MPE - 1>([&](auto kc) { owed(decltype(kc)::value); });
                 sBk[lane] = T[J][m];
                 double A0 = mp_col[4 * m], A1 = mp_col[16 + 4 * m], A2 = mp_col[32 + 4 * m], Dg = mp_dg[4 * m];
