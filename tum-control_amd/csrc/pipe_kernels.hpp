@@ -1648,10 +1648,10 @@ __global__ void __launch_bounds__(64, 1) ipm_kernel(const PArgs pa)
             // (measured 21 cycles; lane layout A[i][k] on lane 16 k + 4 blk + i, B[k][j] on 16 k + 4 blk + j, D[i][j] on
             // 16 i + 4 blk + j, scripts/probes/probe_mfma_4x4x4.cpp) instead of a quarter-used 16x16x4 (64 cycles): E sits in
             // the B layout as it is, the result lands where the 16x16x4 form put it.
-            // Only the diagonal tile is on the dependency path (scale, rank-4 update, next readlane); the two MFMAs
-            // of every tile below it are issued between the segments of the scalar chain of the NEXT micro-panel, where their
-            // 64-cycle result latency costs nothing. (An f64 MFMA occupies the same pipe as the f64 VALU instructions of its
-            // wavefront: measured, MFMA time and chain time add up -- the interleave hides latencies, not issue time.)
+            // Only the diagonal tile is on the dependency path (scale, rank-4 update, next strip); the two MFMAs
+            // of every tile below it are owed to the NEXT micro-panel, which issues them in front of its pivot chain (`owed`, MPE / MPM
+            // below; rounds 2-6a: between the chain's segments, which cost more than it hid). (An f64 MFMA occupies the same pipe as the f64
+            // VALU instructions of its wavefront: measured, MFMA time and chain time add up.)
             // The identity tile T[NT] goes through the same two MFMAs: what comes out is W = L^-T D^-1 of the 16x16 diagonal
             // block, and L^-1 = (W D)^T is stored into the strict lower triangle of the block (the solves use the inverse
             // diagonal blocks; L of the diagonal block itself is never read again).
@@ -1659,7 +1659,7 @@ __global__ void __launch_bounds__(64, 1) ipm_kernel(const PArgs pa)
 #pragma unroll
             for (int m = 0; m < 4; m++) {
                 const int c0 = 16 * J + 4 * m;
-                // k-th MFMA slot between the segments of the scalar chain: what the previous micro-panel owes to the tiles
+                // k-th MFMA slot: what the previous micro-panel owes to the tiles
                 // below the diagonal one and to the identity tile (their scaled columns, then their rank-4 updates)
                 auto owed = [&](int k) {
                     if (m > 0 && k < nd) {
