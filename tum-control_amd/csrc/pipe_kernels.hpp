@@ -675,9 +675,20 @@ __global__ void __launch_bounds__(64, (NT_ == 5) ? 2 : 1) cond_kernel(const PArg
             // LDS between the stages: loaded, updated, stored again.
             constexpr bool PARK = (NT_ == 5) && (Ts == NT_);
             d4 *sPark = reinterpret_cast<d4 *>(lds + D::C_PARK) + lane;
+            // the weighted operands of the stage: all of them AHEAD of the matrix instructions (the nominal OCP: one change between the vector and the
+            // matrix pipe per stage instead of one per tile row, -2 us on 4096 instances, bit-identical -- round 6, profiles/r06_ab_mp_slots.txt); the
+            // coupled SNMPC OCP's instantiations have no registers for the five of them and form one at a time
+            constexpr bool AOPV = !SN;
+            double aopv[AOPV ? Ts : 1];
+            if constexpr (AOPV) {
+#pragma unroll
+                for (int K = 0; K < Ts; K++) aopv[K] = bop[K] * wl;
+                asm volatile("" ::: "memory");
+            }
 #pragma unroll
             for (int K = 0; K < Ts; K++) {
-                const double aop = bop[K] * wl;          // (one weighted operand at a time: five of them held were the registers the last segment lacked)
+                double aop;
+                if constexpr (AOPV) aop = aopv[K]; else aop = bop[K] * wl;
 #pragma unroll
                 for (int I = K; I < Ts; I++) {
                     if constexpr (PARK) {
